@@ -1,0 +1,264 @@
+"""cbl_amd — MI355X-native bulk k-mer insertion for CBL indexes (host-side mirror of the reference API).
+
+`CBL` mirrors the method surface of the reference's `CBL<K, T, PREFIX_BITS>` for the build / insert / merge path
+(/root/reference/src/cbl.rs:71-79 new/new_canonical, :127-160 save_to_file/load_from_file, :164-177
+count/is_empty/is_canonical, :311-324 contains_seq, :328-339 insert_seq, :433-449 `|=`) on top of the C ABI in
+include/cblx.h (libcblx.so, hand-written HIP for gfx950). There is NO CPU fallback: importing works anywhere, but
+creating a `CBL` without the built library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libcblx.so"
+_LIB = None
+
+OK, EINVAL, ESHORT, EFORMAT, EDEVICE, ENOMEM, ERANGE = range(7)
+FLAG_PROFILE = 1
+
+
+class CblxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("prefix_bits", C.c_uint32), ("canonical", C.c_uint32), ("device", C.c_int32),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Consts(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("kmer_bits", "pos_bits", "word_bits", "suffix_bits", "bytes", "chunk_size",
+                                          "threshold", "reserved")]
+
+
+BUCKET_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+
+# name -> (restype, argtypes): every symbol include/cblx.h declares
+SIGNATURES = {
+    "cblx_abi_version": (C.c_uint32, []),
+    "cblx_last_global_error": (C.c_char_p, []),
+    "cblx_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
+    "cblx_destroy": (None, [C.c_void_p]),
+    "cblx_last_error": (C.c_char_p, [C.c_void_p]),
+    "cblx_insert_seq": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64]),
+    "cblx_insert_seqs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "cblx_insert_seqs_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "cblx_flush": (C.c_int, [C.c_void_p]),
+    "cblx_insert_words_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "cblx_seq_words_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
+                                        C.POINTER(C.c_uint64)]),
+    "cblx_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "cblx_num_buckets": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "cblx_is_empty": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "cblx_is_canonical": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "cblx_serialized_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "cblx_serialize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cblx_save_to_file": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "cblx_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64]),
+    "cblx_load_from_file": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "cblx_merge_assign": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cblx_export_buckets": (C.c_int, [C.c_void_p, BUCKET_CB, C.c_void_p]),
+    "cblx_contains_seq": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cblx_get_consts": (C.c_int, [C.c_void_p, C.POINTER(Consts)]),
+    "cblx_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_uint32,
+                                   C.POINTER(C.c_uint32)]),
+    "cblx_stage_times_reset": (C.c_int, [C.c_void_p]),
+    "cblx_kmers_inserted": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "cblx_trim": (C.c_int, [C.c_void_p]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load libcblx.so (built in-tree by __graft_entry__.build()). Fails loudly when it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not LIB_PATH.exists():
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). cbl_amd has no CPU fallback.")
+        L = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def _ptr(x):
+    """Raw address of a torch tensor / numpy array / int."""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    if hasattr(x, "ctypes"):
+        return x.ctypes.data
+    return int(x)
+
+
+class CBL:
+    """A set of k-mers backed by an index resident in the HBM of one MI355X.
+
+    `CBL(k, prefix_bits=24)` = `CBL::<K, T, PREFIX_BITS>::new()`; `canonical=True` = `new_canonical()`.
+    The reference picks T from K (build.rs:34-41); here the word width follows from k the same way.
+    """
+
+    def __init__(self, k: int, prefix_bits: int = 24, canonical: bool = False, device: int = -1, profile: bool = False):
+        self._L = lib()
+        self.k, self.prefix_bits = k, prefix_bits
+        p = Params(k, prefix_bits, int(canonical), device, FLAG_PROFILE if profile else 0, 0)
+        h = C.c_void_p()
+        rc = self._L.cblx_create(C.byref(p), C.byref(h))
+        if rc != OK:
+            raise CblxError(rc, self._L.cblx_last_global_error().decode())
+        self._h = h
+
+    @classmethod
+    def new_canonical(cls, k: int, prefix_bits: int = 24, **kw) -> "CBL":
+        return cls(k, prefix_bits, canonical=True, **kw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cblx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int):
+        if rc != OK:
+            raise CblxError(rc, self._L.cblx_last_error(self._h).decode())
+
+    # ---- src/cbl.rs:328-339 ---------------------------------------------------------------------------------
+    def insert_seq(self, seq: bytes):
+        """Adds all the k-mers of a sequence to the set (enqueued; materialised by the next observer)."""
+        self._chk(self._L.cblx_insert_seq(self._h, seq, len(seq)))
+
+    def insert_seqs(self, bases, offsets):
+        """The caller loop of examples/cbl.rs:160-163 in one call. numpy uint8 / uint64 (host) arrays."""
+        import numpy as np
+
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._chk(self._L.cblx_insert_seqs(self._h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1))
+
+    def insert_seqs_device(self, d_bases, d_offsets, n: int):
+        """Same with inputs resident in HBM (torch uint8 / int64 CUDA tensors or raw device addresses)."""
+        self._chk(self._L.cblx_insert_seqs_device(self._h, _ptr(d_bases), _ptr(d_offsets), n))
+
+    def insert_words_device(self, d_lo, d_hi, n: int):
+        """WordSet::insert_batch (src/wordset/mod.rs:187-216) on device-resident words."""
+        self._chk(self._L.cblx_insert_words_device(self._h, _ptr(d_lo), _ptr(d_hi), n))
+
+    def seq_words_device(self, d_bases, d_offsets, n: int, d_lo, d_hi, cap: int) -> int:
+        """CBL::get_seq_words over every chunk (src/cbl.rs:239-289) into device arrays; returns the word count."""
+        nw = C.c_uint64(0)
+        self._chk(self._L.cblx_seq_words_device(self._h, _ptr(d_bases), _ptr(d_offsets), n, _ptr(d_lo), _ptr(d_hi), cap, C.byref(nw)))
+        return nw.value
+
+    def flush(self):
+        self._chk(self._L.cblx_flush(self._h))
+
+    # ---- src/cbl.rs:164-177 ---------------------------------------------------------------------------------
+    def count(self) -> int:
+        v = C.c_uint64(0)
+        self._chk(self._L.cblx_count(self._h, C.byref(v)))
+        return v.value
+
+    def num_buckets(self) -> int:
+        v = C.c_uint64(0)
+        self._chk(self._L.cblx_num_buckets(self._h, C.byref(v)))
+        return v.value
+
+    def is_empty(self) -> bool:
+        v = C.c_int(0)
+        self._chk(self._L.cblx_is_empty(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def is_canonical(self) -> bool:
+        v = C.c_int(0)
+        self._chk(self._L.cblx_is_canonical(self._h, C.byref(v)))
+        return bool(v.value)
+
+    def contains_seq(self, seq: bytes):
+        """For each k-mer of a sequence, True if it is in the set (src/cbl.rs:311-324)."""
+        cap = max(len(seq), 1)
+        out = (C.c_uint8 * cap)()
+        n = C.c_uint64(0)
+        self._chk(self._L.cblx_contains_seq(self._h, seq, len(seq), out, cap, C.byref(n)))
+        return [bool(out[i]) for i in range(n.value)]
+
+    # ---- src/cbl.rs:127-160 ---------------------------------------------------------------------------------
+    def serialize(self) -> bytes:
+        """The exact bytes `save_to_file` writes (bincode DefaultOptions + varint)."""
+        n = C.c_uint64(0)
+        self._chk(self._L.cblx_serialized_size(self._h, C.byref(n)))
+        buf = (C.c_uint8 * max(n.value, 1))()
+        w = C.c_uint64(0)
+        self._chk(self._L.cblx_serialize(self._h, buf, n.value, C.byref(w)))
+        return bytes(memoryview(buf)[: w.value])
+
+    def save_to_file(self, path):
+        self._chk(self._L.cblx_save_to_file(self._h, os.fsencode(path)))
+
+    def load(self, data: bytes):
+        self._chk(self._L.cblx_load(self._h, data, len(data)))
+
+    @classmethod
+    def load_from_file(cls, path, k: int, prefix_bits: int = 24, **kw) -> "CBL":
+        """K / PREFIX_BITS are compile-time constants of the reference and not stored in the file."""
+        c = cls(k, prefix_bits, **kw)
+        c._chk(c._L.cblx_load_from_file(c._h, os.fsencode(path)))
+        return c
+
+    # ---- src/cbl.rs:433-449 ---------------------------------------------------------------------------------
+    def __ior__(self, other: "CBL") -> "CBL":
+        self._chk(self._L.cblx_merge_assign(self._h, other._h))
+        return self
+
+    # ---- inspection -------------------------------------------------------------------------------------------
+    def consts(self) -> dict:
+        c = Consts()
+        self._chk(self._L.cblx_get_consts(self._h, C.byref(c)))
+        return {n: getattr(c, n) for n, _ in Consts._fields_ if n != "reserved"}
+
+    def buckets(self):
+        """[(prefix, kind, [suffix, ...])] in ascending prefix order; kind 0 = Vec (stored order), 1 = Trie (ascending)."""
+        out = []
+
+        def cb(_u, prefix, kind, n, lo, hi):
+            if hi:
+                out.append((prefix, kind, [lo[i] | (hi[i] << 64) for i in range(n)]))
+            else:
+                out.append((prefix, kind, [lo[i] for i in range(n)]))
+            return 0
+
+        self._chk(self._L.cblx_export_buckets(self._h, BUCKET_CB(cb), None))
+        return out
+
+    def stage_times(self) -> dict:
+        """{stage: (ms, launches)} accumulated HIP-event time per pipeline stage (needs profile=True)."""
+        names = (C.c_char_p * 16)()
+        ms = (C.c_double * 16)()
+        ln = (C.c_uint64 * 16)()
+        n = C.c_uint32(0)
+        self._chk(self._L.cblx_stage_times(self._h, names, ms, ln, 16, C.byref(n)))
+        return {names[i].decode(): (ms[i], ln[i]) for i in range(n.value)}
+
+    def stage_times_reset(self):
+        self._chk(self._L.cblx_stage_times_reset(self._h))
+
+    def kmers_inserted(self) -> int:
+        v = C.c_uint64(0)
+        self._chk(self._L.cblx_kmers_inserted(self._h, C.byref(v)))
+        return v.value
+
+    def trim(self):
+        self._chk(self._L.cblx_trim(self._h))

@@ -1,0 +1,972 @@
+// cblx.cpp — host side of libcblx: the C ABI of include/cblx.h over the HIP kernels (gfx950).
+//
+// Mirrors the reference's `CBL<K, T, PREFIX_BITS>` surface for the bulk-insert path
+// (/root/reference/src/cbl.rs:71-79,127-177,328-339,433-449) with the WordSet state
+// (/root/reference/src/wordset/mod.rs:18-26: prefix bitvector + rank->bucket directory + suffix containers) held in
+// HBM: bitvector words, popcount-scan rank directory, bucket table indexed by rank, one suffix arena.
+// There is no CPU fallback: every data-path step below is a kernel launch.
+#include "../../include/cblx.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <fstream>
+#include <map>
+#include <memory>
+
+#include "kernels_bucket.hpp"
+
+using namespace cblx;
+
+namespace {
+
+thread_local std::string g_global_err;
+
+inline u32 ilog2_npo2(u32 v) { u32 l = 0; while ((1u << l) < v) ++l; return l; }
+inline u64 ceil_div(u64 a, u64 b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------------
+// cached device allocations (hipMalloc is kept out of the hot path between flushes)
+struct Pool {
+    struct Blk { void* p; size_t sz; bool used; };
+    std::vector<Blk> blks;
+    void* alloc(size_t sz) {
+        if (sz == 0) sz = 256;
+        sz = (sz + 255) & ~(size_t)255;
+        int best = -1;
+        for (size_t i = 0; i < blks.size(); ++i)
+            if (!blks[i].used && blks[i].sz >= sz && blks[i].sz <= sz + sz / 2 + 4096 && (best < 0 || blks[i].sz < blks[best].sz)) best = (int)i;
+        if (best >= 0) { blks[best].used = true; return blks[best].p; }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, sz);
+        if (e != hipSuccess) {
+            trim();
+            e = hipMalloc(&p, sz);
+            if (e != hipSuccess) throw Error(CBLX_ENOMEM, "hipMalloc(" + std::to_string(sz) + ") failed: " + hipGetErrorString(e));
+        }
+        blks.push_back({p, sz, true});
+        return p;
+    }
+    void release(void* p) {
+        if (!p) return;
+        for (auto& b : blks) if (b.p == p) { b.used = false; return; }
+    }
+    void trim() {
+        std::vector<Blk> keep;
+        for (auto& b : blks) { if (b.used) keep.push_back(b); else (void)hipFree(b.p); }
+        blks.swap(keep);
+    }
+    ~Pool() { for (auto& b : blks) (void)hipFree(b.p); }
+};
+
+template <typename T> struct Buf {  // RAII view on a pool allocation
+    Pool* pool = nullptr;
+    T* p = nullptr;
+    size_t n = 0;
+    Buf() {}
+    Buf(Pool& pl, size_t count) : pool(&pl), p((T*)pl.alloc(count * sizeof(T))), n(count) {}
+    Buf(const Buf&) = delete;
+    Buf& operator=(const Buf&) = delete;
+    Buf(Buf&& o) noexcept : pool(o.pool), p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    Buf& operator=(Buf&& o) noexcept { if (this != &o) { reset(); pool = o.pool; p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    void reset() { if (p && pool) pool->release(p); p = nullptr; n = 0; }
+    ~Buf() { reset(); }
+    T* get() const { return p; }
+};
+
+// resident index (WordSet state) in HBM
+struct Resident {
+    u64 nb = 0;          // non-empty prefixes (tiered.len())
+    u64 count = 0;       // k-mers
+    Buf<u64> bv;         // 2^PB bits
+    Buf<u64> rank_dir;   // per bv word, exclusive
+    Buf<u32> prefix;     // per rank
+    Buf<u64> start;      // per rank (+1): first arena slot
+    Buf<u32> cnt;        // per rank
+    Buf<u8> kind;        // per rank
+    Buf<u64> a_lo, a_hi; // suffix arena (slack layout); a_hi only when SUFFIX_BITS > 64
+    bool empty() const { return nb == 0; }
+    DirView view() const { return DirView{bv.get(), rank_dir.get(), cnt.get(), kind.get(), start.get(), nb}; }
+};
+
+struct Stage { const char* name; double ms = 0; u64 launches = 0; };
+enum { ST_CHUNKS, ST_ENCODE, ST_HIST, ST_SCAN, ST_SCATTER, ST_DIR, ST_BSMALL, ST_BMED, ST_BHUGE, ST_EXPAND, ST_N };
+const char* kStageNames[ST_N] = {"chunks", "encode", "radix_hist", "radix_scan", "radix_scatter", "directory",
+                                 "bucket_small", "bucket_medium", "bucket_huge", "expand_resident"};
+
+}  // namespace
+
+struct cblx_ctx {
+    Consts P;
+    int device = 0;
+    u32 flags = 0;
+    hipStream_t stream = nullptr;
+    Pool pool;
+    Resident res;
+    std::vector<u8> pend_bases;     // enqueued sequences (host)
+    std::vector<u64> pend_offsets;  // n+1
+    std::string err;
+    u64 kmers_inserted = 0;
+    Stage stages[ST_N];
+    struct Ev { int st; hipEvent_t a, b; };
+    std::vector<Ev> evs;
+    std::vector<hipEvent_t> ev_free;
+
+    cblx_ctx() { for (int i = 0; i < ST_N; ++i) stages[i].name = kStageNames[i]; pend_offsets.push_back(0); }
+};
+
+namespace {
+
+struct StageTimer {  // brackets a group of launches with HIP events when profiling is on
+    cblx_ctx* c;
+    int idx = -1;
+    StageTimer(cblx_ctx* ctx, int st) : c(ctx) {
+        if (!(c->flags & CBLX_FLAG_PROFILE)) return;
+        auto get = [&]() { hipEvent_t e; if (!c->ev_free.empty()) { e = c->ev_free.back(); c->ev_free.pop_back(); } else CBLX_HIP(hipEventCreate(&e)); return e; };
+        cblx_ctx::Ev ev{st, get(), get()};
+        CBLX_HIP(hipEventRecord(ev.a, c->stream));
+        c->evs.push_back(ev);
+        idx = (int)c->evs.size() - 1;
+    }
+    ~StageTimer() { if (idx >= 0) (void)hipEventRecord(c->evs[idx].b, c->stream); }
+};
+void collect_events(cblx_ctx* c) {
+    if (c->evs.empty()) return;
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    for (auto& e : c->evs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { c->stages[e.st].ms += ms; c->stages[e.st].launches++; }
+        c->ev_free.push_back(e.a);
+        c->ev_free.push_back(e.b);
+    }
+    c->evs.clear();
+}
+
+inline dim3 grid1(u64 n, u32 threads) { return dim3((unsigned)std::max<u64>(1, ceil_div(n, threads))); }
+
+template <typename T> T d2h(cblx_ctx* c, const T* dptr) {
+    T v;
+    CBLX_HIP(hipMemcpyAsync(&v, dptr, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    return v;
+}
+template <typename T> std::vector<T> d2h_vec(cblx_ctx* c, const T* dptr, size_t n) {
+    std::vector<T> v(n);
+    if (n) {
+        CBLX_HIP(hipMemcpyAsync(v.data(), dptr, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+    }
+    return v;
+}
+template <typename T> void h2d(cblx_ctx* c, T* dptr, const T* h, size_t n) {
+    if (n) CBLX_HIP(hipMemcpyAsync(dptr, h, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+}
+
+// device-wide exclusive scan of u32 -> OutT; returns the total
+template <typename OutT> u64 exclusive_scan(cblx_ctx* c, const u32* in, u64 n, OutT* out) {
+    if (n == 0) return 0;
+    const u64 nb = ceil_div(n, SCAN_TILE);
+    Buf<u64> sums(c->pool, nb + 1);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, c->stream, in, n, sums.get());
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, c->stream, sums.get(), nb);
+    hipLaunchKernelGGL(k_scan_apply<OutT>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, c->stream, in, n, sums.get(), out);
+    CBLX_HIP(hipGetLastError());
+    return d2h<u64>(c, sums.get() + nb);
+}
+
+// ---- template configuration ------------------------------------------------------------------------------
+template <bool WIDE_, typename HiT_, bool WS_> struct Cfg {
+    static constexpr bool WIDE = WIDE_;
+    typedef HiT_ HiT;
+    static constexpr bool WS = WS_;
+};
+template <typename F> void dispatch(const Consts& P, F&& f) {
+    if (!P.has_hi()) f(Cfg<false, NoHi, false>());
+    else if (!P.wide_kmer()) f(Cfg<false, u8, false>());
+    else if (!P.wide_suffix()) f(Cfg<true, u64, false>());
+    else f(Cfg<true, u64, true>());
+}
+inline size_t hi_elem_size(const Consts& P) { return !P.has_hi() ? 0 : (!P.wide_kmer() ? 1 : 8); }
+
+// ---- the sort + directory + per-bucket pipeline over N records (lo/hi), resident records first -------------
+struct Records {
+    Buf<u64> lo, lo2;
+    Buf<u8> hi, hi2;  // raw bytes; element size = hi_elem_size
+};
+
+template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
+    typedef typename C::HiT HiT;
+    const Consts& P = c->P;
+    Resident nr;
+    if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "more than 2^32-16 words in one index are not supported yet");
+    u64* lo = rec.lo.get();
+    u64* lo2 = rec.lo2.get();
+    HiT* hi = (HiT*)rec.hi.get();
+    HiT* hi2 = (HiT*)rec.hi2.get();
+    // -- KRN-2: stable LSD radix partition on the PREFIX_BITS above SUFFIX_BITS
+    {
+        const u32 ntiles = (u32)ceil_div(N, RDX_TILE);
+        Buf<u32> counts(c->pool, (size_t)256 * ntiles), offsets(c->pool, (size_t)256 * ntiles);
+        const u32 npass = (P.PB + 7) / 8;
+        for (u32 pass = 0; pass < npass; ++pass) {
+            const u32 shift = P.SB + 8 * pass, nbits = std::min(8u, P.PB - 8 * pass);
+            { StageTimer t(c, ST_HIST);
+              hipLaunchKernelGGL(k_radix_hist<HiT>, dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, shift, nbits, ntiles, counts.get()); }
+            { StageTimer t(c, ST_SCAN);
+              exclusive_scan<u32>(c, counts.get(), (u64)256 * ntiles, offsets.get()); }
+            { StageTimer t(c, ST_SCATTER);
+              hipLaunchKernelGGL(k_radix_scatter<HiT>, dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, shift, nbits, ntiles, offsets.get(), lo2, hi2); }
+            std::swap(lo, lo2);
+            std::swap(hi, hi2);
+        }
+        CBLX_HIP(hipGetLastError());
+        if (npass & 1) { std::swap(rec.lo, rec.lo2); std::swap(rec.hi, rec.hi2); }
+    }
+    rec.lo2.reset();
+    rec.hi2.reset();
+    // -- KRN-4: bitvector, rank directory, bucket table
+    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    Buf<u32> res_count, out_count;
+    Buf<u8> res_kind;
+    {
+        StageTimer t(c, ST_DIR);
+        Buf<u32> start_dense(c->pool, nprefix), popc(c->pool, nwords);
+        nr.bv = Buf<u64>(c->pool, nwords);
+        nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
+        CBLX_HIP(hipMemsetAsync(start_dense.get(), 0xFF, nprefix * 4, c->stream));
+        CBLX_HIP(hipMemsetAsync(nr.bv.get(), 0, nwords * 8, c->stream));
+        CBLX_HIP(hipMemsetAsync(popc.get(), 0, nwords * 4, c->stream));
+        hipLaunchKernelGGL(k_boundaries<HiT>, grid1(N, 256), dim3(256), 0, c->stream, lo, hi, N, P.SB, P.PB, start_dense.get());
+        hipLaunchKernelGGL(k_bitvector, grid1(std::max<u64>(nprefix, 64), 256), dim3(256), 0, c->stream, start_dense.get(), nprefix, nr.bv.get(), popc.get());
+        nr.nb = exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get());
+        nr.prefix = Buf<u32>(c->pool, nr.nb + 1);
+        nr.start = Buf<u64>(c->pool, nr.nb + 1);
+        nr.cnt = Buf<u32>(c->pool, nr.nb + 1);
+        nr.kind = Buf<u8>(c->pool, nr.nb + 1);
+        hipLaunchKernelGGL(k_bucket_table, grid1(nprefix, 256), dim3(256), 0, c->stream, start_dense.get(), nprefix, nr.bv.get(), nr.rank_dir.get(), nr.prefix.get(), nr.start.get());
+        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, nr.start.get() + nr.nb, N);
+        CBLX_HIP(hipGetLastError());
+    }
+    // -- KRN-3: per-bucket dedup / sort, by size class
+    const u64 nb = nr.nb;
+    Buf<u32> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1)), list_n(c->pool, CLS_N);
+    res_count = Buf<u32>(c->pool, nb + 1);
+    res_kind = Buf<u8>(c->pool, nb + 1);
+    CBLX_HIP(hipMemsetAsync(list_n.get(), 0, CLS_N * 4, c->stream));
+    hipLaunchKernelGGL(k_classify, grid1(nb, 256), dim3(256), 0, c->stream, nb, C::WS ? 512u : 1024u, nr.prefix.get(), nr.start.get(), c->res.view(),
+                       res_count.get(), res_kind.get(), nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get());
+    std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
+    u64* a_lo = lo;
+    HiT* a_hi = hi;
+    if (ln[CLS_SMALL]) {
+        StageTimer t(c, ST_BSMALL);
+        hipLaunchKernelGGL((k_bucket_small<C::WS, HiT>), grid1((u64)ln[CLS_SMALL] * 64, 256), dim3(256), 0, c->stream,
+                           lists.get() + (size_t)CLS_SMALL * nb, list_n.get() + CLS_SMALL, nr.start.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+    }
+    {
+        StageTimer t(c, ST_BMED);
+        if (ln[CLS_M256])
+            hipLaunchKernelGGL((k_bucket_medium<256, C::WS, HiT>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb,
+                               list_n.get() + CLS_M256, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+        if (ln[CLS_M512])
+            hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb,
+                               list_n.get() + CLS_M512, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+        if constexpr (!C::WS) if (ln[CLS_M1024])  // 128-bit suffixes: 8192 keys + indices exceed the 160 KiB LDS, such runs go to the huge path
+            hipLaunchKernelGGL((k_bucket_medium<1024, C::WS, HiT>), dim3(ln[CLS_M1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)CLS_M1024 * nb,
+                               list_n.get() + CLS_M1024, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+    }
+    if (ln[CLS_HUGE]) {
+        StageTimer t(c, ST_BHUGE);
+        const u32 nh = ln[CLS_HUGE];
+        std::vector<u32> hl = d2h_vec<u32>(c, lists.get() + (size_t)CLS_HUGE * nb, nh);
+        std::vector<u64> starts = d2h_vec<u64>(c, nr.start.get(), nb + 1);
+        std::vector<u64> so(nh);
+        u64 tot = 0;
+        for (u32 i = 0; i < nh; ++i) { so[i] = tot; tot += starts[hl[i] + 1] - starts[hl[i]]; }
+        Buf<u64> d_so(c->pool, nh), s_alo(c->pool, tot), s_blo(c->pool, tot), s_ahi(c->pool, C::WS ? tot : 1), s_bhi(c->pool, C::WS ? tot : 1);
+        Buf<u32> s_aidx(c->pool, tot), s_bidx(c->pool, tot);
+        h2d(c, d_so.get(), so.data(), nh);
+        hipLaunchKernelGGL((k_bucket_huge<C::WS, HiT>), dim3(nh), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE,
+                           nr.start.get(), d_so.get(), res_kind.get(), a_lo, a_hi, P.SB, s_alo.get(), s_ahi.get(), s_aidx.get(), s_blo.get(), s_bhi.get(),
+                           s_bidx.get(), nr.cnt.get(), nr.kind.get());
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+    }
+    CBLX_HIP(hipGetLastError());
+    {
+        Buf<u64> total(c->pool, 1);
+        CBLX_HIP(hipMemsetAsync(total.get(), 0, 8, c->stream));
+        hipLaunchKernelGGL(k_sum_u32, grid1(nb, 256), dim3(256), 0, c->stream, nr.cnt.get(), nb, total.get());
+        nr.count = d2h<u64>(c, total.get());
+    }
+    nr.a_lo = std::move(rec.lo);
+    if (C::WS) {
+        // arena hi lives in the records' hi buffer (u64 elements in this configuration)
+        nr.a_hi.pool = rec.hi.pool; nr.a_hi.p = (u64*)rec.hi.p; nr.a_hi.n = rec.hi.n / 8;
+        rec.hi.p = nullptr; rec.hi.n = 0;
+    } else {
+        rec.hi.reset();
+    }
+    c->res = std::move(nr);
+}
+
+// allocate the record buffers for N words; resident words (if any) are expanded into the front
+template <typename C> u64 begin_records(cblx_ctx* c, Records& rec, u64 n_new) {
+    typedef typename C::HiT HiT;
+    const u64 n_res = c->res.count;
+    const u64 N = n_res + n_new;
+    const size_t hs = hi_elem_size(c->P);
+    rec.lo = Buf<u64>(c->pool, N + 2);
+    rec.lo2 = Buf<u64>(c->pool, N + 2);
+    rec.hi = Buf<u8>(c->pool, hs ? (N + 2) * hs : 8);
+    rec.hi2 = Buf<u8>(c->pool, hs ? (N + 2) * hs : 8);
+    if (n_res) {
+        StageTimer t(c, ST_EXPAND);
+        Buf<u64> res_off(c->pool, c->res.nb + 1);
+        u64 tot = exclusive_scan<u64>(c, c->res.cnt.get(), c->res.nb, res_off.get());
+        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, res_off.get() + c->res.nb, tot);
+        hipLaunchKernelGGL((k_expand_resident<C::WS, HiT>), grid1(n_res, 256), dim3(256), 0, c->stream, n_res, c->res.nb, res_off.get(),
+                           c->res.prefix.get(), c->res.start.get(), c->res.a_lo.get(), c->res.a_hi.get(), c->P.SB, rec.lo.get(), (HiT*)rec.hi.get());
+        CBLX_HIP(hipGetLastError());
+        CBLX_HIP(hipStreamSynchronize(c->stream));  // res_off is released at scope exit
+    }
+    return n_res;
+}
+
+// KRN-1 front end: chunk table + validity + encode. Returns the number of new words written at rec[out_base..).
+struct ChunkPlan {
+    u64 nchunks = 0, n_kmers = 0, total_bases = 0;
+    u32 ndirty = 0;
+    Buf<u64> chunk_start, kmer_off;
+    Buf<u32> chunk_len, tile_first;
+    Buf<u8> dirty;
+};
+void plan_chunks(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq, ChunkPlan& pl) {
+    StageTimer t(c, ST_CHUNKS);
+    const Consts& P = c->P;
+    pl.total_bases = d2h<u64>(c, d_offsets + nseq);
+    const u64 first = d2h<u64>(c, d_offsets);
+    if (first != 0) throw Error(CBLX_EINVAL, "offsets[0] must be 0");
+    Buf<u32> nch(c->pool, nseq + 1);
+    Buf<u64> err(c->pool, 2), chunk_base(c->pool, nseq + 1);
+    CBLX_HIP(hipMemsetAsync(err.get(), 0, 16, c->stream));
+    hipLaunchKernelGGL(k_seq_chunk_count, grid1(nseq, 256), dim3(256), 0, c->stream, d_offsets, nseq, P.K, nch.get(), err.get());
+    pl.nchunks = exclusive_scan<u64>(c, nch.get(), nseq, chunk_base.get());
+    std::vector<u64> e = d2h_vec<u64>(c, err.get(), 2);
+    if (e[0]) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(e[1] - 1) + ") is smaller than K (" + std::to_string(P.K) + ")");
+    if (pl.nchunks >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "too many chunks in one batch");
+    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, chunk_base.get() + nseq, pl.nchunks);
+    pl.chunk_start = Buf<u64>(c->pool, pl.nchunks + 1);
+    pl.chunk_len = Buf<u32>(c->pool, pl.nchunks + 1);
+    Buf<u32> chunk_nk(c->pool, pl.nchunks + 1);
+    pl.dirty = Buf<u8>(c->pool, pl.nchunks + 8);
+    Buf<u32> ndirty(c->pool, 1);
+    hipLaunchKernelGGL(k_chunk_fill, grid1(pl.nchunks, 256), dim3(256), 0, c->stream, d_offsets, chunk_base.get(), nseq, pl.nchunks, P.K,
+                       pl.chunk_start.get(), pl.chunk_len.get(), chunk_nk.get());
+    CBLX_HIP(hipMemsetAsync(pl.dirty.get(), 0, pl.nchunks + 8, c->stream));
+    CBLX_HIP(hipMemsetAsync(ndirty.get(), 0, 4, c->stream));
+    hipLaunchKernelGGL(k_scan_invalid, grid1(ceil_div(pl.total_bases, 16), 256), dim3(256), 0, c->stream, d_bases, pl.total_bases,
+                       pl.chunk_start.get(), pl.chunk_len.get(), pl.nchunks, pl.dirty.get(), ndirty.get());
+    pl.ndirty = d2h<u32>(c, ndirty.get());
+    if (pl.ndirty)
+        hipLaunchKernelGGL(k_dirty_count, grid1(pl.nchunks, 256), dim3(256), 0, c->stream, d_bases, pl.chunk_start.get(), pl.chunk_len.get(),
+                           pl.dirty.get(), pl.nchunks, P.K, chunk_nk.get());
+    pl.kmer_off = Buf<u64>(c->pool, pl.nchunks + 1);
+    pl.n_kmers = exclusive_scan<u64>(c, chunk_nk.get(), pl.nchunks, pl.kmer_off.get());
+    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, pl.kmer_off.get() + pl.nchunks, pl.n_kmers);
+    const u64 ntiles = ceil_div(pl.total_bases, ENC_TILE_BYTES);
+    pl.tile_first = Buf<u32>(c->pool, ntiles + 2);
+    hipLaunchKernelGGL(k_tile_first_chunk, grid1(ntiles + 1, 256), dim3(256), 0, c->stream, pl.chunk_start.get(), pl.nchunks, ntiles, pl.tile_first.get());
+    CBLX_HIP(hipGetLastError());
+    CBLX_HIP(hipStreamSynchronize(c->stream));  // temporaries (nch, err, chunk_base, chunk_nk, ndirty) die here
+}
+template <typename C> void encode(cblx_ctx* c, const u8* d_bases, const ChunkPlan& pl, u64* out_lo, typename C::HiT* out_hi, u64 out_base) {
+    typedef typename C::HiT HiT;
+    StageTimer t(c, ST_ENCODE);
+    const u64 ntiles = ceil_div(pl.total_bases, ENC_TILE_BYTES);
+    if (ntiles)
+        hipLaunchKernelGGL((k_encode<C::WIDE, HiT>), dim3((unsigned)ntiles), dim3(ENC_THREADS), 0, c->stream, d_bases, pl.total_bases, pl.chunk_start.get(),
+                           pl.chunk_len.get(), pl.kmer_off.get(), pl.ndirty ? pl.dirty.get() : (const u8*)nullptr, pl.tile_first.get(), c->P, out_lo, out_hi, out_base);
+    if (pl.ndirty)
+        hipLaunchKernelGGL((k_encode_dirty<C::WIDE, HiT>), grid1(pl.nchunks, 64), dim3(64), 0, c->stream, d_bases, pl.chunk_start.get(), pl.chunk_len.get(),
+                           pl.kmer_off.get(), pl.dirty.get(), pl.nchunks, c->P, out_lo, out_hi, out_base);
+    CBLX_HIP(hipGetLastError());
+}
+
+void check_aligned16(const void* p, const char* what) {
+    if (((uintptr_t)p) & 15) throw Error(CBLX_EINVAL, std::string(what) + " must be 16-byte aligned");
+}
+
+void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq) {
+    if (nseq == 0) return;
+    check_aligned16(d_bases, "d_bases");
+    dispatch(c->P, [&](auto cfg) {
+        typedef decltype(cfg) C;
+        ChunkPlan pl;
+        plan_chunks(c, d_bases, d_offsets, nseq, pl);
+        if (pl.n_kmers == 0) return;
+        Records rec;
+        const u64 base = begin_records<C>(c, rec, pl.n_kmers);
+        encode<C>(c, d_bases, pl, rec.lo.get(), (typename C::HiT*)rec.hi.get(), base);
+        pipeline<C>(c, rec, base + pl.n_kmers);
+        c->kmers_inserted += pl.n_kmers;
+    });
+    collect_events(c);
+}
+
+void flush(cblx_ctx* c) {
+    const u64 nseq = c->pend_offsets.size() - 1;
+    if (nseq == 0) return;
+    CBLX_HIP(hipSetDevice(c->device));
+    {
+        Buf<u8> d_bases(c->pool, c->pend_bases.size() + 64);
+        Buf<u64> d_off(c->pool, nseq + 1);
+        h2d(c, d_bases.get(), c->pend_bases.data(), c->pend_bases.size());
+        h2d(c, d_off.get(), c->pend_offsets.data(), nseq + 1);
+        // the pending queue is consumed even if the insert fails (the reference would have panicked)
+        std::vector<u8> keep_b;
+        std::vector<u64> keep_o;
+        keep_b.swap(c->pend_bases);
+        keep_o.swap(c->pend_offsets);
+        c->pend_offsets.assign(1, 0);
+        insert_device(c, d_bases.get(), d_off.get(), nseq);
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+    }
+}
+
+// ---- host-side views of the resident index (export / serialize / merge) ---------------------------------------
+struct HostIndex {
+    std::vector<u32> prefix, cnt;
+    std::vector<u8> kind;
+    std::vector<u64> off;  // nb+1 into lo/hi
+    std::vector<u64> lo, hi;
+};
+void download(cblx_ctx* c, HostIndex& h) {
+    const Resident& r = c->res;
+    h.prefix = d2h_vec<u32>(c, r.prefix.get(), r.nb);
+    h.cnt = d2h_vec<u32>(c, r.cnt.get(), r.nb);
+    h.kind = d2h_vec<u8>(c, r.kind.get(), r.nb);
+    h.off.assign(r.nb + 1, 0);
+    for (u64 i = 0; i < r.nb; ++i) h.off[i + 1] = h.off[i] + h.cnt[i];
+    const u64 n = h.off[r.nb];
+    if (n == 0) { h.lo.clear(); h.hi.clear(); return; }
+    Buf<u64> d_off(c->pool, r.nb + 1), d_lo(c->pool, n), d_hi(c->pool, c->P.wide_suffix() ? n : 1);
+    h2d(c, d_off.get(), h.off.data(), r.nb + 1);
+    hipLaunchKernelGGL(k_gather_dense, grid1(n, 256), dim3(256), 0, c->stream, n, r.nb, d_off.get(), r.start.get(), r.a_lo.get(),
+                       c->P.wide_suffix() ? r.a_hi.get() : (const u64*)nullptr, c->P.SB, d_lo.get(), c->P.wide_suffix() ? d_hi.get() : (u64*)nullptr);
+    CBLX_HIP(hipGetLastError());
+    h.lo = d2h_vec<u64>(c, d_lo.get(), n);
+    if (c->P.wide_suffix()) h.hi = d2h_vec<u64>(c, d_hi.get(), n); else h.hi.clear();
+}
+// replace the resident index by a host-built one (load / merge): dense arena, directory built on the host
+void upload(cblx_ctx* c, const HostIndex& h) {
+    const Consts& P = c->P;
+    Resident nr;
+    nr.nb = h.prefix.size();
+    const u64 n = h.off.empty() ? 0 : h.off.back();
+    nr.count = n;
+    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    std::vector<u64> bv(nwords, 0), rd(nwords + 1, 0);
+    for (u64 i = 0; i < nr.nb; ++i) {
+        if (h.prefix[i] >= nprefix) throw Error(CBLX_EFORMAT, "prefix out of range for PREFIX_BITS");
+        if (i && h.prefix[i] <= h.prefix[i - 1]) throw Error(CBLX_EFORMAT, "prefixes are not strictly ascending");
+        bv[h.prefix[i] >> 6] |= 1ull << (h.prefix[i] & 63);
+    }
+    for (u64 w = 0; w < nwords; ++w) rd[w + 1] = rd[w] + (u64)__builtin_popcountll(bv[w]);
+    nr.bv = Buf<u64>(c->pool, nwords);
+    nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
+    nr.prefix = Buf<u32>(c->pool, nr.nb + 1);
+    nr.start = Buf<u64>(c->pool, nr.nb + 1);
+    nr.cnt = Buf<u32>(c->pool, nr.nb + 1);
+    nr.kind = Buf<u8>(c->pool, nr.nb + 1);
+    nr.a_lo = Buf<u64>(c->pool, n + 2);
+    if (P.wide_suffix()) nr.a_hi = Buf<u64>(c->pool, n + 2);
+    h2d(c, nr.bv.get(), bv.data(), nwords);
+    h2d(c, nr.rank_dir.get(), rd.data(), nwords + 1);
+    h2d(c, nr.prefix.get(), h.prefix.data(), nr.nb);
+    h2d(c, nr.start.get(), h.off.data(), nr.nb + 1);
+    h2d(c, nr.cnt.get(), h.cnt.data(), nr.nb);
+    h2d(c, nr.kind.get(), h.kind.data(), nr.nb);
+    h2d(c, nr.a_lo.get(), h.lo.data(), n);
+    if (P.wide_suffix()) h2d(c, nr.a_hi.get(), h.hi.data(), n);
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    c->res = std::move(nr);
+}
+
+// ---- bincode 1.3 DefaultOptions (varint, little endian): src/cbl.rs:132-135 -----------------------------------
+struct Sink {
+    u8* buf;
+    u64 cap, pos = 0;
+    Sink(u8* b, u64 c) : buf(b), cap(c) {}
+    inline void u8_(u8 v) { if (buf && pos < cap) buf[pos] = v; ++pos; }
+    inline void raw(const u8* p, u64 n) { if (buf && pos + n <= cap) memcpy(buf + pos, p, n); pos += n; }
+    inline void varint(u64 v) {
+        if (v <= 250) { u8_((u8)v); return; }
+        int nb = v < (1ull << 16) ? 2 : v < (1ull << 32) ? 4 : 8;
+        u8_(nb == 2 ? 0xFB : nb == 4 ? 0xFC : 0xFD);
+        for (int i = 0; i < nb; ++i) u8_((u8)(v >> (8 * i)));
+    }
+};
+struct SfxView {
+    const u64* lo;
+    const u64* hi;
+    inline u128 at(u64 i) const { return hi ? (((u128)hi[i] << 64) | lo[i]) : (u128)lo[i]; }
+};
+// Trie node over sorted suffixes [a, b) that agree on their top `depth` bytes (src/trie.rs:53-57 derive,
+// src/bitvector/tiny/mod.rs:97-105): varint(c) | c byte values | varint(#children) | children...
+void emit_trie(Sink& s, const SfxView& v, u64 a, u64 b, u32 depth, u32 BYTES) {
+    const u32 shift = 8 * (BYTES - 1 - depth);
+    u8 vals[256];
+    u64 starts[257];
+    u32 c = 0;
+    u64 i = a;
+    while (i < b) {
+        const u8 by = (u8)(v.at(i) >> shift);
+        vals[c] = by;
+        starts[c++] = i;
+        // gallop to the end of this byte's run
+        u64 lo = i + 1, hi = b;
+        while (lo < hi) {
+            u64 mid = (lo + hi) >> 1;
+            if ((u8)(v.at(mid) >> shift) == by) lo = mid + 1; else hi = mid;
+        }
+        i = lo;
+    }
+    starts[c] = b;
+    s.varint(c);
+    s.raw(vals, c);
+    if (depth + 1 == BYTES) { s.varint(0); return; }
+    s.varint(c);
+    for (u32 k = 0; k < c; ++k) emit_trie(s, v, starts[k], starts[k + 1], depth + 1, BYTES);
+}
+void serialize_host(const Consts& P, const HostIndex& h, Sink& s) {
+    s.u8_(P.canonical ? 1 : 0);                  // CBL.canonical (src/cbl.rs:48)
+    s.varint(h.prefix.size());                   // serialize_map(Some(tiered.len()))  src/wordset/mod.rs:388
+    SfxView v{h.lo.data(), h.hi.empty() ? nullptr : h.hi.data()};
+    for (u64 r = 0; r < h.prefix.size(); ++r) {
+        s.varint(h.prefix[r]);
+        const u64 a = h.off[r], b = h.off[r + 1];
+        if (h.kind[r] == KIND_VEC) {             // TrieOrVec::Vec  src/trievec/mod.rs:10-11
+            s.varint(0);
+            s.varint(b - a);
+            for (u64 i = a; i < b; ++i) {
+                s.varint(P.BYTES);               // SlicedInt::serialize -> serialize_bytes  src/sliced_int.rs:110-114
+                u128 x = v.at(i);
+                u8 tmp[16];
+                for (u32 k = 0; k < P.BYTES; ++k) tmp[k] = (u8)(x >> (8 * k));
+                s.raw(tmp, P.BYTES);
+            }
+        } else {                                 // TrieOrVec::Trie(trie, len)  src/trievec/mod.rs:12
+            s.varint(1);
+            emit_trie(s, v, a, b, 0, P.BYTES);
+            s.varint(b - a);
+        }
+    }
+}
+struct Src {
+    const u8* p;
+    const u8* end;
+    u8 u8_() { if (p >= end) throw Error(CBLX_EFORMAT, "index: unexpected end of data"); return *p++; }
+    u64 varint() {
+        u8 t = u8_();
+        if (t <= 250) return t;
+        int nb = t == 0xFB ? 2 : t == 0xFC ? 4 : t == 0xFD ? 8 : 0;
+        if (!nb) throw Error(CBLX_EFORMAT, "index: bad varint tag");
+        u64 v = 0;
+        for (int i = 0; i < nb; ++i) v |= (u64)u8_() << (8 * i);
+        return v;
+    }
+};
+void parse_trie(Src& s, u32 depth, u32 BYTES, u128 acc, std::vector<u128>& out) {
+    u64 c = s.varint();
+    if (c > 256) throw Error(CBLX_EFORMAT, "index: trie node with more than 256 entries");
+    u8 vals[256];
+    for (u64 i = 0; i < c; ++i) vals[i] = s.u8_();
+    u64 nc = s.varint();
+    const u32 shift = 8 * (BYTES - 1 - depth);
+    if (depth + 1 == BYTES) {
+        if (nc != 0) throw Error(CBLX_EFORMAT, "index: leaf trie node with children");
+        for (u64 i = 0; i < c; ++i) out.push_back(acc | ((u128)vals[i] << shift));
+        return;
+    }
+    if (nc != c) throw Error(CBLX_EFORMAT, "index: trie node children count mismatch");
+    for (u64 i = 0; i < c; ++i) parse_trie(s, depth + 1, BYTES, acc | ((u128)vals[i] << shift), out);
+}
+void parse_index(const Consts& P, const u8* data, u64 len, HostIndex& h, bool& canonical) {
+    Src s{data, data + len};
+    canonical = s.u8_() != 0;
+    const u64 nb = s.varint();
+    h.off.assign(1, 0);
+    const bool wide = P.wide_suffix();
+    std::vector<u128> tmp;
+    for (u64 r = 0; r < nb; ++r) {
+        h.prefix.push_back((u32)s.varint());
+        const u64 tag = s.varint();
+        if (tag == 0) {
+            const u64 n = s.varint();
+            for (u64 i = 0; i < n; ++i) {
+                const u64 nbts = s.varint();
+                u128 x = 0;
+                for (u64 k = 0; k < nbts; ++k) { u8 b = s.u8_(); if (k < P.BYTES) x |= (u128)b << (8 * k); }
+                h.lo.push_back((u64)x);
+                if (wide) h.hi.push_back((u64)(x >> 64));
+            }
+            h.kind.push_back(KIND_VEC);
+            h.cnt.push_back((u32)n);
+        } else if (tag == 1) {
+            tmp.clear();
+            parse_trie(s, 0, P.BYTES, 0, tmp);
+            const u64 n = s.varint();
+            if (n != tmp.size()) throw Error(CBLX_EFORMAT, "index: trie length field does not match its contents");
+            for (u128 x : tmp) { h.lo.push_back((u64)x); if (wide) h.hi.push_back((u64)(x >> 64)); }
+            h.kind.push_back(KIND_TRIE);
+            h.cnt.push_back((u32)n);
+        } else throw Error(CBLX_EFORMAT, "index: bad TrieOrVec tag");
+        h.off.push_back(h.lo.size());
+    }
+    if (s.p != s.end) throw Error(CBLX_EFORMAT, "index: trailing bytes");  // reject_trailing_bytes
+}
+
+// `self |= other` on host copies (v1): src/wordset/set_ops.rs:123-157 + src/trievec/set_ops.rs:43-71
+void merge_host(const Consts& P, const HostIndex& a, const HostIndex& b, HostIndex& o) {
+    const bool wide = P.wide_suffix();
+    auto get = [&](const HostIndex& h, u64 i) -> u128 { return wide ? (((u128)h.hi[i] << 64) | h.lo[i]) : (u128)h.lo[i]; };
+    auto put = [&](u128 x) { o.lo.push_back((u64)x); if (wide) o.hi.push_back((u64)(x >> 64)); };
+    o.off.assign(1, 0);
+    u64 i = 0, j = 0;
+    const u64 na = a.prefix.size(), nb = b.prefix.size();
+    std::vector<u128> sa, sb;
+    while (i < na || j < nb) {
+        if (j >= nb || (i < na && a.prefix[i] < b.prefix[j])) {  // self only: untouched
+            o.prefix.push_back(a.prefix[i]); o.kind.push_back(a.kind[i]); o.cnt.push_back(a.cnt[i]);
+            for (u64 t = a.off[i]; t < a.off[i + 1]; ++t) put(get(a, t));
+            ++i;
+        } else if (i >= na || b.prefix[j] < a.prefix[i]) {       // other only: cloned as stored
+            o.prefix.push_back(b.prefix[j]); o.kind.push_back(b.kind[j]); o.cnt.push_back(b.cnt[j]);
+            for (u64 t = b.off[j]; t < b.off[j + 1]; ++t) put(get(b, t));
+            ++j;
+        } else {                                                  // both: sorted(self) ++ sorted(other \ self) or trie union
+            sa.clear(); sb.clear();
+            for (u64 t = a.off[i]; t < a.off[i + 1]; ++t) sa.push_back(get(a, t));
+            for (u64 t = b.off[j]; t < b.off[j + 1]; ++t) sb.push_back(get(b, t));
+            std::sort(sa.begin(), sa.end());
+            std::sort(sb.begin(), sb.end());
+            std::vector<u128> ins;
+            std::set_difference(sb.begin(), sb.end(), sa.begin(), sa.end(), std::back_inserter(ins));
+            u64 n = 0;
+            if (a.kind[i] == KIND_VEC) {
+                for (u128 x : sa) { put(x); ++n; }
+                for (u128 x : ins) { put(x); ++n; }   // pushed at the end; no threshold check (Vec may exceed 1024)
+            } else {
+                std::vector<u128> u;
+                std::merge(sa.begin(), sa.end(), ins.begin(), ins.end(), std::back_inserter(u));
+                for (u128 x : u) { put(x); ++n; }
+            }
+            o.prefix.push_back(a.prefix[i]); o.kind.push_back(a.kind[i]); o.cnt.push_back((u32)n);
+            ++i; ++j;
+        }
+        o.off.push_back(o.lo.size());
+    }
+}
+
+template <typename F> int guard(cblx_ctx* c, F&& f) {
+    try {
+        if (c) CBLX_HIP(hipSetDevice(c->device));
+        f();
+        return CBLX_OK;
+    } catch (const Error& e) {
+        (c ? c->err : g_global_err) = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        (c ? c->err : g_global_err) = "out of host memory";
+        return CBLX_ENOMEM;
+    } catch (const std::exception& e) {
+        (c ? c->err : g_global_err) = e.what();
+        return CBLX_EINVAL;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+uint32_t cblx_abi_version(void) { return CBLX_ABI_VERSION; }
+const char* cblx_last_global_error(void) { return g_global_err.c_str(); }
+const char* cblx_last_error(const cblx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_global_err.c_str(); }
+
+int cblx_create(const cblx_params* p, cblx_ctx** out) {
+    return guard(nullptr, [&] {
+        if (!p || !out) throw Error(CBLX_EINVAL, "null argument");
+        *out = nullptr;
+        if (p->k < 5 || p->k > 59 || (p->k & 1) == 0) throw Error(CBLX_EINVAL, "K must be odd and in [5, 59]");
+        Consts P;
+        P.K = p->k; P.PB = p->prefix_bits; P.KB = 2 * p->k; P.POS = ilog2_npo2(P.KB); P.WB = P.KB + P.POS;
+        P.canonical = p->canonical ? 1 : 0;
+        if (P.PB < 1 || P.PB > 32) throw Error(CBLX_EINVAL, "PREFIX_BITS=" + std::to_string(P.PB) + " but it should be in [1, 32]");
+        if (P.PB > 28) throw Error(CBLX_EINVAL, "PREFIX_BITS > 28 is not supported (README.md:130 caps it at 28)");
+        if (P.WB <= P.PB) throw Error(CBLX_EINVAL, "SUFFIX_BITS should be != 0");
+        if (P.WB > 128) throw Error(CBLX_EINVAL, "Cannot fit a K-mer and its length in a 128-bit integer");
+        P.SB = P.WB - P.PB;
+        P.BYTES = (P.SB + 7) / 8;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw Error(CBLX_EDEVICE, "no HIP device available (libcblx has no CPU fallback)");
+        int dev = p->device;
+        if (dev < 0) CBLX_HIP(hipGetDevice(&dev));
+        if (dev >= ndev) throw Error(CBLX_EINVAL, "device ordinal out of range");
+        CBLX_HIP(hipSetDevice(dev));
+        std::unique_ptr<cblx_ctx> c(new cblx_ctx());
+        c->P = P;
+        c->device = dev;
+        c->flags = p->flags;
+        CBLX_HIP(hipStreamCreate(&c->stream));
+        *out = c.release();
+    });
+}
+void cblx_destroy(cblx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& e : ctx->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : ctx->ev_free) (void)hipEventDestroy(e);
+    ctx->res = Resident();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int cblx_insert_seq(cblx_ctx* c, const uint8_t* seq, uint64_t len) {
+    return guard(c, [&] {
+        if (!seq && len) throw Error(CBLX_EINVAL, "null sequence");
+        if (len < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(len) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
+        c->pend_bases.insert(c->pend_bases.end(), seq, seq + len);
+        c->pend_offsets.push_back(c->pend_bases.size());
+    });
+}
+int cblx_insert_seqs(cblx_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint64_t n) {
+    return guard(c, [&] {
+        if (n == 0) return;
+        if (!bases || !offsets) throw Error(CBLX_EINVAL, "null argument");
+        for (u64 i = 0; i < n; ++i) {
+            if (offsets[i + 1] < offsets[i]) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
+            u64 len = offsets[i + 1] - offsets[i];
+            if (len < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(len) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
+        }
+        const u64 base = c->pend_bases.size();
+        c->pend_bases.insert(c->pend_bases.end(), bases + offsets[0], bases + offsets[n]);
+        for (u64 i = 1; i <= n; ++i) c->pend_offsets.push_back(base + (offsets[i] - offsets[0]));
+    });
+}
+int cblx_insert_seqs_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n) {
+    return guard(c, [&] {
+        if (n && (!d_bases || !d_offsets)) throw Error(CBLX_EINVAL, "null argument");
+        flush(c);  // keep stream order with anything enqueued earlier
+        insert_device(c, d_bases, d_offsets, n);
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+int cblx_flush(cblx_ctx* c) { return guard(c, [&] { flush(c); }); }
+
+int cblx_insert_words_device(cblx_ctx* c, const uint64_t* d_lo, const uint64_t* d_hi, uint64_t n) {
+    return guard(c, [&] {
+        flush(c);
+        if (n == 0) return;
+        if (!d_lo || (c->P.has_hi() && !d_hi)) throw Error(CBLX_EINVAL, "null argument");
+        dispatch(c->P, [&](auto cfg) {
+            typedef decltype(cfg) C;
+            typedef typename C::HiT HiT;
+            Records rec;
+            const u64 base = begin_records<C>(c, rec, n);
+            CBLX_HIP(hipMemcpyAsync(rec.lo.get() + base, d_lo, n * 8, hipMemcpyDeviceToDevice, c->stream));
+            if constexpr (std::is_same<HiT, u64>::value) {
+                CBLX_HIP(hipMemcpyAsync((u64*)rec.hi.get() + base, d_hi, n * 8, hipMemcpyDeviceToDevice, c->stream));
+            } else if constexpr (std::is_same<HiT, u8>::value) {
+                // narrow the caller's u64 hi words to the 1-byte-per-record layout
+                hipLaunchKernelGGL(k_narrow_u8, grid1(n, 256), dim3(256), 0, c->stream, d_hi, rec.hi.get() + base, n);
+            }
+            pipeline<C>(c, rec, base + n);
+            c->kmers_inserted += n;
+        });
+        collect_events(c);
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+    });
+}
+int cblx_seq_words_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n, uint64_t* d_lo, uint64_t* d_hi,
+                          uint64_t cap, uint64_t* n_words) {
+    return guard(c, [&] {
+        if (n_words) *n_words = 0;
+        if (n == 0) return;
+        if (!d_bases || !d_offsets || !d_lo) throw Error(CBLX_EINVAL, "null argument");
+        check_aligned16(d_bases, "d_bases");
+        dispatch(c->P, [&](auto cfg) {
+            typedef decltype(cfg) C;
+            typedef typename C::HiT HiT;
+            ChunkPlan pl;
+            plan_chunks(c, d_bases, d_offsets, n, pl);
+            if (n_words) *n_words = pl.n_kmers;
+            if (pl.n_kmers > cap) throw Error(CBLX_ERANGE, "output capacity too small");
+            if (pl.n_kmers == 0) return;
+            if constexpr (std::is_same<HiT, u8>::value) {
+                Buf<u8> tmp(c->pool, pl.n_kmers + 8);
+                encode<C>(c, d_bases, pl, d_lo, tmp.get(), 0);
+                if (d_hi) {
+                    hipLaunchKernelGGL(k_widen_u8, grid1(pl.n_kmers, 256), dim3(256), 0, c->stream, tmp.get(), d_hi, pl.n_kmers);
+                }
+                CBLX_HIP(hipStreamSynchronize(c->stream));
+            } else if constexpr (std::is_same<HiT, u64>::value) {
+                if (!d_hi) throw Error(CBLX_EINVAL, "d_hi is required when 2K + POS_BITS > 64");
+                encode<C>(c, d_bases, pl, d_lo, d_hi, 0);
+                CBLX_HIP(hipStreamSynchronize(c->stream));
+            } else {
+                encode<C>(c, d_bases, pl, d_lo, (NoHi*)nullptr, 0);
+                if (d_hi) CBLX_HIP(hipMemsetAsync(d_hi, 0, pl.n_kmers * 8, c->stream));
+                CBLX_HIP(hipStreamSynchronize(c->stream));
+            }
+        });
+        collect_events(c);
+    });
+}
+
+int cblx_count(cblx_ctx* c, uint64_t* out) { return guard(c, [&] { flush(c); *out = c->res.count; }); }
+int cblx_num_buckets(cblx_ctx* c, uint64_t* out) { return guard(c, [&] { flush(c); *out = c->res.nb; }); }
+int cblx_is_empty(cblx_ctx* c, int* out) { return guard(c, [&] { flush(c); *out = c->res.nb == 0; }); }
+int cblx_is_canonical(const cblx_ctx* c, int* out) { if (!c || !out) return CBLX_EINVAL; *out = (int)c->P.canonical; return CBLX_OK; }
+
+int cblx_serialized_size(cblx_ctx* c, uint64_t* nbytes) {
+    return guard(c, [&] {
+        flush(c);
+        HostIndex h;
+        download(c, h);
+        Sink s(nullptr, 0);
+        serialize_host(c->P, h, s);
+        *nbytes = s.pos;
+    });
+}
+int cblx_serialize(cblx_ctx* c, uint8_t* buf, uint64_t cap, uint64_t* written) {
+    return guard(c, [&] {
+        flush(c);
+        HostIndex h;
+        download(c, h);
+        Sink s(buf, cap);
+        serialize_host(c->P, h, s);
+        if (written) *written = s.pos;
+        if (s.pos > cap) throw Error(CBLX_ERANGE, "buffer too small: need " + std::to_string(s.pos) + " bytes");
+    });
+}
+int cblx_save_to_file(cblx_ctx* c, const char* path) {
+    return guard(c, [&] {
+        flush(c);
+        HostIndex h;
+        download(c, h);
+        Sink cnt(nullptr, 0);
+        serialize_host(c->P, h, cnt);
+        std::vector<u8> out(cnt.pos);
+        Sink s(out.data(), out.size());
+        serialize_host(c->P, h, s);
+        std::ofstream f(path, std::ios::binary);
+        if (!f) throw Error(CBLX_EINVAL, std::string("Failed to create ") + path);
+        f.write((const char*)out.data(), (std::streamsize)out.size());
+        if (!f) throw Error(CBLX_EINVAL, std::string("Failed to write index to ") + path);
+    });
+}
+int cblx_load(cblx_ctx* c, const uint8_t* data, uint64_t len) {
+    return guard(c, [&] {
+        if (!data) throw Error(CBLX_EINVAL, "null argument");
+        HostIndex h;
+        bool canon = false;
+        parse_index(c->P, data, len, h, canon);
+        c->pend_bases.clear();
+        c->pend_offsets.assign(1, 0);
+        upload(c, h);
+        c->P.canonical = canon ? 1 : 0;
+    });
+}
+int cblx_load_from_file(cblx_ctx* c, const char* path) {
+    std::vector<u8> data;
+    int rc = guard(c, [&] {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) throw Error(CBLX_EINVAL, std::string("Failed to open ") + path);
+        data.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    });
+    if (rc) return rc;
+    return cblx_load(c, data.data(), data.size());
+}
+int cblx_merge_assign(cblx_ctx* self, cblx_ctx* other) {
+    return guard(self, [&] {
+        if (!other) throw Error(CBLX_EINVAL, "null argument");
+        if (self->P.K != other->P.K || self->P.PB != other->P.PB) throw Error(CBLX_EINVAL, "merge: K / PREFIX_BITS mismatch");
+        if (self->P.canonical != other->P.canonical) throw Error(CBLX_EINVAL, "One of the index is canonical while the other isn't");
+        flush(self);
+        CBLX_HIP(hipSetDevice(other->device));
+        flush(other);
+        HostIndex a, b, o;
+        download(other, b);
+        CBLX_HIP(hipSetDevice(self->device));
+        download(self, a);
+        merge_host(self->P, a, b, o);
+        upload(self, o);
+    });
+}
+int cblx_export_buckets(cblx_ctx* c, cblx_bucket_cb cb, void* user) {
+    return guard(c, [&] {
+        if (!cb) throw Error(CBLX_EINVAL, "null callback");
+        flush(c);
+        HostIndex h;
+        download(c, h);
+        for (u64 r = 0; r < h.prefix.size(); ++r) {
+            const u64 a = h.off[r];
+            if (cb(user, h.prefix[r], h.kind[r], h.cnt[r], h.lo.data() + a, h.hi.empty() ? nullptr : h.hi.data() + a)) break;
+        }
+    });
+}
+int cblx_contains_seq(cblx_ctx* c, const uint8_t* seq, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* n) {
+    return guard(c, [&] {
+        flush(c);
+        if (len < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(len) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
+        dispatch(c->P, [&](auto cfg) {
+            typedef decltype(cfg) C;
+            typedef typename C::HiT HiT;
+            Buf<u8> d_b(c->pool, len + 64);
+            Buf<u64> d_o(c->pool, 2);
+            u64 offs[2] = {0, len};
+            h2d(c, d_b.get(), seq, len);
+            h2d(c, d_o.get(), offs, 2);
+            ChunkPlan pl;
+            plan_chunks(c, d_b.get(), d_o.get(), 1, pl);
+            if (n) *n = pl.n_kmers;
+            if (pl.n_kmers > cap) throw Error(CBLX_ERANGE, "output capacity too small");
+            Buf<u64> w_lo(c->pool, pl.n_kmers + 2);
+            Buf<u8> w_hi(c->pool, (pl.n_kmers + 2) * std::max<size_t>(1, hi_elem_size(c->P)));
+            Buf<u8> d_out(c->pool, pl.n_kmers + 8);
+            encode<C>(c, d_b.get(), pl, w_lo.get(), (HiT*)w_hi.get(), 0);
+            hipLaunchKernelGGL(k_contains<HiT>, grid1(pl.n_kmers, 256), dim3(256), 0, c->stream, w_lo.get(), (const HiT*)w_hi.get(), pl.n_kmers, c->P.SB,
+                               c->P.PB, c->res.view(), c->res.a_lo.get(), c->P.wide_suffix() ? c->res.a_hi.get() : (const u64*)nullptr, d_out.get());
+            CBLX_HIP(hipGetLastError());
+            CBLX_HIP(hipMemcpyAsync(out, d_out.get(), pl.n_kmers, hipMemcpyDeviceToHost, c->stream));
+            CBLX_HIP(hipStreamSynchronize(c->stream));
+        });
+        collect_events(c);
+    });
+}
+int cblx_get_consts(const cblx_ctx* c, cblx_consts* o) {
+    if (!c || !o) return CBLX_EINVAL;
+    o->kmer_bits = c->P.KB; o->pos_bits = c->P.POS; o->word_bits = c->P.WB; o->suffix_bits = c->P.SB; o->bytes = c->P.BYTES;
+    o->chunk_size = CHUNK_KMERS; o->threshold = VEC_THRESHOLD; o->reserved = 0;
+    return CBLX_OK;
+}
+int cblx_stage_times(cblx_ctx* c, const char** names, double* ms, uint64_t* launches, uint32_t cap, uint32_t* n) {
+    return guard(c, [&] {
+        collect_events(c);
+        u32 k = 0;
+        for (; k < ST_N && k < cap; ++k) {
+            if (names) names[k] = c->stages[k].name;
+            if (ms) ms[k] = c->stages[k].ms;
+            if (launches) launches[k] = c->stages[k].launches;
+        }
+        if (n) *n = k;
+    });
+}
+int cblx_stage_times_reset(cblx_ctx* c) {
+    return guard(c, [&] { collect_events(c); for (auto& s : c->stages) { s.ms = 0; s.launches = 0; } });
+}
+int cblx_kmers_inserted(cblx_ctx* c, uint64_t* out) { if (!c || !out) return CBLX_EINVAL; *out = c->kmers_inserted; return CBLX_OK; }
+int cblx_trim(cblx_ctx* c) { return guard(c, [&] { c->pool.trim(); }); }
+
+}  // extern "C"

@@ -1,0 +1,571 @@
+// kernels_bucket.hpp — KRN-3 (per-bucket dedup-keep-first / sort) and KRN-4 (prefix bitvector, rank directory,
+// bucket table) over the prefix-sorted record array.
+//
+// Replaces (reference, CPU):
+//   KRN-4: Bitvector::insert/rank over RankBV (/root/reference/src/bitvector/mod.rs:35-47, cxx/rank_bv.h:30-33) and the
+//          rank -> bucket id TieredVec32 (/root/reference/cxx/tiered_vec.h:39-45)  -> static bitvector + popcount
+//          scan + bucket table indexed by rank.
+//   KRN-3: TrieVec::insert / insert_iter (/root/reference/src/trievec/mod.rs:72-115): Vec bucket = linear `contains`
+//          then push (first-occurrence order, unsorted); adapt_container_grow
+//          (/root/reference/src/wordset/mod.rs:240-244): > 1024 distinct -> Trie (canonical, order-free; we keep the
+//          sorted distinct list, of which the serialized trie is a pure function).
+//
+// Input to KRN-3: for bucket r the run rec[raw_start[r] .. raw_start[r+1]) holds its words in STREAM order (stable
+// partition), resident entries (if any) first. Output, in place at the start of the run: the distinct suffixes,
+// in first-occurrence order if their number is <= 1024 (and the resident bucket was not already a Trie), else
+// ascending; count[r], kind[r].
+#pragma once
+#include <type_traits>
+
+#include "kernels_radix.hpp"
+
+namespace cblx {
+
+static const u32 EMPTY32 = 0xFFFFFFFFu;
+enum { KIND_VEC = 0, KIND_TRIE = 1 };
+
+// ---- KRN-4 ---------------------------------------------------------------------------------------------
+// start_dense[p] = index of the first record with prefix p (array pre-filled with EMPTY32)
+template <typename HiT>
+__global__ void k_boundaries(const u64* __restrict__ lo, const HiT* __restrict__ hi, u64 n, u32 SB, u32 PB,
+                             u32* __restrict__ start_dense) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 p = get_bits(lo[i], ld_hi<HiT>(hi, i), SB, PB);
+    u32 q = EMPTY32;
+    if (i > 0) q = get_bits(lo[i - 1], ld_hi<HiT>(hi, i - 1), SB, PB);
+    if (p != q) start_dense[p] = (u32)i;
+}
+// one lane per prefix, one wave per bitvector word
+__global__ void k_bitvector(const u32* __restrict__ start_dense, u64 nprefix, u64* __restrict__ bv, u32* __restrict__ popc) {
+    u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    bool has = p < nprefix && start_dense[p] != EMPTY32;
+    u64 bal = __ballot(has);
+    if ((threadIdx.x & 63) == 0 && p < nprefix) {
+        bv[p >> 6] = bal;
+        popc[p >> 6] = (u32)__builtin_popcountll(bal);
+    }
+}
+__global__ void k_bucket_table(const u32* __restrict__ start_dense, u64 nprefix, const u64* __restrict__ bv,
+                               const u64* __restrict__ rank_dir, u32* __restrict__ bucket_prefix, u64* __restrict__ raw_start) {
+    u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nprefix) return;
+    u32 s = start_dense[p];
+    if (s == EMPTY32) return;
+    u64 w = bv[p >> 6];
+    u64 r = rank_dir[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
+    bucket_prefix[r] = (u32)p;
+    raw_start[r] = s;
+}
+
+// Directory of a resident index, for device-side lookups by prefix.
+struct DirView {
+    const u64* bv;        // 2^PB bits
+    const u64* rank_dir;  // exclusive popcount prefix per bv word
+    const u32* count;     // per rank
+    const u8* kind;       // per rank
+    const u64* start;     // per rank: first arena slot
+    u64 nb;
+};
+__device__ __forceinline__ bool dir_lookup(const DirView& d, u32 p, u64& rank) {
+    if (!d.bv) return false;
+    u64 w = d.bv[p >> 6];
+    if (!((w >> (p & 63)) & 1ull)) return false;
+    rank = d.rank_dir[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
+    return true;
+}
+
+// ---- classification of buckets by run length -----------------------------------------------------------
+enum { CLS_SMALL = 0, CLS_M256 = 1, CLS_M512 = 2, CLS_M1024 = 3, CLS_HUGE = 4, CLS_N = 5 };
+static const u32 SMALL_MAX = 64;
+static const u32 MED_ITEMS = 8;
+
+__global__ void k_classify(u64 nb, u32 med_max_threads, const u32* __restrict__ bucket_prefix, const u64* __restrict__ raw_start, DirView old,
+                           u32* __restrict__ res_count, u8* __restrict__ res_kind, u32* __restrict__ out_count,
+                           u8* __restrict__ out_kind, u32* __restrict__ lists /* [CLS_N][nb] */, u32* __restrict__ list_n) {
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nb) return;
+    u64 c = raw_start[r + 1] - raw_start[r];
+    u32 rc = 0;
+    u8 rk = KIND_VEC;
+    u64 orank;
+    if (dir_lookup(old, bucket_prefix[r], orank)) { rc = old.count[orank]; rk = old.kind[orank]; }
+    res_count[r] = rc;
+    res_kind[r] = rk;
+    if (rc != 0 && c == rc) {  // untouched by this batch: keep as is (src/wordset/mod.rs:213-214 only re-checks touched buckets)
+        out_count[r] = rc;
+        out_kind[r] = rk;
+        return;
+    }
+    int cls;
+    if (c <= SMALL_MAX && rk != KIND_TRIE) cls = CLS_SMALL;
+    else if (c <= 256 * MED_ITEMS) cls = CLS_M256;
+    else if (c <= 512 * MED_ITEMS) cls = CLS_M512;
+    else if (c <= 1024 * MED_ITEMS && med_max_threads >= 1024) cls = CLS_M1024;
+    else cls = CLS_HUGE;
+    u32 slot = atomicAdd(&list_n[cls], 1u);
+    lists[(u64)cls * nb + slot] = (u32)r;
+}
+
+// ---- suffix access --------------------------------------------------------------------------------------
+// narrow suffix (SB <= 64): suffix = lo & mask. wide (SB > 64): (hi & mask(SB-64), lo).
+template <bool WS> struct Sfx;
+template <> struct Sfx<false> {
+    u64 lo;
+    __device__ __forceinline__ bool operator==(const Sfx& o) const { return lo == o.lo; }
+    __device__ __forceinline__ bool operator!=(const Sfx& o) const { return lo != o.lo; }
+    __device__ __forceinline__ u32 digit(u32 pass) const { return (u32)(lo >> (8 * pass)) & 255u; }
+};
+template <> struct Sfx<true> {
+    u64 lo, hi;
+    __device__ __forceinline__ bool operator==(const Sfx& o) const { return lo == o.lo && hi == o.hi; }
+    __device__ __forceinline__ bool operator!=(const Sfx& o) const { return lo != o.lo || hi != o.hi; }
+    __device__ __forceinline__ u32 digit(u32 pass) const { return pass < 8 ? (u32)(lo >> (8 * pass)) & 255u : (u32)(hi >> (8 * (pass - 8))) & 255u; }
+};
+template <bool WS, typename HiT>
+__device__ __forceinline__ Sfx<WS> load_sfx(const u64* lo, const HiT* hi, u64 i, u32 SB) {
+    Sfx<WS> s;
+    if constexpr (WS) {
+        s.lo = lo[i];
+        s.hi = ld_hi<HiT>(hi, i) & ((1ull << (SB - 64)) - 1ull);
+    } else {
+        s.lo = SB >= 64 ? lo[i] : (lo[i] & ((1ull << SB) - 1ull));
+    }
+    return s;
+}
+template <bool WS, typename HiT> __device__ __forceinline__ void store_sfx(u64* lo, HiT* hi, u64 i, const Sfx<WS>& s) {
+    lo[i] = s.lo;
+    if constexpr (WS) st_hi<HiT>(hi, i, s.hi);
+}
+template <bool WS> __device__ __forceinline__ Sfx<WS> shfl_sfx(const Sfx<WS>& s, int src) {
+    Sfx<WS> r;
+    r.lo = __shfl(s.lo, src, 64);
+    if constexpr (WS) r.hi = __shfl(s.hi, src, 64);
+    return r;
+}
+
+// ---- KRN-3 small: one wave per bucket, run <= 64, all-pairs "seen before?" (the reference's own
+// `vec.contains(x)` semantics, src/trievec/mod.rs:81-87), ordered compaction by ballot ----------------------
+template <bool WS, typename HiT>
+__global__ __launch_bounds__(256) void k_bucket_small(const u32* __restrict__ list, const u32* __restrict__ list_n,
+                                                      const u64* __restrict__ raw_start, u64* __restrict__ lo,
+                                                      HiT* __restrict__ hi, u32 SB, u32* __restrict__ out_count,
+                                                      u8* __restrict__ out_kind) {
+    const u32 wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wv >= *list_n) return;
+    const u32 r = list[wv];
+    const u64 s0 = raw_start[r];
+    const u32 c = (u32)(raw_start[r + 1] - s0);
+    Sfx<WS> mine;
+    mine.lo = 0;
+    if constexpr (WS) mine.hi = 0;
+    if (lane < c) mine = load_sfx<WS, HiT>(lo, hi, s0 + lane, SB);
+    bool dup = false;
+    for (u32 j = 0; j + 1 < c; ++j) {
+        Sfx<WS> o = shfl_sfx<WS>(mine, (int)j);
+        if (j < lane && o == mine) dup = true;
+    }
+    const bool keep = lane < c && !dup;
+    const u64 bal = __ballot(keep);
+    if (keep) store_sfx<WS, HiT>(lo, hi, s0 + mbcnt(bal), mine);
+    if (lane == 0) {
+        out_count[r] = (u32)__builtin_popcountll(bal);
+        out_kind[r] = KIND_VEC;
+    }
+}
+
+// ---- KRN-3 medium: one workgroup per bucket, run <= THREADS*8, stable LSD radix sort in LDS -----------------
+template <int THREADS, bool WS, typename HiT>
+__global__ __launch_bounds__(THREADS) void k_bucket_medium(const u32* __restrict__ list, const u32* __restrict__ list_n,
+                                                           const u64* __restrict__ raw_start,
+                                                           const u8* __restrict__ res_kind, u64* __restrict__ lo,
+                                                           HiT* __restrict__ hi, u32 SB, u32* __restrict__ out_count,
+                                                           u8* __restrict__ out_kind) {
+    constexpr int ITEMS = MED_ITEMS, NW = THREADS / 64, CAP = THREADS * ITEMS;
+    __shared__ u64 s_klo[CAP];
+    __shared__ u64 s_khi[WS ? CAP : 1];
+    __shared__ u16 s_idx[CAP];
+    __shared__ u32 s_wcnt[NW * 256];
+    __shared__ u32 s_dbase[256];
+    __shared__ u32 s_scan[NW + 1];
+    __shared__ u32 s_bm[CAP / 32];
+    __shared__ u32 s_wtot[NW + 1];
+
+    if (blockIdx.x >= *list_n) return;
+    const u32 r = list[blockIdx.x];
+    const u64 s0 = raw_start[r];
+    const u32 c = (u32)(raw_start[r + 1] - s0);
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const u32 R = (c + THREADS - 1) / THREADS;  // rounds actually needed (<= ITEMS)
+    const u32 EPW = 64 * R;                     // elements per wave slice
+
+    Sfx<WS> key[ITEMS];
+    u32 idx[ITEMS], digit[ITEMS], pos[ITEMS];
+    bool valid[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 e = w * EPW + j * 64 + lane;
+        valid[j] = (u32)j < R && e < c;
+        idx[j] = e;
+        key[j].lo = 0;
+        if constexpr (WS) key[j].hi = 0;
+        if (valid[j]) key[j] = load_sfx<WS, HiT>(lo, hi, s0 + e, SB);
+    }
+    const u32 npass = (SB + 7) / 8;
+    for (u32 pass = 0; pass < npass; ++pass) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) digit[j] = valid[j] ? key[j].digit(pass) : 255u;
+        tile_rank<THREADS, ITEMS>(digit, valid, pos, s_wcnt, s_dbase, s_scan, c);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (valid[j]) {
+                s_klo[pos[j]] = key[j].lo;
+                if constexpr (WS) s_khi[pos[j]] = key[j].hi;
+                s_idx[pos[j]] = (u16)idx[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 e = w * EPW + j * 64 + lane;
+            if (valid[j]) {
+                key[j].lo = s_klo[e];
+                if constexpr (WS) key[j].hi = s_khi[e];
+                idx[j] = s_idx[e];
+            }
+        }
+        __syncthreads();
+    }
+    // heads of equal-suffix runs; equal suffixes are in stream order (stable), so a head is a first occurrence
+    bool head[ITEMS];
+    u32 wave_heads = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 e = w * EPW + j * 64 + lane;
+        head[j] = false;
+        if (valid[j]) {
+            if (e == 0) head[j] = true;
+            else {
+                Sfx<WS> prev;
+                prev.lo = s_klo[e - 1];
+                if constexpr (WS) prev.hi = s_khi[e - 1];
+                head[j] = prev != key[j];
+            }
+        }
+        wave_heads += (u32)__builtin_popcountll(__ballot(head[j]));
+    }
+    if (lane == 0) s_wtot[w] = wave_heads;
+    for (u32 i = tid; i < CAP / 32; i += THREADS) s_bm[i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (int ww = 0; ww < NW; ++ww) { u32 t = s_wtot[ww]; s_wtot[ww] = run; run += t; }
+        s_wtot[NW] = run;
+    }
+    __syncthreads();
+    const u32 d = s_wtot[NW];
+    const bool trie = d > VEC_THRESHOLD || res_kind[r] == KIND_TRIE;
+    if (trie) {
+        u32 run = s_wtot[w];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u64 bal = __ballot(head[j]);
+            if (head[j]) store_sfx<WS, HiT>(lo, hi, s0 + run + mbcnt(bal), key[j]);
+            run += (u32)__builtin_popcountll(bal);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (head[j]) atomicOr(&s_bm[idx[j] >> 5], 1u << (idx[j] & 31));
+        __syncthreads();
+        // original (stream) order compaction: re-read the untouched run
+        Sfx<WS> orig[ITEMS];
+        bool keep[ITEMS];
+        u32 wk = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 e = w * EPW + j * 64 + lane;
+            keep[j] = valid[j] && ((s_bm[e >> 5] >> (e & 31)) & 1u);
+            if (valid[j]) orig[j] = load_sfx<WS, HiT>(lo, hi, s0 + e, SB);
+            wk += (u32)__builtin_popcountll(__ballot(keep[j]));
+        }
+        if (lane == 0) s_wtot[w] = wk;
+        __syncthreads();  // every read of the run is done before any in-place write
+        u32 run = 0;
+        for (u32 ww = 0; ww < w; ++ww) run += s_wtot[ww];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u64 bal = __ballot(keep[j]);
+            if (keep[j]) store_sfx<WS, HiT>(lo, hi, s0 + run + mbcnt(bal), orig[j]);
+            run += (u32)__builtin_popcountll(bal);
+        }
+    }
+    if (tid == 0) {
+        out_count[r] = d;
+        out_kind[r] = trie ? KIND_TRIE : KIND_VEC;
+    }
+}
+
+// ---- KRN-3 huge: one workgroup per bucket, any run length; the same stable LSD radix passes, tile by tile in
+// global scratch (a/b ping-pong of key + stream index). Pathological buckets (poly-A ...) only. -------------------
+template <bool WS, typename HiT>
+__global__ __launch_bounds__(256) void k_bucket_huge(const u32* __restrict__ list, const u32* __restrict__ list_n,
+                                                     const u64* __restrict__ raw_start, const u64* __restrict__ scratch_off,
+                                                     const u8* __restrict__ res_kind, u64* __restrict__ lo,
+                                                     HiT* __restrict__ hi, u32 SB, u64* __restrict__ a_lo,
+                                                     u64* __restrict__ a_hi, u32* __restrict__ a_idx, u64* __restrict__ b_lo,
+                                                     u64* __restrict__ b_hi, u32* __restrict__ b_idx,
+                                                     u32* __restrict__ out_count, u8* __restrict__ out_kind) {
+    constexpr int THREADS = 256, ITEMS = 8, TILE = THREADS * ITEMS;
+    __shared__ u32 s_wcnt[(THREADS / 64) * 256];
+    __shared__ u32 s_dbase[256];
+    __shared__ u32 s_scan[THREADS / 64 + 1];
+    __shared__ u32 s_hist[256];
+    __shared__ u32 s_run[256];
+    __shared__ u32 s_cnt;
+    if (blockIdx.x >= *list_n) return;
+    const u32 r = list[blockIdx.x];
+    const u64 s0 = raw_start[r];
+    const u32 c = (u32)(raw_start[r + 1] - s0);
+    const u64 so = scratch_off[blockIdx.x];
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    u64 *src_lo = a_lo + so, *dst_lo = b_lo + so, *src_hi = WS ? a_hi + so : nullptr, *dst_hi = WS ? b_hi + so : nullptr;
+    u32 *src_idx = a_idx + so, *dst_idx = b_idx + so;
+    // stage the run into scratch A with its stream index
+    for (u32 e = tid; e < c; e += THREADS) {
+        Sfx<WS> s = load_sfx<WS, HiT>(lo, hi, s0 + e, SB);
+        src_lo[e] = s.lo;
+        if constexpr (WS) src_hi[e] = s.hi;
+        src_idx[e] = e;
+    }
+    __syncthreads();
+    const u32 npass = (SB + 7) / 8;
+    const u32 ntile = (c + TILE - 1) / TILE;
+    for (u32 pass = 0; pass < npass; ++pass) {
+        // digit histogram of the whole run
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        for (u32 e = tid; e < c; e += THREADS) {
+            Sfx<WS> s;
+            s.lo = src_lo[e];
+            if constexpr (WS) s.hi = src_hi[e];
+            atomicAdd(&s_hist[s.digit(pass)], 1u);
+        }
+        __syncthreads();
+        u32 hv = tid < 256 ? s_hist[tid] : 0;
+        u32 ex = block_exclusive_scan<THREADS, u32>(hv, s_scan, nullptr);
+        if (tid < 256) s_run[tid] = ex;  // running global start of each digit
+        __syncthreads();
+        for (u32 t = 0; t < ntile; ++t) {
+            Sfx<WS> key[ITEMS];
+            u32 idx[ITEMS], digit[ITEMS], pos[ITEMS];
+            bool valid[ITEMS];
+            const u32 tb = t * TILE;
+            const u32 n_tile = c - tb < (u32)TILE ? c - tb : (u32)TILE;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const u32 e = w * (64 * ITEMS) + j * 64 + lane;
+                valid[j] = e < n_tile;
+                digit[j] = 255;
+                idx[j] = 0;
+                key[j].lo = 0;
+                if constexpr (WS) key[j].hi = 0;
+                if (valid[j]) {
+                    key[j].lo = src_lo[tb + e];
+                    if constexpr (WS) key[j].hi = src_hi[tb + e];
+                    idx[j] = src_idx[tb + e];
+                    digit[j] = key[j].digit(pass);
+                }
+            }
+            tile_rank<THREADS, ITEMS>(digit, valid, pos, s_wcnt, s_dbase, s_scan, n_tile);
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                if (valid[j]) {
+                    const u32 dst = s_run[digit[j]] + (pos[j] - s_dbase[digit[j]]);
+                    dst_lo[dst] = key[j].lo;
+                    if constexpr (WS) dst_hi[dst] = key[j].hi;
+                    dst_idx[dst] = idx[j];
+                }
+            }
+            __syncthreads();
+            // advance the running starts by this tile's digit counts (= next digit base - this digit base)
+            if (tid < 256) {
+                u32 nxt = tid == 255 ? n_tile : s_dbase[tid + 1];
+                s_run[tid] += nxt - s_dbase[tid];
+            }
+            __syncthreads();
+        }
+        u64* tl = src_lo; src_lo = dst_lo; dst_lo = tl;
+        u64* th = src_hi; src_hi = dst_hi; dst_hi = th;
+        u32* ti = src_idx; src_idx = dst_idx; dst_idx = ti;
+        __threadfence_block();
+        __syncthreads();
+    }
+    // src_* now sorted by suffix, stable. Count heads.
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    u32 mine = 0;
+    for (u32 e = tid; e < c; e += THREADS) {
+        bool h = e == 0 || src_lo[e] != src_lo[e - 1];
+        if constexpr (WS) h = h || (e > 0 && src_hi[e] != src_hi[e - 1]);
+        mine += h ? 1u : 0u;
+    }
+    mine = wave_reduce_sum(mine);
+    if (lane == 0) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    const u32 d = s_cnt;
+    const bool trie = d > VEC_THRESHOLD || res_kind[r] == KIND_TRIE;
+    // ordered compaction, chunk of THREADS elements at a time
+    u32 base = 0;
+    if (trie) {
+        for (u32 e0 = 0; e0 < c; e0 += THREADS) {
+            const u32 e = e0 + tid;
+            bool h = false;
+            if (e < c) {
+                h = e == 0 || src_lo[e] != src_lo[e - 1];
+                if constexpr (WS) h = h || (e > 0 && src_hi[e] != src_hi[e - 1]);
+            }
+            u32 tot;
+            u32 ex = block_exclusive_scan<THREADS, u32>(h ? 1u : 0u, s_scan, &tot);
+            if (h) {
+                Sfx<WS> s;
+                s.lo = src_lo[e];
+                if constexpr (WS) s.hi = src_hi[e];
+                store_sfx<WS, HiT>(lo, hi, s0 + base + ex, s);
+            }
+            base += tot;
+        }
+    } else {
+        // mark first occurrences by stream index in dst_idx (reused as a flag array), then compact the original run
+        for (u32 e = tid; e < c; e += THREADS) dst_idx[e] = 0;
+        __syncthreads();
+        for (u32 e = tid; e < c; e += THREADS) {
+            bool h = e == 0 || src_lo[e] != src_lo[e - 1];
+            if constexpr (WS) h = h || (e > 0 && src_hi[e] != src_hi[e - 1]);
+            if (h) dst_idx[src_idx[e]] = 1;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // the original run must be read before it is overwritten: d <= 1024 outputs, stage them in dst_lo/dst_hi
+        for (u32 e0 = 0; e0 < c; e0 += THREADS) {
+            const u32 e = e0 + tid;
+            const bool k = e < c && dst_idx[e] != 0;
+            u32 tot;
+            u32 ex = block_exclusive_scan<THREADS, u32>(k ? 1u : 0u, s_scan, &tot);
+            if (k) {
+                Sfx<WS> s = load_sfx<WS, HiT>(lo, hi, s0 + e, SB);
+                dst_lo[base + ex] = s.lo;
+                if constexpr (WS) dst_hi[base + ex] = s.hi;
+            }
+            base += tot;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (u32 e = tid; e < d; e += THREADS) {
+            Sfx<WS> s;
+            s.lo = dst_lo[e];
+            if constexpr (WS) s.hi = dst_hi[e];
+            store_sfx<WS, HiT>(lo, hi, s0 + e, s);
+        }
+    }
+    if (tid == 0) {
+        out_count[r] = d;
+        out_kind[r] = trie ? KIND_TRIE : KIND_VEC;
+    }
+}
+
+// ---- resident index -> records (prefix || suffix words, bucket order) for a rebuild that includes new words ----
+template <bool WS, typename HiT>
+__global__ void k_expand_resident(u64 nelem, u64 nb, const u64* __restrict__ res_off /* nb+1 */, const u32* __restrict__ bucket_prefix,
+                                  const u64* __restrict__ start, const u64* __restrict__ a_lo, const u64* __restrict__ a_hi,
+                                  u32 SB, u64* __restrict__ out_lo, HiT* __restrict__ out_hi) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nelem) return;
+    u64 l = 0, h = nb;  // last r with res_off[r] <= e
+    while (h - l > 1) {
+        u64 mid = (l + h) >> 1;
+        if (res_off[mid] <= e) l = mid; else h = mid;
+    }
+    const u64 r = l, j = e - res_off[r];
+    // arena slots of buckets a rebuild did not touch still carry the full word: always mask to SB bits
+    u128 sfx = (u128)a_lo[start[r] + j];
+    if constexpr (WS) sfx |= (u128)a_hi[start[r] + j] << 64;
+    sfx &= (((u128)1) << SB) - 1;
+    u128 word = ((u128)bucket_prefix[r] << SB) | sfx;
+    out_lo[e] = (u64)word;
+    st_hi<HiT>(out_hi, e, (u64)(word >> 64));
+}
+
+// dense gather of the resident suffixes (for export / serialization): out[res_off[r] + j] = arena[start[r] + j]
+__global__ void k_gather_dense(u64 nelem, u64 nb, const u64* __restrict__ res_off, const u64* __restrict__ start,
+                               const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u32 SB, u64* __restrict__ out_lo,
+                               u64* __restrict__ out_hi) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nelem) return;
+    u64 l = 0, h = nb;
+    while (h - l > 1) {
+        u64 mid = (l + h) >> 1;
+        if (res_off[mid] <= e) l = mid; else h = mid;
+    }
+    const u64 j = e - res_off[l];
+    const u64 mlo = SB >= 64 ? ~0ull : ((1ull << SB) - 1ull);
+    out_lo[e] = a_lo[start[l] + j] & mlo;
+    if (out_hi) out_hi[e] = a_hi[start[l] + j] & ((1ull << (SB - 64)) - 1ull);
+}
+
+// membership of words in a resident index: WordSet::contains_batch (/root/reference/src/wordset/mod.rs:163-185)
+template <typename HiT>
+__global__ void k_contains(const u64* __restrict__ w_lo, const HiT* __restrict__ w_hi, u64 n, u32 SB, u32 PB, DirView dir,
+                           const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u8* __restrict__ out) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 lo = w_lo[i], hi = ld_hi<HiT>(w_hi, i);
+    const u32 p = get_bits(lo, hi, SB, PB);
+    u64 r;
+    u8 found = 0;
+    if (dir_lookup(dir, p, r)) {
+        const u128 M = (((u128)1) << SB) - 1;
+        const u128 key = (((u128)hi << 64) | lo) & M;
+        const u64 s0 = dir.start[r];
+        const u32 c = dir.count[r];
+        auto at = [&](u32 j) -> u128 {
+            u128 v = a_lo[s0 + j];
+            if (a_hi) v |= (u128)a_hi[s0 + j] << 64;
+            return v & M;
+        };
+        if (dir.kind[r] == KIND_TRIE) {
+            u32 l = 0, h = c;
+            while (l < h) {
+                u32 mid = (l + h) >> 1;
+                u128 v = at(mid);
+                if (v < key) l = mid + 1; else h = mid;
+            }
+            found = l < c && at(l) == key;
+        } else {
+            for (u32 j = 0; j < c && !found; ++j) found = at(j) == key;
+        }
+    }
+    out[i] = found;
+}
+
+__global__ void k_sum_u32(const u32* __restrict__ v, u64 n, u64* __restrict__ out) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 s = i < n ? v[i] : 0;
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd((unsigned long long*)out, (unsigned long long)s);
+}
+__global__ void k_fill_u32(u32* p, u64 n, u32 v) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_set_u64(u64* p, u64 v) { *p = v; }
+__global__ void k_narrow_u8(const u64* __restrict__ in, u8* __restrict__ out, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (u8)in[i];
+}
+__global__ void k_widen_u8(const u8* __restrict__ in, u64* __restrict__ out, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+}  // namespace cblx

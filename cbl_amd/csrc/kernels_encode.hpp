@@ -1,0 +1,340 @@
+// kernels_encode.hpp — KRN-1: chunk table, validity scan, rolling 2-bit pack + necklace word per k-mer.
+//
+// Replaces (reference, CPU): CBL::get_seq_chunks / get_seq_words (/root/reference/src/cbl.rs:239-289),
+// Base::from_nuc (/root/reference/src/kmer.rs:11-24,209-211), Kmer::from_nucs/append (:61-72,133-135),
+// NecklaceQueue (/root/reference/src/necklace/queue.rs) through the normative necklace_pos
+// (/root/reference/src/necklace/mod.rs:13-25), merge_necklace_pos (/root/reference/src/cbl.rs:181-184).
+//
+// Unit of work = a CHUNK (the reference re-seeds its queue per chunk of 2048 k-mers and, in canonical mode,
+// emits a chunk's forward-strand words before its reverse-strand words, src/cbl.rs:248-275).
+// A workgroup owns a TILE = all chunks whose first byte lies in a 4 KiB window of the base stream: bytes are
+// read once with 16-byte coalesced loads, packed to 2 bits/base in LDS, and every lane then builds its k-mer
+// from 3 (or 5) LDS dwords. Chunks holding a non-ACGT byte ("dirty", rare) are left to a scalar kernel that
+// follows the reference's skip semantics exactly.
+#pragma once
+#include "common.hpp"
+#include "necklace.hpp"
+
+namespace cblx {
+
+struct NoHi {};
+template <typename HiT> struct HiTraits { static constexpr bool has = true; };
+template <> struct HiTraits<NoHi> { static constexpr bool has = false; };
+template <typename HiT> __device__ __forceinline__ u64 ld_hi(const HiT* p, u64 i) {
+    if constexpr (HiTraits<HiT>::has) return (u64)p[i];
+    else return 0;
+}
+template <typename HiT> __device__ __forceinline__ void st_hi(HiT* p, u64 i, u64 v) {
+    if constexpr (HiTraits<HiT>::has) p[i] = (HiT)v;
+}
+
+static const u32 ENC_TILE_BYTES = 4096;
+static const u32 ENC_THREADS = 256;
+static const u32 ENC_MAX_CHUNKS = 1024;                                    // >= 4096 / min chunk length (K >= 5)
+static const u32 ENC_MAX_BASES = ENC_TILE_BYTES + CHUNK_KMERS + 64 + 32;   // bytes a tile can span (+ align slack)
+static const u32 ENC_CODE_WORDS = (ENC_MAX_BASES + 15) / 16 + 8;           // packed dwords (+ read-ahead slack)
+static const u32 ENC_MAX_KMERS = ENC_MAX_BASES;                            // k-mers per tile <= bytes spanned
+
+// ---- per-sequence chunk counts; flags sequences shorter than K (src/cbl.rs:329-334) ------------------
+__global__ void k_seq_chunk_count(const u64* __restrict__ offsets, u64 nseq, u32 K, u32* __restrict__ nchunks,
+                                  u64* __restrict__ err /* [0]=count of short seqs, [1]=first bad len+1 */) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseq) return;
+    u64 len = offsets[i + 1] - offsets[i];
+    if (len < K) {
+        atomicAdd((unsigned long long*)&err[0], 1ull);
+        atomicMax((unsigned long long*)&err[1], (unsigned long long)(len + 1));
+        nchunks[i] = 0;
+        return;
+    }
+    u64 nk = len - K + 1;
+    nchunks[i] = (u32)((nk + CHUNK_KMERS - 1) / CHUNK_KMERS);
+}
+
+// one thread per chunk: binary search the owning sequence in the chunk-base scan
+__global__ void k_chunk_fill(const u64* __restrict__ offsets, const u64* __restrict__ chunk_base /* nseq+1 */,
+                             u64 nseq, u64 nchunks, u32 K, u64* __restrict__ chunk_start,
+                             u32* __restrict__ chunk_len, u32* __restrict__ chunk_nk) {
+    u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    u64 lo = 0, hi = nseq;  // last seq with chunk_base[seq] <= c
+    while (hi - lo > 1) {
+        u64 mid = (lo + hi) >> 1;
+        if (chunk_base[mid] <= c) lo = mid; else hi = mid;
+    }
+    u64 seq = lo;
+    u64 j = c - chunk_base[seq];
+    u64 s0 = offsets[seq], len = offsets[seq + 1] - s0;
+    u64 start = j * CHUNK_KMERS;
+    u64 end = start + CHUNK_KMERS + K - 1;
+    if (end > len) end = len;
+    chunk_start[c] = s0 + start;
+    chunk_len[c] = (u32)(end - start);
+    chunk_nk[c] = (u32)(end - start - K + 1);
+}
+
+// ---- validity scan: marks chunks that contain a byte outside ACGTacgt -----------------------------------
+__device__ __forceinline__ u32 valid_mask4(u32 w) {  // 0x80 in every byte lane that holds a valid nucleotide
+    u32 u = w & 0xDFDFDFDFu, m = 0;
+    const u32 L[4] = {0x41414141u, 0x43434343u, 0x47474747u, 0x54545454u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32 v = u ^ L[i];
+        m |= ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
+    }
+    return m;
+}
+__device__ inline void mark_dirty(u64 b, const u64* chunk_start, const u32* chunk_len, u64 nchunks, u8* dirty, u32* ndirty) {
+    u64 lo = 0, hi = nchunks;  // last chunk with start <= b
+    while (hi - lo > 1) {
+        u64 mid = (lo + hi) >> 1;
+        if (chunk_start[mid] <= b) lo = mid; else hi = mid;
+    }
+    for (int k = 0; k < 2; ++k) {  // a byte lies in at most 2 chunks (K-1 overlap inside a long sequence)
+        if (lo < (u64)k) break;
+        u64 c = lo - k;
+        if (chunk_start[c] <= b && b < chunk_start[c] + chunk_len[c]) {
+            dirty[c] = 1;  // benign race: every writer stores 1
+            atomicAdd(ndirty, 1u);
+        }
+    }
+}
+__global__ void k_scan_invalid(const u8* __restrict__ bases, u64 total, const u64* __restrict__ chunk_start,
+                               const u32* __restrict__ chunk_len, u64 nchunks, u8* __restrict__ dirty,
+                               u32* __restrict__ ndirty) {
+    u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 b0 = g * 16;
+    if (b0 >= total) return;
+    if (b0 + 16 <= total) {
+        uint4 v = *reinterpret_cast<const uint4*>(bases + b0);
+        u32 m = valid_mask4(v.x) & valid_mask4(v.y) & valid_mask4(v.z) & valid_mask4(v.w);
+        if (m == 0x80808080u) return;
+    }
+    for (u64 b = b0; b < b0 + 16 && b < total; ++b)
+        if (!nuc_valid(bases[b])) mark_dirty(b, chunk_start, chunk_len, nchunks, dirty, ndirty);
+}
+// exact k-mer count of dirty chunks: 1 + #valid bytes in chunk[K..] (src/cbl.rs:277-287 filter_map)
+__global__ void k_dirty_count(const u8* __restrict__ bases, const u64* __restrict__ chunk_start,
+                              const u32* __restrict__ chunk_len, const u8* __restrict__ dirty, u64 nchunks, u32 K,
+                              u32* __restrict__ chunk_nk) {
+    u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks || !dirty[c]) return;
+    const u8* s = bases + chunk_start[c];
+    u32 len = chunk_len[c], m = 0;
+    for (u32 i = K; i < len; ++i) m += nuc_valid(s[i]) ? 1u : 0u;
+    chunk_nk[c] = 1 + m;
+}
+
+// first chunk of every 4 KiB tile of the base stream (lower_bound over chunk_start)
+__global__ void k_tile_first_chunk(const u64* __restrict__ chunk_start, u64 nchunks, u64 ntiles, u32* __restrict__ tile_first) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > ntiles) return;
+    u64 key = t * ENC_TILE_BYTES;
+    u64 lo = 0, hi = nchunks;  // first c with chunk_start[c] >= key
+    while (lo < hi) {
+        u64 mid = (lo + hi) >> 1;
+        if (chunk_start[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    tile_first[t] = (u32)lo;
+}
+
+// ---- word of one k-mer ---------------------------------------------------------------------------------
+template <bool WIDE> struct KmerT;
+template <> struct KmerT<false> { typedef u64 type; };
+template <> struct KmerT<true> { typedef u128 type; };
+
+template <bool WIDE>
+__device__ __forceinline__ void kmer_word(typename KmerT<WIDE>::type x, const Consts& P, bool take_rc, u64& lo, u64& hi) {
+    typedef typename KmerT<WIDE>::type T;
+    if (take_rc) {
+        if constexpr (WIDE) x = rev_comp128(x, P.K); else x = rev_comp64(x, P.K);
+    }
+    T nk;
+    unsigned pos;
+    necklace_pos_fast<T>(x, P.KB, nk, pos);
+    u128 word = ((u128)nk << P.POS) | (u128)pos;
+    lo = (u64)word;
+    hi = (u64)(word >> 64);
+}
+template <bool WIDE> __device__ __forceinline__ bool kmer_is_fwd(typename KmerT<WIDE>::type x) {  // Kmer::is_canonical, src/kmer.rs:94-96
+    if constexpr (WIDE) return (popcount128(x) & 1u) == 0; else return (__builtin_popcountll(x) & 1) == 0;
+}
+
+// k-mer starting at base index s of the big-endian packed stream `codes` (16 bases per dword, first base on top)
+template <bool WIDE> __device__ __forceinline__ typename KmerT<WIDE>::type extract_kmer(const u32* codes, u32 s, u32 K) {
+    const u32 w = s >> 4, o = (s & 15u) * 2u;
+    if constexpr (!WIDE) {
+        u64 a = ((u64)codes[w] << 32) | codes[w + 1];
+        u64 v = (a << o) | (o ? ((u64)codes[w + 2] >> (32 - o)) : 0ull);
+        return v >> (64 - 2 * K);
+    } else {
+        u128 a = ((u128)codes[w] << 96) | ((u128)codes[w + 1] << 64) | ((u128)codes[w + 2] << 32) | (u128)codes[w + 3];
+        u128 v = (a << o) | (o ? ((u128)codes[w + 4] >> (32 - o)) : (u128)0);
+        return v >> (128 - 2 * K);
+    }
+}
+
+__device__ __forceinline__ u32 pack16(uint4 v) {  // 16 ASCII bases -> 16 2-bit codes, first base in bits 31:30
+    u32 out = 0;
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32 c = (w[i] >> 1) & 0x03030303u;
+        u32 r = ((c & 3u) << 6) | (((c >> 8) & 3u) << 4) | (((c >> 16) & 3u) << 2) | ((c >> 24) & 3u);
+        out |= r << (24 - 8 * i);
+    }
+    return out;
+}
+
+// ---- main encode kernel: one workgroup per 4 KiB tile of the base stream --------------------------------
+template <bool WIDE, typename HiT>
+__global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ bases, u64 total_bases,
+                                                        const u64* __restrict__ chunk_start,
+                                                        const u32* __restrict__ chunk_len,
+                                                        const u64* __restrict__ kmer_off /* nchunks+1 */,
+                                                        const u8* __restrict__ dirty /* may be null */,
+                                                        const u32* __restrict__ tile_first, Consts P,
+                                                        u64* __restrict__ out_lo, HiT* __restrict__ out_hi, u64 out_base) {
+    typedef typename KmerT<WIDE>::type T;
+    __shared__ u32 s_codes[ENC_CODE_WORDS];
+    __shared__ u32 s_koff[ENC_MAX_CHUNKS + 1];
+    __shared__ u32 s_cstart[ENC_MAX_CHUNKS];
+    __shared__ u8 s_dirty[ENC_MAX_CHUNKS];
+    __shared__ u64 s_par[(ENC_MAX_KMERS + ENC_THREADS) / 64 + 2];
+    __shared__ u32 s_parpre[(ENC_MAX_KMERS + ENC_THREADS) / 64 + 2];
+
+    const u32 tid = threadIdx.x;
+    const u32 c0 = tile_first[blockIdx.x], c1 = tile_first[blockIdx.x + 1];
+    if (c0 >= c1) return;
+    const u32 nc = c1 - c0;  // <= ENC_MAX_CHUNKS by construction (chunk length >= K >= 5)
+    const u64 B0 = chunk_start[c0];
+    const u64 B1 = chunk_start[c1 - 1] + chunk_len[c1 - 1];
+    const u64 A0 = B0 & ~(u64)15;
+    const u64 kbase = kmer_off[c0];
+
+    for (u32 i = tid; i <= nc; i += ENC_THREADS) s_koff[i] = (u32)(kmer_off[c0 + i] - kbase);
+    for (u32 i = tid; i < nc; i += ENC_THREADS) {
+        s_cstart[i] = (u32)(chunk_start[c0 + i] - A0);
+        s_dirty[i] = dirty ? dirty[c0 + i] : (u8)0;
+    }
+    const u32 nwords = (u32)((B1 - A0 + 15) >> 4);
+    for (u32 i = tid; i < nwords + 6 && i < ENC_CODE_WORDS; i += ENC_THREADS) {
+        u64 b = A0 + (u64)i * 16;
+        u32 packed = 0;
+        if (i < nwords) {
+            if (b + 16 <= total_bases) {
+                packed = pack16(*reinterpret_cast<const uint4*>(bases + b));
+            } else {
+                for (u32 k = 0; k < 16 && b + k < total_bases; ++k) packed |= nuc_code(bases[b + k]) << (30 - 2 * k);
+            }
+        }
+        s_codes[i] = packed;
+    }
+    __syncthreads();
+    const u32 Q = s_koff[nc];
+
+    auto find_chunk = [&](u32 q) -> u32 {  // last i with s_koff[i] <= q
+        u32 lo = 0, hi = nc;
+        while (hi - lo > 1) {
+            u32 mid = (lo + hi) >> 1;
+            if (s_koff[mid] <= q) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+
+    if (P.canonical) {
+        // strand flags of every k-mer of the tile: bit = 1 -> forward strand (even popcount)
+        const u32 qpad = (Q + ENC_THREADS - 1) / ENC_THREADS * ENC_THREADS;
+        for (u32 q = tid; q < qpad; q += ENC_THREADS) {
+            bool fwd = false;
+            if (q < Q) {
+                u32 ci = find_chunk(q);
+                if (!s_dirty[ci]) fwd = kmer_is_fwd<WIDE>(extract_kmer<WIDE>(s_codes, s_cstart[ci] + (q - s_koff[ci]), P.K));
+            }
+            u64 bal = __ballot(fwd);
+            if ((tid & 63) == 0) s_par[q >> 6] = bal;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            u32 run = 0;
+            const u32 nw = qpad >> 6;
+            for (u32 i = 0; i < nw; ++i) { s_parpre[i] = run; run += (u32)__builtin_popcountll(s_par[i]); }
+            s_parpre[nw] = run;
+            s_par[nw] = 0;
+        }
+        __syncthreads();
+    }
+    auto cum_fwd = [&](u32 q) -> u32 {
+        return s_parpre[q >> 6] + (u32)__builtin_popcountll(s_par[q >> 6] & ((1ull << (q & 63)) - 1ull));
+    };
+
+    for (u32 q = tid; q < Q; q += ENC_THREADS) {
+        const u32 ci = find_chunk(q);
+        if (s_dirty[ci]) continue;
+        const u32 j = q - s_koff[ci];
+        T x = extract_kmer<WIDE>(s_codes, s_cstart[ci] + j, P.K);
+        u64 dst = out_base + kbase + q;
+        bool rc = false;
+        if (P.canonical) {
+            const u32 cb = cum_fwd(s_koff[ci]);
+            const u32 nfwd = cum_fwd(s_koff[ci + 1]) - cb;
+            const u32 rf = cum_fwd(q) - cb;
+            rc = !kmer_is_fwd<WIDE>(x);
+            dst = out_base + kbase + s_koff[ci] + (rc ? (nfwd + (j - rf)) : rf);
+        }
+        u64 lo, hi;
+        kmer_word<WIDE>(x, P, rc, lo, hi);
+        out_lo[dst] = lo;
+        st_hi<HiT>(out_hi, dst, hi);
+    }
+}
+
+// ---- dirty chunks: one thread per chunk, the reference's skip semantics verbatim ------------------------
+// words = K-windows of  zeros(K - n0) ++ valid(chunk[0..K]) ++ valid(chunk[K..])   (src/kmer.rs:133-135: the first
+// k-mer is folded from the valid bases among the first K BYTES; src/cbl.rs:283 filter_map on the rest).
+template <bool WIDE, typename HiT>
+__global__ void k_encode_dirty(const u8* __restrict__ bases, const u64* __restrict__ chunk_start,
+                               const u32* __restrict__ chunk_len, const u64* __restrict__ kmer_off,
+                               const u8* __restrict__ dirty, u64 nchunks, Consts P, u64* __restrict__ out_lo,
+                               HiT* __restrict__ out_hi, u64 out_base) {
+    typedef typename KmerT<WIDE>::type T;
+    u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks || !dirty[c]) return;
+    const u8* s = bases + chunk_start[c];
+    const u32 len = chunk_len[c];
+    const T MASK = (((T)1) << P.KB) - 1;
+    const u64 o0 = out_base + kmer_off[c];
+    const u32 nk = (u32)(kmer_off[c + 1] - kmer_off[c]);
+    u32 nfwd = 0;
+    if (P.canonical) {  // pass 1: count forward-strand k-mers
+        T x = 0;
+        for (u32 i = 0; i < P.K; ++i) if (nuc_valid(s[i])) x = (x << 2) | (T)nuc_code(s[i]);
+        nfwd += kmer_is_fwd<WIDE>(x) ? 1u : 0u;
+        for (u32 i = P.K; i < len; ++i) {
+            if (!nuc_valid(s[i])) continue;
+            x = ((x << 2) | (T)nuc_code(s[i])) & MASK;
+            nfwd += kmer_is_fwd<WIDE>(x) ? 1u : 0u;
+        }
+    }
+    u32 kf = 0, kr = 0, j = 0;
+    T x = 0;
+    auto emit = [&]() {
+        bool rc = P.canonical && !kmer_is_fwd<WIDE>(x);
+        u64 dst = P.canonical ? (rc ? o0 + nfwd + kr++ : o0 + kf++) : o0 + j;
+        ++j;
+        u64 lo, hi;
+        kmer_word<WIDE>(x & MASK, P, rc, lo, hi);
+        out_lo[dst] = lo;
+        st_hi<HiT>(out_hi, dst, hi);
+    };
+    for (u32 i = 0; i < P.K; ++i) if (nuc_valid(s[i])) x = (x << 2) | (T)nuc_code(s[i]);
+    emit();
+    for (u32 i = P.K; i < len; ++i) {
+        if (!nuc_valid(s[i])) continue;
+        x = ((x << 2) | (T)nuc_code(s[i])) & MASK;
+        emit();
+    }
+    (void)nk;
+}
+
+}  // namespace cblx

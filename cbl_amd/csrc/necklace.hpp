@@ -1,0 +1,111 @@
+// necklace.hpp — k-mer -> (necklace, pos) word transform, usable from device and host code.
+//
+// Definition (normative, /root/reference/src/necklace/mod.rs:13-25): necklace = min over p in [0, BITS) of
+// rotl_BITS(x, p), pos = the SMALLEST p attaining it; word = necklace << POS_BITS | pos
+// (/root/reference/src/cbl.rs:181-184). The reference's streaming NecklaceQueue
+// (src/necklace/queue.rs) returns the same pair; a GPU lane per k-mer has no use for the queue.
+//
+// Method (ours): the minimal rotation must start at the top of a LONGEST cyclic run of zero bits. Runs are
+// found with r <- r & rotl(r, 1) (r starts as ~x): after L-1 steps bit s of r says "bits s, s-1, .., s-L+1 of x
+// are all zero". The last non-zero r marks the tops of the longest runs; only those candidates (usually 1-2)
+// are compared, highest s (= smallest p) first with a strict '<' so ties keep the smallest p.
+// ~100-200 integer ops per k-mer instead of BITS full-width rotate+compare steps.
+#pragma once
+#include <cstdint>
+
+#if !defined(__HIPCC__) && !defined(__host__)
+#define __host__
+#define __device__
+#endif
+
+namespace cblx {
+
+typedef unsigned __int128 nk_u128;
+
+template <typename T> struct NkBits;
+template <> struct NkBits<uint64_t> {
+    static __host__ __device__ inline int clz(uint64_t v) { return __builtin_clzll(v); }
+};
+template <> struct NkBits<nk_u128> {
+    static __host__ __device__ inline int clz(nk_u128 v) {
+        uint64_t hi = (uint64_t)(v >> 64);
+        return hi ? __builtin_clzll(hi) : 64 + __builtin_clzll((uint64_t)v);
+    }
+};
+
+// x must already be masked to BITS bits. T = uint64_t (BITS <= 64... we only use BITS <= 62) or nk_u128.
+template <typename T> __host__ __device__ inline void necklace_pos_fast(T x, unsigned BITS, T& necklace, unsigned& pos) {
+    const T MASK = (BITS >= sizeof(T) * 8) ? ~(T)0 : ((((T)1) << BITS) - 1);
+    if (x == 0 || x == MASK) {  // single-symbol words: every rotation equal, smallest p = 0
+        necklace = x;
+        pos = 0;
+        return;
+    }
+    T r = ~x & MASK;
+    for (;;) {
+        T t = r & (((r << 1) & MASK) | (r >> (BITS - 1)));
+        if (t == 0) break;
+        r = t;
+    }
+    constexpr int TB = (int)sizeof(T) * 8;
+    T best = MASK;
+    unsigned bestp = 0;
+    bool first = true;
+    while (r != 0) {
+        int s = TB - 1 - NkBits<T>::clz(r);  // highest remaining candidate
+        r &= ~(((T)1) << s);
+        unsigned p = BITS - 1 - (unsigned)s;
+        T rot = p == 0 ? x : (((x << p) & MASK) | (x >> (BITS - p)));
+        if (first || rot < best) {
+            best = rot;
+            bestp = p;
+            first = false;
+        }
+    }
+    necklace = best;
+    pos = bestp;
+}
+
+// The definition, verbatim in spirit (used by tests and as a debug variant).
+template <typename T> __host__ __device__ inline void necklace_pos_naive(T x, unsigned BITS, T& necklace, unsigned& pos) {
+    T nk = x, rot = x;
+    unsigned p = 0;
+    for (int i = (int)BITS - 1; i >= 0; --i) {
+        rot = ((rot & 1) << (BITS - 1)) | (rot >> 1);
+        if (rot <= nk) { nk = rot; p = (unsigned)i; }
+    }
+    necklace = nk;
+    pos = p;
+}
+
+// Reverse complement of a K-base packed k-mer (/root/reference/src/kmer.rs:293-348; code A=0 C=1 T=2 G=3, so
+// complement = XOR 0b10): reverse the 2-bit groups, complement each, drop the 2*(W/2-K) pad bits.
+__host__ __device__ inline uint64_t rev_comp64(uint64_t x, unsigned K) {
+    uint64_t r = x;
+    r = ((r >> 2) & 0x3333333333333333ull) | ((r & 0x3333333333333333ull) << 2);
+    r = ((r >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((r & 0x0F0F0F0F0F0F0F0Full) << 4);
+    r = __builtin_bswap64(r);
+    r ^= 0xAAAAAAAAAAAAAAAAull;
+    return r >> (2 * (32 - K));
+}
+__host__ __device__ inline nk_u128 rev_comp128(nk_u128 x, unsigned K) {
+    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    // reverse all 64 groups of the 128-bit value: swap halves, reverse groups inside each
+    uint64_t rlo = rev_comp64(hi, 32), rhi = rev_comp64(lo, 32);
+    nk_u128 r = ((nk_u128)rhi << 64) | rlo;
+    return r >> (2 * (64 - K));
+}
+
+__host__ __device__ inline unsigned popcount128(nk_u128 x) {
+    return (unsigned)__builtin_popcountll((uint64_t)x) + (unsigned)__builtin_popcountll((uint64_t)(x >> 64));
+}
+
+// nucleotide code (/root/reference/src/kmer.rs:11-24): A/a=0 C/c=1 T/t=2 G/g=3, anything else invalid (skipped).
+// For the 8 valid bytes the code is (b >> 1) & 3.
+__host__ __device__ inline bool nuc_valid(uint8_t b) {
+    uint8_t u = b & 0xDF;  // upper-case
+    return u == 'A' || u == 'C' || u == 'G' || u == 'T';
+}
+__host__ __device__ inline unsigned nuc_code(uint8_t b) { return (b >> 1) & 3u; }
+
+}  // namespace cblx

@@ -1,0 +1,129 @@
+/* cblx.h — C ABI of the MI355X-native bulk k-mer insertion path for CBL indexes.
+ *
+ * One `cblx_ctx` stands for one `CBL<K, T, PREFIX_BITS>` value of the reference
+ * (/root/reference/src/cbl.rs:40-54). The reference has no plugin registry; its only FFI is
+ * autocxx -> C++ for RankBV / TieredVec32 (/root/reference/src/ffi.rs:7-20). This header is the
+ * `extern "C"` layer a Rust `CBL<K,T,PREFIX_BITS>` facade binds instead:
+ * const generics become the runtime fields of `cblx_params`; `panic!` becomes a non-zero status +
+ * `cblx_last_error` (the shim re-panics with the same message).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a CBLX_E* code otherwise; nothing throws across the ABI;
+ *   - plain pointers + sizes only; input pointers are borrowed for the duration of the call;
+ *   - `*_device` entry points take DEVICE pointers valid on the ctx's GPU, all others HOST pointers;
+ *   - a ctx is single-owner / not re-entrant (the reference API is `&mut self` throughout);
+ *   - `cblx_insert_seq*` may only enqueue; every observer flushes first.
+ *   - the HIP library is the only implementation: there is no CPU fallback behind this ABI.
+ */
+#ifndef CBLX_H
+#define CBLX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBLX_ABI_VERSION 1
+
+enum {
+    CBLX_OK = 0,
+    CBLX_EINVAL = 1,   /* bad parameter (K, PREFIX_BITS, null pointer, params mismatch) */
+    CBLX_ESHORT = 2,   /* "Sequence size (n) is smaller than K (k)"   src/cbl.rs:329-334 */
+    CBLX_EFORMAT = 3,  /* index bytes do not parse / trailing bytes    src/cbl.rs:146-158 */
+    CBLX_EDEVICE = 4,  /* HIP runtime error or no usable GPU */
+    CBLX_ENOMEM = 5,
+    CBLX_ERANGE = 6    /* output buffer too small */
+};
+
+typedef struct cblx_ctx cblx_ctx;
+
+typedef struct cblx_params {
+    uint32_t k;           /* const K: odd, 5..59 (build.rs:18-24; 2K + POS_BITS <= 128, src/cbl.rs:87-91) */
+    uint32_t prefix_bits; /* const PREFIX_BITS: 1..32 and < 2K + POS_BITS (src/wordset/mod.rs:37-41); default 24 */
+    uint32_t canonical;   /* CBL::new() = 0, CBL::new_canonical() = 1 (src/cbl.rs:71-79) */
+    int32_t device;       /* HIP device ordinal; -1 = current device */
+    uint32_t flags;       /* CBLX_FLAG_* */
+    uint32_t reserved;
+} cblx_params;
+
+#define CBLX_FLAG_PROFILE 1u /* record per-stage HIP-event timings of each flush (cblx_stage_times) */
+
+uint32_t cblx_abi_version(void);
+/* Error text of the last failed call on this thread that had no ctx (cblx_create). */
+const char* cblx_last_global_error(void);
+
+/* CBL::new / new_canonical (src/cbl.rs:71-79, asserts :87-91 and src/wordset/mod.rs:37-41). */
+int cblx_create(const cblx_params* params, cblx_ctx** out);
+/* Drop (frees device memory owned by the ctx). */
+void cblx_destroy(cblx_ctx* ctx);
+const char* cblx_last_error(const cblx_ctx* ctx);
+
+/* CBL::insert_seq (src/cbl.rs:328-339): enqueue ONE sequence of ASCII nucleotides (copied). */
+int cblx_insert_seq(cblx_ctx* ctx, const uint8_t* seq, uint64_t len);
+/* The caller loop `for record in reader { cbl.insert_seq(record.seq()) }` (examples/cbl.rs:160-163,242-245)
+ * in one call: sequence i is bases[offsets[i] .. offsets[i+1]), i < n. Stream order = i ascending. */
+int cblx_insert_seqs(cblx_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n);
+/* Same, inputs already resident in HBM (device pointers). Runs the insert before returning. */
+int cblx_insert_seqs_device(cblx_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n);
+/* Materialise everything enqueued so far into the resident index (idempotent). */
+int cblx_flush(cblx_ctx* ctx);
+
+/* WordSet::insert_batch (src/wordset/mod.rs:187-216) on already transformed words, stream order = index
+ * order. Word i = (d_hi[i] << 64) | d_lo[i]; d_hi may be NULL when 2K + POS_BITS <= 64. Device pointers. */
+int cblx_insert_words_device(cblx_ctx* ctx, const uint64_t* d_lo, const uint64_t* d_hi, uint64_t n);
+/* CBL::get_seq_words over every chunk of every sequence (src/cbl.rs:239-289), no insertion: writes the
+ * words in stream order to d_lo/d_hi (device, capacity `cap` words) and their number to *n_words. */
+int cblx_seq_words_device(cblx_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n,
+                          uint64_t* d_lo, uint64_t* d_hi, uint64_t cap, uint64_t* n_words);
+
+/* CBL::count / is_empty / is_canonical (src/cbl.rs:164-177). */
+int cblx_count(cblx_ctx* ctx, uint64_t* out);
+int cblx_num_buckets(cblx_ctx* ctx, uint64_t* out); /* tiered.len() = number of non-empty prefixes */
+int cblx_is_empty(cblx_ctx* ctx, int* out);
+int cblx_is_canonical(const cblx_ctx* ctx, int* out);
+
+/* Serialize (derive on CBL src/cbl.rs:40-54 + WordSet::serialize src/wordset/mod.rs:382-396) with
+ * bincode DefaultOptions + varint (src/cbl.rs:132-135): the exact bytes of CBL::save_to_file. */
+int cblx_serialized_size(cblx_ctx* ctx, uint64_t* nbytes);
+int cblx_serialize(cblx_ctx* ctx, uint8_t* buf, uint64_t cap, uint64_t* written);
+int cblx_save_to_file(cblx_ctx* ctx, const char* path);
+/* Deserialize (src/wordset/mod.rs:398-437; reject_trailing_bytes): replaces the ctx's contents.
+ * K / PREFIX_BITS are not stored in the file (compile-time on both sides in the reference). */
+int cblx_load(cblx_ctx* ctx, const uint8_t* data, uint64_t len);
+int cblx_load_from_file(cblx_ctx* ctx, const char* path);
+
+/* `self |= other` (src/cbl.rs:433-449 -> src/wordset/set_ops.rs:123-157). */
+int cblx_merge_assign(cblx_ctx* self, cblx_ctx* other);
+
+/* Walk the resident buckets in ascending prefix order (lets a Rust shim rebuild a WordSet, and tests
+ * compare bucket contents): kind 0 = Vec (stored = first-occurrence order), 1 = Trie (ascending).
+ * Suffix i of the bucket is (hi[i] << 64) | lo[i]; hi is NULL when SUFFIX_BITS <= 64. Return non-zero
+ * from the callback to stop. */
+typedef int (*cblx_bucket_cb)(void* user, uint32_t prefix, int kind, uint64_t len, const uint64_t* lo,
+                              const uint64_t* hi);
+int cblx_export_buckets(cblx_ctx* ctx, cblx_bucket_cb cb, void* user);
+
+/* CBL::contains_seq (src/cbl.rs:311-324): one byte (0/1) per k-mer of one sequence, into `out[cap]`. */
+int cblx_contains_seq(cblx_ctx* ctx, const uint8_t* seq, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* n);
+
+/* Derived constants (src/cbl.rs:16-32,65-67), for shims and tests. */
+typedef struct cblx_consts {
+    uint32_t kmer_bits, pos_bits, word_bits, suffix_bits, bytes, chunk_size, threshold, reserved;
+} cblx_consts;
+int cblx_get_consts(const cblx_ctx* ctx, cblx_consts* out);
+
+/* Per-stage device time (ms, HIP events on the ctx's stream) accumulated since the last reset; needs
+ * CBLX_FLAG_PROFILE. names[i] points to static storage. Returns the number of stages in *n (<= cap). */
+int cblx_stage_times(cblx_ctx* ctx, const char** names, double* ms, uint64_t* launches, uint32_t cap, uint32_t* n);
+int cblx_stage_times_reset(cblx_ctx* ctx);
+/* k-mers (words) consumed by insert calls since creation — the numerator of the throughput metric. */
+int cblx_kmers_inserted(cblx_ctx* ctx, uint64_t* out);
+/* Release cached device workspace (kept between flushes to avoid hipMalloc in the hot path). */
+int cblx_trim(cblx_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CBLX_H */

@@ -1,0 +1,265 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (include/cblx.h via cbl_amd.CBL), against the
+CPU oracle on the same seeded inputs. Bit-exact: words, bucket contents and order, serialized index bytes.
+
+Mirrors the reference's own test shapes (/root/reference/src/cbl.rs:664-683 batch == single, :726-761 canonical,
+src/wordset/mod.rs:451-533) plus the edge cases of SURVEY.md §7 (non-ACGT bytes, multi-chunk sequences, short
+sequences, duplicates, Vec->Trie threshold, huge buckets, incremental inserts, load/insert, merge).
+"""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import cbl_amd  # noqa: E402
+from cbl_amd import synth  # noqa: E402
+from oracle import Oracle  # noqa: E402
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+
+
+def _rand_seq(rng, n, alphabet=b"ACGT"):
+    return bytes(rng.choice(alphabet) for _ in range(n))
+
+
+def _concat(seqs):
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+    offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(s) for s in seqs])
+    return bases, offsets
+
+
+def _gpu_words(g, seqs):
+    bases, offsets = _concat(seqs)
+    nmax = int(len(bases))
+    pad = (-len(bases)) % 16 + 16
+    d_b = torch.from_numpy(np.concatenate([bases, np.zeros(pad, np.uint8)])).cuda()
+    d_o = torch.from_numpy(offsets.astype(np.int64)).cuda()
+    d_lo = torch.zeros(nmax + 1, dtype=torch.int64, device="cuda")
+    d_hi = torch.zeros(nmax + 1, dtype=torch.int64, device="cuda")
+    n = g.seq_words_device(d_b, d_o, len(seqs), d_lo, d_hi, nmax)
+    lo = d_lo[:n].cpu().numpy().astype(np.uint64)
+    hi = d_hi[:n].cpu().numpy().astype(np.uint64)
+    return [int(a) | (int(b) << 64) for a, b in zip(lo, hi)]
+
+
+def _oracle_words(o, seqs):
+    out = []
+    for s in seqs:
+        out += o.seq_words(s)
+    return out
+
+
+def _check_index(g, o):
+    assert g.count() == o.count()
+    assert g.num_buckets() == o.n_buckets()
+    gb, ob = g.serialize(), o.serialize()
+    if gb != ob:
+        # locate the first differing bucket for the failure message
+        o2 = cbl_amd.CBL(g.k, g.prefix_bits, canonical=g.is_canonical())
+        o2.load(ob)
+        for (p1, k1, s1), (p2, k2, s2) in zip(g.buckets(), o2.buckets()):
+            assert (p1, k1) == (p2, k2), f"bucket header differs: gpu {(p1, k1, len(s1))} oracle {(p2, k2, len(s2))}"
+            assert s1 == s2, f"bucket {p1:#x} kind {k1}: contents/order differ (len {len(s1)} vs {len(s2)})"
+        assert False, "serialized bytes differ but buckets equal?"
+
+
+# ---- KRN-1: words ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k,pb", [(7, 14), (25, 24), (29, 24), (31, 24), (31, 28), (33, 24), (59, 28)])
+@pytest.mark.parametrize("canonical", [False, True])
+def test_words_match_oracle(k, pb, canonical):
+    _need_gpu()
+    rng = random.Random(k * 7 + canonical)
+    seqs = [_rand_seq(rng, n) for n in (k, k + 1, 150, 150, 151, 400, 2 * k, 3000, 150)]
+    g = cbl_amd.CBL(k, pb, canonical=canonical)
+    o = Oracle(k, pb, canonical)
+    assert _gpu_words(g, seqs) == _oracle_words(o, seqs)
+
+
+@pytest.mark.parametrize("k", [31, 59])
+@pytest.mark.parametrize("canonical", [False, True])
+def test_words_multichunk_non_acgt_and_degenerate(k, canonical):
+    """>2048 k-mers per sequence (chunk re-seeding, src/cbl.rs:239-243), skipped non-ACGT bytes incl. inside the first
+    K bytes of a chunk (src/kmer.rs:133-135), lower case, homopolymers and short-period repeats."""
+    _need_gpu()
+    rng = random.Random(k + 99)
+    s1 = bytearray(_rand_seq(rng, 9000, b"ACGTacgt"))
+    for pos in (3, 40, 41, 2048 + 5, 2048 + 200, 4096 + k - 2, 8999):
+        s1[pos] = ord("N")
+    seqs = [bytes(s1), b"A" * 300, b"G" * 200, b"AC" * 150, b"ACGT" * 100, b"N" * k + _rand_seq(rng, 100),
+            _rand_seq(rng, 100) + b"NNNN", b"acgtn" * 60, _rand_seq(rng, 5000)]
+    g = cbl_amd.CBL(k, 24, canonical=canonical)
+    o = Oracle(k, 24, canonical)
+    assert _gpu_words(g, seqs) == _oracle_words(o, seqs)
+
+
+def test_short_sequence_rejected():
+    _need_gpu()
+    g = cbl_amd.CBL(31, 24)
+    with pytest.raises(cbl_amd.CblxError, match="smaller than K") as e:
+        g.insert_seq(b"ACGT")
+    assert e.value.code == cbl_amd.ESHORT
+    with pytest.raises(cbl_amd.CblxError):
+        cbl_amd.CBL(30, 24)  # K must be odd (build.rs:18-24)
+
+
+# ---- whole path: bucket contents, order, serialized bytes -------------------------------------------------
+@pytest.mark.parametrize(
+    "k,pb,nreads,L,canonical",
+    [
+        (25, 24, 2000, 150, False),   # BASELINE cfg 1 shape, scaled
+        (31, 24, 2000, 150, False),   # cfg 2 shape
+        (31, 24, 1500, 150, True),
+        (31, 28, 1500, 150, False),   # cfg 3 shape
+        (59, 28, 1000, 250, False),   # cfg 4 shape (wide k-mer, 97-bit suffix)
+        (59, 28, 600, 250, True),
+        (33, 24, 1000, 150, False),   # wide k-mer, narrow suffix
+        (7, 14, 300, 60, False),
+    ],
+)
+def test_index_matches_oracle(k, pb, nreads, L, canonical):
+    _need_gpu()
+    bases, offsets = synth.reads(42, nreads, L)
+    g = cbl_amd.CBL(k, pb, canonical=canonical)
+    o = Oracle(k, pb, canonical)
+    g.insert_seqs(bases, offsets)
+    o.insert_seqs(bases, offsets)
+    _check_index(g, o)
+
+
+@pytest.mark.parametrize(
+    "k,pb,n,canonical",
+    [(9, 4, 40000, False), (9, 4, 40000, True), (11, 8, 60000, False), (11, 10, 200000, False), (13, 12, 300000, False),
+     (35, 6, 60000, False)],
+)
+def test_threshold_and_big_buckets(k, pb, n, canonical):
+    """Small PREFIX_BITS force every bucket class: Vec (<= 1024 distinct, first-occurrence order with duplicates),
+    Trie (> 1024), runs of > 8192 words (huge path), and for K=35/PB=6 the 128-bit suffix huge path."""
+    _need_gpu()
+    rng = random.Random(n + k)
+    seqs = []
+    for _ in range(3):
+        s = _rand_seq(rng, n // 3)
+        seqs += [s, s[: len(s) // 2]]  # repeats -> duplicates
+    g = cbl_amd.CBL(k, pb, canonical=canonical)
+    o = Oracle(k, pb, canonical)
+    for s in seqs:
+        g.insert_seq(s)
+        o.insert_seq(s)
+    _check_index(g, o)
+    kinds = {kind for _, kind, _ in g.buckets()}
+    assert 1 in kinds
+
+
+def test_duplicate_heavy_reads_keep_first_occurrence_order():
+    """30x coverage of a small genome: every k-mer arrives many times; Vec buckets must keep stream order."""
+    _need_gpu()
+    rng = random.Random(5)
+    genome = _rand_seq(rng, 20000)
+    reads = []
+    for _ in range(4000):
+        p = rng.randrange(0, len(genome) - 150)
+        reads.append(genome[p : p + 150])
+    bases, offsets = _concat(reads)
+    for k, pb in ((31, 24), (21, 12)):
+        g, o = cbl_amd.CBL(k, pb), Oracle(k, pb)
+        g.insert_seqs(bases, offsets)
+        o.insert_seqs(bases, offsets)
+        _check_index(g, o)
+
+
+def test_incremental_flushes_equal_one_shot():
+    """Batch boundaries must not change the result (SURVEY.md §7 hard part 6)."""
+    _need_gpu()
+    for k, pb, n in ((31, 24, 3000), (9, 4, 30000), (11, 8, 50000)):
+        rng = random.Random(k)
+        seqs = [_rand_seq(rng, 150) for _ in range(n // 150)]
+        seqs += seqs[: len(seqs) // 4]
+        one, inc, o = cbl_amd.CBL(k, pb), cbl_amd.CBL(k, pb), Oracle(k, pb)
+        for s in seqs:
+            one.insert_seq(s)
+            o.insert_seq(s)
+        for i, s in enumerate(seqs):
+            inc.insert_seq(s)
+            if i % 37 == 0:
+                inc.flush()
+        assert inc.serialize() == one.serialize() == o.serialize()
+
+
+def test_load_then_insert_is_cbl_insert():
+    """`cbl insert` (examples/cbl.rs:230-249): read_index, insert_seq per record, write_index."""
+    _need_gpu()
+    rng = random.Random(8)
+    for k, pb in ((31, 24), (9, 4)):
+        s1, s2 = _rand_seq(rng, 30000), _rand_seq(rng, 30000)
+        o = Oracle(k, pb)
+        o.insert_seq(s1)
+        blob = o.serialize()
+        g = cbl_amd.CBL(k, pb)
+        g.load(blob)
+        assert g.serialize() == blob and g.count() == o.count()
+        g.insert_seq(s2)
+        o.insert_seq(s2)
+        _check_index(g, o)
+
+
+def test_merge_matches_oracle():
+    """`cbl merge` (examples/cbl.rs:270-279): self |= other, incl. the Vec-may-exceed-1024 quirk."""
+    _need_gpu()
+    rng = random.Random(21)
+    for k, pb, n in ((31, 24, 20000), (9, 4, 9000), (9, 4, 40000), (11, 8, 60000)):
+        s1, s2 = _rand_seq(rng, n), _rand_seq(rng, n // 2) + _rand_seq(rng, 64)
+        g1, g2, o1, o2 = cbl_amd.CBL(k, pb), cbl_amd.CBL(k, pb), Oracle(k, pb), Oracle(k, pb)
+        g1.insert_seq(s1), o1.insert_seq(s1)
+        g2.insert_seq(s2), o2.insert_seq(s2)
+        g1 |= g2
+        o1.merge(o2)
+        _check_index(g1, o1)
+        # an oversized Vec left by |= turns into a Trie only when a later insert touches it (src/wordset/mod.rs:213-214)
+        s3 = _rand_seq(rng, 3000)
+        g1.insert_seq(s3)
+        o1.insert_seq(s3)
+        _check_index(g1, o1)
+
+
+def test_contains_seq():
+    _need_gpu()
+    rng = random.Random(3)
+    for k, pb in ((31, 24), (59, 28), (9, 4)):
+        s1, s2 = _rand_seq(rng, 20000), _rand_seq(rng, 500)
+        g = cbl_amd.CBL(k, pb)
+        g.insert_seq(s1)
+        assert all(g.contains_seq(s1[100:1000]))
+        o = Oracle(k, pb)
+        o.insert_seq(s1)
+        mask = (1 << (2 * k)) - 1
+        x, want = 0, []
+        for i, ch in enumerate(s2):
+            x = ((x << 2) | b"ACTG".index(ch)) & mask
+            if i >= k - 1:
+                want.append(o.contains_kmer(x))
+        assert g.contains_seq(s2) == want
+
+
+def test_insert_words_device_is_insert_batch():
+    """WordSet::insert_batch on already transformed words == insert_seq on the sequence they came from."""
+    _need_gpu()
+    rng = random.Random(17)
+    for k, pb in ((31, 24), (25, 24), (59, 28)):
+        seqs = [_rand_seq(rng, 150) for _ in range(300)]
+        o = Oracle(k, pb)
+        words = []
+        for s in seqs:
+            o.insert_seq(s)
+            words += o.seq_words(s)
+        lo = torch.from_numpy(np.array([w & (2**64 - 1) for w in words], dtype=np.uint64).astype(np.int64)).cuda()
+        hi = torch.from_numpy(np.array([w >> 64 for w in words], dtype=np.uint64).astype(np.int64)).cuda()
+        g = cbl_amd.CBL(k, pb)
+        g.insert_words_device(lo, hi, len(words))
+        _check_index(g, o)
