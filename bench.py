@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — k-mers inserted/sec (build index), K=31 150 bp synthetic reads (BASELINE.json), on N MI355X.
+
+A "step" = one pass of the hot path (insert_seq -> necklace transform -> prefix partition -> bucket insert) over one
+batch of synthetic reads already resident in HBM: BASELINE.json configs[1] (K=31, 68-bit word, PREFIX_BITS=24,
+10M x 150 bp per GPU). N > 1: one process per GPU (torchrun), reads sharded contiguously by rank, prefix space
+sharded by quantile ranges, one RCCL all-to-all of the transformed words (cbl_amd/sharded.py); per-GPU work is fixed
+as N grows ("weak").
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     - the dominant kernel group of the step, algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
+  cpu_baseline - the CPU oracle (a C++ port of the reference algorithm, oracle/) timed on a bounded sample, 1 thread
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# ALGORITHMIC bytes per k-mer of each kernel group: what the kernel's contract must move once.
+#   R = record bytes (8 lo + hi part), BYTES-independent; passes = ceil(PREFIX_BITS / 8).
+def stage_alg_bytes(k: int, pb: int, read_len: int):
+    kb = 2 * k
+    wb = kb + (kb - 1).bit_length()
+    hi = 0 if wb <= 64 else (1 if kb <= 64 else 8)
+    R = 8 + hi
+    passes = (pb + 7) // 8
+    sfx = 8 if wb - pb <= 64 else 16
+    return {
+        "chunks": read_len / (read_len - k + 1),             # validity scan reads every base once
+        "encode": read_len / (read_len - k + 1) + R,           # read bases, write one record
+        "radix_hist": passes * R,                              # read the record's key per pass
+        "radix_scatter": passes * 2 * R,                       # read + write every record per pass
+        "directory": R,                                        # boundary detection reads the sorted records
+        "bucket_medium": 2 * sfx,                              # read the run, write the distinct suffixes
+        "bucket_small": 2 * sfx,
+        "bucket_huge": 2 * sfx,
+    }
+
+
+def survey_b_alg(k: int, pb: int, read_len: int) -> float:
+    """SURVEY.md §8d whole-path figure: L/(L-K+1) + 4R + BYTES with R = 16 (K <= 45) or 24."""
+    kb = 2 * k
+    wb = kb + (kb - 1).bit_length()
+    by = (wb - pb + 7) // 8
+    R = 16 if k <= 45 else 24
+    return read_len / (read_len - k + 1) + 4 * R + by
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--prefix-bits", type=int, default=24)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--canonical", action="store_true")
+    ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torchrun --nproc-per-node {args.gpus}", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible (the product has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+
+    if rank == 0:
+        ge.build()
+    if dist is not None:
+        dist.barrier()
+    import cbl_amd
+    from cbl_amd import sharded, synth
+
+    K, PB, L, NR = args.k, args.prefix_bits, args.read_len, args.reads
+    kmers_per_rank = NR * (L - K + 1)
+    d_bases, d_offsets = synth.reads_torch(42, NR, L, first_read=rank * NR, device=f"cuda:{local_rank}")
+    torch.cuda.synchronize()
+
+    cbl = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank, profile=True)
+    engine = sharded.ShardedBuilder(cbl, dist) if world > 1 else None
+
+    def step():
+        cbl.clear()
+        if engine is None:
+            cbl.insert_seqs_device(d_bases, d_offsets, NR)
+        else:
+            engine.insert_seqs_device(d_bases, d_offsets, NR)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    cbl.stage_times_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    count = cbl.count()
+    if dist is not None:
+        t = torch.tensor([count], dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t)
+        count = int(t.item())
+
+    stages = cbl.stage_times()  # rank 0's stream, HIP events around every launch group, timed steps only
+    total_kmers = kmers_per_rank * world * args.steps
+    value = total_kmers / dt
+
+    # dominant kernel group of the step and its roofline position
+    alg = stage_alg_bytes(K, PB, L)
+    cand = {n: ms for n, (ms, _) in stages.items() if n in alg and ms > 0}
+    dom = max(cand, key=cand.get) if cand else None
+    roofline = None
+    if dom:
+        ms_total, launches = stages[dom]
+        per_step_ms = ms_total / args.steps
+        bytes_per_step = alg[dom] * kmers_per_rank
+        achieved = bytes_per_step / (per_step_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "alg_bytes_per_kmer": round(alg[dom], 3), "ms_per_step": round(per_step_ms, 3),
+            "launches_per_step": launches / args.steps,
+            "whole_path": {  # SURVEY.md §8d accounting over the full step (per GPU)
+                "b_alg_per_kmer": round(survey_b_alg(K, PB, L), 2),
+                "achieved": round(kmers_per_rank * args.steps / dt * survey_b_alg(K, PB, L) / 1e9, 1),
+                "frac": round(kmers_per_rank * args.steps / dt * survey_b_alg(K, PB, L) / 1e9 / HBM_PEAK_GBPS, 4),
+            },
+            "stage_ms_per_step": {n: round(ms / args.steps, 3) for n, (ms, _) in stages.items() if ms > 0},
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import Oracle
+
+        ns = min(args.cpu_sample_reads, NR)
+        b, o = synth.reads(42, ns, L)
+        orc = Oracle(K, PB, args.canonical)
+        secs = orc.insert_seqs(b, o)
+        cpu = {"value": round(ns * (L - K + 1) / secs, 1), "unit": "k-mers/s", "cores": 1, "kind": "port",
+               "sample": f"first {ns} of the same reads (seed 42), one insert_seq call per read, {secs:.1f} s; "
+                         "throughput falls as the index grows, so the full-size CPU figure is lower",
+               "host_cores_available": os.cpu_count()}
+
+    if rank == 0:
+        out = {
+            "metric": "k-mers inserted/sec (build index)", "value": round(value, 1), "unit": "k-mers/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic (iid ACGT reads, splitmix64 seed 42, resident in HBM)",
+            "config": {"workload": f"K={K} (68-bit word) PREFIX_BITS={PB} {NR}x{L}bp reads per GPU, "
+                                   f"{'canonical' if args.canonical else 'non-canonical'}, build from empty index",
+                       "k": K, "prefix_bits": PB, "reads_per_gpu": NR, "read_len": L,
+                       "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: read-sharded encode, prefix-range all-to-all"},
+            "distinct_kmers_in_index": count,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

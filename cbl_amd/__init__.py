@@ -52,6 +52,8 @@ SIGNATURES = {
     "cblx_insert_words_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "cblx_seq_words_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
                                         C.POINTER(C.c_uint64)]),
+    "cblx_partition_words_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
     "cblx_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_num_buckets": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_is_empty": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
@@ -70,6 +72,7 @@ SIGNATURES = {
     "cblx_stage_times_reset": (C.c_int, [C.c_void_p]),
     "cblx_kmers_inserted": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_trim": (C.c_int, [C.c_void_p]),
+    "cblx_clear": (C.c_int, [C.c_void_p]),
 }
 
 
@@ -162,6 +165,16 @@ class CBL:
         nw = C.c_uint64(0)
         self._chk(self._L.cblx_seq_words_device(self._h, _ptr(d_bases), _ptr(d_offsets), n, _ptr(d_lo), _ptr(d_hi), cap, C.byref(nw)))
         return nw.value
+
+    def partition_words_device(self, d_lo, d_hi, n: int, bounds, nd: int, d_out_lo, d_out_hi):
+        """Stable partition of device words by destination prefix range; returns the nd run lengths."""
+        import numpy as np
+
+        b = np.ascontiguousarray(bounds, dtype=np.uint32)
+        counts = np.zeros(nd, dtype=np.uint64)
+        self._chk(self._L.cblx_partition_words_device(self._h, _ptr(d_lo), _ptr(d_hi), n, b.ctypes.data if len(b) else None, nd,
+                                                      _ptr(d_out_lo), _ptr(d_out_hi), counts.ctypes.data))
+        return [int(x) for x in counts]
 
     def flush(self):
         self._chk(self._L.cblx_flush(self._h))
@@ -262,3 +275,7 @@ class CBL:
 
     def trim(self):
         self._chk(self._L.cblx_trim(self._h))
+
+    def clear(self):
+        """Back to `CBL::new()`: empty set, cached device workspace kept."""
+        self._chk(self._L.cblx_clear(self._h))

@@ -210,11 +210,11 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
         for (u32 pass = 0; pass < npass; ++pass) {
             const u32 shift = P.SB + 8 * pass, nbits = std::min(8u, P.PB - 8 * pass);
             { StageTimer t(c, ST_HIST);
-              hipLaunchKernelGGL(k_radix_hist<HiT>, dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, shift, nbits, ntiles, counts.get()); }
+              hipLaunchKernelGGL((k_radix_hist<HiT, DigitBits>), dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits}, ntiles, counts.get()); }
             { StageTimer t(c, ST_SCAN);
               exclusive_scan<u32>(c, counts.get(), (u64)256 * ntiles, offsets.get()); }
             { StageTimer t(c, ST_SCATTER);
-              hipLaunchKernelGGL(k_radix_scatter<HiT>, dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, shift, nbits, ntiles, offsets.get(), lo2, hi2); }
+              hipLaunchKernelGGL((k_radix_scatter<HiT, DigitBits>), dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits}, ntiles, offsets.get(), lo2, hi2); }
             std::swap(lo, lo2);
             std::swap(hi, hi2);
         }
@@ -824,6 +824,43 @@ int cblx_seq_words_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t* d
     });
 }
 
+// Stable partition of words by destination prefix range (multi-GPU exchange step).
+int cblx_partition_words_device(cblx_ctx* c, const uint64_t* d_lo, const uint64_t* d_hi, uint64_t n, const uint32_t* bounds, uint32_t nd,
+                                uint64_t* d_out_lo, uint64_t* d_out_hi, uint64_t* counts) {
+    return guard(c, [&] {
+        if (nd < 1 || nd > MAX_DEST) throw Error(CBLX_EINVAL, "number of destinations must be in [1, 16]");
+        if (!counts || (nd > 1 && !bounds)) throw Error(CBLX_EINVAL, "null argument");
+        for (u32 d = 0; d < nd; ++d) counts[d] = 0;
+        if (n == 0) return;
+        if (!d_lo || !d_out_lo || (c->P.has_hi() && (!d_hi || !d_out_hi))) throw Error(CBLX_EINVAL, "null argument");
+        if (n >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "too many words in one partition call");
+        DigitDest fn;
+        fn.SB = c->P.SB; fn.PB = c->P.PB; fn.nd = nd;
+        for (u32 i = 0; i < MAX_DEST - 1; ++i) fn.bounds[i] = i + 1 < nd ? bounds[i] : 0xFFFFFFFFu;
+        for (u32 i = 1; i + 1 < nd; ++i) if (bounds[i] < bounds[i - 1]) throw Error(CBLX_EINVAL, "bounds must be ascending");
+        const u32 ntiles = (u32)ceil_div(n, RDX_TILE);
+        Buf<u32> cnt(c->pool, (size_t)256 * ntiles), off(c->pool, (size_t)256 * ntiles);
+        auto run = [&](auto hi_tag) {
+            typedef decltype(hi_tag) H;
+            const H* hi = (const H*)d_hi;
+            H* ohi = (H*)d_out_hi;
+            { StageTimer t(c, ST_HIST);
+              hipLaunchKernelGGL((k_radix_hist<H, DigitDest>), dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, d_lo, hi, n, fn, ntiles, cnt.get()); }
+            { StageTimer t(c, ST_SCAN);
+              exclusive_scan<u32>(c, cnt.get(), (u64)256 * ntiles, off.get()); }
+            { StageTimer t(c, ST_SCATTER);
+              hipLaunchKernelGGL((k_radix_scatter<H, DigitDest>), dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, d_lo, hi, n, fn, ntiles, off.get(), d_out_lo, ohi); }
+            CBLX_HIP(hipGetLastError());
+        };
+        if (c->P.has_hi()) run((u64)0); else run(NoHi());
+        // start of every destination = offset of its first tile
+        std::vector<u64> starts(nd + 1, n);
+        for (u32 d = 0; d < nd; ++d) starts[d] = d2h<u32>(c, off.get() + (size_t)d * ntiles);
+        for (u32 d = 0; d < nd; ++d) counts[d] = starts[d + 1] - starts[d];
+        collect_events(c);
+    });
+}
+
 int cblx_count(cblx_ctx* c, uint64_t* out) { return guard(c, [&] { flush(c); *out = c->res.count; }); }
 int cblx_num_buckets(cblx_ctx* c, uint64_t* out) { return guard(c, [&] { flush(c); *out = c->res.nb; }); }
 int cblx_is_empty(cblx_ctx* c, int* out) { return guard(c, [&] { flush(c); *out = c->res.nb == 0; }); }
@@ -968,5 +1005,13 @@ int cblx_stage_times_reset(cblx_ctx* c) {
 }
 int cblx_kmers_inserted(cblx_ctx* c, uint64_t* out) { if (!c || !out) return CBLX_EINVAL; *out = c->kmers_inserted; return CBLX_OK; }
 int cblx_trim(cblx_ctx* c) { return guard(c, [&] { c->pool.trim(); }); }
+int cblx_clear(cblx_ctx* c) {
+    return guard(c, [&] {
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+        c->res = Resident();
+        c->pend_bases.clear();
+        c->pend_offsets.assign(1, 0);
+    });
+}
 
 }  // extern "C"

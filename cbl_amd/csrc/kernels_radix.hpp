@@ -144,10 +144,29 @@ static const int RDX_THREADS = 256;
 static const int RDX_ITEMS = 16;
 static const int RDX_TILE = RDX_THREADS * RDX_ITEMS;  // 4096 records per workgroup
 
+// digit of a record: a bit field of the word (LSD passes) ...
+struct DigitBits {
+    u32 shift, nbits;
+    __device__ __forceinline__ u32 operator()(u64 lo, u64 hi) const { return get_bits(lo, hi, shift, nbits); }
+};
+// ... or the destination rank of its prefix under quantile range sharding: dest = #{i : bounds[i] <= prefix}
+static const u32 MAX_DEST = 16;
+struct DigitDest {
+    u32 SB, PB, nd;
+    u32 bounds[MAX_DEST - 1];
+    __device__ __forceinline__ u32 operator()(u64 lo, u64 hi) const {
+        const u32 p = get_bits(lo, hi, SB, PB);
+        u32 d = 0;
+#pragma unroll
+        for (u32 i = 0; i < MAX_DEST - 1; ++i) d += (i + 1 < nd && bounds[i] <= p) ? 1u : 0u;
+        return d;
+    }
+};
+
 // per-tile digit histogram -> counts[digit * ntiles + tile]
-template <typename HiT>
+template <typename HiT, typename DigitFn>
 __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const u64* __restrict__ lo, const HiT* __restrict__ hi, u64 n,
-                                                            u32 shift, u32 nbits, u32 ntiles, u32* __restrict__ counts) {
+                                                            DigitFn dfn, u32 ntiles, u32* __restrict__ counts) {
     __shared__ u32 s_wcnt[(RDX_THREADS / 64) * 256];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     for (u32 i = tid; i < (RDX_THREADS / 64) * 256; i += RDX_THREADS) s_wcnt[i] = 0;
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const u64* __restric
         const u64 i = tbase + (u64)w * (64 * RDX_ITEMS) + (u64)j * 64 + lane;
         const bool v = i < n;
         u32 d = 0;
-        if (v) d = get_bits(lo[i], ld_hi<HiT>(hi, i), shift, nbits);
+        if (v) d = dfn(lo[i], ld_hi<HiT>(hi, i));
         u64 m = __ballot(v);
         const u64 vm = m;
 #pragma unroll
@@ -182,9 +201,9 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const u64* __restric
 }
 
 // scatter: offsets[digit * ntiles + tile] = global position of the tile's first element with that digit
-template <typename HiT>
+template <typename HiT, typename DigitFn>
 __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __restrict__ lo, const HiT* __restrict__ hi, u64 n,
-                                                               u32 shift, u32 nbits, u32 ntiles,
+                                                               DigitFn dfn, u32 ntiles,
                                                                const u32* __restrict__ offsets, u64* __restrict__ out_lo,
                                                                HiT* __restrict__ out_hi) {
     __shared__ u64 s_lo[RDX_TILE];
@@ -209,7 +228,7 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
         if (valid[j]) {
             klo[j] = lo[tbase + e];
             khi[j] = ld_hi<HiT>(hi, tbase + e);
-            digit[j] = get_bits(klo[j], khi[j], shift, nbits);
+            digit[j] = dfn(klo[j], khi[j]);
         }
     }
     tile_rank<RDX_THREADS, RDX_ITEMS>(digit, valid, pos, s_wcnt, s_dbase, s_scan, n_tile);
@@ -229,7 +248,7 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
             const u64 a = s_lo[s];
             u64 b = 0;
             if constexpr (HiTraits<HiT>::has) b = (u64)s_hi[s];
-            const u32 d = get_bits(a, b, shift, nbits);
+            const u32 d = dfn(a, b);
             const u64 dst = s_gbase[d] + s;
             out_lo[dst] = a;
             st_hi<HiT>(out_hi, dst, b);

@@ -1,0 +1,165 @@
+"""Multi-GPU build: prefix-range sharding of one CBL index over the ranks of a torch.distributed group.
+
+The reference is single-process (no distributed layer); this is the path BASELINE.json's north_star
+adds: buckets are independent by prefix, so the 2^PREFIX_BITS space is cut into `world` contiguous ranges, one per
+GPU, and the transformed words cross xGMI once:
+
+    rank r: its contiguous shard of the reads  --KRN-1-->  words (stream order)
+            --stable partition by destination range (cblx_partition_words_device)-->
+            --all_to_all_single (RCCL)-->  words of MY prefix range, ordered by source rank
+            --KRN-2..4 (cblx_insert_words_device)-->  resident sub-index of my range
+
+Global stream order is "rank 0's reads, then rank 1's, ..." and all_to_all_single delivers by source rank, so the
+first-occurrence order inside Vec buckets (/root/reference/src/trievec/mod.rs:81-87) is that of the one-process
+build. Ranges are balanced by quantiles of a sampled prefix histogram because necklace prefixes are heavily skewed
+toward small values: equal-width ranges would put nearly all work on rank 0.
+
+The serialized index of the whole job = header (canonical byte, total bucket count) + the per-rank bucket entries
+concatenated in rank order (`gather_serialized`).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+HIST_BITS = 16      # resolution of the splitter histogram (top bits of the prefix)
+SAMPLE_STRIDE = 61  # every 61st word feeds the histogram
+
+
+def choose_bounds(hist: np.ndarray, world: int, prefix_bits: int, hist_bits: int) -> np.ndarray:
+    """world-1 ascending prefix values cutting the histogram mass into `world` near-equal parts."""
+    cum = np.cumsum(hist.astype(np.float64))
+    total = cum[-1] if len(cum) else 0.0
+    shift = prefix_bits - hist_bits
+    bounds = []
+    for d in range(1, world):
+        cell = int(np.searchsorted(cum, total * d / world, side="left")) + 1 if total > 0 else d * len(hist) // world
+        cell = min(max(cell, 1), len(hist))
+        bounds.append(min(cell << shift, (1 << prefix_bits) - 1) if shift >= 0 else cell >> -shift)
+    for i in range(1, len(bounds)):
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return np.asarray(bounds, dtype=np.uint32)
+
+
+class GpuEngine:
+    """The three device steps of the sharded build, on libcblx (torch tensors only carry the device memory)."""
+
+    def __init__(self, cbl):
+        import torch
+
+        self.cbl = cbl
+        self.torch = torch
+        c = cbl.consts()
+        self.sb, self.pb, self.has_hi = c["suffix_bits"], cbl.prefix_bits, c["word_bits"] > 64
+        self.device = None
+
+    def seq_words(self, d_bases, d_offsets, n):
+        torch = self.torch
+        self.device = d_bases.device
+        cap = int(d_bases.numel())
+        lo = torch.empty(cap + 1, dtype=torch.int64, device=self.device)
+        hi = torch.empty(cap + 1, dtype=torch.int64, device=self.device) if self.has_hi else None
+        nw = self.cbl.seq_words_device(d_bases, d_offsets, n, lo, hi, cap)
+        return lo[:nw], (hi[:nw] if hi is not None else None)
+
+    def sample_hist(self, lo, hi):
+        """Histogram of the top HIST_BITS prefix bits over a strided sample (int64 tensor on the device)."""
+        torch = self.torch
+        hb = min(HIST_BITS, self.pb)
+        shift = self.sb + self.pb - hb  # bit position of the histogram key inside the word
+        slo = lo[::SAMPLE_STRIDE]
+        if shift >= 64:
+            key = (hi[::SAMPLE_STRIDE] >> (shift - 64)) & ((1 << hb) - 1)
+        else:
+            key = (slo >> shift) & ((1 << (64 - shift)) - 1)
+            if hi is not None and shift + hb > 64:
+                key = key | (hi[::SAMPLE_STRIDE] << (64 - shift))
+            key = key & ((1 << hb) - 1)
+        return torch.bincount(key, minlength=1 << hb)
+
+    def partition(self, lo, hi, bounds, nd):
+        torch = self.torch
+        n = int(lo.numel())
+        out_lo = torch.empty(n + 1, dtype=torch.int64, device=lo.device)
+        out_hi = torch.empty(n + 1, dtype=torch.int64, device=lo.device) if hi is not None else None
+        counts = self.cbl.partition_words_device(lo, hi, n, bounds, nd, out_lo, out_hi)
+        return out_lo[:n], (out_hi[:n] if out_hi is not None else None), counts
+
+    def insert_words(self, lo, hi):
+        self.cbl.insert_words_device(lo, hi, int(lo.numel()))
+
+    def empty_like(self, t, n):
+        return self.torch.empty(n, dtype=t.dtype, device=t.device)
+
+
+class ShardedBuilder:
+    """`insert_seqs_device` over a process group: every rank passes ITS contiguous shard of the reads."""
+
+    def __init__(self, cbl, dist, engine=None):
+        self.cbl, self.dist = cbl, dist
+        self.engine = engine or GpuEngine(cbl)
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.bounds = None  # fixed by the first batch so later batches land on the same owners
+        self.last_counts = None
+
+    def insert_seqs_device(self, d_bases, d_offsets, n):
+        import torch
+
+        dist, eng, W = self.dist, self.engine, self.world
+        lo, hi = eng.seq_words(d_bases, d_offsets, n)
+        if self.bounds is None:
+            hist = eng.sample_hist(lo, hi)
+            dist.all_reduce(hist)
+            hb = min(HIST_BITS, self.cbl.prefix_bits)
+            self.bounds = choose_bounds(hist.cpu().numpy(), W, self.cbl.prefix_bits, hb)
+        plo, phi, counts = eng.partition(lo, hi, self.bounds, W)
+        del lo, hi
+        send = torch.tensor(counts, dtype=torch.int64, device=plo.device)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send)
+        send_l, recv_l = [int(x) for x in counts], [int(x) for x in recv.cpu().tolist()]
+        self.last_counts = (send_l, recv_l)
+        n_recv = sum(recv_l)
+        rlo = eng.empty_like(plo, n_recv)
+        dist.all_to_all_single(rlo, plo.contiguous(), recv_l, send_l)
+        rhi = None
+        if phi is not None:
+            rhi = eng.empty_like(phi, n_recv)
+            dist.all_to_all_single(rhi, phi.contiguous(), recv_l, send_l)
+        del plo, phi
+        eng.insert_words(rlo, rhi)
+
+    def reset(self):
+        self.bounds = None
+
+
+def _read_varint(b: bytes, pos: int):
+    t = b[pos]
+    if t <= 250:
+        return t, pos + 1
+    nb = {0xFB: 2, 0xFC: 4, 0xFD: 8}[t]
+    return int.from_bytes(b[pos + 1 : pos + 1 + nb], "little"), pos + 1 + nb
+
+
+def _varint(v: int) -> bytes:
+    if v <= 250:
+        return bytes([v])
+    if v < 1 << 16:
+        return b"\xfb" + v.to_bytes(2, "little")
+    if v < 1 << 32:
+        return b"\xfc" + v.to_bytes(4, "little")
+    return b"\xfd" + v.to_bytes(8, "little")
+
+
+def gather_serialized(local_blob: bytes, dist, dst: int = 0):
+    """Index file of the whole job from the per-rank serializations (rank order = ascending prefix ranges).
+
+    File = canonical u8 | varint(n_buckets) | entries (/root/reference/src/wordset/mod.rs:388-394); the per-rank
+    entries are disjoint ascending prefix runs, so the job's file is one header + their concatenation."""
+    nb, pos = _read_varint(local_blob, 1)
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, (local_blob[0], nb, local_blob[pos:]))
+    if dist.get_rank() != dst:
+        return None
+    assert len({p[0] for p in parts}) == 1
+    return bytes([parts[0][0]]) + _varint(sum(p[1] for p in parts)) + b"".join(p[2] for p in parts)

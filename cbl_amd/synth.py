@@ -57,3 +57,40 @@ def fasta_bytes(bases: np.ndarray, offsets: np.ndarray) -> bytes:
         parts.append(bases[int(offsets[i]) : int(offsets[i + 1])].tobytes())
         parts.append(b"\n")
     return b"".join(parts)
+
+
+def reads_torch(seed: int, n_reads: int, read_len: int, first_read: int = 0, device="cuda"):
+    """Same stream as `reads`, generated on `device` with torch integer ops (bench start-up: no 1.5 GB H2D copy).
+
+    Returns (bases uint8[n*L (+16 pad)], offsets int64[n+1]); the pad keeps 16-byte loads in bounds.
+    """
+    import torch
+
+    def lsr(z, s):  # logical shift right on int64
+        return (z >> s) & ((1 << (64 - s)) - 1)
+
+    def s64(v):  # python int -> signed 64-bit
+        v &= (1 << 64) - 1
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    start, count = first_read * read_len, n_reads * read_len
+    j0, j1 = start // 32, (start + count + 31) // 32
+    out = torch.empty((j1 - j0) * 32 + 16, dtype=torch.uint8, device=device)
+    out[-16:] = 0
+    lut = torch.tensor(list(b"ACTG"), dtype=torch.uint8, device=device)
+    shifts = (torch.arange(32, dtype=torch.int64, device=device) * 2)[None, :]
+    step = 1 << 22
+    for a in range(j0, j1, step):
+        b = min(a + step, j1)
+        j = torch.arange(a, b, dtype=torch.int64, device=device)
+        z = (j + 1) * s64(0x9E3779B97F4A7C15) + s64(seed)
+        z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)
+        z = z ^ lsr(z, 31)
+        codes = (z[:, None] >> shifts) & 3
+        out[(a - j0) * 32 : (b - j0) * 32] = lut[codes.reshape(-1)]
+    off = start - j0 * 32
+    if off:
+        out = out[off:].clone()
+    offsets = torch.arange(n_reads + 1, dtype=torch.int64, device=device) * read_len
+    return out[: count + 16], offsets

@@ -78,6 +78,13 @@ int cblx_insert_words_device(cblx_ctx* ctx, const uint64_t* d_lo, const uint64_t
 int cblx_seq_words_device(cblx_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n,
                           uint64_t* d_lo, uint64_t* d_hi, uint64_t cap, uint64_t* n_words);
 
+/* Multi-GPU exchange step (no reference counterpart; the reference is single-process): STABLE partition of n words
+ * by destination = #{i : bounds[i] <= prefix(word)}, nd destinations (<= 16), bounds[nd-1] ascending prefix values
+ * (host). Destination d's words land contiguously, in input order, at d_out[sum(counts[0..d])..]; counts[nd] (host)
+ * receives the run lengths. Device pointers for words; d_hi/d_out_hi may be NULL when 2K + POS_BITS <= 64. */
+int cblx_partition_words_device(cblx_ctx* ctx, const uint64_t* d_lo, const uint64_t* d_hi, uint64_t n, const uint32_t* bounds,
+                                uint32_t nd, uint64_t* d_out_lo, uint64_t* d_out_hi, uint64_t* counts);
+
 /* CBL::count / is_empty / is_canonical (src/cbl.rs:164-177). */
 int cblx_count(cblx_ctx* ctx, uint64_t* out);
 int cblx_num_buckets(cblx_ctx* ctx, uint64_t* out); /* tiered.len() = number of non-empty prefixes */
@@ -122,6 +129,8 @@ int cblx_stage_times_reset(cblx_ctx* ctx);
 int cblx_kmers_inserted(cblx_ctx* ctx, uint64_t* out);
 /* Release cached device workspace (kept between flushes to avoid hipMalloc in the hot path). */
 int cblx_trim(cblx_ctx* ctx);
+/* Back to the state of CBL::new(): drops the resident index and anything enqueued, keeps the cached workspace. */
+int cblx_clear(cblx_ctx* ctx);
 
 #ifdef __cplusplus
 }

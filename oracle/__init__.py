@@ -60,6 +60,7 @@ def lib() -> C.CDLL:
             "oracle_destroy": (None, [vp]),
             "oracle_insert_seq": (i32, [vp, C.c_char_p, u64]),
             "oracle_insert_seqs": (i32, [vp, vp, vp, u64, C.POINTER(C.c_double)]),
+            "oracle_insert_words": (i32, [vp, vp, vp, u64]),
             "oracle_count": (u64, [vp]),
             "oracle_n_buckets": (u64, [vp]),
             "oracle_serialize": (i32, [vp, C.POINTER(pu8), pu64]),
@@ -160,6 +161,14 @@ class Oracle:
         secs = C.c_double(0.0)
         self._chk(self._L.oracle_insert_seqs(self._h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, C.byref(secs)))
         return secs.value
+
+    def insert_words(self, words):
+        """WordSet::insert_batch on already transformed words (list of Python ints)."""
+        import numpy as np
+
+        lo = np.array([w & 0xFFFFFFFFFFFFFFFF for w in words], dtype=np.uint64)
+        hi = np.array([w >> 64 for w in words], dtype=np.uint64)
+        self._chk(self._L.oracle_insert_words(self._h, lo.ctypes.data, hi.ctypes.data, len(words)))
 
     def count(self) -> int:
         return self._L.oracle_count(self._h)

@@ -18,6 +18,7 @@ struct ICBL {
     virtual void load(const uint8_t* d, size_t n) = 0;
     virtual void merge(ICBL* other) = 0;
     virtual size_t seq_words(const uint8_t* s, size_t n, int mode, uint64_t* lo, uint64_t* hi, size_t cap) = 0;
+    virtual void insert_words(const uint64_t* lo, const uint64_t* hi, size_t n) = 0;
     virtual bool insert_kmer(u128 k) = 0;
     virtual bool contains_kmer(u128 k) const = 0;
     virtual bool contains_word(u128 w) const = 0;
@@ -53,6 +54,11 @@ template <class T, class S, int TID> struct Impl : ICBL {
             }
         });
         return w;
+    }
+    void insert_words(const uint64_t* lo, const uint64_t* hi, size_t n) override {  // WordSet::insert_batch, src/wordset/mod.rs:187-216
+        std::vector<T> w(n);
+        for (size_t i = 0; i < n; ++i) w[i] = (T)(((u128)(hi ? hi[i] : 0) << 64) | lo[i]);
+        c.wordset.insert_batch(w.data(), n);
     }
     bool insert_kmer(u128 k) override { return c.insert_kmer((T)k); }
     bool contains_kmer(u128 k) const override { return c.contains_kmer((T)k); }
@@ -117,6 +123,9 @@ int oracle_insert_seqs(void* h, const uint8_t* bases, const uint64_t* offsets, u
         auto t1 = std::chrono::steady_clock::now();
         if (secs) *secs = std::chrono::duration<double>(t1 - t0).count();
     });
+}
+int oracle_insert_words(void* h, const uint64_t* lo, const uint64_t* hi, uint64_t n) {
+    return guard([&] { static_cast<ICBL*>(h)->insert_words(lo, hi, n); });
 }
 uint64_t oracle_count(void* h) { return static_cast<ICBL*>(h)->count(); }
 uint64_t oracle_n_buckets(void* h) { return static_cast<ICBL*>(h)->n_buckets(); }

@@ -263,3 +263,61 @@ def test_insert_words_device_is_insert_batch():
         g = cbl_amd.CBL(k, pb)
         g.insert_words_device(lo, hi, len(words))
         _check_index(g, o)
+
+
+# ---- multi-GPU exchange step (run here on one GPU) ---------------------------------------------------------
+@pytest.mark.parametrize("k,pb", [(31, 24), (25, 24), (59, 28)])
+def test_partition_words_device_is_stable(k, pb):
+    _need_gpu()
+    rng = random.Random(k)
+    seqs = [_rand_seq(rng, 150) for _ in range(400)]
+    g = cbl_amd.CBL(k, pb)
+    o = Oracle(k, pb)
+    words = _oracle_words(o, seqs)
+    sb = g.consts()["suffix_bits"]
+    prefixes = sorted(w >> sb for w in words)
+    for nd in (1, 2, 5, 8, 16):
+        bounds = sorted(prefixes[rng.randrange(len(prefixes))] for _ in range(nd - 1))
+        lo = torch.from_numpy(np.array([w & (2**64 - 1) for w in words], dtype=np.uint64).astype(np.int64)).cuda()
+        hi = torch.from_numpy(np.array([w >> 64 for w in words], dtype=np.uint64).astype(np.int64)).cuda()
+        olo, ohi = torch.zeros_like(lo), torch.zeros_like(hi)
+        counts = g.partition_words_device(lo, hi, len(words), bounds, nd, olo, ohi)
+        dest = [sum(1 for b in bounds if b <= (w >> sb)) for w in words]
+        want = [w for d in range(nd) for w, dd in zip(words, dest) if dd == d]
+        got = [int(a) | (int(b) << 64) for a, b in zip(olo.cpu().numpy().astype(np.uint64), ohi.cpu().numpy().astype(np.uint64))]
+        if g.consts()["word_bits"] <= 64:
+            got = [x & (2**64 - 1) for x in got]
+        assert counts == [dest.count(d) for d in range(nd)]
+        assert got == want
+
+
+def test_sharded_builder_single_rank_nccl():
+    """ShardedBuilder over a 1-rank RCCL group == the direct insert (same code path the N-GPU bench runs)."""
+    _need_gpu()
+    import os
+
+    import torch.distributed as dist
+
+    from cbl_amd import sharded
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for k, pb in ((31, 24), (25, 24), (59, 28)):
+            d_b, d_o = synth.reads_torch(42, 3000, 150, device="cuda")
+            a, b = cbl_amd.CBL(k, pb), cbl_amd.CBL(k, pb)
+            a.insert_seqs_device(d_b, d_o, 3000)
+            sharded.ShardedBuilder(b, dist).insert_seqs_device(d_b, d_o, 3000)
+            blob = sharded.gather_serialized(b.serialize(), dist)
+            assert blob == a.serialize()
+            hb, ho = synth.reads(42, 3000, 150)
+            assert (d_b[: 3000 * 150].cpu().numpy() == hb).all()
+            o = Oracle(k, pb)
+            o.insert_seqs(hb, ho)
+            assert blob == o.serialize()
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -1,0 +1,148 @@
+"""N > 1 path on CPU: world_size-2 (and 3) `gloo` runs of cbl_amd.sharded.ShardedBuilder — the orchestration the GPU
+ranks execute (splitter choice, stable partition by destination, count exchange, all_to_all_single, source-rank
+ordered insert, rank-ordered serialization) — with the device steps stood in by the CPU oracle (test-only engine).
+The sharded result must be byte-identical to the one-process build of the same reads in the same order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine:
+    """CPU stand-in for cbl_amd.sharded.GpuEngine (tests only): same four steps on torch CPU tensors."""
+
+    def __init__(self, orc, k, pb):
+        import torch
+        from oracle.pyref import params
+
+        self.torch, self.o = torch, orc
+        P = params(k, pb)
+        self.sb, self.pb = P["SB"], pb
+
+    def _to_ints(self, lo, hi):
+        lo = lo.numpy().astype(np.uint64)
+        hi = hi.numpy().astype(np.uint64)
+        return [int(a) | (int(b) << 64) for a, b in zip(lo, hi)]
+
+    def _from_ints(self, words):
+        t = self.torch
+        lo = np.array([w & (2**64 - 1) for w in words], dtype=np.uint64).astype(np.int64)
+        hi = np.array([w >> 64 for w in words], dtype=np.uint64).astype(np.int64)
+        return t.from_numpy(lo), t.from_numpy(hi)
+
+    def seq_words(self, bases, offsets, n):
+        b = bases.numpy().tobytes()
+        off = offsets.numpy()
+        words = []
+        for i in range(n):
+            words += self.o.seq_words(b[int(off[i]) : int(off[i + 1])])
+        return self._from_ints(words)
+
+    def sample_hist(self, lo, hi):
+        from cbl_amd.sharded import HIST_BITS, SAMPLE_STRIDE
+
+        hb = min(HIST_BITS, self.pb)
+        keys = [(w >> (self.sb + self.pb - hb)) & ((1 << hb) - 1) for w in self._to_ints(lo, hi)[::SAMPLE_STRIDE]]
+        return self.torch.from_numpy(np.bincount(np.array(keys, dtype=np.int64), minlength=1 << hb).astype(np.int64))
+
+    def partition(self, lo, hi, bounds, nd):
+        words = self._to_ints(lo, hi)
+        dest = [int(np.searchsorted(bounds, (w >> self.sb), side="right")) for w in words]
+        order = sorted(range(len(words)), key=lambda i: dest[i])  # Python's sort is stable
+        plo, phi = self._from_ints([words[i] for i in order])
+        return plo, phi, [dest.count(d) for d in range(nd)]
+
+    def insert_words(self, lo, hi):
+        self.o.insert_words(self._to_ints(lo, hi))
+
+    def empty_like(self, t, n):
+        return self.torch.empty(n, dtype=t.dtype)
+
+
+def _worker(rank, world, port, k, pb, nreads, L, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+
+    from cbl_amd import sharded, synth
+    from oracle import Oracle
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        per = nreads // world
+        bases, offsets = synth.reads(7, per, L, first_read=rank * per)
+        orc = Oracle(k, pb)
+
+        class _Cbl:  # the two attributes ShardedBuilder reads from a CBL
+            prefix_bits = pb
+
+        sb = sharded.ShardedBuilder(_Cbl(), dist, engine=OracleEngine(orc, k, pb))
+        # two batches: the second reuses the first batch's splitters
+        h = per // 2
+        for a, b in ((0, h), (h, per)):
+            bb = torch.from_numpy(bases[a * L : b * L].copy())
+            oo = torch.from_numpy((offsets[a : b + 1] - offsets[a]).astype(np.int64))
+            sb.insert_seqs_device(bb, oo, b - a)
+        blob = sharded.gather_serialized(orc.serialize(), dist)
+        if rank == 0:
+            q.put((blob, sb.bounds.tolist(), sb.last_counts))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,k,pb,nreads,L", [(2, 31, 24, 240, 150), (3, 9, 4, 600, 100), (2, 59, 28, 120, 250)])
+def test_sharded_build_equals_single_process(world, k, pb, nreads, L):
+    import torch.multiprocessing as mp
+
+    from cbl_amd import synth
+    from oracle import Oracle
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, k, pb, nreads, L, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    blob, bounds, counts = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # one-process build. Stream order of the sharded job: batch 1 of every rank (rank order), then batch 2.
+    per = nreads // world
+    h = per // 2
+    one = Oracle(k, pb)
+    for a, b in ((0, h), (h, per)):
+        for r in range(world):
+            bases, offsets = synth.reads(7, b - a, L, first_read=r * per + a)
+            one.insert_seqs(bases, offsets)
+    assert blob == one.serialize()
+    assert len(bounds) == world - 1 and bounds == sorted(bounds)
+    assert sum(counts[0]) > 0
+
+
+def test_choose_bounds_balances_skewed_histogram():
+    from cbl_amd.sharded import choose_bounds
+
+    hist = np.zeros(1 << 16, dtype=np.int64)
+    x = np.arange(1 << 16) / (1 << 16)
+    hist[:] = (1e6 * 62 * (1 - x) ** 61).astype(np.int64)  # SURVEY.md F6 density
+    b = choose_bounds(hist, 8, 24, 16)
+    assert len(b) == 7 and all(b[i] <= b[i + 1] for i in range(6))
+    cells = (b >> 8).astype(np.int64)
+    cum = np.cumsum(hist)
+    parts = np.diff(np.concatenate([[0], cum[cells - 1], [cum[-1]]]))
+    assert parts.max() / parts.mean() < 1.05
+    assert (choose_bounds(np.zeros(16, dtype=np.int64), 4, 4, 4) == [4, 8, 12]).all()
