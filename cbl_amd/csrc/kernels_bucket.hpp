@@ -103,8 +103,18 @@ __global__ void k_classify(u64 nb, u32 med_max_threads, const u32* __restrict__ 
     else if (c <= 512 * MED_ITEMS) cls = CLS_M512;
     else if (c <= 1024 * MED_ITEMS && med_max_threads >= 1024) cls = CLS_M1024;
     else cls = CLS_HUGE;
-    u32 slot = atomicAdd(&list_n[cls], 1u);
-    lists[(u64)cls * nb + slot] = (u32)r;
+    // one atomic per (wave, class): the lanes of a class take consecutive slots
+#pragma unroll
+    for (int k = 0; k < CLS_N; ++k) {
+        const u64 bal = __ballot(cls == k);
+        if (cls == k) {
+            u32 base = 0;
+            const u32 leader = (u32)__builtin_ctzll(bal);
+            if (lane_id() == leader) base = atomicAdd(&list_n[k], (u32)__builtin_popcountll(bal));
+            base = __shfl(base, (int)leader, 64);
+            lists[(u64)k * nb + base + mbcnt(bal)] = (u32)r;
+        }
+    }
 }
 
 // ---- suffix access --------------------------------------------------------------------------------------
@@ -215,10 +225,10 @@ __global__ __launch_bounds__(THREADS) void k_bucket_medium(const u32* __restrict
     for (u32 pass = 0; pass < npass; ++pass) {
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) digit[j] = valid[j] ? key[j].digit(pass) : 255u;
-        tile_rank<THREADS, ITEMS>(digit, valid, pos, s_wcnt, s_dbase, s_scan, c);
+        tile_rank<THREADS, ITEMS>(digit, pos, s_wcnt, s_dbase, s_scan, R);
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            if (valid[j]) {
+            if ((u32)j < R) {  // tail slots (digit 255 in every pass) stay in [c, THREADS*R)
                 s_klo[pos[j]] = key[j].lo;
                 if constexpr (WS) s_khi[pos[j]] = key[j].hi;
                 s_idx[pos[j]] = (u16)idx[j];
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(256) void k_bucket_huge(const u32* __restrict__ lis
             for (int j = 0; j < ITEMS; ++j) {
                 const u32 e = w * (64 * ITEMS) + j * 64 + lane;
                 valid[j] = e < n_tile;
-                digit[j] = 255;
+                digit[j] = 255;  // tail slots: last in every pass
                 idx[j] = 0;
                 key[j].lo = 0;
                 if constexpr (WS) key[j].hi = 0;
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(256) void k_bucket_huge(const u32* __restrict__ lis
                     digit[j] = key[j].digit(pass);
                 }
             }
-            tile_rank<THREADS, ITEMS>(digit, valid, pos, s_wcnt, s_dbase, s_scan, n_tile);
+            tile_rank<THREADS, ITEMS>(digit, pos, s_wcnt, s_dbase, s_scan, ITEMS);
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
                 if (valid[j]) {

@@ -82,15 +82,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const u32* __restri
 
 // ------------------------------------------------------------------------------------------------
 // Stable ranking of one tile by an 8-bit digit.
-//   THREADS = 64 * NW lanes, ITEMS rounds; element e = w * (64*ITEMS) + j * 64 + lane  (wave-contiguous slices,
-//   so the order of equal digits is (wave, round, lane) = tile order).
-//   digit[j] must be 0..255; elements past the tile end pass valid=false and are ranked after every valid
-//   element of the tile (they must be the LAST elements of the tile).
+//   THREADS = 64 * NW lanes, `rounds` (<= ITEMS, workgroup-uniform) rounds; element e = w * (64*rounds) + j * 64 + lane
+//   (wave-contiguous slices, so the order of equal digits is (wave, round, lane) = tile order).
+//   Every lane of every round takes part: slots past the end of the data must carry digit 255 and be the LAST
+//   slots of the tile; being stable, the ranking then leaves them in the last positions.
 //   s_wcnt: LDS [NW][256] u32.  s_dbase: LDS [256] u32 (tile-local start of each digit, valid after return).
 //   Returns pos[j] = tile-local sorted position. Contains __syncthreads().
 template <int THREADS, int ITEMS>
-__device__ __forceinline__ void tile_rank(const u32 (&digit)[ITEMS], const bool (&valid)[ITEMS], u32 (&pos)[ITEMS],
-                                          u32* s_wcnt, u32* s_dbase, u32* s_scan /* THREADS/64+1 */, u32 n_valid) {
+__device__ __forceinline__ void tile_rank(const u32 (&digit)[ITEMS], u32 (&pos)[ITEMS], u32* s_wcnt, u32* s_dbase,
+                                          u32* s_scan /* THREADS/64+1 */, u32 rounds) {
     constexpr int NW = THREADS / 64;
     const u32 tid = threadIdx.x, w = tid >> 6;
     for (u32 i = tid; i < NW * 256; i += THREADS) s_wcnt[i] = 0;
@@ -98,24 +98,23 @@ __device__ __forceinline__ void tile_rank(const u32 (&digit)[ITEMS], const bool 
     u32* my = s_wcnt + w * 256;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        const u32 d = digit[j];
-        u64 m = __ballot(valid[j]);
-        const u64 vm = m;
+        if ((u32)j < rounds) {
+            const u32 d = digit[j];
+            u64 m = ~0ull;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bal = __ballot(bit && valid[j]);
-            m &= bit ? bal : ~bal;
+            for (int b = 0; b < 8; ++b) {
+                const u32 bit = (d >> b) & 1u;
+                const u64 bal = __ballot(bit != 0);
+                m &= bal ^ (u64)(long long)((int)bit - 1);  // lanes whose bit b equals mine
+            }
+            const u32 lower = mbcnt(m);
+            const u32 tot = (u32)__builtin_popcountll(m);
+            const u32 old = my[d];
+            __builtin_amdgcn_wave_barrier();
+            if (lower == 0) my[d] = old + tot;
+            __builtin_amdgcn_wave_barrier();
+            pos[j] = old + lower;
         }
-        m &= vm;
-        const u32 lower = mbcnt(m);
-        const u32 tot = (u32)__builtin_popcountll(m);
-        u32 old = 0;
-        if (valid[j]) old = my[d];
-        __builtin_amdgcn_wave_barrier();
-        if (valid[j] && lower == 0) my[d] = old + tot;
-        __builtin_amdgcn_wave_barrier();
-        pos[j] = old + lower;
     }
     __syncthreads();
     // per digit: exclusive scan across waves; digit totals -> exclusive scan across digits
@@ -134,14 +133,12 @@ __device__ __forceinline__ void tile_rank(const u32 (&digit)[ITEMS], const bool 
     if (tid < 256) s_dbase[tid] = ex;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        if (valid[j]) pos[j] += s_dbase[digit[j]] + my[digit[j]];
-        else pos[j] = n_valid + 0;  // never written
-    }
+    for (int j = 0; j < ITEMS; ++j)
+        if ((u32)j < rounds) pos[j] += s_dbase[digit[j]] + my[digit[j]];
 }
 
-static const int RDX_THREADS = 256;
-static const int RDX_ITEMS = 16;
+static const int RDX_THREADS = 512;
+static const int RDX_ITEMS = 8;
 static const int RDX_TILE = RDX_THREADS * RDX_ITEMS;  // 4096 records per workgroup
 
 // digit of a record: a bit field of the word (LSD passes) ...
@@ -217,31 +214,26 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
     const u32 n_tile = (u32)((n - tbase) < (u64)RDX_TILE ? (n - tbase) : (u64)RDX_TILE);
 
     u64 klo[RDX_ITEMS];
-    u64 khi[RDX_ITEMS];
+    typename std::conditional<std::is_same<HiT, u64>::value, u64, u32>::type khi[RDX_ITEMS];
     u32 digit[RDX_ITEMS], pos[RDX_ITEMS];
-    bool valid[RDX_ITEMS];
 #pragma unroll
     for (int j = 0; j < RDX_ITEMS; ++j) {
         const u32 e = w * (64 * RDX_ITEMS) + j * 64 + lane;
-        valid[j] = e < n_tile;
-        klo[j] = 0; khi[j] = 0; digit[j] = 255;
-        if (valid[j]) {
-            klo[j] = lo[tbase + e];
-            khi[j] = ld_hi<HiT>(hi, tbase + e);
-            digit[j] = dfn(klo[j], khi[j]);
-        }
+        const bool valid = e < n_tile;
+        const u64 idx = valid ? tbase + e : tbase;  // tail slots re-read slot 0 and are never written back
+        klo[j] = lo[idx];
+        khi[j] = ld_hi<HiT>(hi, idx);
+        digit[j] = valid ? dfn(klo[j], (u64)khi[j]) : 255u;
     }
-    tile_rank<RDX_THREADS, RDX_ITEMS>(digit, valid, pos, s_wcnt, s_dbase, s_scan, n_tile);
+    tile_rank<RDX_THREADS, RDX_ITEMS>(digit, pos, s_wcnt, s_dbase, s_scan, RDX_ITEMS);
     if (tid < 256) s_gbase[tid] = offsets[(u64)tid * ntiles + blockIdx.x] - s_dbase[tid];
 #pragma unroll
     for (int j = 0; j < RDX_ITEMS; ++j) {
-        if (valid[j]) {
-            s_lo[pos[j]] = klo[j];
-            if constexpr (HiTraits<HiT>::has) s_hi[pos[j]] = (HiT)khi[j];
-        }
+        s_lo[pos[j]] = klo[j];  // pos < RDX_TILE always; tail slots land in [n_tile, RDX_TILE)
+        if constexpr (HiTraits<HiT>::has) s_hi[pos[j]] = (HiT)khi[j];
     }
     __syncthreads();
-#pragma unroll 4
+#pragma unroll
     for (int j = 0; j < RDX_ITEMS; ++j) {
         const u32 s = j * RDX_THREADS + tid;
         if (s < n_tile) {
