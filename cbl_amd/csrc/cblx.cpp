@@ -202,23 +202,48 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
     u64* lo2 = rec.lo2.get();
     HiT* hi = (HiT*)rec.hi.get();
     HiT* hi2 = (HiT*)rec.hi2.get();
-    // -- KRN-2: stable LSD radix partition on the PREFIX_BITS above SUFFIX_BITS
+    // -- KRN-2: stable LSD radix partition on the PREFIX_BITS above SUFFIX_BITS. Default: per pass a tile histogram, a
+    //    device-wide scan and the LDS-staged scatter. CBLX_ONESWEEP=1 selects the single-read form (one up-front digit
+    //    histogram + decoupled look-back), which on MI355X is currently no faster: an agent-scope look-back hop costs
+    //    1-3 us across the non-coherent per-XCD L2s (measurements in DESIGN.md).
     {
         const u32 ntiles = (u32)ceil_div(N, RDX_TILE);
-        Buf<u32> counts(c->pool, (size_t)256 * ntiles), offsets(c->pool, (size_t)256 * ntiles);
         const u32 npass = (P.PB + 7) / 8;
-        for (u32 pass = 0; pass < npass; ++pass) {
-            const u32 shift = P.SB + 8 * pass, nbits = std::min(8u, P.PB - 8 * pass);
+        static const bool onesweep = getenv("CBLX_ONESWEEP") && atoi(getenv("CBLX_ONESWEEP")) != 0;
+        if (!onesweep) {
+            Buf<u32> counts(c->pool, (size_t)256 * ntiles), offsets(c->pool, (size_t)256 * ntiles);
+            for (u32 pass = 0; pass < npass; ++pass) {
+                const u32 shift = P.SB + 8 * pass, nbits = std::min(8u, P.PB - 8 * pass);
+                { StageTimer t(c, ST_HIST);
+                  hipLaunchKernelGGL((k_radix_hist<HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits}, ntiles, counts.get()); }
+                { StageTimer t(c, ST_SCAN);
+                  exclusive_scan<u32>(c, counts.get(), (u64)256 * ntiles, offsets.get()); }
+                { StageTimer t(c, ST_SCATTER);
+                  hipLaunchKernelGGL((k_radix_scatter<HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits}, ntiles, offsets.get(), lo2, hi2); }
+                std::swap(lo, lo2);
+                std::swap(hi, hi2);
+            }
+            CBLX_HIP(hipGetLastError());
+        } else {
+            Buf<unsigned long long> ghist(c->pool, MAX_PASSES * 256);
+            Buf<u32> ctl(c->pool, MAX_PASSES * 128 + 16);  // 8 ticket counters (64 B apart) per pass + error flag
+            Buf<u64> status(c->pool, (size_t)ntiles * 256);
+            CBLX_HIP(hipMemsetAsync(ghist.get(), 0, MAX_PASSES * 256 * 8, c->stream));
+            CBLX_HIP(hipMemsetAsync(ctl.get(), 0, (MAX_PASSES * 128 + 16) * 4, c->stream));
+            CBLX_HIP(hipMemsetAsync(status.get(), 0, (size_t)ntiles * 256 * 8, c->stream));
             { StageTimer t(c, ST_HIST);
-              hipLaunchKernelGGL((k_radix_hist<HiT, DigitBits>), dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits}, ntiles, counts.get()); }
-            { StageTimer t(c, ST_SCAN);
-              exclusive_scan<u32>(c, counts.get(), (u64)256 * ntiles, offsets.get()); }
-            { StageTimer t(c, ST_SCATTER);
-              hipLaunchKernelGGL((k_radix_scatter<HiT, DigitBits>), dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits}, ntiles, offsets.get(), lo2, hi2); }
-            std::swap(lo, lo2);
-            std::swap(hi, hi2);
+              hipLaunchKernelGGL(k_digit_hist<HiT>, dim3((unsigned)std::min<u64>(ceil_div(N, 512 * 8), 256 * 8)), dim3(512), 0, c->stream, lo, hi, N, P.SB, P.PB, npass, ghist.get()); }
+            for (u32 pass = 0; pass < npass; ++pass) {
+                const u32 shift = P.SB + 8 * pass, nbits = std::min(8u, P.PB - 8 * pass);
+                { StageTimer t(c, ST_SCATTER);
+                  hipLaunchKernelGGL((k_onesweep<HiT, DigitBits>), dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits},
+                                     ghist.get() + pass * 256, ctl.get() + pass * 128, ntiles, status.get(), pass + 1, lo2, hi2, ctl.get() + MAX_PASSES * 128, 0u); }
+                std::swap(lo, lo2);
+                std::swap(hi, hi2);
+            }
+            CBLX_HIP(hipGetLastError());
+            if (d2h<u32>(c, ctl.get() + MAX_PASSES * 128)) throw Error(CBLX_EDEVICE, "radix partition: look-back timed out");
         }
-        CBLX_HIP(hipGetLastError());
         if (npass & 1) { std::swap(rec.lo, rec.lo2); std::swap(rec.hi, rec.hi2); }
     }
     rec.lo2.reset();
@@ -845,11 +870,11 @@ int cblx_partition_words_device(cblx_ctx* c, const uint64_t* d_lo, const uint64_
             const H* hi = (const H*)d_hi;
             H* ohi = (H*)d_out_hi;
             { StageTimer t(c, ST_HIST);
-              hipLaunchKernelGGL((k_radix_hist<H, DigitDest>), dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, d_lo, hi, n, fn, ntiles, cnt.get()); }
+              hipLaunchKernelGGL((k_radix_hist<H, DigitDest>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, d_lo, hi, n, fn, ntiles, cnt.get()); }
             { StageTimer t(c, ST_SCAN);
               exclusive_scan<u32>(c, cnt.get(), (u64)256 * ntiles, off.get()); }
             { StageTimer t(c, ST_SCATTER);
-              hipLaunchKernelGGL((k_radix_scatter<H, DigitDest>), dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, d_lo, hi, n, fn, ntiles, off.get(), d_out_lo, ohi); }
+              hipLaunchKernelGGL((k_radix_scatter<H, DigitDest>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, d_lo, hi, n, fn, ntiles, off.get(), d_out_lo, ohi); }
             CBLX_HIP(hipGetLastError());
         };
         if (c->P.has_hi()) run((u64)0); else run(NoHi());
