@@ -76,7 +76,7 @@ __device__ __forceinline__ bool dir_lookup(const DirView& d, u32 p, u64& rank) {
 }
 
 // ---- classification of buckets by run length -----------------------------------------------------------
-enum { CLS_SMALL = 0, CLS_M256 = 1, CLS_M512 = 2, CLS_M1024 = 3, CLS_HUGE = 4, CLS_N = 5 };
+enum { CLS_SMALL = 0, CLS_M64 = 1, CLS_M128 = 2, CLS_M256 = 3, CLS_M512 = 4, CLS_M1024 = 5, CLS_HUGE = 6, CLS_N = 7 };
 static const u32 SMALL_MAX = 64;
 static const u32 MED_ITEMS = 8;
 
@@ -99,6 +99,8 @@ __global__ void k_classify(u64 nb, u32 med_max_threads, const u32* __restrict__ 
     }
     int cls;
     if (c <= SMALL_MAX && rk != KIND_TRIE) cls = CLS_SMALL;
+    else if (c <= 64 * MED_ITEMS) cls = CLS_M64;    // workgroup size follows the run length: THREADS = CAP / 8
+    else if (c <= 128 * MED_ITEMS) cls = CLS_M128;
     else if (c <= 256 * MED_ITEMS) cls = CLS_M256;
     else if (c <= 512 * MED_ITEMS) cls = CLS_M512;
     else if (c <= 1024 * MED_ITEMS && med_max_threads >= 1024) cls = CLS_M1024;
@@ -297,6 +299,207 @@ __global__ __launch_bounds__(THREADS) void k_bucket_medium(const u32* __restrict
             const u32 e = w * EPW + j * 64 + lane;
             keep[j] = valid[j] && ((s_bm[e >> 5] >> (e & 31)) & 1u);
             if (valid[j]) orig[j] = load_sfx<WS, HiT>(lo, hi, s0 + e, SB);
+            wk += (u32)__builtin_popcountll(__ballot(keep[j]));
+        }
+        if (lane == 0) s_wtot[w] = wk;
+        __syncthreads();  // every read of the run is done before any in-place write
+        u32 run = 0;
+        for (u32 ww = 0; ww < w; ++ww) run += s_wtot[ww];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u64 bal = __ballot(keep[j]);
+            if (keep[j]) store_sfx<WS, HiT>(lo, hi, s0 + run + mbcnt(bal), orig[j]);
+            run += (u32)__builtin_popcountll(bal);
+        }
+    }
+    if (tid == 0) {
+        out_count[r] = d;
+        out_kind[r] = trie ? KIND_TRIE : KIND_VEC;
+    }
+}
+
+// ---- KRN-3 fast path: one workgroup per bucket, run <= CAP. Suffixes of one prefix are close to uniformly spread,
+// so one counting-sort step on their top ceil(log2 c) bits leaves sub-buckets of ~1 element; each element then ranks
+// itself inside its sub-bucket by (suffix, stream index) with a handful of compares. O(c) LDS work instead of
+// SUFFIX_BITS/8 radix passes. A bucket whose largest sub-bucket exceeds MSD_LIMIT (heavy duplication / repeats) is
+// handed to the radix kernel through `retry` untouched. -------------------------------------------------------------
+static const u32 MSD_LIMIT = 48;
+
+template <bool WS> __device__ __forceinline__ u32 sfx_top_bits(const Sfx<WS>& k, u32 SB, u32 nbits) {
+    if constexpr (WS) {
+        const u128 v = ((u128)k.hi << 64) | k.lo;
+        return (u32)(v >> (SB - nbits));
+    } else {
+        return (u32)(k.lo >> (SB - nbits));
+    }
+}
+template <bool WS> __device__ __forceinline__ bool sfx_less(const Sfx<WS>& a, u32 ia, const Sfx<WS>& b, u32 ib) {
+    if constexpr (WS) {
+        if (a.hi != b.hi) return a.hi < b.hi;
+    }
+    if (a.lo != b.lo) return a.lo < b.lo;
+    return ia < ib;
+}
+
+template <int THREADS, int CAP, bool WS, typename HiT>
+__global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ list, const u32* __restrict__ list_n,
+                                                        const u64* __restrict__ raw_start, const u8* __restrict__ res_kind,
+                                                        u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
+                                                        u32* __restrict__ out_count, u8* __restrict__ out_kind,
+                                                        u32* __restrict__ retry, u32* __restrict__ retry_n) {
+    constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
+    __shared__ u64 s_klo[CAP];
+    __shared__ u64 s_khi[WS ? CAP : 1];
+    __shared__ u16 s_idx[CAP];
+    __shared__ u32 s_off[CAP + 1];  // sub-bucket counts, then exclusive offsets
+    __shared__ u32 s_scan[NW + 1];
+    __shared__ u32 s_bm[CAP / 32];
+    __shared__ u32 s_wtot[NW + 1];
+    __shared__ u32 s_max;
+
+    if (blockIdx.x >= *list_n) return;
+    const u32 r = list[blockIdx.x];
+    const u64 s0 = raw_start[r];
+    const u32 c = (u32)(raw_start[r + 1] - s0);
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const u32 R = (c + THREADS - 1) / THREADS;
+    u32 nbits = 32 - __builtin_clz(c - 1 > 0 ? c - 1 : 1);  // ceil(log2 c), c >= 2
+    if (nbits > SB) nbits = SB;
+    const u32 NB = 1u << nbits;                              // <= CAP because c <= CAP
+
+    for (u32 i = tid; i < NB + 1; i += THREADS) s_off[i] = 0;
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    Sfx<WS> key[ITEMS];
+    u32 sub[ITEMS], arr[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 e = j * THREADS + tid;
+        if ((u32)j < R && e < c) {
+            key[j] = load_sfx<WS, HiT>(lo, hi, s0 + e, SB);
+            sub[j] = sfx_top_bits<WS>(key[j], SB, nbits);
+            arr[j] = atomicAdd(&s_off[sub[j]], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the NB counts (each thread owns NB/THREADS consecutive entries, at least 1 slot each)
+    {
+        const u32 per = (NB + THREADS - 1) / THREADS;
+        const u32 b0 = tid * per;
+        u32 sum = 0, mx = 0;
+        for (u32 k = 0; k < per; ++k) {
+            const u32 v = (b0 + k < NB) ? s_off[b0 + k] : 0u;
+            sum += v;
+            mx = v > mx ? v : mx;
+        }
+        if (mx > MSD_LIMIT) atomicMax(&s_max, mx);
+        u32 ex = block_exclusive_scan<THREADS, u32>(sum, s_scan, nullptr);
+        for (u32 k = 0; k < per; ++k) {
+            if (b0 + k < NB) { const u32 v = s_off[b0 + k]; s_off[b0 + k] = ex; ex += v; }
+        }
+    }
+    __syncthreads();
+    if (s_max > MSD_LIMIT) {  // skewed bucket: leave it to the radix kernel
+        if (tid == 0) retry[atomicAdd(retry_n, 1u)] = r;
+        return;
+    }
+    if (tid == 0) s_off[NB] = c;
+    // scatter into sub-bucket order (arrival order inside a sub-bucket is arbitrary)
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 e = j * THREADS + tid;
+        if ((u32)j < R && e < c) {
+            const u32 p = s_off[sub[j]] + arr[j];
+            s_klo[p] = key[j].lo;
+            if constexpr (WS) s_khi[p] = key[j].hi;
+            s_idx[p] = (u16)e;
+        }
+    }
+    __syncthreads();
+    // every element ranks itself inside its sub-bucket by (suffix, stream index)
+    u32 fin[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 e = j * THREADS + tid;
+        if ((u32)j < R && e < c) {
+            const u32 a = s_off[sub[j]], b = s_off[sub[j] + 1];
+            u32 rank = 0;
+            for (u32 q = a; q < b; ++q) {
+                Sfx<WS> o;
+                o.lo = s_klo[q];
+                if constexpr (WS) o.hi = s_khi[q];
+                rank += sfx_less<WS>(o, (u32)s_idx[q], key[j], e) ? 1u : 0u;
+            }
+            fin[j] = a + rank;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 e = j * THREADS + tid;
+        if ((u32)j < R && e < c) {
+            s_klo[fin[j]] = key[j].lo;
+            if constexpr (WS) s_khi[fin[j]] = key[j].hi;
+            s_idx[fin[j]] = (u16)e;
+        }
+    }
+    for (u32 i = tid; i < CAP / 32; i += THREADS) s_bm[i] = 0;
+    __syncthreads();
+    // sorted by (suffix, stream index): slot p (wave-contiguous slices so that ballots give ordered compaction)
+    const u32 EPW = 64 * R;
+    bool head[ITEMS];
+    u32 wave_heads = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 p = w * EPW + j * 64 + lane;
+        head[j] = false;
+        if ((u32)j < R && p < c) {
+            key[j].lo = s_klo[p];
+            if constexpr (WS) key[j].hi = s_khi[p];
+            if (p == 0) head[j] = true;
+            else {
+                Sfx<WS> prev;
+                prev.lo = s_klo[p - 1];
+                if constexpr (WS) prev.hi = s_khi[p - 1];
+                head[j] = prev != key[j];
+            }
+        }
+        wave_heads += (u32)__builtin_popcountll(__ballot(head[j]));
+    }
+    if (lane == 0) s_wtot[w] = wave_heads;
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (int ww = 0; ww < NW; ++ww) { u32 t = s_wtot[ww]; s_wtot[ww] = run; run += t; }
+        s_wtot[NW] = run;
+    }
+    __syncthreads();
+    const u32 d = s_wtot[NW];
+    const bool trie = d > VEC_THRESHOLD || res_kind[r] == KIND_TRIE;
+    if (trie) {
+        u32 run = s_wtot[w];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u64 bal = __ballot(head[j]);
+            if (head[j]) store_sfx<WS, HiT>(lo, hi, s0 + run + mbcnt(bal), key[j]);
+            run += (u32)__builtin_popcountll(bal);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 p = w * EPW + j * 64 + lane;
+            if (head[j]) { const u32 ix = s_idx[p]; atomicOr(&s_bm[ix >> 5], 1u << (ix & 31)); }
+        }
+        __syncthreads();
+        Sfx<WS> orig[ITEMS];
+        bool keep[ITEMS];
+        u32 wk = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 e = w * EPW + j * 64 + lane;
+            const bool v = (u32)j < R && e < c;
+            keep[j] = v && ((s_bm[e >> 5] >> (e & 31)) & 1u);
+            if (v) orig[j] = load_sfx<WS, HiT>(lo, hi, s0 + e, SB);
             wk += (u32)__builtin_popcountll(__ballot(keep[j]));
         }
         if (lane == 0) s_wtot[w] = wk;
