@@ -173,6 +173,17 @@ template <typename OutT> u64 exclusive_scan(cblx_ctx* c, const u32* in, u64 n, O
     return d2h<u64>(c, sums.get() + nb);
 }
 
+// offsets[tile][256] from counts[tile][256] (see k_colscan_*): no host readback, everything stays on the stream
+void colscan(cblx_ctx* c, const u32* counts, u32 ntiles, u32* offsets, Buf<u32>& scratch) {
+    const u32 nchunks = (u32)ceil_div(ntiles, COLSCAN_ROWS);
+    if (scratch.n < (size_t)nchunks * 256 + 256) scratch = Buf<u32>(c->pool, (size_t)nchunks * 256 + 256);
+    u32* chunk_sums = scratch.get();
+    u32* base = scratch.get() + (size_t)nchunks * 256;
+    hipLaunchKernelGGL(k_colscan_reduce, dim3(nchunks), dim3(256), 0, c->stream, counts, ntiles, chunk_sums);
+    hipLaunchKernelGGL(k_colscan_spine, dim3(1), dim3(256), 0, c->stream, chunk_sums, nchunks, base);
+    hipLaunchKernelGGL(k_colscan_apply, dim3(nchunks), dim3(256), 0, c->stream, counts, ntiles, chunk_sums, base, offsets);
+}
+
 // ---- template configuration ------------------------------------------------------------------------------
 template <bool WIDE_, typename HiT_, bool WS_> struct Cfg {
     static constexpr bool WIDE = WIDE_;
@@ -211,13 +222,13 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
         const u32 npass = (P.PB + 7) / 8;
         static const bool onesweep = getenv("CBLX_ONESWEEP") && atoi(getenv("CBLX_ONESWEEP")) != 0;
         if (!onesweep) {
-            Buf<u32> counts(c->pool, (size_t)256 * ntiles), offsets(c->pool, (size_t)256 * ntiles);
+            Buf<u32> counts(c->pool, (size_t)256 * ntiles), offsets(c->pool, (size_t)256 * ntiles), scratch;
             for (u32 pass = 0; pass < npass; ++pass) {
                 const u32 shift = P.SB + 8 * pass, nbits = std::min(8u, P.PB - 8 * pass);
                 { StageTimer t(c, ST_HIST);
                   hipLaunchKernelGGL((k_radix_hist<HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits}, ntiles, counts.get()); }
                 { StageTimer t(c, ST_SCAN);
-                  exclusive_scan<u32>(c, counts.get(), (u64)256 * ntiles, offsets.get()); }
+                  colscan(c, counts.get(), ntiles, offsets.get(), scratch); }
                 { StageTimer t(c, ST_SCATTER);
                   hipLaunchKernelGGL((k_radix_scatter<HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits}, ntiles, offsets.get(), lo2, hi2); }
                 std::swap(lo, lo2);
@@ -260,7 +271,7 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
         CBLX_HIP(hipMemsetAsync(start_dense.get(), 0xFF, nprefix * 4, c->stream));
         CBLX_HIP(hipMemsetAsync(nr.bv.get(), 0, nwords * 8, c->stream));
         CBLX_HIP(hipMemsetAsync(popc.get(), 0, nwords * 4, c->stream));
-        hipLaunchKernelGGL(k_boundaries<HiT>, grid1(N, 256), dim3(256), 0, c->stream, lo, hi, N, P.SB, P.PB, start_dense.get());
+        hipLaunchKernelGGL(k_boundaries<HiT>, grid1(ceil_div(N, 4), 256), dim3(256), 0, c->stream, lo, hi, N, P.SB, P.PB, start_dense.get());
         hipLaunchKernelGGL(k_bitvector, grid1(std::max<u64>(nprefix, 64), 256), dim3(256), 0, c->stream, start_dense.get(), nprefix, nr.bv.get(), popc.get());
         nr.nb = exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get());
         nr.prefix = Buf<u32>(c->pool, nr.nb + 1);
@@ -878,7 +889,7 @@ int cblx_partition_words_device(cblx_ctx* c, const uint64_t* d_lo, const uint64_
         for (u32 i = 0; i < MAX_DEST - 1; ++i) fn.bounds[i] = i + 1 < nd ? bounds[i] : 0xFFFFFFFFu;
         for (u32 i = 1; i + 1 < nd; ++i) if (bounds[i] < bounds[i - 1]) throw Error(CBLX_EINVAL, "bounds must be ascending");
         const u32 ntiles = (u32)ceil_div(n, RDX_TILE);
-        Buf<u32> cnt(c->pool, (size_t)256 * ntiles), off(c->pool, (size_t)256 * ntiles);
+        Buf<u32> cnt(c->pool, (size_t)256 * ntiles), off(c->pool, (size_t)256 * ntiles), scratch;
         auto run = [&](auto hi_tag) {
             typedef decltype(hi_tag) H;
             const H* hi = (const H*)d_hi;
@@ -886,7 +897,7 @@ int cblx_partition_words_device(cblx_ctx* c, const uint64_t* d_lo, const uint64_
             { StageTimer t(c, ST_HIST);
               hipLaunchKernelGGL((k_radix_hist<H, DigitDest>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, d_lo, hi, n, fn, ntiles, cnt.get()); }
             { StageTimer t(c, ST_SCAN);
-              exclusive_scan<u32>(c, cnt.get(), (u64)256 * ntiles, off.get()); }
+              colscan(c, cnt.get(), ntiles, off.get(), scratch); }
             { StageTimer t(c, ST_SCATTER);
               hipLaunchKernelGGL((k_radix_scatter<H, DigitDest>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, d_lo, hi, n, fn, ntiles, off.get(), d_out_lo, ohi); }
             CBLX_HIP(hipGetLastError());
@@ -894,7 +905,10 @@ int cblx_partition_words_device(cblx_ctx* c, const uint64_t* d_lo, const uint64_
         if (c->P.has_hi()) run((u64)0); else run(NoHi());
         // start of every destination = offset of its first tile
         std::vector<u64> starts(nd + 1, n);
-        for (u32 d = 0; d < nd; ++d) starts[d] = d2h<u32>(c, off.get() + (size_t)d * ntiles);
+        {
+            std::vector<u32> row0 = d2h_vec<u32>(c, off.get(), 256);  // offsets of tile 0 = start of every destination
+            for (u32 d = 0; d < nd; ++d) starts[d] = row0[d];
+        }
         for (u32 d = 0; d < nd; ++d) counts[d] = starts[d + 1] - starts[d];
         collect_events(c);
     });

@@ -25,16 +25,26 @@ static const u32 EMPTY32 = 0xFFFFFFFFu;
 enum { KIND_VEC = 0, KIND_TRIE = 1 };
 
 // ---- KRN-4 ---------------------------------------------------------------------------------------------
-// start_dense[p] = index of the first record with prefix p (array pre-filled with EMPTY32)
+// start_dense[p] = index of the first record with prefix p (array pre-filled with EMPTY32).
+// Each thread owns 4 consecutive records (32 B of lo per lane), the predecessor's prefix comes from the lane below.
 template <typename HiT>
-__global__ void k_boundaries(const u64* __restrict__ lo, const HiT* __restrict__ hi, u64 n, u32 SB, u32 PB,
-                             u32* __restrict__ start_dense) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 p = get_bits(lo[i], ld_hi<HiT>(hi, i), SB, PB);
-    u32 q = EMPTY32;
-    if (i > 0) q = get_bits(lo[i - 1], ld_hi<HiT>(hi, i - 1), SB, PB);
-    if (p != q) start_dense[p] = (u32)i;
+__global__ __launch_bounds__(256) void k_boundaries(const u64* __restrict__ lo, const HiT* __restrict__ hi, u64 n, u32 SB, u32 PB,
+                                                    u32* __restrict__ start_dense) {
+    const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    u32 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u64 i = i0 + k < n ? i0 + k : n - 1;
+        p[k] = get_bits(lo[i], ld_hi<HiT>(hi, i), SB, PB);
+    }
+    u32 q = __shfl_up(p[3], 1, 64);
+    if ((threadIdx.x & 63) == 0) q = i0 > 0 ? get_bits(lo[i0 - 1], ld_hi<HiT>(hi, i0 - 1), SB, PB) : EMPTY32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + k < n && p[k] != q) start_dense[p[k]] = (u32)(i0 + k);
+        q = p[k];
+    }
 }
 // one lane per prefix, one wave per bitvector word
 __global__ void k_bitvector(const u32* __restrict__ start_dense, u64 nprefix, u64* __restrict__ bv, u32* __restrict__ popc) {

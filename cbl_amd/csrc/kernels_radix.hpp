@@ -183,7 +183,9 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 ntiles) {
 #endif
 }
 
-// per-tile digit histogram -> counts[digit * ntiles + tile]
+// per-tile digit histogram -> counts[tile * 256 + digit] (tile-major: one coalesced 1 KiB row per workgroup).
+// Counting needs no ranks: per-wave private LDS histograms fed by non-returning ds_add (the ballot matching of
+// tile_rank costs ~50 VALU per record and made this kernel VALU-bound).
 template <typename HiT, typename DigitFn>
 __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const u64* __restrict__ lo, const HiT* __restrict__ hi, u64 n,
                                                             DigitFn dfn, u32 ntiles, u32* __restrict__ counts) {
@@ -194,35 +196,32 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const u64* __restric
     const u32 tile = xcd_tile(blockIdx.x, ntiles);
     if (tile >= ntiles) return;
     const u64 tbase = (u64)tile * RDX_TILE;
+    const u32 n_tile = (u32)((n - tbase) < (u64)RDX_TILE ? (n - tbase) : (u64)RDX_TILE);
     u32* my = s_wcnt + w * 256;
-#pragma unroll 4
-    for (int j = 0; j < RDX_ITEMS; ++j) {
-        const u64 i = tbase + (u64)w * (64 * RDX_ITEMS) + (u64)j * 64 + lane;
-        const bool v = i < n;
-        u32 d = 0;
-        if (v) d = dfn(lo[i], ld_hi<HiT>(hi, i));
-        u64 m = __ballot(v);
-        const u64 vm = m;
+    u64 klo[RDX_ITEMS];
+    u32 khi[RDX_ITEMS];
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bal = __ballot(bit && v);
-            m &= bit ? bal : ~bal;
-        }
-        m &= vm;
-        if (v && mbcnt(m) == 0) my[d] += (u32)__builtin_popcountll(m);
-        __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < RDX_ITEMS; ++j) {
+        const u32 e = w * (64 * RDX_ITEMS) + j * 64 + lane;
+        const u64 idx = e < n_tile ? tbase + e : tbase;
+        klo[j] = lo[idx];
+        khi[j] = (u32)ld_hi<HiT>(hi, idx);
+    }
+#pragma unroll
+    for (int j = 0; j < RDX_ITEMS; ++j) {
+        const u32 e = w * (64 * RDX_ITEMS) + j * 64 + lane;
+        if (e < n_tile) atomicAdd(&my[dfn(klo[j], (u64)khi[j])], 1u);
     }
     __syncthreads();
     if (tid < 256) {
         u32 t = 0;
 #pragma unroll
         for (int ww = 0; ww < RDX_THREADS / 64; ++ww) t += s_wcnt[ww * 256 + tid];
-        counts[(u64)tid * ntiles + tile] = t;
+        counts[(u64)tile * 256 + tid] = t;
     }
 }
 
-// scatter: offsets[digit * ntiles + tile] = global position of the tile's first element with that digit
+// scatter: offsets[tile * 256 + digit] = global position of the tile's first element with that digit
 template <typename HiT, typename DigitFn>
 __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __restrict__ lo, const HiT* __restrict__ hi, u64 n,
                                                                DigitFn dfn, u32 ntiles,
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
         digit[j] = valid ? dfn(klo[j], (u64)khi[j]) : 255u;
     }
     tile_rank<RDX_THREADS, RDX_ITEMS>(digit, pos, s_wcnt, s_dbase, s_scan, RDX_ITEMS);
-    if (tid < 256) s_gbase[tid] = offsets[(u64)tid * ntiles + tile] - s_dbase[tid];
+    if (tid < 256) s_gbase[tid] = offsets[(u64)tile * 256 + tid] - s_dbase[tid];
 #pragma unroll
     for (int j = 0; j < RDX_ITEMS; ++j) {
         s_lo[pos[j]] = klo[j];  // pos < RDX_TILE always; tail slots land in [n_tile, RDX_TILE)
@@ -276,6 +275,45 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
             out_lo[dst] = a;
             st_hi<HiT>(out_hi, dst, b);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Offsets for the scatter from the tile-major count matrix C[tile][256]:
+//   O[tile][d] = sum_{d' < d} total[d'] + sum_{t' < tile} C[t'][d]
+// i.e. an exclusive scan down every column plus the exclusive scan of the column totals. Every access is a coalesced
+// 1 KiB row (thread d owns column d); rows are cut into chunks of COLSCAN_ROWS for parallelism.
+static const u32 COLSCAN_ROWS = 1024;
+__global__ __launch_bounds__(256) void k_colscan_reduce(const u32* __restrict__ counts, u32 ntiles, u32* __restrict__ chunk_sums) {
+    const u32 d = threadIdx.x, r0 = blockIdx.x * COLSCAN_ROWS;
+    const u32 r1 = r0 + COLSCAN_ROWS < ntiles ? r0 + COLSCAN_ROWS : ntiles;
+    u32 s = 0;
+#pragma unroll 8
+    for (u32 r = r0; r < r1; ++r) s += counts[(u64)r * 256 + d];
+    chunk_sums[(u64)blockIdx.x * 256 + d] = s;
+}
+__global__ __launch_bounds__(256) void k_colscan_spine(u32* __restrict__ chunk_sums, u32 nchunks, u32* __restrict__ base /* 256 */) {
+    __shared__ u32 sm[256 / 64 + 1];
+    const u32 d = threadIdx.x;
+    u32 run = 0;
+#pragma unroll 8
+    for (u32 c = 0; c < nchunks; ++c) {
+        const u32 v = chunk_sums[(u64)c * 256 + d];
+        chunk_sums[(u64)c * 256 + d] = run;
+        run += v;
+    }
+    base[d] = block_exclusive_scan<256, u32>(run, sm, nullptr);
+}
+__global__ __launch_bounds__(256) void k_colscan_apply(const u32* __restrict__ counts, u32 ntiles, const u32* __restrict__ chunk_sums,
+                                                       const u32* __restrict__ base, u32* __restrict__ offsets) {
+    const u32 d = threadIdx.x, r0 = blockIdx.x * COLSCAN_ROWS;
+    const u32 r1 = r0 + COLSCAN_ROWS < ntiles ? r0 + COLSCAN_ROWS : ntiles;
+    u32 run = base[d] + chunk_sums[(u64)blockIdx.x * 256 + d];
+#pragma unroll 8
+    for (u32 r = r0; r < r1; ++r) {
+        const u32 v = counts[(u64)r * 256 + d];
+        offsets[(u64)r * 256 + d] = run;
+        run += v;
     }
 }
 

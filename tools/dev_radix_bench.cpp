@@ -43,11 +43,11 @@ int main(int argc, char** argv) {
         DigitBits d{SB + 8 * pass, 8};
         printf("--- digit bits %u..%u\n", SB + 8 * pass, SB + 8 * pass + 7);
         timeit("hist", [&] { hipLaunchKernelGGL((k_radix_hist<u8, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, 0, lo, hi, n, d, ntiles, counts); });
-        const u64 ns = (u64)256 * ntiles, nb = (ns + SCAN_TILE - 1) / SCAN_TILE;
-        timeit("scan", [&] {
-            hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, 0, counts, ns, sums);
-            hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, 0, sums, nb);
-            hipLaunchKernelGGL(k_scan_apply<u32>, dim3(nb), dim3(SCAN_THREADS), 0, 0, counts, ns, sums, offsets); });
+                const u32 nch = (ntiles + COLSCAN_ROWS - 1) / COLSCAN_ROWS;
+        timeit("colscan", [&] {
+            hipLaunchKernelGGL(k_colscan_reduce, dim3(nch), dim3(256), 0, 0, counts, ntiles, (u32*)sums);
+            hipLaunchKernelGGL(k_colscan_spine, dim3(1), dim3(256), 0, 0, (u32*)sums, nch, (u32*)sums + (size_t)nch * 256);
+            hipLaunchKernelGGL(k_colscan_apply, dim3(nch), dim3(256), 0, 0, counts, ntiles, (const u32*)sums, (const u32*)sums + (size_t)nch * 256, offsets); });
         timeit("scatter (2-kernel form)", [&] { hipLaunchKernelGGL((k_radix_scatter<u8, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, 0, lo, hi, n, d, ntiles, offsets, lo2, hi2); });
         if (SB + 8 * pass + 8 <= 64) timeit("scatter NoHi (8 B records)", [&] { hipLaunchKernelGGL((k_radix_scatter<NoHi, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, 0, lo, (const NoHi*)nullptr, n, d, ntiles, offsets, lo3, (NoHi*)nullptr); });
         CK(hipMemset(ghist, 0, MAX_PASSES * 256 * 8)); CK(hipMemset(ctl, 0, (MAX_PASSES * 128 + 16) * 4)); CK(hipMemset(status, 0, (size_t)ntiles * 256 * 8));
