@@ -11,6 +11,8 @@
 // (v_mbcnt); per-wave counts are then scanned across waves and digits. Elements are staged through LDS in
 // sorted order so every digit's run leaves the tile as one contiguous global write.
 #pragma once
+#include <type_traits>
+
 #include "kernels_encode.hpp"
 
 namespace cblx {
@@ -199,13 +201,13 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const u64* __restric
     const u32 n_tile = (u32)((n - tbase) < (u64)RDX_TILE ? (n - tbase) : (u64)RDX_TILE);
     u32* my = s_wcnt + w * 256;
     u64 klo[RDX_ITEMS];
-    u32 khi[RDX_ITEMS];
+    typename std::conditional<std::is_same<HiT, u64>::value, u64, u32>::type khi[RDX_ITEMS];
 #pragma unroll
     for (int j = 0; j < RDX_ITEMS; ++j) {
         const u32 e = w * (64 * RDX_ITEMS) + j * 64 + lane;
         const u64 idx = e < n_tile ? tbase + e : tbase;
         klo[j] = lo[idx];
-        khi[j] = (u32)ld_hi<HiT>(hi, idx);
+        khi[j] = ld_hi<HiT>(hi, idx);
     }
 #pragma unroll
     for (int j = 0; j < RDX_ITEMS; ++j) {
