@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--canonical", action="store_true")
-    ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
