@@ -66,6 +66,9 @@ SIGNATURES = {
     "cblx_merge_assign": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cblx_export_buckets": (C.c_int, [C.c_void_p, BUCKET_CB, C.c_void_p]),
     "cblx_contains_seq": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cblx_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "cblx_checksum_words_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cblx_validate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
     "cblx_get_consts": (C.c_int, [C.c_void_p, C.POINTER(Consts)]),
     "cblx_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_uint32,
                                    C.POINTER(C.c_uint32)]),
@@ -255,6 +258,23 @@ class CBL:
 
         self._chk(self._L.cblx_export_buckets(self._h, BUCKET_CB(cb), None))
         return out
+
+    def checksum(self) -> int:
+        """Order-independent 64-bit checksum of the set (sum of a hash of every resident word)."""
+        v = C.c_uint64(0)
+        self._chk(self._L.cblx_checksum(self._h, C.byref(v)))
+        return v.value
+
+    def checksum_words_device(self, d_lo, d_hi, n: int) -> int:
+        v = C.c_uint64(0)
+        self._chk(self._L.cblx_checksum_words_device(self._h, _ptr(d_lo), _ptr(d_hi), n, C.byref(v)))
+        return v.value
+
+    def validate(self, strict: bool = True) -> int:
+        """Number of structural violations in the resident buckets (0 = sound)."""
+        v = C.c_uint64(0)
+        self._chk(self._L.cblx_validate(self._h, int(strict), C.byref(v)))
+        return v.value
 
     def stage_times(self) -> dict:
         """{stage: (ms, launches)} accumulated HIP-event time per pipeline stage (needs profile=True)."""

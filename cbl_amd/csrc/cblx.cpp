@@ -1035,6 +1035,47 @@ int cblx_contains_seq(cblx_ctx* c, const uint8_t* seq, uint64_t len, uint8_t* ou
         collect_events(c);
     });
 }
+int cblx_checksum(cblx_ctx* c, uint64_t* sum) {
+    return guard(c, [&] {
+        flush(c);
+        *sum = 0;
+        const Resident& r = c->res;
+        if (r.count == 0) return;
+        Buf<u64> res_off(c->pool, r.nb + 1), out(c->pool, 1);
+        u64 tot = exclusive_scan<u64>(c, r.cnt.get(), r.nb, res_off.get());
+        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, res_off.get() + r.nb, tot);
+        CBLX_HIP(hipMemsetAsync(out.get(), 0, 8, c->stream));
+        hipLaunchKernelGGL(k_checksum_index, dim3(256 * 16), dim3(256), 0, c->stream, tot, r.nb, res_off.get(), r.prefix.get(), r.start.get(), r.a_lo.get(),
+                           c->P.wide_suffix() ? r.a_hi.get() : (const u64*)nullptr, c->P.SB, out.get());
+        CBLX_HIP(hipGetLastError());
+        *sum = d2h<u64>(c, out.get());
+    });
+}
+int cblx_checksum_words_device(cblx_ctx* c, const uint64_t* d_lo, const uint64_t* d_hi, uint64_t n, uint64_t* sum) {
+    return guard(c, [&] {
+        *sum = 0;
+        if (n == 0) return;
+        Buf<u64> out(c->pool, 1);
+        CBLX_HIP(hipMemsetAsync(out.get(), 0, 8, c->stream));
+        hipLaunchKernelGGL(k_checksum_words, dim3(256 * 16), dim3(256), 0, c->stream, d_lo, d_hi, n, out.get());
+        CBLX_HIP(hipGetLastError());
+        *sum = d2h<u64>(c, out.get());
+    });
+}
+int cblx_validate(cblx_ctx* c, int strict, uint64_t* violations) {
+    return guard(c, [&] {
+        flush(c);
+        *violations = 0;
+        const Resident& r = c->res;
+        if (r.nb == 0) return;
+        Buf<u64> bad(c->pool, 1);
+        CBLX_HIP(hipMemsetAsync(bad.get(), 0, 8, c->stream));
+        hipLaunchKernelGGL(k_validate, grid1(r.nb * 64, 256), dim3(256), 0, c->stream, r.nb, r.start.get(), r.cnt.get(), r.kind.get(), r.a_lo.get(),
+                           c->P.wide_suffix() ? r.a_hi.get() : (const u64*)nullptr, c->P.SB, (u32)(strict != 0), bad.get());
+        CBLX_HIP(hipGetLastError());
+        *violations = d2h<u64>(c, bad.get());
+    });
+}
 int cblx_get_consts(const cblx_ctx* c, cblx_consts* o) {
     if (!c || !o) return CBLX_EINVAL;
     o->kmer_bits = c->P.KB; o->pos_bits = c->P.POS; o->word_bits = c->P.WB; o->suffix_bits = c->P.SB; o->bytes = c->P.BYTES;

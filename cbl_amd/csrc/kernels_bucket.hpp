@@ -771,6 +771,74 @@ __global__ void k_contains(const u64* __restrict__ w_lo, const HiT* __restrict__
     out[i] = found;
 }
 
+// ---- order-independent checksum and structural validation (full-size parity properties) ------------------------------
+__device__ __forceinline__ u64 mix64(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ u64 word_hash(u64 lo, u64 hi) { return mix64(lo + 0x9E3779B97F4A7C15ull) + mix64(hi ^ 0xD1B54A32D192ED03ull); }
+// sum of word_hash over n words given as lo/hi arrays (hi may be null)
+__global__ void k_checksum_words(const u64* __restrict__ lo, const u64* __restrict__ hi, u64 n, u64* __restrict__ out) {
+    u64 s = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) s += word_hash(lo[i], hi ? hi[i] : 0ull);
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)out, (unsigned long long)s);
+}
+// same sum over the resident index: word = prefix << SB | suffix
+__global__ void k_checksum_index(u64 nelem, u64 nb, const u64* __restrict__ res_off, const u32* __restrict__ bucket_prefix,
+                                 const u64* __restrict__ start, const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u32 SB,
+                                 u64* __restrict__ out) {
+    u64 s = 0;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < nelem; e += (u64)gridDim.x * blockDim.x) {
+        u64 l = 0, h = nb;
+        while (h - l > 1) {
+            u64 mid = (l + h) >> 1;
+            if (res_off[mid] <= e) l = mid; else h = mid;
+        }
+        const u64 j = e - res_off[l];
+        u128 sfx = (u128)a_lo[start[l] + j];
+        if (a_hi) sfx |= (u128)a_hi[start[l] + j] << 64;
+        sfx &= (((u128)1) << SB) - 1;
+        const u128 word = ((u128)bucket_prefix[l] << SB) | sfx;
+        s += word_hash((u64)word, (u64)(word >> 64));
+    }
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)out, (unsigned long long)s);
+}
+// one wave per bucket: Trie buckets strictly ascending (hence distinct), Vec buckets pairwise distinct, kinds consistent
+// with the insert-only rule when `strict` (Vec <= 1024 < Trie). bad[0] += violations.
+__global__ __launch_bounds__(256) void k_validate(u64 nb, const u64* __restrict__ start, const u32* __restrict__ count,
+                                                  const u8* __restrict__ kind, const u64* __restrict__ a_lo,
+                                                  const u64* __restrict__ a_hi, u32 SB, u32 strict, u64* __restrict__ bad) {
+    const u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u32 lane = threadIdx.x & 63;
+    if (r >= nb) return;
+    const u64 s0 = start[r];
+    const u32 c = count[r];
+    const u128 M = (((u128)1) << SB) - 1;
+    auto at = [&](u32 j) -> u128 {
+        u128 v = a_lo[s0 + j];
+        if (a_hi) v |= (u128)a_hi[s0 + j] << 64;
+        return v & M;
+    };
+    u64 b = 0;
+    if (lane == 0) {
+        if (c == 0) ++b;
+        if (strict && ((kind[r] == KIND_TRIE) != (c > VEC_THRESHOLD))) ++b;
+    }
+    if (kind[r] == KIND_TRIE) {
+        for (u32 j = lane + 1; j < c; j += 64) b += at(j - 1) >= at(j) ? 1 : 0;
+    } else {
+        for (u32 j = lane; j < c; j += 64) {
+            const u128 x = at(j);
+            for (u32 i = 0; i < j; ++i) b += at(i) == x ? 1 : 0;
+        }
+    }
+    b = wave_reduce_sum(b);
+    if (lane == 0 && b) atomicAdd((unsigned long long*)bad, (unsigned long long)b);
+}
+
 __global__ void k_sum_u32(const u32* __restrict__ v, u64 n, u64* __restrict__ out) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 s = i < n ? v[i] : 0;

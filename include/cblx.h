@@ -115,6 +115,14 @@ int cblx_export_buckets(cblx_ctx* ctx, cblx_bucket_cb cb, void* user);
 /* CBL::contains_seq (src/cbl.rs:311-324): one byte (0/1) per k-mer of one sequence, into `out[cap]`. */
 int cblx_contains_seq(cblx_ctx* ctx, const uint8_t* seq, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* n);
 
+/* Full-size parity properties (no reference counterpart): an order-independent checksum of the set (sum over the
+ * resident words of a 64-bit hash, mod 2^64), the same sum over a device array of words, and a structural check of the
+ * resident buckets (Trie buckets strictly ascending, Vec buckets pairwise distinct, and with `strict` the insert-only
+ * rule Vec <= 1024 < Trie of src/wordset/mod.rs:240-244). */
+int cblx_checksum(cblx_ctx* ctx, uint64_t* sum);
+int cblx_checksum_words_device(cblx_ctx* ctx, const uint64_t* d_lo, const uint64_t* d_hi, uint64_t n, uint64_t* sum);
+int cblx_validate(cblx_ctx* ctx, int strict, uint64_t* violations);
+
 /* Derived constants (src/cbl.rs:16-32,65-67), for shims and tests. */
 typedef struct cblx_consts {
     uint32_t kmer_bits, pos_bits, word_bits, suffix_bits, bytes, chunk_size, threshold, reserved;

@@ -321,3 +321,56 @@ def test_sharded_builder_single_rank_nccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ---- BASELINE.json full size, through size-independent properties --------------------------------------------------
+def _word_hash(w):
+    M = (1 << 64) - 1
+
+    def mix(z):
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    return (mix(((w & M) + 0x9E3779B97F4A7C15) & M) + mix((w >> 64) ^ 0xD1B54A32D192ED03)) & M
+
+
+def test_checksum_matches_oracle_small():
+    _need_gpu()
+    rng = random.Random(4)
+    for k, pb in ((31, 24), (59, 28), (9, 4)):
+        g, o = cbl_amd.CBL(k, pb), Oracle(k, pb)
+        for _ in range(20):
+            s = _rand_seq(rng, 400)
+            g.insert_seq(s), o.insert_seq(s)
+        assert g.checksum() == sum(_word_hash(w) for w in o.iter_words()) & ((1 << 64) - 1)
+        assert g.validate() == 0
+
+
+@pytest.mark.parametrize("k,pb,nreads,L", [(31, 24, 10_000_000, 150)])
+def test_full_size_properties(k, pb, nreads, L):
+    """cfg 2 at full size (1.2 G k-mers): set checksum == checksum of the transformed word stream (no k-mer repeats in
+    this stream, checked via count), buckets structurally sound, sampled reads all present, foreign reads absent,
+    re-inserting everything is idempotent (count and checksum unchanged)."""
+    _need_gpu()
+    d_b, d_o = synth.reads_torch(42, nreads, L, device="cuda")
+    n_kmers = nreads * (L - k + 1)
+    g = cbl_amd.CBL(k, pb)
+    g.insert_seqs_device(d_b, d_o, nreads)
+    count, cs = g.count(), g.checksum()
+    assert g.validate() == 0
+    lo = torch.empty(n_kmers + 1, dtype=torch.int64, device="cuda")
+    hi = torch.empty(n_kmers + 1, dtype=torch.int64, device="cuda")
+    assert g.seq_words_device(d_b, d_o, nreads, lo, hi, n_kmers) == n_kmers
+    assert count <= n_kmers
+    if count == n_kmers:
+        assert cs == g.checksum_words_device(lo, hi, n_kmers)
+    del lo, hi
+    hb, ho = synth.reads(42, 3, L, first_read=nreads - 3)
+    for i in range(3):
+        assert all(g.contains_seq(hb[i * L : (i + 1) * L].tobytes()))
+    fb, _ = synth.reads(4242, 2, L)
+    assert not any(g.contains_seq(fb[:L].tobytes()))
+    g.insert_seqs_device(d_b, d_o, nreads)  # idempotence (resident + new through the incremental path)
+    assert (g.count(), g.checksum()) == (count, cs)
+    assert g.validate() == 0
