@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--canonical", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="dev: run the N-GPU code path on a 1-rank RCCL group")
     args = ap.parse_args()
 
     import torch
@@ -84,11 +85,15 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world > 1:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as ge
 
@@ -105,7 +110,7 @@ def main():
     torch.cuda.synchronize()
 
     cbl = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank, profile=True)
-    engine = sharded.ShardedBuilder(cbl, dist) if world > 1 else None
+    engine = sharded.ShardedBuilder(cbl, dist) if dist is not None else None
 
     def step():
         cbl.clear()

@@ -33,7 +33,7 @@ class Params(C.Structure):
 
 class Consts(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("kmer_bits", "pos_bits", "word_bits", "suffix_bits", "bytes", "chunk_size",
-                                          "threshold", "reserved")]
+                                          "threshold", "hi_bytes")]
 
 
 BUCKET_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
@@ -243,7 +243,7 @@ class CBL:
     def consts(self) -> dict:
         c = Consts()
         self._chk(self._L.cblx_get_consts(self._h, C.byref(c)))
-        return {n: getattr(c, n) for n, _ in Consts._fields_ if n != "reserved"}
+        return {n: getattr(c, n) for n, _ in Consts._fields_}
 
     def buckets(self):
         """[(prefix, kind, [suffix, ...])] in ascending prefix order; kind 0 = Vec (stored order), 1 = Trie (ascending)."""

@@ -202,6 +202,8 @@ inline size_t hi_elem_size(const Consts& P) { return !P.has_hi() ? 0 : (!P.wide_
 struct Records {
     Buf<u64> lo, lo2;
     Buf<u8> hi, hi2;  // raw bytes; element size = hi_elem_size
+    const u64* ext_lo = nullptr;  // optional caller-owned source of the FIRST pass (no resident words in front)
+    const void* ext_hi = nullptr;
 };
 
 template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
@@ -209,10 +211,14 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
     const Consts& P = c->P;
     Resident nr;
     if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "more than 2^32-16 words in one index are not supported yet");
-    u64* lo = rec.lo.get();
-    u64* lo2 = rec.lo2.get();
-    HiT* hi = (HiT*)rec.hi.get();
-    HiT* hi2 = (HiT*)rec.hi2.get();
+    // ping-pong: A = rec.lo/hi, B = rec.lo2/hi2. With an external source pass 0 reads it and writes A.
+    const u64* lo = rec.ext_lo ? rec.ext_lo : rec.lo.get();
+    const HiT* hi = rec.ext_lo ? (const HiT*)rec.ext_hi : (const HiT*)rec.hi.get();
+    u64* lo2 = rec.ext_lo ? rec.lo.get() : rec.lo2.get();
+    HiT* hi2 = rec.ext_lo ? (HiT*)rec.hi.get() : (HiT*)rec.hi2.get();
+    u64* lo_other = rec.ext_lo ? rec.lo2.get() : rec.lo.get();   // the buffer that becomes the destination after pass 0
+    HiT* hi_other = rec.ext_lo ? (HiT*)rec.hi2.get() : (HiT*)rec.hi.get();
+    auto advance = [&]() { const u64* nl = lo2; const HiT* nh = hi2; lo2 = lo_other; hi2 = hi_other; lo_other = const_cast<u64*>(nl); hi_other = const_cast<HiT*>(nh); lo = nl; hi = nh; };
     // -- KRN-2: stable LSD radix partition on the PREFIX_BITS above SUFFIX_BITS. Default: per pass a tile histogram, a
     //    device-wide scan and the LDS-staged scatter. CBLX_ONESWEEP=1 selects the single-read form (one up-front digit
     //    histogram + decoupled look-back), which on MI355X is currently no faster: an agent-scope look-back hop costs
@@ -231,8 +237,7 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
                   colscan(c, counts.get(), ntiles, offsets.get(), scratch); }
                 { StageTimer t(c, ST_SCATTER);
                   hipLaunchKernelGGL((k_radix_scatter<HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits}, ntiles, offsets.get(), lo2, hi2); }
-                std::swap(lo, lo2);
-                std::swap(hi, hi2);
+                advance();
             }
             CBLX_HIP(hipGetLastError());
         } else {
@@ -249,13 +254,12 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
                 { StageTimer t(c, ST_SCATTER);
                   hipLaunchKernelGGL((k_onesweep<HiT, DigitBits>), dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits},
                                      ghist.get() + pass * 256, ctl.get() + pass * 128, ntiles, status.get(), pass + 1, lo2, hi2, ctl.get() + MAX_PASSES * 128, 0u); }
-                std::swap(lo, lo2);
-                std::swap(hi, hi2);
+                advance();
             }
             CBLX_HIP(hipGetLastError());
             if (d2h<u32>(c, ctl.get() + MAX_PASSES * 128)) throw Error(CBLX_EDEVICE, "radix partition: look-back timed out");
         }
-        if (npass & 1) { std::swap(rec.lo, rec.lo2); std::swap(rec.hi, rec.hi2); }
+        if (lo == rec.lo2.get()) { std::swap(rec.lo, rec.lo2); std::swap(rec.hi, rec.hi2); }  // final data -> rec.lo/hi
     }
     rec.lo2.reset();
     rec.hi2.reset();
@@ -291,8 +295,8 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
     hipLaunchKernelGGL(k_classify, grid1(nb, 256), dim3(256), 0, c->stream, nb, C::WS ? 512u : 1024u, nr.prefix.get(), nr.start.get(), c->res.view(),
                        res_count.get(), res_kind.get(), nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get());
     std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
-    u64* a_lo = lo;
-    HiT* a_hi = hi;
+    u64* a_lo = rec.lo.get();
+    HiT* a_hi = (HiT*)rec.hi.get();
     if (ln[CLS_SMALL]) {
         StageTimer t(c, ST_BSMALL);
         hipLaunchKernelGGL((k_bucket_small<C::WS, HiT>), grid1((u64)ln[CLS_SMALL] * 64, 256), dim3(256), 0, c->stream,
@@ -814,22 +818,22 @@ int cblx_insert_seqs_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t*
 }
 int cblx_flush(cblx_ctx* c) { return guard(c, [&] { flush(c); }); }
 
-int cblx_insert_words_device(cblx_ctx* c, const uint64_t* d_lo, const uint64_t* d_hi, uint64_t n) {
+int cblx_insert_words_device(cblx_ctx* c, const uint64_t* d_lo, const void* d_hi, uint64_t n) {
     return guard(c, [&] {
         flush(c);
         if (n == 0) return;
         if (!d_lo || (c->P.has_hi() && !d_hi)) throw Error(CBLX_EINVAL, "null argument");
         dispatch(c->P, [&](auto cfg) {
             typedef decltype(cfg) C;
-            typedef typename C::HiT HiT;
             Records rec;
             const u64 base = begin_records<C>(c, rec, n);
-            CBLX_HIP(hipMemcpyAsync(rec.lo.get() + base, d_lo, n * 8, hipMemcpyDeviceToDevice, c->stream));
-            if constexpr (std::is_same<HiT, u64>::value) {
-                CBLX_HIP(hipMemcpyAsync((u64*)rec.hi.get() + base, d_hi, n * 8, hipMemcpyDeviceToDevice, c->stream));
-            } else if constexpr (std::is_same<HiT, u8>::value) {
-                // narrow the caller's u64 hi words to the 1-byte-per-record layout
-                hipLaunchKernelGGL(k_narrow_u8, grid1(n, 256), dim3(256), 0, c->stream, d_hi, rec.hi.get() + base, n);
+            if (base == 0) {  // empty index: the first partition pass reads the caller's arrays in place
+                rec.ext_lo = d_lo;
+                rec.ext_hi = d_hi;
+            } else {
+                const size_t hs = hi_elem_size(c->P);
+                CBLX_HIP(hipMemcpyAsync(rec.lo.get() + base, d_lo, n * 8, hipMemcpyDeviceToDevice, c->stream));
+                if (hs) CBLX_HIP(hipMemcpyAsync(rec.hi.get() + base * hs, d_hi, n * hs, hipMemcpyDeviceToDevice, c->stream));
             }
             pipeline<C>(c, rec, base + n);
             c->kmers_inserted += n;
@@ -838,12 +842,12 @@ int cblx_insert_words_device(cblx_ctx* c, const uint64_t* d_lo, const uint64_t* 
         CBLX_HIP(hipStreamSynchronize(c->stream));
     });
 }
-int cblx_seq_words_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n, uint64_t* d_lo, uint64_t* d_hi,
+int cblx_seq_words_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n, uint64_t* d_lo, void* d_hi,
                           uint64_t cap, uint64_t* n_words) {
     return guard(c, [&] {
         if (n_words) *n_words = 0;
         if (n == 0) return;
-        if (!d_bases || !d_offsets || !d_lo) throw Error(CBLX_EINVAL, "null argument");
+        if (!d_bases || !d_offsets || !d_lo || (c->P.has_hi() && !d_hi)) throw Error(CBLX_EINVAL, "null argument");
         check_aligned16(d_bases, "d_bases");
         dispatch(c->P, [&](auto cfg) {
             typedef decltype(cfg) C;
@@ -853,30 +857,16 @@ int cblx_seq_words_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t* d
             if (n_words) *n_words = pl.n_kmers;
             if (pl.n_kmers > cap) throw Error(CBLX_ERANGE, "output capacity too small");
             if (pl.n_kmers == 0) return;
-            if constexpr (std::is_same<HiT, u8>::value) {
-                Buf<u8> tmp(c->pool, pl.n_kmers + 8);
-                encode<C>(c, d_bases, pl, d_lo, tmp.get(), 0);
-                if (d_hi) {
-                    hipLaunchKernelGGL(k_widen_u8, grid1(pl.n_kmers, 256), dim3(256), 0, c->stream, tmp.get(), d_hi, pl.n_kmers);
-                }
-                CBLX_HIP(hipStreamSynchronize(c->stream));
-            } else if constexpr (std::is_same<HiT, u64>::value) {
-                if (!d_hi) throw Error(CBLX_EINVAL, "d_hi is required when 2K + POS_BITS > 64");
-                encode<C>(c, d_bases, pl, d_lo, d_hi, 0);
-                CBLX_HIP(hipStreamSynchronize(c->stream));
-            } else {
-                encode<C>(c, d_bases, pl, d_lo, (NoHi*)nullptr, 0);
-                if (d_hi) CBLX_HIP(hipMemsetAsync(d_hi, 0, pl.n_kmers * 8, c->stream));
-                CBLX_HIP(hipStreamSynchronize(c->stream));
-            }
+            encode<C>(c, d_bases, pl, d_lo, (HiT*)d_hi, 0);
+            CBLX_HIP(hipStreamSynchronize(c->stream));
         });
         collect_events(c);
     });
 }
 
 // Stable partition of words by destination prefix range (multi-GPU exchange step).
-int cblx_partition_words_device(cblx_ctx* c, const uint64_t* d_lo, const uint64_t* d_hi, uint64_t n, const uint32_t* bounds, uint32_t nd,
-                                uint64_t* d_out_lo, uint64_t* d_out_hi, uint64_t* counts) {
+int cblx_partition_words_device(cblx_ctx* c, const uint64_t* d_lo, const void* d_hi, uint64_t n, const uint32_t* bounds, uint32_t nd,
+                                uint64_t* d_out_lo, void* d_out_hi, uint64_t* counts) {
     return guard(c, [&] {
         if (nd < 1 || nd > MAX_DEST) throw Error(CBLX_EINVAL, "number of destinations must be in [1, 16]");
         if (!counts || (nd > 1 && !bounds)) throw Error(CBLX_EINVAL, "null argument");
@@ -890,8 +880,8 @@ int cblx_partition_words_device(cblx_ctx* c, const uint64_t* d_lo, const uint64_
         for (u32 i = 1; i + 1 < nd; ++i) if (bounds[i] < bounds[i - 1]) throw Error(CBLX_EINVAL, "bounds must be ascending");
         const u32 ntiles = (u32)ceil_div(n, RDX_TILE);
         Buf<u32> cnt(c->pool, (size_t)256 * ntiles), off(c->pool, (size_t)256 * ntiles), scratch;
-        auto run = [&](auto hi_tag) {
-            typedef decltype(hi_tag) H;
+        dispatch(c->P, [&](auto cfg) {
+            typedef typename decltype(cfg)::HiT H;
             const H* hi = (const H*)d_hi;
             H* ohi = (H*)d_out_hi;
             { StageTimer t(c, ST_HIST);
@@ -901,8 +891,7 @@ int cblx_partition_words_device(cblx_ctx* c, const uint64_t* d_lo, const uint64_
             { StageTimer t(c, ST_SCATTER);
               hipLaunchKernelGGL((k_radix_scatter<H, DigitDest>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, d_lo, hi, n, fn, ntiles, off.get(), d_out_lo, ohi); }
             CBLX_HIP(hipGetLastError());
-        };
-        if (c->P.has_hi()) run((u64)0); else run(NoHi());
+        });
         // start of every destination = offset of its first tile
         std::vector<u64> starts(nd + 1, n);
         {
@@ -1051,13 +1040,16 @@ int cblx_checksum(cblx_ctx* c, uint64_t* sum) {
         *sum = d2h<u64>(c, out.get());
     });
 }
-int cblx_checksum_words_device(cblx_ctx* c, const uint64_t* d_lo, const uint64_t* d_hi, uint64_t n, uint64_t* sum) {
+int cblx_checksum_words_device(cblx_ctx* c, const uint64_t* d_lo, const void* d_hi, uint64_t n, uint64_t* sum) {
     return guard(c, [&] {
         *sum = 0;
         if (n == 0) return;
         Buf<u64> out(c->pool, 1);
         CBLX_HIP(hipMemsetAsync(out.get(), 0, 8, c->stream));
-        hipLaunchKernelGGL(k_checksum_words, dim3(256 * 16), dim3(256), 0, c->stream, d_lo, d_hi, n, out.get());
+        dispatch(c->P, [&](auto cfg) {
+            typedef typename decltype(cfg)::HiT H;
+            hipLaunchKernelGGL(k_checksum_words<H>, dim3(256 * 16), dim3(256), 0, c->stream, d_lo, (const H*)d_hi, n, out.get());
+        });
         CBLX_HIP(hipGetLastError());
         *sum = d2h<u64>(c, out.get());
     });
@@ -1079,7 +1071,7 @@ int cblx_validate(cblx_ctx* c, int strict, uint64_t* violations) {
 int cblx_get_consts(const cblx_ctx* c, cblx_consts* o) {
     if (!c || !o) return CBLX_EINVAL;
     o->kmer_bits = c->P.KB; o->pos_bits = c->P.POS; o->word_bits = c->P.WB; o->suffix_bits = c->P.SB; o->bytes = c->P.BYTES;
-    o->chunk_size = CHUNK_KMERS; o->threshold = VEC_THRESHOLD; o->reserved = 0;
+    o->chunk_size = CHUNK_KMERS; o->threshold = VEC_THRESHOLD; o->hi_bytes = (uint32_t)hi_elem_size(c->P);
     return CBLX_OK;
 }
 int cblx_stage_times(cblx_ctx* c, const char** names, double* ms, uint64_t* launches, uint32_t cap, uint32_t* n) {

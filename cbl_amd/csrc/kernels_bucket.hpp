@@ -779,9 +779,10 @@ __device__ __forceinline__ u64 mix64(u64 z) {
 }
 __device__ __forceinline__ u64 word_hash(u64 lo, u64 hi) { return mix64(lo + 0x9E3779B97F4A7C15ull) + mix64(hi ^ 0xD1B54A32D192ED03ull); }
 // sum of word_hash over n words given as lo/hi arrays (hi may be null)
-__global__ void k_checksum_words(const u64* __restrict__ lo, const u64* __restrict__ hi, u64 n, u64* __restrict__ out) {
+template <typename HiT>
+__global__ void k_checksum_words(const u64* __restrict__ lo, const HiT* __restrict__ hi, u64 n, u64* __restrict__ out) {
     u64 s = 0;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) s += word_hash(lo[i], hi ? hi[i] : 0ull);
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) s += word_hash(lo[i], ld_hi<HiT>(hi, i));
     s = wave_reduce_sum(s);
     if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)out, (unsigned long long)s);
 }
@@ -850,13 +851,6 @@ __global__ void k_fill_u32(u32* p, u64 n, u32 v) {
     if (i < n) p[i] = v;
 }
 __global__ void k_set_u64(u64* p, u64 v) { *p = v; }
-__global__ void k_narrow_u8(const u64* __restrict__ in, u8* __restrict__ out, u64 n) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (u8)in[i];
-}
-__global__ void k_widen_u8(const u8* __restrict__ in, u64* __restrict__ out, u64 n) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i];
-}
+
 
 }  // namespace cblx

@@ -49,7 +49,9 @@ class GpuEngine:
         self.cbl = cbl
         self.torch = torch
         c = cbl.consts()
-        self.sb, self.pb, self.has_hi = c["suffix_bits"], cbl.prefix_bits, c["word_bits"] > 64
+        self.sb, self.pb = c["suffix_bits"], cbl.prefix_bits
+        # element type of the hi array follows from K (cblx_consts.hi_bytes): none, uint8 (K = 31) or 64-bit
+        self.hi_dtype = {0: None, 1: torch.uint8, 8: torch.int64}[c["hi_bytes"]]
         self.device = None
 
     def seq_words(self, d_bases, d_offsets, n):
@@ -57,7 +59,7 @@ class GpuEngine:
         self.device = d_bases.device
         cap = int(d_bases.numel())
         lo = torch.empty(cap + 1, dtype=torch.int64, device=self.device)
-        hi = torch.empty(cap + 1, dtype=torch.int64, device=self.device) if self.has_hi else None
+        hi = torch.empty(cap + 1, dtype=self.hi_dtype, device=self.device) if self.hi_dtype is not None else None
         nw = self.cbl.seq_words_device(d_bases, d_offsets, n, lo, hi, cap)
         return lo[:nw], (hi[:nw] if hi is not None else None)
 
@@ -67,12 +69,13 @@ class GpuEngine:
         hb = min(HIST_BITS, self.pb)
         shift = self.sb + self.pb - hb  # bit position of the histogram key inside the word
         slo = lo[::SAMPLE_STRIDE]
+        shi = hi[::SAMPLE_STRIDE].to(torch.int64) if hi is not None else None
         if shift >= 64:
-            key = (hi[::SAMPLE_STRIDE] >> (shift - 64)) & ((1 << hb) - 1)
+            key = (shi >> (shift - 64)) & ((1 << hb) - 1)
         else:
             key = (slo >> shift) & ((1 << (64 - shift)) - 1)
-            if hi is not None and shift + hb > 64:
-                key = key | (hi[::SAMPLE_STRIDE] << (64 - shift))
+            if shi is not None and shift + hb > 64:
+                key = key | (shi << (64 - shift))
             key = key & ((1 << hb) - 1)
         return torch.bincount(key, minlength=1 << hb)
 
@@ -80,7 +83,7 @@ class GpuEngine:
         torch = self.torch
         n = int(lo.numel())
         out_lo = torch.empty(n + 1, dtype=torch.int64, device=lo.device)
-        out_hi = torch.empty(n + 1, dtype=torch.int64, device=lo.device) if hi is not None else None
+        out_hi = torch.empty(n + 1, dtype=hi.dtype, device=lo.device) if hi is not None else None
         counts = self.cbl.partition_words_device(lo, hi, n, bounds, nd, out_lo, out_hi)
         return out_lo[:n], (out_hi[:n] if out_hi is not None else None), counts
 

@@ -70,20 +70,24 @@ int cblx_insert_seqs_device(cblx_ctx* ctx, const uint8_t* d_bases, const uint64_
 /* Materialise everything enqueued so far into the resident index (idempotent). */
 int cblx_flush(cblx_ctx* ctx);
 
-/* WordSet::insert_batch (src/wordset/mod.rs:187-216) on already transformed words, stream order = index
- * order. Word i = (d_hi[i] << 64) | d_lo[i]; d_hi may be NULL when 2K + POS_BITS <= 64. Device pointers. */
-int cblx_insert_words_device(cblx_ctx* ctx, const uint64_t* d_lo, const uint64_t* d_hi, uint64_t n);
+/* Device word arrays (all *_words_device entry points): word i = (hi[i] << 64) | lo[i]. `lo` is uint64_t[]; the element
+ * type of `hi` follows from K like the reference's T (build.rs:34-41) and is reported by cblx_consts.hi_bytes:
+ *   0 -> no hi array (2K + POS_BITS <= 64; pass NULL), 1 -> uint8_t[] (K = 31: 68-bit words), 8 -> uint64_t[] (K >= 33). */
+
+/* WordSet::insert_batch (src/wordset/mod.rs:187-216) on already transformed words, stream order = index order.
+ * On an empty index the first partition pass reads the caller's arrays in place (no copy). */
+int cblx_insert_words_device(cblx_ctx* ctx, const uint64_t* d_lo, const void* d_hi, uint64_t n);
 /* CBL::get_seq_words over every chunk of every sequence (src/cbl.rs:239-289), no insertion: writes the
  * words in stream order to d_lo/d_hi (device, capacity `cap` words) and their number to *n_words. */
 int cblx_seq_words_device(cblx_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n,
-                          uint64_t* d_lo, uint64_t* d_hi, uint64_t cap, uint64_t* n_words);
+                          uint64_t* d_lo, void* d_hi, uint64_t cap, uint64_t* n_words);
 
 /* Multi-GPU exchange step (no reference counterpart; the reference is single-process): STABLE partition of n words
  * by destination = #{i : bounds[i] <= prefix(word)}, nd destinations (<= 16), bounds[nd-1] ascending prefix values
  * (host). Destination d's words land contiguously, in input order, at d_out[sum(counts[0..d])..]; counts[nd] (host)
- * receives the run lengths. Device pointers for words; d_hi/d_out_hi may be NULL when 2K + POS_BITS <= 64. */
-int cblx_partition_words_device(cblx_ctx* ctx, const uint64_t* d_lo, const uint64_t* d_hi, uint64_t n, const uint32_t* bounds,
-                                uint32_t nd, uint64_t* d_out_lo, uint64_t* d_out_hi, uint64_t* counts);
+ * receives the run lengths. Device word arrays as above. */
+int cblx_partition_words_device(cblx_ctx* ctx, const uint64_t* d_lo, const void* d_hi, uint64_t n, const uint32_t* bounds,
+                                uint32_t nd, uint64_t* d_out_lo, void* d_out_hi, uint64_t* counts);
 
 /* CBL::count / is_empty / is_canonical (src/cbl.rs:164-177). */
 int cblx_count(cblx_ctx* ctx, uint64_t* out);
@@ -120,12 +124,12 @@ int cblx_contains_seq(cblx_ctx* ctx, const uint8_t* seq, uint64_t len, uint8_t* 
  * resident buckets (Trie buckets strictly ascending, Vec buckets pairwise distinct, and with `strict` the insert-only
  * rule Vec <= 1024 < Trie of src/wordset/mod.rs:240-244). */
 int cblx_checksum(cblx_ctx* ctx, uint64_t* sum);
-int cblx_checksum_words_device(cblx_ctx* ctx, const uint64_t* d_lo, const uint64_t* d_hi, uint64_t n, uint64_t* sum);
+int cblx_checksum_words_device(cblx_ctx* ctx, const uint64_t* d_lo, const void* d_hi, uint64_t n, uint64_t* sum);
 int cblx_validate(cblx_ctx* ctx, int strict, uint64_t* violations);
 
 /* Derived constants (src/cbl.rs:16-32,65-67), for shims and tests. */
 typedef struct cblx_consts {
-    uint32_t kmer_bits, pos_bits, word_bits, suffix_bits, bytes, chunk_size, threshold, reserved;
+    uint32_t kmer_bits, pos_bits, word_bits, suffix_bits, bytes, chunk_size, threshold, hi_bytes;
 } cblx_consts;
 int cblx_get_consts(const cblx_ctx* ctx, cblx_consts* out);
 

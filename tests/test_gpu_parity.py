@@ -35,6 +35,27 @@ def _concat(seqs):
     return bases, offsets
 
 
+def _hi_tensor(g, n):
+    hb = g.consts()["hi_bytes"]
+    return None if hb == 0 else torch.zeros(n, dtype=torch.uint8 if hb == 1 else torch.int64, device="cuda")
+
+
+def _hi_from_words(g, words):
+    hb = g.consts()["hi_bytes"]
+    if hb == 0:
+        return None
+    a = np.array([w >> 64 for w in words], dtype=np.uint64)
+    return torch.from_numpy(a.astype(np.uint8) if hb == 1 else a.astype(np.int64)).cuda()
+
+
+def _words_from(lo, hi):
+    lo = lo.cpu().numpy().astype(np.uint64)
+    if hi is None:
+        return [int(a) for a in lo]
+    hi = hi.cpu().numpy().astype(np.uint64)
+    return [int(a) | (int(b) << 64) for a, b in zip(lo, hi)]
+
+
 def _gpu_words(g, seqs):
     bases, offsets = _concat(seqs)
     nmax = int(len(bases))
@@ -42,11 +63,9 @@ def _gpu_words(g, seqs):
     d_b = torch.from_numpy(np.concatenate([bases, np.zeros(pad, np.uint8)])).cuda()
     d_o = torch.from_numpy(offsets.astype(np.int64)).cuda()
     d_lo = torch.zeros(nmax + 1, dtype=torch.int64, device="cuda")
-    d_hi = torch.zeros(nmax + 1, dtype=torch.int64, device="cuda")
+    d_hi = _hi_tensor(g, nmax + 1)
     n = g.seq_words_device(d_b, d_o, len(seqs), d_lo, d_hi, nmax)
-    lo = d_lo[:n].cpu().numpy().astype(np.uint64)
-    hi = d_hi[:n].cpu().numpy().astype(np.uint64)
-    return [int(a) | (int(b) << 64) for a, b in zip(lo, hi)]
+    return _words_from(d_lo[:n], None if d_hi is None else d_hi[:n])
 
 
 def _oracle_words(o, seqs):
@@ -259,8 +278,11 @@ def test_insert_words_device_is_insert_batch():
             o.insert_seq(s)
             words += o.seq_words(s)
         lo = torch.from_numpy(np.array([w & (2**64 - 1) for w in words], dtype=np.uint64).astype(np.int64)).cuda()
-        hi = torch.from_numpy(np.array([w >> 64 for w in words], dtype=np.uint64).astype(np.int64)).cuda()
         g = cbl_amd.CBL(k, pb)
+        hi = _hi_from_words(g, words)
+        g.insert_words_device(lo, hi, len(words))
+        _check_index(g, o)
+        # and on a non-empty index (copy path): insert the same words again -> unchanged
         g.insert_words_device(lo, hi, len(words))
         _check_index(g, o)
 
@@ -279,14 +301,12 @@ def test_partition_words_device_is_stable(k, pb):
     for nd in (1, 2, 5, 8, 16):
         bounds = sorted(prefixes[rng.randrange(len(prefixes))] for _ in range(nd - 1))
         lo = torch.from_numpy(np.array([w & (2**64 - 1) for w in words], dtype=np.uint64).astype(np.int64)).cuda()
-        hi = torch.from_numpy(np.array([w >> 64 for w in words], dtype=np.uint64).astype(np.int64)).cuda()
-        olo, ohi = torch.zeros_like(lo), torch.zeros_like(hi)
+        hi = _hi_from_words(g, words)
+        olo, ohi = torch.zeros_like(lo), (None if hi is None else torch.zeros_like(hi))
         counts = g.partition_words_device(lo, hi, len(words), bounds, nd, olo, ohi)
         dest = [sum(1 for b in bounds if b <= (w >> sb)) for w in words]
         want = [w for d in range(nd) for w, dd in zip(words, dest) if dd == d]
-        got = [int(a) | (int(b) << 64) for a, b in zip(olo.cpu().numpy().astype(np.uint64), ohi.cpu().numpy().astype(np.uint64))]
-        if g.consts()["word_bits"] <= 64:
-            got = [x & (2**64 - 1) for x in got]
+        got = _words_from(olo, ohi)
         assert counts == [dest.count(d) for d in range(nd)]
         assert got == want
 
@@ -360,7 +380,7 @@ def test_full_size_properties(k, pb, nreads, L):
     count, cs = g.count(), g.checksum()
     assert g.validate() == 0
     lo = torch.empty(n_kmers + 1, dtype=torch.int64, device="cuda")
-    hi = torch.empty(n_kmers + 1, dtype=torch.int64, device="cuda")
+    hi = _hi_tensor(g, n_kmers + 1)
     assert g.seq_words_device(d_b, d_o, nreads, lo, hi, n_kmers) == n_kmers
     assert count <= n_kmers
     if count == n_kmers:
