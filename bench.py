@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="dev: run the N-GPU code path on a 1-rank RCCL group")
     args = ap.parse_args()
 
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"  # RCCL's version banner goes to stdout; keep stdout to the one JSON line
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
