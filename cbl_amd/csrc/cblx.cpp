@@ -307,18 +307,26 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
         // fast path (counting sort on the top suffix bits + in-sub-bucket ranking); skewed buckets come back via `retry`
         Buf<u32> retry(c->pool, std::max<u64>(nb, 1)), retry_n(c->pool, 1);
         CBLX_HIP(hipMemsetAsync(retry_n.get(), 0, 4, c->stream));
-        if (ln[CLS_M64])
-            hipLaunchKernelGGL((k_bucket_msd<64, 512, C::WS, HiT>), dim3(ln[CLS_M64]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M64 * nb,
-                               list_n.get() + CLS_M64, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
-        if (ln[CLS_M128])
-            hipLaunchKernelGGL((k_bucket_msd<128, 1024, C::WS, HiT>), dim3(ln[CLS_M128]), dim3(128), 0, c->stream, lists.get() + (size_t)CLS_M128 * nb,
-                               list_n.get() + CLS_M128, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
-        if (ln[CLS_M256])
-            hipLaunchKernelGGL((k_bucket_msd<256, 2048, C::WS, HiT>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb,
-                               list_n.get() + CLS_M256, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
-        if (ln[CLS_M512])
-            hipLaunchKernelGGL((k_bucket_msd<512, 4096, C::WS, HiT>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb,
-                               list_n.get() + CLS_M512, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+        auto msd = [&](auto packed_tag) {
+            constexpr bool PK = decltype(packed_tag)::value;
+            if (ln[CLS_M64])
+                hipLaunchKernelGGL((k_bucket_msd<64, 512, PK, C::WS, HiT>), dim3(ln[CLS_M64]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M64 * nb,
+                                   list_n.get() + CLS_M64, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+            if (ln[CLS_M128])
+                hipLaunchKernelGGL((k_bucket_msd<128, 1024, PK, C::WS, HiT>), dim3(ln[CLS_M128]), dim3(128), 0, c->stream, lists.get() + (size_t)CLS_M128 * nb,
+                                   list_n.get() + CLS_M128, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+            if (ln[CLS_M256])
+                hipLaunchKernelGGL((k_bucket_msd<256, 2048, PK, C::WS, HiT>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb,
+                                   list_n.get() + CLS_M256, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+            if (ln[CLS_M512])
+                hipLaunchKernelGGL((k_bucket_msd<512, 4096, PK, C::WS, HiT>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb,
+                                   list_n.get() + CLS_M512, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+        };
+        if constexpr (!C::WS) {
+            if (P.SB + PK_BITS <= 64) msd(std::true_type()); else msd(std::false_type());
+        } else {
+            msd(std::false_type());
+        }
         const u32 nretry = (ln[CLS_M64] || ln[CLS_M128] || ln[CLS_M256] || ln[CLS_M512]) ? d2h<u32>(c, retry_n.get()) : 0u;
         if (nretry)
             hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(nretry), dim3(512), 0, c->stream, retry.get(), retry_n.get(), nr.start.get(),

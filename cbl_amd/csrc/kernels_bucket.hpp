@@ -351,19 +351,24 @@ template <bool WS> __device__ __forceinline__ bool sfx_less(const Sfx<WS>& a, u3
     return ia < ib;
 }
 
-template <int THREADS, int CAP, bool WS, typename HiT>
+// PACKED (SUFFIX_BITS + 12 <= 64, narrow suffix): an element is ONE u64 = suffix << 12 | stream index, so every LDS
+// access, compare and move handles key and index together (the kernel is LDS-throughput-bound).
+static const u32 PK_BITS = 12;  // CAP <= 4096
+
+template <int THREADS, int CAP, bool PACKED, bool WS, typename HiT>
 __global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ list, const u32* __restrict__ list_n,
                                                         const u64* __restrict__ raw_start, const u8* __restrict__ res_kind,
                                                         u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
                                                         u32* __restrict__ out_count, u8* __restrict__ out_kind,
                                                         u32* __restrict__ retry, u32* __restrict__ retry_n) {
+    static_assert(!(PACKED && WS), "packed elements need a narrow suffix");
+    static_assert(CAP <= (1 << PK_BITS), "stream index must fit PK_BITS");
     constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
     __shared__ u64 s_klo[CAP];
     __shared__ u64 s_khi[WS ? CAP : 1];
-    __shared__ u16 s_idx[CAP];
+    __shared__ u16 s_idx[PACKED ? 1 : CAP];
     __shared__ u32 s_off[CAP + 1];  // sub-bucket counts, then exclusive offsets
     __shared__ u32 s_scan[NW + 1];
-    __shared__ u32 s_bm[CAP / 32];
     __shared__ u32 s_wtot[NW + 1];
     __shared__ u32 s_max;
 
@@ -371,29 +376,32 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ 
     const u32 r = list[blockIdx.x];
     const u64 s0 = raw_start[r];
     const u32 c = (u32)(raw_start[r + 1] - s0);
+    const bool res_trie = res_kind[r] == KIND_TRIE;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const u32 R = (c + THREADS - 1) / THREADS;
-    u32 nbits = 32 - __builtin_clz(c - 1 > 0 ? c - 1 : 1);  // ceil(log2 c), c >= 2
+    const u32 EPW = 64 * R;  // wave-contiguous slices: ballots then compact in stream order
+    u32 nbits = 32 - __builtin_clz(c - 1 > 0 ? c - 1 : 1);  // ceil(log2 c)
     if (nbits > SB) nbits = SB;
-    const u32 NB = 1u << nbits;                              // <= CAP because c <= CAP
+    const u32 NB = 1u << nbits;  // <= CAP because c <= CAP
 
     for (u32 i = tid; i < NB + 1; i += THREADS) s_off[i] = 0;
     if (tid == 0) s_max = 0;
     __syncthreads();
     Sfx<WS> key[ITEMS];
     u32 sub[ITEMS], arr[ITEMS];
+    bool valid[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        const u32 e = j * THREADS + tid;
-        if ((u32)j < R && e < c) {
+        const u32 e = w * EPW + j * 64 + lane;
+        valid[j] = (u32)j < R && e < c;
+        if (valid[j]) {
             key[j] = load_sfx<WS, HiT>(lo, hi, s0 + e, SB);
             sub[j] = sfx_top_bits<WS>(key[j], SB, nbits);
             arr[j] = atomicAdd(&s_off[sub[j]], 1u);
         }
     }
     __syncthreads();
-    // exclusive scan of the NB counts (each thread owns NB/THREADS consecutive entries, at least 1 slot each)
-    {
+    {   // exclusive scan of the NB counts; each thread owns `per` consecutive entries
         const u32 per = (NB + THREADS - 1) / THREADS;
         const u32 b0 = tid * per;
         u32 sum = 0, mx = 0;
@@ -417,67 +425,56 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ 
     // scatter into sub-bucket order (arrival order inside a sub-bucket is arbitrary)
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        const u32 e = j * THREADS + tid;
-        if ((u32)j < R && e < c) {
+        if (valid[j]) {
+            const u32 e = w * EPW + j * 64 + lane;
             const u32 p = s_off[sub[j]] + arr[j];
-            s_klo[p] = key[j].lo;
-            if constexpr (WS) s_khi[p] = key[j].hi;
-            s_idx[p] = (u16)e;
-        }
-    }
-    __syncthreads();
-    // every element ranks itself inside its sub-bucket by (suffix, stream index)
-    u32 fin[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const u32 e = j * THREADS + tid;
-        if ((u32)j < R && e < c) {
-            const u32 a = s_off[sub[j]], b = s_off[sub[j] + 1];
-            u32 rank = 0;
-            for (u32 q = a; q < b; ++q) {
-                Sfx<WS> o;
-                o.lo = s_klo[q];
-                if constexpr (WS) o.hi = s_khi[q];
-                rank += sfx_less<WS>(o, (u32)s_idx[q], key[j], e) ? 1u : 0u;
+            if constexpr (PACKED) {
+                s_klo[p] = (key[j].lo << PK_BITS) | e;
+            } else {
+                s_klo[p] = key[j].lo;
+                if constexpr (WS) s_khi[p] = key[j].hi;
+                s_idx[p] = (u16)e;
             }
-            fin[j] = a + rank;
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const u32 e = j * THREADS + tid;
-        if ((u32)j < R && e < c) {
-            s_klo[fin[j]] = key[j].lo;
-            if constexpr (WS) s_khi[fin[j]] = key[j].hi;
-            s_idx[fin[j]] = (u16)e;
-        }
-    }
-    for (u32 i = tid; i < CAP / 32; i += THREADS) s_bm[i] = 0;
-    __syncthreads();
-    // sorted by (suffix, stream index): slot p (wave-contiguous slices so that ballots give ordered compaction)
-    const u32 EPW = 64 * R;
+    // every element looks at its sub-bucket: rank by (suffix, stream index); head = no equal suffix with a smaller index
+    u32 fin[ITEMS];
     bool head[ITEMS];
     u32 wave_heads = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        const u32 p = w * EPW + j * 64 + lane;
         head[j] = false;
-        if ((u32)j < R && p < c) {
-            key[j].lo = s_klo[p];
-            if constexpr (WS) key[j].hi = s_khi[p];
-            if (p == 0) head[j] = true;
-            else {
-                Sfx<WS> prev;
-                prev.lo = s_klo[p - 1];
-                if constexpr (WS) prev.hi = s_khi[p - 1];
-                head[j] = prev != key[j];
+        fin[j] = 0;
+        if (valid[j]) {
+            const u32 e = w * EPW + j * 64 + lane;
+            const u32 a = s_off[sub[j]], b = s_off[sub[j] + 1];
+            u32 rank = 0;
+            bool dup = false;
+            if constexpr (PACKED) {
+                const u64 me = (key[j].lo << PK_BITS) | e;
+                for (u32 q = a; q < b; ++q) {
+                    const u64 o = s_klo[q];
+                    rank += o < me ? 1u : 0u;
+                    dup |= (o < me) && ((o >> PK_BITS) == key[j].lo);
+                }
+            } else {
+                for (u32 q = a; q < b; ++q) {
+                    Sfx<WS> o;
+                    o.lo = s_klo[q];
+                    if constexpr (WS) o.hi = s_khi[q];
+                    const bool less = sfx_less<WS>(o, (u32)s_idx[q], key[j], e);
+                    rank += less ? 1u : 0u;
+                    dup |= less && o == key[j];
+                }
             }
+            fin[j] = a + rank;
+            head[j] = !dup;
         }
         wave_heads += (u32)__builtin_popcountll(__ballot(head[j]));
     }
     if (lane == 0) s_wtot[w] = wave_heads;
-    __syncthreads();
+    __syncthreads();  // also: every read of the sub-bucket order is done
     if (tid == 0) {
         u32 run = 0;
         for (int ww = 0; ww < NW; ++ww) { u32 t = s_wtot[ww]; s_wtot[ww] = run; run += t; }
@@ -485,8 +482,9 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ 
     }
     __syncthreads();
     const u32 d = s_wtot[NW];
-    const bool trie = d > VEC_THRESHOLD || res_kind[r] == KIND_TRIE;
-    if (trie) {
+    const bool trie = d > VEC_THRESHOLD || res_trie;
+    if (!trie) {
+        // Vec: first occurrences in stream order, straight from registers (slots are in stream order)
         u32 run = s_wtot[w];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -495,31 +493,46 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ 
             run += (u32)__builtin_popcountll(bal);
         }
     } else {
+        // Trie: ascending order. Put every element at its final rank with its head flag, then compact slot by slot.
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (valid[j]) {
+                if constexpr (PACKED) {
+                    s_klo[fin[j]] = (key[j].lo << 1) | (head[j] ? 1ull : 0ull);
+                } else {
+                    s_klo[fin[j]] = key[j].lo;
+                    if constexpr (WS) s_khi[fin[j]] = key[j].hi;
+                    s_idx[fin[j]] = head[j] ? 1 : 0;
+                }
+            }
+        }
+        __syncthreads();
+        u32 wh = 0;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const u32 p = w * EPW + j * 64 + lane;
-            if (head[j]) { const u32 ix = s_idx[p]; atomicOr(&s_bm[ix >> 5], 1u << (ix & 31)); }
+            head[j] = false;
+            if ((u32)j < R && p < c) {
+                if constexpr (PACKED) {
+                    const u64 v = s_klo[p];
+                    head[j] = v & 1ull;
+                    key[j].lo = v >> 1;
+                } else {
+                    key[j].lo = s_klo[p];
+                    if constexpr (WS) key[j].hi = s_khi[p];
+                    head[j] = s_idx[p] != 0;
+                }
+            }
+            wh += (u32)__builtin_popcountll(__ballot(head[j]));
         }
+        if (lane == 0) s_wtot[w] = wh;
         __syncthreads();
-        Sfx<WS> orig[ITEMS];
-        bool keep[ITEMS];
-        u32 wk = 0;
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const u32 e = w * EPW + j * 64 + lane;
-            const bool v = (u32)j < R && e < c;
-            keep[j] = v && ((s_bm[e >> 5] >> (e & 31)) & 1u);
-            if (v) orig[j] = load_sfx<WS, HiT>(lo, hi, s0 + e, SB);
-            wk += (u32)__builtin_popcountll(__ballot(keep[j]));
-        }
-        if (lane == 0) s_wtot[w] = wk;
-        __syncthreads();  // every read of the run is done before any in-place write
         u32 run = 0;
         for (u32 ww = 0; ww < w; ++ww) run += s_wtot[ww];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const u64 bal = __ballot(keep[j]);
-            if (keep[j]) store_sfx<WS, HiT>(lo, hi, s0 + run + mbcnt(bal), orig[j]);
+            const u64 bal = __ballot(head[j]);
+            if (head[j]) store_sfx<WS, HiT>(lo, hi, s0 + run + mbcnt(bal), key[j]);
             run += (u32)__builtin_popcountll(bal);
         }
     }
