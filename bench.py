@@ -37,8 +37,8 @@ def stage_alg_bytes(k: int, pb: int, read_len: int):
     return {
         "chunks": read_len / (read_len - k + 1),             # validity scan reads every base once
         "encode": read_len / (read_len - k + 1) + R,           # read bases, write one record
-        "radix_hist": passes * R,                              # read the record's key per pass
-        "radix_scatter": passes * 2 * R,                       # read + write every record per pass
+        "radix_hist": passes * R,                              # read every record once per pass (passes launches)
+        "radix_scatter": passes * 2 * R,                       # read + write every record once per pass (passes launches)
         "directory": R,                                        # boundary detection reads the sorted records
         "bucket_medium": 2 * sfx,                              # read the run, write the distinct suffixes
         "bucket_small": 2 * sfx,
@@ -150,25 +150,38 @@ def main():
     total_kmers = kmers_per_rank * world * args.steps
     value = total_kmers / dt
 
-    # dominant kernel group of the step and its roofline position
+    # dominant kernel of the step and its roofline position: ALGORITHMIC bytes per launch / average launch time
+    # (HIP events recorded on the ctx's own stream around every launch of that kernel, timed steps only)
     alg = stage_alg_bytes(K, PB, L)
+    kernel_of = {"radix_scatter": "k_radix_scatter", "radix_hist": "k_radix_hist", "encode": "k_encode",
+                 "bucket_medium": "k_bucket_msd", "directory": "k_boundaries+k_bitvector+k_bucket_table", "chunks": "k_scan_invalid+chunk table"}
     cand = {n: ms for n, (ms, _) in stages.items() if n in alg and ms > 0}
     dom = max(cand, key=cand.get) if cand else None
     roofline = None
     if dom:
         ms_total, launches = stages[dom]
-        per_step_ms = ms_total / args.steps
-        bytes_per_step = alg[dom] * kmers_per_rank
-        achieved = bytes_per_step / (per_step_ms * 1e-3) / 1e9
+        launches = max(int(launches), 1)
+        launch_ms = ms_total / launches
+        bytes_per_launch = alg[dom] * kmers_per_rank * args.steps / launches
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        try:  # HBM bytes per launch from the committed PMC passes of this exact configuration (profiles/)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            c = tj["config"]
+            if (c["k"], c["prefix_bits"], c["reads_per_gpu"], c["read_len"]) == (K, PB, NR, L) and tj["kernel"] == kernel_of.get(dom) and world == 1:
+                traffic = tj["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
+        b_alg = survey_b_alg(K, PB, L)
         roofline = {
-            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-            "alg_bytes_per_kmer": round(alg[dom], 3), "ms_per_step": round(per_step_ms, 3),
+            "bound": "hbm", "kernel": kernel_of.get(dom, dom), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "alg_bytes_per_launch": int(bytes_per_launch), "launch_ms_avg": round(launch_ms, 3),
             "launches_per_step": launches / args.steps,
             "whole_path": {  # SURVEY.md §8d accounting over the full step (per GPU)
-                "b_alg_per_kmer": round(survey_b_alg(K, PB, L), 2),
-                "achieved": round(kmers_per_rank * args.steps / dt * survey_b_alg(K, PB, L) / 1e9, 1),
-                "frac": round(kmers_per_rank * args.steps / dt * survey_b_alg(K, PB, L) / 1e9 / HBM_PEAK_GBPS, 4),
+                "b_alg_per_kmer": round(b_alg, 2),
+                "achieved": round(kmers_per_rank * args.steps / dt * b_alg / 1e9, 1),
+                "frac": round(kmers_per_rank * args.steps / dt * b_alg / 1e9 / HBM_PEAK_GBPS, 4),
             },
             "stage_ms_per_step": {n: round(ms / args.steps, 3) for n, (ms, _) in stages.items() if ms > 0},
         }
