@@ -48,6 +48,7 @@ SIGNATURES = {
     "cblx_insert_seq": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64]),
     "cblx_insert_seqs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "cblx_insert_seqs_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "cblx_insert_fastx_file": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]),
     "cblx_flush": (C.c_int, [C.c_void_p]),
     "cblx_insert_words_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "cblx_seq_words_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -154,6 +155,12 @@ class CBL:
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self._chk(self._L.cblx_insert_seqs(self._h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1))
+
+    def insert_fastx_file(self, path) -> int:
+        """`for record in parse_fastx_file(path): insert_seq(record.seq())` (examples/cbl.rs:154-163); returns #records."""
+        n = C.c_uint64(0)
+        self._chk(self._L.cblx_insert_fastx_file(self._h, os.fsencode(path), C.byref(n)))
+        return n.value
 
     def insert_seqs_device(self, d_bases, d_offsets, n: int):
         """Same with inputs resident in HBM (torch uint8 / int64 CUDA tensors or raw device addresses)."""

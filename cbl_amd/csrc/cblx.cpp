@@ -12,6 +12,7 @@
 #include <fstream>
 #include <map>
 #include <memory>
+#include <thread>
 
 #include "kernels_bucket.hpp"
 
@@ -599,29 +600,67 @@ void emit_trie(Sink& s, const SfxView& v, u64 a, u64 b, u32 depth, u32 BYTES) {
     s.varint(c);
     for (u32 k = 0; k < c; ++k) emit_trie(s, v, starts[k], starts[k + 1], depth + 1, BYTES);
 }
+void serialize_bucket(const Consts& P, const HostIndex& h, const SfxView& v, u64 r, Sink& s) {
+    s.varint(h.prefix[r]);
+    const u64 a = h.off[r], b = h.off[r + 1];
+    if (h.kind[r] == KIND_VEC) {             // TrieOrVec::Vec  src/trievec/mod.rs:10-11
+        s.varint(0);
+        s.varint(b - a);
+        for (u64 i = a; i < b; ++i) {
+            s.varint(P.BYTES);               // SlicedInt::serialize -> serialize_bytes  src/sliced_int.rs:110-114
+            u128 x = v.at(i);
+            u8 tmp[16];
+            for (u32 k = 0; k < P.BYTES; ++k) tmp[k] = (u8)(x >> (8 * k));
+            s.raw(tmp, P.BYTES);
+        }
+    } else {                                 // TrieOrVec::Trie(trie, len)  src/trievec/mod.rs:12
+        s.varint(1);
+        emit_trie(s, v, a, b, 0, P.BYTES);
+        s.varint(b - a);
+    }
+}
+// Serialized form, emitted by a pool of host threads: bucket entries are independent byte ranges, so sizes are
+// computed in parallel, prefix-summed, and every bucket is then written at its own offset. (The reference writes
+// sequentially through a BufWriter, examples/cbl.rs:132-142; the bytes are the same.)
 void serialize_host(const Consts& P, const HostIndex& h, Sink& s) {
     s.u8_(P.canonical ? 1 : 0);                  // CBL.canonical (src/cbl.rs:48)
     s.varint(h.prefix.size());                   // serialize_map(Some(tiered.len()))  src/wordset/mod.rs:388
+    const u64 nb = h.prefix.size();
+    if (nb == 0) return;
     SfxView v{h.lo.data(), h.hi.empty() ? nullptr : h.hi.data()};
-    for (u64 r = 0; r < h.prefix.size(); ++r) {
-        s.varint(h.prefix[r]);
-        const u64 a = h.off[r], b = h.off[r + 1];
-        if (h.kind[r] == KIND_VEC) {             // TrieOrVec::Vec  src/trievec/mod.rs:10-11
-            s.varint(0);
-            s.varint(b - a);
-            for (u64 i = a; i < b; ++i) {
-                s.varint(P.BYTES);               // SlicedInt::serialize -> serialize_bytes  src/sliced_int.rs:110-114
-                u128 x = v.at(i);
-                u8 tmp[16];
-                for (u32 k = 0; k < P.BYTES; ++k) tmp[k] = (u8)(x >> (8 * k));
-                s.raw(tmp, P.BYTES);
-            }
-        } else {                                 // TrieOrVec::Trie(trie, len)  src/trievec/mod.rs:12
-            s.varint(1);
-            emit_trie(s, v, a, b, 0, P.BYTES);
-            s.varint(b - a);
-        }
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = std::max(1u, std::min(nt ? nt : 1u, 64u));
+    if (nb < 4096 || h.lo.size() < (1u << 18)) nt = 1;
+    // split the buckets into ranges of roughly equal element counts
+    std::vector<u64> cut(nt + 1, nb);
+    cut[0] = 0;
+    const u64 total = h.off[nb];
+    for (unsigned t = 1; t < nt; ++t) {
+        const u64 target = total / nt * t;
+        cut[t] = (u64)(std::lower_bound(h.off.begin(), h.off.begin() + nb, target) - h.off.begin());
+        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
     }
+    auto run = [&](auto&& fn) {
+        if (nt == 1) { fn(0u); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(fn, t);
+        for (auto& x : th) x.join();
+    };
+    std::vector<u64> part(nt + 1, 0);
+    run([&](unsigned t) {
+        Sink cnt(nullptr, 0);
+        for (u64 r = cut[t]; r < cut[t + 1]; ++r) serialize_bucket(P, h, v, r, cnt);
+        part[t + 1] = cnt.pos;
+    });
+    for (unsigned t = 0; t < nt; ++t) part[t + 1] += part[t];
+    const u64 base = s.pos;
+    if (s.buf && base + part[nt] <= s.cap) {
+        run([&](unsigned t) {
+            Sink out(s.buf + base + part[t], part[t + 1] - part[t]);
+            for (u64 r = cut[t]; r < cut[t + 1]; ++r) serialize_bucket(P, h, v, r, out);
+        });
+    }
+    s.pos = base + part[nt];
 }
 struct Src {
     const u8* p;
@@ -825,6 +864,53 @@ int cblx_insert_seqs_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t*
     });
 }
 int cblx_flush(cblx_ctx* c) { return guard(c, [&] { flush(c); }); }
+
+// The `read_fasta` + `while let Some(record) = reader.next() { cbl.insert_seq(&seqrec.seq()) }` loop of
+// examples/cbl.rs:112-115,154-163 (needletail stand-in): plain-text FASTA (multi-line, CRLF tolerated) or 4-line FASTQ.
+// Every record's sequence goes through insert_seq; batches are flushed to the GPU every ~1 GiB of bases.
+int cblx_insert_fastx_file(cblx_ctx* c, const char* path, uint64_t* n_records) {
+    return guard(c, [&] {
+        if (n_records) *n_records = 0;
+        std::ifstream f(path, std::ios::binary);
+        if (!f) throw Error(CBLX_EINVAL, std::string("Failed to open ") + path);
+        std::string line, seq;
+        u64 nrec = 0;
+        int mode = 0;  // 0 unknown, 1 FASTA, 2 FASTQ
+        auto strip = [](std::string& l) { while (!l.empty() && (l.back() == '\r' || l.back() == '\n')) l.pop_back(); };
+        auto emit = [&]() {
+            if (seq.size() < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(seq.size()) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
+            c->pend_bases.insert(c->pend_bases.end(), seq.begin(), seq.end());
+            c->pend_offsets.push_back(c->pend_bases.size());
+            ++nrec;
+            seq.clear();
+            if (c->pend_bases.size() >= (1ull << 30)) flush(c);
+        };
+        bool have = false;
+        while (std::getline(f, line)) {
+            strip(line);
+            if (mode == 0) {
+                if (line.empty()) continue;
+                if (line[0] == '>') mode = 1;
+                else if (line[0] == '@') mode = 2;
+                else throw Error(CBLX_EFORMAT, "not a FASTA/FASTQ file (first record does not start with '>' or '@')");
+            }
+            if (mode == 1) {
+                if (!line.empty() && line[0] == '>') { if (have) emit(); have = true; }
+                else seq += line;
+            } else {
+                if (line.empty()) continue;
+                if (line[0] != '@') throw Error(CBLX_EFORMAT, "FASTQ: expected '@' header");
+                std::string plus, qual;
+                if (!std::getline(f, seq) || !std::getline(f, plus) || !std::getline(f, qual)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
+                strip(seq); strip(plus);
+                if (plus.empty() || plus[0] != '+') throw Error(CBLX_EFORMAT, "FASTQ: expected '+' separator");
+                emit();
+            }
+        }
+        if (mode == 1 && have) emit();
+        if (n_records) *n_records = nrec;
+    });
+}
 
 int cblx_insert_words_device(cblx_ctx* c, const uint64_t* d_lo, const void* d_hi, uint64_t n) {
     return guard(c, [&] {

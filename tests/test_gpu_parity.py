@@ -394,3 +394,49 @@ def test_full_size_properties(k, pb, nreads, L):
     g.insert_seqs_device(d_b, d_o, nreads)  # idempotence (resident + new through the incremental path)
     assert (g.count(), g.checksum()) == (count, cs)
     assert g.validate() == 0
+
+
+# ---- the CLI path: FASTA / FASTQ file -> index file, byte-identical to the oracle's ------------------------------------
+def test_cli_build_insert_merge_files(tmp_path):
+    _need_gpu()
+    from cbl_amd.__main__ import main as cli
+
+    k, pb = 31, 24
+    b1, o1 = synth.reads(11, 400, 150)
+    b2, o2 = synth.reads(12, 300, 150)
+    fa = tmp_path / "a.fa"
+    fa.write_bytes(synth.fasta_bytes(b1, o1))
+    # multi-line FASTA with CRLF and a lower-case stretch; FASTQ for the second set
+    ml = tmp_path / "b.fa"
+    recs = []
+    for i in range(len(o2) - 1):
+        s = b2[int(o2[i]) : int(o2[i + 1])].tobytes()
+        recs.append(b">r%d desc\r\n" % i + s[:70].lower() + b"\r\n" + s[70:140] + b"\r\n" + s[140:] + b"\r\n")
+    ml.write_bytes(b"".join(recs))
+    fq = tmp_path / "b.fq"
+    fq.write_bytes(b"".join(b"@r%d\n" % i + b2[int(o2[i]) : int(o2[i + 1])].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for i in range(len(o2) - 1)))
+
+    cli(["-k", "31", "build", str(fa), "-o", str(tmp_path / "a.cbl")])
+    oa = Oracle(k, pb)
+    oa.insert_seqs(b1, o1)
+    assert (tmp_path / "a.cbl").read_bytes() == oa.serialize()
+
+    cli(["-k", "31", "insert", str(tmp_path / "a.cbl"), str(ml), "-o", str(tmp_path / "ab.cbl")])
+    oa.insert_seqs(b2, o2)
+    assert (tmp_path / "ab.cbl").read_bytes() == oa.serialize()
+
+    cli(["-k", "31", "build", str(fq), "-o", str(tmp_path / "b.cbl")])
+    ob = Oracle(k, pb)
+    ob.insert_seqs(b2, o2)
+    assert (tmp_path / "b.cbl").read_bytes() == ob.serialize()
+
+    cli(["-k", "31", "merge", str(tmp_path / "a.cbl"), str(tmp_path / "b.cbl"), "-o", str(tmp_path / "m.cbl")])
+    om = Oracle(k, pb)
+    om.insert_seqs(b1, o1)
+    om.merge(ob)
+    assert (tmp_path / "m.cbl").read_bytes() == om.serialize()
+
+    cli(["-k", "31", "build", "-c", str(fa), "-o", str(tmp_path / "c.cbl")])
+    oc = Oracle(k, pb, True)
+    oc.insert_seqs(b1, o1)
+    assert (tmp_path / "c.cbl").read_bytes() == oc.serialize()
