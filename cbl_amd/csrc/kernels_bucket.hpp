@@ -367,7 +367,10 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ 
     __shared__ u64 s_klo[CAP];
     __shared__ u64 s_khi[WS ? CAP : 1];
     __shared__ u16 s_idx[PACKED ? 1 : CAP];
-    __shared__ u32 s_off[CAP + 1];  // sub-bucket counts, then exclusive offsets
+    // sub-bucket counts, then exclusive offsets: 16-bit entries (values <= CAP), counted with 32-bit LDS atomics on the
+    // containing dword (LDS is what bounds residency here)
+    __shared__ u32 s_off32[CAP / 2 + 2];
+    u16* s_off = reinterpret_cast<u16*>(s_off32);
     __shared__ u32 s_scan[NW + 1];
     __shared__ u32 s_wtot[NW + 1];
     __shared__ u32 s_max;
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ 
     if (nbits > SB) nbits = SB;
     const u32 NB = 1u << nbits;  // <= CAP because c <= CAP
 
-    for (u32 i = tid; i < NB + 1; i += THREADS) s_off[i] = 0;
+    for (u32 i = tid; i < NB / 2 + 1; i += THREADS) s_off32[i] = 0;
     if (tid == 0) s_max = 0;
     __syncthreads();
     Sfx<WS> key[ITEMS];
@@ -397,7 +400,8 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ 
         if (valid[j]) {
             key[j] = load_sfx<WS, HiT>(lo, hi, s0 + e, SB);
             sub[j] = sfx_top_bits<WS>(key[j], SB, nbits);
-            arr[j] = atomicAdd(&s_off[sub[j]], 1u);
+            const u32 sh = (sub[j] & 1u) * 16u;
+            arr[j] = (atomicAdd(&s_off32[sub[j] >> 1], 1u << sh) >> sh) & 0xFFFFu;
         }
     }
     __syncthreads();
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ 
         if (mx > MSD_LIMIT) atomicMax(&s_max, mx);
         u32 ex = block_exclusive_scan<THREADS, u32>(sum, s_scan, nullptr);
         for (u32 k = 0; k < per; ++k) {
-            if (b0 + k < NB) { const u32 v = s_off[b0 + k]; s_off[b0 + k] = ex; ex += v; }
+            if (b0 + k < NB) { const u32 v = s_off[b0 + k]; s_off[b0 + k] = (u16)ex; ex += v; }
         }
     }
     __syncthreads();
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ 
         if (tid == 0) retry[atomicAdd(retry_n, 1u)] = r;
         return;
     }
-    if (tid == 0) s_off[NB] = c;
+    if (tid == 0) s_off[NB] = (u16)c;
     // scatter into sub-bucket order (arrival order inside a sub-bucket is arbitrary)
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
