@@ -289,7 +289,8 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
     }
     // -- KRN-3: per-bucket dedup / sort, by size class
     const u64 nb = nr.nb;
-    Buf<u32> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1)), list_n(c->pool, CLS_N);
+    Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
+    Buf<u32> list_n(c->pool, CLS_N);
     res_count = Buf<u32>(c->pool, nb + 1);
     res_kind = Buf<u8>(c->pool, nb + 1);
     CBLX_HIP(hipMemsetAsync(list_n.get(), 0, CLS_N * 4, c->stream));
@@ -301,27 +302,28 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
     if (ln[CLS_SMALL]) {
         StageTimer t(c, ST_BSMALL);
         hipLaunchKernelGGL((k_bucket_small<C::WS, HiT>), grid1((u64)ln[CLS_SMALL] * 64, 256), dim3(256), 0, c->stream,
-                           lists.get() + (size_t)CLS_SMALL * nb, list_n.get() + CLS_SMALL, nr.start.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+                           lists.get() + (size_t)CLS_SMALL * nb, list_n.get() + CLS_SMALL, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
     }
     {
         StageTimer t(c, ST_BMED);
         // fast path (counting sort on the top suffix bits + in-sub-bucket ranking); skewed buckets come back via `retry`
-        Buf<u32> retry(c->pool, std::max<u64>(nb, 1)), retry_n(c->pool, 1);
+        Buf<BDesc> retry(c->pool, std::max<u64>(nb, 1));
+        Buf<u32> retry_n(c->pool, 1);
         CBLX_HIP(hipMemsetAsync(retry_n.get(), 0, 4, c->stream));
         auto msd = [&](auto packed_tag) {
             constexpr bool PK = decltype(packed_tag)::value;
             if (ln[CLS_M64])
                 hipLaunchKernelGGL((k_bucket_msd<64, 512, PK, C::WS, HiT>), dim3(ln[CLS_M64]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M64 * nb,
-                                   list_n.get() + CLS_M64, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+                                   list_n.get() + CLS_M64, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
             if (ln[CLS_M128])
                 hipLaunchKernelGGL((k_bucket_msd<128, 1024, PK, C::WS, HiT>), dim3(ln[CLS_M128]), dim3(128), 0, c->stream, lists.get() + (size_t)CLS_M128 * nb,
-                                   list_n.get() + CLS_M128, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+                                   list_n.get() + CLS_M128, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
             if (ln[CLS_M256])
                 hipLaunchKernelGGL((k_bucket_msd<256, 2048, PK, C::WS, HiT>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb,
-                                   list_n.get() + CLS_M256, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+                                   list_n.get() + CLS_M256, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
             if (ln[CLS_M512])
                 hipLaunchKernelGGL((k_bucket_msd<512, 4096, PK, C::WS, HiT>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb,
-                                   list_n.get() + CLS_M512, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+                                   list_n.get() + CLS_M512, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
         };
         if constexpr (!C::WS) {
             if (P.SB + PK_BITS <= 64) msd(std::true_type()); else msd(std::false_type());
@@ -330,26 +332,24 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
         }
         const u32 nretry = (ln[CLS_M64] || ln[CLS_M128] || ln[CLS_M256] || ln[CLS_M512]) ? d2h<u32>(c, retry_n.get()) : 0u;
         if (nretry)
-            hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(nretry), dim3(512), 0, c->stream, retry.get(), retry_n.get(), nr.start.get(),
-                               res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+            hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(nretry), dim3(512), 0, c->stream, retry.get(), retry_n.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
         if constexpr (!C::WS) if (ln[CLS_M1024])  // 128-bit suffixes: 8192 keys + indices exceed the 160 KiB LDS, such runs go to the huge path
             hipLaunchKernelGGL((k_bucket_medium<1024, C::WS, HiT>), dim3(ln[CLS_M1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)CLS_M1024 * nb,
-                               list_n.get() + CLS_M1024, nr.start.get(), res_kind.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+                               list_n.get() + CLS_M1024, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
         CBLX_HIP(hipStreamSynchronize(c->stream));  // retry buffers die here
     }
     if (ln[CLS_HUGE]) {
         StageTimer t(c, ST_BHUGE);
         const u32 nh = ln[CLS_HUGE];
-        std::vector<u32> hl = d2h_vec<u32>(c, lists.get() + (size_t)CLS_HUGE * nb, nh);
-        std::vector<u64> starts = d2h_vec<u64>(c, nr.start.get(), nb + 1);
+        std::vector<BDesc> hl = d2h_vec<BDesc>(c, lists.get() + (size_t)CLS_HUGE * nb, nh);
         std::vector<u64> so(nh);
         u64 tot = 0;
-        for (u32 i = 0; i < nh; ++i) { so[i] = tot; tot += starts[hl[i] + 1] - starts[hl[i]]; }
+        for (u32 i = 0; i < nh; ++i) { so[i] = tot; tot += hl[i].c & ~BDESC_TRIE; }
         Buf<u64> d_so(c->pool, nh), s_alo(c->pool, tot), s_blo(c->pool, tot), s_ahi(c->pool, C::WS ? tot : 1), s_bhi(c->pool, C::WS ? tot : 1);
         Buf<u32> s_aidx(c->pool, tot), s_bidx(c->pool, tot);
         h2d(c, d_so.get(), so.data(), nh);
         hipLaunchKernelGGL((k_bucket_huge<C::WS, HiT>), dim3(nh), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE,
-                           nr.start.get(), d_so.get(), res_kind.get(), a_lo, a_hi, P.SB, s_alo.get(), s_ahi.get(), s_aidx.get(), s_blo.get(), s_bhi.get(),
+                           d_so.get(), a_lo, a_hi, P.SB, s_alo.get(), s_ahi.get(), s_aidx.get(), s_blo.get(), s_bhi.get(),
                            s_bidx.get(), nr.cnt.get(), nr.kind.get());
         CBLX_HIP(hipStreamSynchronize(c->stream));
     }

@@ -90,9 +90,17 @@ enum { CLS_SMALL = 0, CLS_M64 = 1, CLS_M128 = 2, CLS_M256 = 3, CLS_M512 = 4, CLS
 static const u32 SMALL_MAX = 64;
 static const u32 MED_ITEMS = 8;
 
+// One 16-byte descriptor per bucket and class: a bucket kernel starts from a single load instead of a chain of three.
+struct BDesc {
+    u64 start;  // first record of the run
+    u32 c;      // run length; bit 31 = the resident bucket is already a Trie
+    u32 r;      // bucket rank
+};
+static const u32 BDESC_TRIE = 0x80000000u;
+
 __global__ void k_classify(u64 nb, u32 med_max_threads, const u32* __restrict__ bucket_prefix, const u64* __restrict__ raw_start, DirView old,
                            u32* __restrict__ res_count, u8* __restrict__ res_kind, u32* __restrict__ out_count,
-                           u8* __restrict__ out_kind, u32* __restrict__ lists /* [CLS_N][nb] */, u32* __restrict__ list_n) {
+                           u8* __restrict__ out_kind, BDesc* __restrict__ lists /* [CLS_N][nb] */, u32* __restrict__ list_n) {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nb) return;
     u64 c = raw_start[r + 1] - raw_start[r];
@@ -124,7 +132,7 @@ __global__ void k_classify(u64 nb, u32 med_max_threads, const u32* __restrict__ 
             const u32 leader = (u32)__builtin_ctzll(bal);
             if (lane_id() == leader) base = atomicAdd(&list_n[k], (u32)__builtin_popcountll(bal));
             base = __shfl(base, (int)leader, 64);
-            lists[(u64)k * nb + base + mbcnt(bal)] = (u32)r;
+            lists[(u64)k * nb + base + mbcnt(bal)] = BDesc{raw_start[r], (u32)c | (rk == KIND_TRIE ? BDESC_TRIE : 0u), (u32)r};
         }
     }
 }
@@ -169,15 +177,15 @@ template <bool WS> __device__ __forceinline__ Sfx<WS> shfl_sfx(const Sfx<WS>& s,
 // ---- KRN-3 small: one wave per bucket, run <= 64, all-pairs "seen before?" (the reference's own
 // `vec.contains(x)` semantics, src/trievec/mod.rs:81-87), ordered compaction by ballot ----------------------
 template <bool WS, typename HiT>
-__global__ __launch_bounds__(256) void k_bucket_small(const u32* __restrict__ list, const u32* __restrict__ list_n,
-                                                      const u64* __restrict__ raw_start, u64* __restrict__ lo,
-                                                      HiT* __restrict__ hi, u32 SB, u32* __restrict__ out_count,
-                                                      u8* __restrict__ out_kind) {
+__global__ __launch_bounds__(256) void k_bucket_small(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
+                                                      u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
+                                                      u32* __restrict__ out_count, u8* __restrict__ out_kind) {
     const u32 wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wv >= *list_n) return;
-    const u32 r = list[wv];
-    const u64 s0 = raw_start[r];
-    const u32 c = (u32)(raw_start[r + 1] - s0);
+    const BDesc dsc = list[wv];
+    const u32 r = dsc.r;
+    const u64 s0 = dsc.start;
+    const u32 c = dsc.c & ~BDESC_TRIE;
     Sfx<WS> mine;
     mine.lo = 0;
     if constexpr (WS) mine.hi = 0;
@@ -198,11 +206,9 @@ __global__ __launch_bounds__(256) void k_bucket_small(const u32* __restrict__ li
 
 // ---- KRN-3 medium: one workgroup per bucket, run <= THREADS*8, stable LSD radix sort in LDS -----------------
 template <int THREADS, bool WS, typename HiT>
-__global__ __launch_bounds__(THREADS) void k_bucket_medium(const u32* __restrict__ list, const u32* __restrict__ list_n,
-                                                           const u64* __restrict__ raw_start,
-                                                           const u8* __restrict__ res_kind, u64* __restrict__ lo,
-                                                           HiT* __restrict__ hi, u32 SB, u32* __restrict__ out_count,
-                                                           u8* __restrict__ out_kind) {
+__global__ __launch_bounds__(THREADS) void k_bucket_medium(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
+                                                           u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
+                                                           u32* __restrict__ out_count, u8* __restrict__ out_kind) {
     constexpr int ITEMS = MED_ITEMS, NW = THREADS / 64, CAP = THREADS * ITEMS;
     __shared__ u64 s_klo[CAP];
     __shared__ u64 s_khi[WS ? CAP : 1];
@@ -214,9 +220,11 @@ __global__ __launch_bounds__(THREADS) void k_bucket_medium(const u32* __restrict
     __shared__ u32 s_wtot[NW + 1];
 
     if (blockIdx.x >= *list_n) return;
-    const u32 r = list[blockIdx.x];
-    const u64 s0 = raw_start[r];
-    const u32 c = (u32)(raw_start[r + 1] - s0);
+    const BDesc dsc = list[blockIdx.x];
+    const u32 r = dsc.r;
+    const u64 s0 = dsc.start;
+    const u32 c = dsc.c & ~BDESC_TRIE;
+    const bool res_trie = (dsc.c & BDESC_TRIE) != 0;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const u32 R = (c + THREADS - 1) / THREADS;  // rounds actually needed (<= ITEMS)
     const u32 EPW = 64 * R;                     // elements per wave slice
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(THREADS) void k_bucket_medium(const u32* __restrict
     }
     __syncthreads();
     const u32 d = s_wtot[NW];
-    const bool trie = d > VEC_THRESHOLD || res_kind[r] == KIND_TRIE;
+    const bool trie = d > VEC_THRESHOLD || res_trie;
     if (trie) {
         u32 run = s_wtot[w];
 #pragma unroll
@@ -356,11 +364,10 @@ template <bool WS> __device__ __forceinline__ bool sfx_less(const Sfx<WS>& a, u3
 static const u32 PK_BITS = 12;  // CAP <= 4096
 
 template <int THREADS, int CAP, bool PACKED, bool WS, typename HiT>
-__global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ list, const u32* __restrict__ list_n,
-                                                        const u64* __restrict__ raw_start, const u8* __restrict__ res_kind,
+__global__ __launch_bounds__(THREADS) void k_bucket_msd(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
                                                         u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
                                                         u32* __restrict__ out_count, u8* __restrict__ out_kind,
-                                                        u32* __restrict__ retry, u32* __restrict__ retry_n) {
+                                                        BDesc* __restrict__ retry, u32* __restrict__ retry_n) {
     static_assert(!(PACKED && WS), "packed elements need a narrow suffix");
     static_assert(CAP <= (1 << PK_BITS), "stream index must fit PK_BITS");
     constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
@@ -376,10 +383,11 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ 
     __shared__ u32 s_max;
 
     if (blockIdx.x >= *list_n) return;
-    const u32 r = list[blockIdx.x];
-    const u64 s0 = raw_start[r];
-    const u32 c = (u32)(raw_start[r + 1] - s0);
-    const bool res_trie = res_kind[r] == KIND_TRIE;
+    const BDesc dsc = list[blockIdx.x];
+    const u32 r = dsc.r;
+    const u64 s0 = dsc.start;
+    const u32 c = dsc.c & ~BDESC_TRIE;
+    const bool res_trie = (dsc.c & BDESC_TRIE) != 0;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const u32 R = (c + THREADS - 1) / THREADS;
     const u32 EPW = 64 * R;  // wave-contiguous slices: ballots then compact in stream order
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ 
     }
     __syncthreads();
     if (s_max > MSD_LIMIT) {  // skewed bucket: leave it to the radix kernel
-        if (tid == 0) retry[atomicAdd(retry_n, 1u)] = r;
+        if (tid == 0) retry[atomicAdd(retry_n, 1u)] = dsc;
         return;
     }
     if (tid == 0) s_off[NB] = (u16)c;
@@ -549,9 +557,8 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const u32* __restrict__ 
 // ---- KRN-3 huge: one workgroup per bucket, any run length; the same stable LSD radix passes, tile by tile in
 // global scratch (a/b ping-pong of key + stream index). Pathological buckets (poly-A ...) only. -------------------
 template <bool WS, typename HiT>
-__global__ __launch_bounds__(256) void k_bucket_huge(const u32* __restrict__ list, const u32* __restrict__ list_n,
-                                                     const u64* __restrict__ raw_start, const u64* __restrict__ scratch_off,
-                                                     const u8* __restrict__ res_kind, u64* __restrict__ lo,
+__global__ __launch_bounds__(256) void k_bucket_huge(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
+                                                     const u64* __restrict__ scratch_off, u64* __restrict__ lo,
                                                      HiT* __restrict__ hi, u32 SB, u64* __restrict__ a_lo,
                                                      u64* __restrict__ a_hi, u32* __restrict__ a_idx, u64* __restrict__ b_lo,
                                                      u64* __restrict__ b_hi, u32* __restrict__ b_idx,
@@ -564,9 +571,11 @@ __global__ __launch_bounds__(256) void k_bucket_huge(const u32* __restrict__ lis
     __shared__ u32 s_run[256];
     __shared__ u32 s_cnt;
     if (blockIdx.x >= *list_n) return;
-    const u32 r = list[blockIdx.x];
-    const u64 s0 = raw_start[r];
-    const u32 c = (u32)(raw_start[r + 1] - s0);
+    const BDesc dsc = list[blockIdx.x];
+    const u32 r = dsc.r;
+    const u64 s0 = dsc.start;
+    const u32 c = dsc.c & ~BDESC_TRIE;
+    const bool res_trie = (dsc.c & BDESC_TRIE) != 0;
     const u64 so = scratch_off[blockIdx.x];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     u64 *src_lo = a_lo + so, *dst_lo = b_lo + so, *src_hi = WS ? a_hi + so : nullptr, *dst_hi = WS ? b_hi + so : nullptr;
@@ -654,7 +663,7 @@ __global__ __launch_bounds__(256) void k_bucket_huge(const u32* __restrict__ lis
     if (lane == 0) atomicAdd(&s_cnt, mine);
     __syncthreads();
     const u32 d = s_cnt;
-    const bool trie = d > VEC_THRESHOLD || res_kind[r] == KIND_TRIE;
+    const bool trie = d > VEC_THRESHOLD || res_trie;
     // ordered compaction, chunk of THREADS elements at a time
     u32 base = 0;
     if (trie) {
