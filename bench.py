@@ -71,7 +71,7 @@ def main():
     args = ap.parse_args()
 
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-        os.environ["NCCL_DEBUG"] = "WARN"  # RCCL's version banner goes to stdout; keep stdout to the one JSON line
+        del os.environ["NCCL_DEBUG"]  # RCCL prints its banner (and WARN lines) on STDOUT; keep stdout to the one JSON line
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,6 +199,7 @@ def main():
                          "throughput falls as the index grows, so the full-size CPU figure is lower",
                "host_cores_available": os.cpu_count()}
 
+    out = None
     if rank == 0:
         out = {
             "metric": "k-mers inserted/sec (build index)", "value": round(value, 1), "unit": "k-mers/s", "n_gpus": world,
@@ -212,10 +213,14 @@ def main():
             "distinct_kmers_in_index": count,
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:  # last thing on stdout, on a line of its own
+        sys.stdout.flush()
+        sys.stdout.write("\n" + json.dumps(out) + "\n")
+        sys.stdout.flush()
+
 
 
 if __name__ == "__main__":

@@ -398,16 +398,22 @@ template <typename C> u64 begin_records(cblx_ctx* c, Records& rec, u64 n_new) {
 struct ChunkPlan {
     u64 nchunks = 0, n_kmers = 0, total_bases = 0;
     u32 ndirty = 0;
+    u64 bias = 0;  // bytes skipped in front of the slice (multiple of 16)
     Buf<u64> chunk_start, kmer_off;
     Buf<u32> chunk_len, tile_first;
     Buf<u8> dirty;
 };
-void plan_chunks(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq, ChunkPlan& pl) {
+void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq, ChunkPlan& pl) {
     StageTimer t(c, ST_CHUNKS);
     const Consts& P = c->P;
-    pl.total_bases = d2h<u64>(c, d_offsets + nseq);
+    // offsets may start anywhere in the buffer (a slice of a larger batch): work relative to the 16-byte aligned
+    // position below offsets[0] so that the tile grid and the validity scan cover only this slice
     const u64 first = d2h<u64>(c, d_offsets);
-    if (first != 0) throw Error(CBLX_EINVAL, "offsets[0] must be 0");
+    pl.bias = first & ~(u64)15;
+    const u64 last = d2h<u64>(c, d_offsets + nseq);
+    if (last < first) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
+    pl.total_bases = last - pl.bias;
+    d_bases += pl.bias;
     Buf<u32> nch(c->pool, nseq + 1);
     Buf<u64> err(c->pool, 2), chunk_base(c->pool, nseq + 1);
     CBLX_HIP(hipMemsetAsync(err.get(), 0, 16, c->stream));
@@ -422,7 +428,7 @@ void plan_chunks(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq,
     Buf<u32> chunk_nk(c->pool, pl.nchunks + 1);
     pl.dirty = Buf<u8>(c->pool, pl.nchunks + 8);
     Buf<u32> ndirty(c->pool, 1);
-    hipLaunchKernelGGL(k_chunk_fill, grid1(pl.nchunks, 256), dim3(256), 0, c->stream, d_offsets, chunk_base.get(), nseq, pl.nchunks, P.K,
+    hipLaunchKernelGGL(k_chunk_fill, grid1(pl.nchunks, 256), dim3(256), 0, c->stream, d_offsets, chunk_base.get(), nseq, pl.nchunks, P.K, pl.bias,
                        pl.chunk_start.get(), pl.chunk_len.get(), chunk_nk.get());
     CBLX_HIP(hipMemsetAsync(pl.dirty.get(), 0, pl.nchunks + 8, c->stream));
     CBLX_HIP(hipMemsetAsync(ndirty.get(), 0, 4, c->stream));
@@ -1102,13 +1108,14 @@ int cblx_contains_seq(cblx_ctx* c, const uint8_t* seq, uint64_t len, uint8_t* ou
             h2d(c, d_b.get(), seq, len);
             h2d(c, d_o.get(), offs, 2);
             ChunkPlan pl;
-            plan_chunks(c, d_b.get(), d_o.get(), 1, pl);
+            const u8* pb = d_b.get();
+            plan_chunks(c, pb, d_o.get(), 1, pl);
             if (n) *n = pl.n_kmers;
             if (pl.n_kmers > cap) throw Error(CBLX_ERANGE, "output capacity too small");
             Buf<u64> w_lo(c->pool, pl.n_kmers + 2);
             Buf<u8> w_hi(c->pool, (pl.n_kmers + 2) * std::max<size_t>(1, hi_elem_size(c->P)));
             Buf<u8> d_out(c->pool, pl.n_kmers + 8);
-            encode<C>(c, d_b.get(), pl, w_lo.get(), (HiT*)w_hi.get(), 0);
+            encode<C>(c, pb, pl, w_lo.get(), (HiT*)w_hi.get(), 0);
             hipLaunchKernelGGL(k_contains<HiT>, grid1(pl.n_kmers, 256), dim3(256), 0, c->stream, w_lo.get(), (const HiT*)w_hi.get(), pl.n_kmers, c->P.SB,
                                c->P.PB, c->res.view(), c->res.a_lo.get(), c->P.wide_suffix() ? c->res.a_hi.get() : (const u64*)nullptr, d_out.get());
             CBLX_HIP(hipGetLastError());

@@ -53,7 +53,7 @@ __global__ void k_seq_chunk_count(const u64* __restrict__ offsets, u64 nseq, u32
 
 // one thread per chunk: binary search the owning sequence in the chunk-base scan
 __global__ void k_chunk_fill(const u64* __restrict__ offsets, const u64* __restrict__ chunk_base /* nseq+1 */,
-                             u64 nseq, u64 nchunks, u32 K, u64* __restrict__ chunk_start,
+                             u64 nseq, u64 nchunks, u32 K, u64 bias, u64* __restrict__ chunk_start,
                              u32* __restrict__ chunk_len, u32* __restrict__ chunk_nk) {
     u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
@@ -68,7 +68,7 @@ __global__ void k_chunk_fill(const u64* __restrict__ offsets, const u64* __restr
     u64 start = j * CHUNK_KMERS;
     u64 end = start + CHUNK_KMERS + K - 1;
     if (end > len) end = len;
-    chunk_start[c] = s0 + start;
+    chunk_start[c] = s0 + start - bias;  // relative to the (16-byte aligned) start of this slice
     chunk_len[c] = (u32)(end - start);
     chunk_nk[c] = (u32)(end - start - K + 1);
 }

@@ -6,10 +6,10 @@ GPU, and the transformed words cross xGMI once:
 
     rank r: its contiguous shard of the reads  --KRN-1-->  words (stream order)
             --stable partition by destination range (cblx_partition_words_device)-->
-            --all_to_all_single (RCCL)-->  words of MY prefix range, ordered by source rank
+            --all-to-all over RCCL (grouped send/recv)-->  words of MY prefix range, ordered by source rank
             --KRN-2..4 (cblx_insert_words_device)-->  resident sub-index of my range
 
-Global stream order is "rank 0's reads, then rank 1's, ..." and all_to_all_single delivers by source rank, so the
+Global stream order is "rank 0's reads, then rank 1's, ..." and the exchange delivers by source rank, so the
 first-occurrence order inside Vec buckets (/root/reference/src/trievec/mod.rs:81-87) is that of the one-process
 build. Ranges are balanced by quantiles of a sampled prefix histogram because necklace prefixes are heavily skewed
 toward small values: equal-width ranges would put nearly all work on rank 0.
@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import numpy as np
 
+MAX_MSG_BYTES = 256 << 20  # cap of one point-to-point message of the exchange
 HIST_BITS = 16      # resolution of the splitter histogram (top bits of the prefix)
 SAMPLE_STRIDE = 61  # every 61st word feeds the histogram
 
@@ -57,7 +58,7 @@ class GpuEngine:
     def seq_words(self, d_bases, d_offsets, n):
         torch = self.torch
         self.device = d_bases.device
-        cap = int(d_bases.numel())
+        cap = int(d_offsets[n] - d_offsets[0])  # >= number of k-mers of the slice
         lo = torch.empty(cap + 1, dtype=torch.int64, device=self.device)
         hi = torch.empty(cap + 1, dtype=self.hi_dtype, device=self.device) if self.hi_dtype is not None else None
         nw = self.cbl.seq_words_device(d_bases, d_offsets, n, lo, hi, cap)
@@ -95,42 +96,113 @@ class GpuEngine:
 
 
 class ShardedBuilder:
-    """`insert_seqs_device` over a process group: every rank passes ITS contiguous shard of the reads."""
+    """`insert_seqs_device` over a process group: every rank passes ITS contiguous shard of the reads.
 
-    def __init__(self, cbl, dist, engine=None):
+    The shard is consumed in `slices` slices so that the all-to-all of slice c overlaps the encode + partition of slice
+    c+1 (the exchange is the only step that leaves the GPU: ~7/8 of the words cross xGMI on 8 ranks). The job's stream
+    order is therefore slice-major, rank-minor: (slice 0 of rank 0, slice 0 of rank 1, ..., slice 1 of rank 0, ...),
+    i.e. file order when the file is dealt to the ranks block-cyclically; with slices=1 it is plain rank order.
+    """
+
+    def __init__(self, cbl, dist, engine=None, slices: int = 4, slack: float = 1.3):
         self.cbl, self.dist = cbl, dist
         self.engine = engine or GpuEngine(cbl)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
+        self.slices, self.slack = max(1, slices), slack
         self.bounds = None  # fixed by the first batch so later batches land on the same owners
         self.last_counts = None
+
+    @staticmethod
+    def slice_bounds(n: int, slices: int):
+        """Read ranges [a, b) of the slices of an n-read shard (same formula on every rank)."""
+        slices = max(1, min(slices, n)) if n else 1
+        return [(n * c // slices, n * (c + 1) // slices) for c in range(slices)]
 
     def insert_seqs_device(self, d_bases, d_offsets, n):
         import torch
 
         dist, eng, W = self.dist, self.engine, self.world
-        lo, hi = eng.seq_words(d_bases, d_offsets, n)
-        if self.bounds is None:
-            hist = eng.sample_hist(lo, hi)
-            dist.all_reduce(hist)
-            hb = min(HIST_BITS, self.cbl.prefix_bits)
-            self.bounds = choose_bounds(hist.cpu().numpy(), W, self.cbl.prefix_bits, hb)
-        plo, phi, counts = eng.partition(lo, hi, self.bounds, W)
-        del lo, hi
-        send = torch.tensor(counts, dtype=torch.int64, device=plo.device)
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send)
-        send_l, recv_l = [int(x) for x in counts], [int(x) for x in recv.cpu().tolist()]
-        self.last_counts = (send_l, recv_l)
-        n_recv = sum(recv_l)
-        rlo = eng.empty_like(plo, n_recv)
-        dist.all_to_all_single(rlo, plo.contiguous(), recv_l, send_l)
-        rhi = None
-        if phi is not None:
-            rhi = eng.empty_like(phi, n_recv)
-            dist.all_to_all_single(rhi, phi.contiguous(), recv_l, send_l)
-        del plo, phi
-        eng.insert_words(rlo, rhi)
+        k = self.cbl.k if hasattr(self.cbl, "k") else None
+        recv_lo = recv_hi = None
+        filled, cap = 0, 0
+        inflight = []  # (works, send buffers kept alive)
+        send_tot = [0] * W
+        recv_tot = [0] * W
+        for a, b in self.slice_bounds(n, self.slices):
+            if b <= a:
+                continue
+            lo, hi = eng.seq_words(d_bases, d_offsets[a : b + 1], b - a)  # offsets stay absolute: no copy of the bases
+            if self.bounds is None:
+                hist = eng.sample_hist(lo, hi)
+                dist.all_reduce(hist)
+                hb = min(HIST_BITS, self.cbl.prefix_bits)
+                self.bounds = choose_bounds(hist.cpu().numpy(), W, self.cbl.prefix_bits, hb)
+            plo, phi, counts = eng.partition(lo, hi, self.bounds, W)
+            n_words = int(lo.numel())
+            del lo, hi
+            send = torch.tensor(counts, dtype=torch.int64, device=plo.device)
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send)
+            send_l, recv_l = [int(x) for x in counts], [int(x) for x in recv.cpu().tolist()]
+            n_recv = sum(recv_l)
+            if recv_lo is None:  # one receive buffer for the whole batch: slices land back to back, no gather copy
+                est_total = int(n_words * (n / (b - a)) * self.slack) + 4096
+                cap = max(est_total, n_recv)
+                recv_lo = eng.empty_like(plo, cap)
+                recv_hi = eng.empty_like(phi, cap) if phi is not None else None
+            if filled + n_recv > cap:  # quantile ranges drifted: grow (rare)
+                for wk, *_ in inflight:
+                    for x in wk:
+                        x.wait()
+                inflight = []
+                cap = int((filled + n_recv) * 1.5) + 4096
+                nlo = eng.empty_like(plo, cap)
+                nlo[:filled] = recv_lo[:filled]
+                recv_lo = nlo
+                if recv_hi is not None:
+                    nhi = eng.empty_like(phi, cap)
+                    nhi[:filled] = recv_hi[:filled]
+                    recv_hi = nhi
+            works = self._exchange(plo, recv_lo[filled : filled + n_recv], send_l, recv_l)
+            if phi is not None:
+                works += self._exchange(phi, recv_hi[filled : filled + n_recv], send_l, recv_l)
+            inflight.append((works, plo, phi))
+            filled += n_recv
+            send_tot = [x + y for x, y in zip(send_tot, send_l)]
+            recv_tot = [x + y for x, y in zip(recv_tot, recv_l)]
+        for works, *_ in inflight:
+            for x in works:
+                x.wait()
+        if recv_lo is not None and recv_lo.is_cuda:
+            torch.cuda.current_stream(recv_lo.device).synchronize()  # libcblx runs on its own stream: hand over on the host
+        inflight = []
+        self.last_counts = (send_tot, recv_tot)
+        if filled:
+            eng.insert_words(recv_lo[:filled], recv_hi[:filled] if recv_hi is not None else None)
+
+    def _exchange(self, src, dst, send_l, recv_l):
+        """Personalised exchange: src holds the runs for rank 0..W-1 back to back (send_l), dst receives the runs of
+        source rank 0..W-1 back to back (recv_l). Grouped point-to-point (what RCCL's all-to-all is built from), every
+        message capped at MAX_MSG_BYTES: torch/RCCL all_to_all_single was measured here to drop data once a message
+        reaches 2^31 bytes or 2^30 elements (tools/dev_a2a_check.py). The rank's own run is a local copy.
+        Returns the outstanding requests."""
+        dist, W, me = self.dist, self.world, self.rank
+        step = max(1, MAX_MSG_BYTES // src.element_size())
+        soff = [0] * (W + 1)
+        roff = [0] * (W + 1)
+        for r in range(W):
+            soff[r + 1] = soff[r] + send_l[r]
+            roff[r + 1] = roff[r] + recv_l[r]
+        dst[roff[me] : roff[me + 1]].copy_(src[soff[me] : soff[me + 1]])
+        ops = []
+        for d in range(1, W):  # ring order keeps the pairing of sends and receives symmetric across ranks
+            to, frm = (me + d) % W, (me - d) % W
+            for o in range(0, send_l[to], step):
+                ops.append(dist.P2POp(dist.isend, src[soff[to] + o : soff[to] + min(o + step, send_l[to])], to))
+            for o in range(0, recv_l[frm], step):
+                ops.append(dist.P2POp(dist.irecv, dst[roff[frm] + o : roff[frm] + min(o + step, recv_l[frm])], frm))
+        return list(dist.batch_isend_irecv(ops)) if ops else []
 
     def reset(self):
         self.bounds = None

@@ -65,7 +65,8 @@ int cblx_insert_seq(cblx_ctx* ctx, const uint8_t* seq, uint64_t len);
 /* The caller loop `for record in reader { cbl.insert_seq(record.seq()) }` (examples/cbl.rs:160-163,242-245)
  * in one call: sequence i is bases[offsets[i] .. offsets[i+1]), i < n. Stream order = i ascending. */
 int cblx_insert_seqs(cblx_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n);
-/* Same, inputs already resident in HBM (device pointers). Runs the insert before returning. */
+/* Same, inputs already resident in HBM (device pointers; d_bases 16-byte aligned). offsets[0] need not be 0: a slice
+ * offsets[a..b] of a larger batch addresses the same d_bases. Runs the insert before returning. */
 int cblx_insert_seqs_device(cblx_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n);
 /* The reader loop of examples/cbl.rs:154-163 (needletail stand-in): every record of a plain-text FASTA (multi-line ok)
  * or 4-line FASTQ file goes through insert_seq, in file order. gz is not handled. */

@@ -440,3 +440,25 @@ def test_cli_build_insert_merge_files(tmp_path):
     oc = Oracle(k, pb, True)
     oc.insert_seqs(b1, o1)
     assert (tmp_path / "c.cbl").read_bytes() == oc.serialize()
+
+
+def test_offset_slices_address_the_same_buffer():
+    """Device entry points accept offsets[a..b] of a larger batch (offsets[0] != 0, unaligned) against the full base
+    buffer — what the sliced multi-GPU exchange feeds them."""
+    _need_gpu()
+    rng = random.Random(31)
+    seqs = [_rand_seq(rng, rng.choice((31, 77, 150, 151, 3000))) for _ in range(60)]
+    bases, offsets = _concat(seqs)
+    pad = (-len(bases)) % 16 + 16
+    d_b = torch.from_numpy(np.concatenate([bases, np.zeros(pad, np.uint8)])).cuda()
+    d_o = torch.from_numpy(offsets.astype(np.int64)).cuda()
+    for k, pb, canonical in ((31, 24, False), (31, 24, True), (59, 28, False)):
+        g, o = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
+        seqs_k = [s for s in seqs]
+        for a, b in ((0, 7), (7, 8), (8, 41), (41, 60)):
+            if any(len(s) < k for s in seqs_k[a:b]):
+                continue
+            g.insert_seqs_device(d_b, d_o[a : b + 1].contiguous(), b - a)
+            for s in seqs_k[a:b]:
+                o.insert_seq(s)
+        _check_index(g, o)

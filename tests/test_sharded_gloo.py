@@ -63,7 +63,7 @@ class OracleEngine:
         return self.torch.empty(n, dtype=t.dtype)
 
 
-def _worker(rank, world, port, k, pb, nreads, L, q):
+def _worker(rank, world, port, k, pb, nreads, L, slices, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -73,6 +73,8 @@ def _worker(rank, world, port, k, pb, nreads, L, q):
     from oracle import Oracle
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if slices == 3:
+        sharded.MAX_MSG_BYTES = 64  # force the multi-message path of the exchange (8 words per message)
     try:
         per = nreads // world
         bases, offsets = synth.reads(7, per, L, first_read=rank * per)
@@ -81,7 +83,7 @@ def _worker(rank, world, port, k, pb, nreads, L, q):
         class _Cbl:  # the two attributes ShardedBuilder reads from a CBL
             prefix_bits = pb
 
-        sb = sharded.ShardedBuilder(_Cbl(), dist, engine=OracleEngine(orc, k, pb))
+        sb = sharded.ShardedBuilder(_Cbl(), dist, engine=OracleEngine(orc, k, pb), slices=slices)
         # two batches: the second reuses the first batch's splitters
         h = per // 2
         for a, b in ((0, h), (h, per)):
@@ -103,8 +105,9 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,k,pb,nreads,L", [(2, 31, 24, 240, 150), (3, 9, 4, 600, 100), (2, 59, 28, 120, 250)])
-def test_sharded_build_equals_single_process(world, k, pb, nreads, L):
+@pytest.mark.parametrize("world,k,pb,nreads,L,slices", [(2, 31, 24, 240, 150, 1), (2, 31, 24, 240, 150, 3), (3, 9, 4, 600, 100, 4),
+                                                        (2, 59, 28, 120, 250, 2)])
+def test_sharded_build_equals_single_process(world, k, pb, nreads, L, slices):
     import torch.multiprocessing as mp
 
     from cbl_amd import synth
@@ -113,21 +116,24 @@ def test_sharded_build_equals_single_process(world, k, pb, nreads, L):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, k, pb, nreads, L, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, k, pb, nreads, L, slices, q)) for r in range(world)]
     for p in procs:
         p.start()
     blob, bounds, counts = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # one-process build. Stream order of the sharded job: batch 1 of every rank (rank order), then batch 2.
+    # one-process build. Stream order of the sharded job: per batch, slice-major then rank-minor.
+    from cbl_amd.sharded import ShardedBuilder
+
     per = nreads // world
     h = per // 2
     one = Oracle(k, pb)
     for a, b in ((0, h), (h, per)):
-        for r in range(world):
-            bases, offsets = synth.reads(7, b - a, L, first_read=r * per + a)
-            one.insert_seqs(bases, offsets)
+        for sa, sb_ in ShardedBuilder.slice_bounds(b - a, slices):
+            for r in range(world):
+                bases, offsets = synth.reads(7, sb_ - sa, L, first_read=r * per + a + sa)
+                one.insert_seqs(bases, offsets)
     assert blob == one.serialize()
     assert len(bounds) == world - 1 and bounds == sorted(bounds)
     assert sum(counts[0]) > 0
