@@ -102,15 +102,18 @@ __device__ __forceinline__ void tile_rank(const u32 (&digit)[ITEMS], u32 (&pos)[
     for (int j = 0; j < ITEMS; ++j) {
         if ((u32)j < rounds) {
             const u32 d = digit[j];
-            u64 m = ~0ull;
+            // lanes holding my digit: AND over the 8 bits of (ballot(bit) XNOR my bit). t = 0 / ~0 is my bit spread over
+            // a dword (one v_bfe_i32), so each half of the mask costs one v_xnor + one v_and per bit.
+            u32 m_lo = ~0u, m_hi = ~0u;
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
-                const u32 bit = (d >> b) & 1u;
-                const u64 bal = __ballot(bit != 0);
-                m &= bal ^ (u64)(long long)((int)bit - 1);  // lanes whose bit b equals mine
+                const u32 t = (u32)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);
+                const u64 bal = __ballot(t != 0);
+                m_lo &= ~((u32)bal ^ t);
+                m_hi &= ~((u32)(bal >> 32) ^ t);
             }
-            const u32 lower = mbcnt(m);
-            const u32 tot = (u32)__builtin_popcountll(m);
+            const u32 lower = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+            const u32 tot = (u32)__builtin_popcount(m_lo) + (u32)__builtin_popcount(m_hi);
             const u32 old = my[d];
             __builtin_amdgcn_wave_barrier();
             if (lower == 0) my[d] = old + tot;
@@ -244,13 +247,15 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
     u64 klo[RDX_ITEMS];
     typename std::conditional<std::is_same<HiT, u64>::value, u64, u32>::type khi[RDX_ITEMS];
     u32 digit[RDX_ITEMS], pos[RDX_ITEMS];
+    const u64* __restrict__ lo_t = lo + tbase;
+    const HiT* __restrict__ hi_t = HiTraits<HiT>::has ? hi + tbase : hi;
 #pragma unroll
     for (int j = 0; j < RDX_ITEMS; ++j) {
         const u32 e = w * (64 * RDX_ITEMS) + j * 64 + lane;
         const bool valid = e < n_tile;
-        const u64 idx = valid ? tbase + e : tbase;  // tail slots re-read slot 0 and are never written back
-        klo[j] = lo[idx];
-        khi[j] = ld_hi<HiT>(hi, idx);
+        const u32 eo = valid ? e : 0u;  // tail slots re-read slot 0 and are never written back
+        klo[j] = lo_t[eo];              // uniform tile base + 32-bit lane offset
+        khi[j] = ld_hi<HiT>(hi_t, eo);
         digit[j] = valid ? dfn(klo[j], (u64)khi[j]) : 255u;
     }
     tile_rank<RDX_THREADS, RDX_ITEMS>(digit, pos, s_wcnt, s_dbase, s_scan, RDX_ITEMS);
