@@ -174,15 +174,13 @@ template <typename OutT> u64 exclusive_scan(cblx_ctx* c, const u32* in, u64 n, O
     return d2h<u64>(c, sums.get() + nb);
 }
 
-// offsets[tile][256] from counts[tile][256] (see k_colscan_*): no host readback, everything stays on the stream
-void colscan(cblx_ctx* c, const u32* counts, u32 ntiles, u32* offsets, Buf<u32>& scratch) {
-    const u32 nchunks = (u32)ceil_div(ntiles, COLSCAN_ROWS);
-    if (scratch.n < (size_t)nchunks * 256 + 256) scratch = Buf<u32>(c->pool, (size_t)nchunks * 256 + 256);
-    u32* chunk_sums = scratch.get();
-    u32* base = scratch.get() + (size_t)nchunks * 256;
-    hipLaunchKernelGGL(k_colscan_reduce, dim3(nchunks), dim3(256), 0, c->stream, counts, ntiles, chunk_sums);
-    hipLaunchKernelGGL(k_colscan_spine, dim3(1), dim3(256), 0, c->stream, chunk_sums, nchunks, base);
-    hipLaunchKernelGGL(k_colscan_apply, dim3(nchunks), dim3(256), 0, c->stream, counts, ntiles, chunk_sums, base, offsets);
+// column prefixes + column totals of counts[tile][256] (see k_colscan_*); nt_dev (device) overrides nt_upper when set
+void colscan(cblx_ctx* c, const u32* counts, const u32* nt_dev, u32 nt_upper, u32* colpre, u32* coltot, Buf<u32>& scratch) {
+    const u32 nchunks = (u32)std::max<u64>(1, ceil_div(nt_upper, COLSCAN_ROWS));
+    if (scratch.n < (size_t)nchunks * 256) scratch = Buf<u32>(c->pool, (size_t)nchunks * 256);
+    hipLaunchKernelGGL(k_colscan_reduce, dim3(nchunks), dim3(256), 0, c->stream, counts, nt_dev, nt_upper, scratch.get());
+    hipLaunchKernelGGL(k_colscan_spine, dim3(1), dim3(256), 0, c->stream, scratch.get(), nchunks, coltot);
+    hipLaunchKernelGGL(k_colscan_apply, dim3(nchunks), dim3(256), 0, c->stream, counts, nt_dev, nt_upper, scratch.get(), colpre);
 }
 
 // ---- template configuration ------------------------------------------------------------------------------
@@ -220,47 +218,65 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
     u64* lo_other = rec.ext_lo ? rec.lo2.get() : rec.lo.get();   // the buffer that becomes the destination after pass 0
     HiT* hi_other = rec.ext_lo ? (HiT*)rec.hi2.get() : (HiT*)rec.hi.get();
     auto advance = [&]() { const u64* nl = lo2; const HiT* nh = hi2; lo2 = lo_other; hi2 = hi_other; lo_other = const_cast<u64*>(nl); hi_other = const_cast<HiT*>(nh); lo = nl; hi = nh; };
-    // -- KRN-2: stable LSD radix partition on the PREFIX_BITS above SUFFIX_BITS. Default: per pass a tile histogram, a
-    //    device-wide scan and the LDS-staged scatter. CBLX_ONESWEEP=1 selects the single-read form (one up-front digit
-    //    histogram + decoupled look-back), which on MI355X is currently no faster: an agent-scope look-back hop costs
-    //    1-3 us across the non-coherent per-XCD L2s (measurements in DESIGN.md).
+    // -- KRN-2: stable radix partition on the PREFIX_BITS above SUFFIX_BITS.
+    //    Pass A sorts by the MOST significant 8 prefix bits (the skewed digit: long output runs) and cuts the array into
+    //    <= 256 segments; the remaining bits are sorted by stable LSD passes INSIDE every segment (tiles never straddle a
+    //    segment). For 65..72-bit words (K = 31) the bits the hi byte held are implied by the segment after pass A, so
+    //    it is dropped there: every later pass, the boundary scan and KRN-3 move 8-byte records only.
+    //    Per pass: tile histogram, column scan, per-segment adjust, LDS-staged scatter.
+    constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
+    Buf<u32> seg_start(c->pool, 257);
+    const u32 nA = std::min(8u, P.PB), RB = P.PB - nA;  // bits of pass A, bits left for the LSD passes
     {
-        const u32 ntiles = (u32)ceil_div(N, RDX_TILE);
-        const u32 npass = (P.PB + 7) / 8;
-        static const bool onesweep = getenv("CBLX_ONESWEEP") && atoi(getenv("CBLX_ONESWEEP")) != 0;
-        if (!onesweep) {
-            Buf<u32> counts(c->pool, (size_t)256 * ntiles), offsets(c->pool, (size_t)256 * ntiles), scratch;
-            for (u32 pass = 0; pass < npass; ++pass) {
-                const u32 shift = P.SB + 8 * pass, nbits = std::min(8u, P.PB - 8 * pass);
-                { StageTimer t(c, ST_HIST);
-                  hipLaunchKernelGGL((k_radix_hist<HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits}, ntiles, counts.get()); }
-                { StageTimer t(c, ST_SCAN);
-                  colscan(c, counts.get(), ntiles, offsets.get(), scratch); }
-                { StageTimer t(c, ST_SCATTER);
-                  hipLaunchKernelGGL((k_radix_scatter<HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits}, ntiles, offsets.get(), lo2, hi2); }
-                advance();
-            }
-            CBLX_HIP(hipGetLastError());
-        } else {
-            Buf<unsigned long long> ghist(c->pool, MAX_PASSES * 256);
-            Buf<u32> ctl(c->pool, MAX_PASSES * 128 + 16);  // 8 ticket counters (64 B apart) per pass + error flag
-            Buf<u64> status(c->pool, (size_t)ntiles * 256);
-            CBLX_HIP(hipMemsetAsync(ghist.get(), 0, MAX_PASSES * 256 * 8, c->stream));
-            CBLX_HIP(hipMemsetAsync(ctl.get(), 0, (MAX_PASSES * 128 + 16) * 4, c->stream));
-            CBLX_HIP(hipMemsetAsync(status.get(), 0, (size_t)ntiles * 256 * 8, c->stream));
+        const u32 ntiles = (u32)ceil_div(N, RDX_TILE), nt_max = ntiles + 256;
+        const u32 npassL = (RB + 7) / 8;
+        Buf<u32> counts(c->pool, (size_t)256 * nt_max), colpre(c->pool, (size_t)256 * nt_max), scratch, coltot(c->pool, 256),
+            adj(c->pool, 256 * 256), seg_first(c->pool, 257), nt_dev(c->pool, 1), t_start(c->pool, nt_max), t_count(c->pool, nt_max);
+        Buf<u16> t_seg(c->pool, nt_max);
+        {   // pass A
+            const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
+            const DigitBits dfn{P.SB + RB, nA};
             { StageTimer t(c, ST_HIST);
-              hipLaunchKernelGGL(k_digit_hist<HiT>, dim3((unsigned)std::min<u64>(ceil_div(N, 512 * 8), 256 * 8)), dim3(512), 0, c->stream, lo, hi, N, P.SB, P.PB, npass, ghist.get()); }
-            for (u32 pass = 0; pass < npass; ++pass) {
-                const u32 shift = P.SB + 8 * pass, nbits = std::min(8u, P.PB - 8 * pass);
-                { StageTimer t(c, ST_SCATTER);
-                  hipLaunchKernelGGL((k_onesweep<HiT, DigitBits>), dim3(ntiles), dim3(RDX_THREADS), 0, c->stream, lo, hi, N, DigitBits{shift, nbits},
-                                     ghist.get() + pass * 256, ctl.get() + pass * 128, ntiles, status.get(), pass + 1, lo2, hi2, ctl.get() + MAX_PASSES * 128, 0u); }
-                advance();
-            }
-            CBLX_HIP(hipGetLastError());
-            if (d2h<u32>(c, ctl.get() + MAX_PASSES * 128)) throw Error(CBLX_EDEVICE, "radix partition: look-back timed out");
+              hipLaunchKernelGGL((k_radix_hist<HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, tv, dfn, counts.get()); }
+            { StageTimer t(c, ST_SCAN);
+              colscan(c, counts.get(), nullptr, ntiles, colpre.get(), coltot.get(), scratch);
+              hipLaunchKernelGGL(k_seg_adjust, dim3(1), dim3(256), 0, c->stream, colpre.get(), coltot.get(), (const u32*)nullptr, (const u32*)nullptr,
+                                 (const u32*)nullptr, ntiles, 1u, adj.get());
+              hipLaunchKernelGGL(k_seg_table, dim3(1), dim3(256), 0, c->stream, coltot.get(), seg_start.get(), seg_first.get(), nt_dev.get());
+              hipLaunchKernelGGL(k_tile_table, grid1(nt_max, 256), dim3(256), 0, c->stream, seg_start.get(), seg_first.get(), nt_dev.get(), t_start.get(),
+                                 t_count.get(), t_seg.get()); }
+            { StageTimer t(c, ST_SCATTER);
+              if constexpr (DROP_HI)
+                  hipLaunchKernelGGL((k_radix_scatter<HiT, NoHi, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, tv, dfn, colpre.get(),
+                                     adj.get(), lo2, (NoHi*)nullptr);
+              else
+                  hipLaunchKernelGGL((k_radix_scatter<HiT, HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, tv, dfn, colpre.get(),
+                                     adj.get(), lo2, hi2); }
+            advance();
         }
+        const TileView tvL{t_start.get(), t_count.get(), t_seg.get(), nt_dev.get(), nt_max, N};
+        for (u32 pass = 0; pass < npassL; ++pass) {
+            const DigitBits dfn{P.SB + 8 * pass, std::min(8u, RB - 8 * pass)};
+            auto run = [&](auto hi_tag) {
+                typedef decltype(hi_tag) H;  // record layout of the LSD passes: no hi once it was dropped
+                const H* hin = (const H*)hi;
+                H* hout = (H*)hi2;
+                { StageTimer t(c, ST_HIST);
+                  hipLaunchKernelGGL((k_radix_hist<H, DigitBits>), dim3(xcd_grid(nt_max)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tvL, dfn, counts.get()); }
+                { StageTimer t(c, ST_SCAN);
+                  colscan(c, counts.get(), nt_dev.get(), nt_max, colpre.get(), coltot.get(), scratch);
+                  hipLaunchKernelGGL(k_seg_adjust, dim3(256), dim3(256), 0, c->stream, colpre.get(), coltot.get(), seg_first.get(), seg_start.get(), nt_dev.get(),
+                                     nt_max, 256u, adj.get()); }
+                { StageTimer t(c, ST_SCATTER);
+                  hipLaunchKernelGGL((k_radix_scatter<H, H, DigitBits>), dim3(xcd_grid(nt_max)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tvL, dfn, colpre.get(),
+                                     adj.get(), lo2, hout); }
+            };
+            if constexpr (DROP_HI) run(NoHi()); else run(HiT());
+            advance();
+        }
+        CBLX_HIP(hipGetLastError());
         if (lo == rec.lo2.get()) { std::swap(rec.lo, rec.lo2); std::swap(rec.hi, rec.hi2); }  // final data -> rec.lo/hi
+        CBLX_HIP(hipStreamSynchronize(c->stream));  // the pass tables are released here
     }
     rec.lo2.reset();
     rec.hi2.reset();
@@ -276,7 +292,10 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
         CBLX_HIP(hipMemsetAsync(start_dense.get(), 0xFF, nprefix * 4, c->stream));
         CBLX_HIP(hipMemsetAsync(nr.bv.get(), 0, nwords * 8, c->stream));
         CBLX_HIP(hipMemsetAsync(popc.get(), 0, nwords * 4, c->stream));
-        hipLaunchKernelGGL(k_boundaries<HiT>, grid1(ceil_div(N, 4), 256), dim3(256), 0, c->stream, lo, hi, N, P.SB, P.PB, start_dense.get());
+        if constexpr (DROP_HI)
+            hipLaunchKernelGGL(k_boundaries_seg, grid1(ceil_div(N, 4), 256), dim3(256), 0, c->stream, lo, N, P.SB, RB, seg_start.get(), start_dense.get());
+        else
+            hipLaunchKernelGGL(k_boundaries<HiT>, grid1(ceil_div(N, 4), 256), dim3(256), 0, c->stream, lo, hi, N, P.SB, P.PB, start_dense.get());
         hipLaunchKernelGGL(k_bitvector, grid1(std::max<u64>(nprefix, 64), 256), dim3(256), 0, c->stream, start_dense.get(), nprefix, nr.bv.get(), popc.get());
         nr.nb = exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get());
         nr.prefix = Buf<u32>(c->pool, nr.nb + 1);
@@ -979,24 +998,29 @@ int cblx_partition_words_device(cblx_ctx* c, const uint64_t* d_lo, const void* d
         for (u32 i = 0; i < MAX_DEST - 1; ++i) fn.bounds[i] = i + 1 < nd ? bounds[i] : 0xFFFFFFFFu;
         for (u32 i = 1; i + 1 < nd; ++i) if (bounds[i] < bounds[i - 1]) throw Error(CBLX_EINVAL, "bounds must be ascending");
         const u32 ntiles = (u32)ceil_div(n, RDX_TILE);
-        Buf<u32> cnt(c->pool, (size_t)256 * ntiles), off(c->pool, (size_t)256 * ntiles), scratch;
+        Buf<u32> cnt(c->pool, (size_t)256 * ntiles), colpre(c->pool, (size_t)256 * ntiles), scratch, coltot(c->pool, 256), adj(c->pool, 256);
+        const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, n};
         dispatch(c->P, [&](auto cfg) {
             typedef typename decltype(cfg)::HiT H;
             const H* hi = (const H*)d_hi;
             H* ohi = (H*)d_out_hi;
             { StageTimer t(c, ST_HIST);
-              hipLaunchKernelGGL((k_radix_hist<H, DigitDest>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, d_lo, hi, n, fn, ntiles, cnt.get()); }
+              hipLaunchKernelGGL((k_radix_hist<H, DigitDest>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, d_lo, hi, tv, fn, cnt.get()); }
             { StageTimer t(c, ST_SCAN);
-              colscan(c, cnt.get(), ntiles, off.get(), scratch); }
+              colscan(c, cnt.get(), nullptr, ntiles, colpre.get(), coltot.get(), scratch);
+              hipLaunchKernelGGL(k_seg_adjust, dim3(1), dim3(256), 0, c->stream, colpre.get(), coltot.get(), (const u32*)nullptr, (const u32*)nullptr,
+                                 (const u32*)nullptr, ntiles, 1u, adj.get()); }
             { StageTimer t(c, ST_SCATTER);
-              hipLaunchKernelGGL((k_radix_scatter<H, DigitDest>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, d_lo, hi, n, fn, ntiles, off.get(), d_out_lo, ohi); }
+              hipLaunchKernelGGL((k_radix_scatter<H, H, DigitDest>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, d_lo, hi, tv, fn, colpre.get(),
+                                 adj.get(), d_out_lo, ohi); }
             CBLX_HIP(hipGetLastError());
         });
-        // start of every destination = offset of its first tile
+        // run length of every destination = its column total
         std::vector<u64> starts(nd + 1, n);
         {
-            std::vector<u32> row0 = d2h_vec<u32>(c, off.get(), 256);  // offsets of tile 0 = start of every destination
-            for (u32 d = 0; d < nd; ++d) starts[d] = row0[d];
+            std::vector<u32> tot = d2h_vec<u32>(c, coltot.get(), 256);
+            u64 run = 0;
+            for (u32 d = 0; d < nd; ++d) { starts[d] = run; run += tot[d]; }
         }
         for (u32 d = 0; d < nd; ++d) counts[d] = starts[d + 1] - starts[d];
         collect_events(c);

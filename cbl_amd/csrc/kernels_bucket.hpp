@@ -46,6 +46,35 @@ __global__ __launch_bounds__(256) void k_boundaries(const u64* __restrict__ lo, 
         q = p[k];
     }
 }
+// Same when the hi part was dropped by the first (most significant digit) partition pass: the top `nA` prefix bits of
+// record i are the segment that contains position i (seg_start[257]), the low R bits are still in lo.
+__global__ __launch_bounds__(256) void k_boundaries_seg(const u64* __restrict__ lo, u64 n, u32 SB, u32 R, const u32* __restrict__ seg_start,
+                                                        u32* __restrict__ start_dense) {
+    __shared__ u32 s_seg[257];
+    for (u32 i = threadIdx.x; i < 257; i += blockDim.x) s_seg[i] = seg_start[i];
+    __syncthreads();
+    const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    auto prefix_at = [&](u64 i) -> u32 {
+        u32 l = 0, h = 256;  // last segment with seg_start[s] <= i
+        while (h - l > 1) {
+            const u32 mid = (l + h) >> 1;
+            if (s_seg[mid] <= (u32)i) l = mid; else h = mid;
+        }
+        const u32 low = R ? get_bits(lo[i], 0, SB, R) : 0u;
+        return (l << R) | low;
+    };
+    u32 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = prefix_at(i0 + k < n ? i0 + k : n - 1);
+    u32 q = __shfl_up(p[3], 1, 64);
+    if ((threadIdx.x & 63) == 0) q = i0 > 0 ? prefix_at(i0 - 1) : EMPTY32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + k < n && p[k] != q) start_dense[p[k]] = (u32)(i0 + k);
+        q = p[k];
+    }
+}
 // one lane per prefix, one wave per bitvector word
 __global__ void k_bitvector(const u32* __restrict__ start_dense, u64 nprefix, u64* __restrict__ bv, u32* __restrict__ popc) {
     u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -188,29 +188,59 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 ntiles) {
 #endif
 }
 
+// Where the tiles of a pass live. Plain passes cut [0, n) into RDX_TILE-record tiles. After the first (most significant
+// digit) pass the array is a sequence of SEGMENTS (one per value of that digit); the remaining passes are stable LSD
+// passes INSIDE every segment, so their tiles never straddle a segment: start/count/seg come from a table built on the
+// device (k_seg_table / k_tile_table) and the tile count is read from device memory (no host round trip).
+struct TileView {
+    const u32* start;       // null: tile t = records [t * RDX_TILE, ...)
+    const u32* count;
+    const u16* seg;         // segment of the tile (null: 0)
+    const u32* ntiles_dev;  // null: ntiles below
+    u32 ntiles;
+    u64 n;
+};
+__device__ __forceinline__ bool tile_get(const TileView& tv, u32 b, u32& tile, u64& tbase, u32& n_tile, u32& seg) {
+    const u32 nt = tv.ntiles_dev ? *tv.ntiles_dev : tv.ntiles;
+    if ((b >> 3) >= (nt + 7u) / 8u) return false;  // the grid may be sized for an upper bound of the tile count
+    tile = xcd_tile(b, nt);
+    if (tile >= nt) return false;
+    if (tv.start) {
+        tbase = tv.start[tile];
+        n_tile = tv.count[tile];
+        seg = tv.seg[tile];
+    } else {
+        tbase = (u64)tile * RDX_TILE;
+        n_tile = (u32)((tv.n - tbase) < (u64)RDX_TILE ? (tv.n - tbase) : (u64)RDX_TILE);
+        seg = 0;
+    }
+    return true;
+}
+
 // per-tile digit histogram -> counts[tile * 256 + digit] (tile-major: one coalesced 1 KiB row per workgroup).
 // Counting needs no ranks: per-wave private LDS histograms fed by non-returning ds_add (the ballot matching of
 // tile_rank costs ~50 VALU per record and made this kernel VALU-bound).
 template <typename HiT, typename DigitFn>
-__global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const u64* __restrict__ lo, const HiT* __restrict__ hi, u64 n,
-                                                            DigitFn dfn, u32 ntiles, u32* __restrict__ counts) {
+__global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const u64* __restrict__ lo, const HiT* __restrict__ hi, TileView tv,
+                                                            DigitFn dfn, u32* __restrict__ counts) {
     __shared__ u32 s_wcnt[(RDX_THREADS / 64) * 256];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     for (u32 i = tid; i < (RDX_THREADS / 64) * 256; i += RDX_THREADS) s_wcnt[i] = 0;
     __syncthreads();
-    const u32 tile = xcd_tile(blockIdx.x, ntiles);
-    if (tile >= ntiles) return;
-    const u64 tbase = (u64)tile * RDX_TILE;
-    const u32 n_tile = (u32)((n - tbase) < (u64)RDX_TILE ? (n - tbase) : (u64)RDX_TILE);
+    u32 tile, n_tile, seg;
+    u64 tbase;
+    if (!tile_get(tv, blockIdx.x, tile, tbase, n_tile, seg)) return;
     u32* my = s_wcnt + w * 256;
     u64 klo[RDX_ITEMS];
     typename std::conditional<std::is_same<HiT, u64>::value, u64, u32>::type khi[RDX_ITEMS];
+    const u64* __restrict__ lo_t = lo + tbase;
+    const HiT* __restrict__ hi_t = HiTraits<HiT>::has ? hi + tbase : hi;
 #pragma unroll
     for (int j = 0; j < RDX_ITEMS; ++j) {
         const u32 e = w * (64 * RDX_ITEMS) + j * 64 + lane;
-        const u64 idx = e < n_tile ? tbase + e : tbase;
-        klo[j] = lo[idx];
-        khi[j] = ld_hi<HiT>(hi, idx);
+        const u32 eo = e < n_tile ? e : 0u;
+        klo[j] = lo_t[eo];
+        khi[j] = ld_hi<HiT>(hi_t, eo);
     }
 #pragma unroll
     for (int j = 0; j < RDX_ITEMS; ++j) {
@@ -226,23 +256,26 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const u64* __restric
     }
 }
 
-// scatter: offsets[tile * 256 + digit] = global position of the tile's first element with that digit
-template <typename HiT, typename DigitFn>
-__global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __restrict__ lo, const HiT* __restrict__ hi, u64 n,
-                                                               DigitFn dfn, u32 ntiles,
-                                                               const u32* __restrict__ offsets, u64* __restrict__ out_lo,
-                                                               HiT* __restrict__ out_hi) {
+// scatter. colpre[tile * 256 + d] = records with digit d in earlier tiles (pure column prefix); adj[seg * 256 + d] turns it
+// into a global position (k_seg_adjust). OutHiT = NoHi drops the hi part on the way out (first pass of 65..72-bit words:
+// the bits it held are implied by the segment from then on).
+template <typename HiT, typename OutHiT, typename DigitFn>
+__global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __restrict__ lo, const HiT* __restrict__ hi, TileView tv,
+                                                               DigitFn dfn, const u32* __restrict__ colpre,
+                                                               const u32* __restrict__ adj, u64* __restrict__ out_lo,
+                                                               OutHiT* __restrict__ out_hi) {
+    constexpr bool STAGE_HI = HiTraits<HiT>::has && HiTraits<OutHiT>::has;
     __shared__ u64 s_lo[RDX_TILE];
-    __shared__ typename std::conditional<HiTraits<HiT>::has, HiT, u8>::type s_hi[HiTraits<HiT>::has ? RDX_TILE : 1];
+    __shared__ typename std::conditional<STAGE_HI, HiT, u8>::type s_hi[STAGE_HI ? RDX_TILE : 1];
+    __shared__ u8 s_dig[STAGE_HI ? 1 : RDX_TILE];  // digit of the staged record when it cannot be recomputed from lo alone
     __shared__ u32 s_wcnt[(RDX_THREADS / 64) * 256];
     __shared__ u32 s_dbase[256];
     __shared__ u64 s_gbase[256];
     __shared__ u32 s_scan[RDX_THREADS / 64 + 1];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const u32 tile = xcd_tile(blockIdx.x, ntiles);
-    if (tile >= ntiles) return;
-    const u64 tbase = (u64)tile * RDX_TILE;
-    const u32 n_tile = (u32)((n - tbase) < (u64)RDX_TILE ? (n - tbase) : (u64)RDX_TILE);
+    u32 tile, n_tile, seg;
+    u64 tbase;
+    if (!tile_get(tv, blockIdx.x, tile, tbase, n_tile, seg)) return;
 
     u64 klo[RDX_ITEMS];
     typename std::conditional<std::is_same<HiT, u64>::value, u64, u32>::type khi[RDX_ITEMS];
@@ -259,11 +292,12 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
         digit[j] = valid ? dfn(klo[j], (u64)khi[j]) : 255u;
     }
     tile_rank<RDX_THREADS, RDX_ITEMS>(digit, pos, s_wcnt, s_dbase, s_scan, RDX_ITEMS);
-    if (tid < 256) s_gbase[tid] = offsets[(u64)tile * 256 + tid] - s_dbase[tid];
+    if (tid < 256) s_gbase[tid] = (u64)adj[seg * 256 + tid] + colpre[(u64)tile * 256 + tid] - s_dbase[tid];
 #pragma unroll
     for (int j = 0; j < RDX_ITEMS; ++j) {
         s_lo[pos[j]] = klo[j];  // pos < RDX_TILE always; tail slots land in [n_tile, RDX_TILE)
-        if constexpr (HiTraits<HiT>::has) s_hi[pos[j]] = (HiT)khi[j];
+        if constexpr (STAGE_HI) s_hi[pos[j]] = (HiT)khi[j];
+        else s_dig[pos[j]] = (u8)digit[j];
     }
     __syncthreads();
 #pragma unroll
@@ -272,35 +306,33 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
         if (s < n_tile) {
             const u64 a = s_lo[s];
             u64 b = 0;
-            if constexpr (HiTraits<HiT>::has) b = (u64)s_hi[s];
-            const u32 d = dfn(a, b);
-#ifdef CBLX_DBG_LINEAR_WRITE
-            const u64 dst = tbase + s + (s_gbase[d] & 0);
-#else
+            u32 d;
+            if constexpr (STAGE_HI) { b = (u64)s_hi[s]; d = dfn(a, b); }
+            else d = s_dig[s];
             const u64 dst = s_gbase[d] + s;
-#endif
             out_lo[dst] = a;
-            st_hi<HiT>(out_hi, dst, b);
+            st_hi<OutHiT>(out_hi, dst, b);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Offsets for the scatter from the tile-major count matrix C[tile][256]:
-//   O[tile][d] = sum_{d' < d} total[d'] + sum_{t' < tile} C[t'][d]
-// i.e. an exclusive scan down every column plus the exclusive scan of the column totals. Every access is a coalesced
-// 1 KiB row (thread d owns column d); rows are cut into chunks of COLSCAN_ROWS for parallelism.
+// Column prefixes of the tile-major count matrix C[tile][256]: P[tile][d] = sum_{t' < tile} C[t'][d], and the column
+// totals. Every access is a coalesced 1 KiB row (thread d owns column d); rows are cut into chunks of COLSCAN_ROWS for
+// parallelism. k_seg_adjust then supplies, per segment, what must be added to P to get a global position.
 static const u32 COLSCAN_ROWS = 1024;
-__global__ __launch_bounds__(256) void k_colscan_reduce(const u32* __restrict__ counts, u32 ntiles, u32* __restrict__ chunk_sums) {
+__device__ __forceinline__ u32 dev_ntiles(const u32* ntiles_dev, u32 ntiles) { return ntiles_dev ? *ntiles_dev : ntiles; }
+__global__ __launch_bounds__(256) void k_colscan_reduce(const u32* __restrict__ counts, const u32* ntiles_dev, u32 ntiles,
+                                                        u32* __restrict__ chunk_sums) {
+    const u32 nt = dev_ntiles(ntiles_dev, ntiles);
     const u32 d = threadIdx.x, r0 = blockIdx.x * COLSCAN_ROWS;
-    const u32 r1 = r0 + COLSCAN_ROWS < ntiles ? r0 + COLSCAN_ROWS : ntiles;
+    const u32 r1 = r0 + COLSCAN_ROWS < nt ? r0 + COLSCAN_ROWS : nt;
     u32 s = 0;
 #pragma unroll 8
     for (u32 r = r0; r < r1; ++r) s += counts[(u64)r * 256 + d];
     chunk_sums[(u64)blockIdx.x * 256 + d] = s;
 }
-__global__ __launch_bounds__(256) void k_colscan_spine(u32* __restrict__ chunk_sums, u32 nchunks, u32* __restrict__ base /* 256 */) {
-    __shared__ u32 sm[256 / 64 + 1];
+__global__ __launch_bounds__(256) void k_colscan_spine(u32* __restrict__ chunk_sums, u32 nchunks, u32* __restrict__ coltot /* 256 */) {
     const u32 d = threadIdx.x;
     u32 run = 0;
 #pragma unroll 8
@@ -309,19 +341,68 @@ __global__ __launch_bounds__(256) void k_colscan_spine(u32* __restrict__ chunk_s
         chunk_sums[(u64)c * 256 + d] = run;
         run += v;
     }
-    base[d] = block_exclusive_scan<256, u32>(run, sm, nullptr);
+    coltot[d] = run;
 }
-__global__ __launch_bounds__(256) void k_colscan_apply(const u32* __restrict__ counts, u32 ntiles, const u32* __restrict__ chunk_sums,
-                                                       const u32* __restrict__ base, u32* __restrict__ offsets) {
+__global__ __launch_bounds__(256) void k_colscan_apply(const u32* __restrict__ counts, const u32* ntiles_dev, u32 ntiles,
+                                                       const u32* __restrict__ chunk_sums, u32* __restrict__ colpre) {
+    const u32 nt = dev_ntiles(ntiles_dev, ntiles);
     const u32 d = threadIdx.x, r0 = blockIdx.x * COLSCAN_ROWS;
-    const u32 r1 = r0 + COLSCAN_ROWS < ntiles ? r0 + COLSCAN_ROWS : ntiles;
-    u32 run = base[d] + chunk_sums[(u64)blockIdx.x * 256 + d];
+    const u32 r1 = r0 + COLSCAN_ROWS < nt ? r0 + COLSCAN_ROWS : nt;
+    u32 run = chunk_sums[(u64)blockIdx.x * 256 + d];
 #pragma unroll 8
     for (u32 r = r0; r < r1; ++r) {
         const u32 v = counts[(u64)r * 256 + d];
-        offsets[(u64)r * 256 + d] = run;
+        colpre[(u64)r * 256 + d] = run;
         run += v;
     }
+}
+// One workgroup per segment s (tiles [first[s], first[s+1]), records from seg_start[s]):
+//   adj[s][d] = seg_start[s] + (records of the segment with a smaller digit) - P[first[s]][d]
+// so that adj[s][d] + P[tile][d] is where tile's first record with digit d goes. A plain pass is the case of one segment.
+__global__ __launch_bounds__(256) void k_seg_adjust(const u32* __restrict__ colpre, const u32* __restrict__ coltot,
+                                                    const u32* __restrict__ seg_first /* nseg+1, null: {0, ntiles} */,
+                                                    const u32* __restrict__ seg_start /* nseg, null: {0} */, const u32* ntiles_dev,
+                                                    u32 ntiles, u32 nseg, u32* __restrict__ adj) {
+    __shared__ u32 sm[256 / 64 + 1];
+    const u32 nt = dev_ntiles(ntiles_dev, ntiles);
+    const u32 s = blockIdx.x, d = threadIdx.x;
+    const u32 f0 = seg_first ? seg_first[s] : 0u, f1 = seg_first ? seg_first[s + 1] : nt;
+    const u32 p0 = f0 < nt ? colpre[(u64)f0 * 256 + d] : coltot[d];
+    const u32 p1 = f1 < nt ? colpre[(u64)f1 * 256 + d] : coltot[d];
+    const u32 ex = block_exclusive_scan<256, u32>(p1 - p0, sm, nullptr);
+    adj[s * 256 + d] = (seg_start ? seg_start[s] : 0u) + ex - p0;
+    (void)nseg;
+}
+// Segments of the remaining passes from the first pass's column totals: seg_start (exclusive scan of the totals),
+// seg_first (exclusive scan of the tiles each segment needs), total tile count.
+__global__ __launch_bounds__(256) void k_seg_table(const u32* __restrict__ coltot, u32* __restrict__ seg_start /* 257 */,
+                                                   u32* __restrict__ seg_first /* 257 */, u32* __restrict__ ntiles_dev) {
+    __shared__ u32 sm[256 / 64 + 1];
+    const u32 d = threadIdx.x;
+    const u32 c = coltot[d];
+    u32 tot;
+    const u32 st = block_exclusive_scan<256, u32>(c, sm, &tot);
+    seg_start[d] = st;
+    if (d == 255) seg_start[256] = tot;
+    u32 ttot;
+    const u32 ft = block_exclusive_scan<256, u32>((c + RDX_TILE - 1) / RDX_TILE, sm, &ttot);
+    seg_first[d] = ft;
+    if (d == 255) { seg_first[256] = ttot; *ntiles_dev = ttot; }
+}
+__global__ void k_tile_table(const u32* __restrict__ seg_start, const u32* __restrict__ seg_first, const u32* __restrict__ ntiles_dev,
+                             u32* __restrict__ t_start, u32* __restrict__ t_count, u16* __restrict__ t_seg) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *ntiles_dev) return;
+    u32 lo = 0, hi = 256;  // last segment with seg_first[s] <= t (segments without tiles share their successor's first tile)
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (seg_first[mid] <= t) lo = mid; else hi = mid;
+    }
+    const u32 st = seg_start[lo] + (t - seg_first[lo]) * RDX_TILE;
+    const u32 en = seg_start[lo + 1];
+    t_start[t] = st;
+    t_count[t] = en - st < (u32)RDX_TILE ? en - st : (u32)RDX_TILE;
+    t_seg[t] = (u16)lo;
 }
 
 // ------------------------------------------------------------------------------------------------
