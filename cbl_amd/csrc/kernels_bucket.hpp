@@ -55,14 +55,18 @@ __global__ __launch_bounds__(256) void k_boundaries_seg(const u64* __restrict__ 
     __syncthreads();
     const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i0 >= n) return;
+    u32 cur = 0xFFFFFFFFu;  // segment of the previous lookup: neighbours almost always share it
     auto prefix_at = [&](u64 i) -> u32 {
-        u32 l = 0, h = 256;  // last segment with seg_start[s] <= i
-        while (h - l > 1) {
-            const u32 mid = (l + h) >> 1;
-            if (s_seg[mid] <= (u32)i) l = mid; else h = mid;
+        if (cur == 0xFFFFFFFFu || (u32)i < s_seg[cur] || (u32)i >= s_seg[cur + 1]) {
+            u32 l = 0, h = 256;  // last segment with seg_start[s] <= i
+            while (h - l > 1) {
+                const u32 mid = (l + h) >> 1;
+                if (s_seg[mid] <= (u32)i) l = mid; else h = mid;
+            }
+            cur = l;
         }
         const u32 low = R ? get_bits(lo[i], 0, SB, R) : 0u;
-        return (l << R) | low;
+        return (cur << R) | low;
     };
     u32 p[4];
 #pragma unroll
