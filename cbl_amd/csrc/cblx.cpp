@@ -205,7 +205,8 @@ struct Records {
     const void* ext_hi = nullptr;
 };
 
-template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
+// `countsA`: histogram of the first pass already accumulated by KRN-1 (empty Buf = compute it here)
+template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA = Buf<u32>()) {
     typedef typename C::HiT HiT;
     const Consts& P = c->P;
     Resident nr;
@@ -230,13 +231,15 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N) {
     {
         const u32 ntiles = (u32)ceil_div(N, RDX_TILE), nt_max = ntiles + 256;
         const u32 npassL = (RB + 7) / 8;
-        Buf<u32> counts(c->pool, (size_t)256 * nt_max), colpre(c->pool, (size_t)256 * nt_max), scratch, coltot(c->pool, 256),
+        const bool haveA = countsA.get() != nullptr;
+        Buf<u32> counts = haveA ? std::move(countsA) : Buf<u32>(c->pool, (size_t)256 * nt_max);
+        Buf<u32> colpre(c->pool, (size_t)256 * nt_max), scratch, coltot(c->pool, 256),
             adj(c->pool, 256 * 256), seg_first(c->pool, 257), nt_dev(c->pool, 1), t_start(c->pool, nt_max), t_count(c->pool, nt_max);
         Buf<u16> t_seg(c->pool, nt_max);
         {   // pass A
             const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
             const DigitBits dfn{P.SB + RB, nA};
-            { StageTimer t(c, ST_HIST);
+            if (!haveA) { StageTimer t(c, ST_HIST);
               hipLaunchKernelGGL((k_radix_hist<HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, tv, dfn, counts.get()); }
             { StageTimer t(c, ST_SCAN);
               colscan(c, counts.get(), nullptr, ntiles, colpre.get(), coltot.get(), scratch);
@@ -466,16 +469,17 @@ void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq
     CBLX_HIP(hipGetLastError());
     CBLX_HIP(hipStreamSynchronize(c->stream));  // temporaries (nch, err, chunk_base, chunk_nk, ndirty) die here
 }
-template <typename C> void encode(cblx_ctx* c, const u8* d_bases, const ChunkPlan& pl, u64* out_lo, typename C::HiT* out_hi, u64 out_base) {
+template <typename C> void encode(cblx_ctx* c, const u8* d_bases, const ChunkPlan& pl, u64* out_lo, typename C::HiT* out_hi, u64 out_base,
+                                  EncHist eh = EncHist{nullptr, 0, 0}) {
     typedef typename C::HiT HiT;
     StageTimer t(c, ST_ENCODE);
     const u64 ntiles = ceil_div(pl.total_bases, ENC_TILE_BYTES);
     if (ntiles)
         hipLaunchKernelGGL((k_encode<C::WIDE, HiT>), dim3((unsigned)ntiles), dim3(ENC_THREADS), 0, c->stream, d_bases, pl.total_bases, pl.chunk_start.get(),
-                           pl.chunk_len.get(), pl.kmer_off.get(), pl.ndirty ? pl.dirty.get() : (const u8*)nullptr, pl.tile_first.get(), c->P, out_lo, out_hi, out_base);
+                           pl.chunk_len.get(), pl.kmer_off.get(), pl.ndirty ? pl.dirty.get() : (const u8*)nullptr, pl.tile_first.get(), c->P, out_lo, out_hi, out_base, eh);
     if (pl.ndirty)
         hipLaunchKernelGGL((k_encode_dirty<C::WIDE, HiT>), grid1(pl.nchunks, 64), dim3(64), 0, c->stream, d_bases, pl.chunk_start.get(), pl.chunk_len.get(),
-                           pl.kmer_off.get(), pl.dirty.get(), pl.nchunks, c->P, out_lo, out_hi, out_base);
+                           pl.kmer_off.get(), pl.dirty.get(), pl.nchunks, c->P, out_lo, out_hi, out_base, eh);
     CBLX_HIP(hipGetLastError());
 }
 
@@ -493,8 +497,18 @@ void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nse
         if (pl.n_kmers == 0) return;
         Records rec;
         const u64 base = begin_records<C>(c, rec, pl.n_kmers);
-        encode<C>(c, d_bases, pl, rec.lo.get(), (typename C::HiT*)rec.hi.get(), base);
-        pipeline<C>(c, rec, base + pl.n_kmers);
+        Buf<u32> countsA;
+        EncHist eh{nullptr, 0, 0};
+        if (base == 0) {  // empty index: KRN-1 also accumulates the first partition pass's tile histogram
+            static_assert(ENC_HIST_WINDOW == RDX_TILE, "fused histogram windows must be the partition tiles");
+            const size_t ntmax = (size_t)ceil_div(pl.n_kmers, RDX_TILE) + 256;
+            countsA = Buf<u32>(c->pool, 256 * ntmax);
+            CBLX_HIP(hipMemsetAsync(countsA.get(), 0, 256 * ntmax * 4, c->stream));
+            const u32 nA = std::min(8u, c->P.PB);
+            eh = EncHist{countsA.get(), c->P.SB + (c->P.PB - nA), nA};
+        }
+        encode<C>(c, d_bases, pl, rec.lo.get(), (typename C::HiT*)rec.hi.get(), base, eh);
+        pipeline<C>(c, rec, base + pl.n_kmers, std::move(countsA));
         c->kmers_inserted += pl.n_kmers;
     });
     collect_events(c);

@@ -34,6 +34,14 @@ static const u32 ENC_MAX_CHUNKS = 1024;                                    // >=
 static const u32 ENC_MAX_BASES = ENC_TILE_BYTES + CHUNK_KMERS + 64 + 32;   // bytes a tile can span (+ align slack)
 static const u32 ENC_CODE_WORDS = (ENC_MAX_BASES + 15) / 16 + 8;           // packed dwords (+ read-ahead slack)
 static const u32 ENC_MAX_KMERS = ENC_MAX_BASES;                            // k-mers per tile <= bytes spanned
+// Optional fused histogram of the first partition pass: counts[window * 256 + digit] where window = output position /
+// HIST_WINDOW (= the partition tile size). A tile's outputs are contiguous, so they touch at most ENC_HIST_WINDOWS windows.
+static const u32 ENC_HIST_WINDOW = 4096;
+static const u32 ENC_HIST_WINDOWS = ENC_MAX_KMERS / ENC_HIST_WINDOW + 2;
+struct EncHist {
+    u32* counts;  // null: no fused histogram
+    u32 shift, nbits;
+};
 
 // ---- per-sequence chunk counts; flags sequences shorter than K (src/cbl.rs:329-334) ------------------
 __global__ void k_seq_chunk_count(const u64* __restrict__ offsets, u64 nseq, u32 K, u32* __restrict__ nchunks,
@@ -194,8 +202,10 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
                                                         const u64* __restrict__ kmer_off /* nchunks+1 */,
                                                         const u8* __restrict__ dirty /* may be null */,
                                                         const u32* __restrict__ tile_first, Consts P,
-                                                        u64* __restrict__ out_lo, HiT* __restrict__ out_hi, u64 out_base) {
+                                                        u64* __restrict__ out_lo, HiT* __restrict__ out_hi, u64 out_base,
+                                                        EncHist eh) {
     typedef typename KmerT<WIDE>::type T;
+    __shared__ u32 s_hist[ENC_HIST_WINDOWS * 256];
     __shared__ u32 s_codes[ENC_CODE_WORDS];
     __shared__ u32 s_koff[ENC_MAX_CHUNKS + 1];
     __shared__ u32 s_cstart[ENC_MAX_CHUNKS];
@@ -217,6 +227,9 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
         s_cstart[i] = (u32)(chunk_start[c0 + i] - A0);
         s_dirty[i] = dirty ? dirty[c0 + i] : (u8)0;
     }
+    const u64 win0 = (out_base + kbase) / ENC_HIST_WINDOW;  // first window this tile's outputs fall into
+    if (eh.counts)
+        for (u32 i = tid; i < ENC_HIST_WINDOWS * 256; i += ENC_THREADS) s_hist[i] = 0;
     const u32 nwords = (u32)((B1 - A0 + 15) >> 4);
     for (u32 i = tid; i < nwords + 6 && i < ENC_CODE_WORDS; i += ENC_THREADS) {
         u64 b = A0 + (u64)i * 16;
@@ -286,6 +299,14 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
         kmer_word<WIDE>(x, P, rc, lo, hi);
         out_lo[dst] = lo;
         st_hi<HiT>(out_hi, dst, hi);
+        if (eh.counts) atomicAdd(&s_hist[(u32)(dst / ENC_HIST_WINDOW - win0) * 256 + get_bits(lo, hi, eh.shift, eh.nbits)], 1u);
+    }
+    if (eh.counts) {  // the first-pass digit is the skewed one: only a few dozen bins per window are non-zero
+        __syncthreads();
+        for (u32 i = tid; i < ENC_HIST_WINDOWS * 256; i += ENC_THREADS) {
+            const u32 v = s_hist[i];
+            if (v) atomicAdd(&eh.counts[(win0 + (i >> 8)) * 256 + (i & 255u)], v);
+        }
     }
 }
 
@@ -296,7 +317,7 @@ template <bool WIDE, typename HiT>
 __global__ void k_encode_dirty(const u8* __restrict__ bases, const u64* __restrict__ chunk_start,
                                const u32* __restrict__ chunk_len, const u64* __restrict__ kmer_off,
                                const u8* __restrict__ dirty, u64 nchunks, Consts P, u64* __restrict__ out_lo,
-                               HiT* __restrict__ out_hi, u64 out_base) {
+                               HiT* __restrict__ out_hi, u64 out_base, EncHist eh) {
     typedef typename KmerT<WIDE>::type T;
     u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks || !dirty[c]) return;
@@ -326,6 +347,7 @@ __global__ void k_encode_dirty(const u8* __restrict__ bases, const u64* __restri
         kmer_word<WIDE>(x & MASK, P, rc, lo, hi);
         out_lo[dst] = lo;
         st_hi<HiT>(out_hi, dst, hi);
+        if (eh.counts) atomicAdd(&eh.counts[(dst / ENC_HIST_WINDOW) * 256 + get_bits(lo, hi, eh.shift, eh.nbits)], 1u);
     };
     for (u32 i = 0; i < P.K; ++i) if (nuc_valid(s[i])) x = (x << 2) | (T)nuc_code(s[i]);
     emit();
