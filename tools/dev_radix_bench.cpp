@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #include "kernels_bucket.hpp"
+#include "onesweep_experiment.hpp"
 using namespace cblx;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
@@ -33,7 +34,7 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     const u32 ntiles = (u32)((n + RDX_TILE - 1) / RDX_TILE);
     u32* counts = dalloc<u32>((size_t)256 * ntiles); u32* offsets = dalloc<u32>((size_t)256 * ntiles);
-    u64* sums = dalloc<u64>(((size_t)256 * ntiles + SCAN_TILE - 1) / SCAN_TILE + 2);
+    u64* sums = dalloc<u64>(((size_t)ntiles / COLSCAN_ROWS + 2) * 256 + 1024);
     unsigned long long* ghist = dalloc<unsigned long long>(MAX_PASSES * 256);
     u32* ctl = dalloc<u32>(MAX_PASSES * 128 + 16);
     u64* status = dalloc<u64>((size_t)ntiles * 256);
@@ -42,14 +43,18 @@ int main(int argc, char** argv) {
     for (int pass = 0; pass < 3; ++pass) {
         DigitBits d{SB + 8 * pass, 8};
         printf("--- digit bits %u..%u\n", SB + 8 * pass, SB + 8 * pass + 7);
-        timeit("hist", [&] { hipLaunchKernelGGL((k_radix_hist<u8, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, 0, lo, hi, n, d, ntiles, counts); });
+        const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, n};
+        timeit("hist", [&] { hipLaunchKernelGGL((k_radix_hist<u8, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, 0, lo, hi, tv, d, counts); });
                 const u32 nch = (ntiles + COLSCAN_ROWS - 1) / COLSCAN_ROWS;
-        timeit("colscan", [&] {
-            hipLaunchKernelGGL(k_colscan_reduce, dim3(nch), dim3(256), 0, 0, counts, ntiles, (u32*)sums);
-            hipLaunchKernelGGL(k_colscan_spine, dim3(1), dim3(256), 0, 0, (u32*)sums, nch, (u32*)sums + (size_t)nch * 256);
-            hipLaunchKernelGGL(k_colscan_apply, dim3(nch), dim3(256), 0, 0, counts, ntiles, (const u32*)sums, (const u32*)sums + (size_t)nch * 256, offsets); });
-        timeit("scatter (2-kernel form)", [&] { hipLaunchKernelGGL((k_radix_scatter<u8, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, 0, lo, hi, n, d, ntiles, offsets, lo2, hi2); });
-        if (SB + 8 * pass + 8 <= 64) timeit("scatter NoHi (8 B records)", [&] { hipLaunchKernelGGL((k_radix_scatter<NoHi, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, 0, lo, (const NoHi*)nullptr, n, d, ntiles, offsets, lo3, (NoHi*)nullptr); });
+        u32* chunk = (u32*)sums; u32* coltot = chunk + (size_t)nch * 256; u32* adj = coltot + 256;
+        timeit("colscan + adjust", [&] {
+            hipLaunchKernelGGL(k_colscan_reduce, dim3(nch), dim3(256), 0, 0, counts, (const u32*)nullptr, ntiles, chunk);
+            hipLaunchKernelGGL(k_colscan_spine, dim3(1), dim3(256), 0, 0, chunk, nch, coltot);
+            hipLaunchKernelGGL(k_colscan_apply, dim3(nch), dim3(256), 0, 0, counts, (const u32*)nullptr, ntiles, chunk, offsets);
+            hipLaunchKernelGGL(k_seg_adjust, dim3(1), dim3(256), 0, 0, offsets, coltot, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr, ntiles, 1u, adj); });
+        timeit("scatter (2-kernel form)", [&] { hipLaunchKernelGGL((k_radix_scatter<u8, u8, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, 0, lo, hi, tv, d, offsets, adj, lo2, hi2); });
+        timeit("scatter u8 in, no hi out", [&] { hipLaunchKernelGGL((k_radix_scatter<u8, NoHi, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, 0, lo, hi, tv, d, offsets, adj, lo3, (NoHi*)nullptr); });
+        if (SB + 8 * pass + 8 <= 64) timeit("scatter NoHi (8 B records)", [&] { hipLaunchKernelGGL((k_radix_scatter<NoHi, NoHi, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, 0, lo, (const NoHi*)nullptr, tv, d, offsets, adj, lo3, (NoHi*)nullptr); });
         CK(hipMemset(ghist, 0, MAX_PASSES * 256 * 8)); CK(hipMemset(ctl, 0, (MAX_PASSES * 128 + 16) * 4)); CK(hipMemset(status, 0, (size_t)ntiles * 256 * 8));
         timeit("digit_hist (all passes)", [&] { hipLaunchKernelGGL(k_digit_hist<u8>, dim3(2048), dim3(512), 0, 0, lo, hi, n, SB, PB, 3u, ghist); });
         for (u32 dbg : {0u, 1u, 2u, 4u}) {
