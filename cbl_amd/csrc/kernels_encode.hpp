@@ -258,11 +258,12 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
     if (P.canonical) {
         // strand flags of every k-mer of the tile: bit = 1 -> forward strand (even popcount)
         const u32 qpad = (Q + ENC_THREADS - 1) / ENC_THREADS * ENC_THREADS;
+        u32 cf = tid < Q ? find_chunk(tid) : 0u;
         for (u32 q = tid; q < qpad; q += ENC_THREADS) {
             bool fwd = false;
             if (q < Q) {
-                u32 ci = find_chunk(q);
-                if (!s_dirty[ci]) fwd = kmer_is_fwd<WIDE>(extract_kmer<WIDE>(s_codes, s_cstart[ci] + (q - s_koff[ci]), P.K));
+                while (q >= s_koff[cf + 1]) ++cf;
+                if (!s_dirty[cf]) fwd = kmer_is_fwd<WIDE>(extract_kmer<WIDE>(s_codes, s_cstart[cf] + (q - s_koff[cf]), P.K));
             }
             u64 bal = __ballot(fwd);
             if ((tid & 63) == 0) s_par[q >> 6] = bal;
@@ -281,8 +282,9 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
         return s_parpre[q >> 6] + (u32)__builtin_popcountll(s_par[q >> 6] & ((1ull << (q & 63)) - 1ull));
     };
 
+    u32 ci = tid < Q ? find_chunk(tid) : 0u;
     for (u32 q = tid; q < Q; q += ENC_THREADS) {
-        const u32 ci = find_chunk(q);
+        while (q >= s_koff[ci + 1]) ++ci;  // q only grows: walk forward from the previous chunk instead of searching again
         if (s_dirty[ci]) continue;
         const u32 j = q - s_koff[ci];
         T x = extract_kmer<WIDE>(s_codes, s_cstart[ci] + j, P.K);

@@ -41,9 +41,16 @@ template <typename T> __host__ __device__ inline void necklace_pos_fast(T x, uns
         pos = 0;
         return;
     }
-    T r = ~x & MASK;
+    // rotl by s on the BITS-bit ring (0 < s < BITS)
+    auto rotl_ring = [&](T v, unsigned s) -> T { return ((v << s) & MASK) | (v >> (BITS - s)); };
+    T r = ~x & MASK;  // bit s: x has a zero at s                       (runs >= 1)
+    {   // two doubling steps first: most words hold a run of >= 4 zeros, which skips three of the linear steps
+        const T r2 = r & rotl_ring(r, 1);    // bit s: zeros at s, s-1          (runs >= 2)
+        const T r4 = r2 & rotl_ring(r2, 2);  // bit s: zeros at s .. s-3        (runs >= 4)
+        r = r4 ? r4 : (r2 ? r2 : r);
+    }
     for (;;) {
-        T t = r & (((r << 1) & MASK) | (r >> (BITS - 1)));
+        T t = r & rotl_ring(r, 1);
         if (t == 0) break;
         r = t;
     }
