@@ -55,6 +55,8 @@ SIGNATURES = {
                                         C.POINTER(C.c_uint64)]),
     "cblx_partition_words_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
                                               C.c_void_p, C.c_void_p]),
+    "cblx_seq_words_partitioned_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                    C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_num_buckets": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_is_empty": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
@@ -185,6 +187,17 @@ class CBL:
         self._chk(self._L.cblx_partition_words_device(self._h, _ptr(d_lo), _ptr(d_hi), n, b.ctypes.data if len(b) else None, nd,
                                                       _ptr(d_out_lo), _ptr(d_out_hi), counts.ctypes.data))
         return [int(x) for x in counts]
+
+    def seq_words_partitioned_device(self, d_bases, d_offsets, n: int, bounds, nd: int, d_out_lo, d_out_hi, cap: int):
+        """get_seq_words of the sequences, grouped by destination prefix range; returns (n_words, run lengths)."""
+        import numpy as np
+
+        b = np.ascontiguousarray(bounds, dtype=np.uint32)
+        counts = np.zeros(nd, dtype=np.uint64)
+        nw = C.c_uint64(0)
+        self._chk(self._L.cblx_seq_words_partitioned_device(self._h, _ptr(d_bases), _ptr(d_offsets), n, b.ctypes.data if len(b) else None, nd,
+                                                            _ptr(d_out_lo), _ptr(d_out_hi), cap, counts.ctypes.data, C.byref(nw)))
+        return nw.value, [int(x) for x in counts]
 
     def flush(self):
         self._chk(self._L.cblx_flush(self._h))

@@ -470,7 +470,7 @@ void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq
     CBLX_HIP(hipStreamSynchronize(c->stream));  // temporaries (nch, err, chunk_base, chunk_nk, ndirty) die here
 }
 template <typename C> void encode(cblx_ctx* c, const u8* d_bases, const ChunkPlan& pl, u64* out_lo, typename C::HiT* out_hi, u64 out_base,
-                                  EncHist eh = EncHist{nullptr, 0, 0}) {
+                                  EncHist eh = EncHist{}) {
     typedef typename C::HiT HiT;
     StageTimer t(c, ST_ENCODE);
     const u64 ntiles = ceil_div(pl.total_bases, ENC_TILE_BYTES);
@@ -498,14 +498,16 @@ void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nse
         Records rec;
         const u64 base = begin_records<C>(c, rec, pl.n_kmers);
         Buf<u32> countsA;
-        EncHist eh{nullptr, 0, 0};
+        EncHist eh{};
         if (base == 0) {  // empty index: KRN-1 also accumulates the first partition pass's tile histogram
             static_assert(ENC_HIST_WINDOW == RDX_TILE, "fused histogram windows must be the partition tiles");
             const size_t ntmax = (size_t)ceil_div(pl.n_kmers, RDX_TILE) + 256;
             countsA = Buf<u32>(c->pool, 256 * ntmax);
             CBLX_HIP(hipMemsetAsync(countsA.get(), 0, 256 * ntmax * 4, c->stream));
             const u32 nA = std::min(8u, c->P.PB);
-            eh = EncHist{countsA.get(), c->P.SB + (c->P.PB - nA), nA};
+            eh.counts = countsA.get();
+            eh.shift = c->P.SB + (c->P.PB - nA);
+            eh.nbits = nA;
         }
         encode<C>(c, d_bases, pl, rec.lo.get(), (typename C::HiT*)rec.hi.get(), base, eh);
         pipeline<C>(c, rec, base + pl.n_kmers, std::move(countsA));
@@ -992,6 +994,59 @@ int cblx_seq_words_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t* d
             if (pl.n_kmers == 0) return;
             encode<C>(c, d_bases, pl, d_lo, (HiT*)d_hi, 0);
             CBLX_HIP(hipStreamSynchronize(c->stream));
+        });
+        collect_events(c);
+    });
+}
+
+// KRN-1 + the exchange partition in one call: words of the sequences, already grouped by destination prefix range
+// (stable). The destination histogram is accumulated by KRN-1 itself, so the words are read once (scatter) instead of
+// twice (histogram + scatter), and the unpartitioned words never leave the library's workspace.
+int cblx_seq_words_partitioned_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n, const uint32_t* bounds,
+                                      uint32_t nd, uint64_t* d_out_lo, void* d_out_hi, uint64_t cap, uint64_t* counts, uint64_t* n_words) {
+    return guard(c, [&] {
+        if (n_words) *n_words = 0;
+        if (nd < 1 || nd > MAX_DEST) throw Error(CBLX_EINVAL, "number of destinations must be in [1, 16]");
+        if (!counts || (nd > 1 && !bounds)) throw Error(CBLX_EINVAL, "null argument");
+        for (u32 d = 0; d < nd; ++d) counts[d] = 0;
+        if (n == 0) return;
+        if (!d_bases || !d_offsets || !d_out_lo || (c->P.has_hi() && !d_out_hi)) throw Error(CBLX_EINVAL, "null argument");
+        check_aligned16(d_bases, "d_bases");
+        for (u32 i = 1; i + 1 < nd; ++i) if (bounds[i] < bounds[i - 1]) throw Error(CBLX_EINVAL, "bounds must be ascending");
+        dispatch(c->P, [&](auto cfg) {
+            typedef decltype(cfg) C;
+            typedef typename C::HiT H;
+            ChunkPlan pl;
+            plan_chunks(c, d_bases, d_offsets, n, pl);
+            const u64 nw = pl.n_kmers;
+            if (n_words) *n_words = nw;
+            if (nw > cap) throw Error(CBLX_ERANGE, "output capacity too small");
+            if (nw == 0) return;
+            if (nw >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "too many words in one partition call");
+            const size_t hs = hi_elem_size(c->P);
+            Buf<u64> t_lo(c->pool, nw + 2);
+            Buf<u8> t_hi(c->pool, hs ? (nw + 2) * hs : 8);
+            const u32 ntiles = (u32)ceil_div(nw, RDX_TILE);
+            Buf<u32> cnt(c->pool, (size_t)256 * (ntiles + 2)), colpre(c->pool, (size_t)256 * ntiles), scratch, coltot(c->pool, 256), adj(c->pool, 256);
+            CBLX_HIP(hipMemsetAsync(cnt.get(), 0, (size_t)256 * (ntiles + 2) * 4, c->stream));
+            DigitDest fn;
+            fn.SB = c->P.SB; fn.PB = c->P.PB; fn.nd = nd;
+            EncHist eh{};
+            eh.counts = cnt.get();
+            eh.nd = nd; eh.SB = c->P.SB; eh.PB = c->P.PB;
+            for (u32 i = 0; i < MAX_DEST - 1; ++i) { fn.bounds[i] = i + 1 < nd ? bounds[i] : 0xFFFFFFFFu; eh.bounds[i] = fn.bounds[i]; }
+            encode<C>(c, d_bases, pl, t_lo.get(), (H*)t_hi.get(), 0, eh);
+            const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, nw};
+            { StageTimer t(c, ST_SCAN);
+              colscan(c, cnt.get(), nullptr, ntiles, colpre.get(), coltot.get(), scratch);
+              hipLaunchKernelGGL(k_seg_adjust, dim3(1), dim3(256), 0, c->stream, colpre.get(), coltot.get(), (const u32*)nullptr, (const u32*)nullptr,
+                                 (const u32*)nullptr, ntiles, 1u, adj.get()); }
+            { StageTimer t(c, ST_SCATTER);
+              hipLaunchKernelGGL((k_radix_scatter<H, H, DigitDest>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, t_lo.get(), (const H*)t_hi.get(), tv, fn,
+                                 colpre.get(), adj.get(), d_out_lo, (H*)d_out_hi); }
+            CBLX_HIP(hipGetLastError());
+            std::vector<u32> tot = d2h_vec<u32>(c, coltot.get(), 256);
+            for (u32 d = 0; d < nd; ++d) counts[d] = tot[d];
         });
         collect_events(c);
     });

@@ -40,7 +40,15 @@ static const u32 ENC_HIST_WINDOW = 4096;
 static const u32 ENC_HIST_WINDOWS = ENC_MAX_KMERS / ENC_HIST_WINDOW + 2;
 struct EncHist {
     u32* counts;  // null: no fused histogram
-    u32 shift, nbits;
+    u32 shift, nbits;             // digit = bit field of the word ...
+    u32 nd, SB, PB, bounds[15];   // ... or, when nd != 0, the destination rank of its prefix: #{i < nd-1 : bounds[i] <= prefix}
+    __device__ __forceinline__ u32 digit(u64 lo, u64 hi) const {
+        if (nd == 0) return get_bits(lo, hi, shift, nbits);
+        const u32 p = get_bits(lo, hi, SB, PB);
+        u32 d = 0;
+        for (u32 i = 0; i + 1 < nd; ++i) d += bounds[i] <= p ? 1u : 0u;  // nd is uniform: nd - 1 scalar-bound compares
+        return d;
+    }
 };
 
 // ---- per-sequence chunk counts; flags sequences shorter than K (src/cbl.rs:329-334) ------------------
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
         kmer_word<WIDE>(x, P, rc, lo, hi);
         out_lo[dst] = lo;
         st_hi<HiT>(out_hi, dst, hi);
-        if (eh.counts) atomicAdd(&s_hist[(u32)(dst / ENC_HIST_WINDOW - win0) * 256 + get_bits(lo, hi, eh.shift, eh.nbits)], 1u);
+        if (eh.counts) atomicAdd(&s_hist[(u32)(dst / ENC_HIST_WINDOW - win0) * 256 + eh.digit(lo, hi)], 1u);
     }
     if (eh.counts) {  // the first-pass digit is the skewed one: only a few dozen bins per window are non-zero
         __syncthreads();
@@ -349,7 +357,7 @@ __global__ void k_encode_dirty(const u8* __restrict__ bases, const u64* __restri
         kmer_word<WIDE>(x & MASK, P, rc, lo, hi);
         out_lo[dst] = lo;
         st_hi<HiT>(out_hi, dst, hi);
-        if (eh.counts) atomicAdd(&eh.counts[(dst / ENC_HIST_WINDOW) * 256 + get_bits(lo, hi, eh.shift, eh.nbits)], 1u);
+        if (eh.counts) atomicAdd(&eh.counts[(dst / ENC_HIST_WINDOW) * 256 + eh.digit(lo, hi)], 1u);
     };
     for (u32 i = 0; i < P.K; ++i) if (nuc_valid(s[i])) x = (x << 2) | (T)nuc_code(s[i]);
     emit();

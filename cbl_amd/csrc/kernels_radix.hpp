@@ -165,8 +165,7 @@ struct DigitDest {
     __device__ __forceinline__ u32 operator()(u64 lo, u64 hi) const {
         const u32 p = get_bits(lo, hi, SB, PB);
         u32 d = 0;
-#pragma unroll
-        for (u32 i = 0; i < MAX_DEST - 1; ++i) d += (i + 1 < nd && bounds[i] <= p) ? 1u : 0u;
+        for (u32 i = 0; i + 1 < nd; ++i) d += bounds[i] <= p ? 1u : 0u;  // nd is uniform: nd - 1 scalar-bound compares
         return d;
     }
 };

@@ -88,6 +88,15 @@ class GpuEngine:
         counts = self.cbl.partition_words_device(lo, hi, n, bounds, nd, out_lo, out_hi)
         return out_lo[:n], (out_hi[:n] if out_hi is not None else None), counts
 
+    def seq_words_partitioned(self, d_bases, d_offsets, n, bounds, nd):
+        """KRN-1 and the destination partition in one library call (words are read once on the way out)."""
+        torch = self.torch
+        cap = int(d_offsets[n] - d_offsets[0])
+        lo = torch.empty(cap + 1, dtype=torch.int64, device=d_bases.device)
+        hi = torch.empty(cap + 1, dtype=self.hi_dtype, device=d_bases.device) if self.hi_dtype is not None else None
+        nw, counts = self.cbl.seq_words_partitioned_device(d_bases, d_offsets, n, bounds, nd, lo, hi, cap)
+        return lo[:nw], (hi[:nw] if hi is not None else None), counts
+
     def insert_words(self, lo, hi):
         self.cbl.insert_words_device(lo, hi, int(lo.numel()))
 
@@ -132,15 +141,19 @@ class ShardedBuilder:
         for a, b in self.slice_bounds(n, self.slices):
             if b <= a:
                 continue
-            lo, hi = eng.seq_words(d_bases, d_offsets[a : b + 1], b - a)  # offsets stay absolute: no copy of the bases
-            if self.bounds is None:
-                hist = eng.sample_hist(lo, hi)
-                dist.all_reduce(hist)
-                hb = min(HIST_BITS, self.cbl.prefix_bits)
-                self.bounds = choose_bounds(hist.cpu().numpy(), W, self.cbl.prefix_bits, hb)
-            plo, phi, counts = eng.partition(lo, hi, self.bounds, W)
-            n_words = int(lo.numel())
-            del lo, hi
+            off = d_offsets[a : b + 1]  # offsets stay absolute: no copy of the bases
+            if self.bounds is None or not hasattr(eng, "seq_words_partitioned"):
+                lo, hi = eng.seq_words(d_bases, off, b - a)
+                if self.bounds is None:
+                    hist = eng.sample_hist(lo, hi)
+                    dist.all_reduce(hist)
+                    hb = min(HIST_BITS, self.cbl.prefix_bits)
+                    self.bounds = choose_bounds(hist.cpu().numpy(), W, self.cbl.prefix_bits, hb)
+                plo, phi, counts = eng.partition(lo, hi, self.bounds, W)
+                del lo, hi
+            else:
+                plo, phi, counts = eng.seq_words_partitioned(d_bases, off, b - a, self.bounds, W)
+            n_words = int(plo.numel())
             send = torch.tensor(counts, dtype=torch.int64, device=plo.device)
             recv = torch.empty_like(send)
             dist.all_to_all_single(recv, send)

@@ -93,6 +93,12 @@ int cblx_seq_words_device(cblx_ctx* ctx, const uint8_t* d_bases, const uint64_t*
 int cblx_partition_words_device(cblx_ctx* ctx, const uint64_t* d_lo, const void* d_hi, uint64_t n, const uint32_t* bounds,
                                 uint32_t nd, uint64_t* d_out_lo, void* d_out_hi, uint64_t* counts);
 
+/* cblx_seq_words_device + cblx_partition_words_device in one call (the per-slice step of the multi-GPU build): the
+ * words of the sequences, grouped by destination, written to d_out_lo/d_out_hi (capacity `cap` words). */
+int cblx_seq_words_partitioned_device(cblx_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n,
+                                      const uint32_t* bounds, uint32_t nd, uint64_t* d_out_lo, void* d_out_hi, uint64_t cap,
+                                      uint64_t* counts, uint64_t* n_words);
+
 /* CBL::count / is_empty / is_canonical (src/cbl.rs:164-177). */
 int cblx_count(cblx_ctx* ctx, uint64_t* out);
 int cblx_num_buckets(cblx_ctx* ctx, uint64_t* out); /* tiered.len() = number of non-empty prefixes */

@@ -462,3 +462,30 @@ def test_offset_slices_address_the_same_buffer():
             for s in seqs_k[a:b]:
                 o.insert_seq(s)
         _check_index(g, o)
+
+
+def test_seq_words_partitioned_matches_two_step():
+    """The fused KRN-1 + destination partition equals seq_words followed by partition_words."""
+    _need_gpu()
+    rng = random.Random(23)
+    seqs = [_rand_seq(rng, rng.choice((150, 151, 400, 3000))) for _ in range(120)]
+    bases, offsets = _concat(seqs)
+    pad = (-len(bases)) % 16 + 16
+    d_b = torch.from_numpy(np.concatenate([bases, np.zeros(pad, np.uint8)])).cuda()
+    d_o = torch.from_numpy(offsets.astype(np.int64)).cuda()
+    for k, pb, canonical in ((31, 24, False), (31, 24, True), (25, 24, False), (59, 28, False)):
+        g = cbl_amd.CBL(k, pb, canonical=canonical)
+        words = _gpu_words(g, seqs)
+        sb = g.consts()["suffix_bits"]
+        prefixes = sorted(w >> sb for w in words)
+        for nd in (1, 3, 8):
+            bounds = sorted(prefixes[rng.randrange(len(prefixes))] for _ in range(nd - 1))
+            cap = len(bases)
+            olo = torch.zeros(cap + 1, dtype=torch.int64, device="cuda")
+            ohi = _hi_tensor(g, cap + 1)
+            nw, counts = g.seq_words_partitioned_device(d_b, d_o, len(seqs), bounds, nd, olo, ohi, cap)
+            assert nw == len(words)
+            dest = [sum(1 for b in bounds if b <= (w >> sb)) for w in words]
+            want = [w for d in range(nd) for w, dd in zip(words, dest) if dd == d]
+            assert counts == [dest.count(d) for d in range(nd)]
+            assert _words_from(olo[:nw], None if ohi is None else ohi[:nw]) == want
