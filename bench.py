@@ -25,21 +25,23 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-# ALGORITHMIC bytes per k-mer of each kernel group: what the kernel's contract must move once.
-#   R = record bytes (8 lo + hi part), BYTES-independent; passes = ceil(PREFIX_BITS / 8).
+# ALGORITHMIC bytes per k-mer and step of each kernel group: what the group's contract must move once.
+#   R_in = record bytes out of KRN-1 (8 lo + hi part); after the first partition pass a 65..72-bit word keeps only lo.
 def stage_alg_bytes(k: int, pb: int, read_len: int):
     kb = 2 * k
     wb = kb + (kb - 1).bit_length()
     hi = 0 if wb <= 64 else (1 if kb <= 64 else 8)
-    R = 8 + hi
-    passes = (pb + 7) // 8
+    r_in = 8 + hi
+    r_out = 8 if hi == 1 else r_in
+    n_a = min(8, pb)
+    lsd = (pb - n_a + 7) // 8
     sfx = 8 if wb - pb <= 64 else 16
     return {
         "chunks": read_len / (read_len - k + 1),             # validity scan reads every base once
-        "encode": read_len / (read_len - k + 1) + R,           # read bases, write one record
-        "radix_hist": passes * R,                              # read every record once per pass (passes launches)
-        "radix_scatter": passes * 2 * R,                       # read + write every record once per pass (passes launches)
-        "directory": R,                                        # boundary detection reads the sorted records
+        "encode": read_len / (read_len - k + 1) + r_in,        # read bases, write one record (+ fused first-pass histogram)
+        "radix_hist": lsd * r_out,                             # LSD passes read every record once (pass A's is fused in KRN-1)
+        "radix_scatter": (r_in + r_out) + lsd * 2 * r_out,     # every pass reads + writes every record once
+        "directory": r_out,                                    # boundary detection reads the sorted records
         "bucket_medium": 2 * sfx,                              # read the run, write the distinct suffixes
         "bucket_small": 2 * sfx,
         "bucket_huge": 2 * sfx,
