@@ -205,8 +205,13 @@ struct Records {
     const void* ext_hi = nullptr;
 };
 
+// `self |= other` through the same pipeline: records = self's words then other's; the bucket stage applies the |= rules
+struct MergeCtx {
+    const Resident* other;  // on the same device
+};
+
 // `countsA`: histogram of the first pass already accumulated by KRN-1 (empty Buf = compute it here)
-template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA = Buf<u32>()) {
+template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA = Buf<u32>(), const MergeCtx* mg = nullptr) {
     typedef typename C::HiT HiT;
     const Consts& P = c->P;
     Resident nr;
@@ -309,6 +314,48 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
         hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, nr.start.get() + nr.nb, N);
         CBLX_HIP(hipGetLastError());
     }
+    if (mg) {
+        // -- `self |= other`: classify by (self part, other part), merge the both-sides buckets
+        const u64 nb = nr.nb;
+        Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
+        Buf<u32> list_n(c->pool, CLS_N + 1), m_cs(c->pool, nb + 1);
+        Buf<u64> m_ostart(c->pool, nb + 1);
+        Buf<u8> m_okind(c->pool, nb + 1);
+        CBLX_HIP(hipMemsetAsync(list_n.get(), 0, (CLS_N + 1) * 4, c->stream));
+        hipLaunchKernelGGL(k_classify_merge, grid1(nb, 256), dim3(256), 0, c->stream, nb, C::WS ? 512u : 1024u, nr.prefix.get(), nr.start.get(), c->res.view(),
+                           mg->other->view(), m_cs.get(), m_ostart.get(), m_okind.get(), nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get(), list_n.get() + CLS_N);
+        std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N + 1);
+        if (ln[CLS_N]) throw Error(CBLX_EDEVICE, "merge: run lengths do not match the two indexes (internal error)");
+        const MergeArgs ma{m_cs.get(), m_ostart.get(), m_okind.get(), mg->other->a_lo.get(), mg->other->a_hi.get()};
+        u64* a_lo = rec.lo.get();
+        HiT* a_hi = (HiT*)rec.hi.get();
+        StageTimer t(c, ST_BMED);
+        if (ln[CLS_M256])
+            hipLaunchKernelGGL((k_bucket_medium<256, C::WS, HiT>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb,
+                               list_n.get() + CLS_M256, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
+        if (ln[CLS_M512])
+            hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb,
+                               list_n.get() + CLS_M512, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
+        if constexpr (!C::WS) if (ln[CLS_M1024])
+            hipLaunchKernelGGL((k_bucket_medium<1024, C::WS, HiT>), dim3(ln[CLS_M1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)CLS_M1024 * nb,
+                               list_n.get() + CLS_M1024, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
+        if (ln[CLS_HUGE]) {
+            const u32 nh = ln[CLS_HUGE];
+            std::vector<BDesc> hl = d2h_vec<BDesc>(c, lists.get() + (size_t)CLS_HUGE * nb, nh);
+            std::vector<u64> so(nh);
+            u64 tot = 0;
+            for (u32 i = 0; i < nh; ++i) { so[i] = tot; tot += hl[i].c & ~BDESC_TRIE; }
+            Buf<u64> d_so(c->pool, nh), s_alo(c->pool, tot), s_blo(c->pool, tot), s_ahi(c->pool, C::WS ? tot : 1), s_bhi(c->pool, C::WS ? tot : 1);
+            Buf<u32> s_aidx(c->pool, tot), s_bidx(c->pool, tot);
+            h2d(c, d_so.get(), so.data(), nh);
+            hipLaunchKernelGGL((k_bucket_huge<C::WS, HiT>), dim3(nh), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE,
+                               d_so.get(), a_lo, a_hi, P.SB, s_alo.get(), s_ahi.get(), s_aidx.get(), s_blo.get(), s_bhi.get(), s_bidx.get(), nr.cnt.get(),
+                               nr.kind.get(), ma);
+            CBLX_HIP(hipStreamSynchronize(c->stream));
+        }
+        CBLX_HIP(hipGetLastError());
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+    } else {
     // -- KRN-3: per-bucket dedup / sort, by size class
     const u64 nb = nr.nb;
     Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
@@ -354,10 +401,10 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
         }
         const u32 nretry = (ln[CLS_M64] || ln[CLS_M128] || ln[CLS_M256] || ln[CLS_M512]) ? d2h<u32>(c, retry_n.get()) : 0u;
         if (nretry)
-            hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(nretry), dim3(512), 0, c->stream, retry.get(), retry_n.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+            hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(nretry), dim3(512), 0, c->stream, retry.get(), retry_n.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
         if constexpr (!C::WS) if (ln[CLS_M1024])  // 128-bit suffixes: 8192 keys + indices exceed the 160 KiB LDS, such runs go to the huge path
             hipLaunchKernelGGL((k_bucket_medium<1024, C::WS, HiT>), dim3(ln[CLS_M1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)CLS_M1024 * nb,
-                               list_n.get() + CLS_M1024, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+                               list_n.get() + CLS_M1024, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
         CBLX_HIP(hipStreamSynchronize(c->stream));  // retry buffers die here
     }
     if (ln[CLS_HUGE]) {
@@ -372,14 +419,15 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
         h2d(c, d_so.get(), so.data(), nh);
         hipLaunchKernelGGL((k_bucket_huge<C::WS, HiT>), dim3(nh), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE,
                            d_so.get(), a_lo, a_hi, P.SB, s_alo.get(), s_ahi.get(), s_aidx.get(), s_blo.get(), s_bhi.get(),
-                           s_bidx.get(), nr.cnt.get(), nr.kind.get());
+                           s_bidx.get(), nr.cnt.get(), nr.kind.get(), MergeArgs{});
         CBLX_HIP(hipStreamSynchronize(c->stream));
+    }
     }
     CBLX_HIP(hipGetLastError());
     {
         Buf<u64> total(c->pool, 1);
         CBLX_HIP(hipMemsetAsync(total.get(), 0, 8, c->stream));
-        hipLaunchKernelGGL(k_sum_u32, grid1(nb, 256), dim3(256), 0, c->stream, nr.cnt.get(), nb, total.get());
+        hipLaunchKernelGGL(k_sum_u32, grid1(nr.nb, 256), dim3(256), 0, c->stream, nr.cnt.get(), nr.nb, total.get());
         nr.count = d2h<u64>(c, total.get());
     }
     nr.a_lo = std::move(rec.lo);
@@ -393,9 +441,23 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
     c->res = std::move(nr);
 }
 
+// words of a resident index (bucket order, stored order inside a bucket) written to rec[at ..)
+template <typename C> void expand_into(cblx_ctx* c, const Resident& r, Records& rec, u64 at) {
+    typedef typename C::HiT HiT;
+    if (r.count == 0) return;
+    StageTimer t(c, ST_EXPAND);
+    const size_t hs = hi_elem_size(c->P);
+    Buf<u64> res_off(c->pool, r.nb + 1);
+    u64 tot = exclusive_scan<u64>(c, r.cnt.get(), r.nb, res_off.get());
+    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, res_off.get() + r.nb, tot);
+    hipLaunchKernelGGL((k_expand_resident<C::WS, HiT>), grid1(r.count, 256), dim3(256), 0, c->stream, r.count, r.nb, res_off.get(), r.prefix.get(), r.start.get(),
+                       r.a_lo.get(), r.a_hi.get(), c->P.SB, rec.lo.get() + at, hs ? (HiT*)(rec.hi.get() + at * hs) : (HiT*)nullptr);
+    CBLX_HIP(hipGetLastError());
+    CBLX_HIP(hipStreamSynchronize(c->stream));  // res_off is released at scope exit
+}
+
 // allocate the record buffers for N words; resident words (if any) are expanded into the front
 template <typename C> u64 begin_records(cblx_ctx* c, Records& rec, u64 n_new) {
-    typedef typename C::HiT HiT;
     const u64 n_res = c->res.count;
     const u64 N = n_res + n_new;
     const size_t hs = hi_elem_size(c->P);
@@ -403,16 +465,7 @@ template <typename C> u64 begin_records(cblx_ctx* c, Records& rec, u64 n_new) {
     rec.lo2 = Buf<u64>(c->pool, N + 2);
     rec.hi = Buf<u8>(c->pool, hs ? (N + 2) * hs : 8);
     rec.hi2 = Buf<u8>(c->pool, hs ? (N + 2) * hs : 8);
-    if (n_res) {
-        StageTimer t(c, ST_EXPAND);
-        Buf<u64> res_off(c->pool, c->res.nb + 1);
-        u64 tot = exclusive_scan<u64>(c, c->res.cnt.get(), c->res.nb, res_off.get());
-        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, res_off.get() + c->res.nb, tot);
-        hipLaunchKernelGGL((k_expand_resident<C::WS, HiT>), grid1(n_res, 256), dim3(256), 0, c->stream, n_res, c->res.nb, res_off.get(),
-                           c->res.prefix.get(), c->res.start.get(), c->res.a_lo.get(), c->res.a_hi.get(), c->P.SB, rec.lo.get(), (HiT*)rec.hi.get());
-        CBLX_HIP(hipGetLastError());
-        CBLX_HIP(hipStreamSynchronize(c->stream));  // res_off is released at scope exit
-    }
+    expand_into<C>(c, c->res, rec, 0);
     return n_res;
 }
 
@@ -768,7 +821,9 @@ void parse_index(const Consts& P, const u8* data, u64 len, HostIndex& h, bool& c
 }
 
 // `self |= other` on host copies (v1): src/wordset/set_ops.rs:123-157 + src/trievec/set_ops.rs:43-71
-void merge_host(const Consts& P, const HostIndex& a, const HostIndex& b, HostIndex& o) {
+// returns true when `b` changed: the reference's |= walks other's bucket with iter_sorted, which sorts a Vec in place
+bool merge_host(const Consts& P, const HostIndex& a, HostIndex& b, HostIndex& o) {
+    bool b_changed = false;
     const bool wide = P.wide_suffix();
     auto get = [&](const HostIndex& h, u64 i) -> u128 { return wide ? (((u128)h.hi[i] << 64) | h.lo[i]) : (u128)h.lo[i]; };
     auto put = [&](u128 x) { o.lo.push_back((u64)x); if (wide) o.hi.push_back((u64)(x >> 64)); };
@@ -790,7 +845,11 @@ void merge_host(const Consts& P, const HostIndex& a, const HostIndex& b, HostInd
             for (u64 t = a.off[i]; t < a.off[i + 1]; ++t) sa.push_back(get(a, t));
             for (u64 t = b.off[j]; t < b.off[j + 1]; ++t) sb.push_back(get(b, t));
             std::sort(sa.begin(), sa.end());
-            std::sort(sb.begin(), sb.end());
+            if (!std::is_sorted(sb.begin(), sb.end())) {
+                std::sort(sb.begin(), sb.end());
+                for (u64 t = b.off[j], q = 0; t < b.off[j + 1]; ++t, ++q) { b.lo[t] = (u64)sb[q]; if (wide) b.hi[t] = (u64)(sb[q] >> 64); }
+                b_changed = true;
+            }
             std::vector<u128> ins;
             std::set_difference(sb.begin(), sb.end(), sa.begin(), sa.end(), std::back_inserter(ins));
             u64 n = 0;
@@ -807,6 +866,7 @@ void merge_host(const Consts& P, const HostIndex& a, const HostIndex& b, HostInd
         }
         o.off.push_back(o.lo.size());
     }
+    return b_changed;
 }
 
 template <typename F> int guard(cblx_ctx* c, F&& f) {
@@ -1165,15 +1225,40 @@ int cblx_merge_assign(cblx_ctx* self, cblx_ctx* other) {
         if (!other) throw Error(CBLX_EINVAL, "null argument");
         if (self->P.K != other->P.K || self->P.PB != other->P.PB) throw Error(CBLX_EINVAL, "merge: K / PREFIX_BITS mismatch");
         if (self->P.canonical != other->P.canonical) throw Error(CBLX_EINVAL, "One of the index is canonical while the other isn't");
+        if (self == other) return;  // x |= x
         flush(self);
         CBLX_HIP(hipSetDevice(other->device));
         flush(other);
-        HostIndex a, b, o;
-        download(other, b);
         CBLX_HIP(hipSetDevice(self->device));
-        download(self, a);
-        merge_host(self->P, a, b, o);
-        upload(self, o);
+        if (other->res.count == 0) return;
+        bool on_device = false;
+        if (self->device == other->device && self->res.count != 0 && self->res.count + other->res.count < 0xFFFFFFF0ull) {
+            CBLX_HIP(hipStreamSynchronize(other->stream));
+            dispatch(self->P, [&](auto cfg) {
+                typedef decltype(cfg) C;
+                Records rec;
+                const u64 ns = begin_records<C>(self, rec, other->res.count);  // self's words in front ...
+                expand_into<C>(self, other->res, rec, ns);                      // ... then other's
+                const MergeCtx mg{&other->res};
+                pipeline<C>(self, rec, ns + other->res.count, Buf<u32>(), &mg);
+            });
+            on_device = true;
+            collect_events(self);
+        }
+        if (!on_device) {  // indexes on different devices (or self empty): through the host
+            HostIndex a, b, o;
+            CBLX_HIP(hipSetDevice(other->device));
+            download(other, b);
+            CBLX_HIP(hipSetDevice(self->device));
+            download(self, a);
+            const bool other_changed = merge_host(self->P, a, b, o);
+            upload(self, o);
+            if (other_changed) {
+                CBLX_HIP(hipSetDevice(other->device));
+                upload(other, b);
+                CBLX_HIP(hipSetDevice(self->device));
+            }
+        }
     });
 }
 int cblx_export_buckets(cblx_ctx* c, cblx_bucket_cb cb, void* user) {

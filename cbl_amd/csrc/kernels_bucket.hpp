@@ -170,6 +170,57 @@ __global__ void k_classify(u64 nb, u32 med_max_threads, const u32* __restrict__ 
     }
 }
 
+// ---- `self |= other` on the device: /root/reference/src/wordset/set_ops.rs:123-157 ------------------------
+// The records are self's words (bucket order, stored order inside a bucket) followed by other's; after the stable
+// partition the run of a prefix is [self part][other part]. Per bucket (src/trievec/set_ops.rs:43-71, :118-136):
+//   other part empty -> untouched;  self part empty -> other's bucket cloned as stored (kind and order kept);
+//   both, self is a Vec  -> sorted(self) ++ sorted(other \ self), stays a Vec whatever its size (no threshold check);
+//   both, self is a Trie -> sorted union, Trie.
+// Side effect of the reference kept: other's Vec buckets that also exist in self end up sorted (iter_sorted sorts in place).
+struct MergeArgs {
+    const u32* cs;       // per new rank: size of the self part (null: plain insert)
+    const u64* ostart;   // per new rank: first arena slot of other's bucket
+    const u8* okind;     // per new rank: kind of other's bucket
+    u64* o_lo;           // other's arena (written back sorted)
+    u64* o_hi;
+};
+__global__ void k_classify_merge(u64 nb, u32 med_max_threads, const u32* __restrict__ bucket_prefix, const u64* __restrict__ raw_start,
+                                 DirView self, DirView other, u32* __restrict__ m_cs, u64* __restrict__ m_ostart,
+                                 u8* __restrict__ m_okind, u32* __restrict__ out_count, u8* __restrict__ out_kind,
+                                 BDesc* __restrict__ lists, u32* __restrict__ list_n, u32* __restrict__ bad) {
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nb) return;
+    const u64 c = raw_start[r + 1] - raw_start[r];
+    const u32 p = bucket_prefix[r];
+    u32 cs = 0, co = 0;
+    u8 ks = KIND_VEC, ko = KIND_VEC;
+    u64 rank, os = 0;
+    if (dir_lookup(self, p, rank)) { cs = self.count[rank]; ks = self.kind[rank]; }
+    if (dir_lookup(other, p, rank)) { co = other.count[rank]; ko = other.kind[rank]; os = other.start[rank]; }
+    if ((u64)cs + co != c) atomicAdd(bad, 1u);
+    m_cs[r] = cs;
+    m_ostart[r] = os;
+    m_okind[r] = ko;
+    if (co == 0) { out_count[r] = cs; out_kind[r] = ks; return; }
+    if (cs == 0) { out_count[r] = co; out_kind[r] = ko; return; }
+    int cls;
+    if (c <= 256 * MED_ITEMS) cls = CLS_M256;
+    else if (c <= 512 * MED_ITEMS) cls = CLS_M512;
+    else if (c <= 1024 * MED_ITEMS && med_max_threads >= 1024) cls = CLS_M1024;
+    else cls = CLS_HUGE;
+#pragma unroll
+    for (int k = 0; k < CLS_N; ++k) {
+        const u64 bal = __ballot(cls == k);
+        if (cls == k) {
+            u32 base = 0;
+            const u32 leader = (u32)__builtin_ctzll(bal);
+            if (lane_id() == leader) base = atomicAdd(&list_n[k], (u32)__builtin_popcountll(bal));
+            base = __shfl(base, (int)leader, 64);
+            lists[(u64)k * nb + base + mbcnt(bal)] = BDesc{raw_start[r], (u32)c | (ks == KIND_TRIE ? BDESC_TRIE : 0u), (u32)r};
+        }
+    }
+}
+
 // ---- suffix access --------------------------------------------------------------------------------------
 // narrow suffix (SB <= 64): suffix = lo & mask. wide (SB > 64): (hi & mask(SB-64), lo).
 template <bool WS> struct Sfx;
@@ -241,7 +292,7 @@ __global__ __launch_bounds__(256) void k_bucket_small(const BDesc* __restrict__ 
 template <int THREADS, bool WS, typename HiT>
 __global__ __launch_bounds__(THREADS) void k_bucket_medium(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
                                                            u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
-                                                           u32* __restrict__ out_count, u8* __restrict__ out_kind) {
+                                                           u32* __restrict__ out_count, u8* __restrict__ out_kind, MergeArgs mg) {
     constexpr int ITEMS = MED_ITEMS, NW = THREADS / 64, CAP = THREADS * ITEMS;
     __shared__ u64 s_klo[CAP];
     __shared__ u64 s_khi[WS ? CAP : 1];
@@ -327,6 +378,54 @@ __global__ __launch_bounds__(THREADS) void k_bucket_medium(const BDesc* __restri
     }
     __syncthreads();
     const u32 d = s_wtot[NW];
+    if (mg.cs) {  // `self |= other`: slots hold the run sorted by (suffix, index); index < cs = came from self
+        const u32 cs = mg.cs[r];
+        // ordered compaction of the slots selected by `sel` to dst[base + rank]
+        auto compact = [&](const bool (&sel)[ITEMS], u64* dlo, u64* dhi, u64 base) {
+            u32 wk = 0;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) wk += (u32)__builtin_popcountll(__ballot(sel[j]));
+            __syncthreads();
+            if (lane == 0) s_wtot[w] = wk;
+            __syncthreads();
+            u32 run = 0;
+            for (u32 ww = 0; ww < w; ++ww) run += s_wtot[ww];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const u64 bal = __ballot(sel[j]);
+                if (sel[j]) {
+                    dlo[base + run + mbcnt(bal)] = key[j].lo;
+                    if constexpr (WS) dhi[base + run + mbcnt(bal)] = key[j].hi;
+                }
+                run += (u32)__builtin_popcountll(bal);
+            }
+        };
+        bool sel[ITEMS];
+        if (mg.okind[r] == KIND_VEC) {  // the reference's iter_sorted leaves other's Vec sorted
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) sel[j] = valid[j] && idx[j] >= cs;
+            compact(sel, mg.o_lo, mg.o_hi, mg.ostart[r]);
+        }
+        u64* slo = lo;
+        u64* shi = reinterpret_cast<u64*>(hi);
+        if (res_trie) {  // Trie |= anything: sorted union
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) sel[j] = head[j];
+            compact(sel, slo, shi, s0);
+        } else {         // Vec |= anything: sorted(self) ++ sorted(other \ self); every self element is a head
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) sel[j] = head[j] && idx[j] < cs;
+            compact(sel, slo, shi, s0);
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) sel[j] = head[j] && idx[j] >= cs;
+            compact(sel, slo, shi, s0 + cs);
+        }
+        if (tid == 0) {
+            out_count[r] = d;
+            out_kind[r] = res_trie ? KIND_TRIE : KIND_VEC;
+        }
+        return;
+    }
     const bool trie = d > VEC_THRESHOLD || res_trie;
     if (trie) {
         u32 run = s_wtot[w];
@@ -595,7 +694,7 @@ __global__ __launch_bounds__(256) void k_bucket_huge(const BDesc* __restrict__ l
                                                      HiT* __restrict__ hi, u32 SB, u64* __restrict__ a_lo,
                                                      u64* __restrict__ a_hi, u32* __restrict__ a_idx, u64* __restrict__ b_lo,
                                                      u64* __restrict__ b_hi, u32* __restrict__ b_idx,
-                                                     u32* __restrict__ out_count, u8* __restrict__ out_kind) {
+                                                     u32* __restrict__ out_count, u8* __restrict__ out_kind, MergeArgs mg) {
     constexpr int THREADS = 256, ITEMS = 8, TILE = THREADS * ITEMS;
     __shared__ u32 s_wcnt[(THREADS / 64) * 256];
     __shared__ u32 s_dbase[256];
@@ -696,6 +795,49 @@ __global__ __launch_bounds__(256) void k_bucket_huge(const BDesc* __restrict__ l
     if (lane == 0) atomicAdd(&s_cnt, mine);
     __syncthreads();
     const u32 d = s_cnt;
+    if (mg.cs) {  // `self |= other` (same rules as k_bucket_medium's merge epilogue); the sorted run lives in scratch
+        const u32 cs = mg.cs[r];
+        // mode 0: other's elements -> other's arena; 1: heads; 2: heads from self; 3: heads from other
+        auto emit = [&](int mode, u64 at) {
+            u32 run = 0;
+            for (u32 e0 = 0; e0 < c; e0 += THREADS) {
+                const u32 e = e0 + tid;
+                bool k = false;
+                if (e < c) {
+                    bool h = e == 0 || src_lo[e] != src_lo[e - 1];
+                    if constexpr (WS) h = h || (e > 0 && src_hi[e] != src_hi[e - 1]);
+                    const bool from_other = src_idx[e] >= cs;
+                    k = mode == 0 ? from_other : mode == 1 ? h : mode == 2 ? (h && !from_other) : (h && from_other);
+                }
+                u32 tot;
+                u32 ex = block_exclusive_scan<THREADS, u32>(k ? 1u : 0u, s_scan, &tot);
+                if (k) {
+                    Sfx<WS> s;
+                    s.lo = src_lo[e];
+                    if constexpr (WS) s.hi = src_hi[e];
+                    if (mode == 0) {
+                        mg.o_lo[at + run + ex] = s.lo;
+                        if constexpr (WS) mg.o_hi[at + run + ex] = s.hi;
+                    } else {
+                        store_sfx<WS, HiT>(lo, hi, at + run + ex, s);
+                    }
+                }
+                run += tot;
+            }
+        };
+        if (mg.okind[r] == KIND_VEC) emit(0, mg.ostart[r]);
+        if (res_trie) {
+            emit(1, s0);
+        } else {
+            emit(2, s0);
+            emit(3, s0 + cs);
+        }
+        if (tid == 0) {
+            out_count[r] = d;
+            out_kind[r] = res_trie ? KIND_TRIE : KIND_VEC;
+        }
+        return;
+    }
     const bool trie = d > VEC_THRESHOLD || res_trie;
     // ordered compaction, chunk of THREADS elements at a time
     u32 base = 0;

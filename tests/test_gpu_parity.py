@@ -232,14 +232,20 @@ def test_merge_matches_oracle():
     """`cbl merge` (examples/cbl.rs:270-279): self |= other, incl. the Vec-may-exceed-1024 quirk."""
     _need_gpu()
     rng = random.Random(21)
-    for k, pb, n in ((31, 24, 20000), (9, 4, 9000), (9, 4, 40000), (11, 8, 60000)):
+    for k, pb, n, canonical in ((31, 24, 20000, False), (9, 4, 9000, False), (9, 4, 40000, False), (11, 8, 60000, False), (13, 10, 150000, True),
+                                (15, 12, 400000, False), (35, 6, 3000, False), (35, 10, 100000, False), (59, 28, 30000, True), (31, 24, 2000000, False)):
         s1, s2 = _rand_seq(rng, n), _rand_seq(rng, n // 2) + _rand_seq(rng, 64)
-        g1, g2, o1, o2 = cbl_amd.CBL(k, pb), cbl_amd.CBL(k, pb), Oracle(k, pb), Oracle(k, pb)
+        if n >= 100000:  # shared stretch: both-sides buckets with common words
+            s2 = s2 + s1[n // 3 : n // 3 + n // 4]
+        g1, g2 = cbl_amd.CBL(k, pb, canonical=canonical), cbl_amd.CBL(k, pb, canonical=canonical)
+        o1, o2 = Oracle(k, pb, canonical), Oracle(k, pb, canonical)
         g1.insert_seq(s1), o1.insert_seq(s1)
         g2.insert_seq(s2), o2.insert_seq(s2)
         g1 |= g2
         o1.merge(o2)
         _check_index(g1, o1)
+        _check_index(g2, o2)  # the reference's |= sorts other's Vec buckets that met a bucket of self (iter_sorted)
+        assert g1.validate(strict=False) == 0
         # an oversized Vec left by |= turns into a Trie only when a later insert touches it (src/wordset/mod.rs:213-214)
         s3 = _rand_seq(rng, 3000)
         g1.insert_seq(s3)
