@@ -225,11 +225,17 @@ class CBL:
 
     def contains_seq(self, seq: bytes):
         """For each k-mer of a sequence, True if it is in the set (src/cbl.rs:311-324)."""
+        return self.contains_seq_np(seq).tolist()
+
+    def contains_seq_np(self, seq: bytes):
+        """contains_seq as a numpy bool array (no per-element Python objects)."""
+        import numpy as np
+
         cap = max(len(seq), 1)
-        out = (C.c_uint8 * cap)()
+        out = np.empty(cap, dtype=np.uint8)
         n = C.c_uint64(0)
-        self._chk(self._L.cblx_contains_seq(self._h, seq, len(seq), out, cap, C.byref(n)))
-        return [bool(out[i]) for i in range(n.value)]
+        self._chk(self._L.cblx_contains_seq(self._h, seq, len(seq), out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n)))
+        return out[: n.value].astype(bool)
 
     # ---- src/cbl.rs:127-160 ---------------------------------------------------------------------------------
     def serialize(self) -> bytes:

@@ -15,6 +15,7 @@
 #include <thread>
 
 #include "kernels_bucket.hpp"
+#include "xfer.hpp"
 
 using namespace cblx;
 
@@ -94,6 +95,27 @@ enum { ST_CHUNKS, ST_ENCODE, ST_HIST, ST_SCAN, ST_SCATTER, ST_DIR, ST_BSMALL, ST
 const char* kStageNames[ST_N] = {"chunks", "encode", "radix_hist", "radix_scan", "radix_scatter", "directory",
                                  "bucket_small", "bucket_medium", "bucket_huge", "expand_resident"};
 
+// Sequences enqueued by cblx_insert_seq / cblx_insert_seqs / the FASTA reader. They are staged straight into HBM
+// while the caller keeps enqueueing: small appends fill pinned write blocks that are DMA'd as they fill up, bulk
+// appends go through the Xfer lanes. flush() only has to wait for the last DMA.
+struct Ingest {
+    static constexpr size_t BASES_BLK = 4u << 20, OFF_BLK = 512u << 10;
+    struct Writer {
+        u8* blk[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool busy[2] = {false, false};
+        int cur = 0;
+        size_t cap = 0, fill = 0;
+        u64 issued = 0;  // bytes of the logical stream already handed to the DMA engine
+    };
+    Buf<u8> d_bases;   // capacity >= nbytes + 64
+    Buf<u64> d_off;    // capacity >= nseq + 1; d_off[0] = 0
+    u64 nbytes = 0, nseq = 0;
+    Writer wb, wo;
+    hipStream_t s = nullptr;
+    std::unique_ptr<Xfer> xfer;
+};
+
 }  // namespace
 
 struct cblx_ctx {
@@ -103,8 +125,7 @@ struct cblx_ctx {
     hipStream_t stream = nullptr;
     Pool pool;
     Resident res;
-    std::vector<u8> pend_bases;     // enqueued sequences (host)
-    std::vector<u64> pend_offsets;  // n+1
+    Ingest ing;
     std::string err;
     u64 kmers_inserted = 0;
     Stage stages[ST_N];
@@ -112,7 +133,7 @@ struct cblx_ctx {
     std::vector<Ev> evs;
     std::vector<hipEvent_t> ev_free;
 
-    cblx_ctx() { for (int i = 0; i < ST_N; ++i) stages[i].name = kStageNames[i]; pend_offsets.push_back(0); }
+    cblx_ctx() { for (int i = 0; i < ST_N; ++i) stages[i].name = kStageNames[i]; }
 };
 
 namespace {
@@ -569,24 +590,139 @@ void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nse
     collect_events(c);
 }
 
+// ---- ingest: host sequences -> pending buffers in HBM -----------------------------------------------------------
+Xfer& xfer(cblx_ctx* c) {
+    if (!c->ing.xfer) c->ing.xfer.reset(new Xfer(c->device));
+    return *c->ing.xfer;
+}
+void ingest_wait(cblx_ctx* c) {  // every DMA issued so far has landed
+    Ingest& g = c->ing;
+    if (g.s) CBLX_HIP(hipStreamSynchronize(g.s));
+    if (g.xfer) g.xfer->sync();
+}
+void writer_issue(cblx_ctx* c, Ingest::Writer& w, u8* d_dst) {  // hand the current block to the DMA engine
+    if (w.fill == 0) return;
+    Ingest& g = c->ing;
+    CBLX_HIP(hipMemcpyAsync(d_dst + w.issued, w.blk[w.cur], w.fill, hipMemcpyHostToDevice, g.s));
+    CBLX_HIP(hipEventRecord(w.ev[w.cur], g.s));
+    w.busy[w.cur] = true;
+    w.issued += w.fill;
+    w.fill = 0;
+    w.cur ^= 1;
+    if (w.busy[w.cur]) { CBLX_HIP(hipEventSynchronize(w.ev[w.cur])); w.busy[w.cur] = false; }
+}
+void writer_put(cblx_ctx* c, Ingest::Writer& w, size_t blk_bytes, u8* d_dst, const u8* src, size_t n) {
+    Ingest& g = c->ing;
+    if (!w.blk[0]) {
+        if (!g.s) CBLX_HIP(hipStreamCreateWithFlags(&g.s, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            CBLX_HIP(hipHostMalloc((void**)&w.blk[k], blk_bytes, hipHostMallocDefault));
+            CBLX_HIP(hipEventCreateWithFlags(&w.ev[k], hipEventDisableTiming));
+        }
+        w.cap = blk_bytes;
+    }
+    while (n) {
+        const size_t m = std::min(n, w.cap - w.fill);
+        std::memcpy(w.blk[w.cur] + w.fill, src, m);
+        w.fill += m; src += m; n -= m;
+        if (w.fill == w.cap) writer_issue(c, w, d_dst);
+    }
+}
+// room for `add_bytes` more bases and `add_seqs` more sequences
+void ingest_reserve(cblx_ctx* c, u64 add_bytes, u64 add_seqs) {
+    Ingest& g = c->ing;
+    const u64 need_b = g.nbytes + add_bytes + 64, need_o = g.nseq + add_seqs + 1;
+    if (g.d_bases.n < need_b) {
+        Buf<u8> nb(c->pool, std::max<u64>({need_b, 2 * (u64)g.d_bases.n, 1u << 20}));
+        if (g.nbytes) {
+            ingest_wait(c);
+            CBLX_HIP(hipMemcpyAsync(nb.get(), g.d_bases.get(), g.wb.issued, hipMemcpyDeviceToDevice, c->stream));
+            CBLX_HIP(hipStreamSynchronize(c->stream));
+        }
+        g.d_bases = std::move(nb);
+    }
+    if (g.d_off.n < need_o) {
+        Buf<u64> no(c->pool, std::max<u64>({need_o, 2 * (u64)g.d_off.n, 1u << 14}));
+        ingest_wait(c);
+        CBLX_HIP(hipMemsetAsync(no.get(), 0, 8, c->stream));
+        if (g.nseq) CBLX_HIP(hipMemcpyAsync(no.get() + 1, g.d_off.get() + 1, g.wo.issued, hipMemcpyDeviceToDevice, c->stream));
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+        g.d_off = std::move(no);
+    }
+}
+void flush(cblx_ctx* c);
+// one sequence (the cblx_insert_seq / FASTA-record granularity)
+void ingest_seq(cblx_ctx* c, const u8* seq, u64 len) {
+    Ingest& g = c->ing;
+    ingest_reserve(c, len, 1);
+    writer_put(c, g.wb, Ingest::BASES_BLK, g.d_bases.get(), seq, len);
+    g.nbytes += len;
+    const u64 end = g.nbytes;
+    writer_put(c, g.wo, Ingest::OFF_BLK, (u8*)(g.d_off.get() + 1), (const u8*)&end, 8);
+    g.nseq += 1;
+    if (g.nbytes >= (2ull << 30)) flush(c);  // bound the queue (same result: batches are inserted in order)
+}
+// n sequences at once (offsets already validated)
+void ingest_seqs(cblx_ctx* c, const u8* bases, const u64* offsets, u64 n) {
+    Ingest& g = c->ing;
+    const u64 len = offsets[n] - offsets[0];
+    if (len < (1u << 20)) {
+        for (u64 i = 0; i < n; ++i) ingest_seq(c, bases + offsets[i], offsets[i + 1] - offsets[i]);
+        return;
+    }
+    ingest_reserve(c, len, n);
+    if (!g.s) CBLX_HIP(hipStreamCreateWithFlags(&g.s, hipStreamNonBlocking));
+    if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
+    if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));
+    Xfer& x = xfer(c);
+    x.h2d_copy(g.d_bases.get() + g.nbytes, bases + offsets[0], len);
+    const u64 base = g.nbytes, o0 = offsets[0];
+    x.h2d(g.d_off.get() + 1 + g.nseq, n * 8, [&](u8* dst, size_t off, size_t nb) {
+        u64* d = (u64*)dst;
+        const u64* src = offsets + off / 8 + 1;
+        for (size_t j = 0; j < nb / 8; ++j) d[j] = base + (src[j] - o0);
+    });
+    g.nbytes += len;
+    g.nseq += n;
+    g.wb.issued = g.nbytes;
+    g.wo.issued = g.nseq * 8;
+    if (g.nbytes >= (2ull << 30)) flush(c);
+}
+void ingest_drop(cblx_ctx* c) {  // forget everything enqueued (clear / load)
+    Ingest& g = c->ing;
+    ingest_wait(c);
+    for (Ingest::Writer* w : {&g.wb, &g.wo}) { w->fill = 0; w->issued = 0; w->busy[0] = w->busy[1] = false; }
+    g.nbytes = g.nseq = 0;
+}
+void ingest_destroy(cblx_ctx* c) {
+    Ingest& g = c->ing;
+    if (g.s) (void)hipStreamSynchronize(g.s);
+    g.xfer.reset();
+    for (Ingest::Writer* w : {&g.wb, &g.wo})
+        for (int k = 0; k < 2; ++k) {
+            if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
+            if (w->blk[k]) (void)hipHostFree(w->blk[k]);
+            w->ev[k] = nullptr; w->blk[k] = nullptr;
+        }
+    if (g.s) (void)hipStreamDestroy(g.s);
+    g.s = nullptr;
+    g.d_bases.reset();
+    g.d_off.reset();
+}
+
 void flush(cblx_ctx* c) {
-    const u64 nseq = c->pend_offsets.size() - 1;
+    Ingest& g = c->ing;
+    const u64 nseq = g.nseq;
     if (nseq == 0) return;
     CBLX_HIP(hipSetDevice(c->device));
-    {
-        Buf<u8> d_bases(c->pool, c->pend_bases.size() + 64);
-        Buf<u64> d_off(c->pool, nseq + 1);
-        h2d(c, d_bases.get(), c->pend_bases.data(), c->pend_bases.size());
-        h2d(c, d_off.get(), c->pend_offsets.data(), nseq + 1);
-        // the pending queue is consumed even if the insert fails (the reference would have panicked)
-        std::vector<u8> keep_b;
-        std::vector<u64> keep_o;
-        keep_b.swap(c->pend_bases);
-        keep_o.swap(c->pend_offsets);
-        c->pend_offsets.assign(1, 0);
-        insert_device(c, d_bases.get(), d_off.get(), nseq);
-        CBLX_HIP(hipStreamSynchronize(c->stream));
-    }
+    if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
+    if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));
+    ingest_wait(c);
+    // the pending queue is consumed even if the insert fails (the reference would have panicked)
+    for (Ingest::Writer* w : {&g.wb, &g.wo}) { w->issued = 0; w->busy[0] = w->busy[1] = false; }
+    g.nbytes = g.nseq = 0;
+    insert_device(c, g.d_bases.get(), g.d_off.get(), nseq);
+    CBLX_HIP(hipStreamSynchronize(c->stream));
 }
 
 // ---- host-side views of the resident index (export / serialize / merge) ---------------------------------------
@@ -930,6 +1066,7 @@ void cblx_destroy(cblx_ctx* ctx) {
     for (auto& e : ctx->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : ctx->ev_free) (void)hipEventDestroy(e);
     ctx->res = Resident();
+    ingest_destroy(ctx);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -938,22 +1075,22 @@ int cblx_insert_seq(cblx_ctx* c, const uint8_t* seq, uint64_t len) {
     return guard(c, [&] {
         if (!seq && len) throw Error(CBLX_EINVAL, "null sequence");
         if (len < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(len) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
-        c->pend_bases.insert(c->pend_bases.end(), seq, seq + len);
-        c->pend_offsets.push_back(c->pend_bases.size());
+        ingest_seq(c, seq, len);
     });
 }
 int cblx_insert_seqs(cblx_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint64_t n) {
     return guard(c, [&] {
         if (n == 0) return;
         if (!bases || !offsets) throw Error(CBLX_EINVAL, "null argument");
-        for (u64 i = 0; i < n; ++i) {
-            if (offsets[i + 1] < offsets[i]) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
-            u64 len = offsets[i + 1] - offsets[i];
-            if (len < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(len) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
+        bool mono = true;
+        u64 minlen = ~0ull;
+        for (u64 i = 0; i < n; ++i) {  // branch-free scan; the offender is looked up only on failure
+            mono &= offsets[i + 1] >= offsets[i];
+            minlen = std::min(minlen, offsets[i + 1] - offsets[i]);
         }
-        const u64 base = c->pend_bases.size();
-        c->pend_bases.insert(c->pend_bases.end(), bases + offsets[0], bases + offsets[n]);
-        for (u64 i = 1; i <= n; ++i) c->pend_offsets.push_back(base + (offsets[i] - offsets[0]));
+        if (!mono) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
+        if (minlen < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(minlen) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
+        ingest_seqs(c, bases, offsets, n);
     });
 }
 int cblx_insert_seqs_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n) {
@@ -980,11 +1117,10 @@ int cblx_insert_fastx_file(cblx_ctx* c, const char* path, uint64_t* n_records) {
         auto strip = [](std::string& l) { while (!l.empty() && (l.back() == '\r' || l.back() == '\n')) l.pop_back(); };
         auto emit = [&]() {
             if (seq.size() < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(seq.size()) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
-            c->pend_bases.insert(c->pend_bases.end(), seq.begin(), seq.end());
-            c->pend_offsets.push_back(c->pend_bases.size());
+            ingest_seq(c, (const u8*)seq.data(), seq.size());
             ++nrec;
             seq.clear();
-            if (c->pend_bases.size() >= (1ull << 30)) flush(c);
+            if (c->ing.nbytes >= (1ull << 30)) flush(c);
         };
         bool have = false;
         while (std::getline(f, line)) {
@@ -1204,8 +1340,7 @@ int cblx_load(cblx_ctx* c, const uint8_t* data, uint64_t len) {
         HostIndex h;
         bool canon = false;
         parse_index(c->P, data, len, h, canon);
-        c->pend_bases.clear();
-        c->pend_offsets.assign(1, 0);
+        ingest_drop(c);
         upload(c, h);
         c->P.canonical = canon ? 1 : 0;
     });
@@ -1369,13 +1504,17 @@ int cblx_stage_times_reset(cblx_ctx* c) {
     return guard(c, [&] { collect_events(c); for (auto& s : c->stages) { s.ms = 0; s.launches = 0; } });
 }
 int cblx_kmers_inserted(cblx_ctx* c, uint64_t* out) { if (!c || !out) return CBLX_EINVAL; *out = c->kmers_inserted; return CBLX_OK; }
-int cblx_trim(cblx_ctx* c) { return guard(c, [&] { c->pool.trim(); }); }
+int cblx_trim(cblx_ctx* c) {
+    return guard(c, [&] {
+        if (c->ing.nseq == 0) { ingest_wait(c); c->ing.d_bases.reset(); c->ing.d_off.reset(); }
+        c->pool.trim();
+    });
+}
 int cblx_clear(cblx_ctx* c) {
     return guard(c, [&] {
         CBLX_HIP(hipStreamSynchronize(c->stream));
         c->res = Resident();
-        c->pend_bases.clear();
-        c->pend_offsets.assign(1, 0);
+        ingest_drop(c);
     });
 }
 

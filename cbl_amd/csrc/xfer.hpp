@@ -1,0 +1,155 @@
+// xfer.hpp — host <-> HBM transfers for caller-owned (pageable) buffers.
+//
+// The ABI borrows plain host pointers (include/cblx.h: cblx_insert_seq / cblx_insert_seqs / cblx_load / cblx_serialize).
+// A hipMemcpy from pageable memory runs at a few GB/s on this platform; PCIe Gen5 x16 moves ~55 GB/s from pinned
+// memory. So every bulk transfer goes through a small set of LANES: each lane is a host thread with its own HIP stream
+// and two pinned slots; chunk i of a transfer belongs to lane i % L, which copies (or transforms) it into a slot and
+// issues the DMA while the other slot of the lane is being filled. Chunks carry their destination offset, so lanes
+// never need to agree on an order.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <exception>
+#include <thread>
+#include <vector>
+
+#include "common.hpp"
+
+namespace cblx {
+
+class Xfer {
+public:
+    static constexpr size_t SLOT = 8u << 20;       // bytes per pinned slot
+    static constexpr size_t PARALLEL_MIN = 4u << 20;  // below this a transfer stays on the calling thread (lane 0)
+
+    explicit Xfer(int device) : device_(device) {}
+    Xfer(const Xfer&) = delete;
+    Xfer& operator=(const Xfer&) = delete;
+    ~Xfer() {
+        for (auto& l : lanes_) {
+            if (l.s) (void)hipStreamSynchronize(l.s);
+            for (int k = 0; k < 2; ++k) {
+                if (l.ev[k]) (void)hipEventDestroy(l.ev[k]);
+                if (l.slot[k]) (void)hipHostFree(l.slot[k]);
+            }
+            if (l.s) (void)hipStreamDestroy(l.s);
+        }
+    }
+
+    // host -> device: fill(dst_pinned, off, n) must produce bytes [off, off+n) of the logical source.
+    // Returns when every chunk has been handed to the DMA engines; call sync() before the device reads `d_dst`.
+    template <typename F> void h2d(void* d_dst, size_t bytes, F&& fill) {
+        run(bytes, [&](Lane& l, int k, size_t off, size_t n) {
+            fill(l.slot[k], off, n);
+            CBLX_HIP(hipMemcpyAsync((u8*)d_dst + off, l.slot[k], n, hipMemcpyHostToDevice, l.s));
+        });
+    }
+    void h2d_copy(void* d_dst, const void* h_src, size_t bytes) {
+        h2d(d_dst, bytes, [&](u8* dst, size_t off, size_t n) { std::memcpy(dst, (const u8*)h_src + off, n); });
+    }
+    // device -> host: drain(src_pinned, off, n) consumes bytes [off, off+n). Complete on return.
+    template <typename F> void d2h(const void* d_src, size_t bytes, F&& drain) {
+        // software pipeline per lane: issue chunk j, then drain chunk j-1 while j is in flight
+        const size_t nchunk = (bytes + SLOT - 1) / SLOT;
+        const int L = lanes_for(bytes);
+        ensure(L);
+        auto work = [&](int li) {
+            CBLX_HIP(hipSetDevice(device_));
+            Lane& l = lanes_[li];
+            for (int b = 0; b < 2; ++b)
+                if (l.busy[b]) { CBLX_HIP(hipEventSynchronize(l.ev[b])); l.busy[b] = false; }  // slots still feeding an h2d
+            size_t prev_off = 0, prev_n = 0;
+            int k = 0;
+            bool have_prev = false;
+            for (size_t ci = (size_t)li; ci < nchunk; ci += (size_t)L) {
+                const size_t off = ci * SLOT, n = std::min(SLOT, bytes - off);
+                CBLX_HIP(hipMemcpyAsync(l.slot[k], (const u8*)d_src + off, n, hipMemcpyDeviceToHost, l.s));
+                CBLX_HIP(hipEventRecord(l.ev[k], l.s));
+                if (have_prev) {
+                    CBLX_HIP(hipEventSynchronize(l.ev[k ^ 1]));
+                    drain(l.slot[k ^ 1], prev_off, prev_n);
+                }
+                prev_off = off; prev_n = n; have_prev = true;
+                k ^= 1;
+            }
+            if (have_prev) {
+                CBLX_HIP(hipEventSynchronize(l.ev[k ^ 1]));
+                drain(l.slot[k ^ 1], prev_off, prev_n);
+            }
+        };
+        fan_out(L, work);
+    }
+    void d2h_copy(void* h_dst, const void* d_src, size_t bytes) {
+        d2h(d_src, bytes, [&](const u8* src, size_t off, size_t n) { std::memcpy((u8*)h_dst + off, src, n); });
+    }
+    // all DMA issued by h2d() has landed
+    void sync() {
+        for (auto& l : lanes_) if (l.s) CBLX_HIP(hipStreamSynchronize(l.s));
+    }
+
+private:
+    struct Lane {
+        hipStream_t s = nullptr;
+        u8* slot[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool busy[2] = {false, false};
+    };
+    int device_;
+    std::vector<Lane> lanes_;
+
+    static int max_lanes() {
+        unsigned hc = std::thread::hardware_concurrency();
+        return (int)std::max(1u, std::min(8u, hc ? hc / 2 : 2u));
+    }
+    int lanes_for(size_t bytes) const {
+        if (bytes < PARALLEL_MIN) return 1;
+        return (int)std::min<size_t>((size_t)max_lanes(), (bytes + SLOT - 1) / SLOT);
+    }
+    void ensure(int L) {
+        if ((int)lanes_.size() < L) lanes_.resize(L);
+        for (int i = 0; i < L; ++i) {
+            Lane& l = lanes_[i];
+            if (l.s) continue;
+            CBLX_HIP(hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking));
+            for (int k = 0; k < 2; ++k) {
+                CBLX_HIP(hipHostMalloc((void**)&l.slot[k], SLOT, hipHostMallocDefault));
+                CBLX_HIP(hipEventCreateWithFlags(&l.ev[k], hipEventDisableTiming));
+            }
+        }
+    }
+    template <typename W> void fan_out(int L, W&& work) {
+        if (L == 1) { work(0); return; }
+        std::vector<std::thread> th;
+        std::vector<std::exception_ptr> errs((size_t)L);
+        for (int i = 1; i < L; ++i)
+            th.emplace_back([&, i] { try { work(i); } catch (...) { errs[(size_t)i] = std::current_exception(); } });
+        try { work(0); } catch (...) { errs[0] = std::current_exception(); }
+        for (auto& t : th) t.join();
+        for (auto& e : errs) if (e) std::rethrow_exception(e);
+    }
+    template <typename Issue> void run(size_t bytes, Issue&& issue) {
+        if (bytes == 0) return;
+        const size_t nchunk = (bytes + SLOT - 1) / SLOT;
+        const int L = lanes_for(bytes);
+        ensure(L);
+        auto work = [&](int li) {
+            CBLX_HIP(hipSetDevice(device_));
+            Lane& l = lanes_[li];
+            int k = 0;
+            for (size_t ci = (size_t)li; ci < nchunk; ci += (size_t)L) {
+                const size_t off = ci * SLOT, n = std::min(SLOT, bytes - off);
+                if (l.busy[k]) { CBLX_HIP(hipEventSynchronize(l.ev[k])); l.busy[k] = false; }  // slot's previous DMA done
+                issue(l, k, off, n);
+                CBLX_HIP(hipEventRecord(l.ev[k], l.s));
+                l.busy[k] = true;
+                k ^= 1;
+            }
+        };
+        fan_out(L, work);
+    }
+};
+
+}  // namespace cblx
