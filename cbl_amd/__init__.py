@@ -240,12 +240,23 @@ class CBL:
     # ---- src/cbl.rs:127-160 ---------------------------------------------------------------------------------
     def serialize(self) -> bytes:
         """The exact bytes `save_to_file` writes (bincode DefaultOptions + varint)."""
+        return self.serialize_np().tobytes()
+
+    def serialized_size(self) -> int:
         n = C.c_uint64(0)
         self._chk(self._L.cblx_serialized_size(self._h, C.byref(n)))
-        buf = (C.c_uint8 * max(n.value, 1))()
+        return n.value
+
+    def serialize_np(self, out=None):
+        """serialize() into a numpy uint8 array (`out` if given and large enough); returns the filled view."""
+        import numpy as np
+
+        n = self.serialized_size()
+        if out is None or out.size < n:
+            out = np.empty(max(n, 1), dtype=np.uint8)
         w = C.c_uint64(0)
-        self._chk(self._L.cblx_serialize(self._h, buf, n.value, C.byref(w)))
-        return bytes(memoryview(buf)[: w.value])
+        self._chk(self._L.cblx_serialize(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), n, C.byref(w)))
+        return out[: w.value]
 
     def save_to_file(self, path):
         self._chk(self._L.cblx_save_to_file(self._h, os.fsencode(path)))

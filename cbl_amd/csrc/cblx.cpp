@@ -14,7 +14,11 @@
 #include <memory>
 #include <thread>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include "kernels_bucket.hpp"
+#include "kernels_serde.hpp"
 #include "xfer.hpp"
 
 using namespace cblx;
@@ -892,6 +896,70 @@ void serialize_host(const Consts& P, const HostIndex& h, Sink& s) {
     }
     s.pos = base + part[nt];
 }
+// ---- the same bytes, produced in HBM (kernels_serde.hpp): size pass -> exclusive scan -> emit pass ---------------
+struct DevBlob { Buf<u8> bytes; u64 n = 0; };
+// false: a bucket is longer than the device emitters handle (SER_CAP1024) -> the caller takes the host path
+template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blob) {
+    constexpr bool WS = C::WS;
+    const Resident& r = c->res;
+    const Consts& P = c->P;
+    const u64 nb = r.nb;
+    u8 hdr[16];
+    Sink hs(hdr, sizeof hdr);
+    hs.u8_(P.canonical ? 1 : 0);  // CBL.canonical (src/cbl.rs:48)
+    hs.varint(nb);                // serialize_map(Some(tiered.len()))  src/wordset/mod.rs:388
+    u64 total = 0;
+    Buf<u32> size, lists, list_n;
+    Buf<u64> off;
+    std::vector<u32> ln(SER_NCLS, 0);
+    const u64 *a_lo = r.a_lo.get(), *a_hi = WS ? r.a_hi.get() : (const u64*)nullptr;
+    auto buckets = [&](auto em, u8* body) {
+        constexpr bool EM = decltype(em)::value;
+        if (ln[SER_C64])
+            hipLaunchKernelGGL((k_serde_bucket<64, 16, WS, EM>), dim3(ln[SER_C64]), dim3(64), 0, c->stream, lists.get() + (size_t)SER_C64 * nb, list_n.get() + SER_C64,
+                               r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body);
+        if (ln[SER_C256])
+            hipLaunchKernelGGL((k_serde_bucket<256, 16, WS, EM>), dim3(ln[SER_C256]), dim3(256), 0, c->stream, lists.get() + (size_t)SER_C256 * nb, list_n.get() + SER_C256,
+                               r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body);
+        if (ln[SER_C1024])
+            hipLaunchKernelGGL((k_serde_bucket<1024, 8, WS, EM>), dim3(ln[SER_C1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)SER_C1024 * nb, list_n.get() + SER_C1024,
+                               r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body);
+        CBLX_HIP(hipGetLastError());
+    };
+    if (nb) {
+        size = Buf<u32>(c->pool, nb);
+        lists = Buf<u32>(c->pool, (size_t)SER_NCLS * nb);
+        list_n = Buf<u32>(c->pool, SER_NCLS);
+        off = Buf<u64>(c->pool, nb + 1);
+        CBLX_HIP(hipMemsetAsync(list_n.get(), 0, SER_NCLS * 4, c->stream));
+        hipLaunchKernelGGL((k_serde_tiny<WS, false>), grid1(nb, 256), dim3(256), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
+                           P.SB, P.BYTES, size.get(), (const u64*)nullptr, (u8*)nullptr, lists.get(), list_n.get());
+        CBLX_HIP(hipGetLastError());
+        ln = d2h_vec<u32>(c, list_n.get(), SER_NCLS);
+        if (ln[SER_HOST]) return false;
+        buckets(std::false_type(), nullptr);
+        total = exclusive_scan<u64>(c, size.get(), nb, off.get());
+    }
+    blob.n = hs.pos + total;
+    if (!emit) return true;
+    blob.bytes = Buf<u8>(c->pool, blob.n + 16);
+    CBLX_HIP(hipMemcpyAsync(blob.bytes.get(), hdr, hs.pos, hipMemcpyHostToDevice, c->stream));
+    if (nb) {
+        u8* body = blob.bytes.get() + hs.pos;
+        hipLaunchKernelGGL((k_serde_tiny<WS, true>), grid1(nb, 256), dim3(256), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
+                           P.SB, P.BYTES, size.get(), off.get(), body, (u32*)nullptr, (u32*)nullptr);
+        buckets(std::true_type(), body);
+    }
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    return true;
+}
+bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blob) {
+    if (const char* e = std::getenv("CBLX_HOST_SERDE")) if (e[0] == '1') return false;  // test hook: force the host emitter
+    bool ok = false;
+    dispatch(c->P, [&](auto cfg) { ok = serialize_device<decltype(cfg)>(c, emit, blob); });
+    return ok;
+}
+
 struct Src {
     const u8* p;
     const u8* end;
@@ -1300,6 +1368,8 @@ int cblx_is_canonical(const cblx_ctx* c, int* out) { if (!c || !out) return CBLX
 int cblx_serialized_size(cblx_ctx* c, uint64_t* nbytes) {
     return guard(c, [&] {
         flush(c);
+        DevBlob blob;
+        if (serialize_device(c, false, blob)) { *nbytes = blob.n; return; }
         HostIndex h;
         download(c, h);
         Sink s(nullptr, 0);
@@ -1310,6 +1380,14 @@ int cblx_serialized_size(cblx_ctx* c, uint64_t* nbytes) {
 int cblx_serialize(cblx_ctx* c, uint8_t* buf, uint64_t cap, uint64_t* written) {
     return guard(c, [&] {
         flush(c);
+        DevBlob blob;
+        if (serialize_device(c, false, blob)) {
+            if (written) *written = blob.n;
+            if (blob.n > cap) throw Error(CBLX_ERANGE, "buffer too small: need " + std::to_string(blob.n) + " bytes");
+            serialize_device(c, true, blob);
+            xfer(c).d2h_copy(buf, blob.bytes.get(), blob.n);
+            return;
+        }
         HostIndex h;
         download(c, h);
         Sink s(buf, cap);
@@ -1321,6 +1399,23 @@ int cblx_serialize(cblx_ctx* c, uint8_t* buf, uint64_t cap, uint64_t* written) {
 int cblx_save_to_file(cblx_ctx* c, const char* path) {
     return guard(c, [&] {
         flush(c);
+        DevBlob blob;
+        if (serialize_device(c, true, blob)) {  // the lanes write their chunks straight from pinned memory
+            const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (fd < 0) throw Error(CBLX_EINVAL, std::string("Failed to create ") + path);
+            std::atomic<bool> bad{false};
+            try {
+                xfer(c).d2h(blob.bytes.get(), blob.n, [&](const u8* src, size_t off, size_t n) {
+                    while (n) {
+                        const ssize_t w = ::pwrite(fd, src, n, (off_t)off);
+                        if (w <= 0) { bad = true; return; }
+                        src += w; off += (size_t)w; n -= (size_t)w;
+                    }
+                });
+            } catch (...) { ::close(fd); throw; }
+            if (::close(fd) != 0 || bad) throw Error(CBLX_EINVAL, std::string("Failed to write index to ") + path);
+            return;
+        }
         HostIndex h;
         download(c, h);
         Sink cnt(nullptr, 0);

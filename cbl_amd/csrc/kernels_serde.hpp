@@ -1,0 +1,255 @@
+// kernels_serde.hpp — the serde/bincode index bytes emitted on the device.
+//
+// Reference: `WordSet::serialize` /root/reference/src/wordset/mod.rs:382-396 (map of prefix -> TrieVec, ascending
+// prefixes), `TrieOrVec` derive src/trievec/mod.rs:8-15, `Trie/TrieNode` derive src/trie.rs:8-9,53-57, `TinyBitvector`
+// src/bitvector/tiny/mod.rs:97-105 (popcount + set indices), `SlicedInt::serialize` src/sliced_int.rs:110-114, bincode
+// 1.3 varint options src/cbl.rs:132-135. A bucket entry is a byte range that depends on that bucket only, so: pass 1
+// sizes every entry, an exclusive scan places them, pass 2 writes them.
+//
+// Trie entry as a data-parallel computation over the bucket's sorted suffixes x[0..n):
+//   lcp[j]  = number of leading (big-endian) bytes x[j] shares with x[j-1]  (lcp[0] = -1)
+//   a node at level d starts at j   <=>  lcp[j] <  d      (x[j] is the first suffix with its d-byte prefix)
+//   x[j] adds a child at level d    <=>  lcp[j] <= d      (first suffix with its (d+1)-byte prefix)
+//   so the nodes of level d are the children of level d-1, in the same order, and with X_d = exclusive rank of the
+//   level-d children: c(node k) = X_d[start of node k+1] - X_d[start of node k].
+//   Pre-order = nodes sorted by (start j, level d): position = sum of the header sizes of all earlier (j, d) pairs;
+//   header = varint(c) | c child bytes | varint(#children) where child bytes are written by the children themselves.
+#pragma once
+#include <type_traits>
+
+#include "kernels_bucket.hpp"
+
+namespace cblx {
+
+__device__ __forceinline__ u32 vlen(u64 v) { return v <= 250 ? 1u : v < (1ull << 16) ? 3u : v < (1ull << 32) ? 5u : 9u; }
+__device__ __forceinline__ void put_varint(u8* p, u64 v) {
+    if (v <= 250) { p[0] = (u8)v; return; }
+    const int nb = v < (1ull << 16) ? 2 : v < (1ull << 32) ? 4 : 8;
+    p[0] = nb == 2 ? 0xFB : nb == 4 ? 0xFC : 0xFD;
+    for (int i = 0; i < nb; ++i) p[1 + i] = (u8)(v >> (8 * i));
+}
+
+template <bool WS> __device__ __forceinline__ Sfx<WS> arena_sfx(const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u64 i, u32 SB) {
+    // arena slots of buckets a rebuild did not touch still carry the full word: always mask to SB bits
+    Sfx<WS> s;
+    if constexpr (WS) {
+        s.lo = a_lo[i];
+        s.hi = a_hi[i] & ((1ull << (SB - 64)) - 1ull);
+    } else {
+        s.lo = SB >= 64 ? a_lo[i] : (a_lo[i] & ((1ull << SB) - 1ull));
+    }
+    return s;
+}
+template <bool WS> __device__ __forceinline__ u32 sfx_byte_le(const Sfx<WS>& s, u32 k) {
+    if constexpr (WS) return k < 8 ? (u32)(s.lo >> (8 * k)) & 255u : (u32)(s.hi >> (8 * (k - 8))) & 255u;
+    else return (u32)(s.lo >> (8 * k)) & 255u;
+}
+// little-endian index of the most significant byte where a and b differ (a != b)
+template <bool WS> __device__ __forceinline__ u32 top_diff_byte(const Sfx<WS>& a, const Sfx<WS>& b) {
+    if constexpr (WS) {
+        const u64 xh = a.hi ^ b.hi;
+        if (xh) return 8u + (63u - (u32)__builtin_clzll(xh)) / 8u;
+    }
+    return (63u - (u32)__builtin_clzll(a.lo ^ b.lo)) / 8u;
+}
+
+enum { SER_C64 = 0, SER_C256 = 1, SER_C1024 = 2, SER_HOST = 3, SER_NCLS = 4 };
+static const u32 SER_CAP64 = 64 * 16, SER_CAP256 = 256 * 16, SER_CAP1024 = 1024 * 8;  // bucket lengths per workgroup shape
+static const u32 SER_TINY = 32;  // Vec buckets up to this length are written by one thread each
+
+// Pass over all buckets, one thread each: tiny Vec buckets are sized (EMIT = false) or written (EMIT = true) here; the
+// others are appended to the list of their size class (sizing pass only; unordered).
+template <bool WS, bool EMIT>
+__global__ void k_serde_tiny(u64 nb, const u32* __restrict__ prefix, const u64* __restrict__ start, const u32* __restrict__ cnt,
+                             const u8* __restrict__ kind, const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u32 SB, u32 BYTES,
+                             u32* __restrict__ size, const u64* __restrict__ off, u8* __restrict__ out, u32* __restrict__ lists,
+                             u32* __restrict__ list_n) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = r < nb;
+    const u32 n = live ? cnt[r] : 0;
+    const bool tiny = live && kind[r] == KIND_VEC && n <= SER_TINY;
+    if (tiny) {
+        const u32 pfx = prefix[r];
+        const u32 hdr = vlen(pfx) + 1 + vlen(n);
+        if constexpr (!EMIT) {
+            size[r] = hdr + n * (1 + BYTES);
+        } else {
+            u8* o = out + off[r];
+            put_varint(o, pfx);
+            o[vlen(pfx)] = 0;  // TrieOrVec::Vec
+            put_varint(o + vlen(pfx) + 1, n);
+            o += hdr;
+            const u64 s0 = start[r];
+            for (u32 j = 0; j < n; ++j) {
+                const Sfx<WS> s = arena_sfx<WS>(a_lo, a_hi, s0 + j, SB);
+                o[0] = (u8)BYTES;
+                for (u32 k = 0; k < BYTES; ++k) o[1 + k] = (u8)sfx_byte_le<WS>(s, k);
+                o += 1 + BYTES;
+            }
+        }
+    }
+    if constexpr (!EMIT) {
+        int cls = -1;
+        if (live && !tiny) cls = n <= SER_CAP64 ? SER_C64 : n <= SER_CAP256 ? SER_C256 : n <= SER_CAP1024 ? SER_C1024 : SER_HOST;
+#pragma unroll
+        for (int k = 0; k < SER_NCLS; ++k) {
+            const u64 bal = __ballot(cls == k);
+            if (cls == k) {
+                u32 base = 0;
+                const u32 leader = (u32)__builtin_ctzll(bal);
+                if (lane_id() == leader) base = atomicAdd(&list_n[k], (u32)__builtin_popcountll(bal));
+                base = __shfl(base, (int)leader, 64);
+                lists[(u64)k * nb + base + mbcnt(bal)] = (u32)r;
+            }
+        }
+    }
+}
+
+// One workgroup per listed bucket (n <= THREADS * ITEMS).
+template <int THREADS, int ITEMS, bool WS, bool EMIT>
+__global__ __launch_bounds__(THREADS) void k_serde_bucket(const u32* __restrict__ list, const u32* __restrict__ list_n, const u32* __restrict__ prefix,
+                                                          const u64* __restrict__ start, const u32* __restrict__ cnt, const u8* __restrict__ kind,
+                                                          const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u32 SB, u32 BYTES,
+                                                          u32* __restrict__ size, const u64* __restrict__ off, u8* __restrict__ out) {
+    constexpr int NW = THREADS / 64, EPW = 64 * ITEMS, CAP = THREADS * ITEMS;
+    __shared__ u32 s_wtot[NW + 1];
+    __shared__ u16 s_ns[CAP + 2];                // X_d at the start of node k (+ sentinel)
+    __shared__ u32 s_np[EMIT ? CAP : 1];         // where node k's child bytes start (relative to the entry)
+    if (blockIdx.x >= *list_n) return;
+    const u32 r = list[blockIdx.x];
+    const u32 n = cnt[r], pfx = prefix[r];
+    const u64 s0 = start[r];
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const u32 hdr = vlen(pfx) + 1;
+    u8* o = EMIT ? out + off[r] : nullptr;
+    if (kind[r] == KIND_VEC) {                   // varint(n) then n x (varint(BYTES) | BYTES little-endian bytes), stored order
+        if constexpr (!EMIT) {
+            if (tid == 0) size[r] = hdr + vlen(n) + n * (1 + BYTES);
+        } else {
+            if (tid == 0) { put_varint(o, pfx); o[hdr - 1] = 0; put_varint(o + hdr, n); }
+            u8* body = o + hdr + vlen(n);
+            for (u32 j = tid; j < n; j += THREADS) {
+                const Sfx<WS> s = arena_sfx<WS>(a_lo, a_hi, s0 + j, SB);
+                u8* p = body + (u64)j * (1 + BYTES);
+                p[0] = (u8)BYTES;
+                for (u32 k = 0; k < BYTES; ++k) p[1 + k] = (u8)sfx_byte_le<WS>(s, k);
+            }
+        }
+        return;
+    }
+    // ---- Trie(root, len): pre-order nodes then varint(n)
+    Sfx<WS> x[ITEMS];
+    int lcp[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const u32 e = w * EPW + i * 64 + lane;
+        lcp[i] = 127;  // slots past the end never flag
+        x[i].lo = 0;
+        if constexpr (WS) x[i].hi = 0;
+        if (e < n) {
+            x[i] = arena_sfx<WS>(a_lo, a_hi, s0 + e, SB);
+            if (e == 0) lcp[i] = -1;
+            else {
+                const Sfx<WS> p = arena_sfx<WS>(a_lo, a_hi, s0 + e - 1, SB);
+                lcp[i] = (int)(BYTES - 1) - (int)top_diff_byte<WS>(x[i], p);
+            }
+        }
+    }
+    // exclusive rank (element order) of a flag; returns the number of flags
+    auto rank_flags = [&](const bool (&f)[ITEMS], u32 (&xr)[ITEMS]) -> u32 {
+        u32 run = 0;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const u64 bal = __ballot(f[i]);
+            xr[i] = run + mbcnt(bal);
+            run += (u32)__builtin_popcountll(bal);
+        }
+        if constexpr (NW == 1) return run;
+        __syncthreads();
+        if (lane == 0) s_wtot[w] = run;
+        __syncthreads();
+        u32 base = 0, tot = 0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) { const u32 t = s_wtot[ww]; if ((u32)ww < w) base += t; tot += t; }
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) xr[i] += base;
+        return tot;
+    };
+    // one walk over the levels; EM = false accumulates header bytes per element into acc, EM = true writes them at base + acc
+    auto levels = [&](auto em_tag, u32 (&acc)[ITEMS], const u32 (&base)[ITEMS]) {
+        constexpr bool EM = decltype(em_tag)::value;
+        bool tprev[ITEMS], tcur[ITEMS];
+        u32 xprev[ITEMS], xcur[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) tprev[i] = lcp[i] < 0;
+        u32 nodes = rank_flags(tprev, xprev);  // level 0: the root
+        for (u32 d = 0; d < BYTES; ++d) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) tcur[i] = lcp[i] <= (int)d;
+            const u32 tot = rank_flags(tcur, xcur);
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i)
+                if (tprev[i]) s_ns[xprev[i]] = (u16)xcur[i];
+            if (tid == 0) s_ns[nodes] = (u16)tot;
+            __syncthreads();
+            const bool leaf = d + 1 == BYTES;
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                if (tprev[i]) {
+                    const u32 c = (u32)s_ns[xprev[i] + 1] - (u32)s_ns[xprev[i]];
+                    const u32 hs = vlen(c) + c + (leaf ? 1u : vlen(c));
+                    if constexpr (EM) {
+                        u8* p = o + base[i] + acc[i];
+                        put_varint(p, c);
+                        put_varint(p + vlen(c) + c, leaf ? 0u : c);
+                        s_np[xprev[i]] = base[i] + acc[i] + vlen(c);
+                    }
+                    acc[i] += hs;
+                }
+            }
+            if constexpr (EM) {
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < ITEMS; ++i) {
+                    if (tcur[i]) {
+                        const u32 kp = xprev[i] + (tprev[i] ? 1u : 0u) - 1u;  // the node this child belongs to
+                        o[s_np[kp] + (xcur[i] - (u32)s_ns[kp])] = (u8)sfx_byte_le<WS>(x[i], BYTES - 1 - d);
+                    }
+                }
+            }
+            __syncthreads();  // s_ns / s_np are rewritten by the next level
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) { tprev[i] = tcur[i]; xprev[i] = xcur[i]; }
+            nodes = tot;
+        }
+    };
+    u32 E[ITEMS], base[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) { E[i] = 0; base[i] = 0; }
+    levels(std::false_type(), E, base);
+    // element-order exclusive scan of the per-element header bytes
+    u32 run = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const u32 inc = wave_inclusive_scan(E[i]);
+        base[i] = run + inc - E[i];
+        run += __shfl(inc, 63, 64);
+    }
+    __syncthreads();
+    if (lane == 0) s_wtot[w] = run;
+    __syncthreads();
+    u32 wbase = 0, total = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) { const u32 t = s_wtot[ww]; if ((u32)ww < w) wbase += t; total += t; }
+    if constexpr (!EMIT) {
+        if (tid == 0) size[r] = hdr + total + vlen(n);
+    } else {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) { base[i] += wbase + hdr; E[i] = 0; }
+        if (tid == 0) { put_varint(o, pfx); o[hdr - 1] = 1; put_varint(o + hdr + total, n); }  // TrieOrVec::Trie(.., len)
+        levels(std::true_type(), E, base);
+    }
+}
+
+}  // namespace cblx

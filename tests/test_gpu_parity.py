@@ -495,3 +495,30 @@ def test_seq_words_partitioned_matches_two_step():
             want = [w for d in range(nd) for w, dd in zip(words, dest) if dd == d]
             assert counts == [dest.count(d) for d in range(nd)]
             assert _words_from(olo[:nw], None if ohi is None else ohi[:nw]) == want
+
+
+def test_device_serializer_equals_host_serializer(monkeypatch, tmp_path):
+    """The index bytes are emitted by kernels (kernels_serde.hpp); the multi-threaded host emitter stays as the path
+    for buckets longer than 8192 words. Both must give the same bytes, through serialize() and save_to_file()."""
+    _need_gpu()
+    kinds = set()
+    for k, pb, nreads, L, canonical in ((31, 20, 200_000, 150, False), (59, 22, 60_000, 250, True), (25, 16, 100_000, 100, False), (15, 6, 3000, 100, False)):
+        bases, offsets = synth.reads(5, nreads, L)
+        g = cbl_amd.CBL(k, pb, canonical=canonical)
+        g.insert_seqs(bases, offsets)
+        monkeypatch.delenv("CBLX_HOST_SERDE", raising=False)
+        dev = g.serialize()
+        f = tmp_path / "x.cbl"
+        g.save_to_file(str(f))
+        assert f.read_bytes() == dev
+        monkeypatch.setenv("CBLX_HOST_SERDE", "1")
+        host = g.serialize()
+        monkeypatch.delenv("CBLX_HOST_SERDE")
+        assert len(dev) == len(host)
+        assert dev == host
+        if nreads <= 100_000:
+            kinds |= {kind for _, kind, _ in g.buckets()}
+        g2 = cbl_amd.CBL(k, pb, canonical=canonical)
+        g2.load(dev)
+        assert g2.checksum() == g.checksum() and g2.count() == g.count()
+    assert kinds == {0, 1}
