@@ -230,13 +230,8 @@ struct Records {
     const void* ext_hi = nullptr;
 };
 
-// `self |= other` through the same pipeline: records = self's words then other's; the bucket stage applies the |= rules
-struct MergeCtx {
-    const Resident* other;  // on the same device
-};
-
 // `countsA`: histogram of the first pass already accumulated by KRN-1 (empty Buf = compute it here)
-template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA = Buf<u32>(), const MergeCtx* mg = nullptr) {
+template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA = Buf<u32>()) {
     typedef typename C::HiT HiT;
     const Consts& P = c->P;
     Resident nr;
@@ -339,48 +334,7 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
         hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, nr.start.get() + nr.nb, N);
         CBLX_HIP(hipGetLastError());
     }
-    if (mg) {
-        // -- `self |= other`: classify by (self part, other part), merge the both-sides buckets
-        const u64 nb = nr.nb;
-        Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
-        Buf<u32> list_n(c->pool, CLS_N + 1), m_cs(c->pool, nb + 1);
-        Buf<u64> m_ostart(c->pool, nb + 1);
-        Buf<u8> m_okind(c->pool, nb + 1);
-        CBLX_HIP(hipMemsetAsync(list_n.get(), 0, (CLS_N + 1) * 4, c->stream));
-        hipLaunchKernelGGL(k_classify_merge, grid1(nb, 256), dim3(256), 0, c->stream, nb, C::WS ? 512u : 1024u, nr.prefix.get(), nr.start.get(), c->res.view(),
-                           mg->other->view(), m_cs.get(), m_ostart.get(), m_okind.get(), nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get(), list_n.get() + CLS_N);
-        std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N + 1);
-        if (ln[CLS_N]) throw Error(CBLX_EDEVICE, "merge: run lengths do not match the two indexes (internal error)");
-        const MergeArgs ma{m_cs.get(), m_ostart.get(), m_okind.get(), mg->other->a_lo.get(), mg->other->a_hi.get()};
-        u64* a_lo = rec.lo.get();
-        HiT* a_hi = (HiT*)rec.hi.get();
-        StageTimer t(c, ST_BMED);
-        if (ln[CLS_M256])
-            hipLaunchKernelGGL((k_bucket_medium<256, C::WS, HiT>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb,
-                               list_n.get() + CLS_M256, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
-        if (ln[CLS_M512])
-            hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb,
-                               list_n.get() + CLS_M512, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
-        if constexpr (!C::WS) if (ln[CLS_M1024])
-            hipLaunchKernelGGL((k_bucket_medium<1024, C::WS, HiT>), dim3(ln[CLS_M1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)CLS_M1024 * nb,
-                               list_n.get() + CLS_M1024, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
-        if (ln[CLS_HUGE]) {
-            const u32 nh = ln[CLS_HUGE];
-            std::vector<BDesc> hl = d2h_vec<BDesc>(c, lists.get() + (size_t)CLS_HUGE * nb, nh);
-            std::vector<u64> so(nh);
-            u64 tot = 0;
-            for (u32 i = 0; i < nh; ++i) { so[i] = tot; tot += hl[i].c & ~BDESC_TRIE; }
-            Buf<u64> d_so(c->pool, nh), s_alo(c->pool, tot), s_blo(c->pool, tot), s_ahi(c->pool, C::WS ? tot : 1), s_bhi(c->pool, C::WS ? tot : 1);
-            Buf<u32> s_aidx(c->pool, tot), s_bidx(c->pool, tot);
-            h2d(c, d_so.get(), so.data(), nh);
-            hipLaunchKernelGGL((k_bucket_huge<C::WS, HiT>), dim3(nh), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE,
-                               d_so.get(), a_lo, a_hi, P.SB, s_alo.get(), s_ahi.get(), s_aidx.get(), s_blo.get(), s_bhi.get(), s_bidx.get(), nr.cnt.get(),
-                               nr.kind.get(), ma);
-            CBLX_HIP(hipStreamSynchronize(c->stream));
-        }
-        CBLX_HIP(hipGetLastError());
-        CBLX_HIP(hipStreamSynchronize(c->stream));
-    } else {
+    {
     // -- KRN-3: per-bucket dedup / sort, by size class
     const u64 nb = nr.nb;
     Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
@@ -592,6 +546,98 @@ void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nse
         c->kmers_inserted += pl.n_kmers;
     });
     collect_events(c);
+}
+
+// ---- `self |= other`, both resident on this device (src/cbl.rs:433-449 -> src/wordset/set_ops.rs:123-157) ---------
+template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
+    typedef typename C::HiT HiT;
+    constexpr bool WS = C::WS;
+    const Consts& P = c->P;
+    const Resident& s = c->res;
+    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    Resident nr;
+    Buf<u32> raw, m_cs;
+    Buf<u64> m_sstart, m_ostart;
+    Buf<u8> m_skind, m_okind;
+    u64 N = 0;
+    {
+        StageTimer t(c, ST_DIR);
+        Buf<u32> popc(c->pool, nwords);
+        nr.bv = Buf<u64>(c->pool, nwords);
+        nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
+        hipLaunchKernelGGL(k_bv_or, grid1(nwords, 256), dim3(256), 0, c->stream, nwords, s.bv.get(), o.bv.get(), nr.bv.get(), popc.get());
+        nr.nb = exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get());
+        const u64 nb = nr.nb;
+        nr.prefix = Buf<u32>(c->pool, nb + 1);
+        nr.start = Buf<u64>(c->pool, nb + 1);
+        nr.cnt = Buf<u32>(c->pool, nb + 1);
+        nr.kind = Buf<u8>(c->pool, nb + 1);
+        raw = Buf<u32>(c->pool, nb + 1);
+        m_cs = Buf<u32>(c->pool, nb + 1);
+        m_sstart = Buf<u64>(c->pool, nb + 1);
+        m_ostart = Buf<u64>(c->pool, nb + 1);
+        m_skind = Buf<u8>(c->pool, nb + 1);
+        m_okind = Buf<u8>(c->pool, nb + 1);
+        hipLaunchKernelGGL(k_merge_table, grid1(nprefix, 256), dim3(256), 0, c->stream, nprefix, nr.bv.get(), nr.rank_dir.get(), s.view(), o.view(), nr.prefix.get(),
+                           raw.get(), m_cs.get(), m_sstart.get(), m_ostart.get(), m_skind.get(), m_okind.get());
+        N = exclusive_scan<u64>(c, raw.get(), nb, nr.start.get());
+        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, nr.start.get() + nb, N);
+        CBLX_HIP(hipGetLastError());
+    }
+    if (N != s.count + o.count) throw Error(CBLX_EDEVICE, "merge: run lengths do not match the two indexes (internal error)");
+    const u64 nb = nr.nb;
+    nr.a_lo = Buf<u64>(c->pool, N + 2);
+    if (WS) nr.a_hi = Buf<u64>(c->pool, N + 2);
+    {
+        StageTimer t(c, ST_EXPAND);
+        hipLaunchKernelGGL((k_merge_gather<WS>), dim3((unsigned)ceil_div(nb, 4)), dim3(256), 0, c->stream, nb, nr.start.get(), m_cs.get(), m_sstart.get(), m_ostart.get(),
+                           s.a_lo.get(), s.a_hi.get(), o.a_lo.get(), o.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
+    }
+    Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
+    Buf<u32> list_n(c->pool, CLS_N);
+    CBLX_HIP(hipMemsetAsync(list_n.get(), 0, CLS_N * 4, c->stream));
+    hipLaunchKernelGGL(k_classify_merge, grid1(nb, 256), dim3(256), 0, c->stream, nb, WS ? 512u : 1024u, nr.start.get(), m_cs.get(), m_skind.get(), m_okind.get(),
+                       nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get());
+    CBLX_HIP(hipGetLastError());
+    std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
+    const MergeArgs ma{m_cs.get(), m_ostart.get(), m_okind.get(), o.a_lo.get(), o.a_hi.get()};
+    u64* a_lo = nr.a_lo.get();
+    HiT* a_hi = WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr;
+    {
+        StageTimer t(c, ST_BMED);
+        if (ln[CLS_M256])
+            hipLaunchKernelGGL((k_bucket_medium<256, WS, HiT>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb, list_n.get() + CLS_M256,
+                               a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
+        if (ln[CLS_M512])
+            hipLaunchKernelGGL((k_bucket_medium<512, WS, HiT>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb, list_n.get() + CLS_M512,
+                               a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
+        if constexpr (!WS) if (ln[CLS_M1024])
+            hipLaunchKernelGGL((k_bucket_medium<1024, WS, HiT>), dim3(ln[CLS_M1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)CLS_M1024 * nb,
+                               list_n.get() + CLS_M1024, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
+        CBLX_HIP(hipGetLastError());
+    }
+    if (ln[CLS_HUGE]) {
+        StageTimer t(c, ST_BHUGE);
+        const u32 nh = ln[CLS_HUGE];
+        std::vector<BDesc> hl = d2h_vec<BDesc>(c, lists.get() + (size_t)CLS_HUGE * nb, nh);
+        std::vector<u64> so(nh);
+        u64 tot = 0;
+        for (u32 i = 0; i < nh; ++i) { so[i] = tot; tot += hl[i].c & ~BDESC_TRIE; }
+        Buf<u64> d_so(c->pool, nh), s_alo(c->pool, tot), s_blo(c->pool, tot), s_ahi(c->pool, WS ? tot : 1), s_bhi(c->pool, WS ? tot : 1);
+        Buf<u32> s_aidx(c->pool, tot), s_bidx(c->pool, tot);
+        h2d(c, d_so.get(), so.data(), nh);
+        hipLaunchKernelGGL((k_bucket_huge<WS, HiT>), dim3(nh), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE, d_so.get(), a_lo, a_hi,
+                           P.SB, s_alo.get(), s_ahi.get(), s_aidx.get(), s_blo.get(), s_bhi.get(), s_bidx.get(), nr.cnt.get(), nr.kind.get(), ma);
+        CBLX_HIP(hipGetLastError());
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+    }
+    {
+        Buf<u64> total(c->pool, 1);
+        CBLX_HIP(hipMemsetAsync(total.get(), 0, 8, c->stream));
+        hipLaunchKernelGGL(k_sum_u32, grid1(nb, 256), dim3(256), 0, c->stream, nr.cnt.get(), nb, total.get());
+        nr.count = d2h<u64>(c, total.get());
+    }
+    c->res = std::move(nr);
 }
 
 // ---- ingest: host sequences -> pending buffers in HBM -----------------------------------------------------------
@@ -1464,14 +1510,7 @@ int cblx_merge_assign(cblx_ctx* self, cblx_ctx* other) {
         bool on_device = false;
         if (self->device == other->device && self->res.count != 0 && self->res.count + other->res.count < 0xFFFFFFF0ull) {
             CBLX_HIP(hipStreamSynchronize(other->stream));
-            dispatch(self->P, [&](auto cfg) {
-                typedef decltype(cfg) C;
-                Records rec;
-                const u64 ns = begin_records<C>(self, rec, other->res.count);  // self's words in front ...
-                expand_into<C>(self, other->res, rec, ns);                      // ... then other's
-                const MergeCtx mg{&other->res};
-                pipeline<C>(self, rec, ns + other->res.count, Buf<u32>(), &mg);
-            });
+            dispatch(self->P, [&](auto cfg) { merge_direct<decltype(cfg)>(self, other->res); });
             on_device = true;
             collect_events(self);
         }

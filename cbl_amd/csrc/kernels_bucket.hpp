@@ -177,37 +177,79 @@ __global__ void k_classify(u64 nb, u32 med_max_threads, const u32* __restrict__ 
 //   both, self is a Vec  -> sorted(self) ++ sorted(other \ self), stays a Vec whatever its size (no threshold check);
 //   both, self is a Trie -> sorted union, Trie.
 // Side effect of the reference kept: other's Vec buckets that also exist in self end up sorted (iter_sorted sorts in place).
-struct MergeArgs {
-    const u32* cs;       // per new rank: size of the self part (null: plain insert)
-    const u64* ostart;   // per new rank: first arena slot of other's bucket
-    const u8* okind;     // per new rank: kind of other's bucket
-    u64* o_lo;           // other's arena (written back sorted)
-    u64* o_hi;
-};
-__global__ void k_classify_merge(u64 nb, u32 med_max_threads, const u32* __restrict__ bucket_prefix, const u64* __restrict__ raw_start,
-                                 DirView self, DirView other, u32* __restrict__ m_cs, u64* __restrict__ m_ostart,
-                                 u8* __restrict__ m_okind, u32* __restrict__ out_count, u8* __restrict__ out_kind,
-                                 BDesc* __restrict__ lists, u32* __restrict__ list_n, u32* __restrict__ bad) {
-    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nb) return;
-    const u64 c = raw_start[r + 1] - raw_start[r];
-    const u32 p = bucket_prefix[r];
+// ---- `self |= other` without re-partitioning: both indexes are already grouped by prefix ----------------------------
+// (src/wordset/set_ops.rs:123-157 walks the union of the two prefix bitvectors; here: OR of the bitvector words, rank
+// by popcount scan, one merged run of cs + co slots per prefix, then the per-bucket |= rules of src/trievec/set_ops.rs)
+struct MergeArgs { const u32* cs; const u64* ostart; const u8* okind; u64* o_lo; u64* o_hi; };
+
+__global__ void k_bv_or(u64 nwords, const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ out, u32* __restrict__ popc) {
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    const u64 v = a[w] | b[w];
+    out[w] = v;
+    popc[w] = (u32)__builtin_popcountll(v);
+}
+// one thread per prefix slot of the merged bitvector: both sides' (count, kind, arena start) and the merged run length
+__global__ void k_merge_table(u64 nprefix, const u64* __restrict__ bv, const u64* __restrict__ rank_dir, DirView self, DirView other,
+                              u32* __restrict__ bucket_prefix, u32* __restrict__ raw_cnt, u32* __restrict__ m_cs, u64* __restrict__ m_sstart,
+                              u64* __restrict__ m_ostart, u8* __restrict__ m_skind, u8* __restrict__ m_okind) {
+    const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nprefix) return;
+    const u64 w = bv[p >> 6];
+    if (!((w >> (p & 63)) & 1ull)) return;
+    const u64 r = rank_dir[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
     u32 cs = 0, co = 0;
     u8 ks = KIND_VEC, ko = KIND_VEC;
-    u64 rank, os = 0;
-    if (dir_lookup(self, p, rank)) { cs = self.count[rank]; ks = self.kind[rank]; }
-    if (dir_lookup(other, p, rank)) { co = other.count[rank]; ko = other.kind[rank]; os = other.start[rank]; }
-    if ((u64)cs + co != c) atomicAdd(bad, 1u);
+    u64 rank, ss = 0, os = 0;
+    if (dir_lookup(self, (u32)p, rank)) { cs = self.count[rank]; ks = self.kind[rank]; ss = self.start[rank]; }
+    if (dir_lookup(other, (u32)p, rank)) { co = other.count[rank]; ko = other.kind[rank]; os = other.start[rank]; }
+    bucket_prefix[r] = (u32)p;
+    raw_cnt[r] = cs + co;
     m_cs[r] = cs;
+    m_sstart[r] = ss;
     m_ostart[r] = os;
+    m_skind[r] = ks;
     m_okind[r] = ko;
-    if (co == 0) { out_count[r] = cs; out_kind[r] = ks; return; }
-    if (cs == 0) { out_count[r] = co; out_kind[r] = ko; return; }
-    int cls;
-    if (c <= 256 * MED_ITEMS) cls = CLS_M256;
-    else if (c <= 512 * MED_ITEMS) cls = CLS_M512;
-    else if (c <= 1024 * MED_ITEMS && med_max_threads >= 1024) cls = CLS_M1024;
-    else cls = CLS_HUGE;
+}
+// one wave per merged bucket: self's stored suffixes then other's, copied into the merged run
+template <bool WS>
+__global__ __launch_bounds__(256) void k_merge_gather(u64 nb, const u64* __restrict__ start, const u32* __restrict__ m_cs, const u64* __restrict__ m_sstart,
+                                                      const u64* __restrict__ m_ostart, const u64* __restrict__ s_lo, const u64* __restrict__ s_hi,
+                                                      const u64* __restrict__ o_lo, const u64* __restrict__ o_hi, u64* __restrict__ out_lo,
+                                                      u64* __restrict__ out_hi) {
+    const u64 r = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nb) return;
+    const u32 lane = threadIdx.x & 63;
+    const u64 d0 = start[r];
+    const u32 c = (u32)(start[r + 1] - d0), cs = m_cs[r];
+    const u64 ss = m_sstart[r], os = m_ostart[r];
+    for (u32 j = lane; j < c; j += 64) {
+        const bool from_self = j < cs;
+        const u64 src = from_self ? ss + j : os + (j - cs);
+        out_lo[d0 + j] = from_self ? s_lo[src] : o_lo[src];
+        if constexpr (WS) out_hi[d0 + j] = from_self ? s_hi[src] : o_hi[src];
+    }
+}
+// one-sided buckets are final after the gather (self-only: untouched; other-only: cloned as stored); both-sided ones
+// go to the merge epilogue of the bucket kernel of their length class
+__global__ void k_classify_merge(u64 nb, u32 med_max_threads, const u64* __restrict__ raw_start, const u32* __restrict__ m_cs,
+                                 const u8* __restrict__ m_skind, const u8* __restrict__ m_okind, u32* __restrict__ out_count,
+                                 u8* __restrict__ out_kind, BDesc* __restrict__ lists, u32* __restrict__ list_n) {
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1;
+    u64 c = 0;
+    u8 ks = KIND_VEC;
+    if (r < nb) {
+        c = raw_start[r + 1] - raw_start[r];
+        const u32 cs = m_cs[r], co = (u32)c - cs;
+        ks = m_skind[r];
+        if (co == 0) { out_count[r] = cs; out_kind[r] = ks; }
+        else if (cs == 0) { out_count[r] = co; out_kind[r] = m_okind[r]; }
+        else if (c <= 256 * MED_ITEMS) cls = CLS_M256;
+        else if (c <= 512 * MED_ITEMS) cls = CLS_M512;
+        else if (c <= 1024 * MED_ITEMS && med_max_threads >= 1024) cls = CLS_M1024;
+        else cls = CLS_HUGE;
+    }
 #pragma unroll
     for (int k = 0; k < CLS_N; ++k) {
         const u64 bal = __ballot(cls == k);
