@@ -14,6 +14,7 @@
 #include <memory>
 #include <thread>
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <unistd.h>
 
@@ -115,6 +116,7 @@ struct Ingest {
     Buf<u8> d_bases;   // capacity >= nbytes + 64
     Buf<u64> d_off;    // capacity >= nseq + 1; d_off[0] = 0
     u64 nbytes = 0, nseq = 0;
+    u64 last_end = 0;  // nbytes at the end of the last complete sequence
     Writer wb, wo;
     hipStream_t s = nullptr;
     std::unique_ptr<Xfer> xfer;
@@ -702,15 +704,36 @@ void ingest_reserve(cblx_ctx* c, u64 add_bytes, u64 add_seqs) {
 }
 void flush(cblx_ctx* c);
 // one sequence (the cblx_insert_seq / FASTA-record granularity)
-void ingest_seq(cblx_ctx* c, const u8* seq, u64 len) {
+// a piece of the sequence being enqueued (a FASTA record arrives line by line), then its end
+void ingest_bases(cblx_ctx* c, const u8* p, u64 len) {
     Ingest& g = c->ing;
     ingest_reserve(c, len, 1);
-    writer_put(c, g.wb, Ingest::BASES_BLK, g.d_bases.get(), seq, len);
+    writer_put(c, g.wb, Ingest::BASES_BLK, g.d_bases.get(), p, len);
     g.nbytes += len;
+}
+void ingest_abort_seq(cblx_ctx* c) {  // drop the bases of an unfinished sequence
+    Ingest& g = c->ing;
+    const u64 begin = g.nseq ? g.last_end : 0;
+    g.nbytes = begin;
+    if (begin >= g.wb.issued) g.wb.fill = (size_t)(begin - g.wb.issued);
+    else { g.wb.issued = begin; g.wb.fill = 0; }
+}
+void ingest_end_seq(cblx_ctx* c, u64 flush_at = 2ull << 30) {
+    Ingest& g = c->ing;
+    const u64 begin = g.nseq ? g.last_end : 0, len = g.nbytes - begin;
+    if (len < c->P.K) {  // src/cbl.rs:329-334; the record is dropped from the queue
+        ingest_abort_seq(c);
+        throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(len) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
+    }
     const u64 end = g.nbytes;
     writer_put(c, g.wo, Ingest::OFF_BLK, (u8*)(g.d_off.get() + 1), (const u8*)&end, 8);
     g.nseq += 1;
-    if (g.nbytes >= (2ull << 30)) flush(c);  // bound the queue (same result: batches are inserted in order)
+    g.last_end = end;
+    if (g.nbytes >= flush_at) flush(c);  // bound the queue (same result: batches are inserted in order)
+}
+void ingest_seq(cblx_ctx* c, const u8* seq, u64 len) {
+    ingest_bases(c, seq, len);
+    ingest_end_seq(c);
 }
 // n sequences at once (offsets already validated)
 void ingest_seqs(cblx_ctx* c, const u8* bases, const u64* offsets, u64 n) {
@@ -734,6 +757,7 @@ void ingest_seqs(cblx_ctx* c, const u8* bases, const u64* offsets, u64 n) {
     });
     g.nbytes += len;
     g.nseq += n;
+    g.last_end = g.nbytes;
     g.wb.issued = g.nbytes;
     g.wo.issued = g.nseq * 8;
     if (g.nbytes >= (2ull << 30)) flush(c);
@@ -742,7 +766,7 @@ void ingest_drop(cblx_ctx* c) {  // forget everything enqueued (clear / load)
     Ingest& g = c->ing;
     ingest_wait(c);
     for (Ingest::Writer* w : {&g.wb, &g.wo}) { w->fill = 0; w->issued = 0; w->busy[0] = w->busy[1] = false; }
-    g.nbytes = g.nseq = 0;
+    g.nbytes = g.nseq = g.last_end = 0;
 }
 void ingest_destroy(cblx_ctx* c) {
     Ingest& g = c->ing;
@@ -770,7 +794,7 @@ void flush(cblx_ctx* c) {
     ingest_wait(c);
     // the pending queue is consumed even if the insert fails (the reference would have panicked)
     for (Ingest::Writer* w : {&g.wb, &g.wo}) { w->issued = 0; w->busy[0] = w->busy[1] = false; }
-    g.nbytes = g.nseq = 0;
+    g.nbytes = g.nseq = g.last_end = 0;
     insert_device(c, g.d_bases.get(), g.d_off.get(), nseq);
     CBLX_HIP(hipStreamSynchronize(c->stream));
 }
@@ -1218,47 +1242,123 @@ int cblx_insert_seqs_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t*
 int cblx_flush(cblx_ctx* c) { return guard(c, [&] { flush(c); }); }
 
 // The `read_fasta` + `while let Some(record) = reader.next() { cbl.insert_seq(&seqrec.seq()) }` loop of
-// examples/cbl.rs:112-115,154-163 (needletail stand-in): plain-text FASTA (multi-line, CRLF tolerated) or 4-line FASTQ.
-// Every record's sequence goes through insert_seq; batches are flushed to the GPU every ~1 GiB of bases.
+// examples/cbl.rs:112-115,154-163 (needletail stand-in): FASTA (multi-line, CRLF tolerated) or 4-line FASTQ, plain or
+// gzip (zlib is looked up at run time; without it a .gz input is an error). The file is read in 16 MiB blocks and
+// scanned line by line with memchr; every line of bases goes straight into the pinned ingest blocks, so parsing,
+// PCIe and the GPU insert of the previous batch (every ~1 GiB of bases) overlap.
+struct ByteSource {
+    int fd = -1;
+    void* gz = nullptr;
+    void* zlib = nullptr;
+    int (*gzread_)(void*, void*, unsigned) = nullptr;
+    int (*gzclose_)(void*) = nullptr;
+    ~ByteSource() {
+        if (gz && gzclose_) gzclose_(gz);
+        if (fd >= 0) ::close(fd);
+        if (zlib) dlclose(zlib);
+    }
+    void open(const char* path) {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) throw Error(CBLX_EINVAL, std::string("Failed to open ") + path);
+        u8 magic[2] = {0, 0};
+        const ssize_t got = ::pread(fd, magic, 2, 0);
+        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            zlib = dlopen("libz.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!zlib) throw Error(CBLX_EFORMAT, std::string(path) + " is gzip-compressed and zlib (libz.so.1) is not available");
+            auto gzdopen_ = (void* (*)(int, const char*))dlsym(zlib, "gzdopen");
+            auto gzbuffer_ = (int (*)(void*, unsigned))dlsym(zlib, "gzbuffer");
+            gzread_ = (int (*)(void*, void*, unsigned))dlsym(zlib, "gzread");
+            gzclose_ = (int (*)(void*))dlsym(zlib, "gzclose");
+            if (!gzdopen_ || !gzread_ || !gzclose_) throw Error(CBLX_EFORMAT, "zlib: missing gz* symbols");
+            gz = gzdopen_(fd, "rb");
+            if (!gz) throw Error(CBLX_EINVAL, std::string("Failed to open ") + path);
+            fd = -1;  // owned by the gz handle now
+            if (gzbuffer_) gzbuffer_(gz, 1u << 20);
+        }
+    }
+    size_t read(u8* dst, size_t cap) {
+        if (gz) {
+            const int r = gzread_(gz, dst, (unsigned)std::min<size_t>(cap, 1u << 30));
+            if (r < 0) throw Error(CBLX_EFORMAT, "gzip: read error");
+            return (size_t)r;
+        }
+        const ssize_t r = ::read(fd, dst, cap);
+        if (r < 0) throw Error(CBLX_EINVAL, "read error");
+        return (size_t)r;
+    }
+};
+struct LineReader {
+    ByteSource& src;
+    std::vector<u8> buf;
+    size_t beg = 0, end = 0;
+    bool eof = false;
+    explicit LineReader(ByteSource& s) : src(s), buf(16u << 20) {}
+    // next line without its terminator ('\n' or '\r\n'); false at the end of the input
+    bool next(const u8*& p, size_t& n) {
+        for (;;) {
+            if (beg < end) {
+                const u8* nl = (const u8*)std::memchr(buf.data() + beg, '\n', end - beg);
+                if (nl || eof) {
+                    const size_t stop = nl ? (size_t)(nl - buf.data()) : end;
+                    p = buf.data() + beg;
+                    n = stop - beg;
+                    beg = nl ? stop + 1 : end;
+                    if (n && p[n - 1] == '\r') --n;
+                    return true;
+                }
+            } else if (eof) {
+                return false;
+            }
+            // no complete line buffered: keep the partial one at the front and read more
+            if (beg) { std::memmove(buf.data(), buf.data() + beg, end - beg); end -= beg; beg = 0; }
+            if (end == buf.size()) buf.resize(buf.size() * 2);
+            const size_t got = src.read(buf.data() + end, buf.size() - end);
+            if (got == 0) eof = true;
+            end += got;
+        }
+    }
+};
 int cblx_insert_fastx_file(cblx_ctx* c, const char* path, uint64_t* n_records) {
     return guard(c, [&] {
         if (n_records) *n_records = 0;
-        std::ifstream f(path, std::ios::binary);
-        if (!f) throw Error(CBLX_EINVAL, std::string("Failed to open ") + path);
-        std::string line, seq;
+        if (!path) throw Error(CBLX_EINVAL, "null argument");
+        ByteSource src;
+        src.open(path);
+        LineReader lr(src);
         u64 nrec = 0;
-        int mode = 0;  // 0 unknown, 1 FASTA, 2 FASTQ
-        auto strip = [](std::string& l) { while (!l.empty() && (l.back() == '\r' || l.back() == '\n')) l.pop_back(); };
-        auto emit = [&]() {
-            if (seq.size() < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(seq.size()) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
-            ingest_seq(c, (const u8*)seq.data(), seq.size());
-            ++nrec;
-            seq.clear();
-            if (c->ing.nbytes >= (1ull << 30)) flush(c);
-        };
-        bool have = false;
-        while (std::getline(f, line)) {
-            strip(line);
-            if (mode == 0) {
-                if (line.empty()) continue;
-                if (line[0] == '>') mode = 1;
-                else if (line[0] == '@') mode = 2;
-                else throw Error(CBLX_EFORMAT, "not a FASTA/FASTQ file (first record does not start with '>' or '@')");
+        const u8* p;
+        size_t n;
+        // skip leading blank lines, then the first byte decides the format
+        bool have_line = false;
+        while ((have_line = lr.next(p, n)) && n == 0) {}
+        if (!have_line) return;
+        if (p[0] != '>' && p[0] != '@') throw Error(CBLX_EFORMAT, "not a FASTA/FASTQ file (first record does not start with '>' or '@')");
+        const u64 flush_at = 1ull << 30;
+        try {
+        if (p[0] == '>') {
+            bool open_rec = true;  // the header line has been consumed
+            while (lr.next(p, n)) {
+                if (n && p[0] == '>') { ingest_end_seq(c, flush_at); ++nrec; continue; }
+                if (n) ingest_bases(c, p, n);
             }
-            if (mode == 1) {
-                if (!line.empty() && line[0] == '>') { if (have) emit(); have = true; }
-                else seq += line;
-            } else {
-                if (line.empty()) continue;
-                if (line[0] != '@') throw Error(CBLX_EFORMAT, "FASTQ: expected '@' header");
-                std::string plus, qual;
-                if (!std::getline(f, seq) || !std::getline(f, plus) || !std::getline(f, qual)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
-                strip(seq); strip(plus);
-                if (plus.empty() || plus[0] != '+') throw Error(CBLX_EFORMAT, "FASTQ: expected '+' separator");
-                emit();
+            if (open_rec) { ingest_end_seq(c, flush_at); ++nrec; }
+        } else {
+            for (;;) {
+                if (n == 0) { if (!lr.next(p, n)) break; continue; }  // blank line between records
+                if (p[0] != '@') throw Error(CBLX_EFORMAT, "FASTQ: expected '@' header");
+                const u8 *sq, *pl, *ql;
+                size_t ns, npl, nq;
+                if (!lr.next(sq, ns)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
+                if (ns) ingest_bases(c, sq, ns);  // the buffer may move on the next call: consume the line first
+                if (!lr.next(pl, npl)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
+                if (npl == 0 || pl[0] != '+') throw Error(CBLX_EFORMAT, "FASTQ: expected '+' separator");
+                if (!lr.next(ql, nq)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
+                ingest_end_seq(c, flush_at);
+                ++nrec;
+                if (!lr.next(p, n)) break;
             }
         }
-        if (mode == 1 && have) emit();
+        } catch (...) { ingest_abort_seq(c); if (n_records) *n_records = nrec; throw; }
         if (n_records) *n_records = nrec;
     });
 }

@@ -69,7 +69,7 @@ int cblx_insert_seqs(cblx_ctx* ctx, const uint8_t* bases, const uint64_t* offset
  * offsets[a..b] of a larger batch addresses the same d_bases. Runs the insert before returning. */
 int cblx_insert_seqs_device(cblx_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n);
 /* The reader loop of examples/cbl.rs:154-163 (needletail stand-in): every record of a plain-text FASTA (multi-line ok)
- * or 4-line FASTQ file goes through insert_seq, in file order. gz is not handled. */
+ * or 4-line FASTQ file, plain or gzip (zlib is looked up at run time), goes through insert_seq, in file order. */
 int cblx_insert_fastx_file(cblx_ctx* ctx, const char* path, uint64_t* n_records);
 /* Materialise everything enqueued so far into the resident index (idempotent). */
 int cblx_flush(cblx_ctx* ctx);

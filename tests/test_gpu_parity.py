@@ -522,3 +522,68 @@ def test_device_serializer_equals_host_serializer(monkeypatch, tmp_path):
         g2.load(dev)
         assert g2.checksum() == g.checksum() and g2.count() == g.count()
     assert kinds == {0, 1}
+
+
+def test_fastx_reader_variants(tmp_path):
+    """needletail stand-in (examples/cbl.rs:112-115): what bytes reach insert_seq for FASTA / FASTQ, plain / gzip, LF / CRLF,
+    wrapped lines, blank lines, a missing final newline, a sequence longer than the read block; and its errors."""
+    _need_gpu()
+    import gzip
+
+    k, pb = 31, 24
+    rng = random.Random(77)
+    seqs = [_rand_seq(rng, n) for n in (150, 31, 400, 1000, 33)]
+    o = Oracle(k, pb)
+    for s_ in seqs:
+        o.insert_seq(s_)
+    want = o.serialize()
+
+    def wrap(s_, w, eol):
+        return eol.join(s_[i : i + w] for i in range(0, len(s_), w)) + eol
+
+    files = {
+        "one_line.fa": b"".join(b">r%d\n" % i + s_ + b"\n" for i, s_ in enumerate(seqs)),
+        "wrapped_crlf.fa": b"".join(b">r%d some text\r\n" % i + wrap(s_, 60, b"\r\n") for i, s_ in enumerate(seqs)),
+        "no_final_newline.fa": b"\n\n" + b"".join(b">r%d\n" % i + wrap(s_, 70, b"\n") for i, s_ in enumerate(seqs))[:-1],
+        "blank_lines.fa": b"".join(b">r%d\n" % i + s_[:20] + b"\n\n" + s_[20:] + b"\n\n" for i, s_ in enumerate(seqs)),
+        "reads.fq": b"".join(b"@r%d\n" % i + s_ + b"\n+\n" + b"I" * len(s_) + b"\n" for i, s_ in enumerate(seqs)),
+        "reads_crlf.fq": b"".join(b"@r%d\r\n" % i + s_ + b"\r\n+r%d\r\n" % i + b"@" * len(s_) + b"\r\n" for i, s_ in enumerate(seqs)),
+    }
+    files["one_line.fa.gz"] = gzip.compress(files["one_line.fa"])
+    files["reads.fq.gz"] = gzip.compress(files["reads.fq"])
+    for name, data in files.items():
+        f = tmp_path / name
+        f.write_bytes(data)
+        g = cbl_amd.CBL(k, pb)
+        assert g.insert_fastx_file(str(f)) == len(seqs), name
+        assert g.serialize() == want, name
+    # one sequence much longer than the 16 MiB read block, on a single line and wrapped
+    big = _rand_seq(rng, 5_000_000) * 4
+    ob = Oracle(k, pb)
+    ob.insert_seq(big)
+    for name, data in (("big1.fa", b">chr\n" + big + b"\n"), ("bigw.fa.gz", gzip.compress(b">chr\n" + wrap(big, 80, b"\n"), 1))):
+        f = tmp_path / name
+        f.write_bytes(data)
+        g = cbl_amd.CBL(k, pb)
+        assert g.insert_fastx_file(str(f)) == 1
+        assert g.count() == ob.count() and g.serialize() == ob.serialize(), name
+    # errors: a record shorter than K (src/cbl.rs:329-334) keeps the earlier records; truncated FASTQ; not FASTA/FASTQ
+    bad = tmp_path / "short.fa"
+    bad.write_bytes(b">a\n" + seqs[0] + b"\n>b\nACGT\n>c\n" + seqs[2] + b"\n")
+    g = cbl_amd.CBL(k, pb)
+    with pytest.raises(cbl_amd.CblxError, match="smaller than K"):
+        g.insert_fastx_file(str(bad))
+    o1 = Oracle(k, pb)
+    o1.insert_seq(seqs[0])
+    assert g.serialize() == o1.serialize()
+    for name, data, msg in (("trunc.fq", b"@r\n" + seqs[0] + b"\n+\n", "truncated"), ("noplus.fq", b"@r\n" + seqs[0] + b"\nX\nIII\n", "separator"),
+                            ("text.txt", b"hello\n", "not a FASTA")):
+        f = tmp_path / name
+        f.write_bytes(data)
+        g = cbl_amd.CBL(k, pb)
+        with pytest.raises(cbl_amd.CblxError, match=msg):
+            g.insert_fastx_file(str(f))
+        assert g.count() == 0
+    (tmp_path / "empty.fa").write_bytes(b"")
+    g = cbl_amd.CBL(k, pb)
+    assert g.insert_fastx_file(str(tmp_path / "empty.fa")) == 0 and g.count() == 0

@@ -65,6 +65,27 @@ def main():
     dt = timed(lambda: (g.insert_seqs(h_bases, h_offsets), g.flush()), pre=g.clear)
     out["build_host_buffers"] = {"ms": dt * 1e3, "kmers_per_s": NR * per_read / dt, "note": "pageable numpy buffers -> cblx_insert_seqs + flush"}
 
+    # 2b. FASTA file -> index (examples/cbl.rs build): single-line FASTA on tmpfs, parse + PCIe + insert
+    fa = "/dev/shm/cblx_extras.fa"
+    with open(fa, "wb") as f:
+        step = 1_000_000
+        for a0 in range(0, NR, step):
+            n = min(step, NR - a0)
+            rec = np.empty((n, 11 + L + 1), dtype=np.uint8)  # ">r%08d\n" + bases + "\n"
+            rec[:, 0], rec[:, 1], rec[:, 10], rec[:, -1] = ord(">"), ord("r"), 10, 10
+            ids = np.arange(a0, a0 + n)
+            for d in range(8):
+                rec[:, 9 - d] = 48 + (ids // 10**d) % 10
+            rec[:, 11 : 11 + L] = h_bases[a0 * L : (a0 + n) * L].reshape(n, L)
+            f.write(rec.tobytes())
+    fsize = os.path.getsize(fa)
+    def _file():
+        assert g.insert_fastx_file(fa) == NR
+        g.flush()
+    dt = timed(_file, reps=2, pre=g.clear)
+    os.remove(fa)
+    out["build_from_fasta_file"] = {"ms": dt * 1e3, "kmers_per_s": NR * per_read / dt, "file_bytes": fsize, "file_GB_per_s": fsize / dt / 1e9}
+
     # 3. serialization of the resident index (host, multi-threaded) -- Appendix A bytes
     if not a.skip_serialize:
         t0 = time.perf_counter()
