@@ -16,6 +16,8 @@
 
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "kernels_bucket.hpp"
@@ -1094,6 +1096,200 @@ void parse_index(const Consts& P, const u8* data, u64 len, HostIndex& h, bool& c
     if (s.p != s.end) throw Error(CBLX_EFORMAT, "index: trailing bytes");  // reject_trailing_bytes
 }
 
+// ---- index bytes -> resident index, streamed (cblx_load): one pass over the bytes, elements go to HBM as they are
+// decoded. The format is a sequential pre-order walk (no lengths to skip by), so the walk itself stays on one host
+// thread; everything around it (pinned double buffering, DMA, directory upload) overlaps with it.
+struct StreamUp {  // single producer -> device array of u64
+    static constexpr size_t CAP = 1u << 20;  // elements per pinned block
+    cblx_ctx* c;
+    hipStream_t s = nullptr;
+    u64* blk[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int cur = 0;
+    size_t fill = 0;
+    u64 issued = 0;
+    Buf<u64> dev;
+    StreamUp(cblx_ctx* ctx, u64 guess) : c(ctx) {
+        CBLX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            CBLX_HIP(hipHostMalloc((void**)&blk[k], CAP * 8, hipHostMallocDefault));
+            CBLX_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        }
+        dev = Buf<u64>(c->pool, guess + 2);
+    }
+    StreamUp(const StreamUp&) = delete;
+    ~StreamUp() {
+        if (s) (void)hipStreamSynchronize(s);
+        for (int k = 0; k < 2; ++k) { if (ev[k]) (void)hipEventDestroy(ev[k]); if (blk[k]) (void)hipHostFree(blk[k]); }
+        if (s) (void)hipStreamDestroy(s);
+    }
+    inline u64* room(size_t need) { if (fill + need > CAP) issue(); return blk[cur] + fill; }  // need <= CAP
+    inline void commit(size_t k) { fill += k; }
+    void issue() {
+        if (fill == 0) return;
+        if (dev.n < issued + fill + 2) {
+            Buf<u64> nd(c->pool, std::max<u64>(2 * (u64)dev.n, issued + fill + 2));
+            CBLX_HIP(hipStreamSynchronize(s));
+            if (issued) CBLX_HIP(hipMemcpyAsync(nd.get(), dev.get(), issued * 8, hipMemcpyDeviceToDevice, s));
+            CBLX_HIP(hipStreamSynchronize(s));
+            dev = std::move(nd);
+        }
+        CBLX_HIP(hipMemcpyAsync(dev.get() + issued, blk[cur], fill * 8, hipMemcpyHostToDevice, s));
+        CBLX_HIP(hipEventRecord(ev[cur], s));
+        busy[cur] = true;
+        issued += fill;
+        fill = 0;
+        cur ^= 1;
+        if (busy[cur]) { CBLX_HIP(hipEventSynchronize(ev[cur])); busy[cur] = false; }
+    }
+    Buf<u64> finish() { issue(); CBLX_HIP(hipStreamSynchronize(s)); return std::move(dev); }
+};
+inline u64 load_le64(const u8* p) { u64 v; std::memcpy(&v, p, 8); return v; }
+
+// directory of a loaded / host-merged index: bitvector + rank directory + per-rank tables, arena supplied by the caller
+void install_index(cblx_ctx* c, const std::vector<u32>& prefix, const std::vector<u32>& cnt, const std::vector<u8>& kind, Buf<u64>&& a_lo, Buf<u64>&& a_hi) {
+    const Consts& P = c->P;
+    Resident nr;
+    nr.nb = prefix.size();
+    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    std::vector<u64> bv(nwords, 0), rd(nwords + 1, 0), start(nr.nb + 1, 0);
+    for (u64 i = 0; i < nr.nb; ++i) {
+        if (prefix[i] >= nprefix) throw Error(CBLX_EFORMAT, "prefix out of range for PREFIX_BITS");
+        if (i && prefix[i] <= prefix[i - 1]) throw Error(CBLX_EFORMAT, "prefixes are not strictly ascending");
+        bv[prefix[i] >> 6] |= 1ull << (prefix[i] & 63);
+        start[i + 1] = start[i] + cnt[i];
+    }
+    for (u64 w = 0; w < nwords; ++w) rd[w + 1] = rd[w] + (u64)__builtin_popcountll(bv[w]);
+    nr.count = start[nr.nb];
+    nr.bv = Buf<u64>(c->pool, nwords);
+    nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
+    nr.prefix = Buf<u32>(c->pool, nr.nb + 1);
+    nr.start = Buf<u64>(c->pool, nr.nb + 1);
+    nr.cnt = Buf<u32>(c->pool, nr.nb + 1);
+    nr.kind = Buf<u8>(c->pool, nr.nb + 1);
+    Xfer& x = xfer(c);
+    x.h2d_copy(nr.bv.get(), bv.data(), nwords * 8);
+    x.h2d_copy(nr.rank_dir.get(), rd.data(), (nwords + 1) * 8);
+    x.h2d_copy(nr.prefix.get(), prefix.data(), nr.nb * 4);
+    x.h2d_copy(nr.start.get(), start.data(), (nr.nb + 1) * 8);
+    x.h2d_copy(nr.cnt.get(), cnt.data(), nr.nb * 4);
+    x.h2d_copy(nr.kind.get(), kind.data(), nr.nb);
+    x.sync();
+    nr.a_lo = std::move(a_lo);
+    if (P.wide_suffix()) nr.a_hi = std::move(a_hi);
+    c->res = std::move(nr);
+}
+
+template <bool WS> void load_stream(cblx_ctx* c, const u8* data, u64 len, bool& canonical) {
+    const Consts& P = c->P;
+    const u32 BYTES = P.BYTES;
+    Src s{data, data + len};
+    canonical = s.u8_() != 0;
+    const u64 nb = s.varint();
+    const u64 nprefix = 1ull << P.PB;
+    if (nb > nprefix) throw Error(CBLX_EFORMAT, "index: more buckets than prefixes (wrong PREFIX_BITS?)");
+    std::vector<u32> prefix(nb), cnt(nb);
+    std::vector<u8> kind(nb);
+    StreamUp lo(c, len / 6 + 1024);
+    std::unique_ptr<StreamUp> hi;
+    if (WS) hi.reset(new StreamUp(c, len / 6 + 1024));
+    const u64 lo_mask = BYTES >= 8 ? ~0ull : ((1ull << (8 * BYTES)) - 1ull);
+    const u64 hi_mask = WS ? ((BYTES >= 16) ? ~0ull : ((1ull << (8 * (BYTES - 8))) - 1ull)) : 0ull;
+    u64 total = 0;
+    for (u64 r = 0; r < nb; ++r) {
+        const u64 p = s.varint();
+        if (p >= nprefix) throw Error(CBLX_EFORMAT, "prefix out of range for PREFIX_BITS");
+        prefix[r] = (u32)p;
+        const u64 tag = s.varint();
+        u64 n = 0;
+        if (tag == 0) {  // Vec: varint(n) then n x (varint(BYTES) | BYTES little-endian bytes), stored order
+            n = s.varint();
+            if (n > 0xFFFFFFF0ull) throw Error(CBLX_EFORMAT, "index: bucket too long");
+            u64 left = n;
+            while (left) {
+                const size_t k = (size_t)std::min<u64>(left, StreamUp::CAP);
+                u64* ol = lo.room(k);
+                u64* oh = WS ? hi->room(k) : nullptr;
+                // fast path: every element has the expected length byte and 16 readable bytes follow the chunk
+                if ((u64)(s.end - s.p) >= (u64)k * (1 + BYTES) + 16) {
+                    const u8* q = s.p;
+                    bool regular = true;
+                    for (size_t i = 0; i < k; ++i, q += 1 + BYTES) {
+                        regular &= q[0] == BYTES;
+                        ol[i] = load_le64(q + 1) & lo_mask;
+                        if (WS) oh[i] = load_le64(q + 9) & hi_mask;
+                    }
+                    if (regular) { s.p = q; lo.commit(k); if (WS) hi->commit(k); left -= k; continue; }
+                }
+                for (size_t i = 0; i < k; ++i) {  // general path (length byte != BYTES, or the tail of the input)
+                    const u64 nbts = s.varint();
+                    u128 x = 0;
+                    for (u64 b = 0; b < nbts; ++b) { const u8 v = s.u8_(); if (b < BYTES) x |= (u128)v << (8 * b); }
+                    ol[i] = (u64)x;
+                    if (WS) oh[i] = (u64)(x >> 64);
+                }
+                lo.commit(k);
+                if (WS) hi->commit(k);
+                left -= k;
+            }
+            kind[r] = KIND_VEC;
+        } else if (tag == 1) {  // Trie: pre-order nodes (explicit stack), then varint(len)
+            struct Fr { const u8* vals; u32 c, i; };
+            Fr st[16];
+            u32 d = 0;
+            u64 alo = 0, ahi = 0;
+            auto set_byte = [&](u32 depth, u8 b) {
+                u32 sh = 8 * (BYTES - 1 - depth);
+                if (sh < 64) alo = (alo & ~(0xFFull << sh)) | ((u64)b << sh);
+                else { sh -= 64; ahi = (ahi & ~(0xFFull << sh)) | ((u64)b << sh); }
+            };
+            for (;;) {
+                const u64 cc = s.varint();
+                if (cc > 256) throw Error(CBLX_EFORMAT, "index: trie node with more than 256 entries");
+                if ((u64)(s.end - s.p) < cc) throw Error(CBLX_EFORMAT, "index: unexpected end of data");
+                const u8* vals = s.p;
+                s.p += cc;
+                const u64 nc = s.varint();
+                bool descend = false;
+                if (d + 1 == BYTES) {
+                    if (nc != 0) throw Error(CBLX_EFORMAT, "index: leaf trie node with children");
+                    u64* ol = lo.room((size_t)cc);
+                    for (u64 i = 0; i < cc; ++i) ol[i] = alo | vals[i];
+                    lo.commit((size_t)cc);
+                    if (WS) { u64* oh = hi->room((size_t)cc); for (u64 i = 0; i < cc; ++i) oh[i] = ahi; hi->commit((size_t)cc); }
+                    n += cc;
+                } else {
+                    if (nc != cc) throw Error(CBLX_EFORMAT, "index: trie node children count mismatch");
+                    if (cc) { st[d] = Fr{vals, (u32)cc, 0}; set_byte(d, vals[0]); ++d; descend = true; }
+                }
+                if (descend) continue;
+                bool done = false;
+                for (;;) {  // back up to the next sibling
+                    if (d == 0) { done = true; break; }
+                    Fr& f = st[d - 1];
+                    if (++f.i < f.c) { set_byte(d - 1, f.vals[f.i]); break; }
+                    --d;
+                }
+                if (done) break;
+            }
+            const u64 nlen = s.varint();
+            if (nlen != n) throw Error(CBLX_EFORMAT, "index: trie length field does not match its contents");
+            if (n > 0xFFFFFFF0ull) throw Error(CBLX_EFORMAT, "index: bucket too long");
+            kind[r] = KIND_TRIE;
+        } else {
+            throw Error(CBLX_EFORMAT, "index: bad TrieOrVec tag");
+        }
+        cnt[r] = (u32)n;
+        total += n;
+    }
+    if (s.p != s.end) throw Error(CBLX_EFORMAT, "index: trailing bytes");  // reject_trailing_bytes
+    if (total >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "index: more than 2^32 - 16 words (per-GPU limit of this build)");
+    Buf<u64> a_lo = lo.finish(), a_hi;
+    if (WS) a_hi = hi->finish();
+    install_index(c, prefix, cnt, kind, std::move(a_lo), std::move(a_hi));
+}
+
 // `self |= other` on host copies (v1): src/wordset/set_ops.rs:123-157 + src/trievec/set_ops.rs:43-71
 // returns true when `b` changed: the reference's |= walks other's bucket with iter_sorted, which sorts a Vec in place
 bool merge_host(const Consts& P, const HostIndex& a, HostIndex& b, HostIndex& o) {
@@ -1578,23 +1774,31 @@ int cblx_save_to_file(cblx_ctx* c, const char* path) {
 int cblx_load(cblx_ctx* c, const uint8_t* data, uint64_t len) {
     return guard(c, [&] {
         if (!data) throw Error(CBLX_EINVAL, "null argument");
-        HostIndex h;
         bool canon = false;
-        parse_index(c->P, data, len, h, canon);
+        CBLX_HIP(hipStreamSynchronize(c->stream));
         ingest_drop(c);
-        upload(c, h);
+        c->res = Resident();  // the old index is gone even if the bytes turn out to be malformed (it is being replaced)
+        if (c->P.wide_suffix()) load_stream<true>(c, data, len, canon);
+        else load_stream<false>(c, data, len, canon);
         c->P.canonical = canon ? 1 : 0;
     });
 }
 int cblx_load_from_file(cblx_ctx* c, const char* path) {
-    std::vector<u8> data;
-    int rc = guard(c, [&] {
-        std::ifstream f(path, std::ios::binary);
-        if (!f) throw Error(CBLX_EINVAL, std::string("Failed to open ") + path);
-        data.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-    });
-    if (rc) return rc;
-    return cblx_load(c, data.data(), data.size());
+    if (!c) return CBLX_EINVAL;
+    if (!path) { c->err = "null argument"; return CBLX_EINVAL; }
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { c->err = std::string("Failed to open ") + path; return CBLX_EINVAL; }
+    struct stat st;
+    if (::fstat(fd, &st) != 0) { ::close(fd); c->err = std::string("Failed to stat ") + path; return CBLX_EINVAL; }
+    const size_t len = (size_t)st.st_size;
+    if (len == 0) { ::close(fd); c->err = "index: unexpected end of data"; return CBLX_EFORMAT; }
+    void* m = ::mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) { c->err = std::string("Failed to map ") + path; return CBLX_EINVAL; }
+    (void)::madvise(m, len, MADV_SEQUENTIAL);
+    const int rc = cblx_load(c, (const u8*)m, len);
+    ::munmap(m, len);
+    return rc;
 }
 int cblx_merge_assign(cblx_ctx* self, cblx_ctx* other) {
     return guard(self, [&] {
