@@ -257,14 +257,34 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
     constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
     Buf<u32> seg_start(c->pool, 257);
     const u32 nA = std::min(8u, P.PB), RB = P.PB - nA;  // bits of pass A, bits left for the LSD passes
+    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    Buf<u32> start_dense(c->pool, nprefix);
+    bool have_dense = false;
     {
         const u32 ntiles = (u32)ceil_div(N, RDX_TILE), nt_max = ntiles + 256;
-        const u32 npassL = (RB + 7) / 8;
+        const u32 npassL = (RB + 7) / 8, nseg = 1u << nA;
+        // The last LSD pass cuts its tiles at (segment x lower digits) groups when there are few enough of them; the
+        // bucket directory then comes from that pass's tables (k_dir_gather) instead of a scan of the sorted records.
+        const u32 low_bits = npassL ? 8 * (npassL - 1) : 0, last_bits = RB - low_bits;
+        const bool tbl_dir = npassL >= 1 && nA + low_bits <= 16;
+        const bool grp_tiles = tbl_dir && low_bits > 0;  // low_bits = 0: the groups are the segments (existing tile table)
+        const u32 G = nseg << low_bits, nt_maxC = grp_tiles ? ntiles + G + 256 : nt_max;
         const bool haveA = countsA.get() != nullptr;
         Buf<u32> counts = haveA ? std::move(countsA) : Buf<u32>(c->pool, (size_t)256 * nt_max);
-        Buf<u32> colpre(c->pool, (size_t)256 * nt_max), scratch, coltot(c->pool, 256),
+        Buf<u32> colpre(c->pool, (size_t)256 * nt_maxC), scratch, coltot(c->pool, 256),
             adj(c->pool, 256 * 256), seg_first(c->pool, 257), nt_dev(c->pool, 1), t_start(c->pool, nt_max), t_count(c->pool, nt_max);
         Buf<u16> t_seg(c->pool, nt_max);
+        Buf<u32> grp_start, grp_first, seg_firstC, nt_devC, t_startC, t_countC;
+        Buf<u16> t_segC;
+        if (grp_tiles) {
+            grp_start = Buf<u32>(c->pool, G + 1);
+            grp_first = Buf<u32>(c->pool, G + 1);
+            seg_firstC = Buf<u32>(c->pool, 257);
+            nt_devC = Buf<u32>(c->pool, 1);
+            t_startC = Buf<u32>(c->pool, nt_maxC);
+            t_countC = Buf<u32>(c->pool, nt_maxC);
+            t_segC = Buf<u16>(c->pool, nt_maxC);
+        }
         {   // pass A
             const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
             const DigitBits dfn{P.SB + RB, nA};
@@ -273,7 +293,7 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
             { StageTimer t(c, ST_SCAN);
               colscan(c, counts.get(), nullptr, ntiles, colpre.get(), coltot.get(), scratch);
               hipLaunchKernelGGL(k_seg_adjust, dim3(1), dim3(256), 0, c->stream, colpre.get(), coltot.get(), (const u32*)nullptr, (const u32*)nullptr,
-                                 (const u32*)nullptr, ntiles, 1u, adj.get());
+                                 (const u32*)nullptr, ntiles, 1u, adj.get(), (u32*)nullptr);
               hipLaunchKernelGGL(k_seg_table, dim3(1), dim3(256), 0, c->stream, coltot.get(), seg_start.get(), seg_first.get(), nt_dev.get());
               hipLaunchKernelGGL(k_tile_table, grid1(nt_max, 256), dim3(256), 0, c->stream, seg_start.get(), seg_first.get(), nt_dev.get(), t_start.get(),
                                  t_count.get(), t_seg.get()); }
@@ -286,22 +306,43 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
                                      adj.get(), lo2, hi2); }
             advance();
         }
+        if (counts.n < (size_t)256 * nt_maxC) counts = Buf<u32>(c->pool, (size_t)256 * nt_maxC);
         const TileView tvL{t_start.get(), t_count.get(), t_seg.get(), nt_dev.get(), nt_max, N};
+        const TileView tvC{t_startC.get(), t_countC.get(), t_segC.get(), nt_devC.get(), nt_maxC, N};
         for (u32 pass = 0; pass < npassL; ++pass) {
             const DigitBits dfn{P.SB + 8 * pass, std::min(8u, RB - 8 * pass)};
+            const bool last = pass + 1 == npassL;
+            const bool cut = last && grp_tiles;  // this pass runs on the group-cut tiles
+            const TileView& tv = cut ? tvC : tvL;
+            const u32 ntm = cut ? nt_maxC : nt_max;
+            const u32 *ntd = cut ? nt_devC.get() : nt_dev.get(), *sf = cut ? seg_firstC.get() : seg_first.get();
             auto run = [&](auto hi_tag) {
                 typedef decltype(hi_tag) H;  // record layout of the LSD passes: no hi once it was dropped
                 const H* hin = (const H*)hi;
                 H* hout = (H*)hi2;
                 { StageTimer t(c, ST_HIST);
-                  hipLaunchKernelGGL((k_radix_hist<H, DigitBits>), dim3(xcd_grid(nt_max)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tvL, dfn, counts.get()); }
+                  hipLaunchKernelGGL((k_radix_hist<H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, counts.get()); }
                 { StageTimer t(c, ST_SCAN);
-                  colscan(c, counts.get(), nt_dev.get(), nt_max, colpre.get(), coltot.get(), scratch);
-                  hipLaunchKernelGGL(k_seg_adjust, dim3(256), dim3(256), 0, c->stream, colpre.get(), coltot.get(), seg_first.get(), seg_start.get(), nt_dev.get(),
-                                     nt_max, 256u, adj.get()); }
+                  colscan(c, counts.get(), ntd, ntm, colpre.get(), coltot.get(), scratch);
+                  hipLaunchKernelGGL(k_seg_adjust, dim3(nseg), dim3(256), 0, c->stream, colpre.get(), coltot.get(), sf, seg_start.get(), ntd, ntm, nseg, adj.get(),
+                                     (grp_tiles && pass + 2 == npassL) ? grp_start.get() : (u32*)nullptr);
+                  if (grp_tiles && pass + 2 == npassL) {  // the next pass is the last one: cut its tiles at the groups this pass creates
+                      hipLaunchKernelGGL(k_grp_table, dim3(1), dim3(1024), 0, c->stream, G, low_bits, grp_start.get(), seg_start.get(), (u32)N, grp_first.get(), seg_firstC.get(),
+                                         nt_devC.get());
+                      hipLaunchKernelGGL(k_tile_table_grp, grid1(nt_maxC, 256), dim3(256), 0, c->stream, G, low_bits, grp_start.get(), seg_start.get(), (u32)N, grp_first.get(), nt_devC.get(),
+                                         t_startC.get(), t_countC.get(), t_segC.get());
+                  } }
                 { StageTimer t(c, ST_SCATTER);
-                  hipLaunchKernelGGL((k_radix_scatter<H, H, DigitBits>), dim3(xcd_grid(nt_max)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tvL, dfn, colpre.get(),
+                  hipLaunchKernelGGL((k_radix_scatter<H, H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, colpre.get(),
                                      adj.get(), lo2, hout); }
+                if (last && tbl_dir) {
+                    StageTimer t(c, ST_DIR);
+                    hipLaunchKernelGGL(k_dir_gather, dim3(G), dim3(256), 0, c->stream, low_bits, last_bits, grp_tiles ? grp_first.get() : seg_first.get(), seg_start.get(), ntd,
+                                       colpre.get(), coltot.get(), adj.get(), start_dense.get());
+                    if (grp_tiles)  // cold segments kept plain tiles: their boundaries come from their (few) records, now in lo2
+                        hipLaunchKernelGGL(k_boundaries_cold<H>, dim3(nseg), dim3(256), 0, c->stream, (const u64*)lo2, (const H*)hout, P.SB, RB, seg_start.get(), start_dense.get());
+                    have_dense = true;
+                }
             };
             if constexpr (DROP_HI) run(NoHi()); else run(HiT());
             advance();
@@ -313,21 +354,22 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
     rec.lo2.reset();
     rec.hi2.reset();
     // -- KRN-4: bitvector, rank directory, bucket table
-    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
     Buf<u32> res_count, out_count;
     Buf<u8> res_kind;
     {
         StageTimer t(c, ST_DIR);
-        Buf<u32> start_dense(c->pool, nprefix), popc(c->pool, nwords);
+        Buf<u32> popc(c->pool, nwords);
         nr.bv = Buf<u64>(c->pool, nwords);
         nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
-        CBLX_HIP(hipMemsetAsync(start_dense.get(), 0xFF, nprefix * 4, c->stream));
         CBLX_HIP(hipMemsetAsync(nr.bv.get(), 0, nwords * 8, c->stream));
         CBLX_HIP(hipMemsetAsync(popc.get(), 0, nwords * 4, c->stream));
-        if constexpr (DROP_HI)
-            hipLaunchKernelGGL(k_boundaries_seg, grid1(ceil_div(N, 4), 256), dim3(256), 0, c->stream, lo, N, P.SB, RB, seg_start.get(), start_dense.get());
-        else
-            hipLaunchKernelGGL(k_boundaries<HiT>, grid1(ceil_div(N, 4), 256), dim3(256), 0, c->stream, lo, hi, N, P.SB, P.PB, start_dense.get());
+        if (!have_dense) {  // boundaries from a scan of the sorted records (more groups than the table method takes)
+            CBLX_HIP(hipMemsetAsync(start_dense.get(), 0xFF, nprefix * 4, c->stream));
+            if constexpr (DROP_HI)
+                hipLaunchKernelGGL(k_boundaries_seg, grid1(ceil_div(N, 4), 256), dim3(256), 0, c->stream, lo, N, P.SB, RB, seg_start.get(), start_dense.get());
+            else
+                hipLaunchKernelGGL(k_boundaries<HiT>, grid1(ceil_div(N, 4), 256), dim3(256), 0, c->stream, lo, hi, N, P.SB, P.PB, start_dense.get());
+        }
         hipLaunchKernelGGL(k_bitvector, grid1(std::max<u64>(nprefix, 64), 256), dim3(256), 0, c->stream, start_dense.get(), nprefix, nr.bv.get(), popc.get());
         nr.nb = exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get());
         nr.prefix = Buf<u32>(c->pool, nr.nb + 1);

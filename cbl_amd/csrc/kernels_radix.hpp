@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void k_colscan_apply(const u32* __restrict__ c
 __global__ __launch_bounds__(256) void k_seg_adjust(const u32* __restrict__ colpre, const u32* __restrict__ coltot,
                                                     const u32* __restrict__ seg_first /* nseg+1, null: {0, ntiles} */,
                                                     const u32* __restrict__ seg_start /* nseg, null: {0} */, const u32* ntiles_dev,
-                                                    u32 ntiles, u32 nseg, u32* __restrict__ adj) {
+                                                    u32 ntiles, u32 nseg, u32* __restrict__ adj, u32* __restrict__ grp_start = nullptr) {
     __shared__ u32 sm[256 / 64 + 1];
     const u32 nt = dev_ntiles(ntiles_dev, ntiles);
     const u32 s = blockIdx.x, d = threadIdx.x;
@@ -370,6 +370,8 @@ __global__ __launch_bounds__(256) void k_seg_adjust(const u32* __restrict__ colp
     const u32 p1 = f1 < nt ? colpre[(u64)f1 * 256 + d] : coltot[d];
     const u32 ex = block_exclusive_scan<256, u32>(p1 - p0, sm, nullptr);
     adj[s * 256 + d] = (seg_start ? seg_start[s] : 0u) + ex - p0;
+    // where digit d of segment s starts after this pass: the (segment, digit) GROUPS the next pass may cut its tiles at
+    if (grp_start) grp_start[s * 256 + d] = (seg_start ? seg_start[s] : 0u) + ex;
     (void)nseg;
 }
 // Segments of the remaining passes from the first pass's column totals: seg_start (exclusive scan of the totals),
@@ -402,6 +404,87 @@ __global__ void k_tile_table(const u32* __restrict__ seg_start, const u32* __res
     t_start[t] = st;
     t_count[t] = en - st < (u32)RDX_TILE ? en - st : (u32)RDX_TILE;
     t_seg[t] = (u16)lo;
+}
+
+// ---- tiles of the LAST LSD pass cut at GROUP boundaries (group = segment x value of the lower digits) ---------------
+// After the earlier passes a segment is sorted by the lower digits, so a tile that stays inside one group holds ONE
+// value of them: its records with last-pass digit d all belong to the single bucket (segment, d, lower digits). The
+// bucket boundaries then follow from the last pass's own tables (k_dir_gather) and the sorted array is never re-read to
+// find them. G groups, grp_start[G + 1] (record positions; [G] = n).
+// Cutting costs up to one partly filled tile per group, which only pays in segments that are much longer than their
+// groups are many: a COLD segment (fewer than GRP_COLD_MAX records) keeps plain tiles and its few boundaries are found
+// by a scan of its records (k_boundaries_cold).
+static const u32 GRP_COLD_MAX = 64 * RDX_TILE;
+__device__ __forceinline__ bool seg_cold(const u32* seg_start, u32 s) { return seg_start[s + 1] - seg_start[s] < GRP_COLD_MAX; }
+// records group g contributes to the tiling: a cold segment is tiled as one piece, charged to its first group
+__device__ __forceinline__ u32 grp_tiled_size(u32 g, u32 G, u32 low_bits, const u32* grp_start, const u32* seg_start, u32 n_total) {
+    const u32 s = g >> low_bits;
+    if (seg_cold(seg_start, s)) return (g & ((1u << low_bits) - 1u)) == 0 ? seg_start[s + 1] - seg_start[s] : 0u;
+    return (g + 1 < G ? grp_start[g + 1] : n_total) - grp_start[g];
+}
+__global__ __launch_bounds__(1024) void k_grp_table(u32 G, u32 low_bits, const u32* __restrict__ grp_start, const u32* __restrict__ seg_start, u32 n_total,
+                                                    u32* __restrict__ grp_first /* G+1 */, u32* __restrict__ seg_first /* (G >> low_bits) + 1 */,
+                                                    u32* __restrict__ ntiles_dev) {
+    __shared__ u32 sm[1024 / 64 + 1];
+    const u32 tid = threadIdx.x, per = (G + 1023u) / 1024u, g0 = tid * per < G ? tid * per : G, g1 = g0 + per < G ? g0 + per : G;
+    u32 mine = 0;
+    for (u32 g = g0; g < g1; ++g) mine += (grp_tiled_size(g, G, low_bits, grp_start, seg_start, n_total) + RDX_TILE - 1) / RDX_TILE;
+    u32 tot;
+    u32 run = block_exclusive_scan<1024, u32>(mine, sm, &tot);
+    for (u32 g = g0; g < g1; ++g) {
+        grp_first[g] = run;
+        if ((g & ((1u << low_bits) - 1u)) == 0) seg_first[g >> low_bits] = run;
+        run += (grp_tiled_size(g, G, low_bits, grp_start, seg_start, n_total) + RDX_TILE - 1) / RDX_TILE;
+    }
+    if (tid == 0) { grp_first[G] = tot; seg_first[G >> low_bits] = tot; *ntiles_dev = tot; }
+}
+__global__ void k_tile_table_grp(u32 G, u32 low_bits, const u32* __restrict__ grp_start, const u32* __restrict__ seg_start, u32 n_total,
+                                 const u32* __restrict__ grp_first, const u32* __restrict__ ntiles_dev, u32* __restrict__ t_start, u32* __restrict__ t_count,
+                                 u16* __restrict__ t_seg) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *ntiles_dev) return;
+    u32 lo = 0, hi = G;  // last group with grp_first[g] <= t (groups without tiles share their successor's first tile)
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (grp_first[mid] <= t) lo = mid; else hi = mid;
+    }
+    const u32 st = grp_start[lo] + (t - grp_first[lo]) * RDX_TILE;
+    const u32 en = grp_start[lo] + grp_tiled_size(lo, G, low_bits, grp_start, seg_start, n_total);
+    t_start[t] = st;
+    t_count[t] = en - st < (u32)RDX_TILE ? en - st : (u32)RDX_TILE;
+    t_seg[t] = (u16)(lo >> low_bits);
+}
+// start_dense[prefix] (EMPTY = 0xFFFFFFFF) for every prefix = (segment, last digit d, lower digits) from the last pass's
+// column prefixes: the bucket starts where the group's first tile puts its digit-d records and holds what the group's
+// tiles count for d. One workgroup per group, one thread per digit value.
+__global__ __launch_bounds__(256) void k_dir_gather(u32 low_bits, u32 last_bits, const u32* __restrict__ grp_first, const u32* __restrict__ seg_start,
+                                                    const u32* __restrict__ ntiles_dev, const u32* __restrict__ colpre, const u32* __restrict__ coltot,
+                                                    const u32* __restrict__ adj, u32* __restrict__ start_dense) {
+    const u32 g = blockIdx.x, d = threadIdx.x;
+    if (d >= (1u << last_bits)) return;
+    const u32 nt = *ntiles_dev, s = g >> low_bits, low = g & ((1u << low_bits) - 1u);
+    if (low_bits && seg_cold(seg_start, s)) {  // its tiles were not cut at the groups: k_boundaries_cold fills these in
+        start_dense[(s << (low_bits + last_bits)) | (d << low_bits) | low] = 0xFFFFFFFFu;
+        return;
+    }
+    const u32 f0 = grp_first[g], f1 = grp_first[g + 1];
+    const u32 p0 = f0 < nt ? colpre[(u64)f0 * 256 + d] : coltot[d];
+    const u32 p1 = f1 < nt ? colpre[(u64)f1 * 256 + d] : coltot[d];
+    const u32 prefix = (s << (low_bits + last_bits)) | (d << low_bits) | low;
+    start_dense[prefix] = p1 > p0 ? adj[s * 256 + d] + p0 : 0xFFFFFFFFu;
+}
+
+// bucket boundaries of the cold segments from their (few) sorted records; one workgroup per segment
+template <typename HiT>
+__global__ __launch_bounds__(256) void k_boundaries_cold(const u64* __restrict__ lo, const HiT* __restrict__ hi, u32 SB, u32 R, const u32* __restrict__ seg_start,
+                                                         u32* __restrict__ start_dense) {
+    const u32 s = blockIdx.x;
+    if (!seg_cold(seg_start, s)) return;
+    const u32 a = seg_start[s], b = seg_start[s + 1];
+    for (u32 i = a + threadIdx.x; i < b; i += blockDim.x) {
+        const u32 p = get_bits(lo[i], (u64)ld_hi<HiT>(hi, i), SB, R);
+        if (i == a || get_bits(lo[i - 1], (u64)ld_hi<HiT>(hi, i - 1), SB, R) != p) start_dense[(s << R) | p] = i;
+    }
 }
 
 }  // namespace cblx
