@@ -285,9 +285,21 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
             t_countC = Buf<u32>(c->pool, nt_maxC);
             t_segC = Buf<u16>(c->pool, nt_maxC);
         }
+        // digit side channel: a scatter also writes the NEXT pass's digit of every record (1 byte, same order), when that
+        // digit lies in the lo word (the hi part may have been dropped by then)
+        Buf<u8> dig;
+        bool have_dig = false;
+        auto next_digit = [&](u32 next_pass) -> DigitBits {
+            if (next_pass >= npassL) return DigitBits{0, 0};
+            const u32 sh = P.SB + 8 * next_pass, nb = std::min(8u, RB - 8 * next_pass);
+            return sh + nb <= 64 ? DigitBits{sh, nb} : DigitBits{0, 0};
+        };
+        if (next_digit(0).nbits) dig = Buf<u8>(c->pool, N + 64);
         {   // pass A
             const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
             const DigitBits dfn{P.SB + RB, nA};
+            const DigitBits nd = next_digit(0);
+            u8* ndp = nd.nbits ? dig.get() : nullptr;
             if (!haveA) { StageTimer t(c, ST_HIST);
               hipLaunchKernelGGL((k_radix_hist<HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, tv, dfn, counts.get()); }
             { StageTimer t(c, ST_SCAN);
@@ -300,10 +312,11 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
             { StageTimer t(c, ST_SCATTER);
               if constexpr (DROP_HI)
                   hipLaunchKernelGGL((k_radix_scatter<HiT, NoHi, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, tv, dfn, colpre.get(),
-                                     adj.get(), lo2, (NoHi*)nullptr);
+                                     adj.get(), lo2, (NoHi*)nullptr, nd, ndp);
               else
                   hipLaunchKernelGGL((k_radix_scatter<HiT, HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, tv, dfn, colpre.get(),
-                                     adj.get(), lo2, hi2); }
+                                     adj.get(), lo2, hi2, nd, ndp); }
+            have_dig = ndp != nullptr;
             advance();
         }
         if (counts.n < (size_t)256 * nt_maxC) counts = Buf<u32>(c->pool, (size_t)256 * nt_maxC);
@@ -320,8 +333,13 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
                 typedef decltype(hi_tag) H;  // record layout of the LSD passes: no hi once it was dropped
                 const H* hin = (const H*)hi;
                 H* hout = (H*)hi2;
+                const DigitBits nd = next_digit(pass + 1);
+                u8* ndp = nd.nbits && dig.get() ? dig.get() : nullptr;
                 { StageTimer t(c, ST_HIST);
-                  hipLaunchKernelGGL((k_radix_hist<H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, counts.get()); }
+                  if (have_dig)
+                      hipLaunchKernelGGL(k_radix_hist_bytes, dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, (const u8*)dig.get(), tv, counts.get());
+                  else
+                      hipLaunchKernelGGL((k_radix_hist<H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, counts.get()); }
                 { StageTimer t(c, ST_SCAN);
                   colscan(c, counts.get(), ntd, ntm, colpre.get(), coltot.get(), scratch);
                   hipLaunchKernelGGL(k_seg_adjust, dim3(nseg), dim3(256), 0, c->stream, colpre.get(), coltot.get(), sf, seg_start.get(), ntd, ntm, nseg, adj.get(),
@@ -334,7 +352,8 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
                   } }
                 { StageTimer t(c, ST_SCATTER);
                   hipLaunchKernelGGL((k_radix_scatter<H, H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, colpre.get(),
-                                     adj.get(), lo2, hout); }
+                                     adj.get(), lo2, hout, nd, ndp); }
+                have_dig = ndp != nullptr;
                 if (last && tbl_dir) {
                     StageTimer t(c, ST_DIR);
                     hipLaunchKernelGGL(k_dir_gather, dim3(G), dim3(256), 0, c->stream, low_bits, last_bits, grp_tiles ? grp_first.get() : seg_first.get(), seg_start.get(), ntd,

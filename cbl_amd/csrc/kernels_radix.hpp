@@ -255,6 +255,38 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const u64* __restric
     }
 }
 
+// The same histogram from the DIGIT SIDE CHANNEL the previous pass's scatter left behind (dig[i] = this pass's digit
+// of record i): 1 byte per record is read instead of the whole record. A thread takes one aligned 8-byte word of the
+// tile's byte range (RDX_THREADS * 8 = RDX_TILE bytes, plus one word for an unaligned start).
+__global__ __launch_bounds__(RDX_THREADS) void k_radix_hist_bytes(const u8* __restrict__ dig, TileView tv, u32* __restrict__ counts) {
+    __shared__ u32 s_wcnt[(RDX_THREADS / 64) * 256];
+    const u32 tid = threadIdx.x, w = tid >> 6;
+    for (u32 i = tid; i < (RDX_THREADS / 64) * 256; i += RDX_THREADS) s_wcnt[i] = 0;
+    __syncthreads();
+    u32 tile, n_tile, seg;
+    u64 tbase;
+    if (!tile_get(tv, blockIdx.x, tile, tbase, n_tile, seg)) return;
+    u32* my = s_wcnt + w * 256;
+    const u64 w0 = tbase >> 3, wend = (tbase + n_tile + 7) >> 3;  // aligned words covering [tbase, tbase + n_tile)
+    const u64* __restrict__ words = reinterpret_cast<const u64*>(dig);
+    for (u64 wi = w0 + tid; wi < wend; wi += RDX_THREADS) {
+        const u64 v = words[wi];
+        const u64 b0 = wi << 3;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u64 pos = b0 + k;
+            if (pos >= tbase && pos < tbase + n_tile) atomicAdd(&my[(u32)(v >> (8 * k)) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        u32 t = 0;
+#pragma unroll
+        for (int ww = 0; ww < RDX_THREADS / 64; ++ww) t += s_wcnt[ww * 256 + tid];
+        counts[(u64)tile * 256 + tid] = t;
+    }
+}
+
 // scatter. colpre[tile * 256 + d] = records with digit d in earlier tiles (pure column prefix); adj[seg * 256 + d] turns it
 // into a global position (k_seg_adjust). OutHiT = NoHi drops the hi part on the way out (first pass of 65..72-bit words:
 // the bits it held are implied by the segment from then on).
@@ -262,7 +294,8 @@ template <typename HiT, typename OutHiT, typename DigitFn>
 __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __restrict__ lo, const HiT* __restrict__ hi, TileView tv,
                                                                DigitFn dfn, const u32* __restrict__ colpre,
                                                                const u32* __restrict__ adj, u64* __restrict__ out_lo,
-                                                               OutHiT* __restrict__ out_hi) {
+                                                               OutHiT* __restrict__ out_hi, DigitBits next_dfn = DigitBits{0, 0},
+                                                               u8* __restrict__ out_next = nullptr) {
     constexpr bool STAGE_HI = HiTraits<HiT>::has && HiTraits<OutHiT>::has;
     __shared__ u64 s_lo[RDX_TILE];
     __shared__ typename std::conditional<STAGE_HI, HiT, u8>::type s_hi[STAGE_HI ? RDX_TILE : 1];
@@ -311,6 +344,9 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
             const u64 dst = s_gbase[d] + s;
             out_lo[dst] = a;
             st_hi<OutHiT>(out_hi, dst, b);
+            // side channel: the next pass's histogram reads 1 byte per record instead of the record (measured: packing four
+            // digits of a run into one unaligned dword store is slower than the byte stores — the extra LDS pass costs more)
+            if (out_next) out_next[dst] = (u8)next_dfn(a, b);
         }
     }
 }
