@@ -36,12 +36,16 @@ def stage_alg_bytes(k: int, pb: int, read_len: int):
     n_a = min(8, pb)
     lsd = (pb - n_a + 7) // 8
     sfx = 8 if wb - pb <= 64 else 16
+    # digit side channel: a scatter also writes the next pass's digit (1 B); that pass's histogram then reads 1 B per
+    # record instead of the record
+    side = list(range(lsd))
+    tbl_dir = lsd >= 1 and n_a + 8 * (lsd - 1) <= 16      # bucket directory from the last pass's tables (no record scan)
     return {
         "chunks": read_len / (read_len - k + 1),             # validity scan reads every base once
         "encode": read_len / (read_len - k + 1) + r_in,        # read bases, write one record (+ fused first-pass histogram)
-        "radix_hist": lsd * r_out,                             # LSD passes read every record once (pass A's is fused in KRN-1)
-        "radix_scatter": (r_in + r_out) + lsd * 2 * r_out,     # every pass reads + writes every record once
-        "directory": r_out,                                    # boundary detection reads the sorted records
+        "radix_hist": (lsd - len(side)) * r_out + len(side),   # pass A's histogram is fused in KRN-1
+        "radix_scatter": (r_in + r_out) + lsd * 2 * r_out + len(side),  # every pass reads + writes every record once
+        "directory": 0.0 if tbl_dir else r_out,                # boundary detection reads the sorted records only when the tables cannot give it
         "bucket_medium": 2 * sfx,                              # read the run, write the distinct suffixes
         "bucket_small": 2 * sfx,
         "bucket_huge": 2 * sfx,

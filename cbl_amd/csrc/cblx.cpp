@@ -285,14 +285,13 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
             t_countC = Buf<u32>(c->pool, nt_maxC);
             t_segC = Buf<u16>(c->pool, nt_maxC);
         }
-        // digit side channel: a scatter also writes the NEXT pass's digit of every record (1 byte, same order), when that
-        // digit lies in the lo word (the hi part may have been dropped by then)
+        // digit side channel: a scatter also writes the NEXT pass's digit of every record (1 byte, same order). (When the
+        // hi byte is dropped by pass A the remaining digits all lie in the lo word: the word has <= 72 bits.)
         Buf<u8> dig;
         bool have_dig = false;
         auto next_digit = [&](u32 next_pass) -> DigitBits {
             if (next_pass >= npassL) return DigitBits{0, 0};
-            const u32 sh = P.SB + 8 * next_pass, nb = std::min(8u, RB - 8 * next_pass);
-            return sh + nb <= 64 ? DigitBits{sh, nb} : DigitBits{0, 0};
+            return DigitBits{P.SB + 8 * next_pass, std::min(8u, RB - 8 * next_pass)};
         };
         if (next_digit(0).nbits) dig = Buf<u8>(c->pool, N + 64);
         {   // pass A
