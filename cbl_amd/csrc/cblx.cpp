@@ -406,7 +406,7 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
     res_count = Buf<u32>(c->pool, nb + 1);
     res_kind = Buf<u8>(c->pool, nb + 1);
     CBLX_HIP(hipMemsetAsync(list_n.get(), 0, CLS_N * 4, c->stream));
-    hipLaunchKernelGGL(k_classify, grid1(nb, 256), dim3(256), 0, c->stream, nb, C::WS ? 512u : 1024u, nr.prefix.get(), nr.start.get(), c->res.view(),
+    hipLaunchKernelGGL(k_classify, grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, C::WS ? 512u : 1024u, nr.prefix.get(), nr.start.get(), c->res.view(),
                        res_count.get(), res_kind.get(), nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get());
     std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
     u64* a_lo = rec.lo.get();
@@ -470,7 +470,7 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
     {
         Buf<u64> total(c->pool, 1);
         CBLX_HIP(hipMemsetAsync(total.get(), 0, 8, c->stream));
-        hipLaunchKernelGGL(k_sum_u32, grid1(nr.nb, 256), dim3(256), 0, c->stream, nr.cnt.get(), nr.nb, total.get());
+        hipLaunchKernelGGL(k_sum_u32, dim3((unsigned)std::min<u64>(2048, std::max<u64>(1, ceil_div(nr.nb, 256)))), dim3(256), 0, c->stream, nr.cnt.get(), nr.nb, total.get());
         nr.count = d2h<u64>(c, total.get());
     }
     nr.a_lo = std::move(rec.lo);
@@ -660,7 +660,7 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
     Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
     Buf<u32> list_n(c->pool, CLS_N);
     CBLX_HIP(hipMemsetAsync(list_n.get(), 0, CLS_N * 4, c->stream));
-    hipLaunchKernelGGL(k_classify_merge, grid1(nb, 256), dim3(256), 0, c->stream, nb, WS ? 512u : 1024u, nr.start.get(), m_cs.get(), m_skind.get(), m_okind.get(),
+    hipLaunchKernelGGL(k_classify_merge, grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, WS ? 512u : 1024u, nr.start.get(), m_cs.get(), m_skind.get(), m_okind.get(),
                        nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get());
     CBLX_HIP(hipGetLastError());
     std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
@@ -698,7 +698,7 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
     {
         Buf<u64> total(c->pool, 1);
         CBLX_HIP(hipMemsetAsync(total.get(), 0, 8, c->stream));
-        hipLaunchKernelGGL(k_sum_u32, grid1(nb, 256), dim3(256), 0, c->stream, nr.cnt.get(), nb, total.get());
+        hipLaunchKernelGGL(k_sum_u32, dim3((unsigned)std::min<u64>(2048, std::max<u64>(1, ceil_div(nb, 256)))), dim3(256), 0, c->stream, nr.cnt.get(), nb, total.get());
         nr.count = d2h<u64>(c, total.get());
     }
     c->res = std::move(nr);
@@ -1064,7 +1064,7 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
         list_n = Buf<u32>(c->pool, SER_NCLS);
         off = Buf<u64>(c->pool, nb + 1);
         CBLX_HIP(hipMemsetAsync(list_n.get(), 0, SER_NCLS * 4, c->stream));
-        hipLaunchKernelGGL((k_serde_tiny<WS, false>), grid1(nb, 256), dim3(256), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
+        hipLaunchKernelGGL((k_serde_tiny<WS, false>), grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
                            P.SB, P.BYTES, size.get(), (const u64*)nullptr, (u8*)nullptr, lists.get(), list_n.get());
         CBLX_HIP(hipGetLastError());
         ln = d2h_vec<u32>(c, list_n.get(), SER_NCLS);
@@ -1078,7 +1078,7 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
     CBLX_HIP(hipMemcpyAsync(blob.bytes.get(), hdr, hs.pos, hipMemcpyHostToDevice, c->stream));
     if (nb) {
         u8* body = blob.bytes.get() + hs.pos;
-        hipLaunchKernelGGL((k_serde_tiny<WS, true>), grid1(nb, 256), dim3(256), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
+        hipLaunchKernelGGL((k_serde_tiny<WS, true>), grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
                            P.SB, P.BYTES, size.get(), off.get(), body, (u32*)nullptr, (u32*)nullptr);
         buckets(std::true_type(), body);
     }

@@ -131,43 +131,60 @@ struct BDesc {
 };
 static const u32 BDESC_TRIE = 0x80000000u;
 
-__global__ void k_classify(u64 nb, u32 med_max_threads, const u32* __restrict__ bucket_prefix, const u64* __restrict__ raw_start, DirView old,
-                           u32* __restrict__ res_count, u8* __restrict__ res_kind, u32* __restrict__ out_count,
-                           u8* __restrict__ out_kind, BDesc* __restrict__ lists /* [CLS_N][nb] */, u32* __restrict__ list_n) {
-    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nb) return;
-    u64 c = raw_start[r + 1] - raw_start[r];
-    u32 rc = 0;
-    u8 rk = KIND_VEC;
-    u64 orank;
-    if (dir_lookup(old, bucket_prefix[r], orank)) { rc = old.count[orank]; rk = old.kind[orank]; }
-    res_count[r] = rc;
-    res_kind[r] = rk;
-    if (rc != 0 && c == rc) {  // untouched by this batch: keep as is (src/wordset/mod.rs:213-214 only re-checks touched buckets)
-        out_count[r] = rc;
-        out_kind[r] = rk;
-        return;
-    }
-    int cls;
-    if (c <= SMALL_MAX && rk != KIND_TRIE) cls = CLS_SMALL;
-    else if (c <= 64 * MED_ITEMS) cls = CLS_M64;    // workgroup size follows the run length: THREADS = CAP / 8
-    else if (c <= 128 * MED_ITEMS) cls = CLS_M128;
-    else if (c <= 256 * MED_ITEMS) cls = CLS_M256;
-    else if (c <= 512 * MED_ITEMS) cls = CLS_M512;
-    else if (c <= 1024 * MED_ITEMS && med_max_threads >= 1024) cls = CLS_M1024;
-    else cls = CLS_HUGE;
-    // one atomic per (wave, class): the lanes of a class take consecutive slots
+// Slot of this thread in the list of class `cls` (cls < 0: none). The lanes of a class take consecutive slots; ONE atomic
+// per (workgroup, class) reserves them (per-wave atomics on the handful of list counters were the whole cost of the
+// classification kernels at 2^28 prefixes). Every thread of the workgroup must call it.
+template <int THREADS, int NCLS> __device__ __forceinline__ u32 block_append(int cls, u32* __restrict__ list_n) {
+    constexpr int NW = THREADS / 64;
+    __shared__ u32 s_cnt[NCLS * NW];
+    __shared__ u32 s_base[NCLS];
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32 my_rank = 0;
 #pragma unroll
-    for (int k = 0; k < CLS_N; ++k) {
+    for (int k = 0; k < NCLS; ++k) {
         const u64 bal = __ballot(cls == k);
-        if (cls == k) {
-            u32 base = 0;
-            const u32 leader = (u32)__builtin_ctzll(bal);
-            if (lane_id() == leader) base = atomicAdd(&list_n[k], (u32)__builtin_popcountll(bal));
-            base = __shfl(base, (int)leader, 64);
-            lists[(u64)k * nb + base + mbcnt(bal)] = BDesc{raw_start[r], (u32)c | (rk == KIND_TRIE ? BDESC_TRIE : 0u), (u32)r};
-        }
+        if (cls == k) my_rank = mbcnt(bal);
+        if (lane == 0) s_cnt[k * NW + w] = (u32)__builtin_popcountll(bal);
     }
+    __syncthreads();
+    if (threadIdx.x < NCLS) {
+        const u32 k = threadIdx.x;
+        u32 run = 0;
+        for (int ww = 0; ww < NW; ++ww) { const u32 t = s_cnt[k * NW + ww]; s_cnt[k * NW + ww] = run; run += t; }
+        s_base[k] = run ? atomicAdd(&list_n[k], run) : 0u;
+    }
+    __syncthreads();
+    return cls >= 0 ? s_base[cls] + s_cnt[cls * NW + w] + my_rank : 0u;
+}
+static const int CLASSIFY_THREADS = 1024;
+
+__global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify(u64 nb, u32 med_max_threads, const u32* __restrict__ bucket_prefix, const u64* __restrict__ raw_start,
+                                                                DirView old, u32* __restrict__ res_count, u8* __restrict__ res_kind, u32* __restrict__ out_count,
+                                                                u8* __restrict__ out_kind, BDesc* __restrict__ lists /* [CLS_N][nb] */, u32* __restrict__ list_n) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1;
+    u64 c = 0;
+    u8 rk = KIND_VEC;
+    if (r < nb) {
+        c = raw_start[r + 1] - raw_start[r];
+        u32 rc = 0;
+        u64 orank;
+        if (dir_lookup(old, bucket_prefix[r], orank)) { rc = old.count[orank]; rk = old.kind[orank]; }
+        res_count[r] = rc;
+        res_kind[r] = rk;
+        if (rc != 0 && c == rc) {  // untouched by this batch: keep as is (src/wordset/mod.rs:213-214 only re-checks touched buckets)
+            out_count[r] = rc;
+            out_kind[r] = rk;
+        } else if (c <= SMALL_MAX && rk != KIND_TRIE) cls = CLS_SMALL;
+        else if (c <= 64 * MED_ITEMS) cls = CLS_M64;    // workgroup size follows the run length: THREADS = CAP / 8
+        else if (c <= 128 * MED_ITEMS) cls = CLS_M128;
+        else if (c <= 256 * MED_ITEMS) cls = CLS_M256;
+        else if (c <= 512 * MED_ITEMS) cls = CLS_M512;
+        else if (c <= 1024 * MED_ITEMS && med_max_threads >= 1024) cls = CLS_M1024;
+        else cls = CLS_HUGE;
+    }
+    const u32 slot = block_append<CLASSIFY_THREADS, CLS_N>(cls, list_n);
+    if (cls >= 0) lists[(u64)cls * nb + slot] = BDesc{raw_start[r], (u32)c | (rk == KIND_TRIE ? BDESC_TRIE : 0u), (u32)r};
 }
 
 // ---- `self |= other` on the device: /root/reference/src/wordset/set_ops.rs:123-157 ------------------------
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(256) void k_merge_gather(u64 nb, const u64* __restr
 }
 // one-sided buckets are final after the gather (self-only: untouched; other-only: cloned as stored); both-sided ones
 // go to the merge epilogue of the bucket kernel of their length class
-__global__ void k_classify_merge(u64 nb, u32 med_max_threads, const u64* __restrict__ raw_start, const u32* __restrict__ m_cs,
+__global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify_merge(u64 nb, u32 med_max_threads, const u64* __restrict__ raw_start, const u32* __restrict__ m_cs,
                                  const u8* __restrict__ m_skind, const u8* __restrict__ m_okind, u32* __restrict__ out_count,
                                  u8* __restrict__ out_kind, BDesc* __restrict__ lists, u32* __restrict__ list_n) {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,17 +267,8 @@ __global__ void k_classify_merge(u64 nb, u32 med_max_threads, const u64* __restr
         else if (c <= 1024 * MED_ITEMS && med_max_threads >= 1024) cls = CLS_M1024;
         else cls = CLS_HUGE;
     }
-#pragma unroll
-    for (int k = 0; k < CLS_N; ++k) {
-        const u64 bal = __ballot(cls == k);
-        if (cls == k) {
-            u32 base = 0;
-            const u32 leader = (u32)__builtin_ctzll(bal);
-            if (lane_id() == leader) base = atomicAdd(&list_n[k], (u32)__builtin_popcountll(bal));
-            base = __shfl(base, (int)leader, 64);
-            lists[(u64)k * nb + base + mbcnt(bal)] = BDesc{raw_start[r], (u32)c | (ks == KIND_TRIE ? BDESC_TRIE : 0u), (u32)r};
-        }
-    }
+    const u32 slot = block_append<CLASSIFY_THREADS, CLS_N>(cls, list_n);
+    if (cls >= 0) lists[(u64)cls * nb + slot] = BDesc{raw_start[r], (u32)c | (ks == KIND_TRIE ? BDESC_TRIE : 0u), (u32)r};
 }
 
 // ---- suffix access --------------------------------------------------------------------------------------
@@ -1083,11 +1091,18 @@ __global__ __launch_bounds__(256) void k_validate(u64 nb, const u64* __restrict_
     if (lane == 0 && b) atomicAdd((unsigned long long*)bad, (unsigned long long)b);
 }
 
-__global__ void k_sum_u32(const u32* __restrict__ v, u64 n, u64* __restrict__ out) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 s = i < n ? v[i] : 0;
+// grid-stride sum: one atomic per workgroup (launch with sum_grid(n) workgroups of 256)
+__global__ __launch_bounds__(256) void k_sum_u32(const u32* __restrict__ v, u64 n, u64* __restrict__ out) {
+    __shared__ u64 sm[4];
+    u64 s = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) s += v[i];
     s = wave_reduce_sum(s);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd((unsigned long long*)out, (unsigned long long)s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u64 t = sm[0] + sm[1] + sm[2] + sm[3];
+        if (t) atomicAdd((unsigned long long*)out, (unsigned long long)t);
+    }
 }
 __global__ void k_fill_u32(u32* p, u64 n, u32 v) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -60,7 +60,7 @@ static const u32 SER_TINY = 32;  // Vec buckets up to this length are written by
 // Pass over all buckets, one thread each: tiny Vec buckets are sized (EMIT = false) or written (EMIT = true) here; the
 // others are appended to the list of their size class (sizing pass only; unordered).
 template <bool WS, bool EMIT>
-__global__ void k_serde_tiny(u64 nb, const u32* __restrict__ prefix, const u64* __restrict__ start, const u32* __restrict__ cnt,
+__global__ __launch_bounds__(CLASSIFY_THREADS) void k_serde_tiny(u64 nb, const u32* __restrict__ prefix, const u64* __restrict__ start, const u32* __restrict__ cnt,
                              const u8* __restrict__ kind, const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u32 SB, u32 BYTES,
                              u32* __restrict__ size, const u64* __restrict__ off, u8* __restrict__ out, u32* __restrict__ lists,
                              u32* __restrict__ list_n) {
@@ -91,17 +91,8 @@ __global__ void k_serde_tiny(u64 nb, const u32* __restrict__ prefix, const u64* 
     if constexpr (!EMIT) {
         int cls = -1;
         if (live && !tiny) cls = n <= SER_CAP64 ? SER_C64 : n <= SER_CAP256 ? SER_C256 : n <= SER_CAP1024 ? SER_C1024 : SER_HOST;
-#pragma unroll
-        for (int k = 0; k < SER_NCLS; ++k) {
-            const u64 bal = __ballot(cls == k);
-            if (cls == k) {
-                u32 base = 0;
-                const u32 leader = (u32)__builtin_ctzll(bal);
-                if (lane_id() == leader) base = atomicAdd(&list_n[k], (u32)__builtin_popcountll(bal));
-                base = __shfl(base, (int)leader, 64);
-                lists[(u64)k * nb + base + mbcnt(bal)] = (u32)r;
-            }
-        }
+        const u32 slot = block_append<CLASSIFY_THREADS, SER_NCLS>(cls, list_n);
+        if (cls >= 0) lists[(u64)cls * nb + slot] = (u32)r;
     }
 }
 
