@@ -553,9 +553,9 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const BDesc* __restrict_
     static_assert(!(PACKED && WS), "packed elements need a narrow suffix");
     static_assert(CAP <= (1 << PK_BITS), "stream index must fit PK_BITS");
     constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
-    __shared__ u64 s_klo[CAP];
-    __shared__ u64 s_khi[WS ? CAP : 1];
-    __shared__ u16 s_idx[PACKED ? 1 : CAP];
+    __shared__ u64 s_klo[CAP + 4];  // + slack: the ranking loop reads up to 3 entries past a sub-bucket
+    __shared__ u64 s_khi[WS ? CAP + 4 : 1];
+    __shared__ u16 s_idx[PACKED ? 1 : CAP + 4];
     // sub-bucket counts, then exclusive offsets: 16-bit entries (values <= CAP), counted with 32-bit LDS atomics on the
     // containing dword (LDS is what bounds residency here)
     __shared__ u32 s_off32[CAP / 2 + 2];
@@ -645,21 +645,37 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const BDesc* __restrict_
             const u32 a = s_off[sub[j]], b = s_off[sub[j] + 1];
             u32 rank = 0;
             bool dup = false;
+            // four entries per trip: the reads are independent, so a sub-bucket (1.5 elements on average, 4-5 for the
+            // slowest lane of a wave) costs one LDS round trip instead of one per element
             if constexpr (PACKED) {
                 const u64 me = (key[j].lo << PK_BITS) | e;
-                for (u32 q = a; q < b; ++q) {
-                    const u64 o = s_klo[q];
-                    rank += o < me ? 1u : 0u;
-                    dup |= (o < me) && ((o >> PK_BITS) == key[j].lo);
+                for (u32 q = a; q < b; q += 4) {
+                    u64 o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = s_klo[q + k];  // s_klo has 4 slack entries; entries past b are masked
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool less = (q + k < b) && o[k] < me;
+                        rank += less ? 1u : 0u;
+                        dup |= less && ((o[k] >> PK_BITS) == key[j].lo);
+                    }
                 }
             } else {
-                for (u32 q = a; q < b; ++q) {
-                    Sfx<WS> o;
-                    o.lo = s_klo[q];
-                    if constexpr (WS) o.hi = s_khi[q];
-                    const bool less = sfx_less<WS>(o, (u32)s_idx[q], key[j], e);
-                    rank += less ? 1u : 0u;
-                    dup |= less && o == key[j];
+                for (u32 q = a; q < b; q += 2) {
+                    Sfx<WS> o[2];
+                    u32 oi[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        o[k].lo = s_klo[q + k];
+                        if constexpr (WS) o[k].hi = s_khi[q + k];
+                        oi[k] = (u32)s_idx[q + k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const bool less = (q + k < b) && sfx_less<WS>(o[k], oi[k], key[j], e);
+                        rank += less ? 1u : 0u;
+                        dup |= less && o[k] == key[j];
+                    }
                 }
             }
             fin[j] = a + rank;
