@@ -596,18 +596,20 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const BDesc* __restrict_
     }
     __syncthreads();
     {   // exclusive scan of the NB counts; each thread owns `per` consecutive entries
-        const u32 per = (NB + THREADS - 1) / THREADS;
+        const u32 per = (NB + THREADS - 1) / THREADS;  // <= ITEMS
         const u32 b0 = tid * per;
-        u32 sum = 0, mx = 0;
-        for (u32 k = 0; k < per; ++k) {
-            const u32 v = (b0 + k < NB) ? s_off[b0 + k] : 0u;
-            sum += v;
-            mx = v > mx ? v : mx;
+        u32 sum = 0, mx = 0, cnt[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {  // counts stay in registers: the write-back below does not re-read them
+            cnt[k] = ((u32)k < per && b0 + k < NB) ? s_off[b0 + k] : 0u;
+            sum += cnt[k];
+            mx = cnt[k] > mx ? cnt[k] : mx;
         }
         if (mx > MSD_LIMIT) atomicMax(&s_max, mx);
         u32 ex = block_exclusive_scan<THREADS, u32>(sum, s_scan, nullptr);
-        for (u32 k = 0; k < per; ++k) {
-            if (b0 + k < NB) { const u32 v = s_off[b0 + k]; s_off[b0 + k] = (u16)ex; ex += v; }
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            if ((u32)k < per && b0 + k < NB) { s_off[b0 + k] = (u16)ex; ex += cnt[k]; }
         }
     }
     __syncthreads();
@@ -636,13 +638,19 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const BDesc* __restrict_
     u32 fin[ITEMS];
     bool head[ITEMS];
     u32 wave_heads = 0;
+    u32 sa[ITEMS], sb[ITEMS];  // sub-bucket bounds of every item, fetched in one batch of independent LDS reads
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        sa[j] = sb[j] = 0;
+        if (valid[j]) { sa[j] = s_off[sub[j]]; sb[j] = s_off[sub[j] + 1]; }
+    }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         head[j] = false;
         fin[j] = 0;
         if (valid[j]) {
             const u32 e = w * EPW + j * 64 + lane;
-            const u32 a = s_off[sub[j]], b = s_off[sub[j] + 1];
+            const u32 a = sa[j], b = sb[j];
             u32 rank = 0;
             bool dup = false;
             // four entries per trip: the reads are independent, so a sub-bucket (1.5 elements on average, 4-5 for the
