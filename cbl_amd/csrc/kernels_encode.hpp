@@ -168,9 +168,14 @@ __device__ __forceinline__ void kmer_word(typename KmerT<WIDE>::type x, const Co
     T nk;
     unsigned pos;
     necklace_pos_fast<T>(x, P.KB, nk, pos);
-    u128 word = ((u128)nk << P.POS) | (u128)pos;
-    lo = (u64)word;
-    hi = (u64)(word >> 64);
+    if constexpr (!WIDE) {  // 0 < POS < 64: two plain 64-bit shifts instead of a generic 128-bit one
+        lo = ((u64)nk << P.POS) | (u64)pos;
+        hi = (u64)nk >> (64 - P.POS);
+    } else {
+        u128 word = ((u128)nk << P.POS) | (u128)pos;
+        lo = (u64)word;
+        hi = (u64)(word >> 64);
+    }
 }
 template <bool WIDE> __device__ __forceinline__ bool kmer_is_fwd(typename KmerT<WIDE>::type x) {  // Kmer::is_canonical, src/kmer.rs:94-96
     if constexpr (WIDE) return (popcount128(x) & 1u) == 0; else return (__builtin_popcountll(x) & 1) == 0;
@@ -181,11 +186,11 @@ template <bool WIDE> __device__ __forceinline__ typename KmerT<WIDE>::type extra
     const u32 w = s >> 4, o = (s & 15u) * 2u;
     if constexpr (!WIDE) {
         u64 a = ((u64)codes[w] << 32) | codes[w + 1];
-        u64 v = (a << o) | (o ? ((u64)codes[w + 2] >> (32 - o)) : 0ull);
+        u64 v = (a << o) | (((u64)codes[w + 2] << o) >> 32);  // no branch: o = 0 contributes nothing
         return v >> (64 - 2 * K);
     } else {
         u128 a = ((u128)codes[w] << 96) | ((u128)codes[w + 1] << 64) | ((u128)codes[w + 2] << 32) | (u128)codes[w + 3];
-        u128 v = (a << o) | (o ? ((u128)codes[w + 4] >> (32 - o)) : (u128)0);
+        u128 v = (a << o) | (u128)(((u64)codes[w + 4] << o) >> 32);
         return v >> (128 - 2 * K);
     }
 }

@@ -33,7 +33,7 @@ template <> struct NkBits<nk_u128> {
     }
 };
 
-// x must already be masked to BITS bits. T = uint64_t (BITS <= 64... we only use BITS <= 62) or nk_u128.
+// x must already be masked to BITS bits, BITS < 8 * sizeof(T). T = uint64_t (BITS <= 62) or nk_u128 (BITS <= 118).
 template <typename T> __host__ __device__ inline void necklace_pos_fast(T x, unsigned BITS, T& necklace, unsigned& pos) {
     const T MASK = (BITS >= sizeof(T) * 8) ? ~(T)0 : ((((T)1) << BITS) - 1);
     if (x == 0 || x == MASK) {  // single-symbol words: every rotation equal, smallest p = 0
@@ -44,12 +44,20 @@ template <typename T> __host__ __device__ inline void necklace_pos_fast(T x, uns
     // rotl by s on the BITS-bit ring (0 < s < BITS)
     auto rotl_ring = [&](T v, unsigned s) -> T { return ((v << s) & MASK) | (v >> (BITS - s)); };
     T r = ~x & MASK;  // bit s: x has a zero at s                       (runs >= 1)
-    {   // two doubling steps first: most words hold a run of >= 4 zeros, which skips three of the linear steps
-        const T r2 = r & rotl_ring(r, 1);    // bit s: zeros at s, s-1          (runs >= 2)
-        const T r4 = r2 & rotl_ring(r2, 2);  // bit s: zeros at s .. s-3        (runs >= 4)
-        r = r4 ? r4 : (r2 ? r2 : r);
+    {   // Doubling, then a greedy binary refinement: with R_L = "a run of >= L zeros ends (downwards) at bit s",
+        // R_{L+d} = R_L & rotl(R_L, d) for d <= L. Every lane of a wave executes the same few steps (a lane-dependent
+        // linear search cost every lane the length of the longest run in the wave).
+        const T r2 = r & rotl_ring(r, 1);    // runs >= 2
+        const T r4 = r2 & rotl_ring(r2, 2);  // runs >= 4
+        if (r4) {
+            r = r4;                                            // L = 4
+            T t = r & rotl_ring(r, 4); r = t ? t : r;          // L in {4, 8}
+            t = r & rotl_ring(r, 2); r = t ? t : r;            // L in {4, 6, 8, 10}
+        } else if (r2) {
+            r = r2;                                            // L in {2, 3}
+        }
     }
-    for (;;) {
+    for (;;) {  // at most a step or two for all but the longest runs
         T t = r & rotl_ring(r, 1);
         if (t == 0) break;
         r = t;
@@ -62,7 +70,8 @@ template <typename T> __host__ __device__ inline void necklace_pos_fast(T x, uns
         int s = TB - 1 - NkBits<T>::clz(r);  // highest remaining candidate
         r &= ~(((T)1) << s);
         unsigned p = BITS - 1 - (unsigned)s;
-        T rot = p == 0 ? x : (((x << p) & MASK) | (x >> (BITS - p)));
+        // BITS < bit width of T (K is odd): p = 0 shifts right by BITS, which leaves 0 of the masked x
+        T rot = ((x << p) & MASK) | (x >> (BITS - p));
         if (first || rot < best) {
             best = rot;
             bestp = p;
