@@ -349,16 +349,31 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
                       hipLaunchKernelGGL(k_tile_table_grp, grid1(nt_maxC, 256), dim3(256), 0, c->stream, G, low_bits, grp_start.get(), seg_start.get(), (u32)N, grp_first.get(), nt_devC.get(),
                                          t_startC.get(), t_countC.get(), t_segC.get());
                   } }
+                // more groups than the table method takes: the last pass finds the bucket starts itself (fused directory)
+                const bool fused_dir = last && !tbl_dir;
+                const u32 amb_stride = 1u << dfn.nbits;
+                Buf<u32> amb;
+                if (fused_dir) {
+                    amb = Buf<u32>(c->pool, (size_t)ntm * amb_stride);
+                    CBLX_HIP(hipMemsetAsync(start_dense.get(), 0xFF, nprefix * 4, c->stream));
+                }
                 { StageTimer t(c, ST_SCATTER);
                   hipLaunchKernelGGL((k_radix_scatter<H, H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, colpre.get(),
-                                     adj.get(), lo2, hout, nd, ndp); }
+                                     adj.get(), lo2, hout, nd, ndp, fused_dir ? start_dense.get() : (u32*)nullptr, P.SB, RB, low_bits, amb.get(), amb_stride); }
+                if (fused_dir) {
+                    StageTimer t(c, ST_DIR);
+                    hipLaunchKernelGGL(k_dir_resolve<H>, grid1((u64)ntm * amb_stride, 256), dim3(256), 0, c->stream, ntd, amb_stride, (const u32*)amb.get(), tv.seg,
+                                       (const u32*)seg_start.get(), (const u64*)lo2, (const H*)hout, P.SB, RB, start_dense.get());
+                    CBLX_HIP(hipStreamSynchronize(c->stream));  // amb is released at the end of this scope
+                    have_dense = true;
+                }
                 have_dig = ndp != nullptr;
                 if (last && tbl_dir) {
                     StageTimer t(c, ST_DIR);
                     hipLaunchKernelGGL(k_dir_gather, dim3(G), dim3(256), 0, c->stream, low_bits, last_bits, grp_tiles ? grp_first.get() : seg_first.get(), seg_start.get(), ntd,
                                        colpre.get(), coltot.get(), adj.get(), start_dense.get());
                     if (grp_tiles)  // cold segments kept plain tiles: their boundaries come from their (few) records, now in lo2
-                        hipLaunchKernelGGL(k_boundaries_cold<H>, dim3(nseg), dim3(256), 0, c->stream, (const u64*)lo2, (const H*)hout, P.SB, RB, seg_start.get(), start_dense.get());
+                        hipLaunchKernelGGL(k_boundaries_cold<H>, dim3(nseg, 32), dim3(256), 0, c->stream, (const u64*)lo2, (const H*)hout, P.SB, RB, seg_start.get(), start_dense.get());
                     have_dense = true;
                 }
             };

@@ -295,7 +295,9 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
                                                                DigitFn dfn, const u32* __restrict__ colpre,
                                                                const u32* __restrict__ adj, u64* __restrict__ out_lo,
                                                                OutHiT* __restrict__ out_hi, DigitBits next_dfn = DigitBits{0, 0},
-                                                               u8* __restrict__ out_next = nullptr) {
+                                                               u8* __restrict__ out_next = nullptr, u32* __restrict__ start_dense = nullptr,
+                                                               u32 pfx_shift = 0, u32 pfx_bits = 0, u32 grp_bits = 0, u32* __restrict__ amb = nullptr,
+                                                               u32 amb_stride = 0) {
     constexpr bool STAGE_HI = HiTraits<HiT>::has && HiTraits<OutHiT>::has;
     __shared__ u64 s_lo[RDX_TILE];
     __shared__ typename std::conditional<STAGE_HI, HiT, u8>::type s_hi[STAGE_HI ? RDX_TILE : 1];
@@ -325,6 +327,11 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
     }
     tile_rank<RDX_THREADS, RDX_ITEMS>(digit, pos, s_wcnt, s_dbase, s_scan, RDX_ITEMS);
     if (tid < 256) s_gbase[tid] = (u64)adj[seg * 256 + tid] + colpre[(u64)tile * 256 + tid] - s_dbase[tid];
+    u32 g_first = 0;
+    if (start_dense) {  // fused directory (last pass): group the tile starts in; its row of parked candidates starts empty
+        g_first = get_bits(lo_t[0], (u64)ld_hi<HiT>(hi_t, 0), pfx_shift, pfx_bits) & ((1u << grp_bits) - 1u);
+        if (tid < amb_stride) amb[(u64)tile * amb_stride + tid] = 0xFFFFFFFFu;
+    }
 #pragma unroll
     for (int j = 0; j < RDX_ITEMS; ++j) {
         s_lo[pos[j]] = klo[j];  // pos < RDX_TILE always; tail slots land in [n_tile, RDX_TILE)
@@ -347,8 +354,42 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
             // side channel: the next pass's histogram reads 1 byte per record instead of the record (measured: packing four
             // digits of a run into one unaligned dword store is slower than the byte stores — the extra LDS pass costs more)
             if (out_next) out_next[dst] = (u8)next_dfn(a, b);
+            // LAST pass, bucket directory on the fly: the tile (sorted by this digit, and by the lower digits before that)
+            // is in final order, so a record whose prefix differs from its predecessor's starts a bucket — unless an
+            // earlier tile holds the same prefix, which can only be for the GROUP (value of the lower digits) the tile
+            // starts in. Those (at most one per digit) are parked in amb[tile][digit] and settled by k_dir_resolve, which
+            // looks at the record in front of them in the finished array (atomicMin here cost 7 ms at 2^28 prefixes).
+            if (start_dense) {
+                const u32 p = get_bits(a, b, pfx_shift, pfx_bits);
+                bool st = s == 0;
+                if (s > 0) {
+                    const u64 a1 = s_lo[s - 1];
+                    u64 b1 = 0;
+                    if constexpr (STAGE_HI) b1 = (u64)s_hi[s - 1];
+                    st = get_bits(a1, b1, pfx_shift, pfx_bits) != p;
+                }
+                if (st) {
+                    if ((p & ((1u << grp_bits) - 1u)) == g_first) amb[(u64)tile * amb_stride + d] = (u32)dst;
+                    else start_dense[((u64)seg << pfx_bits) | p] = (u32)dst;
+                }
+            }
         }
     }
+}
+// settles the parked candidates of the fused directory: a candidate starts its bucket iff the record in front of it (in
+// the finished array) has another prefix or belongs to another segment
+template <typename HiT>
+__global__ void k_dir_resolve(const u32* __restrict__ ntiles_dev, u32 amb_stride, const u32* __restrict__ amb, const u16* __restrict__ t_seg,
+                              const u32* __restrict__ seg_start, const u64* __restrict__ lo, const HiT* __restrict__ hi, u32 pfx_shift,
+                              u32 pfx_bits, u32* __restrict__ start_dense) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (u64)*ntiles_dev * amb_stride) return;
+    const u32 dst = amb[i];
+    if (dst == 0xFFFFFFFFu) return;
+    const u32 seg = t_seg ? t_seg[i / amb_stride] : 0u;
+    const u32 p = get_bits(lo[dst], (u64)ld_hi<HiT>(hi, dst), pfx_shift, pfx_bits);
+    const bool first = dst == (seg_start ? seg_start[seg] : 0u) || get_bits(lo[dst - 1], (u64)ld_hi<HiT>(hi, dst - 1), pfx_shift, pfx_bits) != p;
+    if (first) start_dense[((u64)seg << pfx_bits) | p] = dst;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -510,14 +551,14 @@ __global__ __launch_bounds__(256) void k_dir_gather(u32 low_bits, u32 last_bits,
     start_dense[prefix] = p1 > p0 ? adj[s * 256 + d] + p0 : 0xFFFFFFFFu;
 }
 
-// bucket boundaries of the cold segments from their (few) sorted records; one workgroup per segment
+// bucket boundaries of the cold segments from their (few) sorted records
 template <typename HiT>
 __global__ __launch_bounds__(256) void k_boundaries_cold(const u64* __restrict__ lo, const HiT* __restrict__ hi, u32 SB, u32 R, const u32* __restrict__ seg_start,
                                                          u32* __restrict__ start_dense) {
-    const u32 s = blockIdx.x;
+    const u32 s = blockIdx.x;  // gridDim.y workgroups share a segment
     if (!seg_cold(seg_start, s)) return;
     const u32 a = seg_start[s], b = seg_start[s + 1];
-    for (u32 i = a + threadIdx.x; i < b; i += blockDim.x) {
+    for (u32 i = a + blockIdx.y * blockDim.x + threadIdx.x; i < b; i += blockDim.x * gridDim.y) {
         const u32 p = get_bits(lo[i], (u64)ld_hi<HiT>(hi, i), SB, R);
         if (i == a || get_bits(lo[i - 1], (u64)ld_hi<HiT>(hi, i - 1), SB, R) != p) start_dense[(s << R) | p] = i;
     }
