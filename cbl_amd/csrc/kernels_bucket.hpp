@@ -533,6 +533,16 @@ template <bool WS> __device__ __forceinline__ u32 sfx_top_bits(const Sfx<WS>& k,
         return (u32)(k.lo >> (SB - nbits));
     }
 }
+// Sub-bucket of a bucket that can only end up a Vec (run length <= threshold, not a Trie yet): any function of the suffix
+// will do, and a hash of ALL its bits spreads what the top bits do not — consecutive k-mers of a read tend to share the
+// leading bits of their necklace, prefix and top suffix bits alike (the locality CBL is built on).
+template <bool WS> __device__ __forceinline__ u32 sfx_hash_bits(const Sfx<WS>& k, u32 nbits) {
+    u64 v = k.lo;
+    if constexpr (WS) v ^= k.hi * 0xD6E8FEB86659FD93ull;
+    v ^= v >> 32;
+    v *= 0x9E3779B97F4A7C15ull;
+    return nbits ? (u32)(v >> (64 - nbits)) : 0u;
+}
 template <bool WS> __device__ __forceinline__ bool sfx_less(const Sfx<WS>& a, u32 ia, const Sfx<WS>& b, u32 ib) {
     if constexpr (WS) {
         if (a.hi != b.hi) return a.hi < b.hi;
@@ -576,6 +586,7 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const BDesc* __restrict_
     u32 nbits = 32 - __builtin_clz(c - 1 > 0 ? c - 1 : 1);  // ceil(log2 c)
     if (nbits > SB) nbits = SB;
     const u32 NB = 1u << nbits;  // <= CAP because c <= CAP
+    const bool vec_only = c <= VEC_THRESHOLD && !res_trie;  // no sorted output needed: sub-buckets by hash
 
     for (u32 i = tid; i < NB / 2 + 1; i += THREADS) s_off32[i] = 0;
     if (tid == 0) s_max = 0;
@@ -589,7 +600,7 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const BDesc* __restrict_
         valid[j] = (u32)j < R && e < c;
         if (valid[j]) {
             key[j] = load_sfx<WS, HiT>(lo, hi, s0 + e, SB);
-            sub[j] = sfx_top_bits<WS>(key[j], SB, nbits);
+            sub[j] = vec_only ? sfx_hash_bits<WS>(key[j], nbits) : sfx_top_bits<WS>(key[j], SB, nbits);
             const u32 sh = (sub[j] & 1u) * 16u;
             arr[j] = (atomicAdd(&s_off32[sub[j] >> 1], 1u << sh) >> sh) & 0xFFFFu;
         }
