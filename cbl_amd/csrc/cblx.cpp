@@ -426,10 +426,17 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
     std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
     u64* a_lo = rec.lo.get();
     HiT* a_hi = (HiT*)rec.hi.get();
-    if (ln[CLS_SMALL]) {
+    if (ln[CLS_SMALL] | ln[CLS_S32] | ln[CLS_S16]) {
         StageTimer t(c, ST_BSMALL);
-        hipLaunchKernelGGL((k_bucket_small<C::WS, HiT>), grid1((u64)ln[CLS_SMALL] * 64, 256), dim3(256), 0, c->stream,
-                           lists.get() + (size_t)CLS_SMALL * nb, list_n.get() + CLS_SMALL, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+        if (ln[CLS_S16])
+            hipLaunchKernelGGL((k_bucket_small<16, C::WS, HiT>), grid1((u64)ln[CLS_S16] * 16, 256), dim3(256), 0, c->stream,
+                               lists.get() + (size_t)CLS_S16 * nb, list_n.get() + CLS_S16, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+        if (ln[CLS_S32])
+            hipLaunchKernelGGL((k_bucket_small<32, C::WS, HiT>), grid1((u64)ln[CLS_S32] * 32, 256), dim3(256), 0, c->stream,
+                               lists.get() + (size_t)CLS_S32 * nb, list_n.get() + CLS_S32, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+        if (ln[CLS_SMALL])
+            hipLaunchKernelGGL((k_bucket_small<64, C::WS, HiT>), grid1((u64)ln[CLS_SMALL] * 64, 256), dim3(256), 0, c->stream,
+                               lists.get() + (size_t)CLS_SMALL * nb, list_n.get() + CLS_SMALL, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
     }
     {
         StageTimer t(c, ST_BMED);

@@ -119,7 +119,7 @@ __device__ __forceinline__ bool dir_lookup(const DirView& d, u32 p, u64& rank) {
 }
 
 // ---- classification of buckets by run length -----------------------------------------------------------
-enum { CLS_SMALL = 0, CLS_M64 = 1, CLS_M128 = 2, CLS_M256 = 3, CLS_M512 = 4, CLS_M1024 = 5, CLS_HUGE = 6, CLS_N = 7 };
+enum { CLS_SMALL = 0, CLS_M64 = 1, CLS_M128 = 2, CLS_M256 = 3, CLS_M512 = 4, CLS_M1024 = 5, CLS_HUGE = 6, CLS_S16 = 7, CLS_S32 = 8, CLS_N = 9 };
 static const u32 SMALL_MAX = 64;
 static const u32 MED_ITEMS = 8;
 
@@ -175,7 +175,10 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify(u64 nb, u32 med_m
         if (rc != 0 && c == rc) {  // untouched by this batch: keep as is (src/wordset/mod.rs:213-214 only re-checks touched buckets)
             out_count[r] = rc;
             out_kind[r] = rk;
-        } else if (c <= SMALL_MAX && rk != KIND_TRIE) cls = CLS_SMALL;
+        } else if (c == 1 && rc == 0) {  // a single new word: nothing to deduplicate, it already sits in its slot
+            out_count[r] = 1;
+            out_kind[r] = KIND_VEC;
+        } else if (c <= SMALL_MAX && rk != KIND_TRIE) cls = c <= 16 ? CLS_S16 : c <= 32 ? CLS_S32 : CLS_SMALL;  // lanes per bucket: 16 / 32 / 64
         else if (c <= 64 * MED_ITEMS) cls = CLS_M64;    // workgroup size follows the run length: THREADS = CAP / 8
         else if (c <= 128 * MED_ITEMS) cls = CLS_M128;
         else if (c <= 256 * MED_ITEMS) cls = CLS_M256;
@@ -308,31 +311,37 @@ template <bool WS> __device__ __forceinline__ Sfx<WS> shfl_sfx(const Sfx<WS>& s,
     return r;
 }
 
-// ---- KRN-3 small: one wave per bucket, run <= 64, all-pairs "seen before?" (the reference's own
-// `vec.contains(x)` semantics, src/trievec/mod.rs:81-87), ordered compaction by ballot ----------------------
-template <bool WS, typename HiT>
+// ---- KRN-3 small: WIDTH lanes per bucket (run <= WIDTH <= 64; 64 / WIDTH buckets share a wave), all-pairs "seen
+// before?" (the reference's own `vec.contains(x)` semantics, src/trievec/mod.rs:81-87), ordered compaction by ballot ---
+template <int WIDTH, bool WS, typename HiT>
 __global__ __launch_bounds__(256) void k_bucket_small(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
                                                       u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
                                                       u32* __restrict__ out_count, u8* __restrict__ out_kind) {
-    const u32 wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wv >= *list_n) return;
-    const BDesc dsc = list[wv];
+    const u32 g = (blockIdx.x * blockDim.x + threadIdx.x) / WIDTH, lane = threadIdx.x & 63, gl = lane & (WIDTH - 1);
+    const bool live = g < *list_n;
+    BDesc dsc{0, 0, 0};
+    if (live) dsc = list[g];
     const u32 r = dsc.r;
     const u64 s0 = dsc.start;
-    const u32 c = dsc.c & ~BDESC_TRIE;
+    const u32 c = dsc.c & ~BDESC_TRIE;  // 0 for the idle groups of the last wave
     Sfx<WS> mine;
     mine.lo = 0;
     if constexpr (WS) mine.hi = 0;
-    if (lane < c) mine = load_sfx<WS, HiT>(lo, hi, s0 + lane, SB);
+    if (gl < c) mine = load_sfx<WS, HiT>(lo, hi, s0 + gl, SB);
+    // the groups of a wave loop together: up to the longest run among them
+    u32 cmax = c;
+#pragma unroll
+    for (int o = WIDTH; o < 64; o <<= 1) { const u32 t = (u32)__shfl_xor((int)cmax, o, 64); cmax = t > cmax ? t : cmax; }
     bool dup = false;
-    for (u32 j = 0; j + 1 < c; ++j) {
-        Sfx<WS> o = shfl_sfx<WS>(mine, (int)j);
-        if (j < lane && o == mine) dup = true;
+    const u32 gbase = lane & ~(u32)(WIDTH - 1);
+    for (u32 j = 0; j + 1 < cmax; ++j) {
+        Sfx<WS> o = shfl_sfx<WS>(mine, (int)(gbase + j));
+        if (j < gl && j < c && o == mine) dup = true;
     }
-    const bool keep = lane < c && !dup;
-    const u64 bal = __ballot(keep);
-    if (keep) store_sfx<WS, HiT>(lo, hi, s0 + mbcnt(bal), mine);
-    if (lane == 0) {
+    const bool keep = gl < c && !dup;
+    const u64 bal = (__ballot(keep) >> gbase) & (WIDTH == 64 ? ~0ull : ((1ull << WIDTH) - 1ull));
+    if (keep) store_sfx<WS, HiT>(lo, hi, s0 + (u32)__builtin_popcountll(bal & ((1ull << gl) - 1ull)), mine);
+    if (gl == 0 && live) {
         out_count[r] = (u32)__builtin_popcountll(bal);
         out_kind[r] = KIND_VEC;
     }
