@@ -426,7 +426,7 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
     std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
     u64* a_lo = rec.lo.get();
     HiT* a_hi = (HiT*)rec.hi.get();
-    if (ln[CLS_SMALL] | ln[CLS_S32] | ln[CLS_S16]) {
+    if (ln[CLS_S32] | ln[CLS_S16]) {
         StageTimer t(c, ST_BSMALL);
         if (ln[CLS_S16])
             hipLaunchKernelGGL((k_bucket_small<16, C::WS, HiT>), grid1((u64)ln[CLS_S16] * 16, 256), dim3(256), 0, c->stream,
@@ -434,9 +434,6 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
         if (ln[CLS_S32])
             hipLaunchKernelGGL((k_bucket_small<32, C::WS, HiT>), grid1((u64)ln[CLS_S32] * 32, 256), dim3(256), 0, c->stream,
                                lists.get() + (size_t)CLS_S32 * nb, list_n.get() + CLS_S32, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
-        if (ln[CLS_SMALL])
-            hipLaunchKernelGGL((k_bucket_small<64, C::WS, HiT>), grid1((u64)ln[CLS_SMALL] * 64, 256), dim3(256), 0, c->stream,
-                               lists.get() + (size_t)CLS_SMALL * nb, list_n.get() + CLS_SMALL, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
     }
     {
         StageTimer t(c, ST_BMED);
@@ -446,6 +443,9 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
         CBLX_HIP(hipMemsetAsync(retry_n.get(), 0, 4, c->stream));
         auto msd = [&](auto packed_tag) {
             constexpr bool PK = decltype(packed_tag)::value;
+            if (ln[CLS_M16])
+                hipLaunchKernelGGL((k_bucket_msd<64, 128, PK, C::WS, HiT>), dim3(ln[CLS_M16]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M16 * nb,
+                                   list_n.get() + CLS_M16, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
             if (ln[CLS_M64])
                 hipLaunchKernelGGL((k_bucket_msd<64, 512, PK, C::WS, HiT>), dim3(ln[CLS_M64]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M64 * nb,
                                    list_n.get() + CLS_M64, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());

@@ -119,8 +119,8 @@ __device__ __forceinline__ bool dir_lookup(const DirView& d, u32 p, u64& rank) {
 }
 
 // ---- classification of buckets by run length -----------------------------------------------------------
-enum { CLS_SMALL = 0, CLS_M64 = 1, CLS_M128 = 2, CLS_M256 = 3, CLS_M512 = 4, CLS_M1024 = 5, CLS_HUGE = 6, CLS_S16 = 7, CLS_S32 = 8, CLS_N = 9 };
-static const u32 SMALL_MAX = 64;
+enum { CLS_M16 = 0, CLS_M64 = 1, CLS_M128 = 2, CLS_M256 = 3, CLS_M512 = 4, CLS_M1024 = 5, CLS_HUGE = 6, CLS_S16 = 7, CLS_S32 = 8, CLS_N = 9 };
+static const u32 SMALL_MAX = 32;  // all-pairs in a slice of a wave up to here; counting-sort kernels above
 static const u32 MED_ITEMS = 8;
 
 // One 16-byte descriptor per bucket and class: a bucket kernel starts from a single load instead of a chain of three.
@@ -178,7 +178,8 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify(u64 nb, u32 med_m
         } else if (c == 1 && rc == 0) {  // a single new word: nothing to deduplicate, it already sits in its slot
             out_count[r] = 1;
             out_kind[r] = KIND_VEC;
-        } else if (c <= SMALL_MAX && rk != KIND_TRIE) cls = c <= 16 ? CLS_S16 : c <= 32 ? CLS_S32 : CLS_SMALL;  // lanes per bucket: 16 / 32 / 64
+        } else if (c <= SMALL_MAX && rk != KIND_TRIE) cls = c <= 16 ? CLS_S16 : CLS_S32;  // lanes per bucket: 16 / 32
+        else if (c <= 16 * MED_ITEMS) cls = CLS_M16;
         else if (c <= 64 * MED_ITEMS) cls = CLS_M64;    // workgroup size follows the run length: THREADS = CAP / 8
         else if (c <= 128 * MED_ITEMS) cls = CLS_M128;
         else if (c <= 256 * MED_ITEMS) cls = CLS_M256;
