@@ -291,7 +291,7 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist_bytes(const u8* __re
 // into a global position (k_seg_adjust). OutHiT = NoHi drops the hi part on the way out (first pass of 65..72-bit words:
 // the bits it held are implied by the segment from then on).
 template <typename HiT, typename OutHiT, typename DigitFn>
-__global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __restrict__ lo, const HiT* __restrict__ hi, TileView tv,
+__global__ __launch_bounds__(RDX_THREADS, 8) void k_radix_scatter(const u64* __restrict__ lo, const HiT* __restrict__ hi, TileView tv,
                                                                DigitFn dfn, const u32* __restrict__ colpre,
                                                                const u32* __restrict__ adj, u64* __restrict__ out_lo,
                                                                OutHiT* __restrict__ out_hi, DigitBits next_dfn = DigitBits{0, 0},
@@ -302,7 +302,10 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
     __shared__ u64 s_lo[RDX_TILE];
     __shared__ typename std::conditional<STAGE_HI, HiT, u8>::type s_hi[STAGE_HI ? RDX_TILE : 1];
     __shared__ u8 s_dig[STAGE_HI ? 1 : RDX_TILE];  // digit of the staged record when it cannot be recomputed from lo alone
-    __shared__ u32 s_wcnt[(RDX_THREADS / 64) * 256];
+    // the ranking counters live in the staging area (they are dead before the first record is staged): 39 KB of LDS per
+    // workgroup instead of 47 KB = four resident workgroups per CU instead of three
+    static_assert((RDX_THREADS / 64) * 256 * 4 <= RDX_TILE * 8, "rank counters must fit the staging area");
+    u32* s_wcnt = reinterpret_cast<u32*>(s_lo);
     __shared__ u32 s_dbase[256];
     __shared__ u64 s_gbase[256];
     __shared__ u32 s_scan[RDX_THREADS / 64 + 1];
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_scatter(const u64* __rest
     }
     tile_rank<RDX_THREADS, RDX_ITEMS>(digit, pos, s_wcnt, s_dbase, s_scan, RDX_ITEMS);
     if (tid < 256) s_gbase[tid] = (u64)adj[seg * 256 + tid] + colpre[(u64)tile * 256 + tid] - s_dbase[tid];
+    __syncthreads();  // every wave is done with the rank counters before records are staged over them
     u32 g_first = 0;
     if (start_dense) {  // fused directory (last pass): group the tile starts in; its row of parked candidates starts empty
         g_first = get_bits(lo_t[0], (u64)ld_hi<HiT>(hi_t, 0), pfx_shift, pfx_bits) & ((1u << grp_bits) - 1u);
