@@ -142,6 +142,60 @@ __device__ __forceinline__ void tile_rank(const u32 (&digit)[ITEMS], u32 (&pos)[
         if ((u32)j < rounds) pos[j] += s_dbase[digit[j]] + my[digit[j]];
 }
 
+// Same ranking with digit and position in ONE register per element: in: dp[j] = digit; out: dp[j] = digit << 16 | position
+// (tile <= 65536 records). The scatter kernel is register-bound: 8 registers fewer keep it at 64 VGPRs without spills.
+template <int THREADS, int ITEMS>
+__device__ __forceinline__ void tile_rank_packed(u32 (&dp)[ITEMS], u32* s_wcnt, u32* s_dbase,
+                                          u32* s_scan /* THREADS/64+1 */, u32 rounds) {
+    constexpr int NW = THREADS / 64;
+    const u32 tid = threadIdx.x, w = tid >> 6;
+    for (u32 i = tid; i < NW * 256; i += THREADS) s_wcnt[i] = 0;
+    __syncthreads();
+    u32* my = s_wcnt + w * 256;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if ((u32)j < rounds) {
+            const u32 d = dp[j];
+            // lanes holding my digit: AND over the 8 bits of (ballot(bit) XNOR my bit). t = 0 / ~0 is my bit spread over
+            // a dword (one v_bfe_i32), so each half of the mask costs one v_xnor + one v_and per bit.
+            u32 m_lo = ~0u, m_hi = ~0u;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const u32 t = (u32)__builtin_amdgcn_sbfe((int)d, (unsigned)b, 1u);
+                const u64 bal = __ballot(t != 0);
+                m_lo &= ~((u32)bal ^ t);
+                m_hi &= ~((u32)(bal >> 32) ^ t);
+            }
+            const u32 lower = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+            const u32 tot = (u32)__builtin_popcount(m_lo) + (u32)__builtin_popcount(m_hi);
+            const u32 old = my[d];
+            __builtin_amdgcn_wave_barrier();
+            if (lower == 0) my[d] = old + tot;
+            __builtin_amdgcn_wave_barrier();
+            dp[j] = (old + lower) | (d << 16);
+        }
+    }
+    __syncthreads();
+    // per digit: exclusive scan across waves; digit totals -> exclusive scan across digits
+    u32 dtot = 0;
+    if (tid < 256) {
+        u32 run = 0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) {
+            u32 t = s_wcnt[ww * 256 + tid];
+            s_wcnt[ww * 256 + tid] = run;
+            run += t;
+        }
+        dtot = run;
+    }
+    u32 ex = block_exclusive_scan<THREADS, u32>(dtot, s_scan, nullptr);
+    if (tid < 256) s_dbase[tid] = ex;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+        if ((u32)j < rounds) { const u32 d = dp[j] >> 16; dp[j] += s_dbase[d] + my[d]; }
+}
+
 #ifndef CBLX_RDX_THREADS
 #define CBLX_RDX_THREADS 512
 #endif
@@ -291,7 +345,7 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist_bytes(const u8* __re
 // into a global position (k_seg_adjust). OutHiT = NoHi drops the hi part on the way out (first pass of 65..72-bit words:
 // the bits it held are implied by the segment from then on).
 template <typename HiT, typename OutHiT, typename DigitFn>
-__global__ __launch_bounds__(RDX_THREADS, 8) void k_radix_scatter(const u64* __restrict__ lo, const HiT* __restrict__ hi, TileView tv,
+__global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT>::has) ? 4 : 8) void k_radix_scatter(const u64* __restrict__ lo, const HiT* __restrict__ hi, TileView tv,
                                                                DigitFn dfn, const u32* __restrict__ colpre,
                                                                const u32* __restrict__ adj, u64* __restrict__ out_lo,
                                                                OutHiT* __restrict__ out_hi, DigitBits next_dfn = DigitBits{0, 0},
@@ -316,7 +370,7 @@ __global__ __launch_bounds__(RDX_THREADS, 8) void k_radix_scatter(const u64* __r
 
     u64 klo[RDX_ITEMS];
     typename std::conditional<std::is_same<HiT, u64>::value, u64, u32>::type khi[RDX_ITEMS];
-    u32 digit[RDX_ITEMS], pos[RDX_ITEMS];
+    u32 digit[RDX_ITEMS];
     const u64* __restrict__ lo_t = lo + tbase;
     const HiT* __restrict__ hi_t = HiTraits<HiT>::has ? hi + tbase : hi;
 #pragma unroll
@@ -328,7 +382,7 @@ __global__ __launch_bounds__(RDX_THREADS, 8) void k_radix_scatter(const u64* __r
         khi[j] = ld_hi<HiT>(hi_t, eo);
         digit[j] = valid ? dfn(klo[j], (u64)khi[j]) : 255u;
     }
-    tile_rank<RDX_THREADS, RDX_ITEMS>(digit, pos, s_wcnt, s_dbase, s_scan, RDX_ITEMS);
+    tile_rank_packed<RDX_THREADS, RDX_ITEMS>(digit, s_wcnt, s_dbase, s_scan, RDX_ITEMS);  // digit[j] = digit << 16 | position
     if (tid < 256) s_gbase[tid] = (u64)adj[seg * 256 + tid] + colpre[(u64)tile * 256 + tid] - s_dbase[tid];
     __syncthreads();  // every wave is done with the rank counters before records are staged over them
     u32 g_first = 0;
@@ -338,9 +392,10 @@ __global__ __launch_bounds__(RDX_THREADS, 8) void k_radix_scatter(const u64* __r
     }
 #pragma unroll
     for (int j = 0; j < RDX_ITEMS; ++j) {
-        s_lo[pos[j]] = klo[j];  // pos < RDX_TILE always; tail slots land in [n_tile, RDX_TILE)
-        if constexpr (STAGE_HI) s_hi[pos[j]] = (HiT)khi[j];
-        else s_dig[pos[j]] = (u8)digit[j];
+        const u32 pj = digit[j] & 0xFFFFu;  // < RDX_TILE always; tail slots land in [n_tile, RDX_TILE)
+        s_lo[pj] = klo[j];
+        if constexpr (STAGE_HI) s_hi[pj] = (HiT)khi[j];
+        else s_dig[pj] = (u8)(digit[j] >> 16);
     }
     __syncthreads();
 #pragma unroll
