@@ -336,7 +336,7 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
                 u8* ndp = nd.nbits && dig.get() ? dig.get() : nullptr;
                 { StageTimer t(c, ST_HIST);
                   if (have_dig)
-                      hipLaunchKernelGGL(k_radix_hist_bytes, dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, (const u8*)dig.get(), tv, counts.get());
+                      hipLaunchKernelGGL(k_radix_hist_bytes, dim3((xcd_grid(ntm) + HISTB_WAVES - 1) / HISTB_WAVES + 8), dim3(64 * HISTB_WAVES), 0, c->stream, (const u8*)dig.get(), tv, counts.get());
                   else
                       hipLaunchKernelGGL((k_radix_hist<H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, counts.get()); }
                 { StageTimer t(c, ST_SCAN);

@@ -312,18 +312,22 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const u64* __restric
 // The same histogram from the DIGIT SIDE CHANNEL the previous pass's scatter left behind (dig[i] = this pass's digit
 // of record i): 1 byte per record is read instead of the whole record. A thread takes one aligned 8-byte word of the
 // tile's byte range (RDX_THREADS * 8 = RDX_TILE bytes, plus one word for an unaligned start).
-__global__ __launch_bounds__(RDX_THREADS) void k_radix_hist_bytes(const u8* __restrict__ dig, TileView tv, u32* __restrict__ counts) {
-    __shared__ u32 s_wcnt[(RDX_THREADS / 64) * 256];
-    const u32 tid = threadIdx.x, w = tid >> 6;
-    for (u32 i = tid; i < (RDX_THREADS / 64) * 256; i += RDX_THREADS) s_wcnt[i] = 0;
-    __syncthreads();
+static const int HISTB_WAVES = 4;  // tiles per workgroup of k_radix_hist_bytes
+__global__ __launch_bounds__(64 * HISTB_WAVES) void k_radix_hist_bytes(const u8* __restrict__ dig, TileView tv, u32* __restrict__ counts) {
+    // one WAVE per tile (no workgroup barrier): a lane takes every 64th aligned 8-byte word of the tile's byte range
+    __shared__ u32 s_cnt[HISTB_WAVES * 256];
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32* my = s_cnt + w * 256;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) my[k * 64 + lane] = 0;
     u32 tile, n_tile, seg;
     u64 tbase;
-    if (!tile_get(tv, blockIdx.x, tile, tbase, n_tile, seg)) return;
-    u32* my = s_wcnt + w * 256;
+    // tile_get maps a WORKGROUP index to a tile (XCD-aware); here the unit is the wave
+    if (!tile_get(tv, blockIdx.x * HISTB_WAVES + w, tile, tbase, n_tile, seg)) return;
+    __builtin_amdgcn_wave_barrier();
     const u64 w0 = tbase >> 3, wend = (tbase + n_tile + 7) >> 3;  // aligned words covering [tbase, tbase + n_tile)
     const u64* __restrict__ words = reinterpret_cast<const u64*>(dig);
-    for (u64 wi = w0 + tid; wi < wend; wi += RDX_THREADS) {
+    for (u64 wi = w0 + lane; wi < wend; wi += 64) {
         const u64 v = words[wi];
         const u64 b0 = wi << 3;
 #pragma unroll
@@ -332,13 +336,10 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist_bytes(const u8* __re
             if (pos >= tbase && pos < tbase + n_tile) atomicAdd(&my[(u32)(v >> (8 * k)) & 255u], 1u);
         }
     }
-    __syncthreads();
-    if (tid < 256) {
-        u32 t = 0;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
 #pragma unroll
-        for (int ww = 0; ww < RDX_THREADS / 64; ++ww) t += s_wcnt[ww * 256 + tid];
-        counts[(u64)tile * 256 + tid] = t;
-    }
+    for (int k = 0; k < 4; ++k) counts[(u64)tile * 256 + k * 64 + lane] = my[k * 64 + lane];
 }
 
 // scatter. colpre[tile * 256 + d] = records with digit d in earlier tiles (pure column prefix); adj[seg * 256 + d] turns it
