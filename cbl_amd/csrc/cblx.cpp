@@ -802,7 +802,17 @@ void ingest_abort_seq(cblx_ctx* c) {  // drop the bases of an unfinished sequenc
     if (begin >= g.wb.issued) g.wb.fill = (size_t)(begin - g.wb.issued);
     else { g.wb.issued = begin; g.wb.fill = 0; }
 }
-void ingest_end_seq(cblx_ctx* c, u64 flush_at = 2ull << 30) {
+// the queue is bounded: past this many pending bases the batch is inserted (same result: batches go in in order).
+// CBLX_INGEST_FLUSH_BYTES overrides it (tests use a tiny value to exercise the incremental path).
+u64 ingest_flush_bytes() {
+    static const u64 v = [] {
+        const char* e = std::getenv("CBLX_INGEST_FLUSH_BYTES");
+        const u64 x = e ? std::strtoull(e, nullptr, 10) : 0;
+        return x ? x : (2ull << 30);
+    }();
+    return v;
+}
+void ingest_end_seq(cblx_ctx* c, u64 flush_at = ingest_flush_bytes()) {
     Ingest& g = c->ing;
     const u64 begin = g.nseq ? g.last_end : 0, len = g.nbytes - begin;
     if (len < c->P.K) {  // src/cbl.rs:329-334; the record is dropped from the queue
@@ -844,7 +854,7 @@ void ingest_seqs(cblx_ctx* c, const u8* bases, const u64* offsets, u64 n) {
     g.last_end = g.nbytes;
     g.wb.issued = g.nbytes;
     g.wo.issued = g.nseq * 8;
-    if (g.nbytes >= (2ull << 30)) flush(c);
+    if (g.nbytes >= ingest_flush_bytes()) flush(c);
 }
 void ingest_drop(cblx_ctx* c) {  // forget everything enqueued (clear / load)
     Ingest& g = c->ing;
@@ -1611,7 +1621,7 @@ int cblx_insert_fastx_file(cblx_ctx* c, const char* path, uint64_t* n_records) {
         while ((have_line = lr.next(p, n)) && n == 0) {}
         if (!have_line) return;
         if (p[0] != '>' && p[0] != '@') throw Error(CBLX_EFORMAT, "not a FASTA/FASTQ file (first record does not start with '>' or '@')");
-        const u64 flush_at = 1ull << 30;
+        const u64 flush_at = std::min<u64>(1ull << 30, ingest_flush_bytes());
         try {
         if (p[0] == '>') {
             bool open_rec = true;  // the header line has been consumed

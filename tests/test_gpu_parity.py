@@ -5,12 +5,14 @@ Mirrors the reference's own test shapes (/root/reference/src/cbl.rs:664-683 batc
 src/wordset/mod.rs:451-533) plus the edge cases of SURVEY.md §7 (non-ACGT bytes, multi-chunk sequences, short
 sequences, duplicates, Vec->Trie threshold, huge buckets, incremental inserts, load/insert, merge).
 """
+import os
 import random
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 torch = pytest.importorskip("torch")
 
@@ -587,3 +589,44 @@ def test_fastx_reader_variants(tmp_path):
     (tmp_path / "empty.fa").write_bytes(b"")
     g = cbl_amd.CBL(k, pb)
     assert g.insert_fastx_file(str(tmp_path / "empty.fa")) == 0 and g.count() == 0
+
+
+def test_bounded_ingest_queue_flushes_in_order(tmp_path):
+    """The pending-sequence queue is bounded (2 GiB of bases by default): past the bound a batch is inserted and the next
+    one goes through the incremental path. A tiny bound (child process: the bound is read once per process) must give the
+    same index through insert_seq, insert_seqs (bulk lanes) and the FASTA reader."""
+    _need_gpu()
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import cbl_amd
+from cbl_amd import synth
+from oracle import Oracle
+k, pb = 31, 24
+bases, offsets = synth.reads(9, 3000, 150)
+o = Oracle(k, pb); o.insert_seqs(bases, offsets); want = o.serialize()
+g = cbl_amd.CBL(k, pb)
+for i in range(len(offsets) - 1):
+    g.insert_seq(bases[int(offsets[i]):int(offsets[i + 1])].tobytes())
+assert g.serialize() == want, "insert_seq"
+g = cbl_amd.CBL(k, pb)
+for a in range(0, 3000, 700):
+    b = min(a + 700, 3000)
+    g.insert_seqs(bases[int(offsets[a]):int(offsets[b])], (offsets[a:b + 1] - offsets[a]).astype(np.uint64))
+assert g.serialize() == want, "insert_seqs"
+big_b, big_o = synth.reads(10, 20000, 150)   # 3 MB: the bulk lanes, bound hit inside one call
+o2 = Oracle(k, pb); o2.insert_seqs(big_b, big_o)
+g = cbl_amd.CBL(k, pb); g.insert_seqs(big_b, big_o.astype(np.uint64)); g.insert_seqs(big_b[:150 * 50], big_o[:51].astype(np.uint64))
+assert g.serialize() == o2.serialize(), "bulk"
+fa = %r
+open(fa, "wb").write(synth.fasta_bytes(bases, offsets))
+g = cbl_amd.CBL(k, pb); assert g.insert_fastx_file(fa) == 3000
+assert g.serialize() == want, "fasta"
+print("ok")
+""" % (ROOT, str(tmp_path / "q.fa"))
+    env = dict(os.environ, CBLX_INGEST_FLUSH_BYTES="100000")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
