@@ -100,7 +100,7 @@ struct Resident {
 struct Stage { const char* name; double ms = 0; u64 launches = 0; };
 enum { ST_CHUNKS, ST_ENCODE, ST_HIST, ST_SCAN, ST_SCATTER, ST_DIR, ST_BSMALL, ST_BMED, ST_BHUGE, ST_EXPAND, ST_N };
 const char* kStageNames[ST_N] = {"chunks", "encode", "radix_hist", "radix_scan", "radix_scatter", "directory",
-                                 "bucket_small", "bucket_medium", "bucket_huge", "expand_resident"};
+                                 "bucket_small", "bucket_medium", "bucket_huge", "merge_gather"};
 
 // Sequences enqueued by cblx_insert_seq / cblx_insert_seqs / the FASTA reader. They are staged straight into HBM
 // while the caller keeps enqueueing: small appends fill pinned write blocks that are DMA'd as they fill up, bulk
@@ -234,11 +234,12 @@ struct Records {
     const void* ext_hi = nullptr;
 };
 
+// KRN-2 + KRN-4 over N records: stable partition by prefix, then the directory (bitvector, rank directory, bucket table
+// with the RAW run of every prefix; nr.cnt / nr.kind are allocated, not filled). The sorted records end up in rec.lo/hi.
 // `countsA`: histogram of the first pass already accumulated by KRN-1 (empty Buf = compute it here)
-template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA = Buf<u32>()) {
+template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA, Resident& nr) {
     typedef typename C::HiT HiT;
     const Consts& P = c->P;
-    Resident nr;
     if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "more than 2^32-16 words in one index are not supported yet");
     // ping-pong: A = rec.lo/hi, B = rec.lo2/hi2. With an external source pass 0 reads it and writes A.
     const u64* lo = rec.ext_lo ? rec.ext_lo : rec.lo.get();
@@ -387,8 +388,6 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
     rec.lo2.reset();
     rec.hi2.reset();
     // -- KRN-4: bitvector, rank directory, bucket table
-    Buf<u32> res_count, out_count;
-    Buf<u8> res_kind;
     {
         StageTimer t(c, ST_DIR);
         Buf<u32> popc(c->pool, nwords);
@@ -413,19 +412,24 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
         hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, nr.start.get() + nr.nb, N);
         CBLX_HIP(hipGetLastError());
     }
+}
+
+// KRN-3 over the runs of `nr` (run of a prefix = [its resident suffixes as stored][the new words in stream order]) in the
+// arena a_lo / a_hi: per-bucket dedup / sort by size class; fills nr.cnt, nr.kind, nr.count. `old` = the resident index
+// the runs were built against (tells which buckets are untouched and which are Tries already).
+template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, typename C::HiT* a_hi, const DirView& old) {
+    typedef typename C::HiT HiT;
+    const Consts& P = c->P;
     {
-    // -- KRN-3: per-bucket dedup / sort, by size class
     const u64 nb = nr.nb;
     Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
     Buf<u32> list_n(c->pool, CLS_N);
-    res_count = Buf<u32>(c->pool, nb + 1);
-    res_kind = Buf<u8>(c->pool, nb + 1);
+    Buf<u32> res_count(c->pool, nb + 1);
+    Buf<u8> res_kind(c->pool, nb + 1);
     CBLX_HIP(hipMemsetAsync(list_n.get(), 0, CLS_N * 4, c->stream));
-    hipLaunchKernelGGL(k_classify, grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, C::WS ? 512u : 1024u, nr.prefix.get(), nr.start.get(), c->res.view(),
+    hipLaunchKernelGGL(k_classify, grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, C::WS ? 512u : 1024u, nr.prefix.get(), nr.start.get(), old,
                        res_count.get(), res_kind.get(), nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get());
     std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
-    u64* a_lo = rec.lo.get();
-    HiT* a_hi = (HiT*)rec.hi.get();
     if (ln[CLS_S32] | ln[CLS_S16]) {
         StageTimer t(c, ST_BSMALL);
         if (ln[CLS_S16])
@@ -495,43 +499,97 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
         hipLaunchKernelGGL(k_sum_u32, dim3((unsigned)std::min<u64>(2048, std::max<u64>(1, ceil_div(nr.nb, 256)))), dim3(256), 0, c->stream, nr.cnt.get(), nr.nb, total.get());
         nr.count = d2h<u64>(c, total.get());
     }
-    nr.a_lo = std::move(rec.lo);
-    if (C::WS) {
-        // arena hi lives in the records' hi buffer (u64 elements in this configuration)
-        nr.a_hi.pool = rec.hi.pool; nr.a_hi.p = (u64*)rec.hi.p; nr.a_hi.n = rec.hi.n / 8;
-        rec.hi.p = nullptr; rec.hi.n = 0;
-    } else {
-        rec.hi.reset();
+}
+
+// rows of k_merge_table's `other` side for a freshly partitioned batch: every run is a Vec of its raw length
+__global__ void k_run_lengths(u64 nb, const u64* __restrict__ start, u32* __restrict__ cnt, u8* __restrict__ kind) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nb) return;
+    cnt[r] = (u32)(start[r + 1] - start[r]);
+    kind[r] = KIND_VEC;
+}
+
+// One batch of N new words (rec, first n_pre slots unused = 0) into the index.
+//   Empty index: partition + buckets, the sorted record array becomes the arena.
+//   Non-empty index: only the NEW words are partitioned; the resident buckets are already grouped by prefix, so the merged
+//   directory is the OR of the two bitvectors and every merged run = [resident suffixes as stored][new words of the
+//   prefix] is gathered straight from the two arrays (the resident words are never expanded and re-partitioned).
+template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA = Buf<u32>()) {
+    typedef typename C::HiT HiT;
+    constexpr bool WS = C::WS;
+    const Consts& P = c->P;
+    Resident nb_;  // directory of the batch
+    partition_and_directory<C>(c, rec, N, std::move(countsA), nb_);
+    auto adopt_arena = [&](Resident& nr) {
+        nr.a_lo = std::move(rec.lo);
+        if (WS) {  // arena hi lives in the records' hi buffer (u64 elements in this configuration)
+            nr.a_hi.pool = rec.hi.pool; nr.a_hi.p = (u64*)rec.hi.p; nr.a_hi.n = rec.hi.n / 8;
+            rec.hi.p = nullptr; rec.hi.n = 0;
+        } else {
+            rec.hi.reset();
+        }
+    };
+    if (c->res.count == 0) {
+        bucket_stage<C>(c, nb_, rec.lo.get(), (HiT*)rec.hi.get(), c->res.view());
+        adopt_arena(nb_);
+        c->res = std::move(nb_);
+        return;
     }
+    const Resident& s = c->res;
+    if (s.count + N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "more than 2^32-16 words in one index are not supported yet");
+    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    hipLaunchKernelGGL(k_run_lengths, grid1(nb_.nb, 256), dim3(256), 0, c->stream, nb_.nb, nb_.start.get(), nb_.cnt.get(), nb_.kind.get());
+    adopt_arena(nb_);  // the sorted batch plays `other` in the gather below
+    Resident nr;
+    Buf<u32> raw, m_cs;
+    Buf<u64> m_sstart, m_ostart;
+    Buf<u8> m_skind, m_okind;
+    u64 T = 0;
+    {
+        StageTimer t(c, ST_DIR);
+        Buf<u32> popc(c->pool, nwords);
+        nr.bv = Buf<u64>(c->pool, nwords);
+        nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
+        hipLaunchKernelGGL(k_bv_or, grid1(nwords, 256), dim3(256), 0, c->stream, nwords, s.bv.get(), nb_.bv.get(), nr.bv.get(), popc.get());
+        nr.nb = exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get());
+        const u64 nb = nr.nb;
+        nr.prefix = Buf<u32>(c->pool, nb + 1);
+        nr.start = Buf<u64>(c->pool, nb + 1);
+        nr.cnt = Buf<u32>(c->pool, nb + 1);
+        nr.kind = Buf<u8>(c->pool, nb + 1);
+        raw = Buf<u32>(c->pool, nb + 1);
+        m_cs = Buf<u32>(c->pool, nb + 1);
+        m_sstart = Buf<u64>(c->pool, nb + 1);
+        m_ostart = Buf<u64>(c->pool, nb + 1);
+        m_skind = Buf<u8>(c->pool, nb + 1);
+        m_okind = Buf<u8>(c->pool, nb + 1);
+        hipLaunchKernelGGL(k_merge_table, grid1(nprefix, 256), dim3(256), 0, c->stream, nprefix, nr.bv.get(), nr.rank_dir.get(), s.view(), nb_.view(), nr.prefix.get(),
+                           raw.get(), m_cs.get(), m_sstart.get(), m_ostart.get(), m_skind.get(), m_okind.get());
+        T = exclusive_scan<u64>(c, raw.get(), nb, nr.start.get());
+        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, nr.start.get() + nb, T);
+        CBLX_HIP(hipGetLastError());
+    }
+    if (T != s.count + N) throw Error(CBLX_EDEVICE, "insert: run lengths do not match the index and the batch (internal error)");
+    nr.a_lo = Buf<u64>(c->pool, T + 2);
+    if (WS) nr.a_hi = Buf<u64>(c->pool, T + 2);
+    {
+        StageTimer t(c, ST_EXPAND);
+        hipLaunchKernelGGL((k_merge_gather<WS>), dim3((unsigned)ceil_div(nr.nb, 4)), dim3(256), 0, c->stream, nr.nb, nr.start.get(), m_cs.get(), m_sstart.get(), m_ostart.get(),
+                           s.a_lo.get(), s.a_hi.get(), nb_.a_lo.get(), nb_.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
+        CBLX_HIP(hipGetLastError());
+    }
+    bucket_stage<C>(c, nr, nr.a_lo.get(), WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr, s.view());
+    CBLX_HIP(hipStreamSynchronize(c->stream));  // the batch and the table buffers are released at scope exit
     c->res = std::move(nr);
 }
 
-// words of a resident index (bucket order, stored order inside a bucket) written to rec[at ..)
-template <typename C> void expand_into(cblx_ctx* c, const Resident& r, Records& rec, u64 at) {
-    typedef typename C::HiT HiT;
-    if (r.count == 0) return;
-    StageTimer t(c, ST_EXPAND);
+// record buffers (ping-pong) for a batch of n_new words
+template <typename C> void begin_records(cblx_ctx* c, Records& rec, u64 n_new) {
     const size_t hs = hi_elem_size(c->P);
-    Buf<u64> res_off(c->pool, r.nb + 1);
-    u64 tot = exclusive_scan<u64>(c, r.cnt.get(), r.nb, res_off.get());
-    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, res_off.get() + r.nb, tot);
-    hipLaunchKernelGGL((k_expand_resident<C::WS, HiT>), grid1(r.count, 256), dim3(256), 0, c->stream, r.count, r.nb, res_off.get(), r.prefix.get(), r.start.get(),
-                       r.a_lo.get(), r.a_hi.get(), c->P.SB, rec.lo.get() + at, hs ? (HiT*)(rec.hi.get() + at * hs) : (HiT*)nullptr);
-    CBLX_HIP(hipGetLastError());
-    CBLX_HIP(hipStreamSynchronize(c->stream));  // res_off is released at scope exit
-}
-
-// allocate the record buffers for N words; resident words (if any) are expanded into the front
-template <typename C> u64 begin_records(cblx_ctx* c, Records& rec, u64 n_new) {
-    const u64 n_res = c->res.count;
-    const u64 N = n_res + n_new;
-    const size_t hs = hi_elem_size(c->P);
-    rec.lo = Buf<u64>(c->pool, N + 2);
-    rec.lo2 = Buf<u64>(c->pool, N + 2);
-    rec.hi = Buf<u8>(c->pool, hs ? (N + 2) * hs : 8);
-    rec.hi2 = Buf<u8>(c->pool, hs ? (N + 2) * hs : 8);
-    expand_into<C>(c, c->res, rec, 0);
-    return n_res;
+    rec.lo = Buf<u64>(c->pool, n_new + 2);
+    rec.lo2 = Buf<u64>(c->pool, n_new + 2);
+    rec.hi = Buf<u8>(c->pool, hs ? (n_new + 2) * hs : 8);
+    rec.hi2 = Buf<u8>(c->pool, hs ? (n_new + 2) * hs : 8);
 }
 
 // KRN-1 front end: chunk table + validity + encode. Returns the number of new words written at rec[out_base..).
@@ -614,10 +672,11 @@ void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nse
         plan_chunks(c, d_bases, d_offsets, nseq, pl);
         if (pl.n_kmers == 0) return;
         Records rec;
-        const u64 base = begin_records<C>(c, rec, pl.n_kmers);
+        begin_records<C>(c, rec, pl.n_kmers);
+        const u64 base = 0;
         Buf<u32> countsA;
         EncHist eh{};
-        if (base == 0) {  // empty index: KRN-1 also accumulates the first partition pass's tile histogram
+        {   // KRN-1 also accumulates the first partition pass's tile histogram
             static_assert(ENC_HIST_WINDOW == RDX_TILE, "fused histogram windows must be the partition tiles");
             const size_t ntmax = (size_t)ceil_div(pl.n_kmers, RDX_TILE) + 256;
             countsA = Buf<u32>(c->pool, 256 * ntmax);
@@ -1659,16 +1718,10 @@ int cblx_insert_words_device(cblx_ctx* c, const uint64_t* d_lo, const void* d_hi
         dispatch(c->P, [&](auto cfg) {
             typedef decltype(cfg) C;
             Records rec;
-            const u64 base = begin_records<C>(c, rec, n);
-            if (base == 0) {  // empty index: the first partition pass reads the caller's arrays in place
-                rec.ext_lo = d_lo;
-                rec.ext_hi = d_hi;
-            } else {
-                const size_t hs = hi_elem_size(c->P);
-                CBLX_HIP(hipMemcpyAsync(rec.lo.get() + base, d_lo, n * 8, hipMemcpyDeviceToDevice, c->stream));
-                if (hs) CBLX_HIP(hipMemcpyAsync(rec.hi.get() + base * hs, d_hi, n * hs, hipMemcpyDeviceToDevice, c->stream));
-            }
-            pipeline<C>(c, rec, base + n);
+            begin_records<C>(c, rec, n);
+            rec.ext_lo = d_lo;  // the first partition pass reads the caller's arrays in place
+            rec.ext_hi = d_hi;
+            pipeline<C>(c, rec, n);
             c->kmers_inserted += n;
         });
         collect_events(c);

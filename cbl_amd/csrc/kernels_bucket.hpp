@@ -993,28 +993,6 @@ __global__ __launch_bounds__(256) void k_bucket_huge(const BDesc* __restrict__ l
     }
 }
 
-// ---- resident index -> records (prefix || suffix words, bucket order) for a rebuild that includes new words ----
-template <bool WS, typename HiT>
-__global__ void k_expand_resident(u64 nelem, u64 nb, const u64* __restrict__ res_off /* nb+1 */, const u32* __restrict__ bucket_prefix,
-                                  const u64* __restrict__ start, const u64* __restrict__ a_lo, const u64* __restrict__ a_hi,
-                                  u32 SB, u64* __restrict__ out_lo, HiT* __restrict__ out_hi) {
-    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nelem) return;
-    u64 l = 0, h = nb;  // last r with res_off[r] <= e
-    while (h - l > 1) {
-        u64 mid = (l + h) >> 1;
-        if (res_off[mid] <= e) l = mid; else h = mid;
-    }
-    const u64 r = l, j = e - res_off[r];
-    // arena slots of buckets a rebuild did not touch still carry the full word: always mask to SB bits
-    u128 sfx = (u128)a_lo[start[r] + j];
-    if constexpr (WS) sfx |= (u128)a_hi[start[r] + j] << 64;
-    sfx &= (((u128)1) << SB) - 1;
-    u128 word = ((u128)bucket_prefix[r] << SB) | sfx;
-    out_lo[e] = (u64)word;
-    st_hi<HiT>(out_hi, e, (u64)(word >> 64));
-}
-
 // dense gather of the resident suffixes (for export / serialization): out[res_off[r] + j] = arena[start[r] + j]
 __global__ void k_gather_dense(u64 nelem, u64 nb, const u64* __restrict__ res_off, const u64* __restrict__ start,
                                const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u32 SB, u64* __restrict__ out_lo,
