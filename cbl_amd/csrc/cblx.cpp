@@ -973,8 +973,10 @@ void download(cblx_ctx* c, HostIndex& h) {
     hipLaunchKernelGGL(k_gather_dense, grid1(n, 256), dim3(256), 0, c->stream, n, r.nb, d_off.get(), r.start.get(), r.a_lo.get(),
                        c->P.wide_suffix() ? r.a_hi.get() : (const u64*)nullptr, c->P.SB, d_lo.get(), c->P.wide_suffix() ? d_hi.get() : (u64*)nullptr);
     CBLX_HIP(hipGetLastError());
-    h.lo = d2h_vec<u64>(c, d_lo.get(), n);
-    if (c->P.wide_suffix()) h.hi = d2h_vec<u64>(c, d_hi.get(), n); else h.hi.clear();
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    h.lo.resize(n);
+    xfer(c).d2h_copy(h.lo.data(), d_lo.get(), n * 8);  // pinned lanes (a pageable hipMemcpy runs at a few GB/s)
+    if (c->P.wide_suffix()) { h.hi.resize(n); xfer(c).d2h_copy(h.hi.data(), d_hi.get(), n * 8); } else h.hi.clear();
 }
 // replace the resident index by a host-built one (load / merge): dense arena, directory built on the host
 void upload(cblx_ctx* c, const HostIndex& h) {
@@ -1005,8 +1007,9 @@ void upload(cblx_ctx* c, const HostIndex& h) {
     h2d(c, nr.start.get(), h.off.data(), nr.nb + 1);
     h2d(c, nr.cnt.get(), h.cnt.data(), nr.nb);
     h2d(c, nr.kind.get(), h.kind.data(), nr.nb);
-    h2d(c, nr.a_lo.get(), h.lo.data(), n);
-    if (P.wide_suffix()) h2d(c, nr.a_hi.get(), h.hi.data(), n);
+    xfer(c).h2d_copy(nr.a_lo.get(), h.lo.data(), n * 8);
+    if (P.wide_suffix()) xfer(c).h2d_copy(nr.a_hi.get(), h.hi.data(), n * 8);
+    xfer(c).sync();
     CBLX_HIP(hipStreamSynchronize(c->stream));
     c->res = std::move(nr);
 }
@@ -2001,7 +2004,8 @@ int cblx_contains_seq(cblx_ctx* c, const uint8_t* seq, uint64_t len, uint8_t* ou
             Buf<u8> d_b(c->pool, len + 64);
             Buf<u64> d_o(c->pool, 2);
             u64 offs[2] = {0, len};
-            h2d(c, d_b.get(), seq, len);
+            xfer(c).h2d_copy(d_b.get(), seq, len);  // pinned lanes: the caller's buffer is pageable
+            xfer(c).sync();
             h2d(c, d_o.get(), offs, 2);
             ChunkPlan pl;
             const u8* pb = d_b.get();
@@ -2015,8 +2019,8 @@ int cblx_contains_seq(cblx_ctx* c, const uint8_t* seq, uint64_t len, uint8_t* ou
             hipLaunchKernelGGL(k_contains<HiT>, grid1(pl.n_kmers, 256), dim3(256), 0, c->stream, w_lo.get(), (const HiT*)w_hi.get(), pl.n_kmers, c->P.SB,
                                c->P.PB, c->res.view(), c->res.a_lo.get(), c->P.wide_suffix() ? c->res.a_hi.get() : (const u64*)nullptr, d_out.get());
             CBLX_HIP(hipGetLastError());
-            CBLX_HIP(hipMemcpyAsync(out, d_out.get(), pl.n_kmers, hipMemcpyDeviceToHost, c->stream));
             CBLX_HIP(hipStreamSynchronize(c->stream));
+            xfer(c).d2h_copy(out, d_out.get(), pl.n_kmers);
         });
         collect_events(c);
     });
