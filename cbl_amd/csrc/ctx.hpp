@@ -1,0 +1,219 @@
+// ctx.hpp — the context behind the opaque cblx_ctx handle: device memory pool, resident index (WordSet state in HBM),
+// ingest queue, stage timers, small device<->host helpers, the word-layout dispatch. Included by cblx.cpp only.
+#pragma once
+#include "../../include/cblx.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kernels_bucket.hpp"
+#include "xfer.hpp"
+
+using namespace cblx;
+
+namespace {
+
+thread_local std::string g_global_err;
+
+inline u32 ilog2_npo2(u32 v) { u32 l = 0; while ((1u << l) < v) ++l; return l; }
+inline u64 ceil_div(u64 a, u64 b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------------
+// cached device allocations (hipMalloc is kept out of the hot path between flushes)
+struct Pool {
+    struct Blk { void* p; size_t sz; bool used; };
+    std::vector<Blk> blks;
+    void* alloc(size_t sz) {
+        if (sz == 0) sz = 256;
+        sz = (sz + 255) & ~(size_t)255;
+        int best = -1;
+        for (size_t i = 0; i < blks.size(); ++i)
+            if (!blks[i].used && blks[i].sz >= sz && blks[i].sz <= sz + sz / 2 + 4096 && (best < 0 || blks[i].sz < blks[best].sz)) best = (int)i;
+        if (best >= 0) { blks[best].used = true; return blks[best].p; }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, sz);
+        if (e != hipSuccess) {
+            trim();
+            e = hipMalloc(&p, sz);
+            if (e != hipSuccess) throw Error(CBLX_ENOMEM, "hipMalloc(" + std::to_string(sz) + ") failed: " + hipGetErrorString(e));
+        }
+        blks.push_back({p, sz, true});
+        return p;
+    }
+    void release(void* p) {
+        if (!p) return;
+        for (auto& b : blks) if (b.p == p) { b.used = false; return; }
+    }
+    void trim() {
+        std::vector<Blk> keep;
+        for (auto& b : blks) { if (b.used) keep.push_back(b); else (void)hipFree(b.p); }
+        blks.swap(keep);
+    }
+    ~Pool() { for (auto& b : blks) (void)hipFree(b.p); }
+};
+
+template <typename T> struct Buf {  // RAII view on a pool allocation
+    Pool* pool = nullptr;
+    T* p = nullptr;
+    size_t n = 0;
+    Buf() {}
+    Buf(Pool& pl, size_t count) : pool(&pl), p((T*)pl.alloc(count * sizeof(T))), n(count) {}
+    Buf(const Buf&) = delete;
+    Buf& operator=(const Buf&) = delete;
+    Buf(Buf&& o) noexcept : pool(o.pool), p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    Buf& operator=(Buf&& o) noexcept { if (this != &o) { reset(); pool = o.pool; p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    void reset() { if (p && pool) pool->release(p); p = nullptr; n = 0; }
+    ~Buf() { reset(); }
+    T* get() const { return p; }
+};
+
+// resident index (WordSet state) in HBM
+struct Resident {
+    u64 nb = 0;          // non-empty prefixes (tiered.len())
+    u64 count = 0;       // k-mers
+    Buf<u64> bv;         // 2^PB bits
+    Buf<u64> rank_dir;   // per bv word, exclusive
+    Buf<u32> prefix;     // per rank
+    Buf<u64> start;      // per rank (+1): first arena slot
+    Buf<u32> cnt;        // per rank
+    Buf<u8> kind;        // per rank
+    Buf<u64> a_lo, a_hi; // suffix arena (slack layout); a_hi only when SUFFIX_BITS > 64
+    bool empty() const { return nb == 0; }
+    DirView view() const { return DirView{bv.get(), rank_dir.get(), cnt.get(), kind.get(), start.get(), nb}; }
+};
+
+struct Stage { const char* name; double ms = 0; u64 launches = 0; };
+enum { ST_CHUNKS, ST_ENCODE, ST_HIST, ST_SCAN, ST_SCATTER, ST_DIR, ST_BSMALL, ST_BMED, ST_BHUGE, ST_EXPAND, ST_N };
+const char* kStageNames[ST_N] = {"chunks", "encode", "radix_hist", "radix_scan", "radix_scatter", "directory",
+                                 "bucket_small", "bucket_medium", "bucket_huge", "merge_gather"};
+
+// Sequences enqueued by cblx_insert_seq / cblx_insert_seqs / the FASTA reader. They are staged straight into HBM
+// while the caller keeps enqueueing: small appends fill pinned write blocks that are DMA'd as they fill up, bulk
+// appends go through the Xfer lanes. flush() only has to wait for the last DMA.
+struct Ingest {
+    static constexpr size_t BASES_BLK = 4u << 20, OFF_BLK = 512u << 10;
+    struct Writer {
+        u8* blk[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool busy[2] = {false, false};
+        int cur = 0;
+        size_t cap = 0, fill = 0;
+        u64 issued = 0;  // bytes of the logical stream already handed to the DMA engine
+    };
+    Buf<u8> d_bases;   // capacity >= nbytes + 64
+    Buf<u64> d_off;    // capacity >= nseq + 1; d_off[0] = 0
+    u64 nbytes = 0, nseq = 0;
+    u64 last_end = 0;  // nbytes at the end of the last complete sequence
+    Writer wb, wo;
+    hipStream_t s = nullptr;
+    std::unique_ptr<Xfer> xfer;
+};
+
+}  // namespace
+
+struct cblx_ctx {
+    Consts P;
+    int device = 0;
+    u32 flags = 0;
+    hipStream_t stream = nullptr;
+    Pool pool;
+    Resident res;
+    Ingest ing;
+    std::string err;
+    u64 kmers_inserted = 0;
+    Stage stages[ST_N];
+    struct Ev { int st; hipEvent_t a, b; };
+    std::vector<Ev> evs;
+    std::vector<hipEvent_t> ev_free;
+
+    cblx_ctx() { for (int i = 0; i < ST_N; ++i) stages[i].name = kStageNames[i]; }
+};
+
+namespace {
+
+struct StageTimer {  // brackets a group of launches with HIP events when profiling is on
+    cblx_ctx* c;
+    int idx = -1;
+    StageTimer(cblx_ctx* ctx, int st) : c(ctx) {
+        if (!(c->flags & CBLX_FLAG_PROFILE)) return;
+        auto get = [&]() { hipEvent_t e; if (!c->ev_free.empty()) { e = c->ev_free.back(); c->ev_free.pop_back(); } else CBLX_HIP(hipEventCreate(&e)); return e; };
+        cblx_ctx::Ev ev{st, get(), get()};
+        CBLX_HIP(hipEventRecord(ev.a, c->stream));
+        c->evs.push_back(ev);
+        idx = (int)c->evs.size() - 1;
+    }
+    ~StageTimer() { if (idx >= 0) (void)hipEventRecord(c->evs[idx].b, c->stream); }
+};
+void collect_events(cblx_ctx* c) {
+    if (c->evs.empty()) return;
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    for (auto& e : c->evs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { c->stages[e.st].ms += ms; c->stages[e.st].launches++; }
+        c->ev_free.push_back(e.a);
+        c->ev_free.push_back(e.b);
+    }
+    c->evs.clear();
+}
+
+inline dim3 grid1(u64 n, u32 threads) { return dim3((unsigned)std::max<u64>(1, ceil_div(n, threads))); }
+
+template <typename T> T d2h(cblx_ctx* c, const T* dptr) {
+    T v;
+    CBLX_HIP(hipMemcpyAsync(&v, dptr, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    return v;
+}
+template <typename T> std::vector<T> d2h_vec(cblx_ctx* c, const T* dptr, size_t n) {
+    std::vector<T> v(n);
+    if (n) {
+        CBLX_HIP(hipMemcpyAsync(v.data(), dptr, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+    }
+    return v;
+}
+template <typename T> void h2d(cblx_ctx* c, T* dptr, const T* h, size_t n) {
+    if (n) CBLX_HIP(hipMemcpyAsync(dptr, h, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+}
+
+// device-wide exclusive scan of u32 -> OutT; returns the total
+template <typename OutT> u64 exclusive_scan(cblx_ctx* c, const u32* in, u64 n, OutT* out) {
+    if (n == 0) return 0;
+    const u64 nb = ceil_div(n, SCAN_TILE);
+    Buf<u64> sums(c->pool, nb + 1);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, c->stream, in, n, sums.get());
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, c->stream, sums.get(), nb);
+    hipLaunchKernelGGL(k_scan_apply<OutT>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, c->stream, in, n, sums.get(), out);
+    CBLX_HIP(hipGetLastError());
+    return d2h<u64>(c, sums.get() + nb);
+}
+
+// column prefixes + column totals of counts[tile][256] (see k_colscan_*); nt_dev (device) overrides nt_upper when set
+void colscan(cblx_ctx* c, const u32* counts, const u32* nt_dev, u32 nt_upper, u32* colpre, u32* coltot, Buf<u32>& scratch) {
+    const u32 nchunks = (u32)std::max<u64>(1, ceil_div(nt_upper, COLSCAN_ROWS));
+    if (scratch.n < (size_t)nchunks * 256) scratch = Buf<u32>(c->pool, (size_t)nchunks * 256);
+    hipLaunchKernelGGL(k_colscan_reduce, dim3(nchunks), dim3(256), 0, c->stream, counts, nt_dev, nt_upper, scratch.get());
+    hipLaunchKernelGGL(k_colscan_spine, dim3(1), dim3(256), 0, c->stream, scratch.get(), nchunks, coltot);
+    hipLaunchKernelGGL(k_colscan_apply, dim3(nchunks), dim3(256), 0, c->stream, counts, nt_dev, nt_upper, scratch.get(), colpre);
+}
+
+// ---- template configuration ------------------------------------------------------------------------------
+template <bool WIDE_, typename HiT_, bool WS_> struct Cfg {
+    static constexpr bool WIDE = WIDE_;
+    typedef HiT_ HiT;
+    static constexpr bool WS = WS_;
+};
+template <typename F> void dispatch(const Consts& P, F&& f) {
+    if (!P.has_hi()) f(Cfg<false, NoHi, false>());
+    else if (!P.wide_kmer()) f(Cfg<false, u8, false>());
+    else if (!P.wide_suffix()) f(Cfg<true, u64, false>());
+    else f(Cfg<true, u64, true>());
+}
+inline size_t hi_elem_size(const Consts& P) { return !P.has_hi() ? 0 : (!P.wide_kmer() ? 1 : 8); }
+
+
+}  // namespace

@@ -1,0 +1,557 @@
+// host_index.hpp — the index as bytes: host-side copy of the resident index (export, different-device merge), the bincode
+// emitter on the host and its device counterpart's driver (kernels_serde.hpp), the parser, the streaming loader, the host
+// merge. Included by cblx.cpp only.
+#pragma once
+#include <sys/mman.h>
+#include <sys/stat.h>
+
+#include <fstream>
+
+#include "ingest.hpp"
+#include "kernels_serde.hpp"
+
+namespace {
+
+// ---- host-side views of the resident index (export / serialize / merge) ---------------------------------------
+struct HostIndex {
+    std::vector<u32> prefix, cnt;
+    std::vector<u8> kind;
+    std::vector<u64> off;  // nb+1 into lo/hi
+    std::vector<u64> lo, hi;
+};
+void download(cblx_ctx* c, HostIndex& h) {
+    const Resident& r = c->res;
+    h.prefix = d2h_vec<u32>(c, r.prefix.get(), r.nb);
+    h.cnt = d2h_vec<u32>(c, r.cnt.get(), r.nb);
+    h.kind = d2h_vec<u8>(c, r.kind.get(), r.nb);
+    h.off.assign(r.nb + 1, 0);
+    for (u64 i = 0; i < r.nb; ++i) h.off[i + 1] = h.off[i] + h.cnt[i];
+    const u64 n = h.off[r.nb];
+    if (n == 0) { h.lo.clear(); h.hi.clear(); return; }
+    Buf<u64> d_off(c->pool, r.nb + 1), d_lo(c->pool, n), d_hi(c->pool, c->P.wide_suffix() ? n : 1);
+    h2d(c, d_off.get(), h.off.data(), r.nb + 1);
+    hipLaunchKernelGGL(k_gather_dense, grid1(n, 256), dim3(256), 0, c->stream, n, r.nb, d_off.get(), r.start.get(), r.a_lo.get(),
+                       c->P.wide_suffix() ? r.a_hi.get() : (const u64*)nullptr, c->P.SB, d_lo.get(), c->P.wide_suffix() ? d_hi.get() : (u64*)nullptr);
+    CBLX_HIP(hipGetLastError());
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    h.lo.resize(n);
+    xfer(c).d2h_copy(h.lo.data(), d_lo.get(), n * 8);  // pinned lanes (a pageable hipMemcpy runs at a few GB/s)
+    if (c->P.wide_suffix()) { h.hi.resize(n); xfer(c).d2h_copy(h.hi.data(), d_hi.get(), n * 8); } else h.hi.clear();
+}
+// replace the resident index by a host-built one (load / merge): dense arena, directory built on the host
+void upload(cblx_ctx* c, const HostIndex& h) {
+    const Consts& P = c->P;
+    Resident nr;
+    nr.nb = h.prefix.size();
+    const u64 n = h.off.empty() ? 0 : h.off.back();
+    nr.count = n;
+    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    std::vector<u64> bv(nwords, 0), rd(nwords + 1, 0);
+    for (u64 i = 0; i < nr.nb; ++i) {
+        if (h.prefix[i] >= nprefix) throw Error(CBLX_EFORMAT, "prefix out of range for PREFIX_BITS");
+        if (i && h.prefix[i] <= h.prefix[i - 1]) throw Error(CBLX_EFORMAT, "prefixes are not strictly ascending");
+        bv[h.prefix[i] >> 6] |= 1ull << (h.prefix[i] & 63);
+    }
+    for (u64 w = 0; w < nwords; ++w) rd[w + 1] = rd[w] + (u64)__builtin_popcountll(bv[w]);
+    nr.bv = Buf<u64>(c->pool, nwords);
+    nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
+    nr.prefix = Buf<u32>(c->pool, nr.nb + 1);
+    nr.start = Buf<u64>(c->pool, nr.nb + 1);
+    nr.cnt = Buf<u32>(c->pool, nr.nb + 1);
+    nr.kind = Buf<u8>(c->pool, nr.nb + 1);
+    nr.a_lo = Buf<u64>(c->pool, n + 2);
+    if (P.wide_suffix()) nr.a_hi = Buf<u64>(c->pool, n + 2);
+    h2d(c, nr.bv.get(), bv.data(), nwords);
+    h2d(c, nr.rank_dir.get(), rd.data(), nwords + 1);
+    h2d(c, nr.prefix.get(), h.prefix.data(), nr.nb);
+    h2d(c, nr.start.get(), h.off.data(), nr.nb + 1);
+    h2d(c, nr.cnt.get(), h.cnt.data(), nr.nb);
+    h2d(c, nr.kind.get(), h.kind.data(), nr.nb);
+    xfer(c).h2d_copy(nr.a_lo.get(), h.lo.data(), n * 8);
+    if (P.wide_suffix()) xfer(c).h2d_copy(nr.a_hi.get(), h.hi.data(), n * 8);
+    xfer(c).sync();
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    c->res = std::move(nr);
+}
+
+// ---- bincode 1.3 DefaultOptions (varint, little endian): src/cbl.rs:132-135 -----------------------------------
+struct Sink {
+    u8* buf;
+    u64 cap, pos = 0;
+    Sink(u8* b, u64 c) : buf(b), cap(c) {}
+    inline void u8_(u8 v) { if (buf && pos < cap) buf[pos] = v; ++pos; }
+    inline void raw(const u8* p, u64 n) { if (buf && pos + n <= cap) memcpy(buf + pos, p, n); pos += n; }
+    inline void varint(u64 v) {
+        if (v <= 250) { u8_((u8)v); return; }
+        int nb = v < (1ull << 16) ? 2 : v < (1ull << 32) ? 4 : 8;
+        u8_(nb == 2 ? 0xFB : nb == 4 ? 0xFC : 0xFD);
+        for (int i = 0; i < nb; ++i) u8_((u8)(v >> (8 * i)));
+    }
+};
+struct SfxView {
+    const u64* lo;
+    const u64* hi;
+    inline u128 at(u64 i) const { return hi ? (((u128)hi[i] << 64) | lo[i]) : (u128)lo[i]; }
+};
+// Trie node over sorted suffixes [a, b) that agree on their top `depth` bytes (src/trie.rs:53-57 derive,
+// src/bitvector/tiny/mod.rs:97-105): varint(c) | c byte values | varint(#children) | children...
+void emit_trie(Sink& s, const SfxView& v, u64 a, u64 b, u32 depth, u32 BYTES) {
+    const u32 shift = 8 * (BYTES - 1 - depth);
+    u8 vals[256];
+    u64 starts[257];
+    u32 c = 0;
+    u64 i = a;
+    while (i < b) {
+        const u8 by = (u8)(v.at(i) >> shift);
+        vals[c] = by;
+        starts[c++] = i;
+        // gallop to the end of this byte's run
+        u64 lo = i + 1, hi = b;
+        while (lo < hi) {
+            u64 mid = (lo + hi) >> 1;
+            if ((u8)(v.at(mid) >> shift) == by) lo = mid + 1; else hi = mid;
+        }
+        i = lo;
+    }
+    starts[c] = b;
+    s.varint(c);
+    s.raw(vals, c);
+    if (depth + 1 == BYTES) { s.varint(0); return; }
+    s.varint(c);
+    for (u32 k = 0; k < c; ++k) emit_trie(s, v, starts[k], starts[k + 1], depth + 1, BYTES);
+}
+void serialize_bucket(const Consts& P, const HostIndex& h, const SfxView& v, u64 r, Sink& s) {
+    s.varint(h.prefix[r]);
+    const u64 a = h.off[r], b = h.off[r + 1];
+    if (h.kind[r] == KIND_VEC) {             // TrieOrVec::Vec  src/trievec/mod.rs:10-11
+        s.varint(0);
+        s.varint(b - a);
+        for (u64 i = a; i < b; ++i) {
+            s.varint(P.BYTES);               // SlicedInt::serialize -> serialize_bytes  src/sliced_int.rs:110-114
+            u128 x = v.at(i);
+            u8 tmp[16];
+            for (u32 k = 0; k < P.BYTES; ++k) tmp[k] = (u8)(x >> (8 * k));
+            s.raw(tmp, P.BYTES);
+        }
+    } else {                                 // TrieOrVec::Trie(trie, len)  src/trievec/mod.rs:12
+        s.varint(1);
+        emit_trie(s, v, a, b, 0, P.BYTES);
+        s.varint(b - a);
+    }
+}
+// Serialized form, emitted by a pool of host threads: bucket entries are independent byte ranges, so sizes are
+// computed in parallel, prefix-summed, and every bucket is then written at its own offset. (The reference writes
+// sequentially through a BufWriter, examples/cbl.rs:132-142; the bytes are the same.)
+void serialize_host(const Consts& P, const HostIndex& h, Sink& s) {
+    s.u8_(P.canonical ? 1 : 0);                  // CBL.canonical (src/cbl.rs:48)
+    s.varint(h.prefix.size());                   // serialize_map(Some(tiered.len()))  src/wordset/mod.rs:388
+    const u64 nb = h.prefix.size();
+    if (nb == 0) return;
+    SfxView v{h.lo.data(), h.hi.empty() ? nullptr : h.hi.data()};
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = std::max(1u, std::min(nt ? nt : 1u, 64u));
+    if (nb < 4096 || h.lo.size() < (1u << 18)) nt = 1;
+    // split the buckets into ranges of roughly equal element counts
+    std::vector<u64> cut(nt + 1, nb);
+    cut[0] = 0;
+    const u64 total = h.off[nb];
+    for (unsigned t = 1; t < nt; ++t) {
+        const u64 target = total / nt * t;
+        cut[t] = (u64)(std::lower_bound(h.off.begin(), h.off.begin() + nb, target) - h.off.begin());
+        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    }
+    auto run = [&](auto&& fn) {
+        if (nt == 1) { fn(0u); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(fn, t);
+        for (auto& x : th) x.join();
+    };
+    std::vector<u64> part(nt + 1, 0);
+    run([&](unsigned t) {
+        Sink cnt(nullptr, 0);
+        for (u64 r = cut[t]; r < cut[t + 1]; ++r) serialize_bucket(P, h, v, r, cnt);
+        part[t + 1] = cnt.pos;
+    });
+    for (unsigned t = 0; t < nt; ++t) part[t + 1] += part[t];
+    const u64 base = s.pos;
+    if (s.buf && base + part[nt] <= s.cap) {
+        run([&](unsigned t) {
+            Sink out(s.buf + base + part[t], part[t + 1] - part[t]);
+            for (u64 r = cut[t]; r < cut[t + 1]; ++r) serialize_bucket(P, h, v, r, out);
+        });
+    }
+    s.pos = base + part[nt];
+}
+// ---- the same bytes, produced in HBM (kernels_serde.hpp): size pass -> exclusive scan -> emit pass ---------------
+struct DevBlob { Buf<u8> bytes; u64 n = 0; };
+// false: a bucket is longer than the device emitters handle (SER_CAP1024) -> the caller takes the host path
+template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blob) {
+    constexpr bool WS = C::WS;
+    const Resident& r = c->res;
+    const Consts& P = c->P;
+    const u64 nb = r.nb;
+    u8 hdr[16];
+    Sink hs(hdr, sizeof hdr);
+    hs.u8_(P.canonical ? 1 : 0);  // CBL.canonical (src/cbl.rs:48)
+    hs.varint(nb);                // serialize_map(Some(tiered.len()))  src/wordset/mod.rs:388
+    u64 total = 0;
+    Buf<u32> size, lists, list_n;
+    Buf<u64> off;
+    std::vector<u32> ln(SER_NCLS, 0);
+    const u64 *a_lo = r.a_lo.get(), *a_hi = WS ? r.a_hi.get() : (const u64*)nullptr;
+    auto buckets = [&](auto em, u8* body) {
+        constexpr bool EM = decltype(em)::value;
+        if (ln[SER_C64])
+            hipLaunchKernelGGL((k_serde_bucket<64, 16, WS, EM>), dim3(ln[SER_C64]), dim3(64), 0, c->stream, lists.get() + (size_t)SER_C64 * nb, list_n.get() + SER_C64,
+                               r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body);
+        if (ln[SER_C256])
+            hipLaunchKernelGGL((k_serde_bucket<256, 16, WS, EM>), dim3(ln[SER_C256]), dim3(256), 0, c->stream, lists.get() + (size_t)SER_C256 * nb, list_n.get() + SER_C256,
+                               r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body);
+        if (ln[SER_C1024])
+            hipLaunchKernelGGL((k_serde_bucket<1024, 8, WS, EM>), dim3(ln[SER_C1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)SER_C1024 * nb, list_n.get() + SER_C1024,
+                               r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body);
+        CBLX_HIP(hipGetLastError());
+    };
+    if (nb) {
+        size = Buf<u32>(c->pool, nb);
+        lists = Buf<u32>(c->pool, (size_t)SER_NCLS * nb);
+        list_n = Buf<u32>(c->pool, SER_NCLS);
+        off = Buf<u64>(c->pool, nb + 1);
+        CBLX_HIP(hipMemsetAsync(list_n.get(), 0, SER_NCLS * 4, c->stream));
+        hipLaunchKernelGGL((k_serde_tiny<WS, false>), grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
+                           P.SB, P.BYTES, size.get(), (const u64*)nullptr, (u8*)nullptr, lists.get(), list_n.get());
+        CBLX_HIP(hipGetLastError());
+        ln = d2h_vec<u32>(c, list_n.get(), SER_NCLS);
+        if (ln[SER_HOST]) return false;
+        buckets(std::false_type(), nullptr);
+        total = exclusive_scan<u64>(c, size.get(), nb, off.get());
+    }
+    blob.n = hs.pos + total;
+    if (!emit) return true;
+    blob.bytes = Buf<u8>(c->pool, blob.n + 16);
+    CBLX_HIP(hipMemcpyAsync(blob.bytes.get(), hdr, hs.pos, hipMemcpyHostToDevice, c->stream));
+    if (nb) {
+        u8* body = blob.bytes.get() + hs.pos;
+        hipLaunchKernelGGL((k_serde_tiny<WS, true>), grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
+                           P.SB, P.BYTES, size.get(), off.get(), body, (u32*)nullptr, (u32*)nullptr);
+        buckets(std::true_type(), body);
+    }
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    return true;
+}
+bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blob) {
+    if (const char* e = std::getenv("CBLX_HOST_SERDE")) if (e[0] == '1') return false;  // test hook: force the host emitter
+    bool ok = false;
+    dispatch(c->P, [&](auto cfg) { ok = serialize_device<decltype(cfg)>(c, emit, blob); });
+    return ok;
+}
+
+struct Src {
+    const u8* p;
+    const u8* end;
+    u8 u8_() { if (p >= end) throw Error(CBLX_EFORMAT, "index: unexpected end of data"); return *p++; }
+    u64 varint() {
+        u8 t = u8_();
+        if (t <= 250) return t;
+        int nb = t == 0xFB ? 2 : t == 0xFC ? 4 : t == 0xFD ? 8 : 0;
+        if (!nb) throw Error(CBLX_EFORMAT, "index: bad varint tag");
+        u64 v = 0;
+        for (int i = 0; i < nb; ++i) v |= (u64)u8_() << (8 * i);
+        return v;
+    }
+};
+void parse_trie(Src& s, u32 depth, u32 BYTES, u128 acc, std::vector<u128>& out) {
+    u64 c = s.varint();
+    if (c > 256) throw Error(CBLX_EFORMAT, "index: trie node with more than 256 entries");
+    u8 vals[256];
+    for (u64 i = 0; i < c; ++i) vals[i] = s.u8_();
+    u64 nc = s.varint();
+    const u32 shift = 8 * (BYTES - 1 - depth);
+    if (depth + 1 == BYTES) {
+        if (nc != 0) throw Error(CBLX_EFORMAT, "index: leaf trie node with children");
+        for (u64 i = 0; i < c; ++i) out.push_back(acc | ((u128)vals[i] << shift));
+        return;
+    }
+    if (nc != c) throw Error(CBLX_EFORMAT, "index: trie node children count mismatch");
+    for (u64 i = 0; i < c; ++i) parse_trie(s, depth + 1, BYTES, acc | ((u128)vals[i] << shift), out);
+}
+void parse_index(const Consts& P, const u8* data, u64 len, HostIndex& h, bool& canonical) {
+    Src s{data, data + len};
+    canonical = s.u8_() != 0;
+    const u64 nb = s.varint();
+    h.off.assign(1, 0);
+    const bool wide = P.wide_suffix();
+    std::vector<u128> tmp;
+    for (u64 r = 0; r < nb; ++r) {
+        h.prefix.push_back((u32)s.varint());
+        const u64 tag = s.varint();
+        if (tag == 0) {
+            const u64 n = s.varint();
+            for (u64 i = 0; i < n; ++i) {
+                const u64 nbts = s.varint();
+                u128 x = 0;
+                for (u64 k = 0; k < nbts; ++k) { u8 b = s.u8_(); if (k < P.BYTES) x |= (u128)b << (8 * k); }
+                h.lo.push_back((u64)x);
+                if (wide) h.hi.push_back((u64)(x >> 64));
+            }
+            h.kind.push_back(KIND_VEC);
+            h.cnt.push_back((u32)n);
+        } else if (tag == 1) {
+            tmp.clear();
+            parse_trie(s, 0, P.BYTES, 0, tmp);
+            const u64 n = s.varint();
+            if (n != tmp.size()) throw Error(CBLX_EFORMAT, "index: trie length field does not match its contents");
+            for (u128 x : tmp) { h.lo.push_back((u64)x); if (wide) h.hi.push_back((u64)(x >> 64)); }
+            h.kind.push_back(KIND_TRIE);
+            h.cnt.push_back((u32)n);
+        } else throw Error(CBLX_EFORMAT, "index: bad TrieOrVec tag");
+        h.off.push_back(h.lo.size());
+    }
+    if (s.p != s.end) throw Error(CBLX_EFORMAT, "index: trailing bytes");  // reject_trailing_bytes
+}
+
+// ---- index bytes -> resident index, streamed (cblx_load): one pass over the bytes, elements go to HBM as they are
+// decoded. The format is a sequential pre-order walk (no lengths to skip by), so the walk itself stays on one host
+// thread; everything around it (pinned double buffering, DMA, directory upload) overlaps with it.
+struct StreamUp {  // single producer -> device array of u64
+    static constexpr size_t CAP = 1u << 20;  // elements per pinned block
+    cblx_ctx* c;
+    hipStream_t s = nullptr;
+    u64* blk[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int cur = 0;
+    size_t fill = 0;
+    u64 issued = 0;
+    Buf<u64> dev;
+    StreamUp(cblx_ctx* ctx, u64 guess) : c(ctx) {
+        CBLX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            CBLX_HIP(hipHostMalloc((void**)&blk[k], CAP * 8, hipHostMallocDefault));
+            CBLX_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        }
+        dev = Buf<u64>(c->pool, guess + 2);
+    }
+    StreamUp(const StreamUp&) = delete;
+    ~StreamUp() {
+        if (s) (void)hipStreamSynchronize(s);
+        for (int k = 0; k < 2; ++k) { if (ev[k]) (void)hipEventDestroy(ev[k]); if (blk[k]) (void)hipHostFree(blk[k]); }
+        if (s) (void)hipStreamDestroy(s);
+    }
+    inline u64* room(size_t need) { if (fill + need > CAP) issue(); return blk[cur] + fill; }  // need <= CAP
+    inline void commit(size_t k) { fill += k; }
+    void issue() {
+        if (fill == 0) return;
+        if (dev.n < issued + fill + 2) {
+            Buf<u64> nd(c->pool, std::max<u64>(2 * (u64)dev.n, issued + fill + 2));
+            CBLX_HIP(hipStreamSynchronize(s));
+            if (issued) CBLX_HIP(hipMemcpyAsync(nd.get(), dev.get(), issued * 8, hipMemcpyDeviceToDevice, s));
+            CBLX_HIP(hipStreamSynchronize(s));
+            dev = std::move(nd);
+        }
+        CBLX_HIP(hipMemcpyAsync(dev.get() + issued, blk[cur], fill * 8, hipMemcpyHostToDevice, s));
+        CBLX_HIP(hipEventRecord(ev[cur], s));
+        busy[cur] = true;
+        issued += fill;
+        fill = 0;
+        cur ^= 1;
+        if (busy[cur]) { CBLX_HIP(hipEventSynchronize(ev[cur])); busy[cur] = false; }
+    }
+    Buf<u64> finish() { issue(); CBLX_HIP(hipStreamSynchronize(s)); return std::move(dev); }
+};
+inline u64 load_le64(const u8* p) { u64 v; std::memcpy(&v, p, 8); return v; }
+
+// directory of a loaded / host-merged index: bitvector + rank directory + per-rank tables, arena supplied by the caller
+void install_index(cblx_ctx* c, const std::vector<u32>& prefix, const std::vector<u32>& cnt, const std::vector<u8>& kind, Buf<u64>&& a_lo, Buf<u64>&& a_hi) {
+    const Consts& P = c->P;
+    Resident nr;
+    nr.nb = prefix.size();
+    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    std::vector<u64> bv(nwords, 0), rd(nwords + 1, 0), start(nr.nb + 1, 0);
+    for (u64 i = 0; i < nr.nb; ++i) {
+        if (prefix[i] >= nprefix) throw Error(CBLX_EFORMAT, "prefix out of range for PREFIX_BITS");
+        if (i && prefix[i] <= prefix[i - 1]) throw Error(CBLX_EFORMAT, "prefixes are not strictly ascending");
+        bv[prefix[i] >> 6] |= 1ull << (prefix[i] & 63);
+        start[i + 1] = start[i] + cnt[i];
+    }
+    for (u64 w = 0; w < nwords; ++w) rd[w + 1] = rd[w] + (u64)__builtin_popcountll(bv[w]);
+    nr.count = start[nr.nb];
+    nr.bv = Buf<u64>(c->pool, nwords);
+    nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
+    nr.prefix = Buf<u32>(c->pool, nr.nb + 1);
+    nr.start = Buf<u64>(c->pool, nr.nb + 1);
+    nr.cnt = Buf<u32>(c->pool, nr.nb + 1);
+    nr.kind = Buf<u8>(c->pool, nr.nb + 1);
+    Xfer& x = xfer(c);
+    x.h2d_copy(nr.bv.get(), bv.data(), nwords * 8);
+    x.h2d_copy(nr.rank_dir.get(), rd.data(), (nwords + 1) * 8);
+    x.h2d_copy(nr.prefix.get(), prefix.data(), nr.nb * 4);
+    x.h2d_copy(nr.start.get(), start.data(), (nr.nb + 1) * 8);
+    x.h2d_copy(nr.cnt.get(), cnt.data(), nr.nb * 4);
+    x.h2d_copy(nr.kind.get(), kind.data(), nr.nb);
+    x.sync();
+    nr.a_lo = std::move(a_lo);
+    if (P.wide_suffix()) nr.a_hi = std::move(a_hi);
+    c->res = std::move(nr);
+}
+
+template <bool WS> void load_stream(cblx_ctx* c, const u8* data, u64 len, bool& canonical) {
+    const Consts& P = c->P;
+    const u32 BYTES = P.BYTES;
+    Src s{data, data + len};
+    canonical = s.u8_() != 0;
+    const u64 nb = s.varint();
+    const u64 nprefix = 1ull << P.PB;
+    if (nb > nprefix) throw Error(CBLX_EFORMAT, "index: more buckets than prefixes (wrong PREFIX_BITS?)");
+    std::vector<u32> prefix(nb), cnt(nb);
+    std::vector<u8> kind(nb);
+    StreamUp lo(c, len / 6 + 1024);
+    std::unique_ptr<StreamUp> hi;
+    if (WS) hi.reset(new StreamUp(c, len / 6 + 1024));
+    const u64 lo_mask = BYTES >= 8 ? ~0ull : ((1ull << (8 * BYTES)) - 1ull);
+    const u64 hi_mask = WS ? ((BYTES >= 16) ? ~0ull : ((1ull << (8 * (BYTES - 8))) - 1ull)) : 0ull;
+    u64 total = 0;
+    for (u64 r = 0; r < nb; ++r) {
+        const u64 p = s.varint();
+        if (p >= nprefix) throw Error(CBLX_EFORMAT, "prefix out of range for PREFIX_BITS");
+        prefix[r] = (u32)p;
+        const u64 tag = s.varint();
+        u64 n = 0;
+        if (tag == 0) {  // Vec: varint(n) then n x (varint(BYTES) | BYTES little-endian bytes), stored order
+            n = s.varint();
+            if (n > 0xFFFFFFF0ull) throw Error(CBLX_EFORMAT, "index: bucket too long");
+            u64 left = n;
+            while (left) {
+                const size_t k = (size_t)std::min<u64>(left, StreamUp::CAP);
+                u64* ol = lo.room(k);
+                u64* oh = WS ? hi->room(k) : nullptr;
+                // fast path: every element has the expected length byte and 16 readable bytes follow the chunk
+                if ((u64)(s.end - s.p) >= (u64)k * (1 + BYTES) + 16) {
+                    const u8* q = s.p;
+                    bool regular = true;
+                    for (size_t i = 0; i < k; ++i, q += 1 + BYTES) {
+                        regular &= q[0] == BYTES;
+                        ol[i] = load_le64(q + 1) & lo_mask;
+                        if (WS) oh[i] = load_le64(q + 9) & hi_mask;
+                    }
+                    if (regular) { s.p = q; lo.commit(k); if (WS) hi->commit(k); left -= k; continue; }
+                }
+                for (size_t i = 0; i < k; ++i) {  // general path (length byte != BYTES, or the tail of the input)
+                    const u64 nbts = s.varint();
+                    u128 x = 0;
+                    for (u64 b = 0; b < nbts; ++b) { const u8 v = s.u8_(); if (b < BYTES) x |= (u128)v << (8 * b); }
+                    ol[i] = (u64)x;
+                    if (WS) oh[i] = (u64)(x >> 64);
+                }
+                lo.commit(k);
+                if (WS) hi->commit(k);
+                left -= k;
+            }
+            kind[r] = KIND_VEC;
+        } else if (tag == 1) {  // Trie: pre-order nodes (explicit stack), then varint(len)
+            struct Fr { const u8* vals; u32 c, i; };
+            Fr st[16];
+            u32 d = 0;
+            u64 alo = 0, ahi = 0;
+            auto set_byte = [&](u32 depth, u8 b) {
+                u32 sh = 8 * (BYTES - 1 - depth);
+                if (sh < 64) alo = (alo & ~(0xFFull << sh)) | ((u64)b << sh);
+                else { sh -= 64; ahi = (ahi & ~(0xFFull << sh)) | ((u64)b << sh); }
+            };
+            for (;;) {
+                const u64 cc = s.varint();
+                if (cc > 256) throw Error(CBLX_EFORMAT, "index: trie node with more than 256 entries");
+                if ((u64)(s.end - s.p) < cc) throw Error(CBLX_EFORMAT, "index: unexpected end of data");
+                const u8* vals = s.p;
+                s.p += cc;
+                const u64 nc = s.varint();
+                bool descend = false;
+                if (d + 1 == BYTES) {
+                    if (nc != 0) throw Error(CBLX_EFORMAT, "index: leaf trie node with children");
+                    u64* ol = lo.room((size_t)cc);
+                    for (u64 i = 0; i < cc; ++i) ol[i] = alo | vals[i];
+                    lo.commit((size_t)cc);
+                    if (WS) { u64* oh = hi->room((size_t)cc); for (u64 i = 0; i < cc; ++i) oh[i] = ahi; hi->commit((size_t)cc); }
+                    n += cc;
+                } else {
+                    if (nc != cc) throw Error(CBLX_EFORMAT, "index: trie node children count mismatch");
+                    if (cc) { st[d] = Fr{vals, (u32)cc, 0}; set_byte(d, vals[0]); ++d; descend = true; }
+                }
+                if (descend) continue;
+                bool done = false;
+                for (;;) {  // back up to the next sibling
+                    if (d == 0) { done = true; break; }
+                    Fr& f = st[d - 1];
+                    if (++f.i < f.c) { set_byte(d - 1, f.vals[f.i]); break; }
+                    --d;
+                }
+                if (done) break;
+            }
+            const u64 nlen = s.varint();
+            if (nlen != n) throw Error(CBLX_EFORMAT, "index: trie length field does not match its contents");
+            if (n > 0xFFFFFFF0ull) throw Error(CBLX_EFORMAT, "index: bucket too long");
+            kind[r] = KIND_TRIE;
+        } else {
+            throw Error(CBLX_EFORMAT, "index: bad TrieOrVec tag");
+        }
+        cnt[r] = (u32)n;
+        total += n;
+    }
+    if (s.p != s.end) throw Error(CBLX_EFORMAT, "index: trailing bytes");  // reject_trailing_bytes
+    if (total >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "index: more than 2^32 - 16 words (per-GPU limit of this build)");
+    Buf<u64> a_lo = lo.finish(), a_hi;
+    if (WS) a_hi = hi->finish();
+    install_index(c, prefix, cnt, kind, std::move(a_lo), std::move(a_hi));
+}
+
+// `self |= other` on host copies (v1): src/wordset/set_ops.rs:123-157 + src/trievec/set_ops.rs:43-71
+// returns true when `b` changed: the reference's |= walks other's bucket with iter_sorted, which sorts a Vec in place
+bool merge_host(const Consts& P, const HostIndex& a, HostIndex& b, HostIndex& o) {
+    bool b_changed = false;
+    const bool wide = P.wide_suffix();
+    auto get = [&](const HostIndex& h, u64 i) -> u128 { return wide ? (((u128)h.hi[i] << 64) | h.lo[i]) : (u128)h.lo[i]; };
+    auto put = [&](u128 x) { o.lo.push_back((u64)x); if (wide) o.hi.push_back((u64)(x >> 64)); };
+    o.off.assign(1, 0);
+    u64 i = 0, j = 0;
+    const u64 na = a.prefix.size(), nb = b.prefix.size();
+    std::vector<u128> sa, sb;
+    while (i < na || j < nb) {
+        if (j >= nb || (i < na && a.prefix[i] < b.prefix[j])) {  // self only: untouched
+            o.prefix.push_back(a.prefix[i]); o.kind.push_back(a.kind[i]); o.cnt.push_back(a.cnt[i]);
+            for (u64 t = a.off[i]; t < a.off[i + 1]; ++t) put(get(a, t));
+            ++i;
+        } else if (i >= na || b.prefix[j] < a.prefix[i]) {       // other only: cloned as stored
+            o.prefix.push_back(b.prefix[j]); o.kind.push_back(b.kind[j]); o.cnt.push_back(b.cnt[j]);
+            for (u64 t = b.off[j]; t < b.off[j + 1]; ++t) put(get(b, t));
+            ++j;
+        } else {                                                  // both: sorted(self) ++ sorted(other \ self) or trie union
+            sa.clear(); sb.clear();
+            for (u64 t = a.off[i]; t < a.off[i + 1]; ++t) sa.push_back(get(a, t));
+            for (u64 t = b.off[j]; t < b.off[j + 1]; ++t) sb.push_back(get(b, t));
+            std::sort(sa.begin(), sa.end());
+            if (!std::is_sorted(sb.begin(), sb.end())) {
+                std::sort(sb.begin(), sb.end());
+                for (u64 t = b.off[j], q = 0; t < b.off[j + 1]; ++t, ++q) { b.lo[t] = (u64)sb[q]; if (wide) b.hi[t] = (u64)(sb[q] >> 64); }
+                b_changed = true;
+            }
+            std::vector<u128> ins;
+            std::set_difference(sb.begin(), sb.end(), sa.begin(), sa.end(), std::back_inserter(ins));
+            u64 n = 0;
+            if (a.kind[i] == KIND_VEC) {
+                for (u128 x : sa) { put(x); ++n; }
+                for (u128 x : ins) { put(x); ++n; }   // pushed at the end; no threshold check (Vec may exceed 1024)
+            } else {
+                std::vector<u128> u;
+                std::merge(sa.begin(), sa.end(), ins.begin(), ins.end(), std::back_inserter(u));
+                for (u128 x : u) { put(x); ++n; }
+            }
+            o.prefix.push_back(a.prefix[i]); o.kind.push_back(a.kind[i]); o.cnt.push_back((u32)n);
+            ++i; ++j;
+        }
+        o.off.push_back(o.lo.size());
+    }
+    return b_changed;
+}
+
+
+}  // namespace

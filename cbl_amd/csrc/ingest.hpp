@@ -1,0 +1,260 @@
+// ingest.hpp — host sequences on their way to HBM: the pinned ingest queue behind cblx_insert_seq / cblx_insert_seqs, flush,
+// and the FASTA / FASTQ reader behind cblx_insert_fastx_file. Included by cblx.cpp only.
+#pragma once
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <cstring>
+
+#include "pipeline.hpp"
+
+namespace {
+
+// ---- ingest: host sequences -> pending buffers in HBM -----------------------------------------------------------
+Xfer& xfer(cblx_ctx* c) {
+    if (!c->ing.xfer) c->ing.xfer.reset(new Xfer(c->device));
+    return *c->ing.xfer;
+}
+void ingest_wait(cblx_ctx* c) {  // every DMA issued so far has landed
+    Ingest& g = c->ing;
+    if (g.s) CBLX_HIP(hipStreamSynchronize(g.s));
+    if (g.xfer) g.xfer->sync();
+}
+void writer_issue(cblx_ctx* c, Ingest::Writer& w, u8* d_dst) {  // hand the current block to the DMA engine
+    if (w.fill == 0) return;
+    Ingest& g = c->ing;
+    CBLX_HIP(hipMemcpyAsync(d_dst + w.issued, w.blk[w.cur], w.fill, hipMemcpyHostToDevice, g.s));
+    CBLX_HIP(hipEventRecord(w.ev[w.cur], g.s));
+    w.busy[w.cur] = true;
+    w.issued += w.fill;
+    w.fill = 0;
+    w.cur ^= 1;
+    if (w.busy[w.cur]) { CBLX_HIP(hipEventSynchronize(w.ev[w.cur])); w.busy[w.cur] = false; }
+}
+void writer_put(cblx_ctx* c, Ingest::Writer& w, size_t blk_bytes, u8* d_dst, const u8* src, size_t n) {
+    Ingest& g = c->ing;
+    if (!w.blk[0]) {
+        if (!g.s) CBLX_HIP(hipStreamCreateWithFlags(&g.s, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            CBLX_HIP(hipHostMalloc((void**)&w.blk[k], blk_bytes, hipHostMallocDefault));
+            CBLX_HIP(hipEventCreateWithFlags(&w.ev[k], hipEventDisableTiming));
+        }
+        w.cap = blk_bytes;
+    }
+    while (n) {
+        const size_t m = std::min(n, w.cap - w.fill);
+        std::memcpy(w.blk[w.cur] + w.fill, src, m);
+        w.fill += m; src += m; n -= m;
+        if (w.fill == w.cap) writer_issue(c, w, d_dst);
+    }
+}
+// room for `add_bytes` more bases and `add_seqs` more sequences
+void ingest_reserve(cblx_ctx* c, u64 add_bytes, u64 add_seqs) {
+    Ingest& g = c->ing;
+    const u64 need_b = g.nbytes + add_bytes + 64, need_o = g.nseq + add_seqs + 1;
+    if (g.d_bases.n < need_b) {
+        Buf<u8> nb(c->pool, std::max<u64>({need_b, 2 * (u64)g.d_bases.n, 1u << 20}));
+        if (g.nbytes) {
+            ingest_wait(c);
+            CBLX_HIP(hipMemcpyAsync(nb.get(), g.d_bases.get(), g.wb.issued, hipMemcpyDeviceToDevice, c->stream));
+            CBLX_HIP(hipStreamSynchronize(c->stream));
+        }
+        g.d_bases = std::move(nb);
+    }
+    if (g.d_off.n < need_o) {
+        Buf<u64> no(c->pool, std::max<u64>({need_o, 2 * (u64)g.d_off.n, 1u << 14}));
+        ingest_wait(c);
+        CBLX_HIP(hipMemsetAsync(no.get(), 0, 8, c->stream));
+        if (g.nseq) CBLX_HIP(hipMemcpyAsync(no.get() + 1, g.d_off.get() + 1, g.wo.issued, hipMemcpyDeviceToDevice, c->stream));
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+        g.d_off = std::move(no);
+    }
+}
+void flush(cblx_ctx* c);
+// one sequence (the cblx_insert_seq / FASTA-record granularity)
+// a piece of the sequence being enqueued (a FASTA record arrives line by line), then its end
+void ingest_bases(cblx_ctx* c, const u8* p, u64 len) {
+    Ingest& g = c->ing;
+    ingest_reserve(c, len, 1);
+    writer_put(c, g.wb, Ingest::BASES_BLK, g.d_bases.get(), p, len);
+    g.nbytes += len;
+}
+void ingest_abort_seq(cblx_ctx* c) {  // drop the bases of an unfinished sequence
+    Ingest& g = c->ing;
+    const u64 begin = g.nseq ? g.last_end : 0;
+    g.nbytes = begin;
+    if (begin >= g.wb.issued) g.wb.fill = (size_t)(begin - g.wb.issued);
+    else { g.wb.issued = begin; g.wb.fill = 0; }
+}
+// the queue is bounded: past this many pending bases the batch is inserted (same result: batches go in in order).
+// CBLX_INGEST_FLUSH_BYTES overrides it (tests use a tiny value to exercise the incremental path).
+u64 ingest_flush_bytes() {
+    static const u64 v = [] {
+        const char* e = std::getenv("CBLX_INGEST_FLUSH_BYTES");
+        const u64 x = e ? std::strtoull(e, nullptr, 10) : 0;
+        return x ? x : (2ull << 30);
+    }();
+    return v;
+}
+void ingest_end_seq(cblx_ctx* c, u64 flush_at = ingest_flush_bytes()) {
+    Ingest& g = c->ing;
+    const u64 begin = g.nseq ? g.last_end : 0, len = g.nbytes - begin;
+    if (len < c->P.K) {  // src/cbl.rs:329-334; the record is dropped from the queue
+        ingest_abort_seq(c);
+        throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(len) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
+    }
+    const u64 end = g.nbytes;
+    writer_put(c, g.wo, Ingest::OFF_BLK, (u8*)(g.d_off.get() + 1), (const u8*)&end, 8);
+    g.nseq += 1;
+    g.last_end = end;
+    if (g.nbytes >= flush_at) flush(c);  // bound the queue (same result: batches are inserted in order)
+}
+void ingest_seq(cblx_ctx* c, const u8* seq, u64 len) {
+    ingest_bases(c, seq, len);
+    ingest_end_seq(c);
+}
+// n sequences at once (offsets already validated)
+void ingest_seqs(cblx_ctx* c, const u8* bases, const u64* offsets, u64 n) {
+    Ingest& g = c->ing;
+    const u64 len = offsets[n] - offsets[0];
+    if (len < (1u << 20)) {
+        for (u64 i = 0; i < n; ++i) ingest_seq(c, bases + offsets[i], offsets[i + 1] - offsets[i]);
+        return;
+    }
+    ingest_reserve(c, len, n);
+    if (!g.s) CBLX_HIP(hipStreamCreateWithFlags(&g.s, hipStreamNonBlocking));
+    if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
+    if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));
+    Xfer& x = xfer(c);
+    x.h2d_copy(g.d_bases.get() + g.nbytes, bases + offsets[0], len);
+    const u64 base = g.nbytes, o0 = offsets[0];
+    x.h2d(g.d_off.get() + 1 + g.nseq, n * 8, [&](u8* dst, size_t off, size_t nb) {
+        u64* d = (u64*)dst;
+        const u64* src = offsets + off / 8 + 1;
+        for (size_t j = 0; j < nb / 8; ++j) d[j] = base + (src[j] - o0);
+    });
+    g.nbytes += len;
+    g.nseq += n;
+    g.last_end = g.nbytes;
+    g.wb.issued = g.nbytes;
+    g.wo.issued = g.nseq * 8;
+    if (g.nbytes >= ingest_flush_bytes()) flush(c);
+}
+void ingest_drop(cblx_ctx* c) {  // forget everything enqueued (clear / load)
+    Ingest& g = c->ing;
+    ingest_wait(c);
+    for (Ingest::Writer* w : {&g.wb, &g.wo}) { w->fill = 0; w->issued = 0; w->busy[0] = w->busy[1] = false; }
+    g.nbytes = g.nseq = g.last_end = 0;
+}
+void ingest_destroy(cblx_ctx* c) {
+    Ingest& g = c->ing;
+    if (g.s) (void)hipStreamSynchronize(g.s);
+    g.xfer.reset();
+    for (Ingest::Writer* w : {&g.wb, &g.wo})
+        for (int k = 0; k < 2; ++k) {
+            if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
+            if (w->blk[k]) (void)hipHostFree(w->blk[k]);
+            w->ev[k] = nullptr; w->blk[k] = nullptr;
+        }
+    if (g.s) (void)hipStreamDestroy(g.s);
+    g.s = nullptr;
+    g.d_bases.reset();
+    g.d_off.reset();
+}
+
+void flush(cblx_ctx* c) {
+    Ingest& g = c->ing;
+    const u64 nseq = g.nseq;
+    if (nseq == 0) return;
+    CBLX_HIP(hipSetDevice(c->device));
+    if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
+    if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));
+    ingest_wait(c);
+    // the pending queue is consumed even if the insert fails (the reference would have panicked)
+    for (Ingest::Writer* w : {&g.wb, &g.wo}) { w->issued = 0; w->busy[0] = w->busy[1] = false; }
+    g.nbytes = g.nseq = g.last_end = 0;
+    insert_device(c, g.d_bases.get(), g.d_off.get(), nseq);
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+}
+
+
+// The `read_fasta` + `while let Some(record) = reader.next() { cbl.insert_seq(&seqrec.seq()) }` loop of
+// examples/cbl.rs:112-115,154-163 (needletail stand-in): FASTA (multi-line, CRLF tolerated) or 4-line FASTQ, plain or
+// gzip (zlib is looked up at run time; without it a .gz input is an error). The file is read in 16 MiB blocks and
+// scanned line by line with memchr; every line of bases goes straight into the pinned ingest blocks, so parsing,
+// PCIe and the GPU insert of the previous batch (every ~1 GiB of bases) overlap.
+struct ByteSource {
+    int fd = -1;
+    void* gz = nullptr;
+    void* zlib = nullptr;
+    int (*gzread_)(void*, void*, unsigned) = nullptr;
+    int (*gzclose_)(void*) = nullptr;
+    ~ByteSource() {
+        if (gz && gzclose_) gzclose_(gz);
+        if (fd >= 0) ::close(fd);
+        if (zlib) dlclose(zlib);
+    }
+    void open(const char* path) {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) throw Error(CBLX_EINVAL, std::string("Failed to open ") + path);
+        u8 magic[2] = {0, 0};
+        const ssize_t got = ::pread(fd, magic, 2, 0);
+        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            zlib = dlopen("libz.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!zlib) throw Error(CBLX_EFORMAT, std::string(path) + " is gzip-compressed and zlib (libz.so.1) is not available");
+            auto gzdopen_ = (void* (*)(int, const char*))dlsym(zlib, "gzdopen");
+            auto gzbuffer_ = (int (*)(void*, unsigned))dlsym(zlib, "gzbuffer");
+            gzread_ = (int (*)(void*, void*, unsigned))dlsym(zlib, "gzread");
+            gzclose_ = (int (*)(void*))dlsym(zlib, "gzclose");
+            if (!gzdopen_ || !gzread_ || !gzclose_) throw Error(CBLX_EFORMAT, "zlib: missing gz* symbols");
+            gz = gzdopen_(fd, "rb");
+            if (!gz) throw Error(CBLX_EINVAL, std::string("Failed to open ") + path);
+            fd = -1;  // owned by the gz handle now
+            if (gzbuffer_) gzbuffer_(gz, 1u << 20);
+        }
+    }
+    size_t read(u8* dst, size_t cap) {
+        if (gz) {
+            const int r = gzread_(gz, dst, (unsigned)std::min<size_t>(cap, 1u << 30));
+            if (r < 0) throw Error(CBLX_EFORMAT, "gzip: read error");
+            return (size_t)r;
+        }
+        const ssize_t r = ::read(fd, dst, cap);
+        if (r < 0) throw Error(CBLX_EINVAL, "read error");
+        return (size_t)r;
+    }
+};
+struct LineReader {
+    ByteSource& src;
+    std::vector<u8> buf;
+    size_t beg = 0, end = 0;
+    bool eof = false;
+    explicit LineReader(ByteSource& s) : src(s), buf(16u << 20) {}
+    // next line without its terminator ('\n' or '\r\n'); false at the end of the input
+    bool next(const u8*& p, size_t& n) {
+        for (;;) {
+            if (beg < end) {
+                const u8* nl = (const u8*)std::memchr(buf.data() + beg, '\n', end - beg);
+                if (nl || eof) {
+                    const size_t stop = nl ? (size_t)(nl - buf.data()) : end;
+                    p = buf.data() + beg;
+                    n = stop - beg;
+                    beg = nl ? stop + 1 : end;
+                    if (n && p[n - 1] == '\r') --n;
+                    return true;
+                }
+            } else if (eof) {
+                return false;
+            }
+            // no complete line buffered: keep the partial one at the front and read more
+            if (beg) { std::memmove(buf.data(), buf.data() + beg, end - beg); end -= beg; beg = 0; }
+            if (end == buf.size()) buf.resize(buf.size() * 2);
+            const size_t got = src.read(buf.data() + end, buf.size() - end);
+            if (got == 0) eof = true;
+            end += got;
+        }
+    }
+};
+
+}  // namespace

@@ -1,0 +1,568 @@
+// pipeline.hpp — one batch of words into the resident index: KRN-1 front end (chunk plan + encode), KRN-2 stable partition,
+// KRN-4 directory, KRN-3 bucket kernels, the incremental (non-empty index) path and `self |= other`. Included by cblx.cpp only.
+#pragma once
+#include "ctx.hpp"
+
+namespace {
+
+// ---- the sort + directory + per-bucket pipeline over N records (lo/hi), resident records first -------------
+struct Records {
+    Buf<u64> lo, lo2;
+    Buf<u8> hi, hi2;  // raw bytes; element size = hi_elem_size
+    const u64* ext_lo = nullptr;  // optional caller-owned source of the FIRST pass (no resident words in front)
+    const void* ext_hi = nullptr;
+};
+
+// KRN-2 + KRN-4 over N records: stable partition by prefix, then the directory (bitvector, rank directory, bucket table
+// with the RAW run of every prefix; nr.cnt / nr.kind are allocated, not filled). The sorted records end up in rec.lo/hi.
+// `countsA`: histogram of the first pass already accumulated by KRN-1 (empty Buf = compute it here)
+template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA, Resident& nr) {
+    typedef typename C::HiT HiT;
+    const Consts& P = c->P;
+    if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "more than 2^32-16 words in one index are not supported yet");
+    // ping-pong: A = rec.lo/hi, B = rec.lo2/hi2. With an external source pass 0 reads it and writes A.
+    const u64* lo = rec.ext_lo ? rec.ext_lo : rec.lo.get();
+    const HiT* hi = rec.ext_lo ? (const HiT*)rec.ext_hi : (const HiT*)rec.hi.get();
+    u64* lo2 = rec.ext_lo ? rec.lo.get() : rec.lo2.get();
+    HiT* hi2 = rec.ext_lo ? (HiT*)rec.hi.get() : (HiT*)rec.hi2.get();
+    u64* lo_other = rec.ext_lo ? rec.lo2.get() : rec.lo.get();   // the buffer that becomes the destination after pass 0
+    HiT* hi_other = rec.ext_lo ? (HiT*)rec.hi2.get() : (HiT*)rec.hi.get();
+    auto advance = [&]() { const u64* nl = lo2; const HiT* nh = hi2; lo2 = lo_other; hi2 = hi_other; lo_other = const_cast<u64*>(nl); hi_other = const_cast<HiT*>(nh); lo = nl; hi = nh; };
+    // -- KRN-2: stable radix partition on the PREFIX_BITS above SUFFIX_BITS.
+    //    Pass A sorts by the MOST significant 8 prefix bits (the skewed digit: long output runs) and cuts the array into
+    //    <= 256 segments; the remaining bits are sorted by stable LSD passes INSIDE every segment (tiles never straddle a
+    //    segment). For 65..72-bit words (K = 31) the bits the hi byte held are implied by the segment after pass A, so
+    //    it is dropped there: every later pass, the boundary scan and KRN-3 move 8-byte records only.
+    //    Per pass: tile histogram, column scan, per-segment adjust, LDS-staged scatter.
+    constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
+    Buf<u32> seg_start(c->pool, 257);
+    const u32 nA = std::min(8u, P.PB), RB = P.PB - nA;  // bits of pass A, bits left for the LSD passes
+    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    Buf<u32> start_dense(c->pool, nprefix);
+    bool have_dense = false;
+    {
+        const u32 ntiles = (u32)ceil_div(N, RDX_TILE), nt_max = ntiles + 256;
+        const u32 npassL = (RB + 7) / 8, nseg = 1u << nA;
+        // The last LSD pass cuts its tiles at (segment x lower digits) groups when there are few enough of them; the
+        // bucket directory then comes from that pass's tables (k_dir_gather) instead of a scan of the sorted records.
+        const u32 low_bits = npassL ? 8 * (npassL - 1) : 0, last_bits = RB - low_bits;
+        const bool tbl_dir = npassL >= 1 && nA + low_bits <= 16;
+        const bool grp_tiles = tbl_dir && low_bits > 0;  // low_bits = 0: the groups are the segments (existing tile table)
+        const u32 G = nseg << low_bits, nt_maxC = grp_tiles ? ntiles + G + 256 : nt_max;
+        const bool haveA = countsA.get() != nullptr;
+        Buf<u32> counts = haveA ? std::move(countsA) : Buf<u32>(c->pool, (size_t)256 * nt_max);
+        Buf<u32> colpre(c->pool, (size_t)256 * nt_maxC), scratch, coltot(c->pool, 256),
+            adj(c->pool, 256 * 256), seg_first(c->pool, 257), nt_dev(c->pool, 1), t_start(c->pool, nt_max), t_count(c->pool, nt_max);
+        Buf<u16> t_seg(c->pool, nt_max);
+        Buf<u32> grp_start, grp_first, seg_firstC, nt_devC, t_startC, t_countC;
+        Buf<u16> t_segC;
+        if (grp_tiles) {
+            grp_start = Buf<u32>(c->pool, G + 1);
+            grp_first = Buf<u32>(c->pool, G + 1);
+            seg_firstC = Buf<u32>(c->pool, 257);
+            nt_devC = Buf<u32>(c->pool, 1);
+            t_startC = Buf<u32>(c->pool, nt_maxC);
+            t_countC = Buf<u32>(c->pool, nt_maxC);
+            t_segC = Buf<u16>(c->pool, nt_maxC);
+        }
+        // digit side channel: a scatter also writes the NEXT pass's digit of every record (1 byte, same order). (When the
+        // hi byte is dropped by pass A the remaining digits all lie in the lo word: the word has <= 72 bits.)
+        Buf<u8> dig;
+        bool have_dig = false;
+        auto next_digit = [&](u32 next_pass) -> DigitBits {
+            if (next_pass >= npassL) return DigitBits{0, 0};
+            return DigitBits{P.SB + 8 * next_pass, std::min(8u, RB - 8 * next_pass)};
+        };
+        if (next_digit(0).nbits) dig = Buf<u8>(c->pool, N + 64);
+        {   // pass A
+            const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
+            const DigitBits dfn{P.SB + RB, nA};
+            const DigitBits nd = next_digit(0);
+            u8* ndp = nd.nbits ? dig.get() : nullptr;
+            if (!haveA) { StageTimer t(c, ST_HIST);
+              hipLaunchKernelGGL((k_radix_hist<HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, tv, dfn, counts.get()); }
+            { StageTimer t(c, ST_SCAN);
+              colscan(c, counts.get(), nullptr, ntiles, colpre.get(), coltot.get(), scratch);
+              hipLaunchKernelGGL(k_seg_adjust, dim3(1), dim3(256), 0, c->stream, colpre.get(), coltot.get(), (const u32*)nullptr, (const u32*)nullptr,
+                                 (const u32*)nullptr, ntiles, 1u, adj.get(), (u32*)nullptr);
+              hipLaunchKernelGGL(k_seg_table, dim3(1), dim3(256), 0, c->stream, coltot.get(), seg_start.get(), seg_first.get(), nt_dev.get());
+              hipLaunchKernelGGL(k_tile_table, grid1(nt_max, 256), dim3(256), 0, c->stream, seg_start.get(), seg_first.get(), nt_dev.get(), t_start.get(),
+                                 t_count.get(), t_seg.get()); }
+            { StageTimer t(c, ST_SCATTER);
+              if constexpr (DROP_HI)
+                  hipLaunchKernelGGL((k_radix_scatter<HiT, NoHi, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, tv, dfn, colpre.get(),
+                                     adj.get(), lo2, (NoHi*)nullptr, nd, ndp);
+              else
+                  hipLaunchKernelGGL((k_radix_scatter<HiT, HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, tv, dfn, colpre.get(),
+                                     adj.get(), lo2, hi2, nd, ndp); }
+            have_dig = ndp != nullptr;
+            advance();
+        }
+        if (counts.n < (size_t)256 * nt_maxC) counts = Buf<u32>(c->pool, (size_t)256 * nt_maxC);
+        const TileView tvL{t_start.get(), t_count.get(), t_seg.get(), nt_dev.get(), nt_max, N};
+        const TileView tvC{t_startC.get(), t_countC.get(), t_segC.get(), nt_devC.get(), nt_maxC, N};
+        for (u32 pass = 0; pass < npassL; ++pass) {
+            const DigitBits dfn{P.SB + 8 * pass, std::min(8u, RB - 8 * pass)};
+            const bool last = pass + 1 == npassL;
+            const bool cut = last && grp_tiles;  // this pass runs on the group-cut tiles
+            const TileView& tv = cut ? tvC : tvL;
+            const u32 ntm = cut ? nt_maxC : nt_max;
+            const u32 *ntd = cut ? nt_devC.get() : nt_dev.get(), *sf = cut ? seg_firstC.get() : seg_first.get();
+            auto run = [&](auto hi_tag) {
+                typedef decltype(hi_tag) H;  // record layout of the LSD passes: no hi once it was dropped
+                const H* hin = (const H*)hi;
+                H* hout = (H*)hi2;
+                const DigitBits nd = next_digit(pass + 1);
+                u8* ndp = nd.nbits && dig.get() ? dig.get() : nullptr;
+                { StageTimer t(c, ST_HIST);
+                  if (have_dig)
+                      hipLaunchKernelGGL(k_radix_hist_bytes, dim3((xcd_grid(ntm) + HISTB_WAVES - 1) / HISTB_WAVES + 8), dim3(64 * HISTB_WAVES), 0, c->stream, (const u8*)dig.get(), tv, counts.get());
+                  else
+                      hipLaunchKernelGGL((k_radix_hist<H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, counts.get()); }
+                { StageTimer t(c, ST_SCAN);
+                  colscan(c, counts.get(), ntd, ntm, colpre.get(), coltot.get(), scratch);
+                  hipLaunchKernelGGL(k_seg_adjust, dim3(nseg), dim3(256), 0, c->stream, colpre.get(), coltot.get(), sf, seg_start.get(), ntd, ntm, nseg, adj.get(),
+                                     (grp_tiles && pass + 2 == npassL) ? grp_start.get() : (u32*)nullptr);
+                  if (grp_tiles && pass + 2 == npassL) {  // the next pass is the last one: cut its tiles at the groups this pass creates
+                      hipLaunchKernelGGL(k_grp_table, dim3(1), dim3(1024), 0, c->stream, G, low_bits, grp_start.get(), seg_start.get(), (u32)N, grp_first.get(), seg_firstC.get(),
+                                         nt_devC.get());
+                      hipLaunchKernelGGL(k_tile_table_grp, grid1(nt_maxC, 256), dim3(256), 0, c->stream, G, low_bits, grp_start.get(), seg_start.get(), (u32)N, grp_first.get(), nt_devC.get(),
+                                         t_startC.get(), t_countC.get(), t_segC.get());
+                  } }
+                // more groups than the table method takes: the last pass finds the bucket starts itself (fused directory)
+                const bool fused_dir = last && !tbl_dir;
+                const u32 amb_stride = 1u << dfn.nbits;
+                Buf<u32> amb;
+                if (fused_dir) {
+                    amb = Buf<u32>(c->pool, (size_t)ntm * amb_stride);
+                    CBLX_HIP(hipMemsetAsync(start_dense.get(), 0xFF, nprefix * 4, c->stream));
+                }
+                { StageTimer t(c, ST_SCATTER);
+                  hipLaunchKernelGGL((k_radix_scatter<H, H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, colpre.get(),
+                                     adj.get(), lo2, hout, nd, ndp, fused_dir ? start_dense.get() : (u32*)nullptr, P.SB, RB, low_bits, amb.get(), amb_stride); }
+                if (fused_dir) {
+                    StageTimer t(c, ST_DIR);
+                    hipLaunchKernelGGL(k_dir_resolve<H>, grid1((u64)ntm * amb_stride, 256), dim3(256), 0, c->stream, ntd, amb_stride, (const u32*)amb.get(), tv.seg,
+                                       (const u32*)seg_start.get(), (const u64*)lo2, (const H*)hout, P.SB, RB, start_dense.get());
+                    CBLX_HIP(hipStreamSynchronize(c->stream));  // amb is released at the end of this scope
+                    have_dense = true;
+                }
+                have_dig = ndp != nullptr;
+                if (last && tbl_dir) {
+                    StageTimer t(c, ST_DIR);
+                    hipLaunchKernelGGL(k_dir_gather, dim3(G), dim3(256), 0, c->stream, low_bits, last_bits, grp_tiles ? grp_first.get() : seg_first.get(), seg_start.get(), ntd,
+                                       colpre.get(), coltot.get(), adj.get(), start_dense.get());
+                    if (grp_tiles)  // cold segments kept plain tiles: their boundaries come from their (few) records, now in lo2
+                        hipLaunchKernelGGL(k_boundaries_cold<H>, dim3(nseg, 32), dim3(256), 0, c->stream, (const u64*)lo2, (const H*)hout, P.SB, RB, seg_start.get(), start_dense.get());
+                    have_dense = true;
+                }
+            };
+            if constexpr (DROP_HI) run(NoHi()); else run(HiT());
+            advance();
+        }
+        CBLX_HIP(hipGetLastError());
+        if (lo == rec.lo2.get()) { std::swap(rec.lo, rec.lo2); std::swap(rec.hi, rec.hi2); }  // final data -> rec.lo/hi
+        CBLX_HIP(hipStreamSynchronize(c->stream));  // the pass tables are released here
+    }
+    rec.lo2.reset();
+    rec.hi2.reset();
+    // -- KRN-4: bitvector, rank directory, bucket table
+    {
+        StageTimer t(c, ST_DIR);
+        Buf<u32> popc(c->pool, nwords);
+        nr.bv = Buf<u64>(c->pool, nwords);
+        nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
+        CBLX_HIP(hipMemsetAsync(nr.bv.get(), 0, nwords * 8, c->stream));
+        CBLX_HIP(hipMemsetAsync(popc.get(), 0, nwords * 4, c->stream));
+        if (!have_dense) {  // boundaries from a scan of the sorted records (more groups than the table method takes)
+            CBLX_HIP(hipMemsetAsync(start_dense.get(), 0xFF, nprefix * 4, c->stream));
+            if constexpr (DROP_HI)
+                hipLaunchKernelGGL(k_boundaries_seg, grid1(ceil_div(N, 4), 256), dim3(256), 0, c->stream, lo, N, P.SB, RB, seg_start.get(), start_dense.get());
+            else
+                hipLaunchKernelGGL(k_boundaries<HiT>, grid1(ceil_div(N, 4), 256), dim3(256), 0, c->stream, lo, hi, N, P.SB, P.PB, start_dense.get());
+        }
+        hipLaunchKernelGGL(k_bitvector, grid1(std::max<u64>(nprefix, 64), 256), dim3(256), 0, c->stream, start_dense.get(), nprefix, nr.bv.get(), popc.get());
+        nr.nb = exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get());
+        nr.prefix = Buf<u32>(c->pool, nr.nb + 1);
+        nr.start = Buf<u64>(c->pool, nr.nb + 1);
+        nr.cnt = Buf<u32>(c->pool, nr.nb + 1);
+        nr.kind = Buf<u8>(c->pool, nr.nb + 1);
+        hipLaunchKernelGGL(k_bucket_table, grid1(nprefix, 256), dim3(256), 0, c->stream, start_dense.get(), nprefix, nr.bv.get(), nr.rank_dir.get(), nr.prefix.get(), nr.start.get());
+        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, nr.start.get() + nr.nb, N);
+        CBLX_HIP(hipGetLastError());
+    }
+}
+
+// KRN-3 over the runs of `nr` (run of a prefix = [its resident suffixes as stored][the new words in stream order]) in the
+// arena a_lo / a_hi: per-bucket dedup / sort by size class; fills nr.cnt, nr.kind, nr.count. `old` = the resident index
+// the runs were built against (tells which buckets are untouched and which are Tries already).
+template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, typename C::HiT* a_hi, const DirView& old) {
+    typedef typename C::HiT HiT;
+    const Consts& P = c->P;
+    {
+    const u64 nb = nr.nb;
+    Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
+    Buf<u32> list_n(c->pool, CLS_N);
+    Buf<u32> res_count(c->pool, nb + 1);
+    Buf<u8> res_kind(c->pool, nb + 1);
+    CBLX_HIP(hipMemsetAsync(list_n.get(), 0, CLS_N * 4, c->stream));
+    hipLaunchKernelGGL(k_classify, grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, C::WS ? 512u : 1024u, nr.prefix.get(), nr.start.get(), old,
+                       res_count.get(), res_kind.get(), nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get());
+    std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
+    if (ln[CLS_S32] | ln[CLS_S16]) {
+        StageTimer t(c, ST_BSMALL);
+        if (ln[CLS_S16])
+            hipLaunchKernelGGL((k_bucket_small<16, C::WS, HiT>), grid1((u64)ln[CLS_S16] * 16, 256), dim3(256), 0, c->stream,
+                               lists.get() + (size_t)CLS_S16 * nb, list_n.get() + CLS_S16, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+        if (ln[CLS_S32])
+            hipLaunchKernelGGL((k_bucket_small<32, C::WS, HiT>), grid1((u64)ln[CLS_S32] * 32, 256), dim3(256), 0, c->stream,
+                               lists.get() + (size_t)CLS_S32 * nb, list_n.get() + CLS_S32, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
+    }
+    {
+        StageTimer t(c, ST_BMED);
+        // fast path (counting sort on the top suffix bits + in-sub-bucket ranking); skewed buckets come back via `retry`
+        Buf<BDesc> retry(c->pool, std::max<u64>(nb, 1));
+        Buf<u32> retry_n(c->pool, 1);
+        CBLX_HIP(hipMemsetAsync(retry_n.get(), 0, 4, c->stream));
+        auto msd = [&](auto packed_tag) {
+            constexpr bool PK = decltype(packed_tag)::value;
+            if (ln[CLS_M16])
+                hipLaunchKernelGGL((k_bucket_msd<64, 128, PK, C::WS, HiT>), dim3(ln[CLS_M16]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M16 * nb,
+                                   list_n.get() + CLS_M16, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+            if (ln[CLS_M64])
+                hipLaunchKernelGGL((k_bucket_msd<64, 512, PK, C::WS, HiT>), dim3(ln[CLS_M64]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M64 * nb,
+                                   list_n.get() + CLS_M64, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+            if (ln[CLS_M128])
+                hipLaunchKernelGGL((k_bucket_msd<128, 1024, PK, C::WS, HiT>), dim3(ln[CLS_M128]), dim3(128), 0, c->stream, lists.get() + (size_t)CLS_M128 * nb,
+                                   list_n.get() + CLS_M128, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+            if (ln[CLS_M256])
+                hipLaunchKernelGGL((k_bucket_msd<256, 2048, PK, C::WS, HiT>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb,
+                                   list_n.get() + CLS_M256, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+            if (ln[CLS_M512])
+                hipLaunchKernelGGL((k_bucket_msd<512, 4096, PK, C::WS, HiT>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb,
+                                   list_n.get() + CLS_M512, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+        };
+        if constexpr (!C::WS) {
+            if (P.SB + PK_BITS <= 64) msd(std::true_type()); else msd(std::false_type());
+        } else {
+            msd(std::false_type());
+        }
+        const u32 nretry = (ln[CLS_M64] || ln[CLS_M128] || ln[CLS_M256] || ln[CLS_M512]) ? d2h<u32>(c, retry_n.get()) : 0u;
+        if (nretry)
+            hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(nretry), dim3(512), 0, c->stream, retry.get(), retry_n.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
+        if constexpr (!C::WS) if (ln[CLS_M1024])  // 128-bit suffixes: 8192 keys + indices exceed the 160 KiB LDS, such runs go to the huge path
+            hipLaunchKernelGGL((k_bucket_medium<1024, C::WS, HiT>), dim3(ln[CLS_M1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)CLS_M1024 * nb,
+                               list_n.get() + CLS_M1024, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
+        CBLX_HIP(hipStreamSynchronize(c->stream));  // retry buffers die here
+    }
+    if (ln[CLS_HUGE]) {
+        StageTimer t(c, ST_BHUGE);
+        const u32 nh = ln[CLS_HUGE];
+        std::vector<BDesc> hl = d2h_vec<BDesc>(c, lists.get() + (size_t)CLS_HUGE * nb, nh);
+        std::vector<u64> so(nh);
+        u64 tot = 0;
+        for (u32 i = 0; i < nh; ++i) { so[i] = tot; tot += hl[i].c & ~BDESC_TRIE; }
+        Buf<u64> d_so(c->pool, nh), s_alo(c->pool, tot), s_blo(c->pool, tot), s_ahi(c->pool, C::WS ? tot : 1), s_bhi(c->pool, C::WS ? tot : 1);
+        Buf<u32> s_aidx(c->pool, tot), s_bidx(c->pool, tot);
+        h2d(c, d_so.get(), so.data(), nh);
+        hipLaunchKernelGGL((k_bucket_huge<C::WS, HiT>), dim3(nh), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE,
+                           d_so.get(), a_lo, a_hi, P.SB, s_alo.get(), s_ahi.get(), s_aidx.get(), s_blo.get(), s_bhi.get(),
+                           s_bidx.get(), nr.cnt.get(), nr.kind.get(), MergeArgs{});
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+    }
+    }
+    CBLX_HIP(hipGetLastError());
+    {
+        Buf<u64> total(c->pool, 1);
+        CBLX_HIP(hipMemsetAsync(total.get(), 0, 8, c->stream));
+        hipLaunchKernelGGL(k_sum_u32, dim3((unsigned)std::min<u64>(2048, std::max<u64>(1, ceil_div(nr.nb, 256)))), dim3(256), 0, c->stream, nr.cnt.get(), nr.nb, total.get());
+        nr.count = d2h<u64>(c, total.get());
+    }
+}
+
+// rows of k_merge_table's `other` side for a freshly partitioned batch: every run is a Vec of its raw length
+__global__ void k_run_lengths(u64 nb, const u64* __restrict__ start, u32* __restrict__ cnt, u8* __restrict__ kind) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nb) return;
+    cnt[r] = (u32)(start[r + 1] - start[r]);
+    kind[r] = KIND_VEC;
+}
+
+// One batch of N new words (rec, first n_pre slots unused = 0) into the index.
+//   Empty index: partition + buckets, the sorted record array becomes the arena.
+//   Non-empty index: only the NEW words are partitioned; the resident buckets are already grouped by prefix, so the merged
+//   directory is the OR of the two bitvectors and every merged run = [resident suffixes as stored][new words of the
+//   prefix] is gathered straight from the two arrays (the resident words are never expanded and re-partitioned).
+template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA = Buf<u32>()) {
+    typedef typename C::HiT HiT;
+    constexpr bool WS = C::WS;
+    const Consts& P = c->P;
+    Resident nb_;  // directory of the batch
+    partition_and_directory<C>(c, rec, N, std::move(countsA), nb_);
+    auto adopt_arena = [&](Resident& nr) {
+        nr.a_lo = std::move(rec.lo);
+        if (WS) {  // arena hi lives in the records' hi buffer (u64 elements in this configuration)
+            nr.a_hi.pool = rec.hi.pool; nr.a_hi.p = (u64*)rec.hi.p; nr.a_hi.n = rec.hi.n / 8;
+            rec.hi.p = nullptr; rec.hi.n = 0;
+        } else {
+            rec.hi.reset();
+        }
+    };
+    if (c->res.count == 0) {
+        bucket_stage<C>(c, nb_, rec.lo.get(), (HiT*)rec.hi.get(), c->res.view());
+        adopt_arena(nb_);
+        c->res = std::move(nb_);
+        return;
+    }
+    const Resident& s = c->res;
+    if (s.count + N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "more than 2^32-16 words in one index are not supported yet");
+    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    hipLaunchKernelGGL(k_run_lengths, grid1(nb_.nb, 256), dim3(256), 0, c->stream, nb_.nb, nb_.start.get(), nb_.cnt.get(), nb_.kind.get());
+    adopt_arena(nb_);  // the sorted batch plays `other` in the gather below
+    Resident nr;
+    Buf<u32> raw, m_cs;
+    Buf<u64> m_sstart, m_ostart;
+    Buf<u8> m_skind, m_okind;
+    u64 T = 0;
+    {
+        StageTimer t(c, ST_DIR);
+        Buf<u32> popc(c->pool, nwords);
+        nr.bv = Buf<u64>(c->pool, nwords);
+        nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
+        hipLaunchKernelGGL(k_bv_or, grid1(nwords, 256), dim3(256), 0, c->stream, nwords, s.bv.get(), nb_.bv.get(), nr.bv.get(), popc.get());
+        nr.nb = exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get());
+        const u64 nb = nr.nb;
+        nr.prefix = Buf<u32>(c->pool, nb + 1);
+        nr.start = Buf<u64>(c->pool, nb + 1);
+        nr.cnt = Buf<u32>(c->pool, nb + 1);
+        nr.kind = Buf<u8>(c->pool, nb + 1);
+        raw = Buf<u32>(c->pool, nb + 1);
+        m_cs = Buf<u32>(c->pool, nb + 1);
+        m_sstart = Buf<u64>(c->pool, nb + 1);
+        m_ostart = Buf<u64>(c->pool, nb + 1);
+        m_skind = Buf<u8>(c->pool, nb + 1);
+        m_okind = Buf<u8>(c->pool, nb + 1);
+        hipLaunchKernelGGL(k_merge_table, grid1(nprefix, 256), dim3(256), 0, c->stream, nprefix, nr.bv.get(), nr.rank_dir.get(), s.view(), nb_.view(), nr.prefix.get(),
+                           raw.get(), m_cs.get(), m_sstart.get(), m_ostart.get(), m_skind.get(), m_okind.get());
+        T = exclusive_scan<u64>(c, raw.get(), nb, nr.start.get());
+        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, nr.start.get() + nb, T);
+        CBLX_HIP(hipGetLastError());
+    }
+    if (T != s.count + N) throw Error(CBLX_EDEVICE, "insert: run lengths do not match the index and the batch (internal error)");
+    nr.a_lo = Buf<u64>(c->pool, T + 2);
+    if (WS) nr.a_hi = Buf<u64>(c->pool, T + 2);
+    {
+        StageTimer t(c, ST_EXPAND);
+        hipLaunchKernelGGL((k_merge_gather<WS>), dim3((unsigned)ceil_div(nr.nb, 4)), dim3(256), 0, c->stream, nr.nb, nr.start.get(), m_cs.get(), m_sstart.get(), m_ostart.get(),
+                           s.a_lo.get(), s.a_hi.get(), nb_.a_lo.get(), nb_.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
+        CBLX_HIP(hipGetLastError());
+    }
+    bucket_stage<C>(c, nr, nr.a_lo.get(), WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr, s.view());
+    CBLX_HIP(hipStreamSynchronize(c->stream));  // the batch and the table buffers are released at scope exit
+    c->res = std::move(nr);
+}
+
+// record buffers (ping-pong) for a batch of n_new words
+template <typename C> void begin_records(cblx_ctx* c, Records& rec, u64 n_new) {
+    const size_t hs = hi_elem_size(c->P);
+    rec.lo = Buf<u64>(c->pool, n_new + 2);
+    rec.lo2 = Buf<u64>(c->pool, n_new + 2);
+    rec.hi = Buf<u8>(c->pool, hs ? (n_new + 2) * hs : 8);
+    rec.hi2 = Buf<u8>(c->pool, hs ? (n_new + 2) * hs : 8);
+}
+
+// KRN-1 front end: chunk table + validity + encode. Returns the number of new words written at rec[out_base..).
+struct ChunkPlan {
+    u64 nchunks = 0, n_kmers = 0, total_bases = 0;
+    u32 ndirty = 0;
+    u64 bias = 0;  // bytes skipped in front of the slice (multiple of 16)
+    Buf<u64> chunk_start, kmer_off;
+    Buf<u32> chunk_len, tile_first;
+    Buf<u8> dirty;
+};
+void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq, ChunkPlan& pl) {
+    StageTimer t(c, ST_CHUNKS);
+    const Consts& P = c->P;
+    // offsets may start anywhere in the buffer (a slice of a larger batch): work relative to the 16-byte aligned
+    // position below offsets[0] so that the tile grid and the validity scan cover only this slice
+    const u64 first = d2h<u64>(c, d_offsets);
+    pl.bias = first & ~(u64)15;
+    const u64 last = d2h<u64>(c, d_offsets + nseq);
+    if (last < first) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
+    pl.total_bases = last - pl.bias;
+    d_bases += pl.bias;
+    Buf<u32> nch(c->pool, nseq + 1);
+    Buf<u64> err(c->pool, 2), chunk_base(c->pool, nseq + 1);
+    CBLX_HIP(hipMemsetAsync(err.get(), 0, 16, c->stream));
+    hipLaunchKernelGGL(k_seq_chunk_count, grid1(nseq, 256), dim3(256), 0, c->stream, d_offsets, nseq, P.K, nch.get(), err.get());
+    pl.nchunks = exclusive_scan<u64>(c, nch.get(), nseq, chunk_base.get());
+    std::vector<u64> e = d2h_vec<u64>(c, err.get(), 2);
+    if (e[0]) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(e[1] - 1) + ") is smaller than K (" + std::to_string(P.K) + ")");
+    if (pl.nchunks >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "too many chunks in one batch");
+    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, chunk_base.get() + nseq, pl.nchunks);
+    pl.chunk_start = Buf<u64>(c->pool, pl.nchunks + 1);
+    pl.chunk_len = Buf<u32>(c->pool, pl.nchunks + 1);
+    Buf<u32> chunk_nk(c->pool, pl.nchunks + 1);
+    pl.dirty = Buf<u8>(c->pool, pl.nchunks + 8);
+    Buf<u32> ndirty(c->pool, 1);
+    hipLaunchKernelGGL(k_chunk_fill, grid1(pl.nchunks, 256), dim3(256), 0, c->stream, d_offsets, chunk_base.get(), nseq, pl.nchunks, P.K, pl.bias,
+                       pl.chunk_start.get(), pl.chunk_len.get(), chunk_nk.get());
+    CBLX_HIP(hipMemsetAsync(pl.dirty.get(), 0, pl.nchunks + 8, c->stream));
+    CBLX_HIP(hipMemsetAsync(ndirty.get(), 0, 4, c->stream));
+    hipLaunchKernelGGL(k_scan_invalid, grid1(ceil_div(pl.total_bases, 16), 256), dim3(256), 0, c->stream, d_bases, pl.total_bases,
+                       pl.chunk_start.get(), pl.chunk_len.get(), pl.nchunks, pl.dirty.get(), ndirty.get());
+    pl.ndirty = d2h<u32>(c, ndirty.get());
+    if (pl.ndirty)
+        hipLaunchKernelGGL(k_dirty_count, grid1(pl.nchunks, 256), dim3(256), 0, c->stream, d_bases, pl.chunk_start.get(), pl.chunk_len.get(),
+                           pl.dirty.get(), pl.nchunks, P.K, chunk_nk.get());
+    pl.kmer_off = Buf<u64>(c->pool, pl.nchunks + 1);
+    pl.n_kmers = exclusive_scan<u64>(c, chunk_nk.get(), pl.nchunks, pl.kmer_off.get());
+    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, pl.kmer_off.get() + pl.nchunks, pl.n_kmers);
+    const u64 ntiles = ceil_div(pl.total_bases, ENC_TILE_BYTES);
+    pl.tile_first = Buf<u32>(c->pool, ntiles + 2);
+    hipLaunchKernelGGL(k_tile_first_chunk, grid1(ntiles + 1, 256), dim3(256), 0, c->stream, pl.chunk_start.get(), pl.nchunks, ntiles, pl.tile_first.get());
+    CBLX_HIP(hipGetLastError());
+    CBLX_HIP(hipStreamSynchronize(c->stream));  // temporaries (nch, err, chunk_base, chunk_nk, ndirty) die here
+}
+template <typename C> void encode(cblx_ctx* c, const u8* d_bases, const ChunkPlan& pl, u64* out_lo, typename C::HiT* out_hi, u64 out_base,
+                                  EncHist eh = EncHist{}) {
+    typedef typename C::HiT HiT;
+    StageTimer t(c, ST_ENCODE);
+    const u64 ntiles = ceil_div(pl.total_bases, ENC_TILE_BYTES);
+    if (ntiles)
+        hipLaunchKernelGGL((k_encode<C::WIDE, HiT>), dim3((unsigned)ntiles), dim3(ENC_THREADS), 0, c->stream, d_bases, pl.total_bases, pl.chunk_start.get(),
+                           pl.chunk_len.get(), pl.kmer_off.get(), pl.ndirty ? pl.dirty.get() : (const u8*)nullptr, pl.tile_first.get(), c->P, out_lo, out_hi, out_base, eh);
+    if (pl.ndirty)
+        hipLaunchKernelGGL((k_encode_dirty<C::WIDE, HiT>), grid1(pl.nchunks, 64), dim3(64), 0, c->stream, d_bases, pl.chunk_start.get(), pl.chunk_len.get(),
+                           pl.kmer_off.get(), pl.dirty.get(), pl.nchunks, c->P, out_lo, out_hi, out_base, eh);
+    CBLX_HIP(hipGetLastError());
+}
+
+void check_aligned16(const void* p, const char* what) {
+    if (((uintptr_t)p) & 15) throw Error(CBLX_EINVAL, std::string(what) + " must be 16-byte aligned");
+}
+
+void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq) {
+    if (nseq == 0) return;
+    check_aligned16(d_bases, "d_bases");
+    dispatch(c->P, [&](auto cfg) {
+        typedef decltype(cfg) C;
+        ChunkPlan pl;
+        plan_chunks(c, d_bases, d_offsets, nseq, pl);
+        if (pl.n_kmers == 0) return;
+        Records rec;
+        begin_records<C>(c, rec, pl.n_kmers);
+        const u64 base = 0;
+        Buf<u32> countsA;
+        EncHist eh{};
+        {   // KRN-1 also accumulates the first partition pass's tile histogram
+            static_assert(ENC_HIST_WINDOW == RDX_TILE, "fused histogram windows must be the partition tiles");
+            const size_t ntmax = (size_t)ceil_div(pl.n_kmers, RDX_TILE) + 256;
+            countsA = Buf<u32>(c->pool, 256 * ntmax);
+            CBLX_HIP(hipMemsetAsync(countsA.get(), 0, 256 * ntmax * 4, c->stream));
+            const u32 nA = std::min(8u, c->P.PB);
+            eh.counts = countsA.get();
+            eh.shift = c->P.SB + (c->P.PB - nA);
+            eh.nbits = nA;
+        }
+        encode<C>(c, d_bases, pl, rec.lo.get(), (typename C::HiT*)rec.hi.get(), base, eh);
+        pipeline<C>(c, rec, base + pl.n_kmers, std::move(countsA));
+        c->kmers_inserted += pl.n_kmers;
+    });
+    collect_events(c);
+}
+
+// ---- `self |= other`, both resident on this device (src/cbl.rs:433-449 -> src/wordset/set_ops.rs:123-157) ---------
+template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
+    typedef typename C::HiT HiT;
+    constexpr bool WS = C::WS;
+    const Consts& P = c->P;
+    const Resident& s = c->res;
+    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    Resident nr;
+    Buf<u32> raw, m_cs;
+    Buf<u64> m_sstart, m_ostart;
+    Buf<u8> m_skind, m_okind;
+    u64 N = 0;
+    {
+        StageTimer t(c, ST_DIR);
+        Buf<u32> popc(c->pool, nwords);
+        nr.bv = Buf<u64>(c->pool, nwords);
+        nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
+        hipLaunchKernelGGL(k_bv_or, grid1(nwords, 256), dim3(256), 0, c->stream, nwords, s.bv.get(), o.bv.get(), nr.bv.get(), popc.get());
+        nr.nb = exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get());
+        const u64 nb = nr.nb;
+        nr.prefix = Buf<u32>(c->pool, nb + 1);
+        nr.start = Buf<u64>(c->pool, nb + 1);
+        nr.cnt = Buf<u32>(c->pool, nb + 1);
+        nr.kind = Buf<u8>(c->pool, nb + 1);
+        raw = Buf<u32>(c->pool, nb + 1);
+        m_cs = Buf<u32>(c->pool, nb + 1);
+        m_sstart = Buf<u64>(c->pool, nb + 1);
+        m_ostart = Buf<u64>(c->pool, nb + 1);
+        m_skind = Buf<u8>(c->pool, nb + 1);
+        m_okind = Buf<u8>(c->pool, nb + 1);
+        hipLaunchKernelGGL(k_merge_table, grid1(nprefix, 256), dim3(256), 0, c->stream, nprefix, nr.bv.get(), nr.rank_dir.get(), s.view(), o.view(), nr.prefix.get(),
+                           raw.get(), m_cs.get(), m_sstart.get(), m_ostart.get(), m_skind.get(), m_okind.get());
+        N = exclusive_scan<u64>(c, raw.get(), nb, nr.start.get());
+        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, nr.start.get() + nb, N);
+        CBLX_HIP(hipGetLastError());
+    }
+    if (N != s.count + o.count) throw Error(CBLX_EDEVICE, "merge: run lengths do not match the two indexes (internal error)");
+    const u64 nb = nr.nb;
+    nr.a_lo = Buf<u64>(c->pool, N + 2);
+    if (WS) nr.a_hi = Buf<u64>(c->pool, N + 2);
+    {
+        StageTimer t(c, ST_EXPAND);
+        hipLaunchKernelGGL((k_merge_gather<WS>), dim3((unsigned)ceil_div(nb, 4)), dim3(256), 0, c->stream, nb, nr.start.get(), m_cs.get(), m_sstart.get(), m_ostart.get(),
+                           s.a_lo.get(), s.a_hi.get(), o.a_lo.get(), o.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
+    }
+    Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
+    Buf<u32> list_n(c->pool, CLS_N);
+    CBLX_HIP(hipMemsetAsync(list_n.get(), 0, CLS_N * 4, c->stream));
+    hipLaunchKernelGGL(k_classify_merge, grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, WS ? 512u : 1024u, nr.start.get(), m_cs.get(), m_skind.get(), m_okind.get(),
+                       nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get());
+    CBLX_HIP(hipGetLastError());
+    std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
+    const MergeArgs ma{m_cs.get(), m_ostart.get(), m_okind.get(), o.a_lo.get(), o.a_hi.get()};
+    u64* a_lo = nr.a_lo.get();
+    HiT* a_hi = WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr;
+    {
+        StageTimer t(c, ST_BMED);
+        if (ln[CLS_M256])
+            hipLaunchKernelGGL((k_bucket_medium<256, WS, HiT>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb, list_n.get() + CLS_M256,
+                               a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
+        if (ln[CLS_M512])
+            hipLaunchKernelGGL((k_bucket_medium<512, WS, HiT>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb, list_n.get() + CLS_M512,
+                               a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
+        if constexpr (!WS) if (ln[CLS_M1024])
+            hipLaunchKernelGGL((k_bucket_medium<1024, WS, HiT>), dim3(ln[CLS_M1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)CLS_M1024 * nb,
+                               list_n.get() + CLS_M1024, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
+        CBLX_HIP(hipGetLastError());
+    }
+    if (ln[CLS_HUGE]) {
+        StageTimer t(c, ST_BHUGE);
+        const u32 nh = ln[CLS_HUGE];
+        std::vector<BDesc> hl = d2h_vec<BDesc>(c, lists.get() + (size_t)CLS_HUGE * nb, nh);
+        std::vector<u64> so(nh);
+        u64 tot = 0;
+        for (u32 i = 0; i < nh; ++i) { so[i] = tot; tot += hl[i].c & ~BDESC_TRIE; }
+        Buf<u64> d_so(c->pool, nh), s_alo(c->pool, tot), s_blo(c->pool, tot), s_ahi(c->pool, WS ? tot : 1), s_bhi(c->pool, WS ? tot : 1);
+        Buf<u32> s_aidx(c->pool, tot), s_bidx(c->pool, tot);
+        h2d(c, d_so.get(), so.data(), nh);
+        hipLaunchKernelGGL((k_bucket_huge<WS, HiT>), dim3(nh), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE, d_so.get(), a_lo, a_hi,
+                           P.SB, s_alo.get(), s_ahi.get(), s_aidx.get(), s_blo.get(), s_bhi.get(), s_bidx.get(), nr.cnt.get(), nr.kind.get(), ma);
+        CBLX_HIP(hipGetLastError());
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+    }
+    {
+        Buf<u64> total(c->pool, 1);
+        CBLX_HIP(hipMemsetAsync(total.get(), 0, 8, c->stream));
+        hipLaunchKernelGGL(k_sum_u32, dim3((unsigned)std::min<u64>(2048, std::max<u64>(1, ceil_div(nb, 256)))), dim3(256), 0, c->stream, nr.cnt.get(), nb, total.get());
+        nr.count = d2h<u64>(c, total.get());
+    }
+    c->res = std::move(nr);
+}
+
+
+}  // namespace
