@@ -36,6 +36,10 @@ class Consts(C.Structure):
                                           "threshold", "hi_bytes")]
 
 
+class BatchView(C.Structure):
+    _fields_ = [("n_buckets", C.c_uint64), ("n_words", C.c_uint64), ("d_prefix", C.c_void_p), ("d_count", C.c_void_p), ("d_suffix", C.c_void_p)]
+
+
 BUCKET_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 
 # name -> (restype, argtypes): every symbol include/cblx.h declares
@@ -57,6 +61,10 @@ SIGNATURES = {
                                               C.c_void_p, C.c_void_p]),
     "cblx_seq_words_partitioned_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
                                                     C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "cblx_sorted_batch_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_uint64)]),
+    "cblx_sorted_batch_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cblx_insert_sorted_batches_device": (C.c_int, [C.c_void_p, C.POINTER(BatchView), C.c_uint32]),
     "cblx_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_num_buckets": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_is_empty": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
@@ -198,6 +206,27 @@ class CBL:
         self._chk(self._L.cblx_seq_words_partitioned_device(self._h, _ptr(d_bases), _ptr(d_offsets), n, b.ctypes.data if len(b) else None, nd,
                                                             _ptr(d_out_lo), _ptr(d_out_hi), cap, counts.ctypes.data, C.byref(nw)))
         return nw.value, [int(x) for x in counts]
+
+    # ---- multi-GPU build, sorted-batch protocol (include/cblx.h) -----------------------------------------------------
+    def sorted_batch_begin(self, d_bases, d_offsets, n: int, bounds, nd: int):
+        """KRN-1 + full partition; returns (bucket_split, word_split): nd + 1 host entries each."""
+        import numpy as np
+
+        b = np.ascontiguousarray(bounds, dtype=np.uint32)
+        bs = (C.c_uint64 * (nd + 1))()
+        ws = (C.c_uint64 * (nd + 1))()
+        self._chk(self._L.cblx_sorted_batch_begin(self._h, _ptr(d_bases), _ptr(d_offsets), n, b.ctypes.data_as(C.POINTER(C.c_uint32)), nd, bs, ws))
+        return list(bs), list(ws)
+
+    def sorted_batch_export(self, d_prefix, d_count, d_suffix):
+        self._chk(self._L.cblx_sorted_batch_export(self._h, _ptr(d_prefix), _ptr(d_count), _ptr(d_suffix)))
+
+    def insert_sorted_batches_device(self, batches):
+        """batches: [(n_buckets, n_words, d_prefix, d_count, d_suffix)] in stream order."""
+        arr = (BatchView * max(len(batches), 1))()
+        for i, (nb, nw, p, c, s) in enumerate(batches):
+            arr[i] = BatchView(nb, nw, _ptr(p) if nb else None, _ptr(c) if nb else None, _ptr(s) if nw else None)
+        self._chk(self._L.cblx_insert_sorted_batches_device(self._h, arr, len(batches)))
 
     def flush(self):
         self._chk(self._L.cblx_flush(self._h))

@@ -289,6 +289,33 @@ int cblx_partition_words_device(cblx_ctx* c, const uint64_t* d_lo, const void* d
     });
 }
 
+int cblx_sorted_batch_begin(cblx_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n, const uint32_t* bounds, uint32_t nd,
+                            uint64_t* bucket_split, uint64_t* word_split) {
+    return guard(c, [&] {
+        if (nd == 0 || nd > MAX_DEST) throw Error(CBLX_EINVAL, "nd must be in 1.." + std::to_string(MAX_DEST));
+        if (!bucket_split || !word_split || (nd > 1 && !bounds) || (n && (!d_bases || !d_offsets))) throw Error(CBLX_EINVAL, "null argument");
+        for (u32 d = 0; d + 2 < nd; ++d) if (bounds[d + 1] < bounds[d]) throw Error(CBLX_EINVAL, "bounds must be ascending");
+        if (n) check_aligned16(d_bases, "d_bases");
+        dispatch(c->P, [&](auto cfg) { sorted_batch_begin<decltype(cfg)>(c, d_bases, d_offsets, n, bounds, nd, bucket_split, word_split); });
+        collect_events(c);
+    });
+}
+int cblx_sorted_batch_export(cblx_ctx* c, uint32_t* d_prefix, uint32_t* d_count, uint8_t* d_suffix) {
+    return guard(c, [&] {
+        if (c->batch.nb && (!d_prefix || !d_count || !d_suffix)) throw Error(CBLX_EINVAL, "null argument");
+        dispatch(c->P, [&](auto cfg) { sorted_batch_export<decltype(cfg)>(c, d_prefix, d_count, d_suffix); });
+    });
+}
+int cblx_insert_sorted_batches_device(cblx_ctx* c, const cblx_batch_view* batches, uint32_t n_batches) {
+    return guard(c, [&] {
+        flush(c);
+        if (n_batches == 0) return;
+        if (!batches) throw Error(CBLX_EINVAL, "null argument");
+        dispatch(c->P, [&](auto cfg) { insert_sorted_batches<decltype(cfg)>(c, batches, n_batches); });
+        collect_events(c);
+    });
+}
+
 int cblx_count(cblx_ctx* c, uint64_t* out) { return guard(c, [&] { flush(c); *out = c->res.count; }); }
 int cblx_num_buckets(cblx_ctx* c, uint64_t* out) { return guard(c, [&] { flush(c); *out = c->res.nb; }); }
 int cblx_is_empty(cblx_ctx* c, int* out) { return guard(c, [&] { flush(c); *out = c->res.nb == 0; }); }

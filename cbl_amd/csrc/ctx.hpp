@@ -113,6 +113,15 @@ struct Ingest {
     std::unique_ptr<Xfer> xfer;
 };
 
+// a fully partitioned batch of words waiting to be exported (multi-GPU build, sender side)
+struct SortedBatch {
+    u64 n = 0, nb = 0;   // words, non-empty prefixes
+    Buf<u32> prefix;     // [nb]
+    Buf<u64> start;      // [nb + 1] first record of every prefix
+    Buf<u64> lo;         // sorted records
+    Buf<u8> hi;          // their hi parts (raw bytes, element size = hi_elem_size; empty when dropped)
+};
+
 }  // namespace
 
 struct cblx_ctx {
@@ -123,6 +132,7 @@ struct cblx_ctx {
     Pool pool;
     Resident res;
     Ingest ing;
+    SortedBatch batch;
     std::string err;
     u64 kmers_inserted = 0;
     Stage stages[ST_N];

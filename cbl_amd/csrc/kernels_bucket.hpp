@@ -312,6 +312,112 @@ template <bool WS> __device__ __forceinline__ Sfx<WS> shfl_sfx(const Sfx<WS>& s,
     return r;
 }
 
+// ---- sorted batches (multi-GPU build): a batch = ascending non-empty prefixes, words per prefix, and the suffixes alone,
+// packed to BYTES little-endian bytes each, bucket-major and in stream order inside a bucket. A rank partitions its own
+// words completely, ships per destination a slice of that batch (6 B per word at K=31 / PREFIX_BITS=24 instead of 9), and
+// the receiver merges the batches of all ranks bucket by bucket: nothing is partitioned twice. ---------------------------
+__device__ __forceinline__ u64 rank_of(const u64* __restrict__ bv, const u64* __restrict__ rank_dir, u32 p) {
+    const u64 w = bv[p >> 6];
+    return rank_dir[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
+}
+// sorted records -> packed suffixes (one thread per word)
+template <bool WS, typename HiT>
+__global__ void k_batch_pack(u64 n, const u64* __restrict__ lo, const HiT* __restrict__ hi, u32 SB, u32 BYTES, u8* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Sfx<WS> s = load_sfx<WS, HiT>(lo, hi, i, SB);
+    u8* o = out + i * BYTES;
+    for (u32 k = 0; k < BYTES; ++k) {
+        u32 b;
+        if constexpr (WS) b = k < 8 ? (u32)(s.lo >> (8 * k)) : (u32)(s.hi >> (8 * (k - 8)));
+        else b = (u32)(s.lo >> (8 * k));
+        o[k] = (u8)b;
+    }
+}
+__global__ void k_batch_counts(u64 nb, const u64* __restrict__ start, u32* __restrict__ cnt) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nb) cnt[r] = (u32)(start[r + 1] - start[r]);
+}
+// first bucket with prefix >= bounds[d] (d < nbounds), and the words in front of it
+__global__ void k_batch_split(u64 nb, const u32* __restrict__ prefix, const u64* __restrict__ start, u32 nbounds, const u32* __restrict__ bounds,
+                              u64* __restrict__ bucket_split, u64* __restrict__ word_split) {
+    const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nbounds) return;
+    u64 l = 0, h = nb;
+    while (l < h) {
+        const u64 mid = (l + h) >> 1;
+        if (prefix[mid] < bounds[d]) l = mid + 1; else h = mid;
+    }
+    bucket_split[d] = l;
+    word_split[d] = start[l];  // start has nb + 1 entries
+}
+__global__ void k_batch_bits(u64 nbk, const u32* __restrict__ prefix, u64 nprefix, u64* __restrict__ bv, u32* __restrict__ bad) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbk) return;
+    const u32 p = prefix[i];
+    if (p >= nprefix || (i > 0 && prefix[i - 1] >= p)) { atomicAdd(bad, 1u); return; }  // out of range / not strictly ascending
+    atomicOr((unsigned long long*)&bv[p >> 6], 1ull << (p & 63));
+}
+__global__ void k_popc_words(u64 nwords, const u64* __restrict__ bv, u32* __restrict__ popc) {
+    const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nwords) popc[w] = (u32)__builtin_popcountll(bv[w]);
+}
+// Batches are applied one after the other (stream order): where in the merged run of its prefix does this batch's part go.
+// Prefixes are unique inside a batch, so run_len has no concurrent writers.
+__global__ void k_batch_offsets(u64 nbk, const u32* __restrict__ prefix, const u32* __restrict__ cnt, const u64* __restrict__ bv,
+                                const u64* __restrict__ rank_dir, u32* __restrict__ run_len, u32* __restrict__ off_in_run) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbk) return;
+    const u64 r = rank_of(bv, rank_dir, prefix[i]);
+    const u32 o = run_len[r];
+    off_in_run[i] = o;
+    run_len[r] = o + cnt[i];
+}
+// resident suffixes (stored order) to the front of their merged runs; one wave per merged bucket
+template <bool WS>
+__global__ __launch_bounds__(256) void k_gather_resident(u64 nb, const u64* __restrict__ start, const u32* __restrict__ m_cs, const u64* __restrict__ m_sstart,
+                                                         const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, u64* __restrict__ out_lo,
+                                                         u64* __restrict__ out_hi) {
+    const u64 r = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nb) return;
+    const u32 lane = threadIdx.x & 63, cs = m_cs[r];
+    const u64 d0 = start[r], ss = m_sstart[r];
+    for (u32 j = lane; j < cs; j += 64) {
+        out_lo[d0 + j] = s_lo[ss + j];
+        if constexpr (WS) out_hi[d0 + j] = s_hi[ss + j];
+    }
+}
+// one batch's packed suffixes into the merged runs; one wave per bucket of the batch
+template <bool WS>
+__global__ __launch_bounds__(256) void k_gather_packed(u64 nbk, const u32* __restrict__ prefix, const u32* __restrict__ cnt, const u64* __restrict__ src_off,
+                                                       const u32* __restrict__ off_in_run, const u8* __restrict__ packed, u64 packed_bytes, u32 BYTES,
+                                                       const u64* __restrict__ bv, const u64* __restrict__ rank_dir, const u64* __restrict__ start,
+                                                       u64* __restrict__ out_lo, u64* __restrict__ out_hi) {
+    const u64 i = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nbk) return;
+    const u32 lane = threadIdx.x & 63, c = cnt[i];
+    const u64 d0 = start[rank_of(bv, rank_dir, prefix[i])] + off_in_run[i];
+    const u64 e0 = src_off[i];
+    const u64 lo_mask = BYTES >= 8 ? ~0ull : ((1ull << (8 * BYTES)) - 1ull);
+    const u64 hi_mask = BYTES >= 16 ? ~0ull : (BYTES > 8 ? ((1ull << (8 * (BYTES - 8))) - 1ull) : 0ull);
+    for (u32 j = lane; j < c; j += 64) {
+        const u64 byte0 = (e0 + j) * BYTES;
+        const u8* q = packed + byte0;
+        u64 lo = 0, hi = 0;
+        if (byte0 + 16 <= packed_bytes) {  // two (unaligned) 8-byte loads; only the last element or two of a batch go byte by byte
+            lo = *reinterpret_cast<const u64*>(q) & lo_mask;
+            if constexpr (WS) hi = *reinterpret_cast<const u64*>(q + 8) & hi_mask;
+        } else {
+            for (u32 k = 0; k < BYTES; ++k) {
+                const u64 b = q[k];
+                if (k < 8) lo |= b << (8 * k); else hi |= b << (8 * (k - 8));
+            }
+        }
+        out_lo[d0 + j] = lo;
+        if constexpr (WS) out_hi[d0 + j] = hi;
+    }
+}
+
 // ---- KRN-3 small: WIDTH lanes per bucket (run <= WIDTH <= 64; 64 / WIDTH buckets share a wave), all-pairs "seen
 // before?" (the reference's own `vec.contains(x)` semantics, src/trievec/mod.rs:81-87), ordered compaction by ballot ---
 template <int WIDTH, bool WS, typename HiT>

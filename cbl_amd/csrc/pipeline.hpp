@@ -472,6 +472,148 @@ void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nse
     collect_events(c);
 }
 
+// ---- sorted batches (multi-GPU build, include/cblx.h) -------------------------------------------------------------
+// sender: KRN-1 + the full partition of the words of nseq sequences; the batch stays in c->batch
+template <typename C> void sorted_batch_begin(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq, const u32* bounds, u32 nd, u64* bucket_split,
+                                              u64* word_split) {
+    c->batch = SortedBatch();
+    for (u32 d = 0; d <= nd; ++d) bucket_split[d] = word_split[d] = 0;
+    if (nseq == 0) return;
+    ChunkPlan pl;
+    plan_chunks(c, d_bases, d_offsets, nseq, pl);
+    if (pl.n_kmers == 0) return;
+    const u64 N = pl.n_kmers;
+    Records rec;
+    begin_records<C>(c, rec, N);
+    const size_t ntmax = (size_t)ceil_div(N, RDX_TILE) + 256;
+    Buf<u32> countsA(c->pool, 256 * ntmax);
+    CBLX_HIP(hipMemsetAsync(countsA.get(), 0, 256 * ntmax * 4, c->stream));
+    const u32 nA = std::min(8u, c->P.PB);
+    EncHist eh{};
+    eh.counts = countsA.get();
+    eh.shift = c->P.SB + (c->P.PB - nA);
+    eh.nbits = nA;
+    encode<C>(c, d_bases, pl, rec.lo.get(), (typename C::HiT*)rec.hi.get(), 0, eh);
+    Resident dir;
+    partition_and_directory<C>(c, rec, N, std::move(countsA), dir);
+    SortedBatch& b = c->batch;
+    b.n = N;
+    b.nb = dir.nb;
+    b.prefix = std::move(dir.prefix);
+    b.start = std::move(dir.start);
+    b.lo = std::move(rec.lo);
+    b.hi = std::move(rec.hi);
+    bucket_split[nd] = b.nb;
+    word_split[nd] = N;
+    if (nd > 1) {
+        Buf<u32> d_bounds(c->pool, nd);
+        Buf<u64> d_bs(c->pool, nd), d_ws(c->pool, nd);
+        h2d(c, d_bounds.get(), bounds, nd - 1);
+        hipLaunchKernelGGL(k_batch_split, grid1(nd - 1, 64), dim3(64), 0, c->stream, b.nb, b.prefix.get(), b.start.get(), nd - 1, d_bounds.get(), d_bs.get(), d_ws.get());
+        CBLX_HIP(hipGetLastError());
+        std::vector<u64> bs = d2h_vec<u64>(c, d_bs.get(), nd - 1), ws = d2h_vec<u64>(c, d_ws.get(), nd - 1);
+        for (u32 d = 1; d < nd; ++d) { bucket_split[d] = bs[d - 1]; word_split[d] = ws[d - 1]; }
+    }
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+}
+template <typename C> void sorted_batch_export(cblx_ctx* c, u32* d_prefix, u32* d_count, u8* d_suffix) {
+    typedef typename C::HiT HiT;
+    SortedBatch& b = c->batch;
+    if (b.nb) {
+        CBLX_HIP(hipMemcpyAsync(d_prefix, b.prefix.get(), b.nb * 4, hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_batch_counts, grid1(b.nb, 256), dim3(256), 0, c->stream, b.nb, b.start.get(), d_count);
+        // the hi part matters only for suffixes wider than 64 bits (then it was carried through every pass)
+        hipLaunchKernelGGL((k_batch_pack<C::WS, HiT>), grid1(b.n, 256), dim3(256), 0, c->stream, b.n, b.lo.get(), C::WS ? (const HiT*)b.hi.get() : (const HiT*)nullptr,
+                           c->P.SB, c->P.BYTES, d_suffix);
+        CBLX_HIP(hipGetLastError());
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+    }
+    c->batch = SortedBatch();
+}
+// receiver: WordSet::insert_batch over sorted batches, stream order = batch order; the resident index (if any) comes first
+template <typename C> void insert_sorted_batches(cblx_ctx* c, const cblx_batch_view* bt, u32 nbt) {
+    typedef typename C::HiT HiT;
+    constexpr bool WS = C::WS;
+    const Consts& P = c->P;
+    const Resident& s = c->res;
+    u64 add = 0;
+    for (u32 b = 0; b < nbt; ++b) {
+        if (bt[b].n_buckets && (!bt[b].d_prefix || !bt[b].d_count)) throw Error(CBLX_EINVAL, "null batch arrays");
+        if (bt[b].n_words && !bt[b].d_suffix) throw Error(CBLX_EINVAL, "null batch suffixes");
+        add += bt[b].n_words;
+    }
+    if (add == 0) return;
+    if (s.count + add >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "more than 2^32-16 words in one index are not supported yet");
+    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    Resident nr;
+    Buf<u32> raw, m_cs, bad(c->pool, 1);
+    Buf<u64> m_sstart, m_ostart;
+    Buf<u8> m_skind, m_okind;
+    std::vector<Buf<u32>> off_in_run(nbt);
+    std::vector<Buf<u64>> src_off(nbt);
+    u64 T = 0;
+    {
+        StageTimer t(c, ST_DIR);
+        Buf<u32> popc(c->pool, nwords);
+        nr.bv = Buf<u64>(c->pool, nwords);
+        nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
+        if (s.count) CBLX_HIP(hipMemcpyAsync(nr.bv.get(), s.bv.get(), nwords * 8, hipMemcpyDeviceToDevice, c->stream));
+        else CBLX_HIP(hipMemsetAsync(nr.bv.get(), 0, nwords * 8, c->stream));
+        CBLX_HIP(hipMemsetAsync(bad.get(), 0, 4, c->stream));
+        for (u32 b = 0; b < nbt; ++b)
+            if (bt[b].n_buckets)
+                hipLaunchKernelGGL(k_batch_bits, grid1(bt[b].n_buckets, 256), dim3(256), 0, c->stream, bt[b].n_buckets, bt[b].d_prefix, nprefix, nr.bv.get(), bad.get());
+        hipLaunchKernelGGL(k_popc_words, grid1(nwords, 256), dim3(256), 0, c->stream, nwords, nr.bv.get(), popc.get());
+        nr.nb = exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get());
+        if (d2h<u32>(c, bad.get())) throw Error(CBLX_EINVAL, "sorted batch: prefixes must be strictly ascending and below 2^PREFIX_BITS");
+        const u64 nb = nr.nb;
+        nr.prefix = Buf<u32>(c->pool, nb + 1);
+        nr.start = Buf<u64>(c->pool, nb + 1);
+        nr.cnt = Buf<u32>(c->pool, nb + 1);
+        nr.kind = Buf<u8>(c->pool, nb + 1);
+        raw = Buf<u32>(c->pool, nb + 1);
+        m_cs = Buf<u32>(c->pool, nb + 1);
+        m_sstart = Buf<u64>(c->pool, nb + 1);
+        m_ostart = Buf<u64>(c->pool, nb + 1);
+        m_skind = Buf<u8>(c->pool, nb + 1);
+        m_okind = Buf<u8>(c->pool, nb + 1);
+        // the resident part of every merged run (raw = its length), then batch after batch on top of it
+        hipLaunchKernelGGL(k_merge_table, grid1(nprefix, 256), dim3(256), 0, c->stream, nprefix, nr.bv.get(), nr.rank_dir.get(), s.view(), DirView{}, nr.prefix.get(),
+                           raw.get(), m_cs.get(), m_sstart.get(), m_ostart.get(), m_skind.get(), m_okind.get());
+        for (u32 b = 0; b < nbt; ++b) {
+            if (!bt[b].n_buckets) continue;
+            off_in_run[b] = Buf<u32>(c->pool, bt[b].n_buckets);
+            src_off[b] = Buf<u64>(c->pool, bt[b].n_buckets + 1);
+            hipLaunchKernelGGL(k_batch_offsets, grid1(bt[b].n_buckets, 256), dim3(256), 0, c->stream, bt[b].n_buckets, bt[b].d_prefix, bt[b].d_count, nr.bv.get(),
+                               nr.rank_dir.get(), raw.get(), off_in_run[b].get());
+            const u64 nw = exclusive_scan<u64>(c, bt[b].d_count, bt[b].n_buckets, src_off[b].get());
+            if (nw != bt[b].n_words) throw Error(CBLX_EINVAL, "sorted batch: n_words does not match the counts");
+        }
+        T = exclusive_scan<u64>(c, raw.get(), nb, nr.start.get());
+        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, nr.start.get() + nb, T);
+        CBLX_HIP(hipGetLastError());
+    }
+    if (T != s.count + add) throw Error(CBLX_EDEVICE, "sorted batches: run lengths do not add up (internal error)");
+    nr.a_lo = Buf<u64>(c->pool, T + 2);
+    if (WS) nr.a_hi = Buf<u64>(c->pool, T + 2);
+    {
+        StageTimer t(c, ST_EXPAND);
+        if (s.count)
+            hipLaunchKernelGGL((k_gather_resident<WS>), dim3((unsigned)ceil_div(nr.nb, 4)), dim3(256), 0, c->stream, nr.nb, nr.start.get(), m_cs.get(), m_sstart.get(),
+                               s.a_lo.get(), s.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
+        for (u32 b = 0; b < nbt; ++b)
+            if (bt[b].n_buckets)
+                hipLaunchKernelGGL((k_gather_packed<WS>), dim3((unsigned)ceil_div(bt[b].n_buckets, 4)), dim3(256), 0, c->stream, bt[b].n_buckets, bt[b].d_prefix,
+                                   bt[b].d_count, src_off[b].get(), off_in_run[b].get(), bt[b].d_suffix, bt[b].n_words * P.BYTES, P.BYTES, nr.bv.get(), nr.rank_dir.get(), nr.start.get(),
+                                   nr.a_lo.get(), nr.a_hi.get());
+        CBLX_HIP(hipGetLastError());
+    }
+    bucket_stage<C>(c, nr, nr.a_lo.get(), WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr, s.view());
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    c->res = std::move(nr);
+    c->kmers_inserted += add;
+}
+
 // ---- `self |= other`, both resident on this device (src/cbl.rs:433-449 -> src/wordset/set_ops.rs:123-157) ---------
 template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
     typedef typename C::HiT HiT;

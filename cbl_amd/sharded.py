@@ -2,14 +2,20 @@
 
 The reference is single-process (no distributed layer); this is the path BASELINE.json's north_star
 adds: buckets are independent by prefix, so the 2^PREFIX_BITS space is cut into `world` contiguous ranges, one per
-GPU, and the transformed words cross xGMI once:
+GPU, and what the k-mers turn into crosses xGMI once. Two wire protocols (ShardedBuilder(protocol=...)):
 
-    rank r: its contiguous shard of the reads  --KRN-1-->  words (stream order)
-            --stable partition by destination range (cblx_partition_words_device)-->
-            --all-to-all over RCCL (grouped send/recv)-->  words of MY prefix range, ordered by source rank
-            --KRN-2..4 (cblx_insert_words_device)-->  resident sub-index of my range
+  "sorted" (default)
+    rank r: its contiguous shard of the reads  --KRN-1 + the FULL stable partition (cblx_sorted_batch_begin)-->
+            a prefix-sorted batch; per destination a contiguous slice of it: non-empty prefixes, words per prefix, and
+            the suffixes alone, packed (6 B per word at K=31 / PREFIX_BITS=24; a full word is 9 B)
+            --grouped send/recv over RCCL-->  the batches of all ranks for MY prefix range
+            --bucket-by-bucket merge + KRN-3 (cblx_insert_sorted_batches_device)-->  resident sub-index of my range
+    Nothing is partitioned twice, and a third fewer bytes cross the links (the exchange is what bounds the job).
+  "words"
+    rank r: KRN-1 --> words --stable partition by destination (cblx_seq_words_partitioned_device)--> exchange of the
+            9-byte words --> the whole single-GPU pipeline on the receiver (cblx_insert_words_device).
 
-Global stream order is "rank 0's reads, then rank 1's, ..." and the exchange delivers by source rank, so the
+Global stream order is slice-major, rank-minor and both protocols deliver by (slice, source rank), so the
 first-occurrence order inside Vec buckets (/root/reference/src/trievec/mod.rs:81-87) is that of the one-process
 build. Ranges are balanced by quantiles of a sampled prefix histogram because necklace prefixes are heavily skewed
 toward small values: equal-width ranges would put nearly all work on rank 0.
@@ -103,6 +109,25 @@ class GpuEngine:
     def empty_like(self, t, n):
         return self.torch.empty(n, dtype=t.dtype, device=t.device)
 
+    # ---- sorted-batch protocol ----------------------------------------------------------------------------------------
+    def suffix_bytes(self):
+        return self.cbl.consts()["bytes"]
+
+    def sorted_batch_begin(self, d_bases, d_offsets, n, bounds, nd):
+        self.device = d_bases.device
+        return self.cbl.sorted_batch_begin(d_bases, d_offsets, n, bounds, nd)
+
+    def sorted_batch_export(self, n_buckets, n_words):
+        torch = self.torch
+        prefix = torch.empty(max(n_buckets, 1), dtype=torch.int32, device=self.device)
+        count = torch.empty(max(n_buckets, 1), dtype=torch.int32, device=self.device)
+        suffix = torch.empty(max(n_words * self.suffix_bytes(), 1), dtype=torch.uint8, device=self.device)
+        self.cbl.sorted_batch_export(prefix, count, suffix)
+        return prefix[:n_buckets], count[:n_buckets], suffix[: n_words * self.suffix_bytes()]
+
+    def insert_sorted_batches(self, batches):
+        self.cbl.insert_sorted_batches_device(batches)
+
 
 class ShardedBuilder:
     """`insert_seqs_device` over a process group: every rank passes ITS contiguous shard of the reads.
@@ -113,9 +138,12 @@ class ShardedBuilder:
     i.e. file order when the file is dealt to the ranks block-cyclically; with slices=1 it is plain rank order.
     """
 
-    def __init__(self, cbl, dist, engine=None, slices: int = 4, slack: float = 1.3):
+    def __init__(self, cbl, dist, engine=None, slices: int = 4, slack: float = 1.3, protocol: str = "sorted"):
         self.cbl, self.dist = cbl, dist
         self.engine = engine or GpuEngine(cbl)
+        if protocol not in ("sorted", "words"):
+            raise ValueError("protocol must be 'sorted' or 'words'")
+        self.protocol = protocol if hasattr(self.engine, "sorted_batch_begin") else "words"
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.slices, self.slack = max(1, slices), slack
@@ -129,6 +157,71 @@ class ShardedBuilder:
         return [(n * c // slices, n * (c + 1) // slices) for c in range(slices)]
 
     def insert_seqs_device(self, d_bases, d_offsets, n):
+        if self.protocol == "sorted":
+            return self._insert_sorted(d_bases, d_offsets, n)
+        return self._insert_words(d_bases, d_offsets, n)
+
+    def _choose_bounds_from(self, d_bases, off, n):
+        """First batch only: quantile ranges from a sampled, all-reduced prefix histogram of the first slice."""
+        eng, dist = self.engine, self.dist
+        lo, hi = eng.seq_words(d_bases, off, n)
+        hist = eng.sample_hist(lo, hi)
+        dist.all_reduce(hist)
+        hb = min(HIST_BITS, self.cbl.prefix_bits)
+        self.bounds = choose_bounds(hist.cpu().numpy(), self.world, self.cbl.prefix_bits, hb)
+
+    def _insert_sorted(self, d_bases, d_offsets, n):
+        import torch
+
+        dist, eng, W = self.dist, self.engine, self.world
+        B = eng.suffix_bytes()
+        slices_in = []  # (recv_b, recv_w, prefix_r, count_r, suffix_r) per slice
+        inflight = []
+        send_tot, recv_tot = [0] * W, [0] * W
+        for a, b in self.slice_bounds(n, self.slices):
+            if b <= a:
+                continue
+            off = d_offsets[a : b + 1]  # offsets stay absolute: no copy of the bases
+            if self.bounds is None:
+                self._choose_bounds_from(d_bases, off, b - a)
+            bs, ws = eng.sorted_batch_begin(d_bases, off, b - a, self.bounds, W)
+            send_b = [int(bs[d + 1] - bs[d]) for d in range(W)]
+            send_w = [int(ws[d + 1] - ws[d]) for d in range(W)]
+            prefix, count, suffix = eng.sorted_batch_export(int(bs[W]), int(ws[W]))
+            send = torch.tensor([send_b, send_w], dtype=torch.int64, device=prefix.device).t().contiguous()  # [W, 2]
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send)
+            recv_h = recv.cpu().tolist()
+            recv_b, recv_w = [int(x[0]) for x in recv_h], [int(x[1]) for x in recv_h]
+            prefix_r = eng.empty_like(prefix, max(sum(recv_b), 1))
+            count_r = eng.empty_like(count, max(sum(recv_b), 1))
+            suffix_r = eng.empty_like(suffix, max(sum(recv_w) * B, 1))
+            works = self._exchange(prefix, prefix_r, send_b, recv_b)
+            works += self._exchange(count, count_r, send_b, recv_b)
+            works += self._exchange(suffix, suffix_r, [w * B for w in send_w], [w * B for w in recv_w])
+            inflight.append((works, prefix, count, suffix))
+            slices_in.append((recv_b, recv_w, prefix_r, count_r, suffix_r))
+            send_tot = [x + y for x, y in zip(send_tot, send_w)]
+            recv_tot = [x + y for x, y in zip(recv_tot, recv_w)]
+        for works, *_ in inflight:
+            for x in works:
+                x.wait()
+        if slices_in and slices_in[0][2].is_cuda:
+            torch.cuda.current_stream(slices_in[0][2].device).synchronize()  # libcblx runs on its own stream: hand over on the host
+        inflight = []
+        self.last_counts = (send_tot, recv_tot)
+        batches = []  # stream order: slice-major, source-rank-minor
+        for recv_b, recv_w, prefix_r, count_r, suffix_r in slices_in:
+            bo = wo = 0
+            for r in range(W):
+                if recv_w[r]:
+                    batches.append((recv_b[r], recv_w[r], prefix_r[bo : bo + recv_b[r]], count_r[bo : bo + recv_b[r]], suffix_r[wo * B : (wo + recv_w[r]) * B]))
+                bo += recv_b[r]
+                wo += recv_w[r]
+        if batches:
+            eng.insert_sorted_batches(batches)
+
+    def _insert_words(self, d_bases, d_offsets, n):
         import torch
 
         dist, eng, W = self.dist, self.engine, self.world

@@ -99,6 +99,31 @@ int cblx_seq_words_partitioned_device(cblx_ctx* ctx, const uint8_t* d_bases, con
                                       const uint32_t* bounds, uint32_t nd, uint64_t* d_out_lo, void* d_out_hi, uint64_t cap,
                                       uint64_t* counts, uint64_t* n_words);
 
+/* Multi-GPU build, "sorted batch" protocol (no reference counterpart). A rank partitions ITS words completely before the
+ * exchange; per destination it ships a slice of the prefix-sorted batch — the non-empty prefixes, their word counts and
+ * the suffixes alone, packed to suffix_bytes (= cblx_consts.bytes) little-endian bytes each: 6 B per word at K=31 /
+ * PREFIX_BITS=24 instead of the 9 B of a full word — and the receiver merges the batches of all ranks bucket by bucket
+ * without partitioning anything again. */
+typedef struct cblx_batch_view {
+    uint64_t n_buckets;       /* non-empty prefixes of the batch */
+    uint64_t n_words;
+    const uint32_t* d_prefix; /* device [n_buckets], strictly ascending */
+    const uint32_t* d_count;  /* device [n_buckets], words per prefix */
+    const uint8_t* d_suffix;  /* device [n_words * suffix_bytes], bucket-major, stream order inside a bucket */
+} cblx_batch_view;
+/* Sender: KRN-1 + the full stable partition of the words of n device-resident sequences. The batch stays in the ctx until
+ * it is exported (or replaced by the next begin). Destination d = #{i : bounds[i] <= prefix} (nd destinations, nd-1
+ * ascending host bounds) owns buckets [bucket_split[d], bucket_split[d+1]) and words [word_split[d], word_split[d+1])
+ * of it (host arrays of nd + 1 entries). */
+int cblx_sorted_batch_begin(cblx_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n, const uint32_t* bounds,
+                            uint32_t nd, uint64_t* bucket_split, uint64_t* word_split);
+/* Writes the pending batch — all destinations, in order — to caller-owned device arrays of bucket_split[nd],
+ * bucket_split[nd] and word_split[nd] * suffix_bytes elements, and drops it. */
+int cblx_sorted_batch_export(cblx_ctx* ctx, uint32_t* d_prefix, uint32_t* d_count, uint8_t* d_suffix);
+/* Receiver: WordSet::insert_batch (src/wordset/mod.rs:187-216) over n_batches sorted batches; stream order = batch
+ * order (then bucket order is irrelevant, and stream order inside a bucket of a batch is kept). */
+int cblx_insert_sorted_batches_device(cblx_ctx* ctx, const cblx_batch_view* batches, uint32_t n_batches);
+
 /* CBL::count / is_empty / is_canonical (src/cbl.rs:164-177). */
 int cblx_count(cblx_ctx* ctx, uint64_t* out);
 int cblx_num_buckets(cblx_ctx* ctx, uint64_t* out); /* tiered.len() = number of non-empty prefixes */

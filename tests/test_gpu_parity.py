@@ -338,9 +338,12 @@ def test_sharded_builder_single_rank_nccl():
             d_b, d_o = synth.reads_torch(42, 3000, 150, device="cuda")
             a, b = cbl_amd.CBL(k, pb), cbl_amd.CBL(k, pb)
             a.insert_seqs_device(d_b, d_o, 3000)
-            sharded.ShardedBuilder(b, dist).insert_seqs_device(d_b, d_o, 3000)
+            sharded.ShardedBuilder(b, dist).insert_seqs_device(d_b, d_o, 3000)  # "sorted" protocol
             blob = sharded.gather_serialized(b.serialize(), dist)
             assert blob == a.serialize()
+            w = cbl_amd.CBL(k, pb)
+            sharded.ShardedBuilder(w, dist, protocol="words").insert_seqs_device(d_b, d_o, 3000)
+            assert w.serialize() == blob
             hb, ho = synth.reads(42, 3000, 150)
             assert (d_b[: 3000 * 150].cpu().numpy() == hb).all()
             o = Oracle(k, pb)
@@ -630,3 +633,73 @@ print("ok")
     env = dict(os.environ, CBLX_INGEST_FLUSH_BYTES="100000")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_sorted_batch_protocol_matches_oracle():
+    """cblx_sorted_batch_begin / _export / cblx_insert_sorted_batches_device (the multi-GPU wire protocol): the exported
+    batch is the oracle's words stably sorted by prefix (prefixes, counts, packed suffixes, destination splits), and
+    inserting batches — several sources, with and without a resident index — equals inserting the reads in batch order."""
+    _need_gpu()
+    for k, pb, canonical, nreads, L in ((31, 24, False, 900, 150), (59, 28, True, 300, 250), (9, 4, False, 500, 120), (25, 16, False, 2000, 100)):
+        P = cbl_amd.CBL(k, pb, canonical=canonical)
+        sb_, B = P.consts()["suffix_bits"], P.consts()["bytes"]
+        nd = 4
+        bounds = np.array(sorted({(1 << pb) // 64, (1 << pb) // 16, (1 << pb) // 3}), dtype=np.uint32)
+        assert len(bounds) == nd - 1
+        recv = cbl_amd.CBL(k, pb, canonical=canonical)
+        o = Oracle(k, pb, canonical)
+        # a resident index first (reads of seed 1), then batches of seeds 2, 3, 4 exported by another ctx
+        hb, ho = synth.reads(1, nreads, L)
+        recv.insert_seqs(hb, ho)
+        o.insert_seqs(hb, ho)
+        keep = []
+        batches = []
+        for seed in (2, 3, 4):
+            hb, ho = synth.reads(seed, nreads, L)
+            d_b = torch.from_numpy(np.concatenate([hb, np.zeros(32, np.uint8)])).cuda()
+            d_o = torch.from_numpy(ho.astype(np.int64)).cuda()
+            bs, ws = P.sorted_batch_begin(d_b, d_o, nreads, bounds, nd)
+            nbk, nw = bs[nd], ws[nd]
+            prefix = torch.empty(nbk, dtype=torch.int32, device="cuda")
+            count = torch.empty(nbk, dtype=torch.int32, device="cuda")
+            suffix = torch.empty(nw * B, dtype=torch.uint8, device="cuda")
+            P.sorted_batch_export(prefix, count, suffix)
+            # against the oracle's words of the same reads, stably sorted by prefix
+            ow = Oracle(k, pb, canonical)
+            words = []
+            for i in range(nreads):
+                words += ow.seq_words(hb[int(ho[i]) : int(ho[i + 1])].tobytes())
+            assert nw == len(words)
+            words.sort(key=lambda w: w >> sb_)
+            from collections import Counter
+
+            pre = [w >> sb_ for w in words]
+            tally = Counter(pre)
+            uniq = sorted(tally)
+            assert prefix.cpu().numpy().astype(np.uint32).tolist() == uniq
+            cnt = count.cpu().tolist()
+            assert sum(cnt) == nw and cnt == [tally[p] for p in uniq]
+            raw = suffix.cpu().numpy().tobytes()
+            mask = (1 << sb_) - 1
+            assert raw == b"".join((w & mask).to_bytes(B, "little") for w in words)
+            for d in range(1, nd):
+                kb = int(np.searchsorted(np.array(uniq, dtype=np.int64), int(bounds[d - 1]), side="left"))
+                assert bs[d] == kb and ws[d] == int(np.sum(cnt[:kb]))
+            # ship it as two batches (destinations 0-1 and 2-3 of the split) to exercise several sources per insert
+            cut_b, cut_w = bs[2], ws[2]
+            for (b0, b1, w0, w1) in ((0, cut_b, 0, cut_w), (cut_b, nbk, cut_w, nw)):
+                batches.append((b1 - b0, w1 - w0, prefix[b0:b1], count[b0:b1], suffix[w0 * B : w1 * B]))
+            keep.append((prefix, count, suffix))
+            o.insert_seqs(hb, ho)
+        recv.insert_sorted_batches_device(batches[:2])   # one source on top of the resident index
+        recv.insert_sorted_batches_device(batches[2:])   # then two sources at once
+        _check_index(recv, o)
+        assert recv.validate() == 0
+        # empty index + all batches at once
+        fresh = cbl_amd.CBL(k, pb, canonical=canonical)
+        fresh.insert_sorted_batches_device(batches)
+        o2 = Oracle(k, pb, canonical)
+        for seed in (2, 3, 4):
+            hb, ho = synth.reads(seed, nreads, L)
+            o2.insert_seqs(hb, ho)
+        _check_index(fresh, o2)

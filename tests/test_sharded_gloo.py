@@ -62,8 +62,53 @@ class OracleEngine:
     def empty_like(self, t, n):
         return self.torch.empty(n, dtype=t.dtype)
 
+    # ---- sorted-batch protocol: same contracts as cblx_sorted_batch_* / cblx_insert_sorted_batches_device ------------
+    def suffix_bytes(self):
+        return (self.sb + 7) // 8
 
-def _worker(rank, world, port, k, pb, nreads, L, slices, q):
+    def sorted_batch_begin(self, bases, offsets, n, bounds, nd):
+        lo, hi = self.seq_words(bases, offsets, n)
+        words = self._to_ints(lo, hi)
+        order = sorted(range(len(words)), key=lambda i: words[i] >> self.sb)  # stable: stream order inside a prefix
+        self._batch = [words[i] for i in order]
+        from collections import Counter
+
+        tally = Counter(w >> self.sb for w in self._batch)
+        uniq = sorted(tally)
+        self._prefix = uniq
+        self._count = [tally[p] for p in uniq]
+        bs, ws = [0], [0]
+        for d in range(1, nd):
+            k = int(np.searchsorted(np.array(uniq, dtype=np.int64), int(bounds[d - 1]), side="left"))
+            bs.append(k)
+            ws.append(sum(self._count[:k]))
+        bs.append(len(uniq))
+        ws.append(len(words))
+        return bs, ws
+
+    def sorted_batch_export(self, n_buckets, n_words):
+        t = self.torch
+        B = self.suffix_bytes()
+        assert n_buckets == len(self._prefix) and n_words == len(self._batch)
+        mask = (1 << self.sb) - 1
+        raw = b"".join((w & mask).to_bytes(B, "little") for w in self._batch)
+        return (t.tensor(self._prefix, dtype=t.int32), t.tensor(self._count, dtype=t.int32),
+                t.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()) if raw else t.empty(0, dtype=t.uint8))
+
+    def insert_sorted_batches(self, batches):
+        B = self.suffix_bytes()
+        for nb, nw, prefix, count, suffix in batches:
+            raw = suffix.numpy().tobytes()
+            words, k = [], 0
+            for p, c in zip(prefix.tolist(), count.tolist()):
+                for _ in range(c):
+                    words.append(((p & 0xFFFFFFFF) << self.sb) | int.from_bytes(raw[k * B : (k + 1) * B], "little"))
+                    k += 1
+            assert k == nw
+            self.o.insert_words(words)
+
+
+def _worker(rank, world, port, k, pb, nreads, L, slices, protocol, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -83,7 +128,8 @@ def _worker(rank, world, port, k, pb, nreads, L, slices, q):
         class _Cbl:  # the two attributes ShardedBuilder reads from a CBL
             prefix_bits = pb
 
-        sb = sharded.ShardedBuilder(_Cbl(), dist, engine=OracleEngine(orc, k, pb), slices=slices)
+        sb = sharded.ShardedBuilder(_Cbl(), dist, engine=OracleEngine(orc, k, pb), slices=slices, protocol=protocol)
+        assert sb.protocol == protocol
         # two batches: the second reuses the first batch's splitters
         h = per // 2
         for a, b in ((0, h), (h, per)):
@@ -105,9 +151,10 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("protocol", ["sorted", "words"])
 @pytest.mark.parametrize("world,k,pb,nreads,L,slices", [(2, 31, 24, 240, 150, 1), (2, 31, 24, 240, 150, 3), (3, 9, 4, 600, 100, 4),
                                                         (2, 59, 28, 120, 250, 2)])
-def test_sharded_build_equals_single_process(world, k, pb, nreads, L, slices):
+def test_sharded_build_equals_single_process(world, k, pb, nreads, L, slices, protocol):
     import torch.multiprocessing as mp
 
     from cbl_amd import synth
@@ -116,7 +163,7 @@ def test_sharded_build_equals_single_process(world, k, pb, nreads, L, slices):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, k, pb, nreads, L, slices, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, k, pb, nreads, L, slices, protocol, q)) for r in range(world)]
     for p in procs:
         p.start()
     blob, bounds, counts = q.get(timeout=300)
