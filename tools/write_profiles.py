@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<tag>/ (made by tools/collect_profiles.sh on the GPU box) into the committed profiles/<round>_* files.
+Usage: tools/write_profiles.py <tag> <round>      e.g.  tools/write_profiles.py r01h r01"""
+import json
+import re
+import sys
+
+tag, rnd = sys.argv[1], sys.argv[2]
+base = f"gpurun_out/{tag}/"
+line = open(base + "bench_line.json").read().strip().splitlines()[-1]
+bl = json.loads(line)
+
+
+def parse(md):
+    out = {}
+    for l in open(md):
+        m = re.match(r"\| (.+?) \| (\w+) \| (\d+) \| ([\d.e+]+) \| ([\d.e+]+) \|", l)
+        if m:
+            out[m.group(1)] = (int(m.group(3)), float(m.group(4)), float(m.group(5)))
+    return out
+
+
+f, w = parse(base + "pmc_fetch.md"), parse(base + "pmc_write.md")
+kA = [k for k in f if "k_radix_scatter<unsigned char" in k][0]
+kL = [k for k in f if "k_radix_scatter<cblx::NoHi, cblx::NoHi, cblx::DigitBits>" in k][0]
+NK = bl["config"]["reads_per_gpu"] * (bl["config"]["read_len"] - bl["config"]["k"] + 1)
+la = {"fetch_kb_raw": f[kA][2], "write_kb_raw": w[kA][2], "alg_bytes": 18 * NK}
+ll = {"fetch_kb_raw": f[kL][2], "write_kb_raw": w[kL][2], "alg_bytes": int(16.5 * NK)}
+hbm = lambda d: (2 * d["fetch_kb_raw"] + d["write_kb_raw"]) * 1024
+avg = (hbm(la) + 2 * hbm(ll)) / 3
+tr = {
+    "config": {k: bl["config"][k] for k in ("k", "prefix_bits", "reads_per_gpu", "read_len")},
+    "kernel": "k_radix_scatter",
+    "launches": {"k_radix_scatter<u8,NoHi> (pass A: 9 B in, 8 B + 1 B digit out)": la,
+                 "k_radix_scatter<NoHi,NoHi> (LSD passes, x2: 8 B in, 8 B (+1 B digit) out)": ll},
+    "hbm_bytes_per_launch": int(avg),
+    "algorithmic_bytes_per_launch": int(51 * NK / 3),
+    "source": f"profiles/{rnd}_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE in separate passes, KB per dispatch x 1024; "
+              "FETCH doubled per the gfx950 note); average over the 3 scatter launches of a step",
+}
+json.dump(tr, open(f"profiles/{rnd}_traffic.json", "w"), indent=1)
+hdr = (f"# {rnd} (final) — rocprofv3 --kernel-trace --stats, bench.py --steps 3 --warmup 1 (cfg 2: K=31, PB=24, 10M x 150 bp, 1 x MI355X)\n\n"
+       f"Command: `bash tools/collect_profiles.sh {tag}` on the GPU box (`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 "
+       f"--no-cpu-baseline`; 4 steps incl. warm-up; averages are per launch). Same build and box: profiles/{rnd}_bench_line.json "
+       f"({bl['ms_per_step']:.1f} ms/step, {bl['value'] / 1e9:.1f} G k-mers/s).\n\n")
+rows = open(base + "kernel_stats.md").read().splitlines()
+open(f"profiles/{rnd}_kernel_stats.md", "w").write(hdr + "\n".join(rows[:48]) + "\n")
+h2 = (f"# {rnd} (final) — HBM traffic counters, separate rocprofv3 --pmc passes (kernel-trace only), bench.py --steps 1 --warmup 0\n\n"
+      "FETCH_SIZE / WRITE_SIZE in KB per dispatch (`bash tools/collect_profiles.sh`). On gfx950 FETCH_SIZE reports half of a wide coalesced "
+      "streaming read (MI355X_MICROARCH.md, HBM section): double it. k_radix_scatter, average of the three launches of a step: "
+      f"{avg / 1e9:.2f} GB of HBM traffic per launch against {51 * NK / 3 / 1e9:.2f} GB algorithmic (records + the 1-byte next-digit side channel).\n\n")
+open(f"profiles/{rnd}_pmc_hbm_traffic.md", "w").write(h2 + open(base + "pmc_fetch.md").read() + "\n" + open(base + "pmc_write.md").read())
+open(f"profiles/{rnd}_bench_line.json", "w").write(line + "\n")
+print(f"hbm {avg / 1e9:.2f} GB/launch, algorithmic {51 * NK / 3 / 1e9:.2f} GB/launch, {bl['ms_per_step']} ms/step")
