@@ -710,17 +710,22 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const BDesc* __restrict_
     Sfx<WS> key[ITEMS];
     u32 sub[ITEMS], arr[ITEMS];
     bool valid[ITEMS];
+    // all loads first, unconditionally (slots past the run re-read its first element): eight independent global loads in
+    // flight per lane instead of eight load -> wait -> use round trips inside per-slot branches
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const u32 e = w * EPW + j * 64 + lane;
         valid[j] = (u32)j < R && e < c;
-        if (valid[j]) {
-            key[j] = load_sfx<WS, HiT>(lo, hi, s0 + e, SB);
-            sub[j] = vec_only ? sfx_hash_bits<WS>(key[j], nbits) : sfx_top_bits<WS>(key[j], SB, nbits);
-            const u32 sh = (sub[j] & 1u) * 16u;
-            arr[j] = (atomicAdd(&s_off32[sub[j] >> 1], 1u << sh) >> sh) & 0xFFFFu;
-        }
+        key[j] = load_sfx<WS, HiT>(lo, hi, s0 + (valid[j] ? e : 0u), SB);
     }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        sub[j] = vec_only ? sfx_hash_bits<WS>(key[j], nbits) : sfx_top_bits<WS>(key[j], SB, nbits);
+        arr[j] = 0;
+        if (valid[j]) arr[j] = atomicAdd(&s_off32[sub[j] >> 1], 1u << ((sub[j] & 1u) * 16u));  // raw dword; the field is cut out below
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) arr[j] = (arr[j] >> ((sub[j] & 1u) * 16u)) & 0xFFFFu;
     __syncthreads();
     {   // exclusive scan of the NB counts; each thread owns `per` consecutive entries
         const u32 per = (NB + THREADS - 1) / THREADS;  // <= ITEMS
