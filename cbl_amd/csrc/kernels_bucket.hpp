@@ -750,12 +750,16 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const BDesc* __restrict_
         return;
     }
     if (tid == 0) s_off[NB] = (u16)c;
-    // scatter into sub-bucket order (arrival order inside a sub-bucket is arbitrary)
+    // scatter into sub-bucket order (arrival order inside a sub-bucket is arbitrary); the offsets are fetched for all
+    // slots at once, outside the per-slot branches (sub[] is in range for unused slots too)
+    u32 sbase[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) sbase[j] = s_off[sub[j]];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         if (valid[j]) {
             const u32 e = w * EPW + j * 64 + lane;
-            const u32 p = s_off[sub[j]] + arr[j];
+            const u32 p = sbase[j] + arr[j];
             if constexpr (PACKED) {
                 s_klo[p] = (key[j].lo << PK_BITS) | e;
             } else {
@@ -772,10 +776,7 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const BDesc* __restrict_
     u32 wave_heads = 0;
     u32 sa[ITEMS], sb[ITEMS];  // sub-bucket bounds of every item, fetched in one batch of independent LDS reads
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        sa[j] = sb[j] = 0;
-        if (valid[j]) { sa[j] = s_off[sub[j]]; sb[j] = s_off[sub[j] + 1]; }
-    }
+    for (int j = 0; j < ITEMS; ++j) { sa[j] = s_off[sub[j]]; sb[j] = s_off[sub[j] + 1]; }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         head[j] = false;
@@ -858,23 +859,24 @@ __global__ __launch_bounds__(THREADS) void k_bucket_msd(const BDesc* __restrict_
         }
         __syncthreads();
         u32 wh = 0;
+        // slot reads for all rounds at once (clamped index, no per-slot branch around the LDS read)
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const u32 p = w * EPW + j * 64 + lane;
-            head[j] = false;
-            if ((u32)j < R && p < c) {
-                if constexpr (PACKED) {
-                    const u64 v = s_klo[p];
-                    head[j] = v & 1ull;
-                    key[j].lo = v >> 1;
-                } else {
-                    key[j].lo = s_klo[p];
-                    if constexpr (WS) key[j].hi = s_khi[p];
-                    head[j] = s_idx[p] != 0;
-                }
+            const bool live = (u32)j < R && p < c;
+            const u32 pc = live ? p : 0u;
+            if constexpr (PACKED) {
+                const u64 v = s_klo[pc];
+                head[j] = live && (v & 1ull);
+                key[j].lo = v >> 1;
+            } else {
+                key[j].lo = s_klo[pc];
+                if constexpr (WS) key[j].hi = s_khi[pc];
+                head[j] = live && s_idx[pc] != 0;
             }
-            wh += (u32)__builtin_popcountll(__ballot(head[j]));
         }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) wh += (u32)__builtin_popcountll(__ballot(head[j]));
         if (lane == 0) s_wtot[w] = wh;
         __syncthreads();
         u32 run = 0;
