@@ -567,6 +567,7 @@ int cblx_clear(cblx_ctx* c) {
     return guard(c, [&] {
         CBLX_HIP(hipStreamSynchronize(c->stream));
         c->res = Resident();
+        c->batch = SortedBatch();
         ingest_drop(c);
     });
 }
