@@ -111,6 +111,10 @@ int cblx_insert_fastx_file(cblx_ctx* c, const char* path, uint64_t* n_records) {
     return guard(c, [&] {
         if (n_records) *n_records = 0;
         if (!path) throw Error(CBLX_EINVAL, "null argument");
+        {   // large plain files: parallel reader; anything it does not take is read sequentially below
+            u64 npar = 0;
+            if (fastx_parallel(c, path, &npar)) { if (n_records) *n_records = npar; return; }
+        }
         ByteSource src;
         src.open(path);
         LineReader lr(src);

@@ -3,7 +3,11 @@
 #pragma once
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
+
+#include <atomic>
 
 #include <cstring>
 
@@ -256,5 +260,198 @@ struct LineReader {
         }
     }
 };
+
+// ---- the same reader, parallel (plain files): regions of the mapped file are cut at record starts; pass 1 counts the
+// records and bases of every region (and finds anything irregular), prefix sums give every region its place in the
+// pending queue, pass 2 copies the sequence lines through one Xfer lane per thread straight to that place. Anything
+// irregular (a record shorter than K, a malformed FASTQ record, gzip, a small file) leaves it to the sequential reader
+// above, which then reproduces the reference's behaviour record by record.
+struct FastxRegion {
+    size_t beg = 0, end = 0;
+    u64 nrec = 0, nbases = 0;
+    bool bad = false;
+    std::vector<u64> ends;  // pass 2: end of every record, relative to the region's first base
+};
+inline const u8* fx_line_end(const u8* p, const u8* end) {
+    const u8* nl = (const u8*)std::memchr(p, '\n', (size_t)(end - p));
+    return nl ? nl : end;
+}
+// next position >= pos where a record starts (or size)
+size_t fx_next_record(const u8* d, size_t size, size_t pos, char fmt) {
+    const u8* end = d + size;
+    const u8* p = d + pos;
+    if (pos != 0) {  // move to the start of the next line
+        p = fx_line_end(p - 1, end);
+        if (p < end) ++p;
+    }
+    while (p < end) {
+        if (*p == (u8)fmt) {
+            if (fmt == '>') return (size_t)(p - d);
+            // FASTQ: a header is a '@' line whose second next line starts with '+' (a quality line starting with '@' is
+            // followed by a header and then a sequence line, which never starts with '+')
+            const u8* l1 = fx_line_end(p, end);
+            const u8* l2 = l1 < end ? fx_line_end(l1 + 1, end) : end;
+            if (l2 < end && l2 + 1 < end && l2[1] == '+') return (size_t)(p - d);
+        }
+        p = fx_line_end(p, end);
+        if (p < end) ++p;
+    }
+    return size;
+}
+// one walk over a region; Sink: seq(ptr, n) for every piece of sequence, rec_end() after every record
+template <typename Sink> bool fx_walk(const u8* d, const FastxRegion& r, char fmt, u32 K, Sink&& sink) {
+    const u8* p = d + r.beg;
+    const u8* end = d + r.end;
+    auto line = [&](const u8*& b, size_t& n) -> bool {
+        if (p >= end) return false;
+        const u8* e = fx_line_end(p, end);
+        b = p;
+        n = (size_t)(e - p);
+        if (n && b[n - 1] == '\r') --n;
+        p = e < end ? e + 1 : end;
+        return true;
+    };
+    const u8* b;
+    size_t n;
+    if (fmt == '>') {
+        bool open_rec = false;
+        u64 len = 0;
+        while (line(b, n)) {
+            if (n && b[0] == '>') {
+                if (open_rec) { if (len < K) return false; sink.rec_end(); }
+                open_rec = true;
+                len = 0;
+            } else if (n) {
+                if (!open_rec) return false;  // sequence before the first header
+                sink.seq(b, n);
+                len += n;
+            }
+        }
+        if (open_rec) { if (len < K) return false; sink.rec_end(); }
+        return true;
+    }
+    while (line(b, n)) {
+        if (n == 0) continue;  // blank line between records
+        if (b[0] != '@') return false;
+        const u8 *sq, *pl, *ql;
+        size_t ns, npl, nq;
+        if (!line(sq, ns) || !line(pl, npl) || !line(ql, nq)) return false;
+        if (npl == 0 || pl[0] != '+' || ns < K) return false;
+        sink.seq(sq, ns);
+        sink.rec_end();
+    }
+    return true;
+}
+bool fastx_parallel(cblx_ctx* c, const char* path, u64* nrec_out) {
+    auto env_bytes = [](const char* name, size_t dflt) {  // test hooks: small files through the parallel path
+        const char* e = std::getenv(name);
+        const unsigned long long v = e ? std::strtoull(e, nullptr, 10) : 0;
+        return v ? (size_t)v : dflt;
+    };
+    const size_t MIN_BYTES = env_bytes("CBLX_FASTX_PARALLEL_MIN", 32u << 20), REGION = env_bytes("CBLX_FASTX_REGION_BYTES", 16u << 20);
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || (size_t)st.st_size < MIN_BYTES) { ::close(fd); return false; }
+    const size_t size = (size_t)st.st_size;
+    const u8* d = (const u8*)::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (d == (const u8*)MAP_FAILED) return false;
+    struct Unmap { const u8* d; size_t n; ~Unmap() { ::munmap((void*)d, n); } } unmap{d, size};
+    (void)::madvise((void*)d, size, MADV_SEQUENTIAL);
+    if (d[0] == 0x1f && d[1] == 0x8b) return false;  // gzip: sequential reader
+    size_t first = 0;
+    while (first < size && (d[first] == '\n' || d[first] == '\r')) ++first;
+    if (first == size || (d[first] != '>' && d[first] != '@')) return false;
+    const char fmt = (char)d[first];
+    // regions
+    std::vector<FastxRegion> regs;
+    for (size_t pos = first; pos < size;) {
+        const size_t nxt = pos + REGION < size ? fx_next_record(d, size, pos + REGION, fmt) : size;
+        FastxRegion r;
+        r.beg = pos;
+        r.end = nxt;
+        regs.push_back(std::move(r));
+        pos = nxt;
+    }
+    const int T = (int)std::min<size_t>((size_t)Xfer::max_parallel(), regs.size());
+    const u32 K = c->P.K;
+    auto parallel_for = [&](auto&& fn) {  // counting needs no lanes: use more threads than pass 2 may
+        const unsigned hc = std::thread::hardware_concurrency();
+        const int TC = (int)std::min<size_t>(std::max(1u, std::min(32u, hc ? hc / 2 : 2u)), regs.size());
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        auto body = [&] { for (size_t i; (i = next.fetch_add(1)) < regs.size();) fn(regs[i]); };
+        for (int t = 1; t < TC; ++t) th.emplace_back(body);
+        body();
+        for (auto& x : th) x.join();
+    };
+    // pass 1: count
+    struct Count { u64 nrec = 0, nbases = 0; void seq(const u8*, size_t n) { nbases += n; } void rec_end() { ++nrec; } };
+    parallel_for([&](FastxRegion& r) {
+        Count cnt;
+        r.bad = !fx_walk(d, r, fmt, K, cnt);
+        r.nrec = cnt.nrec;
+        r.nbases = cnt.nbases;
+    });
+    for (auto& r : regs) if (r.bad) return false;
+    // pass 2, in windows of about 1 GiB of bases (the sequential reader's flush cadence)
+    const u64 flush_at = std::min<u64>(1ull << 30, ingest_flush_bytes());
+    Ingest& g = c->ing;
+    u64 total_rec = 0;
+    for (size_t w0 = 0; w0 < regs.size();) {
+        size_t w1 = w0;
+        u64 wb = 0, wr = 0;
+        while (w1 < regs.size() && (w1 == w0 || wb + regs[w1].nbases <= flush_at)) { wb += regs[w1].nbases; wr += regs[w1].nrec; ++w1; }
+        if (wr) {
+            ingest_reserve(c, wb, wr);
+            if (!g.s) CBLX_HIP(hipStreamCreateWithFlags(&g.s, hipStreamNonBlocking));
+            if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
+            if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));
+            std::vector<u64> base(w1 - w0 + 1, g.nbytes);
+            for (size_t i = w0; i < w1; ++i) base[i - w0 + 1] = base[i - w0] + regs[i].nbases;
+            Xfer& x = xfer(c);
+            std::atomic<size_t> next{w0};
+            std::atomic<bool> failed{false};
+            const int TW = (int)std::min<size_t>((size_t)T, w1 - w0);
+            x.with_lanes(TW, [&](int t) {
+                for (size_t i; (i = next.fetch_add(1)) < w1;) {
+                    FastxRegion& r = regs[i];
+                    Xfer::LaneWriter lw(x, t, g.d_bases.get() + base[i - w0]);
+                    struct Copy {
+                        Xfer::LaneWriter& lw;
+                        std::vector<u64>& ends;
+                        void seq(const u8* p, size_t n) { lw.put(p, n); }
+                        void rec_end() { ends.push_back(lw.written()); }
+                    } cp{lw, r.ends};
+                    r.ends.reserve(r.nrec);
+                    if (!fx_walk(d, r, fmt, K, cp) || lw.written() != r.nbases || r.ends.size() != r.nrec) failed = true;
+                    lw.finish();
+                }
+            });
+            x.sync();
+            if (failed) throw Error(CBLX_EDEVICE, "fastx: the file changed while it was being read");
+            // record ends -> absolute positions in the pending queue, appended to the offsets
+            std::vector<u64> ends;
+            ends.reserve(wr);
+            for (size_t i = w0; i < w1; ++i) {
+                for (u64 e : regs[i].ends) ends.push_back(base[i - w0] + e);
+                std::vector<u64>().swap(regs[i].ends);
+            }
+            x.h2d_copy(g.d_off.get() + 1 + g.nseq, ends.data(), ends.size() * 8);
+            x.sync();
+            g.nbytes += wb;
+            g.nseq += wr;
+            g.last_end = g.nbytes;
+            g.wb.issued = g.nbytes;
+            g.wo.issued = g.nseq * 8;
+            total_rec += wr;
+            if (g.nbytes >= flush_at) flush(c);
+        }
+        w0 = w1;
+    }
+    if (nrec_out) *nrec_out = total_rec;
+    return true;
+}
 
 }  // namespace

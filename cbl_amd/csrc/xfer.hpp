@@ -21,6 +21,13 @@
 namespace cblx {
 
 class Xfer {
+    struct Lane {
+        hipStream_t s = nullptr;
+        u8* slot[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool busy[2] = {false, false};
+    };
+
 public:
     static constexpr size_t SLOT = 8u << 20;       // bytes per pinned slot
     static constexpr size_t PARALLEL_MIN = 4u << 20;  // below this a transfer stays on the calling thread (lane 0)
@@ -85,18 +92,58 @@ public:
     void d2h_copy(void* h_dst, const void* d_src, size_t bytes) {
         d2h(d_src, bytes, [&](const u8* src, size_t off, size_t n) { std::memcpy((u8*)h_dst + off, src, n); });
     }
+    // Lanes lent to producers that generate bytes at their own pace (file parsers): with_lanes(T, work) runs work(t) on T
+    // threads; thread t may open LaneWriters on lane t only. A LaneWriter is an append-only stream into device memory:
+    // put() copies into the lane's pinned slots and DMAs every full slot to d_dst + (bytes put so far).
+    static int max_parallel() {  // producers are CPU-bound (parsing): more lanes than a plain copy needs to fill the link
+        unsigned hc = std::thread::hardware_concurrency();
+        return (int)std::max(1u, std::min(16u, hc ? hc / 2 : 2u));
+    }
+    template <typename W> void with_lanes(int T, W&& work) {
+        ensure(T);
+        fan_out(T, [&](int t) { CBLX_HIP(hipSetDevice(device_)); work(t); });
+    }
+    class LaneWriter {
+    public:
+        LaneWriter(Xfer& x, int lane, u8* d_dst) : l_(x.lanes_[(size_t)lane]), d_dst_(d_dst) {
+            for (int b = 0; b < 2; ++b)
+                if (l_.busy[b]) { CBLX_HIP(hipEventSynchronize(l_.ev[b])); l_.busy[b] = false; }
+        }
+        void put(const void* src, size_t n) {
+            const u8* p = (const u8*)src;
+            while (n) {
+                const size_t m = std::min(n, SLOT - fill_);
+                std::memcpy(l_.slot[k_] + fill_, p, m);
+                fill_ += m; p += m; n -= m;
+                if (fill_ == SLOT) issue();
+            }
+        }
+        void finish() { issue(); }
+        u64 written() const { return done_ + fill_; }
+    private:
+        void issue() {
+            if (fill_ == 0) return;
+            CBLX_HIP(hipMemcpyAsync(d_dst_ + done_, l_.slot[k_], fill_, hipMemcpyHostToDevice, l_.s));
+            CBLX_HIP(hipEventRecord(l_.ev[k_], l_.s));
+            l_.busy[k_] = true;
+            done_ += fill_;
+            fill_ = 0;
+            k_ ^= 1;
+            if (l_.busy[k_]) { CBLX_HIP(hipEventSynchronize(l_.ev[k_])); l_.busy[k_] = false; }
+        }
+        Lane& l_;
+        u8* d_dst_;
+        int k_ = 0;
+        size_t fill_ = 0;
+        u64 done_ = 0;
+    };
+
     // all DMA issued by h2d() has landed
     void sync() {
         for (auto& l : lanes_) if (l.s) CBLX_HIP(hipStreamSynchronize(l.s));
     }
 
 private:
-    struct Lane {
-        hipStream_t s = nullptr;
-        u8* slot[2] = {nullptr, nullptr};
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        bool busy[2] = {false, false};
-    };
     int device_;
     std::vector<Lane> lanes_;
 

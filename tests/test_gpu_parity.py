@@ -703,3 +703,51 @@ def test_sorted_batch_protocol_matches_oracle():
             hb, ho = synth.reads(seed, nreads, L)
             o2.insert_seqs(hb, ho)
         _check_index(fresh, o2)
+
+
+def test_parallel_fastx_reader(tmp_path):
+    """Large plain FASTA / FASTQ files are read by several threads (regions cut at record starts, two passes). With the
+    thresholds lowered (child process) small files take that path: many regions, several flush windows; irregular input
+    falls back to the sequential reader and fails exactly as it does."""
+    _need_gpu()
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import cbl_amd
+from cbl_amd import synth
+from oracle import Oracle
+k, pb = 31, 24
+tmp = %r
+bases, offsets = synth.reads(77, 12000, 150)
+o = Oracle(k, pb); o.insert_seqs(bases, offsets); want = o.serialize()
+seqs = [bases[int(offsets[i]):int(offsets[i + 1])].tobytes() for i in range(len(offsets) - 1)]
+files = {
+  "a.fa": b"".join(b">r%%d\n" %% i + s + b"\n" for i, s in enumerate(seqs)),
+  "b.fa": b"\n" + b"".join(b">r%%d x\r\n" %% i + s[:70] + b"\r\n" + s[70:] + b"\r\n\r\n" for i, s in enumerate(seqs))[:-2],
+  "c.fq": b"".join(b"@r%%d\n" %% i + s + b"\n+\n" + (b"@" if i %% 3 == 0 else b"I") * len(s) + b"\n" for i, s in enumerate(seqs)),
+}
+for name, data in files.items():
+    path = tmp + "/" + name
+    open(path, "wb").write(data)
+    g = cbl_amd.CBL(k, pb)
+    assert g.insert_fastx_file(path) == len(seqs), name
+    assert g.serialize() == want, name
+# a short record in the middle: same error and same partial result as the sequential reader
+bad = tmp + "/bad.fa"
+open(bad, "wb").write(files["a.fa"][:200000].rsplit(b">", 1)[0] + b">short\nACGT\n" + files["a.fa"][200000:].split(b"\n", 1)[1])
+g = cbl_amd.CBL(k, pb)
+try:
+    g.insert_fastx_file(bad)
+    raise SystemExit("no error")
+except cbl_amd.CblxError as e:
+    assert "smaller than K" in str(e)
+n_before = files["a.fa"][:200000].rsplit(b">", 1)[0].count(b">")
+o2 = Oracle(k, pb); o2.insert_seqs(bases[: n_before * 150], offsets[: n_before + 1]); assert g.serialize() == o2.serialize()
+print("ok")
+""" % (ROOT, str(tmp_path))
+    env = dict(os.environ, CBLX_FASTX_PARALLEL_MIN="1000", CBLX_FASTX_REGION_BYTES="90000", CBLX_INGEST_FLUSH_BYTES="500000")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
