@@ -44,6 +44,7 @@ template <typename T> __host__ __device__ inline void necklace_pos_fast(T x, uns
     // rotl by s on the BITS-bit ring (0 < s < BITS)
     auto rotl_ring = [&](T v, unsigned s) -> T { return ((v << s) & MASK) | (v >> (BITS - s)); };
     T r = ~x & MASK;  // bit s: x has a zero at s                       (runs >= 1)
+    unsigned L = 1;   // length of the runs r marks
     {   // Doubling, then a greedy binary refinement: with R_L = "a run of >= L zeros ends (downwards) at bit s",
         // R_{L+d} = R_L & rotl(R_L, d) for d <= L. Every lane of a wave executes the same few steps (a lane-dependent
         // linear search cost every lane the length of the longest run in the wave).
@@ -51,16 +52,26 @@ template <typename T> __host__ __device__ inline void necklace_pos_fast(T x, uns
         const T r4 = r2 & rotl_ring(r2, 2);  // runs >= 4
         if (r4) {
             r = r4;                                            // L = 4
-            T t = r & rotl_ring(r, 4); r = t ? t : r;          // L in {4, 8}
-            t = r & rotl_ring(r, 2); r = t ? t : r;            // L in {4, 6, 8, 10}
+            L = 4;
+            T t = r & rotl_ring(r, 4); if (t) { r = t; L += 4; }  // L in {4, 8}
+            t = r & rotl_ring(r, 2); if (t) { r = t; L += 2; }    // L in {4, 6, 8, 10}
         } else if (r2) {
             r = r2;                                            // L in {2, 3}
+            L = 2;
         }
     }
     for (;;) {  // at most a step or two for all but the longest runs
         T t = r & rotl_ring(r, 1);
         if (t == 0) break;
         r = t;
+        ++L;
+    }
+    {   // Every candidate reads 0^L 1 from its top; the next bit decides next: keep only the candidates that continue with
+        // a 0, if there are any (a cheap mask operation that saves a round of the rotate-and-compare loop below for the
+        // slowest lane of most waves).
+        const T z = ~x & MASK;
+        const T t = r & rotl_ring(z, L + 1);  // L + 1 <= BITS; a rotation by BITS is the identity here
+        r = t ? t : r;
     }
     constexpr int TB = (int)sizeof(T) * 8;
     T best = MASK;
