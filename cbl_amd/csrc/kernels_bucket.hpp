@@ -351,11 +351,12 @@ __global__ void k_batch_split(u64 nb, const u32* __restrict__ prefix, const u64*
     bucket_split[d] = l;
     word_split[d] = start[l];  // start has nb + 1 entries
 }
-__global__ void k_batch_bits(u64 nbk, const u32* __restrict__ prefix, u64 nprefix, u64* __restrict__ bv, u32* __restrict__ bad) {
+__global__ void k_batch_bits(u64 nbk, const u32* __restrict__ prefix, const u32* __restrict__ cnt, u64 nprefix, u64* __restrict__ bv, u32* __restrict__ bad) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nbk) return;
     const u32 p = prefix[i];
-    if (p >= nprefix || (i > 0 && prefix[i - 1] >= p)) { atomicAdd(bad, 1u); return; }  // out of range / not strictly ascending
+    // out of range / not strictly ascending / an empty bucket (would leave a set bit without words)
+    if (p >= nprefix || (i > 0 && prefix[i - 1] >= p) || cnt[i] == 0) { atomicAdd(bad, 1u); return; }
     atomicOr((unsigned long long*)&bv[p >> 6], 1ull << (p & 63));
 }
 __global__ void k_popc_words(u64 nwords, const u64* __restrict__ bv, u32* __restrict__ popc) {

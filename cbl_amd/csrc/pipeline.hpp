@@ -562,10 +562,10 @@ template <typename C> void insert_sorted_batches(cblx_ctx* c, const cblx_batch_v
         CBLX_HIP(hipMemsetAsync(bad.get(), 0, 4, c->stream));
         for (u32 b = 0; b < nbt; ++b)
             if (bt[b].n_buckets)
-                hipLaunchKernelGGL(k_batch_bits, grid1(bt[b].n_buckets, 256), dim3(256), 0, c->stream, bt[b].n_buckets, bt[b].d_prefix, nprefix, nr.bv.get(), bad.get());
+                hipLaunchKernelGGL(k_batch_bits, grid1(bt[b].n_buckets, 256), dim3(256), 0, c->stream, bt[b].n_buckets, bt[b].d_prefix, bt[b].d_count, nprefix, nr.bv.get(), bad.get());
         hipLaunchKernelGGL(k_popc_words, grid1(nwords, 256), dim3(256), 0, c->stream, nwords, nr.bv.get(), popc.get());
         nr.nb = exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get());
-        if (d2h<u32>(c, bad.get())) throw Error(CBLX_EINVAL, "sorted batch: prefixes must be strictly ascending and below 2^PREFIX_BITS");
+        if (d2h<u32>(c, bad.get())) throw Error(CBLX_EINVAL, "sorted batch: prefixes must be strictly ascending and below 2^PREFIX_BITS, counts non-zero");
         const u64 nb = nr.nb;
         nr.prefix = Buf<u32>(c->pool, nb + 1);
         nr.start = Buf<u64>(c->pool, nb + 1);

@@ -703,6 +703,17 @@ def test_sorted_batch_protocol_matches_oracle():
             hb, ho = synth.reads(seed, nreads, L)
             o2.insert_seqs(hb, ho)
         _check_index(fresh, o2)
+    # malformed batches are refused and leave the index as it was
+    g = cbl_amd.CBL(31, 24)
+    g.insert_seq(b"ACGT" * 20)
+    before = g.serialize()
+    pfx = torch.tensor([5, 5], dtype=torch.int32, device="cuda")
+    cnt = torch.tensor([1, 1], dtype=torch.int32, device="cuda")
+    sfx = torch.zeros(12, dtype=torch.uint8, device="cuda")
+    for bad_p, bad_c in ((pfx, cnt), (torch.tensor([3, 9], dtype=torch.int32, device="cuda"), torch.tensor([2, 0], dtype=torch.int32, device="cuda"))):
+        with pytest.raises(cbl_amd.CblxError):
+            g.insert_sorted_batches_device([(2, 2, bad_p, bad_c, sfx)])
+        assert g.serialize() == before
 
 
 def test_parallel_fastx_reader(tmp_path):
