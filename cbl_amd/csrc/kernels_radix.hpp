@@ -314,17 +314,20 @@ __global__ __launch_bounds__(RDX_THREADS) void k_radix_hist(const u64* __restric
 // tile's byte range (RDX_THREADS * 8 = RDX_TILE bytes, plus one word for an unaligned start).
 static const int HISTB_WAVES = 4;  // tiles per workgroup of k_radix_hist_bytes
 __global__ __launch_bounds__(64 * HISTB_WAVES) void k_radix_hist_bytes(const u8* __restrict__ dig, TileView tv, u32* __restrict__ counts) {
-    // one WAVE per tile (no workgroup barrier): a lane takes every 64th aligned 8-byte word of the tile's byte range
-    __shared__ u32 s_cnt[HISTB_WAVES * 256];
+    // one WAVE per tile (no workgroup barrier): a lane takes every 64th aligned 8-byte word of the tile's byte range.
+    // Two private counter sets per wave (even / odd lanes) halve the same-address serialisation of the LDS atomics
+    // (four sets measured the same).
+    __shared__ u32 s_cnt[HISTB_WAVES * 512];
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    u32* my = s_cnt + w * 256;
+    u32* my = s_cnt + w * 512;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) my[k * 64 + lane] = 0;
+    for (int k = 0; k < 8; ++k) my[k * 64 + lane] = 0;
     u32 tile, n_tile, seg;
     u64 tbase;
     // tile_get maps a WORKGROUP index to a tile (XCD-aware); here the unit is the wave
     if (!tile_get(tv, blockIdx.x * HISTB_WAVES + w, tile, tbase, n_tile, seg)) return;
     __builtin_amdgcn_wave_barrier();
+    u32* mine = my + (lane & 1u) * 256;
     const u64 w0 = tbase >> 3, wend = (tbase + n_tile + 7) >> 3;  // aligned words covering [tbase, tbase + n_tile)
     const u64* __restrict__ words = reinterpret_cast<const u64*>(dig);
     for (u64 wi = w0 + lane; wi < wend; wi += 64) {
@@ -333,13 +336,13 @@ __global__ __launch_bounds__(64 * HISTB_WAVES) void k_radix_hist_bytes(const u8*
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const u64 pos = b0 + k;
-            if (pos >= tbase && pos < tbase + n_tile) atomicAdd(&my[(u32)(v >> (8 * k)) & 255u], 1u);
+            if (pos >= tbase && pos < tbase + n_tile) atomicAdd(&mine[(u32)(v >> (8 * k)) & 255u], 1u);
         }
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) counts[(u64)tile * 256 + k * 64 + lane] = my[k * 64 + lane];
+    for (int k = 0; k < 4; ++k) counts[(u64)tile * 256 + k * 64 + lane] = my[k * 64 + lane] + my[256 + k * 64 + lane];
 }
 
 // scatter. colpre[tile * 256 + d] = records with digit d in earlier tiles (pure column prefix); adj[seg * 256 + d] turns it
