@@ -72,7 +72,7 @@ SIGNATURES = {
     "cblx_serialized_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_serialize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cblx_save_to_file": (C.c_int, [C.c_void_p, C.c_char_p]),
-    "cblx_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64]),
+    "cblx_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "cblx_load_from_file": (C.c_int, [C.c_void_p, C.c_char_p]),
     "cblx_merge_assign": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cblx_export_buckets": (C.c_int, [C.c_void_p, BUCKET_CB, C.c_void_p]),
@@ -290,8 +290,12 @@ class CBL:
     def save_to_file(self, path):
         self._chk(self._L.cblx_save_to_file(self._h, os.fsencode(path)))
 
-    def load(self, data: bytes):
-        self._chk(self._L.cblx_load(self._h, data, len(data)))
+    def load(self, data):
+        """Replace the index by a serialized one (bytes, or a numpy uint8 array: no copy is made)."""
+        if hasattr(data, "ctypes"):
+            self._chk(self._L.cblx_load(self._h, data.ctypes.data, data.size))
+        else:
+            self._chk(self._L.cblx_load(self._h, data, len(data)))
 
     @classmethod
     def load_from_file(cls, path, k: int, prefix_bits: int = 24, **kw) -> "CBL":
