@@ -1,0 +1,100 @@
+"""Randomised differential test: HIP path (through the C ABI) vs the CPU oracle on random configurations and operation
+sequences (insert_seq / insert_seqs / incremental flushes / |= / serialize-load round trips / sorted batches). Not part of
+the default suites (minutes of run time); run on a GPU box:  python tests/fuzz_parity.py [--cases 150] [--seed 1]"""
+import argparse
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import cbl_amd
+from oracle import Oracle
+
+
+def rand_seq(rng, n, alphabet):
+    return bytes(rng.choice(alphabet) for _ in range(n))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    rng = random.Random(a.seed)
+    for case in range(a.cases):
+        k = rng.choice([5, 7, 9, 11, 13, 15, 21, 25, 27, 29, 31, 33, 35, 45, 59])
+        wb = 2 * k + (2 * k - 1).bit_length()
+        pb = rng.randint(1, min(28, wb - 1, 2 * k))
+        if wb - pb > 128:
+            continue
+        canonical = rng.random() < 0.3
+        alphabet = b"ACGT" if rng.random() < 0.7 else b"ACGTacgtN"
+        if rng.random() < 0.2:
+            alphabet = b"AAAC"  # low complexity: heavy duplication, long runs
+        try:
+            g, o = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
+        except Exception as e:  # parameter combinations both sides refuse
+            continue
+        desc = f"case {case}: k={k} pb={pb} canonical={canonical} alphabet={alphabet!r}"
+        ops = []
+        print("START", desc, file=sys.stderr, flush=True)
+        for step in range(rng.randint(1, 5)):
+            op = rng.choice(["seq", "seqs", "seqs", "merge", "roundtrip", "sorted"])
+            ops.append(op)
+            if op == "seq":
+                for _ in range(rng.randint(1, 5)):
+                    s = rand_seq(rng, rng.randint(k, k + rng.choice([0, 1, 5, 300, 5000])), alphabet)
+                    g.insert_seq(s), o.insert_seq(s)
+            elif op == "seqs":
+                seqs = [rand_seq(rng, rng.randint(k, k + rng.choice([0, 3, 100, 2500])), alphabet) for _ in range(rng.randint(1, 60))]
+                bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+                offsets = np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64)
+                g.insert_seqs(bases, offsets), o.insert_seqs(bases, offsets)
+                if rng.random() < 0.5:
+                    g.flush()
+            elif op == "merge":
+                g2, o2 = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
+                for _ in range(rng.randint(1, 20)):
+                    s = rand_seq(rng, rng.randint(k, k + 2000), alphabet)
+                    g2.insert_seq(s), o2.insert_seq(s)
+                g |= g2
+                o.merge(o2)
+                assert g2.serialize() == o2.serialize(), desc + " (other after |=) " + str(ops)
+            elif op == "roundtrip":
+                blob = g.serialize()
+                assert blob == o.serialize(), desc + " (before round trip) " + str(ops)
+                g = cbl_amd.CBL(k, pb, canonical=canonical)
+                g.load(blob)
+            elif op == "sorted":
+                seqs = [rand_seq(rng, rng.randint(k, k + 800), b"ACGT") for _ in range(rng.randint(1, 40))]
+                hb = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+                ho = np.cumsum([0] + [len(s) for s in seqs]).astype(np.int64)
+                d_b = torch.from_numpy(np.concatenate([hb, np.zeros(32, np.uint8)])).cuda()
+                d_o = torch.from_numpy(ho).cuda()
+                nd = rng.randint(1, 5)
+                bounds = np.sort(np.array([rng.randrange(1 << pb) for _ in range(nd - 1)], dtype=np.uint32))
+                snd = cbl_amd.CBL(k, pb, canonical=canonical)
+                bs, ws = snd.sorted_batch_begin(d_b, d_o, len(seqs), bounds, nd)
+                B = snd.consts()["bytes"]
+                pfx = torch.empty(max(bs[nd], 1), dtype=torch.int32, device="cuda")
+                cnt = torch.empty(max(bs[nd], 1), dtype=torch.int32, device="cuda")
+                sfx = torch.empty(max(ws[nd] * B, 1), dtype=torch.uint8, device="cuda")
+                snd.sorted_batch_export(pfx, cnt, sfx)
+                batches = [(bs[d + 1] - bs[d], ws[d + 1] - ws[d], pfx[bs[d] : bs[d + 1]], cnt[bs[d] : bs[d + 1]], sfx[ws[d] * B : ws[d + 1] * B])
+                           for d in range(nd) if ws[d + 1] > ws[d]]
+                g.insert_sorted_batches_device(batches)
+                for s in seqs:
+                    o.insert_seq(s)
+            assert g.count() == o.count(), desc + f" count after {ops}"
+        assert g.serialize() == o.serialize(), desc + " " + str(ops)
+        assert g.validate(strict=False) == 0, desc
+        if case % 10 == 0:
+            print(desc, ops, "ok", flush=True)
+    print("fuzz ok")
+
+
+if __name__ == "__main__":
+    main()
