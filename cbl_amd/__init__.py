@@ -77,6 +77,11 @@ SIGNATURES = {
     "cblx_merge_assign": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cblx_export_buckets": (C.c_int, [C.c_void_p, BUCKET_CB, C.c_void_p]),
     "cblx_contains_seq": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cblx_contains_all": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_int)]),
+    "cblx_insert_kmers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "cblx_contains_kmers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "cblx_export_kmers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cblx_bucket_sizes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cblx_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_checksum_words_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cblx_validate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
@@ -265,6 +270,102 @@ class CBL:
         n = C.c_uint64(0)
         self._chk(self._L.cblx_contains_seq(self._h, seq, len(seq), out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n)))
         return out[: n.value].astype(bool)
+
+    def contains_all(self, seq: bytes) -> bool:
+        """True if the set contains all the k-mers of a sequence (src/cbl.rs:293-307)."""
+        v = C.c_int(0)
+        self._chk(self._L.cblx_contains_all(self._h, seq, len(seq), C.byref(v)))
+        return bool(v.value)
+
+    # ---- packed k-mers (IntKmer::to_int(): 2K bits, first base most significant) — src/cbl.rs:219-228,358-361 ------------
+    @staticmethod
+    def _split_kmers(kmers):
+        import numpy as np
+
+        ks = [int(x) for x in kmers]
+        lo = np.array([x & 0xFFFFFFFFFFFFFFFF for x in ks], dtype=np.uint64)
+        hi = np.array([x >> 64 for x in ks], dtype=np.uint64)
+        return lo, hi
+
+    def insert_kmers(self, kmers):
+        """n successive `insert` calls; returns their results as a numpy bool array (True = the k-mer was absent)."""
+        import numpy as np
+
+        lo, hi = self._split_kmers(kmers)
+        out = np.zeros(max(len(lo), 1), dtype=np.uint8)
+        self._chk(self._L.cblx_insert_kmers(self._h, _ptr(lo), _ptr(hi), len(lo), _ptr(out)))
+        return out[: len(lo)].astype(bool)
+
+    def contains_kmers(self, kmers):
+        import numpy as np
+
+        lo, hi = self._split_kmers(kmers)
+        out = np.zeros(max(len(lo), 1), dtype=np.uint8)
+        self._chk(self._L.cblx_contains_kmers(self._h, _ptr(lo), _ptr(hi), len(lo), _ptr(out)))
+        return out[: len(lo)].astype(bool)
+
+    def insert(self, kmer: int) -> bool:
+        """Adds a packed k-mer; True if it was absent (src/cbl.rs:226-228)."""
+        return bool(self.insert_kmers([kmer])[0])
+
+    def contains(self, kmer: int) -> bool:
+        """True if the set contains the packed k-mer (src/cbl.rs:219-221)."""
+        return bool(self.contains_kmers([kmer])[0])
+
+    def kmers_np(self):
+        """All k-mers of the set in the reference's iteration order as (lo, hi) uint64 arrays (hi is None for K <= 31)."""
+        import numpy as np
+
+        n = self.count()
+        lo = np.empty(max(n, 1), dtype=np.uint64)
+        hi = np.empty(max(n, 1), dtype=np.uint64) if self.k > 31 else None
+        got = C.c_uint64(0)
+        self._chk(self._L.cblx_export_kmers(self._h, _ptr(lo), _ptr(hi) if hi is not None else None, n, C.byref(got)))
+        return lo[: got.value], (hi[: got.value] if hi is not None else None)
+
+    def iter(self):
+        """Iterator over the packed k-mers of the set (src/cbl.rs:358-361)."""
+        lo, hi = self.kmers_np()
+        if hi is None:
+            return iter(int(x) for x in lo)
+        return iter((int(h) << 64) | int(l) for l, h in zip(lo, hi))
+
+    __iter__ = iter
+
+    # ---- bucket statistics (src/cbl.rs:364-386) ---------------------------------------------------------------------
+    def bucket_table_np(self):
+        """(prefix, length, kind) arrays of the non-empty buckets, ascending prefixes."""
+        import numpy as np
+
+        nb = self.num_buckets()
+        prefix = np.empty(max(nb, 1), dtype=np.uint32)
+        length = np.empty(max(nb, 1), dtype=np.uint32)
+        kind = np.empty(max(nb, 1), dtype=np.uint8)
+        got = C.c_uint64(0)
+        self._chk(self._L.cblx_bucket_sizes(self._h, _ptr(prefix), _ptr(length), _ptr(kind), nb, C.byref(got)))
+        return prefix[: got.value], length[: got.value], kind[: got.value]
+
+    def prefix_load(self) -> float:
+        """Proportion of available prefixes used in the set (src/cbl.rs:364-367)."""
+        return self.num_buckets() / float(1 << self.prefix_bits)
+
+    def buckets_sizes(self):
+        """(prefix, bucket length) pairs, ascending prefixes (src/cbl.rs:370-373)."""
+        p, l, _ = self.bucket_table_np()
+        return list(zip(p.tolist(), l.tolist()))
+
+    def buckets_size_count(self) -> dict:
+        """bucket length -> number of buckets of that length, sorted by length (src/cbl.rs:376-379)."""
+        import numpy as np
+
+        _, l, _ = self.bucket_table_np()
+        v, c = np.unique(l, return_counts=True)
+        return dict(zip(v.tolist(), c.tolist()))
+
+    def buckets_load_repartition(self) -> dict:
+        """bucket length -> share of the k-mers held by buckets of that length (src/cbl.rs:382-385)."""
+        total = float(max(self.count(), 1))
+        return {size: size * n / total for size, n in self.buckets_size_count().items()}
 
     # ---- src/cbl.rs:127-160 ---------------------------------------------------------------------------------
     def serialize(self) -> bytes:

@@ -6,6 +6,7 @@
 // HBM: bitvector words, popcount-scan rank directory, bucket table indexed by rank, one suffix arena.
 // There is no CPU fallback: every data-path step below is a kernel launch.
 #include "host_index.hpp"
+#include "kernels_kmer.hpp"
 
 namespace {
 
@@ -24,6 +25,50 @@ template <typename F> int guard(cblx_ctx* c, F&& f) {
         (c ? c->err : g_global_err) = e.what();
         return CBLX_EINVAL;
     }
+}
+
+// membership flags of n device words against the resident index (WordSet::contains_batch)
+template <typename C> void contains_words(cblx_ctx* c, const u64* w_lo, const typename C::HiT* w_hi, u64 n, u8* d_out) {
+    typedef typename C::HiT HiT;
+    hipLaunchKernelGGL(k_contains<HiT>, grid1(n, 256), dim3(256), 0, c->stream, w_lo, w_hi, n, c->P.SB, c->P.PB, c->res.view(), c->res.a_lo.get(),
+                       c->P.wide_suffix() ? c->res.a_hi.get() : (const u64*)nullptr, d_out);
+    CBLX_HIP(hipGetLastError());
+}
+// words of the k-mers of one host sequence, on the device (KRN-1 over a one-sequence batch)
+template <typename C> u64 seq_words_of_host_seq(cblx_ctx* c, const uint8_t* seq, uint64_t len, Buf<u64>& w_lo, Buf<u8>& w_hi) {
+    typedef typename C::HiT HiT;
+    Buf<u8> d_b(c->pool, len + 64);
+    Buf<u64> d_o(c->pool, 2);
+    u64 offs[2] = {0, len};
+    xfer(c).h2d_copy(d_b.get(), seq, len);  // pinned lanes: the caller's buffer is pageable
+    xfer(c).sync();
+    h2d(c, d_o.get(), offs, 2);
+    ChunkPlan pl;
+    const u8* pb = d_b.get();
+    plan_chunks(c, pb, d_o.get(), 1, pl);
+    w_lo = Buf<u64>(c->pool, pl.n_kmers + 2);
+    w_hi = Buf<u8>(c->pool, (pl.n_kmers + 2) * std::max<size_t>(1, hi_elem_size(c->P)));
+    encode<C>(c, pb, pl, w_lo.get(), (HiT*)w_hi.get(), 0);
+    CBLX_HIP(hipStreamSynchronize(c->stream));  // d_b / d_o go back to the pool on return
+    return pl.n_kmers;
+}
+// words (get_word, src/cbl.rs:199-206) of n packed host k-mers, on the device
+template <typename C> void words_of_host_kmers(cblx_ctx* c, const uint64_t* lo, const uint64_t* hi, u64 n, Buf<u64>& w_lo, Buf<u8>& w_hi) {
+    typedef typename C::HiT HiT;
+    if (!lo || (C::WIDE && !hi)) throw Error(CBLX_EINVAL, C::WIDE ? "null argument (K >= 33 needs the hi halves of the k-mers)" : "null argument");
+    if (n >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "too many k-mers in one call");
+    Buf<u64> k_lo(c->pool, n + 1), k_hi(c->pool, hi ? n + 1 : 1);
+    Buf<u32> bad(c->pool, 1);
+    xfer(c).h2d_copy(k_lo.get(), lo, n * 8);
+    if (hi) xfer(c).h2d_copy(k_hi.get(), hi, n * 8);
+    xfer(c).sync();
+    CBLX_HIP(hipMemsetAsync(bad.get(), 0, 4, c->stream));
+    w_lo = Buf<u64>(c->pool, n + 2);
+    w_hi = Buf<u8>(c->pool, (n + 2) * std::max<size_t>(1, hi_elem_size(c->P)));
+    hipLaunchKernelGGL((k_kmers_to_words<C::WIDE, HiT>), grid1(n, 256), dim3(256), 0, c->stream, k_lo.get(), hi ? k_hi.get() : (const u64*)nullptr, n, c->P,
+                       w_lo.get(), (HiT*)w_hi.get(), bad.get());
+    CBLX_HIP(hipGetLastError());
+    if (d2h<u32>(c, bad.get())) throw Error(CBLX_EINVAL, "k-mer has bits set above 2K (not an IntKmer<K>)");
 }
 
 }  // namespace
@@ -471,28 +516,124 @@ int cblx_contains_seq(cblx_ctx* c, const uint8_t* seq, uint64_t len, uint8_t* ou
         dispatch(c->P, [&](auto cfg) {
             typedef decltype(cfg) C;
             typedef typename C::HiT HiT;
-            Buf<u8> d_b(c->pool, len + 64);
-            Buf<u64> d_o(c->pool, 2);
-            u64 offs[2] = {0, len};
-            xfer(c).h2d_copy(d_b.get(), seq, len);  // pinned lanes: the caller's buffer is pageable
-            xfer(c).sync();
-            h2d(c, d_o.get(), offs, 2);
-            ChunkPlan pl;
-            const u8* pb = d_b.get();
-            plan_chunks(c, pb, d_o.get(), 1, pl);
-            if (n) *n = pl.n_kmers;
-            if (pl.n_kmers > cap) throw Error(CBLX_ERANGE, "output capacity too small");
-            Buf<u64> w_lo(c->pool, pl.n_kmers + 2);
-            Buf<u8> w_hi(c->pool, (pl.n_kmers + 2) * std::max<size_t>(1, hi_elem_size(c->P)));
-            Buf<u8> d_out(c->pool, pl.n_kmers + 8);
-            encode<C>(c, pb, pl, w_lo.get(), (HiT*)w_hi.get(), 0);
-            hipLaunchKernelGGL(k_contains<HiT>, grid1(pl.n_kmers, 256), dim3(256), 0, c->stream, w_lo.get(), (const HiT*)w_hi.get(), pl.n_kmers, c->P.SB,
-                               c->P.PB, c->res.view(), c->res.a_lo.get(), c->P.wide_suffix() ? c->res.a_hi.get() : (const u64*)nullptr, d_out.get());
-            CBLX_HIP(hipGetLastError());
+            Buf<u64> w_lo;
+            Buf<u8> w_hi;
+            const u64 nk = seq_words_of_host_seq<C>(c, seq, len, w_lo, w_hi);
+            if (n) *n = nk;
+            if (nk > cap) throw Error(CBLX_ERANGE, "output capacity too small");
+            Buf<u8> d_out(c->pool, nk + 8);
+            contains_words<C>(c, w_lo.get(), (const HiT*)w_hi.get(), nk, d_out.get());
             CBLX_HIP(hipStreamSynchronize(c->stream));
-            xfer(c).d2h_copy(out, d_out.get(), pl.n_kmers);
+            xfer(c).d2h_copy(out, d_out.get(), nk);
         });
         collect_events(c);
+    });
+}
+int cblx_contains_all(cblx_ctx* c, const uint8_t* seq, uint64_t len, int* out) {
+    return guard(c, [&] {
+        if (!out) throw Error(CBLX_EINVAL, "null argument");
+        flush(c);
+        if (len < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(len) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
+        dispatch(c->P, [&](auto cfg) {
+            typedef decltype(cfg) C;
+            typedef typename C::HiT HiT;
+            Buf<u64> w_lo;
+            Buf<u8> w_hi;
+            const u64 nk = seq_words_of_host_seq<C>(c, seq, len, w_lo, w_hi);
+            Buf<u8> d_out(c->pool, nk + 8);
+            Buf<u32> zeros(c->pool, 1);
+            CBLX_HIP(hipMemsetAsync(zeros.get(), 0, 4, c->stream));
+            contains_words<C>(c, w_lo.get(), (const HiT*)w_hi.get(), nk, d_out.get());
+            hipLaunchKernelGGL(k_count_zero_u8, dim3((unsigned)std::min<u64>(1024, std::max<u64>(1, ceil_div(nk, 256)))), dim3(256), 0, c->stream, d_out.get(), nk, zeros.get());
+            CBLX_HIP(hipGetLastError());
+            *out = d2h<u32>(c, zeros.get()) == 0;
+        });
+        collect_events(c);
+    });
+}
+int cblx_contains_kmers(cblx_ctx* c, const uint64_t* lo, const uint64_t* hi, uint64_t n, uint8_t* out) {
+    return guard(c, [&] {
+        flush(c);
+        if (n == 0) return;
+        if (!out) throw Error(CBLX_EINVAL, "null argument");
+        dispatch(c->P, [&](auto cfg) {
+            typedef decltype(cfg) C;
+            typedef typename C::HiT HiT;
+            Buf<u64> w_lo;
+            Buf<u8> w_hi;
+            words_of_host_kmers<C>(c, lo, hi, n, w_lo, w_hi);
+            Buf<u8> d_out(c->pool, n + 8);
+            contains_words<C>(c, w_lo.get(), (const HiT*)w_hi.get(), n, d_out.get());
+            CBLX_HIP(hipStreamSynchronize(c->stream));
+            xfer(c).d2h_copy(out, d_out.get(), n);
+        });
+    });
+}
+int cblx_insert_kmers(cblx_ctx* c, const uint64_t* lo, const uint64_t* hi, uint64_t n, uint8_t* was_absent) {
+    return guard(c, [&] {
+        flush(c);  // keep stream order with anything enqueued earlier
+        if (n == 0) return;
+        dispatch(c->P, [&](auto cfg) {
+            typedef decltype(cfg) C;
+            typedef typename C::HiT HiT;
+            Buf<u64> w_lo;
+            Buf<u8> w_hi;
+            words_of_host_kmers<C>(c, lo, hi, n, w_lo, w_hi);
+            if (was_absent) {  // the return values of n successive CBL::insert calls, before the index changes
+                Buf<u8> flag(c->pool, n + 8);
+                contains_words<C>(c, w_lo.get(), (const HiT*)w_hi.get(), n, flag.get());
+                u64 slots = 64;
+                while (slots < 2 * n) slots <<= 1;
+                Buf<u32> table(c->pool, slots);
+                CBLX_HIP(hipMemsetAsync(table.get(), 0, slots * 4, c->stream));
+                hipLaunchKernelGGL(k_first_claim<HiT>, grid1(n, 256), dim3(256), 0, c->stream, w_lo.get(), (const HiT*)w_hi.get(), n, table.get(), (u32)(slots - 1));
+                hipLaunchKernelGGL(k_first_flag<HiT>, grid1(n, 256), dim3(256), 0, c->stream, w_lo.get(), (const HiT*)w_hi.get(), n, table.get(), (u32)(slots - 1),
+                                   flag.get());
+                CBLX_HIP(hipGetLastError());
+                CBLX_HIP(hipStreamSynchronize(c->stream));
+                xfer(c).d2h_copy(was_absent, flag.get(), n);
+            }
+            Records rec;
+            begin_records<C>(c, rec, n);
+            rec.ext_lo = w_lo.get();  // the first partition pass reads the words in place
+            rec.ext_hi = w_hi.get();
+            pipeline<C>(c, rec, n);
+            c->kmers_inserted += n;
+            CBLX_HIP(hipStreamSynchronize(c->stream));  // w_lo / w_hi go back to the pool on return
+        });
+        collect_events(c);
+    });
+}
+int cblx_export_kmers(cblx_ctx* c, uint64_t* lo, uint64_t* hi, uint64_t cap, uint64_t* n) {
+    return guard(c, [&] {
+        flush(c);
+        const Resident& r = c->res;
+        if (n) *n = r.count;
+        if (r.count == 0) return;
+        if (r.count > cap) throw Error(CBLX_ERANGE, "output capacity too small: the index holds " + std::to_string(r.count) + " k-mers");
+        if (!lo || (c->P.wide_kmer() && !hi)) throw Error(CBLX_EINVAL, c->P.wide_kmer() ? "null argument (K >= 33 needs a hi array)" : "null argument");
+        Buf<u64> res_off(c->pool, r.nb + 1), d_lo(c->pool, r.count), d_hi(c->pool, hi ? r.count : 1);
+        const u64 tot = exclusive_scan<u64>(c, r.cnt.get(), r.nb, res_off.get());
+        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, res_off.get() + r.nb, tot);
+        hipLaunchKernelGGL(k_export_kmers, grid1(tot, 256), dim3(256), 0, c->stream, tot, r.nb, res_off.get(), r.prefix.get(), r.start.get(), r.a_lo.get(),
+                           c->P.wide_suffix() ? r.a_hi.get() : (const u64*)nullptr, c->P, d_lo.get(), hi ? d_hi.get() : (u64*)nullptr);
+        CBLX_HIP(hipGetLastError());
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+        xfer(c).d2h_copy(lo, d_lo.get(), tot * 8);
+        if (hi) xfer(c).d2h_copy(hi, d_hi.get(), tot * 8);
+    });
+}
+int cblx_bucket_sizes(cblx_ctx* c, uint32_t* prefix, uint32_t* len, uint8_t* kind, uint64_t cap, uint64_t* n) {
+    return guard(c, [&] {
+        flush(c);
+        const Resident& r = c->res;
+        if (n) *n = r.nb;
+        if (r.nb == 0) return;
+        if (r.nb > cap) throw Error(CBLX_ERANGE, "output capacity too small: the index holds " + std::to_string(r.nb) + " buckets");
+        if (prefix) CBLX_HIP(hipMemcpyAsync(prefix, r.prefix.get(), r.nb * 4, hipMemcpyDeviceToHost, c->stream));
+        if (len) CBLX_HIP(hipMemcpyAsync(len, r.cnt.get(), r.nb * 4, hipMemcpyDeviceToHost, c->stream));
+        if (kind) CBLX_HIP(hipMemcpyAsync(kind, r.kind.get(), r.nb, hipMemcpyDeviceToHost, c->stream));
+        CBLX_HIP(hipStreamSynchronize(c->stream));
     });
 }
 int cblx_checksum(cblx_ctx* c, uint64_t* sum) {

@@ -153,6 +153,26 @@ int cblx_export_buckets(cblx_ctx* ctx, cblx_bucket_cb cb, void* user);
 
 /* CBL::contains_seq (src/cbl.rs:311-324): one byte (0/1) per k-mer of one sequence, into `out[cap]`. */
 int cblx_contains_seq(cblx_ctx* ctx, const uint8_t* seq, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* n);
+/* CBL::contains_all (src/cbl.rs:293-307): *out = 1 iff every k-mer of the sequence is in the set. */
+int cblx_contains_all(cblx_ctx* ctx, const uint8_t* seq, uint64_t len, int* out);
+
+/* Packed k-mers: k-mer i is IntKmer::to_int() (2K bits, first base most significant, src/kmer.rs:200-202) given as
+ * lo[i] (low 64 bits) and hi[i] (the rest; `hi` may be NULL when K <= 31, must not be when K >= 33).
+ *   cblx_insert_kmers   = n successive CBL::insert calls (src/cbl.rs:226-228 -> get_word :199-206 -> WordSet::insert
+ *                         src/wordset/mod.rs:97-120); was_absent[i] (may be NULL) is the i-th call's return value:
+ *                         1 iff the k-mer was neither in the set nor earlier in this batch.
+ *   cblx_contains_kmers = CBL::contains (src/cbl.rs:219-221) for each k-mer, one byte (0/1) each.
+ * In a canonical index the k-mer is replaced by its canonical form first, as in the reference. A k-mer with bits set
+ * above 2K is refused (CBLX_EINVAL) and nothing is inserted. */
+int cblx_insert_kmers(cblx_ctx* ctx, const uint64_t* lo, const uint64_t* hi, uint64_t n, uint8_t* was_absent);
+int cblx_contains_kmers(cblx_ctx* ctx, const uint64_t* lo, const uint64_t* hi, uint64_t n, uint8_t* out);
+/* CBL::iter (src/cbl.rs:358-361): every k-mer of the set, packed as above, in the reference's iteration order
+ * (prefixes ascending; a Vec bucket in stored order, a Trie bucket ascending), recovered from its word by
+ * revert_necklace_pos (src/necklace/mod.rs:29-31). *n = count(); `hi` may be NULL when K <= 31. */
+int cblx_export_kmers(cblx_ctx* ctx, uint64_t* lo, uint64_t* hi, uint64_t cap, uint64_t* n);
+/* Bucket table only (CBL::buckets_sizes src/cbl.rs:370-373 and the statistics built on it): per non-empty prefix in
+ * ascending order its value, the bucket's length and kind (0 = Vec, 1 = Trie). Any of the arrays may be NULL. */
+int cblx_bucket_sizes(cblx_ctx* ctx, uint32_t* prefix, uint32_t* len, uint8_t* kind, uint64_t cap, uint64_t* n);
 
 /* Full-size parity properties (no reference counterpart): an order-independent checksum of the set (sum over the
  * resident words of a 64-bit hash, mod 2^64), the same sum over a device array of words, and a structural check of the

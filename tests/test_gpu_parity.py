@@ -762,3 +762,81 @@ print("ok")
     env = dict(os.environ, CBLX_FASTX_PARALLEL_MIN="1000", CBLX_FASTX_REGION_BYTES="90000", CBLX_INGEST_FLUSH_BYTES="500000")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+# ---- packed k-mers: CBL::insert / contains / iter and the bucket statistics (/root/reference/src/cbl.rs:219-228,358-386;
+# the reference's own shape: src/cbl.rs:591-662 insert/contains of random k-mers, :700-724 iter) ------------------------
+@pytest.mark.parametrize("k,pb,canonical", [(31, 24, False), (31, 24, True), (25, 12, False), (11, 8, True), (59, 28, False), (45, 20, True), (33, 16, False)])
+def test_single_kmer_insert_contains_iter(k, pb, canonical):
+    _need_gpu()
+    rng = random.Random(1000 * k + pb + canonical)
+    g, o = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
+    pool = [rng.getrandbits(2 * k) for _ in range(700)]
+    pool += [0, (1 << (2 * k)) - 1, 1, 1 << (2 * k - 1), int("01" * k, 2), int("10" * k, 2)]
+    # a first batch with repeats inside the batch, then a sequence, then a batch that meets resident k-mers
+    seq = _rand_seq(rng, 4 * k + 300, b"ACGTN")
+    b1 = [rng.choice(pool) for _ in range(1500)]
+    b2 = [rng.choice(pool) for _ in range(900)] + [rng.getrandbits(2 * k) for _ in range(300)]
+    got1 = g.insert_kmers(b1)
+    exp1 = [o.insert_kmer(x) for x in b1]
+    assert got1.tolist() == exp1
+    assert g.count() == o.count()
+    g.insert_seq(seq), o.insert_seq(seq)
+    got2 = g.insert_kmers(b2)
+    exp2 = [o.insert_kmer(x) for x in b2]
+    assert got2.tolist() == exp2
+    assert g.count() == o.count()
+    assert g.serialize() == o.serialize()
+    probe = pool + [rng.getrandbits(2 * k) for _ in range(500)] + b2[-50:]
+    assert g.contains_kmers(probe).tolist() == [o.contains_kmer(x) for x in probe]
+    assert g.insert(b2[-1]) is False and g.contains(b2[-1]) is True
+    # iter: the oracle's words in iteration order, each turned back into its k-mer
+    exp_kmers = [o.kmer_of_word(w) for w in o.iter_words()]
+    assert list(g.iter()) == exp_kmers
+    assert len(exp_kmers) == g.count()
+    # every k-mer the iterator yields is a member, and (non-canonical) so was every inserted one
+    assert all(g.contains_kmers(exp_kmers[:2000]))
+    # contains_all
+    assert g.contains_all(seq) is True
+    other = _rand_seq(random.Random(5), 5 * k, b"ACGT")
+    assert g.contains_all(other) == all(g.contains_seq(other))
+    # statistics
+    sizes = g.buckets_sizes()
+    exp_sizes = {}
+    sb = g.consts()["suffix_bits"]
+    for w in o.iter_words():
+        exp_sizes[w >> sb] = exp_sizes.get(w >> sb, 0) + 1
+    assert sizes == sorted(exp_sizes.items())
+    assert g.prefix_load() == len(exp_sizes) / float(1 << pb)
+    sc = g.buckets_size_count()
+    assert sum(s * c for s, c in sc.items()) == g.count() and list(sc) == sorted(sc)
+    assert abs(sum(g.buckets_load_repartition().values()) - 1.0) < 1e-9
+
+
+def test_insert_kmers_rejects_out_of_range_and_keeps_index():
+    _need_gpu()
+    g = cbl_amd.CBL(15, 10)
+    g.insert_kmers([1, 2, 3])
+    with pytest.raises(cbl_amd.CblxError):
+        g.insert_kmers([5, 1 << 30])  # 2K = 30 bits
+    with pytest.raises(cbl_amd.CblxError):
+        g.contains_kmers([1 << 64])
+    assert g.count() == 3
+    assert g.insert_kmers([]).tolist() == []
+    e = cbl_amd.CBL(15, 10)
+    assert list(e.iter()) == [] and e.buckets_sizes() == [] and e.prefix_load() == 0.0
+
+
+def test_single_insert_crosses_vec_trie_threshold():
+    """One prefix fed by single inserts past 1024 distinct suffixes: first-occurrence order until the conversion, then a
+    Trie (/root/reference/src/wordset/mod.rs:97-120,240-244)."""
+    _need_gpu()
+    k, pb = 15, 4
+    rng = random.Random(77)
+    g, o = cbl_amd.CBL(k, pb), Oracle(k, pb)
+    for n in (600, 500, 2500):
+        batch = [rng.getrandbits(2 * k) for _ in range(n)]
+        batch += batch[: n // 10]
+        assert g.insert_kmers(batch).tolist() == [o.insert_kmer(x) for x in batch]
+        assert g.serialize() == o.serialize()
+    assert g.validate() == 0
