@@ -77,6 +77,11 @@ SIGNATURES = {
     "cblx_merge_assign": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cblx_export_buckets": (C.c_int, [C.c_void_p, BUCKET_CB, C.c_void_p]),
     "cblx_contains_seq": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "cblx_contains_seqs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                     C.POINTER(C.c_uint64)]),
+    "cblx_contains_seqs_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64)]),
+    "cblx_query_fastx_file": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cblx_contains_all": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_int)]),
     "cblx_insert_kmers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "cblx_contains_kmers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
@@ -270,6 +275,32 @@ class CBL:
         n = C.c_uint64(0)
         self._chk(self._L.cblx_contains_seq(self._h, seq, len(seq), out.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n)))
         return out[: n.value].astype(bool)
+
+    def contains_seqs(self, bases, offsets, flags: bool = True):
+        """contains_seq for a batch (bases: uint8 array, offsets: uint64 array of n+1 entries). Returns
+        (flags as a numpy bool array or None, k-mers queried, positives)."""
+        import numpy as np
+
+        n = len(offsets) - 1
+        cap = max(int(offsets[-1] - offsets[0]), 1) if n > 0 else 1
+        out = np.empty(cap, dtype=np.uint8) if flags else None
+        tot, pos = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.cblx_contains_seqs(self._h, _ptr(bases), _ptr(offsets), max(n, 0), _ptr(out) if flags else None, cap, C.byref(tot), C.byref(pos)))
+        return (out[: tot.value].astype(bool) if flags else None), tot.value, pos.value
+
+    def contains_seqs_device(self, d_bases, d_offsets, n: int, d_out=None, cap: int = 0):
+        """Device-resident batch; returns (k-mers queried, positives). d_out (uint8 tensor) receives the flags when given."""
+        tot, pos = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.cblx_contains_seqs_device(self._h, _ptr(d_bases), _ptr(d_offsets), n, _ptr(d_out), cap, C.byref(tot), C.byref(pos)))
+        return tot.value, pos.value
+
+    def query_fastx_file(self, path):
+        """`cbl query`: (records, k-mers queried, positives) for a FASTA/FASTQ(.gz) file; the index is not modified."""
+        import os
+
+        nrec, tot, pos = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.cblx_query_fastx_file(self._h, os.fsencode(path), C.byref(nrec), C.byref(tot), C.byref(pos)))
+        return nrec.value, tot.value, pos.value
 
     def contains_all(self, seq: bytes) -> bool:
         """True if the set contains all the k-mers of a sequence (src/cbl.rs:293-307)."""

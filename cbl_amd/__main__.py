@@ -1,5 +1,5 @@
-"""`python -m cbl_amd <command>` — the build / insert / merge / count subcommands of the reference CLI
-(/root/reference/examples/cbl.rs:147-167,230-249,270-279,168-173) on the MI355X path.
+"""`python -m cbl_amd <command>` — the build / insert / merge / count / query / list subcommands of the reference CLI
+(/root/reference/examples/cbl.rs:147-167,230-249,270-279,168-229) on the MI355X path.
 
 K and PREFIX_BITS are compile-time constants of the reference (env K / PREFIX_BITS at cargo build time, build.rs:9-56);
 here they are flags with the same defaults (K=25, PREFIX_BITS=24). Index files are interchangeable with the reference's.
@@ -30,6 +30,12 @@ def main(argv=None):
     m.add_argument("-o", "--output")
     c = sub.add_parser("count", help="Count the k-mers contained in an index")
     c.add_argument("index")
+    q = sub.add_parser("query", help="Query an index for every k-mer contained in a FASTA/Q file")
+    q.add_argument("index")
+    q.add_argument("input")
+    ls = sub.add_parser("list", help="List the k-mers contained in an index")
+    ls.add_argument("index")
+    ls.add_argument("-o", "--output")
     a = ap.parse_args(argv)
 
     if a.cmd == "build":
@@ -58,6 +64,33 @@ def main(argv=None):
         cbl = CBL.load_from_file(a.index, a.k, a.prefix_bits, device=a.device)
         print(f"It contains {cbl.count()} {a.k}-mers", file=sys.stderr)
         print(cbl.count())
+    elif a.cmd == "query":  # examples/cbl.rs:205-228
+        cbl = CBL.load_from_file(a.index, a.k, a.prefix_bits, device=a.device)
+        print(f"Querying the {'canonical ' if cbl.is_canonical() else ''}{a.k}-mers contained in {a.input}", file=sys.stderr)
+        _, total, positive = cbl.query_fastx_file(a.input)
+        print(f"# queries: {total}", file=sys.stderr)
+        print(f"# positive queries: {positive} ({positive * 100 / total if total else float('nan'):.2f}%)", file=sys.stderr)
+        print(total, positive)
+    elif a.cmd == "list":  # examples/cbl.rs:177-203: one k-mer per line, IntKmer::to_nucs (first base most significant)
+        import numpy as np
+
+        cbl = CBL.load_from_file(a.index, a.k, a.prefix_bits, device=a.device)
+        print(f"Listing {'canonical ' if cbl.is_canonical() else ''}{a.k}-mers contained in {a.index}", file=sys.stderr)
+        lo, hi = cbl.kmers_np()
+        nuc = np.frombuffer(b"ACTG", dtype=np.uint8)  # src/kmer.rs:26-27
+        out = open(a.output, "wb") if a.output else sys.stdout.buffer
+        for c0 in range(0, len(lo), 1 << 20):
+            l = lo[c0 : c0 + (1 << 20)]
+            h = hi[c0 : c0 + (1 << 20)] if hi is not None else None
+            lines = np.empty((len(l), a.k + 1), dtype=np.uint8)
+            lines[:, a.k] = ord("\n")
+            for j in range(a.k):  # base j sits 2 * (k - 1 - j) bits up
+                sh = 2 * (a.k - 1 - j)
+                code = (l >> np.uint64(sh)) if sh < 64 else (h >> np.uint64(sh - 64))
+                lines[:, j] = nuc[(code & np.uint64(3)).astype(np.intp)]
+            out.write(lines.tobytes())
+        if a.output:
+            out.close()
 
 
 if __name__ == "__main__":

@@ -6,7 +6,6 @@
 // HBM: bitvector words, popcount-scan rank directory, bucket table indexed by rank, one suffix arena.
 // There is no CPU fallback: every data-path step below is a kernel launch.
 #include "host_index.hpp"
-#include "kernels_kmer.hpp"
 
 namespace {
 
@@ -27,13 +26,6 @@ template <typename F> int guard(cblx_ctx* c, F&& f) {
     }
 }
 
-// membership flags of n device words against the resident index (WordSet::contains_batch)
-template <typename C> void contains_words(cblx_ctx* c, const u64* w_lo, const typename C::HiT* w_hi, u64 n, u8* d_out) {
-    typedef typename C::HiT HiT;
-    hipLaunchKernelGGL(k_contains<HiT>, grid1(n, 256), dim3(256), 0, c->stream, w_lo, w_hi, n, c->P.SB, c->P.PB, c->res.view(), c->res.a_lo.get(),
-                       c->P.wide_suffix() ? c->res.a_hi.get() : (const u64*)nullptr, d_out);
-    CBLX_HIP(hipGetLastError());
-}
 // words of the k-mers of one host sequence, on the device (KRN-1 over a one-sequence batch)
 template <typename C> u64 seq_words_of_host_seq(cblx_ctx* c, const uint8_t* seq, uint64_t len, Buf<u64>& w_lo, Buf<u8>& w_hi) {
     typedef typename C::HiT HiT;
@@ -69,6 +61,55 @@ template <typename C> void words_of_host_kmers(cblx_ctx* c, const uint64_t* lo, 
                        w_lo.get(), (HiT*)w_hi.get(), bad.get());
     CBLX_HIP(hipGetLastError());
     if (d2h<u32>(c, bad.get())) throw Error(CBLX_EINVAL, "k-mer has bits set above 2K (not an IntKmer<K>)");
+}
+
+void read_fastx_into_queue(cblx_ctx* c, const char* path, uint64_t* n_records) {
+    {
+        if (n_records) *n_records = 0;
+        if (!path) throw Error(CBLX_EINVAL, "null argument");
+        {   // large plain files: parallel reader; anything it does not take is read sequentially below
+            u64 npar = 0;
+            if (fastx_parallel(c, path, &npar)) { if (n_records) *n_records = npar; return; }
+        }
+        ByteSource src;
+        src.open(path);
+        LineReader lr(src);
+        u64 nrec = 0;
+        const u8* p;
+        size_t n;
+        // skip leading blank lines, then the first byte decides the format
+        bool have_line = false;
+        while ((have_line = lr.next(p, n)) && n == 0) {}
+        if (!have_line) return;
+        if (p[0] != '>' && p[0] != '@') throw Error(CBLX_EFORMAT, "not a FASTA/FASTQ file (first record does not start with '>' or '@')");
+        const u64 flush_at = std::min<u64>(1ull << 30, ingest_flush_bytes());
+        try {
+        if (p[0] == '>') {
+            bool open_rec = true;  // the header line has been consumed
+            while (lr.next(p, n)) {
+                if (n && p[0] == '>') { ingest_end_seq(c, flush_at); ++nrec; continue; }
+                if (n) ingest_bases(c, p, n);
+            }
+            if (open_rec) { ingest_end_seq(c, flush_at); ++nrec; }
+        } else {
+            for (;;) {
+                if (n == 0) { if (!lr.next(p, n)) break; continue; }  // blank line between records
+                if (p[0] != '@') throw Error(CBLX_EFORMAT, "FASTQ: expected '@' header");
+                const u8 *sq, *pl, *ql;
+                size_t ns, npl, nq;
+                if (!lr.next(sq, ns)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
+                if (ns) ingest_bases(c, sq, ns);  // the buffer may move on the next call: consume the line first
+                if (!lr.next(pl, npl)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
+                if (npl == 0 || pl[0] != '+') throw Error(CBLX_EFORMAT, "FASTQ: expected '+' separator");
+                if (!lr.next(ql, nq)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
+                ingest_end_seq(c, flush_at);
+                ++nrec;
+                if (!lr.next(p, n)) break;
+            }
+        }
+        } catch (...) { ingest_abort_seq(c); if (n_records) *n_records = nrec; throw; }
+        if (n_records) *n_records = nrec;
+    }
 }
 
 }  // namespace
@@ -153,51 +194,27 @@ int cblx_insert_seqs_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t*
 int cblx_flush(cblx_ctx* c) { return guard(c, [&] { flush(c); }); }
 
 int cblx_insert_fastx_file(cblx_ctx* c, const char* path, uint64_t* n_records) {
+    return guard(c, [&] { read_fastx_into_queue(c, path, n_records); });
+}
+int cblx_query_fastx_file(cblx_ctx* c, const char* path, uint64_t* n_records, uint64_t* total, uint64_t* positive) {
     return guard(c, [&] {
-        if (n_records) *n_records = 0;
-        if (!path) throw Error(CBLX_EINVAL, "null argument");
-        {   // large plain files: parallel reader; anything it does not take is read sequentially below
-            u64 npar = 0;
-            if (fastx_parallel(c, path, &npar)) { if (n_records) *n_records = npar; return; }
-        }
-        ByteSource src;
-        src.open(path);
-        LineReader lr(src);
-        u64 nrec = 0;
-        const u8* p;
-        size_t n;
-        // skip leading blank lines, then the first byte decides the format
-        bool have_line = false;
-        while ((have_line = lr.next(p, n)) && n == 0) {}
-        if (!have_line) return;
-        if (p[0] != '>' && p[0] != '@') throw Error(CBLX_EFORMAT, "not a FASTA/FASTQ file (first record does not start with '>' or '@')");
-        const u64 flush_at = std::min<u64>(1ull << 30, ingest_flush_bytes());
+        if (total) *total = 0;
+        if (positive) *positive = 0;
+        flush(c);  // pending inserts first: the queue changes consumer
+        Ingest& g = c->ing;
+        g.query = true;
+        g.q_total = g.q_positive = 0;
         try {
-        if (p[0] == '>') {
-            bool open_rec = true;  // the header line has been consumed
-            while (lr.next(p, n)) {
-                if (n && p[0] == '>') { ingest_end_seq(c, flush_at); ++nrec; continue; }
-                if (n) ingest_bases(c, p, n);
-            }
-            if (open_rec) { ingest_end_seq(c, flush_at); ++nrec; }
-        } else {
-            for (;;) {
-                if (n == 0) { if (!lr.next(p, n)) break; continue; }  // blank line between records
-                if (p[0] != '@') throw Error(CBLX_EFORMAT, "FASTQ: expected '@' header");
-                const u8 *sq, *pl, *ql;
-                size_t ns, npl, nq;
-                if (!lr.next(sq, ns)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
-                if (ns) ingest_bases(c, sq, ns);  // the buffer may move on the next call: consume the line first
-                if (!lr.next(pl, npl)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
-                if (npl == 0 || pl[0] != '+') throw Error(CBLX_EFORMAT, "FASTQ: expected '+' separator");
-                if (!lr.next(ql, nq)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
-                ingest_end_seq(c, flush_at);
-                ++nrec;
-                if (!lr.next(p, n)) break;
-            }
+            read_fastx_into_queue(c, path, n_records);
+            flush(c);
+        } catch (...) {
+            ingest_drop(c);
+            g.query = false;
+            throw;
         }
-        } catch (...) { ingest_abort_seq(c); if (n_records) *n_records = nrec; throw; }
-        if (n_records) *n_records = nrec;
+        g.query = false;
+        if (total) *total = g.q_total;
+        if (positive) *positive = g.q_positive;
     });
 }
 
@@ -527,6 +544,48 @@ int cblx_contains_seq(cblx_ctx* c, const uint8_t* seq, uint64_t len, uint8_t* ou
             xfer(c).d2h_copy(out, d_out.get(), nk);
         });
         collect_events(c);
+    });
+}
+int cblx_contains_seqs(cblx_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* n_out,
+                       uint64_t* positive) {
+    return guard(c, [&] {
+        if (n_out) *n_out = 0;
+        if (positive) *positive = 0;
+        flush(c);
+        if (n == 0) return;
+        if (!bases || !offsets) throw Error(CBLX_EINVAL, "null argument");
+        u64 minlen = ~0ull;
+        bool mono = true;
+        for (u64 i = 0; i < n; ++i) { mono &= offsets[i + 1] >= offsets[i]; minlen = std::min(minlen, offsets[i + 1] - offsets[i]); }
+        if (!mono) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
+        if (minlen < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(minlen) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
+        const u64 b0 = offsets[0], nb = offsets[n] - b0;
+        Buf<u8> d_b(c->pool, nb + 64), d_out(c->pool, out ? nb + 8 : 8);
+        Buf<u64> d_o(c->pool, n + 1);
+        std::vector<u64> rel(n + 1);
+        for (u64 i = 0; i <= n; ++i) rel[i] = offsets[i] - b0;
+        xfer(c).h2d_copy(d_b.get(), bases + b0, nb);  // pinned lanes: the caller's buffers are pageable
+        xfer(c).h2d_copy(d_o.get(), rel.data(), (n + 1) * 8);
+        xfer(c).sync();
+        u64 tot = 0;
+        query_device(c, d_b.get(), d_o.get(), n, out ? d_out.get() : nullptr, nb, &tot, positive);
+        if (n_out) *n_out = tot;
+        if (out) {
+            if (tot > cap) throw Error(CBLX_ERANGE, "output capacity too small: " + std::to_string(tot) + " k-mers");
+            xfer(c).d2h_copy(out, d_out.get(), tot);
+        }
+    });
+}
+int cblx_contains_seqs_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t* n_out,
+                              uint64_t* positive) {
+    return guard(c, [&] {
+        if (n_out) *n_out = 0;
+        if (positive) *positive = 0;
+        flush(c);
+        if (n == 0) return;
+        if (!d_bases || !d_offsets) throw Error(CBLX_EINVAL, "null argument");
+        query_device(c, d_bases, d_offsets, n, d_out, cap, n_out, positive);
+        CBLX_HIP(hipStreamSynchronize(c->stream));
     });
 }
 int cblx_contains_all(cblx_ctx* c, const uint8_t* seq, uint64_t len, int* out) {

@@ -111,6 +111,9 @@ struct Ingest {
     Writer wb, wo;
     hipStream_t s = nullptr;
     std::unique_ptr<Xfer> xfer;
+    // consumer of the queue: the insert pipeline, or (cblx_query_fastx_file) the membership query with these tallies
+    bool query = false;
+    u64 q_total = 0, q_positive = 0;
 };
 
 // a fully partitioned batch of words waiting to be exported (multi-GPU build, sender side)
@@ -170,7 +173,13 @@ void collect_events(cblx_ctx* c) {
     c->evs.clear();
 }
 
-inline dim3 grid1(u64 n, u32 threads) { return dim3((unsigned)std::max<u64>(1, ceil_div(n, threads))); }
+// 1-D grid for n work items. A HIP launch addresses at most 2^32 - 1 work items in x: a larger grid does not fail, it
+// wraps (measured: 9.6 G threads ran as 9.6 G mod 2^32), so it is refused here and big launches are cut by the caller.
+inline dim3 grid1(u64 n, u32 threads) {
+    const u64 blocks = std::max<u64>(1, ceil_div(n, threads));
+    if (blocks * threads >= (1ull << 32)) throw Error(CBLX_ERANGE, "launch of " + std::to_string(n) + " work items exceeds the 2^32 limit of one grid");
+    return dim3((unsigned)blocks);
+}
 
 template <typename T> T d2h(cblx_ctx* c, const T* dptr) {
     T v;

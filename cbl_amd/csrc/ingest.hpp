@@ -178,7 +178,14 @@ void flush(cblx_ctx* c) {
     // the pending queue is consumed even if the insert fails (the reference would have panicked)
     for (Ingest::Writer* w : {&g.wb, &g.wo}) { w->issued = 0; w->busy[0] = w->busy[1] = false; }
     g.nbytes = g.nseq = g.last_end = 0;
-    insert_device(c, g.d_bases.get(), g.d_off.get(), nseq);
+    if (g.query) {  // examples/cbl.rs:205-228: contains_seq per record, tallies only
+        u64 tot = 0, pos = 0;
+        query_device(c, g.d_bases.get(), g.d_off.get(), nseq, nullptr, 0, &tot, &pos);
+        g.q_total += tot;
+        g.q_positive += pos;
+    } else {
+        insert_device(c, g.d_bases.get(), g.d_off.get(), nseq);
+    }
     CBLX_HIP(hipStreamSynchronize(c->stream));
 }
 

@@ -1124,16 +1124,21 @@ __global__ void k_gather_dense(u64 nelem, u64 nb, const u64* __restrict__ res_of
     if (out_hi) out_hi[e] = a_hi[start[l] + j] & ((1ull << (SB - 64)) - 1ull);
 }
 
-// membership of words in a resident index: WordSet::contains_batch (/root/reference/src/wordset/mod.rs:163-185)
+// membership of words in a resident index: WordSet::contains_batch (/root/reference/src/wordset/mod.rs:163-185).
+// QL lanes share a query: the directory lookup is a broadcast, a Vec bucket (first-occurrence order, so nothing to
+// search by) is scanned QL suffixes (64 coalesced bytes) per step, a Trie bucket (ascending) by a (QL + 1)-ary search —
+// QL probes per step instead of one — until at most QL candidates are left for the equality test.
+static const u32 QL = 8;
 template <typename HiT>
-__global__ void k_contains(const u64* __restrict__ w_lo, const HiT* __restrict__ w_hi, u64 n, u32 SB, u32 PB, DirView dir,
-                           const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u8* __restrict__ out) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(256) void k_contains(const u64* __restrict__ w_lo, const HiT* __restrict__ w_hi, u64 n, u32 SB, u32 PB, DirView dir,
+                                                   const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u8* __restrict__ out) {
+    const u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / QL;
+    if (i >= n) return;  // whole groups leave together (QL divides the workgroup size)
+    const u32 lane = threadIdx.x & 63u, sub = lane & (QL - 1u), gsh = lane & ~(QL - 1u);
     const u64 lo = w_lo[i], hi = ld_hi<HiT>(w_hi, i);
     const u32 p = get_bits(lo, hi, SB, PB);
     u64 r;
-    u8 found = 0;
+    bool found = false;
     if (dir_lookup(dir, p, r)) {
         const u128 M = (((u128)1) << SB) - 1;
         const u128 key = (((u128)hi << 64) | lo) & M;
@@ -1144,19 +1149,27 @@ __global__ void k_contains(const u64* __restrict__ w_lo, const HiT* __restrict__
             if (a_hi) v |= (u128)a_hi[s0 + j] << 64;
             return v & M;
         };
+        auto group_any = [&](bool b) -> bool { return ((__ballot(b) >> gsh) & ((1ull << QL) - 1ull)) != 0; };
+        u32 l = 0, h = c;  // candidates [l, h)
         if (dir.kind[r] == KIND_TRIE) {
-            u32 l = 0, h = c;
-            while (l < h) {
-                u32 mid = (l + h) >> 1;
-                u128 v = at(mid);
-                if (v < key) l = mid + 1; else h = mid;
+            while (h - l > QL) {  // group-uniform
+                const u32 width = h - l;
+                const u32 m = l + (u32)(((u64)(sub + 1u) * width) / (QL + 1u));  // l < m < h, ascending in sub
+                const bool less = at(m) < key;
+                const u32 cnt = (u32)__builtin_popcountll((__ballot(less) >> gsh) & ((1ull << QL) - 1ull));  // probes below the key: the first cnt
+                const u32 nl = cnt ? l + (u32)(((u64)cnt * width) / (QL + 1u)) + 1u : l;
+                const u32 nh = cnt < QL ? l + (u32)(((u64)(cnt + 1u) * width) / (QL + 1u)) + 1u : h;
+                l = nl;
+                h = nh;
             }
-            found = l < c && at(l) == key;
-        } else {
-            for (u32 j = 0; j < c && !found; ++j) found = at(j) == key;
+        }
+        for (u32 j0 = l; j0 < h; j0 += QL) {  // group-uniform trip count; a Vec is scanned whole unless the key turns up
+            const u32 j = j0 + sub;
+            found = j < h && at(j) == key;
+            if (group_any(found)) { found = true; break; }
         }
     }
-    out[i] = found;
+    if (sub == 0) out[i] = found ? 1 : 0;
 }
 
 // ---- order-independent checksum and structural validation (full-size parity properties) ------------------------------

@@ -2,6 +2,7 @@
 // KRN-4 directory, KRN-3 bucket kernels, the incremental (non-empty index) path and `self |= other`. Included by cblx.cpp only.
 #pragma once
 #include "ctx.hpp"
+#include "kernels_kmer.hpp"
 
 namespace {
 
@@ -468,6 +469,50 @@ void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nse
         encode<C>(c, d_bases, pl, rec.lo.get(), (typename C::HiT*)rec.hi.get(), base, eh);
         pipeline<C>(c, rec, base + pl.n_kmers, std::move(countsA));
         c->kmers_inserted += pl.n_kmers;
+    });
+    collect_events(c);
+}
+
+// membership flags of n device words against the resident index (WordSet::contains_batch)
+template <typename C> void contains_words(cblx_ctx* c, const u64* w_lo, const typename C::HiT* w_hi, u64 n, u8* d_out) {
+    typedef typename C::HiT HiT;
+    const u64 step = 1ull << 28;  // QL lanes per query: 2^31 work items per launch
+    for (u64 a = 0; a < n; a += step) {
+        const u64 m = std::min(step, n - a);
+        hipLaunchKernelGGL(k_contains<HiT>, grid1(m * QL, 256), dim3(256), 0, c->stream, w_lo + a, HiTraits<HiT>::has ? w_hi + a : w_hi, m, c->P.SB, c->P.PB, c->res.view(),
+                           c->res.a_lo.get(), c->P.wide_suffix() ? c->res.a_hi.get() : (const u64*)nullptr, d_out + a);
+    }
+    CBLX_HIP(hipGetLastError());
+}
+// CBL::contains_seq over a batch of device-resident sequences: KRN-1, then one membership flag per k-mer (sequence after
+// sequence, each in get_seq_words order) into d_out[cap] when given; *total / *positive count the flags.
+void query_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq, u8* d_out, u64 cap, u64* total, u64* positive) {
+    if (total) *total = 0;
+    if (positive) *positive = 0;
+    if (nseq == 0) return;
+    check_aligned16(d_bases, "d_bases");
+    dispatch(c->P, [&](auto cfg) {
+        typedef decltype(cfg) C;
+        typedef typename C::HiT HiT;
+        ChunkPlan pl;
+        plan_chunks(c, d_bases, d_offsets, nseq, pl);
+        const u64 nk = pl.n_kmers;
+        if (total) *total = nk;
+        if (nk == 0) return;
+        if (nk >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "too many k-mers in one query batch");
+        if (d_out && nk > cap) throw Error(CBLX_ERANGE, "output capacity too small: " + std::to_string(nk) + " k-mers");
+        Buf<u64> w_lo(c->pool, nk + 2);
+        Buf<u8> w_hi(c->pool, (nk + 2) * std::max<size_t>(1, hi_elem_size(c->P)));
+        Buf<u8> flags;
+        if (!d_out) { flags = Buf<u8>(c->pool, nk + 8); d_out = flags.get(); }
+        Buf<u32> zeros(c->pool, 1);
+        CBLX_HIP(hipMemsetAsync(zeros.get(), 0, 4, c->stream));
+        encode<C>(c, d_bases, pl, w_lo.get(), (HiT*)w_hi.get(), 0);
+        contains_words<C>(c, w_lo.get(), (const HiT*)w_hi.get(), nk, d_out);
+        hipLaunchKernelGGL(k_count_zero_u8, dim3((unsigned)std::min<u64>(4096, ceil_div(nk, 256))), dim3(256), 0, c->stream, (const u8*)d_out, nk, zeros.get());
+        CBLX_HIP(hipGetLastError());
+        const u64 z = d2h<u32>(c, zeros.get());  // also: the temporaries may go back to the pool
+        if (positive) *positive = nk - z;
     });
     collect_events(c);
 }

@@ -153,6 +153,17 @@ int cblx_export_buckets(cblx_ctx* ctx, cblx_bucket_cb cb, void* user);
 
 /* CBL::contains_seq (src/cbl.rs:311-324): one byte (0/1) per k-mer of one sequence, into `out[cap]`. */
 int cblx_contains_seq(cblx_ctx* ctx, const uint8_t* seq, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* n);
+/* The same for a batch of sequences in one pass (the loop of `cbl query`, examples/cbl.rs:205-228): flags of sequence 0,
+ * then sequence 1, ... (`out` may be NULL when only the tallies are wanted); *n_out = k-mers queried, *positive = flags
+ * set. Every sequence must hold at least K bytes (CBLX_ESHORT otherwise, nothing is queried).
+ * _device: d_bases (16-byte aligned, 16 readable bytes past the end) / d_offsets / d_out are device pointers. */
+int cblx_contains_seqs(cblx_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n, uint8_t* out, uint64_t cap,
+                       uint64_t* n_out, uint64_t* positive);
+int cblx_contains_seqs_device(cblx_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n, uint8_t* d_out,
+                              uint64_t cap, uint64_t* n_out, uint64_t* positive);
+/* `cbl query <index> <fastx>` (examples/cbl.rs:205-228): contains_seq for every record of a FASTA/FASTQ(.gz) file, read like
+ * cblx_insert_fastx_file; *total = k-mers queried, *positive = those found. The index is not modified. */
+int cblx_query_fastx_file(cblx_ctx* ctx, const char* path, uint64_t* n_records, uint64_t* total, uint64_t* positive);
 /* CBL::contains_all (src/cbl.rs:293-307): *out = 1 iff every k-mer of the sequence is in the set. */
 int cblx_contains_all(cblx_ctx* ctx, const uint8_t* seq, uint64_t len, int* out);
 

@@ -402,6 +402,11 @@ def test_full_size_properties(k, pb, nreads, L):
         assert all(g.contains_seq(hb[i * L : (i + 1) * L].tobytes()))
     fb, _ = synth.reads(4242, 2, L)
     assert not any(g.contains_seq(fb[:L].tobytes()))
+    # the batched query at full size: every k-mer of the indexed reads is found, none of an unrelated read set
+    assert g.contains_seqs_device(d_b, d_o, nreads) == (n_kmers, n_kmers)
+    f_b, f_o = synth.reads_torch(4242, nreads // 10, L, device="cuda")
+    assert g.contains_seqs_device(f_b, f_o, nreads // 10) == (nreads // 10 * (L - k + 1), 0)
+    del f_b, f_o
     g.insert_seqs_device(d_b, d_o, nreads)  # idempotence (resident + new through the incremental path)
     assert (g.count(), g.checksum()) == (count, cs)
     assert g.validate() == 0
@@ -451,6 +456,20 @@ def test_cli_build_insert_merge_files(tmp_path):
     oc = Oracle(k, pb, True)
     oc.insert_seqs(b1, o1)
     assert (tmp_path / "c.cbl").read_bytes() == oc.serialize()
+
+    # list: one k-mer per line in iteration order (examples/cbl.rs:177-203); query: tallies (:205-228)
+    cli(["-k", "31", "list", str(tmp_path / "a.cbl"), "-o", str(tmp_path / "a.txt")])
+    oa1 = Oracle(k, pb)
+    oa1.insert_seqs(b1, o1)
+    want = b"".join(bytes(b"ACTG"[(oa1.kmer_of_word(w) >> (2 * (k - 1 - j))) & 3] for j in range(k)) + b"\n" for w in oa1.iter_words()[:3000])
+    got = (tmp_path / "a.txt").read_bytes()
+    assert got[: len(want)] == want and len(got) == oa1.count() * (k + 1)
+    g = cbl_amd.CBL.load_from_file(str(tmp_path / "a.cbl"), k, pb)
+    nrec, total, positive = g.query_fastx_file(str(fq))
+    exp = [oa1.contains_word(w) for i in range(len(o2) - 1) for w in oa1.seq_words(b2[int(o2[i]) : int(o2[i + 1])].tobytes())]
+    assert (nrec, total, positive) == (len(o2) - 1, len(exp), sum(exp))
+    assert g.query_fastx_file(str(fa))[1:] == ((len(o1) - 1) * (150 - k + 1),) * 2  # every k-mer of the indexed file is found
+    cli(["-k", "31", "query", str(tmp_path / "a.cbl"), str(ml)])
 
 
 def test_offset_slices_address_the_same_buffer():
@@ -840,3 +859,63 @@ def test_single_insert_crosses_vec_trie_threshold():
         assert g.insert_kmers(batch).tolist() == [o.insert_kmer(x) for x in batch]
         assert g.serialize() == o.serialize()
     assert g.validate() == 0
+
+
+# ---- batched query: the `cbl query` loop (/root/reference/examples/cbl.rs:205-228) ------------------------------------------
+@pytest.mark.parametrize("k,pb,canonical", [(31, 24, False), (31, 10, True), (15, 4, False), (59, 28, False), (45, 6, True)])
+def test_batched_query_matches_oracle(k, pb, canonical, tmp_path):
+    """contains_seqs / query_fastx_file against the oracle's membership of every word, with Vec buckets, big Trie buckets
+    (small PREFIX_BITS), misses that share a bucket with hits, and sequences with non-ACGT bytes."""
+    _need_gpu()
+    rng = random.Random(31 * k + pb)
+    g, o = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
+    genome = _rand_seq(rng, 60000)
+    g.insert_seq(genome), o.insert_seq(genome)
+    assert g.serialize() == o.serialize()
+    if pb <= 6:
+        assert g.bucket_table_np()[2].max() == 1  # Trie buckets are searched too
+    queries = []
+    for _ in range(40):
+        a = rng.randrange(0, len(genome) - 2000)
+        s = bytearray(genome[a : a + rng.randint(k, 1500)])
+        for _ in range(rng.randint(0, 6)):  # point mutations: k-mers that miss but fall into populated buckets
+            s[rng.randrange(len(s))] = rng.choice(b"ACGTN")
+        queries.append(bytes(s))
+    queries.append(_rand_seq(rng, 5000))          # multi-chunk miss-heavy sequence
+    queries.append(genome[1000 : 1000 + k])       # a single k-mer
+    bases, offsets = _concat(queries)
+    flags, tot, pos = g.contains_seqs(bases, offsets)
+    want = []
+    for q in queries:
+        want += [o.contains_word(w) for w in o.seq_words(q)]
+    assert tot == len(want) and flags.tolist() == want and pos == sum(want)
+    # per-sequence entry point gives the same flags
+    assert g.contains_seq(queries[0]) == want[: len(o.seq_words(queries[0]))]
+    # tallies only, device-resident batch
+    pad = (-len(bases)) % 16 + 16
+    d_b = torch.from_numpy(np.concatenate([bases, np.zeros(pad, np.uint8)])).cuda()
+    d_o = torch.from_numpy(offsets.astype(np.int64)).cuda()
+    d_f = torch.zeros(len(bases), dtype=torch.uint8, device="cuda")
+    assert g.contains_seqs_device(d_b, d_o, len(queries)) == (tot, pos)
+    assert g.contains_seqs_device(d_b, d_o, len(queries), d_f, len(bases)) == (tot, pos)
+    assert d_f[:tot].cpu().numpy().astype(bool).tolist() == want
+    _, tot2, pos2 = g.contains_seqs(bases, offsets, flags=False)
+    assert (tot2, pos2) == (tot, pos)
+    # the file loop; the index is untouched and pending inserts are applied first
+    fa = tmp_path / "q.fa"
+    with open(fa, "wb") as f:
+        for i, q in enumerate(queries):
+            f.write(b">q%d\n" % i)
+            for j in range(0, len(q), 70):
+                f.write(q[j : j + 70] + b"\n")
+    before = g.count()
+    extra = _rand_seq(rng, 3 * k)
+    g.insert_seq(extra), o.insert_seq(extra)  # stays pending until the query flushes it
+    want2 = []
+    for q in queries:
+        want2 += [o.contains_word(w) for w in o.seq_words(q)]
+    assert g.query_fastx_file(fa) == (len(queries), len(want2), sum(want2))
+    assert g.count() == o.count() >= before and g.serialize() == o.serialize()
+    with pytest.raises(cbl_amd.CblxError):
+        g.contains_seqs(*_concat([queries[0], b"ACG"]))
+    assert g.contains_seqs(*_concat([]))[1:] == (0, 0)

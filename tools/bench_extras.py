@@ -129,6 +129,16 @@ def main():
     hits = g.contains_seq_np(q)
     dt = time.perf_counter() - t0
     out["contains_seq"] = {"ms": dt * 1e3, "kmers": len(hits), "kmers_per_s": len(hits) / dt, "hit_fraction": float(np.mean(hits))}
+    # 5b. batched query (cbl query): all reads of the indexed set (hits) and an unrelated read set (misses), device-resident
+    dt = timed(lambda: g.contains_seqs_device(d_bases, d_offsets, NR), reps=2)
+    tot, pos = g.contains_seqs_device(d_bases, d_offsets, NR)
+    out["query_batched_hits"] = {"ms": dt * 1e3, "kmers": tot, "positive": pos, "kmers_per_s": tot / dt}
+    m_bases, m_offsets = synth.reads_torch(77, NR, L, device=dev)
+    torch.cuda.synchronize()
+    dt = timed(lambda: g.contains_seqs_device(m_bases, m_offsets, NR), reps=2)
+    tot, pos = g.contains_seqs_device(m_bases, m_offsets, NR)
+    out["query_batched_misses"] = {"ms": dt * 1e3, "kmers": tot, "positive": pos, "kmers_per_s": tot / dt}
+    del m_bases, m_offsets
     g.clear()
     del h_bases, h_offsets
 
