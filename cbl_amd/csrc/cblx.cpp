@@ -47,7 +47,7 @@ template <typename C> u64 seq_words_of_host_seq(cblx_ctx* c, const uint8_t* seq,
 // words (get_word, src/cbl.rs:199-206) of n packed host k-mers, on the device
 template <typename C> void words_of_host_kmers(cblx_ctx* c, const uint64_t* lo, const uint64_t* hi, u64 n, Buf<u64>& w_lo, Buf<u8>& w_hi) {
     typedef typename C::HiT HiT;
-    if (!lo || (C::WIDE && !hi)) throw Error(CBLX_EINVAL, C::WIDE ? "null argument (K >= 33 needs the hi halves of the k-mers)" : "null argument");
+    if (!lo || (c->P.wide_kmer() && !hi)) throw Error(CBLX_EINVAL, c->P.wide_kmer() ? "null argument (K >= 33 needs the hi halves of the k-mers)" : "null argument");
     if (n >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "too many k-mers in one call");
     Buf<u64> k_lo(c->pool, n + 1), k_hi(c->pool, hi ? n + 1 : 1);
     Buf<u32> bad(c->pool, 1);

@@ -228,11 +228,11 @@ template <bool WIDE_, typename HiT_, bool WS_> struct Cfg {
 };
 template <typename F> void dispatch(const Consts& P, F&& f) {
     if (!P.has_hi()) f(Cfg<false, NoHi, false>());
-    else if (!P.wide_kmer()) f(Cfg<false, u8, false>());
+    else if (!P.wide_kmer() && !P.wide_suffix()) f(Cfg<false, u8, false>());  // 65..72-bit word, hi bits inside the first pass's digit
     else if (!P.wide_suffix()) f(Cfg<true, u64, false>());
     else f(Cfg<true, u64, true>());
 }
-inline size_t hi_elem_size(const Consts& P) { return !P.has_hi() ? 0 : (!P.wide_kmer() ? 1 : 8); }
+inline size_t hi_elem_size(const Consts& P) { return !P.has_hi() ? 0 : ((!P.wide_kmer() && !P.wide_suffix()) ? 1 : 8); }
 
 
 }  // namespace

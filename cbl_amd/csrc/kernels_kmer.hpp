@@ -17,7 +17,7 @@ __global__ void k_kmers_to_words(const u64* __restrict__ k_lo, const u64* __rest
     T x;
     bool oob;
     if constexpr (WIDE) {
-        x = ((u128)k_hi[i] << 64) | (u128)k_lo[i];
+        x = ((u128)(k_hi ? k_hi[i] : 0ull) << 64) | (u128)k_lo[i];  // K = 31 with a > 64-bit suffix runs this layout too
         oob = (x >> P.KB) != 0;
     } else {
         x = k_lo[i];

@@ -42,7 +42,7 @@ def main():
         ops = []
         print("START", desc, file=sys.stderr, flush=True)
         for step in range(rng.randint(1, 5)):
-            op = rng.choice(["seq", "seqs", "seqs", "merge", "roundtrip", "sorted"])
+            op = rng.choice(["seq", "seqs", "seqs", "merge", "roundtrip", "sorted", "kmers", "query"])
             ops.append(op)
             if op == "seq":
                 for _ in range(rng.randint(1, 5)):
@@ -68,6 +68,22 @@ def main():
                 assert blob == o.serialize(), desc + " (before round trip) " + str(ops)
                 g = cbl_amd.CBL(k, pb, canonical=canonical)
                 g.load(blob)
+            elif op == "kmers":  # single-k-mer inserts: return values and final state
+                pool = [rng.getrandbits(2 * k) for _ in range(rng.randint(1, 200))]
+                batch = [rng.choice(pool) for _ in range(rng.randint(1, 400))]
+                got = g.insert_kmers(batch).tolist()
+                assert got == [o.insert_kmer(x) for x in batch], desc + " (insert_kmers) " + str(ops)
+                probe = batch[:50] + [rng.getrandbits(2 * k) for _ in range(50)]
+                assert g.contains_kmers(probe).tolist() == [o.contains_kmer(x) for x in probe], desc + " (contains_kmers) " + str(ops)
+            elif op == "query":
+                seqs = [rand_seq(rng, rng.randint(k, k + rng.choice([0, 7, 500, 3000])), alphabet) for _ in range(rng.randint(1, 30))]
+                bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+                offsets = np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64)
+                flags, tot, pos = g.contains_seqs(bases, offsets)
+                want = [o.contains_word(w) for s in seqs for w in o.seq_words(s)]
+                assert flags.tolist() == want and tot == len(want) and pos == sum(want), desc + " (query) " + str(ops)
+                if rng.random() < 0.3:
+                    assert [o.kmer_of_word(w) for w in o.iter_words()] == list(g.iter()), desc + " (iter) " + str(ops)
             elif op == "sorted":
                 seqs = [rand_seq(rng, rng.randint(k, k + 800), b"ACGT") for _ in range(rng.randint(1, 40))]
                 hb = np.frombuffer(b"".join(seqs), dtype=np.uint8)

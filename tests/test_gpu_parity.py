@@ -92,7 +92,7 @@ def _check_index(g, o):
 
 
 # ---- KRN-1: words ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("k,pb", [(7, 14), (25, 24), (29, 24), (31, 24), (31, 28), (33, 24), (59, 28)])
+@pytest.mark.parametrize("k,pb", [(7, 14), (25, 24), (29, 24), (31, 24), (31, 28), (33, 24), (59, 28), (31, 2), (31, 5)])
 @pytest.mark.parametrize("canonical", [False, True])
 def test_words_match_oracle(k, pb, canonical):
     _need_gpu()
@@ -142,6 +142,10 @@ def test_short_sequence_rejected():
         (59, 28, 600, 250, True),
         (33, 24, 1000, 150, False),   # wide k-mer, narrow suffix
         (7, 14, 300, 60, False),
+        (31, 2, 800, 150, False),     # 68-bit word with a 66-bit suffix: the hi bits are suffix bits, the wide layout takes it
+        (31, 3, 800, 150, True),
+        (31, 4, 800, 150, False),     # smallest PREFIX_BITS whose first-pass digit still covers the hi bits
+        (29, 1, 800, 150, True),
     ],
 )
 def test_index_matches_oracle(k, pb, nreads, L, canonical):
@@ -785,7 +789,7 @@ print("ok")
 
 # ---- packed k-mers: CBL::insert / contains / iter and the bucket statistics (/root/reference/src/cbl.rs:219-228,358-386;
 # the reference's own shape: src/cbl.rs:591-662 insert/contains of random k-mers, :700-724 iter) ------------------------
-@pytest.mark.parametrize("k,pb,canonical", [(31, 24, False), (31, 24, True), (25, 12, False), (11, 8, True), (59, 28, False), (45, 20, True), (33, 16, False)])
+@pytest.mark.parametrize("k,pb,canonical", [(31, 24, False), (31, 24, True), (25, 12, False), (11, 8, True), (59, 28, False), (45, 20, True), (33, 16, False), (31, 2, True), (31, 3, False)])
 def test_single_kmer_insert_contains_iter(k, pb, canonical):
     _need_gpu()
     rng = random.Random(1000 * k + pb + canonical)
@@ -862,7 +866,7 @@ def test_single_insert_crosses_vec_trie_threshold():
 
 
 # ---- batched query: the `cbl query` loop (/root/reference/examples/cbl.rs:205-228) ------------------------------------------
-@pytest.mark.parametrize("k,pb,canonical", [(31, 24, False), (31, 10, True), (15, 4, False), (59, 28, False), (45, 6, True)])
+@pytest.mark.parametrize("k,pb,canonical", [(31, 24, False), (31, 10, True), (15, 4, False), (59, 28, False), (45, 6, True), (31, 2, False)])
 def test_batched_query_matches_oracle(k, pb, canonical, tmp_path):
     """contains_seqs / query_fastx_file against the oracle's membership of every word, with Vec buckets, big Trie buckets
     (small PREFIX_BITS), misses that share a bucket with hits, and sequences with non-ACGT bytes."""
@@ -919,3 +923,25 @@ def test_batched_query_matches_oracle(k, pb, canonical, tmp_path):
     with pytest.raises(cbl_amd.CblxError):
         g.contains_seqs(*_concat([queries[0], b"ACG"]))
     assert g.contains_seqs(*_concat([]))[1:] == (0, 0)
+
+
+@pytest.mark.parametrize("preload", [False, True])
+def test_heavily_duplicated_runs_of_33_to_128_words(preload):
+    """A run of 33..128 words that are (nearly) all equal overflows a sub-bucket of the counting-sort kernel and comes back
+    through its retry list — also when no longer bucket class is populated (regression: the retry count was only read
+    when a longer class had work, such buckets were never finalized)."""
+    _need_gpu()
+    k, pb = 7, 8
+    g, o = cbl_amd.CBL(k, pb), Oracle(k, pb)
+    if preload:
+        s = b"ACGTTGCAAC" * 3
+        g.insert_seq(s), o.insert_seq(s)
+    batch = [8027, 7897, 1847] * 80 + [8027] * 40
+    assert g.insert_kmers(batch).tolist() == [o.insert_kmer(x) for x in batch]
+    assert g.count() == o.count() and g.serialize() == o.serialize() and g.validate() == 0
+    # the same shape through insert_seq: poly-A stretches inside distinct contexts
+    for k2, pb2 in ((31, 24), (15, 10)):
+        g2, o2 = cbl_amd.CBL(k2, pb2), Oracle(k2, pb2)
+        s = (b"A" * (k2 + 70) + b"C") * 3
+        g2.insert_seq(s), o2.insert_seq(s)
+        assert g2.serialize() == o2.serialize() and g2.validate() == 0
