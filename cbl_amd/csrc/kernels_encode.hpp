@@ -295,27 +295,36 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
         return s_parpre[q >> 6] + (u32)__builtin_popcountll(s_par[q >> 6] & ((1ull << (q & 63)) - 1ull));
     };
 
-    u32 ci = tid < Q ? find_chunk(tid) : 0u;
-    for (u32 q = tid; q < Q; q += ENC_THREADS) {
-        while (q >= s_koff[ci + 1]) ++ci;  // q only grows: walk forward from the previous chunk instead of searching again
-        if (s_dirty[ci]) continue;
-        const u32 j = q - s_koff[ci];
-        T x = extract_kmer<WIDE>(s_codes, s_cstart[ci] + j, P.K);
-        u64 dst = out_base + kbase + q;
-        bool rc = false;
-        if (P.canonical) {
-            const u32 cb = cum_fwd(s_koff[ci]);
-            const u32 nfwd = cum_fwd(s_koff[ci + 1]) - cb;
-            const u32 rf = cum_fwd(q) - cb;
-            rc = !kmer_is_fwd<WIDE>(x);
-            dst = out_base + kbase + s_koff[ci] + (rc ? (nfwd + (j - rf)) : rf);
+    // The k-mer loop, once with K as a compile-time constant for the headline K = 31 (every rotate / mask / shift of the
+    // necklace then has constant operands) and once with K read from P.
+    auto kmer_loop = [&](auto kc) {
+        constexpr u32 KC = decltype(kc)::value;
+        Consts PK = P;
+        if constexpr (KC != 0) { PK.K = KC; PK.KB = 2 * KC; PK.POS = 32 - __builtin_clz(2 * KC - 1); }
+        u32 ci = tid < Q ? find_chunk(tid) : 0u;
+        for (u32 q = tid; q < Q; q += ENC_THREADS) {
+            while (q >= s_koff[ci + 1]) ++ci;  // q only grows: walk forward from the previous chunk instead of searching again
+            if (s_dirty[ci]) continue;
+            const u32 j = q - s_koff[ci];
+            T x = extract_kmer<WIDE>(s_codes, s_cstart[ci] + j, PK.K);
+            u64 dst = out_base + kbase + q;
+            bool rc = false;
+            if (P.canonical) {
+                const u32 cb = cum_fwd(s_koff[ci]);
+                const u32 nfwd = cum_fwd(s_koff[ci + 1]) - cb;
+                const u32 rf = cum_fwd(q) - cb;
+                rc = !kmer_is_fwd<WIDE>(x);
+                dst = out_base + kbase + s_koff[ci] + (rc ? (nfwd + (j - rf)) : rf);
+            }
+            u64 lo, hi;
+            kmer_word<WIDE>(x, PK, rc, lo, hi);
+            out_lo[dst] = lo;
+            st_hi<HiT>(out_hi, dst, hi);
+            if (eh.counts) atomicAdd(&s_hist[(u32)(dst / ENC_HIST_WINDOW - win0) * 256 + eh.digit(lo, hi)], 1u);
         }
-        u64 lo, hi;
-        kmer_word<WIDE>(x, P, rc, lo, hi);
-        out_lo[dst] = lo;
-        st_hi<HiT>(out_hi, dst, hi);
-        if (eh.counts) atomicAdd(&s_hist[(u32)(dst / ENC_HIST_WINDOW - win0) * 256 + eh.digit(lo, hi)], 1u);
-    }
+    };
+    if (!WIDE && P.K == 31) kmer_loop(std::integral_constant<u32, 31>());
+    else kmer_loop(std::integral_constant<u32, 0>());
     if (eh.counts) {  // the first-pass digit is the skewed one: only a few dozen bins per window are non-zero
         __syncthreads();
         for (u32 i = tid; i < ENC_HIST_WINDOWS * 256; i += ENC_THREADS) {
