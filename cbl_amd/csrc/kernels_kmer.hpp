@@ -74,6 +74,107 @@ __global__ void k_count_zero_u8(const u8* __restrict__ v, u64 n, u32* __restrict
     if ((threadIdx.x & 63) == 0 && z) atomicAdd(zeros, z);
 }
 
+// ---- membership tallies by JOIN (the `cbl query` loop at scale, examples/cbl.rs:205-228): the query words go through the
+// same stable partition as a batch of new words, so the queries of one prefix sit in one run; one workgroup then joins that
+// run with the resident bucket of the prefix — the bucket is read once per workgroup instead of once per query:
+//   a resident bucket of <= JOIN_TAB_MAX elements, Vec or Trie: an open-addressing table of (tag, element index) in LDS;
+//   a longer Trie (ascending): binary search per query, the probes of the run's queries share the cache;
+//   a longer Vec (only `|=` makes them): scanned per query.
+// per_run[b] = queries of run b found. No per-query flags: the partition does not keep the queries' positions. -------------------
+static const u32 JOIN_THREADS = 256, JOIN_FULL_MAX = 2730, JOIN_TAB_MAX = 4095, JOIN_SLOTS = 8192;
+template <bool WS, typename HiT>
+__global__ __launch_bounds__(JOIN_THREADS) void k_query_join(u64 nbq, u64 b0, const u32* __restrict__ q_prefix, const u64* __restrict__ q_start,
+                                                             const u64* __restrict__ q_lo, const HiT* __restrict__ q_hi, u32 SB, DirView dir,
+                                                             const u64* __restrict__ a_lo, const u64* __restrict__ a_hi,
+                                                             u32* __restrict__ per_run /* zero-filled, one per run */) {
+    // 32 KB of LDS, one of two tables: FULL = 4096 slots holding the suffix itself (narrow suffixes, up to JOIN_FULL_MAX
+    // elements: a probe never leaves LDS — a verifying read per hit cost 40 ps, 4x the rest of the join), or 8192 slots of
+    // 20-bit tag << 12 | element index (0xFFFFFFFF = empty; index 4095 is never used), verified in the bucket on a tag match
+    __shared__ u64 s_full[JOIN_SLOTS / 2];
+    u32* s_tab = reinterpret_cast<u32*>(s_full);
+    const u64 b = b0 + blockIdx.x;
+    if (b >= nbq) return;
+    u64 r;
+    if (!dir_lookup(dir, q_prefix[b], r)) return;  // no resident bucket: every query of the run misses
+    const u64 qs = q_start[b], qe = q_start[b + 1];
+    const u64 rs = dir.start[r];
+    const u32 rc = dir.count[r];
+    const bool trie = dir.kind[r] == KIND_TRIE;
+    const u32 tid = threadIdx.x;
+    auto res_at = [&](u32 j) -> Sfx<WS> { return load_sfx<WS, u64>(a_lo + rs, WS ? a_hi + rs : a_hi, j, SB); };
+    auto less = [&](const Sfx<WS>& x, const Sfx<WS>& y) -> bool {
+        if constexpr (WS) { if (x.hi != y.hi) return x.hi < y.hi; }
+        return x.lo < y.lo;
+    };
+    // Up to JOIN_TAB_MAX elements (Vec or Trie alike: the elements of a bucket are distinct) go into an open-addressing
+    // table in LDS, at most half full; the tag keeps the probes off global memory until a candidate matches.
+    const bool full = !WS && SB < 64 && rc <= JOIN_FULL_MAX;
+    const bool table = !full && rc <= JOIN_TAB_MAX;
+    if (full) {
+        for (u32 i = tid; i < JOIN_SLOTS / 2; i += JOIN_THREADS) s_full[i] = ~0ull;
+        __syncthreads();
+        for (u32 j = tid; j < rc; j += JOIN_THREADS) {
+            const Sfx<WS> e = res_at(j);
+            u32 h = sfx_hash_bits<WS>(e, 12);
+            while (atomicCAS((unsigned long long*)&s_full[h], ~0ull, (unsigned long long)e.lo) != ~0ull) h = (h + 1u) & (JOIN_SLOTS / 2 - 1u);
+        }
+        __syncthreads();
+    }
+    if (table) {
+        for (u32 i = tid; i < JOIN_SLOTS; i += JOIN_THREADS) s_tab[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (u32 j = tid; j < rc; j += JOIN_THREADS) {
+            const u32 hv = sfx_hash_bits<WS>(res_at(j), 32);
+            u32 h = hv >> 19;
+            const u32 e = ((hv & 0xFFFFFu) << 12) | j;
+            while (atomicCAS(&s_tab[h], 0xFFFFFFFFu, e) != 0xFFFFFFFFu) h = (h + 1u) & (JOIN_SLOTS - 1u);
+        }
+        __syncthreads();
+    }
+    u32 found = 0;
+    for (u64 q = qs + tid; q < qe; q += JOIN_THREADS) {
+        const Sfx<WS> key = load_sfx<WS, HiT>(q_lo, q_hi, q, SB);
+        if (full) {
+            u32 h = sfx_hash_bits<WS>(key, 12);
+            for (;;) {
+                const u64 e = s_full[h];
+                if (e == key.lo) { ++found; break; }
+                if (e == ~0ull) break;
+                h = (h + 1u) & (JOIN_SLOTS / 2 - 1u);
+            }
+        } else if (table) {
+            const u32 hv = sfx_hash_bits<WS>(key, 32);
+            u32 h = hv >> 19;
+            const u32 tag = hv & 0xFFFFFu;
+            for (;;) {
+                const u32 e = s_tab[h];
+                if (e == 0xFFFFFFFFu) break;
+                if ((e >> 12) == tag && res_at(e & 0xFFFu) == key) { ++found; break; }
+                h = (h + 1u) & (JOIN_SLOTS - 1u);
+            }
+        } else if (trie) {  // ascending: binary search, the probes of the run's queries share the cache
+            u32 l = 0, h = rc;
+            while (l < h) {
+                const u32 mid = (l + h) >> 1;
+                if (less(res_at(mid), key)) l = mid + 1; else h = mid;
+            }
+            found += (l < rc && res_at(l) == key) ? 1u : 0u;
+        } else {  // a Vec this long only comes out of `|=`
+            bool hit = false;
+            for (u32 j = 0; j < rc && !hit; ++j) hit = res_at(j) == key;
+            found += hit ? 1u : 0u;
+        }
+    }
+    // one result per run (summed afterwards): 19 M wave-level atomics on ONE counter cost 47 ms at cfg 2
+    found = wave_reduce_sum(found);
+    __syncthreads();  // every probe of the table is done: its first word takes the tally
+    if (tid == 0) s_tab[0] = 0;
+    __syncthreads();
+    if ((tid & 63u) == 0 && found) atomicAdd(&s_tab[0], found);
+    __syncthreads();
+    if (tid == 0) per_run[b] = s_tab[0];
+}
+
 // CBL::iter: element e of the index in iteration order (prefixes ascending, bucket order as stored: a Vec in
 // first-occurrence order, a Trie ascending — src/wordset/mod.rs:298-309, src/trievec/mod.rs:198-206) -> word ->
 // recover_kmer (src/cbl.rs:208-214, revert_necklace_pos src/necklace/mod.rs:29-31).

@@ -484,6 +484,45 @@ template <typename C> void contains_words(cblx_ctx* c, const u64* w_lo, const ty
     }
     CBLX_HIP(hipGetLastError());
 }
+// Tallies of a big query batch by join (k_query_join): KRN-1 + the stable partition of the query words + one workgroup per
+// prefix run. CBLX_QUERY_JOIN_MIN overrides the batch size (k-mers) from which it replaces the per-query kernel.
+u64 query_join_min() {  // read per call: tests switch it
+    const char* e = std::getenv("CBLX_QUERY_JOIN_MIN");
+    return e ? std::strtoull(e, nullptr, 10) : (u64)(4u << 20);
+}
+template <typename C> u64 query_join(cblx_ctx* c, const u8* d_bases /* as left by plan_chunks */, const ChunkPlan& pl) {
+    typedef typename C::HiT HiT;
+    const u64 nk = pl.n_kmers;
+    if (nk == 0 || c->res.count == 0) return 0;
+    Records rec;
+    begin_records<C>(c, rec, nk);
+    Buf<u32> countsA;
+    EncHist eh{};
+    {   // as insert_device: KRN-1 accumulates the first partition pass's tile histogram
+        const size_t ntmax = (size_t)ceil_div(nk, RDX_TILE) + 256;
+        countsA = Buf<u32>(c->pool, 256 * ntmax);
+        CBLX_HIP(hipMemsetAsync(countsA.get(), 0, 256 * ntmax * 4, c->stream));
+        const u32 nA = std::min(8u, c->P.PB);
+        eh.counts = countsA.get();
+        eh.shift = c->P.SB + (c->P.PB - nA);
+        eh.nbits = nA;
+    }
+    encode<C>(c, d_bases, pl, rec.lo.get(), (HiT*)rec.hi.get(), 0, eh);
+    Resident qd;  // directory of the query batch: prefixes and run starts
+    partition_and_directory<C>(c, rec, nk, std::move(countsA), qd);
+    Buf<u64> pos(c->pool, 1);
+    Buf<u32> per_run(c->pool, qd.nb + 1);
+    CBLX_HIP(hipMemsetAsync(pos.get(), 0, 8, c->stream));
+    CBLX_HIP(hipMemsetAsync(per_run.get(), 0, (qd.nb + 1) * 4, c->stream));
+    const u64 step = 1ull << 23;  // workgroups per launch (x 256 threads < 2^32 work items)
+    for (u64 b0 = 0; b0 < qd.nb; b0 += step)
+        hipLaunchKernelGGL((k_query_join<C::WS, HiT>), dim3((unsigned)std::min(step, qd.nb - b0)), dim3(JOIN_THREADS), 0, c->stream, qd.nb, b0, qd.prefix.get(),
+                           qd.start.get(), rec.lo.get(), (const HiT*)rec.hi.get(), c->P.SB, c->res.view(), c->res.a_lo.get(),
+                           c->P.wide_suffix() ? c->res.a_hi.get() : (const u64*)nullptr, per_run.get());
+    hipLaunchKernelGGL(k_sum_u32, dim3((unsigned)std::min<u64>(2048, std::max<u64>(1, ceil_div(qd.nb, 256)))), dim3(256), 0, c->stream, per_run.get(), qd.nb, pos.get());
+    CBLX_HIP(hipGetLastError());
+    return d2h<u64>(c, pos.get());  // also: the temporaries may go back to the pool
+}
 // CBL::contains_seq over a batch of device-resident sequences: KRN-1, then one membership flag per k-mer (sequence after
 // sequence, each in get_seq_words order) into d_out[cap] when given; *total / *positive count the flags.
 void query_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq, u8* d_out, u64 cap, u64* total, u64* positive) {
@@ -500,6 +539,11 @@ void query_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq
         if (total) *total = nk;
         if (nk == 0) return;
         if (nk >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "too many k-mers in one query batch");
+        if (!d_out && nk >= query_join_min()) {  // tallies only, big batch: join instead of one bucket read per query
+            const u64 p = query_join<C>(c, d_bases, pl);
+            if (positive) *positive = p;
+            return;
+        }
         if (d_out && nk > cap) throw Error(CBLX_ERANGE, "output capacity too small: " + std::to_string(nk) + " k-mers");
         Buf<u64> w_lo(c->pool, nk + 2);
         Buf<u8> w_hi(c->pool, (nk + 2) * std::max<size_t>(1, hi_elem_size(c->P)));

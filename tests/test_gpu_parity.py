@@ -867,7 +867,7 @@ def test_single_insert_crosses_vec_trie_threshold():
 
 # ---- batched query: the `cbl query` loop (/root/reference/examples/cbl.rs:205-228) ------------------------------------------
 @pytest.mark.parametrize("k,pb,canonical", [(31, 24, False), (31, 10, True), (15, 4, False), (59, 28, False), (45, 6, True), (31, 2, False)])
-def test_batched_query_matches_oracle(k, pb, canonical, tmp_path):
+def test_batched_query_matches_oracle(k, pb, canonical, tmp_path, monkeypatch):
     """contains_seqs / query_fastx_file against the oracle's membership of every word, with Vec buckets, big Trie buckets
     (small PREFIX_BITS), misses that share a bucket with hits, and sequences with non-ACGT bytes."""
     _need_gpu()
@@ -905,6 +905,12 @@ def test_batched_query_matches_oracle(k, pb, canonical, tmp_path):
     assert d_f[:tot].cpu().numpy().astype(bool).tolist() == want
     _, tot2, pos2 = g.contains_seqs(bases, offsets, flags=False)
     assert (tot2, pos2) == (tot, pos)
+    # the same tallies through the join (big batches take it by themselves; forced here), Vec and Trie buckets alike
+    monkeypatch.setenv("CBLX_QUERY_JOIN_MIN", "1")
+    assert g.contains_seqs(bases, offsets, flags=False)[1:] == (tot, pos)
+    assert g.contains_seqs_device(d_b, d_o, len(queries)) == (tot, pos)
+    e = cbl_amd.CBL(k, pb, canonical=canonical)
+    assert e.contains_seqs(bases, offsets, flags=False)[1:] == (tot, 0)  # empty index
     # the file loop; the index is untouched and pending inserts are applied first
     fa = tmp_path / "q.fa"
     with open(fa, "wb") as f:
