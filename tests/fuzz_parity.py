@@ -19,6 +19,7 @@ def rand_seq(rng, n, alphabet):
 
 
 def main():
+    os.environ["CBLX_QUERY_JOIN_MIN"] = "1"  # tallies-only queries take the join path whatever their size
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
@@ -82,6 +83,7 @@ def main():
                 flags, tot, pos = g.contains_seqs(bases, offsets)
                 want = [o.contains_word(w) for s in seqs for w in o.seq_words(s)]
                 assert flags.tolist() == want and tot == len(want) and pos == sum(want), desc + " (query) " + str(ops)
+                assert g.contains_seqs(bases, offsets, flags=False)[1:] == (tot, pos), desc + " (query by join) " + str(ops)
                 if rng.random() < 0.3:
                     assert [o.kmer_of_word(w) for w in o.iter_words()] == list(g.iter()), desc + " (iter) " + str(ops)
             elif op == "sorted":
