@@ -295,8 +295,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
         return s_parpre[q >> 6] + (u32)__builtin_popcountll(s_par[q >> 6] & ((1ull << (q & 63)) - 1ull));
     };
 
-    // The k-mer loop, once with K as a compile-time constant for the headline K = 31 (every rotate / mask / shift of the
-    // necklace then has constant operands) and once with K read from P.
+    // The k-mer loop with K as a compile-time constant (every rotate / mask / shift of the necklace then has constant
+    // operands) or read from P.
     auto kmer_loop = [&](auto kc) {
         constexpr u32 KC = decltype(kc)::value;
         Consts PK = P;
@@ -323,8 +323,15 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
             if (eh.counts) atomicAdd(&s_hist[(u32)(dst / ENC_HIST_WINDOW - win0) * 256 + eh.digit(lo, hi)], 1u);
         }
     };
-    if (!WIDE && P.K == 31) kmer_loop(std::integral_constant<u32, 31>());
-    else kmer_loop(std::integral_constant<u32, 0>());
+    // the K of BASELINE.json's configurations get their own copy of the loop; any other K reads it from P
+    if constexpr (!WIDE) {
+        if (P.K == 31) kmer_loop(std::integral_constant<u32, 31>());
+        else if (P.K == 25) kmer_loop(std::integral_constant<u32, 25>());
+        else kmer_loop(std::integral_constant<u32, 0>());
+    } else {
+        if (P.K == 59) kmer_loop(std::integral_constant<u32, 59>());
+        else kmer_loop(std::integral_constant<u32, 0>());
+    }
     if (eh.counts) {  // the first-pass digit is the skewed one: only a few dozen bins per window are non-zero
         __syncthreads();
         for (u32 i = tid; i < ENC_HIST_WINDOWS * 256; i += ENC_THREADS) {
