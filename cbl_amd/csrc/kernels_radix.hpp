@@ -330,13 +330,30 @@ __global__ __launch_bounds__(64 * HISTB_WAVES) void k_radix_hist_bytes(const u8*
     u32* mine = my + (lane & 1u) * 256;
     const u64 w0 = tbase >> 3, wend = (tbase + n_tile + 7) >> 3;  // aligned words covering [tbase, tbase + n_tile)
     const u64* __restrict__ words = reinterpret_cast<const u64*>(dig);
-    for (u64 wi = w0 + lane; wi < wend; wi += 64) {
-        const u64 v = words[wi];
-        const u64 b0 = wi << 3;
+    // a tile spans at most RDX_TILE / 8 + 1 aligned words = 8 full rounds of the wave + one word: all loads are issued
+    // before the first counter update (one load -> 8 LDS atomics -> next load left the wave latency-bound)
+    constexpr int ROUNDS = RDX_TILE / 512 + 1;
+    u64 v[ROUNDS];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const u64 pos = b0 + k;
-            if (pos >= tbase && pos < tbase + n_tile) atomicAdd(&mine[(u32)(v >> (8 * k)) & 255u], 1u);
+    for (int r = 0; r < ROUNDS; ++r) {
+        const u64 wi = w0 + lane + (u64)r * 64;
+        v[r] = wi < wend ? words[wi] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const u64 wi = w0 + lane + (u64)r * 64;
+        if (wi < wend) {
+            const u64 b0 = wi << 3;
+            if (b0 >= tbase && b0 + 8 <= tbase + n_tile) {  // whole word inside the tile (all but the first and last)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) atomicAdd(&mine[(u32)(v[r] >> (8 * k)) & 255u], 1u);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const u64 pos = b0 + k;
+                    if (pos >= tbase && pos < tbase + n_tile) atomicAdd(&mine[(u32)(v[r] >> (8 * k)) & 255u], 1u);
+                }
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
