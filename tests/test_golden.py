@@ -60,3 +60,34 @@ def test_gpu_reproduces_literal_vectors(v):
     h = cbl_amd.CBL(v["k"], v["prefix_bits"], canonical=v["canonical"])
     h.load(bytes.fromhex(v["index_hex"]))
     assert h.serialize().hex() == v["index_hex"]
+
+
+# ---- single-k-mer surface: insert return values, membership flags of a query sequence, iteration order ---------------------
+@pytest.mark.parametrize("v", GOLD["kmers"], ids=lambda v: v["name"])
+def test_oracle_reproduces_kmer_vectors(v):
+    from oracle import Oracle
+
+    o = Oracle(v["k"], v["prefix_bits"], v["canonical"])
+    o.insert_seq(v["sequence"].encode())
+    assert [o.insert_kmer(int(x, 16)) for x in v["kmers"]] == v["was_absent"]
+    assert o.serialize().hex() == v["index_hex"] and o.count() == v["count"]
+    assert [o.contains_word(w) for w in o.seq_words(v["query"].encode())] == v["query_flags"]
+    assert [hex(o.kmer_of_word(w)) for w in o.iter_words()] == v["iter"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("v", GOLD["kmers"], ids=lambda v: v["name"])
+def test_gpu_reproduces_kmer_vectors(v):
+    import cbl_amd
+
+    g = cbl_amd.CBL(v["k"], v["prefix_bits"], canonical=v["canonical"])
+    g.insert_seq(v["sequence"].encode())
+    assert g.insert_kmers([int(x, 16) for x in v["kmers"]]).tolist() == v["was_absent"]
+    assert g.serialize().hex() == v["index_hex"] and g.count() == v["count"]
+    assert g.contains_seq(v["query"].encode()) == v["query_flags"]
+    assert [hex(x) for x in g.iter()] == v["iter"]
+    assert g.contains_kmers([int(x, 16) for x in v["iter"]]).all()
+    # one k-mer at a time gives the same answers as the batch
+    h = cbl_amd.CBL(v["k"], v["prefix_bits"], canonical=v["canonical"])
+    h.insert_seq(v["sequence"].encode())
+    assert [h.insert(int(x, 16)) for x in v["kmers"][:25]] == v["was_absent"][:25]
