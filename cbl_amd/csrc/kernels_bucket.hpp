@@ -671,9 +671,12 @@ template <bool WS> __device__ __forceinline__ bool sfx_less(const Sfx<WS>& a, u3
 // PACKED (SUFFIX_BITS + 12 <= 64, narrow suffix): an element is ONE u64 = suffix << 12 | stream index, so every LDS
 // access, compare and move handles key and index together (the kernel is LDS-throughput-bound).
 static const u32 PK_BITS = 12;  // CAP <= 4096
+#ifndef CBLX_MSD_WAVES
+#define CBLX_MSD_WAVES 7  // waves per SIMD the register allocation aims at (LDS allows 7 workgroups of the 256-thread class; 76 -> 72 VGPRs: 7.28 -> 7.10 ms)
+#endif
 
 template <int THREADS, int CAP, bool PACKED, bool WS, typename HiT>
-__global__ __launch_bounds__(THREADS) void k_bucket_msd(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MSD_WAVES, 8))) void k_bucket_msd(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
                                                         u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
                                                         u32* __restrict__ out_count, u8* __restrict__ out_kind,
                                                         BDesc* __restrict__ retry, u32* __restrict__ retry_n) {
