@@ -184,7 +184,7 @@ void serialize_host(const Consts& P, const HostIndex& h, Sink& s) {
 }
 // ---- the same bytes, produced in HBM (kernels_serde.hpp): size pass -> exclusive scan -> emit pass ---------------
 struct DevBlob { Buf<u8> bytes; u64 n = 0; };
-// false: a bucket is longer than the device emitters handle (SER_CAP1024) -> the caller takes the host path
+// false: only when an entry would not fit the 32-bit size table (>= 4 GiB) -> the caller takes the all-host path
 template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blob) {
     constexpr bool WS = C::WS;
     const Resident& r = c->res;
@@ -197,7 +197,8 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
     u64 total = 0;
     Buf<u32> size, lists, list_n;
     Buf<u64> off;
-    std::vector<u32> ln(SER_NCLS, 0);
+    std::vector<u32> ln(SER_NCLS, 0), host_r;
+    std::vector<std::vector<u8>> host_bytes;
     const u64 *a_lo = r.a_lo.get(), *a_hi = WS ? r.a_hi.get() : (const u64*)nullptr;
     auto buckets = [&](auto em, u8* body) {
         constexpr bool EM = decltype(em)::value;
@@ -222,7 +223,61 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
                            P.SB, P.BYTES, size.get(), (const u64*)nullptr, (u8*)nullptr, lists.get(), list_n.get());
         CBLX_HIP(hipGetLastError());
         ln = d2h_vec<u32>(c, list_n.get(), SER_NCLS);
-        if (ln[SER_HOST]) return false;
+        if (ln[SER_HOST]) {
+            // Buckets longer than one workgroup's emitter takes (low-complexity k-mers, tiny PREFIX_BITS): their entries
+            // are emitted by host threads from a download of just those buckets and patched into the device-emitted
+            // body at their offsets; every other bucket stays on the device path.
+            host_r = d2h_vec<u32>(c, lists.get() + (size_t)SER_HOST * nb, ln[SER_HOST]);
+            const size_t nh = host_r.size();
+            host_bytes.assign(nh, std::vector<u8>());
+            std::vector<HostIndex> hb(nh);
+            const u64 lo_mask = P.SB >= 64 ? ~0ull : ((1ull << P.SB) - 1ull);
+            const u64 hi_mask = WS ? (P.SB >= 128 ? ~0ull : ((1ull << (P.SB - 64)) - 1ull)) : 0ull;
+            for (size_t i = 0; i < nh; ++i) {
+                const u32 rr = host_r[i];
+                HostIndex& h = hb[i];
+                h.prefix = {d2h<u32>(c, r.prefix.get() + rr)};
+                h.cnt = {d2h<u32>(c, r.cnt.get() + rr)};
+                h.kind = {d2h<u8>(c, r.kind.get() + rr)};
+                h.off = {0, h.cnt[0]};
+                const u64 st = d2h<u64>(c, r.start.get() + rr);
+                h.lo.resize(h.cnt[0]);
+                xfer(c).d2h_copy(h.lo.data(), a_lo + st, (size_t)h.cnt[0] * 8);
+                for (u64& x : h.lo) x &= lo_mask;
+                if (WS) {
+                    h.hi.resize(h.cnt[0]);
+                    xfer(c).d2h_copy(h.hi.data(), a_hi + st, (size_t)h.cnt[0] * 8);
+                    for (u64& x : h.hi) x &= hi_mask;
+                }
+            }
+            std::atomic<size_t> next{0};
+            std::atomic<bool> too_big{false};
+            auto work = [&]() {
+                for (size_t i; (i = next.fetch_add(1)) < nh;) {
+                    const HostIndex& h = hb[i];
+                    SfxView v{h.lo.data(), h.hi.empty() ? nullptr : h.hi.data()};
+                    Sink cnt_(nullptr, 0);
+                    serialize_bucket(P, h, v, 0, cnt_);
+                    if (cnt_.pos >= (1ull << 32)) { too_big = true; continue; }
+                    host_bytes[i].resize(cnt_.pos);
+                    Sink out(host_bytes[i].data(), cnt_.pos);
+                    serialize_bucket(P, h, v, 0, out);
+                }
+            };
+            {
+                unsigned nt = std::max(1u, std::min<unsigned>({std::thread::hardware_concurrency(), 16u, (unsigned)nh}));
+                std::vector<std::thread> th;
+                for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+                work();
+                for (auto& x : th) x.join();
+            }
+            if (too_big) return false;  // an entry of 4 GiB or more: the all-host emitter (64-bit sizes) takes the call
+            for (size_t i = 0; i < nh; ++i) {
+                const u32 sz = (u32)host_bytes[i].size();
+                CBLX_HIP(hipMemcpyAsync(size.get() + host_r[i], &sz, 4, hipMemcpyHostToDevice, c->stream));
+                CBLX_HIP(hipStreamSynchronize(c->stream));  // `sz` is a stack variable
+            }
+        }
         buckets(std::false_type(), nullptr);
         total = exclusive_scan<u64>(c, size.get(), nb, off.get());
     }
@@ -235,6 +290,11 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
         hipLaunchKernelGGL((k_serde_tiny<WS, true>), grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
                            P.SB, P.BYTES, size.get(), off.get(), body, (u32*)nullptr, (u32*)nullptr);
         buckets(std::true_type(), body);
+        for (size_t i = 0; i < host_r.size(); ++i) {
+            const u64 o = d2h<u64>(c, off.get() + host_r[i]);
+            xfer(c).h2d_copy(body + o, host_bytes[i].data(), host_bytes[i].size());
+        }
+        if (!host_r.empty()) xfer(c).sync();
     }
     CBLX_HIP(hipStreamSynchronize(c->stream));
     return true;

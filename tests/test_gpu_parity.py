@@ -951,3 +951,26 @@ def test_heavily_duplicated_runs_of_33_to_128_words(preload):
         s = (b"A" * (k2 + 70) + b"C") * 3
         g2.insert_seq(s), o2.insert_seq(s)
         assert g2.serialize() == o2.serialize() and g2.validate() == 0
+
+
+def test_serializer_patches_huge_buckets_into_the_device_body(monkeypatch):
+    """Low-complexity reads put > 8192 distinct words under one prefix (a 12-base poly-A run zeroes the whole 24-bit prefix):
+    the entries of such buckets are emitted on the host and patched into the body the kernels emit for everything else."""
+    _need_gpu()
+    k, pb = 31, 24
+    rng = random.Random(2024)
+    seqs = [_rand_seq(rng, 40) + b"A" * 14 + _rand_seq(rng, 60) for _ in range(3000)] + [_rand_seq(rng, 150) for _ in range(3000)]
+    bases, offsets = _concat(seqs)
+    g, o = cbl_amd.CBL(k, pb), Oracle(k, pb)
+    g.insert_seqs(bases, offsets)
+    o.insert_seqs(bases, offsets)
+    _, lens, kinds = g.bucket_table_np()
+    assert lens.max() > 8192 and (lens <= 8192).sum() > 1000 and kinds[lens.argmax()] == 1
+    blob = g.serialize()
+    assert blob == o.serialize() and g.serialized_size() == len(blob)
+    monkeypatch.setenv("CBLX_HOST_SERDE", "1")
+    assert g.serialize() == blob
+    monkeypatch.delenv("CBLX_HOST_SERDE")
+    h = cbl_amd.CBL(k, pb)
+    h.load(blob)
+    assert h.serialize() == blob and h.count() == o.count()
