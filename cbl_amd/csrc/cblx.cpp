@@ -491,6 +491,25 @@ int cblx_merge_assign(cblx_ctx* self, cblx_ctx* other) {
         flush(other);
         CBLX_HIP(hipSetDevice(self->device));
         if (other->res.count == 0) return;
+        if (self->res.count == 0 && self->device == other->device) {
+            // every bucket is other-only: cloned as stored, kind and order kept (src/trievec/set_ops.rs:43-71) = a deep copy
+            CBLX_HIP(hipStreamSynchronize(other->stream));
+            const Resident& o = other->res;
+            Resident nr;
+            nr.nb = o.nb;
+            nr.count = o.count;
+            auto dup = [&](auto& dst, const auto& src) {
+                typedef typename std::remove_reference<decltype(*src.get())>::type T;
+                if (!src.get()) return;
+                dst = Buf<T>(self->pool, src.n);
+                CBLX_HIP(hipMemcpyAsync(dst.get(), src.get(), src.n * sizeof(T), hipMemcpyDeviceToDevice, self->stream));
+            };
+            dup(nr.bv, o.bv); dup(nr.rank_dir, o.rank_dir); dup(nr.prefix, o.prefix); dup(nr.start, o.start);
+            dup(nr.cnt, o.cnt); dup(nr.kind, o.kind); dup(nr.a_lo, o.a_lo); dup(nr.a_hi, o.a_hi);
+            CBLX_HIP(hipStreamSynchronize(self->stream));
+            self->res = std::move(nr);
+            return;
+        }
         bool on_device = false;
         if (self->device == other->device && self->res.count != 0 && self->res.count + other->res.count < 0xFFFFFFF0ull) {
             CBLX_HIP(hipStreamSynchronize(other->stream));

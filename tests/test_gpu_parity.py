@@ -974,3 +974,22 @@ def test_serializer_patches_huge_buckets_into_the_device_body(monkeypatch):
     h = cbl_amd.CBL(k, pb)
     h.load(blob)
     assert h.serialize() == blob and h.count() == o.count()
+
+
+def test_merge_into_an_empty_index_is_a_clone():
+    """`empty |= other`: every bucket is other-only and is cloned as stored (/root/reference/src/wordset/set_ops.rs:123-157) —
+    a device-side deep copy; `other` keeps working and the copy is independent of it."""
+    _need_gpu()
+    rng = random.Random(8)
+    for k, pb, canonical in ((31, 24, False), (13, 6, True), (59, 28, False)):
+        s1, s2 = _rand_seq(rng, 30000), _rand_seq(rng, 4000)
+        g, o = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
+        g.insert_seq(s1), o.insert_seq(s1)
+        e, oe = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
+        e |= g
+        oe.merge(o)
+        assert e.serialize() == oe.serialize() == g.serialize() and e.validate(strict=False) == 0
+        e.insert_seq(s2), oe.insert_seq(s2)   # the clone is a full index of its own
+        assert e.serialize() == oe.serialize() and g.serialize() == o.serialize()
+        g.insert_seq(s2), o.insert_seq(s2)
+        assert g.serialize() == o.serialize() == e.serialize()
