@@ -174,7 +174,7 @@ def main():
         try:  # HBM bytes per launch from the committed PMC passes of this exact configuration (profiles/)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             c = tj["config"]
-            if (c["k"], c["prefix_bits"], c["reads_per_gpu"], c["read_len"]) == (K, PB, NR, L) and tj["kernel"] == kernel_of.get(dom) and world == 1:
+            if (c["k"], c["prefix_bits"], c["reads_per_gpu"], c["read_len"]) == (K, PB, NR, L) and tj["kernel"] == kernel_of.get(dom) and world == 1 and engine is None:
                 traffic = tj["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
