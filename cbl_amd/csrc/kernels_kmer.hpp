@@ -81,12 +81,21 @@ __global__ void k_count_zero_u8(const u8* __restrict__ v, u64 n, u32* __restrict
 //   a longer Trie (ascending): binary search per query, the probes of the run's queries share the cache;
 //   a longer Vec (only `|=` makes them): scanned per query.
 // per_run[b] = queries of run b found. No per-query flags: the partition does not keep the queries' positions. -------------------
+// hi64[i] = i << 32 | hi[i]: the ordinal of a query word rides through the partition in the unused upper half of a 64-bit
+// hi part (words of at most 96 bits), so the join can write per-query flags in query order
+template <typename HiT>
+__global__ void k_query_tag(u64 n, const HiT* __restrict__ hi, u64* __restrict__ hi64) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) hi64[i] = (i << 32) | ld_hi<HiT>(hi, i);
+}
+
 static const u32 JOIN_THREADS = 256, JOIN_FULL_MAX = 2730, JOIN_TAB_MAX = 4095, JOIN_SLOTS = 8192;
 template <bool WS, typename HiT>
 __global__ __launch_bounds__(JOIN_THREADS) void k_query_join(u64 nbq, u64 b0, const u32* __restrict__ q_prefix, const u64* __restrict__ q_start,
                                                              const u64* __restrict__ q_lo, const HiT* __restrict__ q_hi, u32 SB, DirView dir,
                                                              const u64* __restrict__ a_lo, const u64* __restrict__ a_hi,
-                                                             u32* __restrict__ per_run /* zero-filled, one per run */) {
+                                                             u32* __restrict__ per_run /* zero-filled, one per run */,
+                                                             u8* __restrict__ flags = nullptr /* zero-filled; ordinal = q_hi >> 32 */) {
     // 32 KB of LDS, one of two tables: FULL = 4096 slots holding the suffix itself (narrow suffixes, up to JOIN_FULL_MAX
     // elements: a probe never leaves LDS — a verifying read per hit cost 40 ps, 4x the rest of the join), or 8192 slots of
     // 20-bit tag << 12 | element index (0xFFFFFFFF = empty; index 4095 is never used), verified in the bucket on a tag match
@@ -134,11 +143,12 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_query_join(u64 nbq, u64 b0, co
     u32 found = 0;
     for (u64 q = qs + tid; q < qe; q += JOIN_THREADS) {
         const Sfx<WS> key = load_sfx<WS, HiT>(q_lo, q_hi, q, SB);
+        bool hit = false;
         if (full) {
             u32 h = sfx_hash_bits<WS>(key, 12);
             for (;;) {
                 const u64 e = s_full[h];
-                if (e == key.lo) { ++found; break; }
+                if (e == key.lo) { hit = true; break; }
                 if (e == ~0ull) break;
                 h = (h + 1u) & (JOIN_SLOTS / 2 - 1u);
             }
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_query_join(u64 nbq, u64 b0, co
             for (;;) {
                 const u32 e = s_tab[h];
                 if (e == 0xFFFFFFFFu) break;
-                if ((e >> 12) == tag && res_at(e & 0xFFFu) == key) { ++found; break; }
+                if ((e >> 12) == tag && res_at(e & 0xFFFu) == key) { hit = true; break; }
                 h = (h + 1u) & (JOIN_SLOTS - 1u);
             }
         } else if (trie) {  // ascending: binary search, the probes of the run's queries share the cache
@@ -158,11 +168,13 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_query_join(u64 nbq, u64 b0, co
                 const u32 mid = (l + h) >> 1;
                 if (less(res_at(mid), key)) l = mid + 1; else h = mid;
             }
-            found += (l < rc && res_at(l) == key) ? 1u : 0u;
+            hit = l < rc && res_at(l) == key;
         } else {  // a Vec this long only comes out of `|=`
-            bool hit = false;
             for (u32 j = 0; j < rc && !hit; ++j) hit = res_at(j) == key;
-            found += hit ? 1u : 0u;
+        }
+        found += hit ? 1u : 0u;
+        if constexpr (std::is_same<HiT, u64>::value && !WS) {  // per-query flags: the query's ordinal rides in the upper half of hi
+            if (flags && hit) flags[q_hi[q] >> 32] = 1;
         }
     }
     // one result per run (summed afterwards): 19 M wave-level atomics on ONE counter cost 47 ms at cfg 2

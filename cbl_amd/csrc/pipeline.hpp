@@ -490,39 +490,68 @@ u64 query_join_min() {  // read per call: tests switch it
     const char* e = std::getenv("CBLX_QUERY_JOIN_MIN");
     return e ? std::strtoull(e, nullptr, 10) : (u64)(4u << 20);
 }
-template <typename C> u64 query_join(cblx_ctx* c, const u8* d_bases /* as left by plan_chunks */, const ChunkPlan& pl) {
+template <typename C> u64 query_join(cblx_ctx* c, const u8* d_bases /* as left by plan_chunks */, const ChunkPlan& pl, u8* d_flags /* nk bytes or null */) {
     typedef typename C::HiT HiT;
+    const Consts& P = c->P;
     const u64 nk = pl.n_kmers;
+    if (d_flags && nk) CBLX_HIP(hipMemsetAsync(d_flags, 0, nk, c->stream));
     if (nk == 0 || c->res.count == 0) return 0;
-    Records rec;
-    begin_records<C>(c, rec, nk);
     Buf<u32> countsA;
     EncHist eh{};
     {   // as insert_device: KRN-1 accumulates the first partition pass's tile histogram
         const size_t ntmax = (size_t)ceil_div(nk, RDX_TILE) + 256;
         countsA = Buf<u32>(c->pool, 256 * ntmax);
         CBLX_HIP(hipMemsetAsync(countsA.get(), 0, 256 * ntmax * 4, c->stream));
-        const u32 nA = std::min(8u, c->P.PB);
+        const u32 nA = std::min(8u, P.PB);
         eh.counts = countsA.get();
-        eh.shift = c->P.SB + (c->P.PB - nA);
+        eh.shift = P.SB + (P.PB - nA);
         eh.nbits = nA;
     }
-    encode<C>(c, d_bases, pl, rec.lo.get(), (HiT*)rec.hi.get(), 0, eh);
+    Records rec;
     Resident qd;  // directory of the query batch: prefixes and run starts
-    partition_and_directory<C>(c, rec, nk, std::move(countsA), qd);
     Buf<u64> pos(c->pool, 1);
-    Buf<u32> per_run(c->pool, qd.nb + 1);
     CBLX_HIP(hipMemsetAsync(pos.get(), 0, 8, c->stream));
-    CBLX_HIP(hipMemsetAsync(per_run.get(), 0, (qd.nb + 1) * 4, c->stream));
     const u64 step = 1ull << 23;  // workgroups per launch (x 256 threads < 2^32 work items)
-    for (u64 b0 = 0; b0 < qd.nb; b0 += step)
-        hipLaunchKernelGGL((k_query_join<C::WS, HiT>), dim3((unsigned)std::min(step, qd.nb - b0)), dim3(JOIN_THREADS), 0, c->stream, qd.nb, b0, qd.prefix.get(),
-                           qd.start.get(), rec.lo.get(), (const HiT*)rec.hi.get(), c->P.SB, c->res.view(), c->res.a_lo.get(),
-                           c->P.wide_suffix() ? c->res.a_hi.get() : (const u64*)nullptr, per_run.get());
-    hipLaunchKernelGGL(k_sum_u32, dim3((unsigned)std::min<u64>(2048, std::max<u64>(1, ceil_div(qd.nb, 256)))), dim3(256), 0, c->stream, per_run.get(), qd.nb, pos.get());
-    CBLX_HIP(hipGetLastError());
+    auto join = [&](auto hi_tag, u8* flags) {
+        typedef decltype(hi_tag) H;
+        Buf<u32> per_run(c->pool, qd.nb + 1);
+        CBLX_HIP(hipMemsetAsync(per_run.get(), 0, (qd.nb + 1) * 4, c->stream));
+        for (u64 b0 = 0; b0 < qd.nb; b0 += step)
+            hipLaunchKernelGGL((k_query_join<C::WS, H>), dim3((unsigned)std::min(step, qd.nb - b0)), dim3(JOIN_THREADS), 0, c->stream, qd.nb, b0, qd.prefix.get(),
+                               qd.start.get(), rec.lo.get(), (const H*)rec.hi.get(), P.SB, c->res.view(), c->res.a_lo.get(),
+                               P.wide_suffix() ? c->res.a_hi.get() : (const u64*)nullptr, per_run.get(), flags);
+        hipLaunchKernelGGL(k_sum_u32, dim3((unsigned)std::min<u64>(2048, std::max<u64>(1, ceil_div(qd.nb, 256)))), dim3(256), 0, c->stream, per_run.get(), qd.nb, pos.get());
+        CBLX_HIP(hipGetLastError());
+        CBLX_HIP(hipStreamSynchronize(c->stream));  // per_run dies here
+    };
+    if constexpr (!C::WS) {
+        if (d_flags) {
+            // per-query flags: 16-byte records (lo, ordinal << 32 | hi bits) through the partition of the 64-bit-hi layout
+            typedef Cfg<C::WIDE, u64, false> QC;
+            rec.lo = Buf<u64>(c->pool, nk + 2);
+            rec.lo2 = Buf<u64>(c->pool, nk + 2);
+            rec.hi = Buf<u8>(c->pool, (nk + 2) * 8);
+            rec.hi2 = Buf<u8>(c->pool, (nk + 2) * 8);
+            {
+                Buf<u8> hi_tmp(c->pool, (nk + 2) * std::max<size_t>(1, hi_elem_size(P)));
+                encode<C>(c, d_bases, pl, rec.lo.get(), (HiT*)hi_tmp.get(), 0, eh);
+                hipLaunchKernelGGL(k_query_tag<HiT>, grid1(nk, 256), dim3(256), 0, c->stream, nk, (const HiT*)hi_tmp.get(), (u64*)rec.hi.get());
+                CBLX_HIP(hipGetLastError());
+                CBLX_HIP(hipStreamSynchronize(c->stream));  // hi_tmp dies here
+            }
+            partition_and_directory<QC>(c, rec, nk, std::move(countsA), qd);
+            join(u64(), d_flags);
+            return d2h<u64>(c, pos.get());
+        }
+    }
+    begin_records<C>(c, rec, nk);
+    encode<C>(c, d_bases, pl, rec.lo.get(), (HiT*)rec.hi.get(), 0, eh);
+    partition_and_directory<C>(c, rec, nk, std::move(countsA), qd);
+    join(HiT(), (u8*)nullptr);
     return d2h<u64>(c, pos.get());  // also: the temporaries may go back to the pool
 }
+// words whose hi part leaves 32 bits for the query's ordinal, and whose suffix fits 64 bits: flags can come from the join
+inline bool query_flags_by_join(const Consts& P) { return !P.wide_suffix() && P.WB <= 96; }
 // CBL::contains_seq over a batch of device-resident sequences: KRN-1, then one membership flag per k-mer (sequence after
 // sequence, each in get_seq_words order) into d_out[cap] when given; *total / *positive count the flags.
 void query_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq, u8* d_out, u64 cap, u64* total, u64* positive) {
@@ -539,8 +568,9 @@ void query_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq
         if (total) *total = nk;
         if (nk == 0) return;
         if (nk >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "too many k-mers in one query batch");
-        if (!d_out && nk >= query_join_min()) {  // tallies only, big batch: join instead of one bucket read per query
-            const u64 p = query_join<C>(c, d_bases, pl);
+        if (nk >= query_join_min() && (!d_out || query_flags_by_join(c->P))) {  // big batch: join instead of one bucket read per query
+            if (d_out && nk > cap) throw Error(CBLX_ERANGE, "output capacity too small: " + std::to_string(nk) + " k-mers");
+            const u64 p = query_join<C>(c, d_bases, pl, d_out);
             if (positive) *positive = p;
             return;
         }

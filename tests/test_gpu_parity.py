@@ -408,6 +408,9 @@ def test_full_size_properties(k, pb, nreads, L):
     assert not any(g.contains_seq(fb[:L].tobytes()))
     # the batched query at full size: every k-mer of the indexed reads is found, none of an unrelated read set
     assert g.contains_seqs_device(d_b, d_o, nreads) == (n_kmers, n_kmers)
+    d_f = torch.zeros(n_kmers + 8, dtype=torch.uint8, device="cuda")
+    assert g.contains_seqs_device(d_b, d_o, nreads, d_f, n_kmers) == (n_kmers, n_kmers) and int(d_f.sum(dtype=torch.int64)) == n_kmers
+    del d_f
     f_b, f_o = synth.reads_torch(4242, nreads // 10, L, device="cuda")
     assert g.contains_seqs_device(f_b, f_o, nreads // 10) == (nreads // 10 * (L - k + 1), 0)
     del f_b, f_o
@@ -909,6 +912,9 @@ def test_batched_query_matches_oracle(k, pb, canonical, tmp_path, monkeypatch):
     monkeypatch.setenv("CBLX_QUERY_JOIN_MIN", "1")
     assert g.contains_seqs(bases, offsets, flags=False)[1:] == (tot, pos)
     assert g.contains_seqs_device(d_b, d_o, len(queries)) == (tot, pos)
+    jf, jt, jp = g.contains_seqs(bases, offsets)  # per-k-mer flags by join where the word leaves room for the ordinal
+    assert (jf.tolist(), jt, jp) == (want, tot, pos)
+    assert g.contains_seq(queries[0]) == want[: len(o.seq_words(queries[0]))]
     e = cbl_amd.CBL(k, pb, canonical=canonical)
     assert e.contains_seqs(bases, offsets, flags=False)[1:] == (tot, 0)  # empty index
     # the file loop; the index is untouched and pending inserts are applied first

@@ -138,7 +138,12 @@ def main():
     dt = timed(lambda: g.contains_seqs_device(m_bases, m_offsets, NR), reps=2)
     tot, pos = g.contains_seqs_device(m_bases, m_offsets, NR)
     out["query_batched_misses"] = {"ms": dt * 1e3, "kmers": tot, "positive": pos, "kmers_per_s": tot / dt}
-    del m_bases, m_offsets
+    d_flags = torch.zeros(NR * per_read + 8, dtype=torch.uint8, device=dev)
+    dt = timed(lambda: g.contains_seqs_device(d_bases, d_offsets, NR, d_flags, NR * per_read), reps=2)
+    out["query_batched_hits_with_flags"] = {"ms": dt * 1e3, "kmers_per_s": NR * per_read / dt, "flags_set": int(d_flags.sum(dtype=torch.int64))}
+    dt = timed(lambda: g.contains_seqs_device(m_bases, m_offsets, NR, d_flags, NR * per_read), reps=2)
+    out["query_batched_misses_with_flags"] = {"ms": dt * 1e3, "kmers_per_s": NR * per_read / dt, "flags_set": int(d_flags.sum(dtype=torch.int64))}
+    del m_bases, m_offsets, d_flags
     g.clear()
     del h_bases, h_offsets
 

@@ -19,3 +19,11 @@ for name, (b, o) in (("hits", (d_b, d_o)), ("misses", (m_b, m_o)), ("hits", (d_b
     dt = time.perf_counter() - t0
     st = {k: round(v[0], 2) for k, v in g.stage_times().items() if v[0] > 0}
     print(name, r, f"{dt * 1e3:.1f} ms", st, "unaccounted (join + host): %.1f ms" % (dt * 1e3 - sum(st.values())))
+
+d_f = torch.zeros(NR * (L - K + 1) + 8, dtype=torch.uint8, device="cuda:0")
+for name, (b, o) in (("hits+flags", (d_b, d_o)), ("misses+flags", (m_b, m_o)), ("hits+flags", (d_b, d_o))):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = g.contains_seqs_device(b, o, NR, d_f, NR * (L - K + 1))
+    torch.cuda.synchronize()
+    print(name, r, f"{(time.perf_counter() - t0) * 1e3:.1f} ms", "flags set:", int(d_f.sum(dtype=torch.int64)))
