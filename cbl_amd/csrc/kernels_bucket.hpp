@@ -839,13 +839,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     const u32 d = s_wtot[NW];
     const bool trie = d > VEC_THRESHOLD || res_trie;
     if (!trie) {
-        // Vec: first occurrences in stream order, straight from registers (slots are in stream order)
+        // Vec: first occurrences in stream order, straight from registers (slots are in stream order). Without a
+        // duplicate (d == c) every element already sits in its slot and nothing is written.
         u32 run = s_wtot[w];
+        if (d != c) {
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const u64 bal = __ballot(head[j]);
-            if (head[j]) store_sfx<WS, HiT>(lo, hi, s0 + run + mbcnt(bal), key[j]);
-            run += (u32)__builtin_popcountll(bal);
+            for (int j = 0; j < ITEMS; ++j) {
+                const u64 bal = __ballot(head[j]);
+                if (head[j]) store_sfx<WS, HiT>(lo, hi, s0 + run + mbcnt(bal), key[j]);
+                run += (u32)__builtin_popcountll(bal);
+            }
         }
     } else {
         // Trie: ascending order. Put every element at its final rank with its head flag, then compact slot by slot.
