@@ -423,9 +423,21 @@ int cblx_save_to_file(cblx_ctx* c, const char* path) {
         flush(c);
         DevBlob blob;
         if (serialize_device(c, true, blob)) {  // the lanes write their chunks straight from pinned memory
-            const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            const int fd = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
             if (fd < 0) throw Error(CBLX_EINVAL, std::string("Failed to create ") + path);
             std::atomic<bool> bad{false};
+            // The lanes fill a shared mapping of the file when the file system gives one: concurrent pwrite()s to ONE file
+            // serialise on its inode lock (3 GB/s on tmpfs with eight lanes), page faults of a mapping do not.
+            void* map = MAP_FAILED;
+            if (blob.n >= (64u << 20) && ::ftruncate(fd, (off_t)blob.n) == 0) map = ::mmap(nullptr, blob.n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (map != MAP_FAILED) {
+                try {
+                    xfer(c).d2h(blob.bytes.get(), blob.n, [&](const u8* src, size_t off, size_t n) { std::memcpy((u8*)map + off, src, n); });
+                } catch (...) { ::munmap(map, blob.n); ::close(fd); throw; }
+                const bool ok = ::munmap(map, blob.n) == 0;
+                if (::close(fd) != 0 || !ok) throw Error(CBLX_EINVAL, std::string("Failed to write index to ") + path);
+                return;
+            }
             try {
                 xfer(c).d2h(blob.bytes.get(), blob.n, [&](const u8* src, size_t off, size_t n) {
                     while (n) {

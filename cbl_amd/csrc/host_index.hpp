@@ -6,6 +6,7 @@
 #include <sys/stat.h>
 
 #include <fstream>
+#include <mutex>
 
 #include "ingest.hpp"
 #include "kernels_serde.hpp"
@@ -371,10 +372,12 @@ void parse_index(const Consts& P, const u8* data, u64 len, HostIndex& h, bool& c
 }
 
 // ---- index bytes -> resident index, streamed (cblx_load): one pass over the bytes, elements go to HBM as they are
-// decoded. The format is a sequential pre-order walk (no lengths to skip by), so the walk itself stays on one host
-// thread; everything around it (pinned double buffering, DMA, directory upload) overlaps with it.
+// decoded. The format is a sequential pre-order walk (no lengths to skip by): small files are walked by one host thread
+// with everything around it (pinned double buffering, DMA, directory upload) overlapped; big files are cut speculatively
+// at recognised entry starts and walked by several (load_parallel).
 struct StreamUp {  // single producer -> device array of u64
     static constexpr size_t CAP = 1u << 20;  // elements per pinned block
+    static std::mutex& pool_mu() { static std::mutex m; return m; }
     cblx_ctx* c;
     hipStream_t s = nullptr;
     u64* blk[2] = {nullptr, nullptr};
@@ -403,6 +406,7 @@ struct StreamUp {  // single producer -> device array of u64
     void issue() {
         if (fill == 0) return;
         if (dev.n < issued + fill + 2) {
+            std::lock_guard<std::mutex> lk(pool_mu());  // the pool is single-threaded; the parallel loader grows buffers from its threads
             Buf<u64> nd(c->pool, std::max<u64>(2 * (u64)dev.n, issued + fill + 2));
             CBLX_HIP(hipStreamSynchronize(s));
             if (issued) CBLX_HIP(hipMemcpyAsync(nd.get(), dev.get(), issued * 8, hipMemcpyDeviceToDevice, s));
@@ -455,107 +459,252 @@ void install_index(cblx_ctx* c, const std::vector<u32>& prefix, const std::vecto
     c->res = std::move(nr);
 }
 
+// One `prefix, TrieOrVec` entry -> its elements through `out` (room(k) / commit(k) for the
+// lo and hi arrays). STRICT adds the checks the speculative splitter needs to tell an entry from bytes that merely look
+// like one (ascending node values, element length bytes, non-empty nodes).
+struct NullOut {  // validation only
+    std::vector<u64> scratch = std::vector<u64>(StreamUp::CAP);
+    u64* room_lo(size_t) { return scratch.data(); }
+    u64* room_hi(size_t) { return scratch.data(); }
+    void commit_lo(size_t) {}
+    void commit_hi(size_t) {}
+};
+struct StreamOut {
+    StreamUp* lo;
+    StreamUp* hi;
+    u64* room_lo(size_t k) { return lo->room(k); }
+    u64* room_hi(size_t k) { return hi->room(k); }
+    void commit_lo(size_t k) { lo->commit(k); }
+    void commit_hi(size_t k) { hi->commit(k); }
+};
+template <bool WS, bool STRICT, typename Out>
+void parse_entry(Src& s, const Consts& P, u64 nprefix, Out& out, u32& prefix_out, u32& cnt_out, u8& kind_out) {
+    const u32 BYTES = P.BYTES;
+    const u64 lo_mask = BYTES >= 8 ? ~0ull : ((1ull << (8 * BYTES)) - 1ull);
+    const u64 hi_mask = WS ? ((BYTES >= 16) ? ~0ull : ((1ull << (8 * (BYTES - 8))) - 1ull)) : 0ull;
+    const u64 p = s.varint();
+    if (p >= nprefix) throw Error(CBLX_EFORMAT, "prefix out of range for PREFIX_BITS");
+    prefix_out = (u32)p;
+    const u64 tag = s.varint();
+    u64 n = 0;
+    if (tag == 0) {  // Vec: varint(n) then n x (varint(BYTES) | BYTES little-endian bytes), stored order
+        n = s.varint();
+        if (n > 0xFFFFFFF0ull) throw Error(CBLX_EFORMAT, "index: bucket too long");
+        if (STRICT && (n == 0 || n > (u64)(s.end - s.p) / (1 + BYTES))) throw Error(CBLX_EFORMAT, "index: implausible Vec length");
+        u64 left = n;
+        while (left) {
+            const size_t k = (size_t)std::min<u64>(left, StreamUp::CAP);
+            u64* ol = out.room_lo(k);
+            u64* oh = WS ? out.room_hi(k) : nullptr;
+            // fast path: every element has the expected length byte and 16 readable bytes follow the chunk
+            if ((u64)(s.end - s.p) >= (u64)k * (1 + BYTES) + 16) {
+                const u8* q = s.p;
+                bool regular = true;
+                for (size_t i = 0; i < k; ++i, q += 1 + BYTES) {
+                    regular &= q[0] == BYTES;
+                    ol[i] = load_le64(q + 1) & lo_mask;
+                    if (WS) oh[i] = load_le64(q + 9) & hi_mask;
+                }
+                if (regular) { s.p = q; out.commit_lo(k); if (WS) out.commit_hi(k); left -= k; continue; }
+                if (STRICT) throw Error(CBLX_EFORMAT, "index: element length byte");
+            }
+            for (size_t i = 0; i < k; ++i) {  // general path (length byte != BYTES, or the tail of the input)
+                const u64 nbts = s.varint();
+                if (STRICT && nbts != BYTES) throw Error(CBLX_EFORMAT, "index: element length byte");
+                u128 x = 0;
+                for (u64 b = 0; b < nbts; ++b) { const u8 v = s.u8_(); if (b < BYTES) x |= (u128)v << (8 * b); }
+                ol[i] = (u64)x;
+                if (WS) oh[i] = (u64)(x >> 64);
+            }
+            out.commit_lo(k);
+            if (WS) out.commit_hi(k);
+            left -= k;
+        }
+        kind_out = KIND_VEC;
+    } else if (tag == 1) {  // Trie: pre-order nodes (explicit stack), then varint(len)
+        struct Fr { const u8* vals; u32 c, i; };
+        Fr st[16];
+        u32 d = 0;
+        u64 alo = 0, ahi = 0;
+        auto set_byte = [&](u32 depth, u8 b) {
+            u32 sh = 8 * (BYTES - 1 - depth);
+            if (sh < 64) alo = (alo & ~(0xFFull << sh)) | ((u64)b << sh);
+            else { sh -= 64; ahi = (ahi & ~(0xFFull << sh)) | ((u64)b << sh); }
+        };
+        for (;;) {
+            const u64 cc = s.varint();
+            if (cc > 256) throw Error(CBLX_EFORMAT, "index: trie node with more than 256 entries");
+            if ((u64)(s.end - s.p) < cc) throw Error(CBLX_EFORMAT, "index: unexpected end of data");
+            const u8* vals = s.p;
+            s.p += cc;
+            if (STRICT) {
+                if (cc == 0) throw Error(CBLX_EFORMAT, "index: empty trie node");
+                for (u64 i = 1; i < cc; ++i) if (vals[i] <= vals[i - 1]) throw Error(CBLX_EFORMAT, "index: trie node values not ascending");
+            }
+            const u64 nc = s.varint();
+            bool descend = false;
+            if (d + 1 == BYTES) {
+                if (nc != 0) throw Error(CBLX_EFORMAT, "index: leaf trie node with children");
+                u64* ol = out.room_lo((size_t)cc);
+                for (u64 i = 0; i < cc; ++i) ol[i] = alo | vals[i];
+                out.commit_lo((size_t)cc);
+                if (WS) { u64* oh = out.room_hi((size_t)cc); for (u64 i = 0; i < cc; ++i) oh[i] = ahi; out.commit_hi((size_t)cc); }
+                n += cc;
+            } else {
+                if (nc != cc) throw Error(CBLX_EFORMAT, "index: trie node children count mismatch");
+                if (cc) { st[d] = Fr{vals, (u32)cc, 0}; set_byte(d, vals[0]); ++d; descend = true; }
+            }
+            if (descend) continue;
+            bool done = false;
+            for (;;) {  // back up to the next sibling
+                if (d == 0) { done = true; break; }
+                Fr& f = st[d - 1];
+                if (++f.i < f.c) { set_byte(d - 1, f.vals[f.i]); break; }
+                --d;
+            }
+            if (done) break;
+        }
+        const u64 nlen = s.varint();
+        if (nlen != n) throw Error(CBLX_EFORMAT, "index: trie length field does not match its contents");
+        if (n > 0xFFFFFFF0ull) throw Error(CBLX_EFORMAT, "index: bucket too long");
+        kind_out = KIND_TRIE;
+    } else {
+        throw Error(CBLX_EFORMAT, "index: bad TrieOrVec tag");
+    }
+    cnt_out = (u32)n;
+}
+
+// Speculative split for big files: the format has nothing to skip by, but an entry start can be RECOGNISED — from a byte
+// offset, scan forward for a position from which a few consecutive entries parse under the strict checks with ascending
+// prefixes. Every region [start_t, start_t+1) is then parsed by its own thread into its own pinned blocks / stream /
+// device buffer. A wrong guess cannot survive: thread t must stop EXACTLY at start_t+1, the entries must add up to the
+// header's count and the prefixes must ascend across regions — anything else sends the whole file down the sequential
+// path (which also owns the error messages).
+template <bool WS> const u8* find_entry_start(const u8* from, const u8* end, const Consts& P, u64 nprefix, NullOut& dry) {
+    const u8* stop = std::min(end, from + (32u << 20));
+    for (const u8* p = from; p < stop; ++p) {
+        if (*p > 250 && *p != 0xFB && *p != 0xFC) continue;  // a prefix is a varint of at most 32 bits
+        try {
+            Src s{p, end};
+            u32 last = 0, pf, cn;
+            u8 kd;
+            int e = 0;
+            for (; e < 4 && s.p < end; ++e) {
+                parse_entry<WS, true>(s, P, nprefix, dry, pf, cn, kd);
+                if (e && pf <= last) throw Error(CBLX_EFORMAT, "prefix order");
+                last = pf;
+            }
+            if (e >= 2 || s.p == end) return p;
+        } catch (const Error&) {
+        }
+    }
+    return nullptr;
+}
+template <bool WS> bool load_parallel(cblx_ctx* c, const Consts& P, const u8* body, const u8* end, u64 nb, u64 nprefix) {
+    const u64 len = (u64)(end - body);
+    unsigned hc = std::thread::hardware_concurrency();
+    unsigned T = (unsigned)std::min<u64>({16ull, hc ? hc / 2 : 1ull, len / (48ull << 20)});
+    if (const char* e = std::getenv("CBLX_LOAD_THREADS")) T = (unsigned)std::strtoul(e, nullptr, 10);
+    if (T < 2 || nb < 8 * (u64)T) return false;
+    std::vector<const u8*> start(T + 1, nullptr);
+    start[0] = body;
+    start[T] = end;
+    {   // entry starts near the even cuts, found in parallel
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; ++t)
+            th.emplace_back([&, t] { NullOut dry; start[t] = find_entry_start<WS>(body + len / T * t, end, P, nprefix, dry); });
+        for (auto& x : th) x.join();
+        for (unsigned t = 1; t < T; ++t) if (!start[t] || start[t] <= start[t - 1]) return false;
+    }
+    struct Part {
+        std::vector<u32> prefix, cnt;
+        std::vector<u8> kind;
+        std::unique_ptr<StreamUp> lo, hi;
+        Buf<u64> d_lo, d_hi;
+        u64 total = 0;
+        bool ok = false;
+    };
+    std::vector<Part> part(T);
+    for (unsigned t = 0; t < T; ++t) {  // streams, pinned blocks and first device buffers from the calling thread
+        const u64 guess = (u64)(start[t + 1] - start[t]) / 6 + 1024;
+        part[t].lo.reset(new StreamUp(c, guess));
+        if (WS) part[t].hi.reset(new StreamUp(c, guess));
+    }
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; ++t)
+            th.emplace_back([&, t] {
+                try {
+                    CBLX_HIP(hipSetDevice(c->device));
+                    Part& pt = part[t];
+                    StreamOut out{pt.lo.get(), pt.hi.get()};
+                    Src s{start[t], end};
+                    u32 pf, cn;
+                    u8 kd;
+                    while (s.p < start[t + 1]) {
+                        parse_entry<WS, false>(s, P, nprefix, out, pf, cn, kd);
+                        pt.prefix.push_back(pf); pt.cnt.push_back(cn); pt.kind.push_back(kd);
+                        pt.total += cn;
+                    }
+                    if (s.p != start[t + 1]) return;  // walked over the next region's guessed start: the guess was wrong
+                    pt.d_lo = pt.lo->finish();
+                    if (WS) pt.d_hi = pt.hi->finish();
+                    pt.ok = true;
+                } catch (...) {
+                }
+            });
+        for (auto& x : th) x.join();
+    }
+    u64 total = 0, entries = 0;
+    for (unsigned t = 0; t < T; ++t) {
+        if (!part[t].ok) return false;
+        if (t && !part[t].prefix.empty() && !part[t - 1].prefix.empty() && part[t].prefix.front() <= part[t - 1].prefix.back()) return false;
+        total += part[t].total;
+        entries += part[t].prefix.size();
+    }
+    if (entries != nb) return false;
+    if (total >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "index: more than 2^32 - 16 words (per-GPU limit of this build)");
+    std::vector<u32> prefix, cnt;
+    std::vector<u8> kind;
+    prefix.reserve(nb); cnt.reserve(nb); kind.reserve(nb);
+    Buf<u64> a_lo(c->pool, total + 2), a_hi;
+    if (WS) a_hi = Buf<u64>(c->pool, total + 2);
+    u64 at = 0;
+    for (unsigned t = 0; t < T; ++t) {
+        Part& pt = part[t];
+        prefix.insert(prefix.end(), pt.prefix.begin(), pt.prefix.end());
+        cnt.insert(cnt.end(), pt.cnt.begin(), pt.cnt.end());
+        kind.insert(kind.end(), pt.kind.begin(), pt.kind.end());
+        if (pt.total) {
+            CBLX_HIP(hipMemcpyAsync(a_lo.get() + at, pt.d_lo.get(), pt.total * 8, hipMemcpyDeviceToDevice, c->stream));
+            if (WS) CBLX_HIP(hipMemcpyAsync(a_hi.get() + at, pt.d_hi.get(), pt.total * 8, hipMemcpyDeviceToDevice, c->stream));
+        }
+        at += pt.total;
+    }
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    part.clear();
+    install_index(c, prefix, cnt, kind, std::move(a_lo), std::move(a_hi));
+    return true;
+}
+
 template <bool WS> void load_stream(cblx_ctx* c, const u8* data, u64 len, bool& canonical) {
     const Consts& P = c->P;
-    const u32 BYTES = P.BYTES;
     Src s{data, data + len};
     canonical = s.u8_() != 0;
     const u64 nb = s.varint();
     const u64 nprefix = 1ull << P.PB;
     if (nb > nprefix) throw Error(CBLX_EFORMAT, "index: more buckets than prefixes (wrong PREFIX_BITS?)");
+    if (load_parallel<WS>(c, P, s.p, s.end, nb, nprefix)) return;
     std::vector<u32> prefix(nb), cnt(nb);
     std::vector<u8> kind(nb);
     StreamUp lo(c, len / 6 + 1024);
     std::unique_ptr<StreamUp> hi;
     if (WS) hi.reset(new StreamUp(c, len / 6 + 1024));
-    const u64 lo_mask = BYTES >= 8 ? ~0ull : ((1ull << (8 * BYTES)) - 1ull);
-    const u64 hi_mask = WS ? ((BYTES >= 16) ? ~0ull : ((1ull << (8 * (BYTES - 8))) - 1ull)) : 0ull;
+    StreamOut out{&lo, hi.get()};
     u64 total = 0;
     for (u64 r = 0; r < nb; ++r) {
-        const u64 p = s.varint();
-        if (p >= nprefix) throw Error(CBLX_EFORMAT, "prefix out of range for PREFIX_BITS");
-        prefix[r] = (u32)p;
-        const u64 tag = s.varint();
-        u64 n = 0;
-        if (tag == 0) {  // Vec: varint(n) then n x (varint(BYTES) | BYTES little-endian bytes), stored order
-            n = s.varint();
-            if (n > 0xFFFFFFF0ull) throw Error(CBLX_EFORMAT, "index: bucket too long");
-            u64 left = n;
-            while (left) {
-                const size_t k = (size_t)std::min<u64>(left, StreamUp::CAP);
-                u64* ol = lo.room(k);
-                u64* oh = WS ? hi->room(k) : nullptr;
-                // fast path: every element has the expected length byte and 16 readable bytes follow the chunk
-                if ((u64)(s.end - s.p) >= (u64)k * (1 + BYTES) + 16) {
-                    const u8* q = s.p;
-                    bool regular = true;
-                    for (size_t i = 0; i < k; ++i, q += 1 + BYTES) {
-                        regular &= q[0] == BYTES;
-                        ol[i] = load_le64(q + 1) & lo_mask;
-                        if (WS) oh[i] = load_le64(q + 9) & hi_mask;
-                    }
-                    if (regular) { s.p = q; lo.commit(k); if (WS) hi->commit(k); left -= k; continue; }
-                }
-                for (size_t i = 0; i < k; ++i) {  // general path (length byte != BYTES, or the tail of the input)
-                    const u64 nbts = s.varint();
-                    u128 x = 0;
-                    for (u64 b = 0; b < nbts; ++b) { const u8 v = s.u8_(); if (b < BYTES) x |= (u128)v << (8 * b); }
-                    ol[i] = (u64)x;
-                    if (WS) oh[i] = (u64)(x >> 64);
-                }
-                lo.commit(k);
-                if (WS) hi->commit(k);
-                left -= k;
-            }
-            kind[r] = KIND_VEC;
-        } else if (tag == 1) {  // Trie: pre-order nodes (explicit stack), then varint(len)
-            struct Fr { const u8* vals; u32 c, i; };
-            Fr st[16];
-            u32 d = 0;
-            u64 alo = 0, ahi = 0;
-            auto set_byte = [&](u32 depth, u8 b) {
-                u32 sh = 8 * (BYTES - 1 - depth);
-                if (sh < 64) alo = (alo & ~(0xFFull << sh)) | ((u64)b << sh);
-                else { sh -= 64; ahi = (ahi & ~(0xFFull << sh)) | ((u64)b << sh); }
-            };
-            for (;;) {
-                const u64 cc = s.varint();
-                if (cc > 256) throw Error(CBLX_EFORMAT, "index: trie node with more than 256 entries");
-                if ((u64)(s.end - s.p) < cc) throw Error(CBLX_EFORMAT, "index: unexpected end of data");
-                const u8* vals = s.p;
-                s.p += cc;
-                const u64 nc = s.varint();
-                bool descend = false;
-                if (d + 1 == BYTES) {
-                    if (nc != 0) throw Error(CBLX_EFORMAT, "index: leaf trie node with children");
-                    u64* ol = lo.room((size_t)cc);
-                    for (u64 i = 0; i < cc; ++i) ol[i] = alo | vals[i];
-                    lo.commit((size_t)cc);
-                    if (WS) { u64* oh = hi->room((size_t)cc); for (u64 i = 0; i < cc; ++i) oh[i] = ahi; hi->commit((size_t)cc); }
-                    n += cc;
-                } else {
-                    if (nc != cc) throw Error(CBLX_EFORMAT, "index: trie node children count mismatch");
-                    if (cc) { st[d] = Fr{vals, (u32)cc, 0}; set_byte(d, vals[0]); ++d; descend = true; }
-                }
-                if (descend) continue;
-                bool done = false;
-                for (;;) {  // back up to the next sibling
-                    if (d == 0) { done = true; break; }
-                    Fr& f = st[d - 1];
-                    if (++f.i < f.c) { set_byte(d - 1, f.vals[f.i]); break; }
-                    --d;
-                }
-                if (done) break;
-            }
-            const u64 nlen = s.varint();
-            if (nlen != n) throw Error(CBLX_EFORMAT, "index: trie length field does not match its contents");
-            if (n > 0xFFFFFFF0ull) throw Error(CBLX_EFORMAT, "index: bucket too long");
-            kind[r] = KIND_TRIE;
-        } else {
-            throw Error(CBLX_EFORMAT, "index: bad TrieOrVec tag");
-        }
-        cnt[r] = (u32)n;
-        total += n;
+        parse_entry<WS, false>(s, P, nprefix, out, prefix[r], cnt[r], kind[r]);
+        total += cnt[r];
     }
     if (s.p != s.end) throw Error(CBLX_EFORMAT, "index: trailing bytes");  // reject_trailing_bytes
     if (total >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "index: more than 2^32 - 16 words (per-GPU limit of this build)");

@@ -999,3 +999,28 @@ def test_merge_into_an_empty_index_is_a_clone():
         assert e.serialize() == oe.serialize() and g.serialize() == o.serialize()
         g.insert_seq(s2), o.insert_seq(s2)
         assert g.serialize() == o.serialize() == e.serialize()
+
+
+@pytest.mark.parametrize("k,pb,canonical,threads", [(31, 24, False, 4), (31, 10, False, 3), (59, 28, True, 5), (15, 6, False, 2), (25, 24, False, 16)])
+def test_parallel_index_loader(k, pb, canonical, threads, monkeypatch):
+    """Big index files are cut speculatively at recognised entry starts and parsed by several threads (forced here on a
+    small file); the result is the sequential loader's, and malformed input still fails like it."""
+    _need_gpu()
+    bases, offsets = synth.reads(5, 6000, 150)
+    g = cbl_amd.CBL(k, pb, canonical=canonical)
+    g.insert_seqs(bases, offsets)
+    blob = g.serialize()
+    monkeypatch.setenv("CBLX_LOAD_THREADS", "1")
+    a = cbl_amd.CBL(k, pb)
+    a.load(blob)
+    monkeypatch.setenv("CBLX_LOAD_THREADS", str(threads))
+    b = cbl_amd.CBL(k, pb)
+    b.load(blob)
+    assert b.serialize() == a.serialize() == blob and b.count() == g.count() and b.is_canonical() == canonical
+    assert b.validate(strict=False) == 0
+    extra = _rand_seq(random.Random(1), 500)
+    b.insert_seq(extra), g.insert_seq(extra)
+    assert b.serialize() == g.serialize()
+    for bad in (blob[:-1], blob + b"\0", blob[: len(blob) // 2], blob[: len(blob) // 3] + blob[len(blob) // 3 + 1 :]):  # truncated, trailing, a byte lost
+        with pytest.raises(cbl_amd.CblxError):
+            cbl_amd.CBL(k, pb).load(bad)
