@@ -152,9 +152,19 @@ class ShardedBuilder:
 
     @staticmethod
     def slice_bounds(n: int, slices: int):
-        """Read ranges [a, b) of the slices of an n-read shard (same formula on every rank)."""
+        """Read ranges [a, b) of the slices of an n-read shard (same formula on every rank). With three or more slices the
+        first and the last are half as long as the others: the first slice's encode + partition is the only work no
+        exchange hides (it bounds the job when the links do), the last slice's exchange the only exchange no kernel hides
+        (it bounds the job when the kernels do)."""
         slices = max(1, min(slices, n)) if n else 1
-        return [(n * c // slices, n * (c + 1) // slices) for c in range(slices)]
+        if slices < 3:
+            return [(n * c // slices, n * (c + 1) // slices) for c in range(slices)]
+        w = [1] + [2] * (slices - 2) + [1]
+        tot, acc, cuts = sum(w), 0, [0]
+        for x in w:
+            acc += x
+            cuts.append(n * acc // tot)
+        return [(cuts[c], cuts[c + 1]) for c in range(slices)]
 
     def insert_seqs_device(self, d_bases, d_offsets, n):
         if self.protocol == "sorted":
