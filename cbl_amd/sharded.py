@@ -156,7 +156,7 @@ class ShardedBuilder:
         first and the last are half as long as the others: the first slice's encode + partition is the only work no
         exchange hides (it bounds the job when the links do), the last slice's exchange the only exchange no kernel hides
         (it bounds the job when the kernels do)."""
-        slices = max(1, min(slices, n)) if n else 1
+        slices = max(1, slices)  # every rank walks the same number of slices whatever its n (an empty slice still takes part in the exchange)
         if slices < 3:
             return [(n * c // slices, n * (c + 1) // slices) for c in range(slices)]
         w = [1] + [2] * (slices - 2) + [1]
@@ -189,8 +189,6 @@ class ShardedBuilder:
         inflight = []
         send_tot, recv_tot = [0] * W, [0] * W
         for a, b in self.slice_bounds(n, self.slices):
-            if b <= a:
-                continue
             off = d_offsets[a : b + 1]  # offsets stay absolute: no copy of the bases
             if self.bounds is None:
                 self._choose_bounds_from(d_bases, off, b - a)
@@ -242,8 +240,6 @@ class ShardedBuilder:
         send_tot = [0] * W
         recv_tot = [0] * W
         for a, b in self.slice_bounds(n, self.slices):
-            if b <= a:
-                continue
             off = d_offsets[a : b + 1]  # offsets stay absolute: no copy of the bases
             if self.bounds is None or not hasattr(eng, "seq_words_partitioned"):
                 lo, hi = eng.seq_words(d_bases, off, b - a)
@@ -263,7 +259,7 @@ class ShardedBuilder:
             send_l, recv_l = [int(x) for x in counts], [int(x) for x in recv.cpu().tolist()]
             n_recv = sum(recv_l)
             if recv_lo is None:  # one receive buffer for the whole batch: slices land back to back, no gather copy
-                est_total = int(n_words * (n / (b - a)) * self.slack) + 4096
+                est_total = int(n_words * (n / max(b - a, 1)) * self.slack) + 4096
                 cap = max(est_total, n_recv)
                 recv_lo = eng.empty_like(plo, cap)
                 recv_hi = eng.empty_like(phi, cap) if phi is not None else None

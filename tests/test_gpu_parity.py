@@ -353,6 +353,16 @@ def test_sharded_builder_single_rank_nccl():
             o = Oracle(k, pb)
             o.insert_seqs(hb, ho)
             assert blob == o.serialize()
+            # fewer reads than slices, then none at all: empty slices still walk the whole protocol
+            for proto in ("sorted", "words"):
+                t = cbl_amd.CBL(k, pb)
+                sbld = sharded.ShardedBuilder(t, dist, protocol=proto)
+                sbld.insert_seqs_device(d_b, d_o, 2)
+                sbld.insert_seqs_device(d_b, d_o[2:], 0)
+                sbld.insert_seqs_device(d_b, d_o[2:], 1)
+                o3 = Oracle(k, pb)
+                o3.insert_seqs(hb, ho[:4])
+                assert t.serialize() == o3.serialize()
     finally:
         if created:
             dist.destroy_process_group()

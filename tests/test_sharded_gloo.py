@@ -199,3 +199,69 @@ def test_choose_bounds_balances_skewed_histogram():
     parts = np.diff(np.concatenate([[0], cum[cells - 1], [cum[-1]]]))
     assert parts.max() / parts.mean() < 1.05
     assert (choose_bounds(np.zeros(16, dtype=np.int64), 4, 4, 4) == [4, 8, 12]).all()
+
+
+def _worker_ragged(rank, world, port, k, pb, L, counts, protocol, q):
+    """Ranks with very different read counts, fewer reads than slices, and a batch in which one rank has nothing."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+
+    from cbl_amd import sharded, synth
+    from oracle import Oracle
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = Oracle(k, pb)
+
+        class _Cbl:
+            prefix_bits = pb
+
+        sb = sharded.ShardedBuilder(_Cbl(), dist, engine=OracleEngine(orc, k, pb), slices=4, protocol=protocol)
+        first = 0
+        for batch in counts:  # batch = reads per rank
+            n = batch[rank]
+            bases, offsets = synth.reads(11, n, L, first_read=first + sum(batch[:rank]))
+            sb.insert_seqs_device(torch.from_numpy(bases.copy()), torch.from_numpy(offsets.astype(np.int64)), n)
+            first += sum(batch)
+        blob = sharded.gather_serialized(orc.serialize(), dist)
+        if rank == 0:
+            q.put(blob)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("protocol", ["sorted", "words"])
+def test_sharded_build_with_ragged_and_empty_shards(protocol):
+    import torch.multiprocessing as mp
+
+    from cbl_amd import synth
+    from cbl_amd.sharded import ShardedBuilder
+    from oracle import Oracle
+
+    k, pb, L, world = 31, 24, 120, 2
+    counts = [(9, 2), (5, 0), (0, 3)]  # per batch: reads of rank 0, rank 1 (fewer than the 4 slices; none at all)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, k, pb, L, counts, protocol, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    blob = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    one = Oracle(k, pb)  # stream order: per batch, slice-major then rank-minor
+    first = 0
+    for batch in counts:
+        starts = [first + sum(batch[:r]) for r in range(world)]
+        sl = [ShardedBuilder.slice_bounds(batch[r], 4) for r in range(world)]
+        for c in range(4):
+            for r in range(world):
+                a, b = sl[r][c]
+                if b > a:
+                    bases, offsets = synth.reads(11, b - a, L, first_read=starts[r] + a)
+                    one.insert_seqs(bases, offsets)
+        first += sum(batch)
+    assert blob == one.serialize()
