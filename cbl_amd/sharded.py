@@ -350,3 +350,36 @@ def gather_serialized(local_blob: bytes, dist, dst: int = 0):
         return None
     assert len({p[0] for p in parts}) == 1
     return bytes([parts[0][0]]) + _varint(sum(p[1] for p in parts)) + b"".join(p[2] for p in parts)
+
+
+def save_serialized(local_blob, dist, path) -> int:
+    """The same file as `gather_serialized`, written in place: every rank writes its entries at its own offset of `path`
+    (one node, one file system), so no rank ever holds another rank's bytes — `gather_serialized` ships every part to
+    every rank through pickles, which is fine for tests and hopeless for 9 GB parts. `local_blob`: bytes or a numpy
+    uint8 array (`CBL.serialize_np()`). Returns the file size."""
+    import numpy as np
+    import torch
+
+    blob = np.frombuffer(local_blob, dtype=np.uint8) if isinstance(local_blob, (bytes, bytearray, memoryview)) else local_blob
+    head = bytes(blob[:16].tobytes())
+    nb, pos = _read_varint(head, 1)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor([nb, len(blob) - pos, head[0]], dtype=torch.int64, device=dev)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    parts = [p.cpu().tolist() for p in parts]
+    assert len({p[2] for p in parts}) == 1, "One of the index is canonical while the other isn't"
+    header = bytes([head[0]]) + _varint(sum(p[0] for p in parts))
+    offset = len(header) + sum(p[1] for p in parts[:rank])
+    total = len(header) + sum(p[1] for p in parts)
+    if rank == 0:
+        with open(path, "wb") as f:
+            f.write(header)
+            f.truncate(total)
+    dist.barrier()
+    with open(path, "r+b") as f:
+        f.seek(offset)
+        blob[pos:].tofile(f)
+    dist.barrier()
+    return total

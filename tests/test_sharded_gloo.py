@@ -137,7 +137,13 @@ def _worker(rank, world, port, k, pb, nreads, L, slices, protocol, q):
             oo = torch.from_numpy((offsets[a : b + 1] - offsets[a]).astype(np.int64))
             sb.insert_seqs_device(bb, oo, b - a)
         blob = sharded.gather_serialized(orc.serialize(), dist)
+        path = os.path.join(os.environ.get("CBLX_TEST_TMP", "/tmp"), "cblx_sharded_%d.cbl" % port)
+        size = sharded.save_serialized(orc.serialize(), dist, path)  # every rank writes its entries in place
         if rank == 0:
+            with open(path, "rb") as f:
+                on_disk = f.read()
+            os.remove(path)
+            assert size == len(on_disk) and on_disk == blob
             q.put((blob, sb.bounds.tolist(), sb.last_counts))
     finally:
         dist.destroy_process_group()
