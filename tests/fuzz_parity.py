@@ -43,7 +43,7 @@ def main():
         ops = []
         print("START", desc, file=sys.stderr, flush=True)
         for step in range(rng.randint(1, 5)):
-            op = rng.choice(["seq", "seqs", "seqs", "merge", "roundtrip", "sorted", "kmers", "query"])
+            op = rng.choice(["seq", "seqs", "seqs", "merge", "roundtrip", "sorted", "kmers", "query", "file"])
             ops.append(op)
             if op == "seq":
                 for _ in range(rng.randint(1, 5)):
@@ -86,6 +86,33 @@ def main():
                 assert g.contains_seqs(bases, offsets, flags=False)[1:] == (tot, pos), desc + " (query by join) " + str(ops)
                 if rng.random() < 0.3:
                     assert [o.kmer_of_word(w) for w in o.iter_words()] == list(g.iter()), desc + " (iter) " + str(ops)
+            elif op == "file":  # FASTA in (multi-line, mixed case), index file out and back in, the file query loop
+                import tempfile
+
+                seqs = [rand_seq(rng, rng.randint(k, k + rng.choice([0, 9, 400, 2600])), alphabet) for _ in range(rng.randint(1, 25))]
+                with tempfile.TemporaryDirectory() as td:
+                    fa, ix = os.path.join(td, "in.fa"), os.path.join(td, "x.cbl")
+                    width = rng.choice([60, 70, 10_000])
+                    with open(fa, "wb") as f:
+                        for i, sq in enumerate(seqs):
+                            f.write(b">r%d some text\n" % i)
+                            for j in range(0, len(sq), width):
+                                f.write(sq[j : j + width] + (b"\r\n" if width == 70 else b"\n"))
+                    assert g.insert_fastx_file(fa) == len(seqs), desc + " (records) " + str(ops)
+                    for sq in seqs:
+                        o.insert_seq(sq)
+                    g.save_to_file(ix)
+                    with open(ix, "rb") as f:
+                        assert f.read() == o.serialize(), desc + " (index file) " + str(ops)
+                    g = cbl_amd.CBL.load_from_file(ix, k, pb)
+                    want = [o.contains_word(w) for sq in seqs for w in o.seq_words(sq)]
+                    assert g.query_fastx_file(fa) == (len(seqs), len(want), sum(want)), desc + " (file query) " + str(ops)
+                    assert g.contains_all(seqs[0]) == all(o.contains_word(w) for w in o.seq_words(seqs[0])), desc + " (contains_all) " + str(ops)
+                sizes = {}
+                sbits = g.consts()["suffix_bits"]
+                for w in o.iter_words():
+                    sizes[w >> sbits] = sizes.get(w >> sbits, 0) + 1
+                assert g.buckets_sizes() == sorted(sizes.items()), desc + " (buckets_sizes) " + str(ops)
             elif op == "sorted":
                 seqs = [rand_seq(rng, rng.randint(k, k + 800), b"ACGT") for _ in range(rng.randint(1, 40))]
                 hb = np.frombuffer(b"".join(seqs), dtype=np.uint8)
