@@ -225,6 +225,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
     __shared__ u8 s_dirty[ENC_MAX_CHUNKS];
     __shared__ u64 s_par[(ENC_MAX_KMERS + ENC_THREADS) / 64 + 2];
     __shared__ u32 s_parpre[(ENC_MAX_KMERS + ENC_THREADS) / 64 + 2];
+    __shared__ u32 s_cfwd[ENC_MAX_CHUNKS + 1];  // canonical: forward-strand k-mers of the tile in front of each chunk
 
     const u32 tid = threadIdx.x;
     const u32 c0 = tile_first[blockIdx.x], c1 = tile_first[blockIdx.x + 1];
@@ -294,6 +295,10 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
     auto cum_fwd = [&](u32 q) -> u32 {
         return s_parpre[q >> 6] + (u32)__builtin_popcountll(s_par[q >> 6] & ((1ull << (q & 63)) - 1ull));
     };
+    if (P.canonical) {  // once per chunk instead of twice per k-mer
+        for (u32 i = tid; i <= nc; i += ENC_THREADS) s_cfwd[i] = cum_fwd(s_koff[i]);
+        __syncthreads();
+    }
 
     // The k-mer loop with K as a compile-time constant (every rotate / mask / shift of the necklace then has constant
     // operands) or read from P.
@@ -310,8 +315,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
             u64 dst = out_base + kbase + q;
             bool rc = false;
             if (P.canonical) {
-                const u32 cb = cum_fwd(s_koff[ci]);
-                const u32 nfwd = cum_fwd(s_koff[ci + 1]) - cb;
+                const u32 cb = s_cfwd[ci];
+                const u32 nfwd = s_cfwd[ci + 1] - cb;
                 const u32 rf = cum_fwd(q) - cb;
                 rc = !kmer_is_fwd<WIDE>(x);
                 dst = out_base + kbase + s_koff[ci] + (rc ? (nfwd + (j - rf)) : rf);
