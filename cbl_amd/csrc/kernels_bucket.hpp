@@ -754,6 +754,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
         return;
     }
     if (tid == 0) s_off[NB] = (u16)c;
+    if constexpr (PACKED) { if (tid < 4) s_klo[c + tid] = ~0ull; }  // the slack the ranking loop may read compares greater than every element
     // scatter into sub-bucket order (arrival order inside a sub-bucket is arbitrary); the offsets are fetched for all
     // slots at once, outside the per-slot branches (sub[] is in range for unused slots too)
     u32 sbase[ITEMS];
@@ -794,15 +795,30 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
             // slowest lane of a wave) costs one LDS round trip instead of one per element
             if constexpr (PACKED) {
                 const u64 me = (key[j].lo << PK_BITS) | e;
-                for (u32 q = a; q < b; q += 4) {
-                    u64 o[4];
+                if (vec_only) {  // hashed sub-buckets: what follows a sub-bucket is unrelated, entries past b are masked
+                    for (u32 q = a; q < b; q += 4) {
+                        u64 o[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = s_klo[q + k];  // s_klo has 4 slack entries; entries past b are masked
+                        for (int k = 0; k < 4; ++k) o[k] = s_klo[q + k];  // s_klo has 4 slack entries
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const bool less = (q + k < b) && o[k] < me;
-                        rank += less ? 1u : 0u;
-                        dup |= less && ((o[k] >> PK_BITS) == key[j].lo);
+                        for (int k = 0; k < 4; ++k) {
+                            const bool less = (q + k < b) && o[k] < me;
+                            rank += less ? 1u : 0u;
+                            dup |= less && ((o[k] >> PK_BITS) == key[j].lo);
+                        }
+                    }
+                } else {  // sub-buckets by the top suffix bits are in ascending order: whatever follows b (the next
+                          // sub-bucket, or the all-ones slack) is greater than `me` and needs no bound check
+                    for (u32 q = a; q < b; q += 4) {
+                        u64 o[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = s_klo[q + k];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bool less = o[k] < me;
+                            rank += less ? 1u : 0u;
+                            dup |= less && ((o[k] >> PK_BITS) == key[j].lo);
+                        }
                     }
                 }
             } else {
