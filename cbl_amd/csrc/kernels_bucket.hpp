@@ -671,6 +671,10 @@ template <bool WS> __device__ __forceinline__ bool sfx_less(const Sfx<WS>& a, u3
 // PACKED (SUFFIX_BITS + 12 <= 64, narrow suffix): an element is ONE u64 = suffix << 12 | stream index, so every LDS
 // access, compare and move handles key and index together (the kernel is LDS-throughput-bound).
 static const u32 PK_BITS = 12;  // CAP <= 4096
+#ifndef CBLX_MSD_TRIP
+#define CBLX_MSD_TRIP 3  // measured at cfg 2: 2 -> 6.87 ms, 3 -> 6.66 ms, 4 -> 6.86 ms, 8 -> +0.8 ms
+#endif
+static const int MSD_TRIP = CBLX_MSD_TRIP;  // sub-bucket entries read per trip of the ranking loop (<= the 4 slack entries)
 #ifndef CBLX_MSD_WAVES
 #define CBLX_MSD_WAVES 7  // waves per SIMD the register allocation aims at (LDS allows 7 workgroups of the 256-thread class; 76 -> 72 VGPRs: 7.28 -> 7.10 ms)
 #endif
@@ -796,12 +800,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
             if constexpr (PACKED) {
                 const u64 me = (key[j].lo << PK_BITS) | e;
                 if (vec_only) {  // hashed sub-buckets: what follows a sub-bucket is unrelated, entries past b are masked
-                    for (u32 q = a; q < b; q += 4) {
-                        u64 o[4];
+                    for (u32 q = a; q < b; q += MSD_TRIP) {
+                        u64 o[MSD_TRIP];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) o[k] = s_klo[q + k];  // s_klo has 4 slack entries
+                        for (int k = 0; k < MSD_TRIP; ++k) o[k] = s_klo[q + k];  // s_klo has 4 slack entries
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
+                        for (int k = 0; k < MSD_TRIP; ++k) {
                             const bool less = (q + k < b) && o[k] < me;
                             rank += less ? 1u : 0u;
                             dup |= less && ((o[k] >> PK_BITS) == key[j].lo);
@@ -809,12 +813,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
                     }
                 } else {  // sub-buckets by the top suffix bits are in ascending order: whatever follows b (the next
                           // sub-bucket, or the all-ones slack) is greater than `me` and needs no bound check
-                    for (u32 q = a; q < b; q += 4) {
-                        u64 o[4];
+                    for (u32 q = a; q < b; q += MSD_TRIP) {
+                        u64 o[MSD_TRIP];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) o[k] = s_klo[q + k];
+                        for (int k = 0; k < MSD_TRIP; ++k) o[k] = s_klo[q + k];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
+                        for (int k = 0; k < MSD_TRIP; ++k) {
                             const bool less = o[k] < me;
                             rank += less ? 1u : 0u;
                             dup |= less && ((o[k] >> PK_BITS) == key[j].lo);
