@@ -60,11 +60,19 @@ template <typename T> __host__ __device__ inline void necklace_pos_fast(T x, uns
             L = 2;
         }
     }
-    for (;;) {  // at most a step or two for all but the longest runs
+    {   // One +1 step settles every case but one: the doubling above left L in {1, 2, 4, 6, 8, 10} with the longest run known
+        // to be < L + 2 unless L = 10 (L = 1: no run of 2 at all, the step is a no-op), so a second step can only succeed
+        // after 10 -> 11. (A plain loop paid one extra rotate-and-test per k-mer to find that out.)
         T t = r & rotl_ring(r, 1);
-        if (t == 0) break;
-        r = t;
-        ++L;
+        if (t != 0) { r = t; ++L; }
+        if (L == 11) {
+            for (;;) {
+                t = r & rotl_ring(r, 1);
+                if (t == 0) break;
+                r = t;
+                ++L;
+            }
+        }
     }
     {   // Every candidate reads 0^L 1 from its top; the next bit decides next: keep only the candidates that continue with
         // a 0, if there are any (a cheap mask operation that saves a round of the rotate-and-compare loop below for the
