@@ -67,13 +67,20 @@ __global__ void k_seq_chunk_count(const u64* __restrict__ offsets, u64 nseq, u32
     nchunks[i] = (u32)((nk + CHUNK_KMERS - 1) / CHUNK_KMERS);
 }
 
-// one thread per chunk: binary search the owning sequence in the chunk-base scan
+// one thread per chunk: search the owning sequence in the chunk-base scan
 __global__ void k_chunk_fill(const u64* __restrict__ offsets, const u64* __restrict__ chunk_base /* nseq+1 */,
                              u64 nseq, u64 nchunks, u32 K, u64 bias, u64* __restrict__ chunk_start,
                              u32* __restrict__ chunk_len, u32* __restrict__ chunk_nk) {
     u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
-    u64 lo = 0, hi = nseq;  // last seq with chunk_base[seq] <= c
+    // last seq with chunk_base[seq] <= c. Every sequence has at least one chunk, so chunk_base[i] >= i and the answer is at
+    // most min(c, nseq - 1) — exactly that when the sequences before it have one chunk each (reads): gallop down from
+    // there instead of bisecting [0, nseq) (24 dependent loads per chunk at 10 M reads).
+    u64 hi = (c < nseq - 1 ? c : nseq - 1) + 1, lo = hi - 1;  // invariant: chunk_base[hi] > c (or hi is past the range)
+    for (u64 step = 1; chunk_base[lo] > c; step <<= 1) {
+        hi = lo;
+        lo = lo > step ? lo - step : 0;
+    }
     while (hi - lo > 1) {
         u64 mid = (lo + hi) >> 1;
         if (chunk_base[mid] <= c) lo = mid; else hi = mid;
