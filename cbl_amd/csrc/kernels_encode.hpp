@@ -228,8 +228,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
     __shared__ u32 s_hist[ENC_HIST_WINDOWS * 256];
     __shared__ u32 s_codes[ENC_CODE_WORDS];
     __shared__ u32 s_koff[ENC_MAX_CHUNKS + 1];
-    __shared__ u32 s_cstart[ENC_MAX_CHUNKS];
-    __shared__ u8 s_dirty[ENC_MAX_CHUNKS];
+    __shared__ u32 s_cstart[ENC_MAX_CHUNKS];  // first base of the chunk in the tile's code stream; bit 31: the chunk is dirty
     __shared__ u64 s_par[(ENC_MAX_KMERS + ENC_THREADS) / 64 + 2];
     __shared__ u32 s_parpre[(ENC_MAX_KMERS + ENC_THREADS) / 64 + 2];
     __shared__ u32 s_cfwd[ENC_MAX_CHUNKS + 1];  // canonical: forward-strand k-mers of the tile in front of each chunk
@@ -245,8 +244,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
 
     for (u32 i = tid; i <= nc; i += ENC_THREADS) s_koff[i] = (u32)(kmer_off[c0 + i] - kbase);
     for (u32 i = tid; i < nc; i += ENC_THREADS) {
-        s_cstart[i] = (u32)(chunk_start[c0 + i] - A0);
-        s_dirty[i] = dirty ? dirty[c0 + i] : (u8)0;
+        s_cstart[i] = (u32)(chunk_start[c0 + i] - A0) | ((dirty && dirty[c0 + i]) ? 0x80000000u : 0u);
     }
     const u64 win0 = (out_base + kbase) / ENC_HIST_WINDOW;  // first window this tile's outputs fall into
     if (eh.counts)
@@ -284,7 +282,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
             bool fwd = false;
             if (q < Q) {
                 while (q >= s_koff[cf + 1]) ++cf;
-                if (!s_dirty[cf]) fwd = kmer_is_fwd<WIDE>(extract_kmer<WIDE>(s_codes, s_cstart[cf] + (q - s_koff[cf]), P.K));
+                const u32 cs = s_cstart[cf];
+                if (!(cs >> 31)) fwd = kmer_is_fwd<WIDE>(extract_kmer<WIDE>(s_codes, cs + (q - s_koff[cf]), P.K));
             }
             u64 bal = __ballot(fwd);
             if ((tid & 63) == 0) s_par[q >> 6] = bal;
@@ -316,9 +315,10 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
         u32 ci = tid < Q ? find_chunk(tid) : 0u;
         for (u32 q = tid; q < Q; q += ENC_THREADS) {
             while (q >= s_koff[ci + 1]) ++ci;  // q only grows: walk forward from the previous chunk instead of searching again
-            if (s_dirty[ci]) continue;
+            const u32 cs = s_cstart[ci];
+            if (cs >> 31) continue;
             const u32 j = q - s_koff[ci];
-            T x = extract_kmer<WIDE>(s_codes, s_cstart[ci] + j, PK.K);
+            T x = extract_kmer<WIDE>(s_codes, cs + j, PK.K);
             u64 dst = out_base + kbase + q;
             bool rc = false;
             if (P.canonical) {
