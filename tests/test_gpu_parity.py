@@ -1034,3 +1034,118 @@ def test_parallel_index_loader(k, pb, canonical, threads, monkeypatch):
     for bad in (blob[:-1], blob + b"\0", blob[: len(blob) // 2], blob[: len(blob) // 3] + blob[len(blob) // 3 + 1 :]):  # truncated, trailing, a byte lost
         with pytest.raises(cbl_amd.CblxError):
             cbl_amd.CBL(k, pb).load(bad)
+
+
+# ---- the N-GPU code path with real device steps on ONE GPU: two processes share cuda:0, the collectives go through gloo ----
+class _GlooShim:
+    """torch.distributed look-alike for ShardedBuilder: device tensors are staged through the host and exchanged over gloo.
+    RCCL refuses two ranks on one GPU ("Duplicate GPU detected"), so this is how the W = 2 exchange of the GPU engine —
+    offsets, slices, empty messages, stream order — gets exercised on a one-GPU box; only RCCL itself is not."""
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class _Work:
+        def __init__(self, w, dst=None, host=None):
+            self.w, self.dst, self.host = w, dst, host
+
+        def wait(self):
+            self.w.wait()
+            if self.dst is not None:
+                self.dst.copy_(self.host)
+
+    isend, irecv = "isend", "irecv"
+
+    def __init__(self, d):
+        self.d = d
+
+    def get_world_size(self):
+        return self.d.get_world_size()
+
+    def get_rank(self):
+        return self.d.get_rank()
+
+    def barrier(self):
+        self.d.barrier()
+
+    def all_reduce(self, t):
+        h = t.cpu()
+        self.d.all_reduce(h)
+        t.copy_(h)
+
+    def all_to_all_single(self, out, inp):
+        ho, hi = out.cpu(), inp.cpu()
+        self.d.all_to_all_single(ho, hi)
+        out.copy_(ho)
+
+    def batch_isend_irecv(self, ops):
+        works = []
+        for o in ops:
+            if o.op == "isend":
+                works.append(self._Work(self.d.isend(o.tensor.cpu().contiguous(), o.peer)))
+            else:
+                h = torch.empty(o.tensor.shape, dtype=o.tensor.dtype)
+                works.append(self._Work(self.d.irecv(h, o.peer), o.tensor, h))
+        return works
+
+
+def _two_rank_worker(rank, port, k, pb, canonical, protocol, per, L, q):
+    import torch.distributed as dist
+
+    from cbl_amd import sharded
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        g = cbl_amd.CBL(k, pb, canonical=canonical, device=0)
+        sb = sharded.ShardedBuilder(g, _GlooShim(dist), slices=3, protocol=protocol)
+        for batch, n in enumerate(per[rank]):  # two batches; the second reuses the first one's splitters
+            first = sum(per[0][:batch]) + sum(per[1][:batch]) + (per[0][batch] if rank else 0)
+            d_b, d_o = synth.reads_torch(23, n, L, first_read=first, device="cuda:0")
+            sb.insert_seqs_device(d_b, d_o, n)
+        blob = sharded.gather_serialized(g.serialize(), dist)
+        if rank == 0:
+            q.put((blob, [int(x) for x in sb.bounds], g.count()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,pb,canonical,protocol", [(31, 24, False, "sorted"), (31, 24, True, "words"), (59, 28, False, "sorted"), (25, 12, False, "sorted")])
+def test_two_ranks_on_one_gpu_through_a_gloo_shim(k, pb, canonical, protocol):
+    _need_gpu()
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from cbl_amd.sharded import ShardedBuilder
+
+    L = 150 if k < 59 else 250
+    per = [(700, 2), (300, 450)]  # reads per batch of rank 0, of rank 1 (ragged; fewer reads than slices in one batch)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, port, k, pb, canonical, protocol, per, L, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    blob, bounds, count0 = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    one = Oracle(k, pb, canonical)  # stream order of the job: per batch, slice-major then rank-minor
+    for batch in range(2):
+        first = sum(per[0][:batch]) + sum(per[1][:batch])
+        starts = [first, first + per[0][batch]]
+        sl = [ShardedBuilder.slice_bounds(per[r][batch], 3) for r in range(2)]
+        for c in range(3):
+            for r in range(2):
+                a, b = sl[r][c]
+                if b > a:
+                    hb, ho = synth.reads(23, b - a, L, first_read=starts[r] + a)
+                    one.insert_seqs(hb, ho)
+    assert blob == one.serialize()
+    assert len(bounds) == 1 and 0 < count0 < one.count()  # both ranks own part of the index
