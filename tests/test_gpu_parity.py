@@ -1090,19 +1090,19 @@ class _GlooShim:
         return works
 
 
-def _two_rank_worker(rank, port, k, pb, canonical, protocol, per, L, q):
+def _two_rank_worker(rank, world, port, k, pb, canonical, protocol, per, L, q):
     import torch.distributed as dist
 
     from cbl_amd import sharded
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g = cbl_amd.CBL(k, pb, canonical=canonical, device=0)
         sb = sharded.ShardedBuilder(g, _GlooShim(dist), slices=3, protocol=protocol)
         for batch, n in enumerate(per[rank]):  # two batches; the second reuses the first one's splitters
-            first = sum(per[0][:batch]) + sum(per[1][:batch]) + (per[0][batch] if rank else 0)
+            first = sum(per[r][bb] for r in range(world) for bb in range(batch)) + sum(per[r][batch] for r in range(rank))
             d_b, d_o = synth.reads_torch(23, n, L, first_read=first, device="cuda:0")
             sb.insert_seqs_device(d_b, d_o, n)
         blob = sharded.gather_serialized(g.serialize(), dist)
@@ -1112,8 +1112,9 @@ def _two_rank_worker(rank, port, k, pb, canonical, protocol, per, L, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,pb,canonical,protocol", [(31, 24, False, "sorted"), (31, 24, True, "words"), (59, 28, False, "sorted"), (25, 12, False, "sorted")])
-def test_two_ranks_on_one_gpu_through_a_gloo_shim(k, pb, canonical, protocol):
+@pytest.mark.parametrize("world,k,pb,canonical,protocol", [(2, 31, 24, False, "sorted"), (2, 31, 24, True, "words"), (2, 59, 28, False, "sorted"),
+                                                         (2, 25, 12, False, "sorted"), (4, 31, 24, False, "sorted"), (3, 31, 24, False, "words")])
+def test_two_ranks_on_one_gpu_through_a_gloo_shim(world, k, pb, canonical, protocol):
     _need_gpu()
     import socket
 
@@ -1122,14 +1123,14 @@ def test_two_ranks_on_one_gpu_through_a_gloo_shim(k, pb, canonical, protocol):
     from cbl_amd.sharded import ShardedBuilder
 
     L = 150 if k < 59 else 250
-    per = [(700, 2), (300, 450)]  # reads per batch of rank 0, of rank 1 (ragged; fewer reads than slices in one batch)
+    per = [(700, 2), (300, 450), (1, 600), (512, 0)][:world]  # reads per batch of every rank (ragged; fewer reads than slices; none)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, port, k, pb, canonical, protocol, per, L, q)) for r in range(2)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, k, pb, canonical, protocol, per, L, q)) for r in range(world)]
     for p in procs:
         p.start()
     blob, bounds, count0 = q.get(timeout=600)
@@ -1138,14 +1139,14 @@ def test_two_ranks_on_one_gpu_through_a_gloo_shim(k, pb, canonical, protocol):
         assert p.exitcode == 0
     one = Oracle(k, pb, canonical)  # stream order of the job: per batch, slice-major then rank-minor
     for batch in range(2):
-        first = sum(per[0][:batch]) + sum(per[1][:batch])
-        starts = [first, first + per[0][batch]]
-        sl = [ShardedBuilder.slice_bounds(per[r][batch], 3) for r in range(2)]
+        first = sum(per[r][bb] for r in range(world) for bb in range(batch))
+        starts = [first + sum(per[rr][batch] for rr in range(r)) for r in range(world)]
+        sl = [ShardedBuilder.slice_bounds(per[r][batch], 3) for r in range(world)]
         for c in range(3):
-            for r in range(2):
+            for r in range(world):
                 a, b = sl[r][c]
                 if b > a:
                     hb, ho = synth.reads(23, b - a, L, first_read=starts[r] + a)
                     one.insert_seqs(hb, ho)
     assert blob == one.serialize()
-    assert len(bounds) == 1 and 0 < count0 < one.count()  # both ranks own part of the index
+    assert len(bounds) == world - 1 and 0 < count0 < one.count()  # rank 0 owns part of the index, not all of it
