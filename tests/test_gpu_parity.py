@@ -1113,7 +1113,7 @@ def _two_rank_worker(rank, world, port, k, pb, canonical, protocol, per, L, q):
 
 
 @pytest.mark.parametrize("world,k,pb,canonical,protocol", [(2, 31, 24, False, "sorted"), (2, 31, 24, True, "words"), (2, 59, 28, False, "sorted"),
-                                                         (2, 25, 12, False, "sorted"), (4, 31, 24, False, "sorted"), (3, 31, 24, False, "words")])
+                                                         (2, 25, 12, False, "sorted"), (4, 31, 24, False, "sorted"), (3, 31, 24, False, "words"), (8, 31, 24, False, "sorted")])
 def test_two_ranks_on_one_gpu_through_a_gloo_shim(world, k, pb, canonical, protocol):
     _need_gpu()
     import socket
@@ -1123,7 +1123,7 @@ def test_two_ranks_on_one_gpu_through_a_gloo_shim(world, k, pb, canonical, proto
     from cbl_amd.sharded import ShardedBuilder
 
     L = 150 if k < 59 else 250
-    per = [(700, 2), (300, 450), (1, 600), (512, 0)][:world]  # reads per batch of every rank (ragged; fewer reads than slices; none)
+    per = [(700, 2), (300, 450), (1, 600), (512, 0), (64, 64), (0, 900), (333, 5), (90, 90)][:world]  # reads per batch of every rank (ragged; fewer reads than slices; none)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -1133,9 +1133,9 @@ def test_two_ranks_on_one_gpu_through_a_gloo_shim(world, k, pb, canonical, proto
     procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, k, pb, canonical, protocol, per, L, q)) for r in range(world)]
     for p in procs:
         p.start()
-    blob, bounds, count0 = q.get(timeout=600)
+    blob, bounds, count0 = q.get(timeout=900)
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=300)
         assert p.exitcode == 0
     one = Oracle(k, pb, canonical)  # stream order of the job: per batch, slice-major then rank-minor
     for batch in range(2):
