@@ -2,20 +2,35 @@
 """bench.py — k-mers inserted/sec (build index), K=31 150 bp synthetic reads (BASELINE.json), on N MI355X.
 
 A "step" = one pass of the hot path (insert_seq -> necklace transform -> prefix partition -> bucket insert) over one
-batch of synthetic reads already resident in HBM: BASELINE.json configs[1] (K=31, 68-bit word, PREFIX_BITS=24,
-10M x 150 bp per GPU). N > 1: one process per GPU (torchrun), reads sharded contiguously by rank, prefix space
-sharded by quantile ranges, one RCCL all-to-all of the transformed words (cbl_amd/sharded.py); per-GPU work is fixed
-as N grows ("weak").
+batch of synthetic reads already resident in HBM. Workloads (`--config`, BASELINE.json `configs`):
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     - the dominant kernel group of the step, algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
+  cfg2  (default at N = 1)  K=31 (68-bit word) PREFIX_BITS=24, 10 M x 150 bp per GPU — the configuration the metric is quoted on
+  cfg3  (default at N > 1)  K=31 PREFIX_BITS=28, 12.5 M x 150 bp per GPU (= 100 M reads on 8 GPUs), prefix-sharded
+  cfg4                      K=59 (125-bit word) PREFIX_BITS=28, 6.25 M x 250 bp per GPU (= 50 M reads on 8 GPUs)
+  merge                     cfg 5's per-GPU share: `A |= B` of two indexes of 6.25 M x 150 bp reads per GPU each (K=31, PB=24);
+                            at N > 1 both operands are prefix-sharded with their own quantile bounds and B is re-sharded
+                            to A's bounds through the exchange before the per-rank merge
+
+N > 1: one process per GPU. Started under torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment) every process is
+one rank; started plainly (`python bench.py --gpus 8`) this process only LAUNCHES the N ranks as fresh child processes
+(it never touches a GPU itself) and relays rank 0's line. Reads are sharded contiguously by rank, the prefix space by
+quantile ranges, one exchange of the partitioned words over RCCL (cbl_amd/sharded.py); per-GPU work is fixed as N grows
+("weak"). `--shared-gpu` runs the N ranks on ONE GPU with the exchange staged through gloo (dry run of the N-rank code).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline     - the dominant kernel group of the step (algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak), and
+                 `kernels`: the same figures for every kernel group of the step
   cpu_baseline - the CPU oracle (a C++ port of the reference algorithm, oracle/) timed on a bounded sample, 1 thread
+  exchange     - (N > 1) world size as the process group reports it, bytes sent / received per rank, effective GB/s
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,107 +40,189 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-# ALGORITHMIC bytes per k-mer and step of each kernel group (DESIGN.md §3/§4): what the group's contract must move once.
-#   R_in = record bytes out of KRN-1 (8 lo + hi part); after the first partition pass a 65..72-bit word keeps only lo.
-def stage_alg_bytes(k: int, pb: int, read_len: int):
+CONFIGS = {
+    "cfg2": dict(k=31, prefix_bits=24, reads=10_000_000, read_len=150, kind="build"),
+    "cfg3": dict(k=31, prefix_bits=28, reads=12_500_000, read_len=150, kind="build"),
+    "cfg4": dict(k=59, prefix_bits=28, reads=6_250_000, read_len=250, kind="build"),
+    "merge": dict(k=31, prefix_bits=24, reads=6_250_000, read_len=150, kind="merge"),
+}
+
+
+def word_layout(k: int, pb: int):
     kb = 2 * k
     wb = kb + (kb - 1).bit_length()
     hi = 0 if wb <= 64 else (1 if kb <= 64 else 8)
+    sfx = 8 if wb - pb <= 64 else 16
+    return kb, wb, hi, sfx, (wb - pb + 7) // 8
+
+
+# ALGORITHMIC bytes per k-mer and step of each kernel group (DESIGN.md §3/§4): what the group's contract must move once.
+#   R_in = record bytes out of KRN-1 (8 lo + hi part); after the first partition pass a 65..72-bit word keeps only lo.
+def stage_alg_bytes(k: int, pb: int, read_len: int):
+    _, _, hi, sfx, _ = word_layout(k, pb)
     r_in = 8 + hi
     r_out = 8 if hi == 1 else r_in
     n_a = min(8, pb)
     lsd = (pb - n_a + 7) // 8
-    sfx = 8 if wb - pb <= 64 else 16
     # digit side channel: a scatter also writes the next pass's digit (1 B); that pass's histogram then reads 1 B per
     # record instead of the record
-    side = list(range(lsd))
+    side = lsd
     tbl_dir = lsd >= 1 and n_a + 8 * (lsd - 1) <= 16      # bucket directory from the last pass's tables (no record scan)
     return {
         "chunks": read_len / (read_len - k + 1),             # validity scan reads every base once
         "encode": read_len / (read_len - k + 1) + r_in,        # read bases, write one record (+ fused first-pass histogram)
-        "radix_hist": (lsd - len(side)) * r_out + len(side),   # pass A's histogram is fused in KRN-1
-        "radix_scatter": (r_in + r_out) + lsd * 2 * r_out + len(side),  # every pass reads + writes every record once
+        "radix_hist": float(side),                             # pass A's histogram is fused in KRN-1; the others read the side channel
+        "radix_scatter": (r_in + r_out) + lsd * 2 * r_out + side,  # every pass reads + writes every record once
         "directory": 0.0 if tbl_dir else r_out,                # boundary detection reads the sorted records only when the tables cannot give it
         "bucket_medium": 2 * sfx,                              # read the run, write the distinct suffixes
         "bucket_small": 2 * sfx,
         "bucket_huge": 2 * sfx,
+        "merge_gather": 2 * sfx,
     }
+
+
+# `A |= B`: bytes per word of the merged runs (|A| + |B| words)
+def merge_alg_bytes(k: int, pb: int):
+    _, _, _, sfx, _ = word_layout(k, pb)
+    return {"merge_gather": 2 * sfx, "bucket_medium": 2 * sfx, "bucket_huge": 2 * sfx, "directory": 0.0}
+
+
+KERNEL_OF = {"radix_scatter": "k_radix_scatter", "radix_hist": "k_radix_hist_bytes", "radix_scan": "k_colscan_*+k_seg_*", "encode": "k_encode",
+             "bucket_medium": "k_bucket_msd", "bucket_small": "k_bucket_small", "bucket_huge": "k_bucket_huge",
+             "directory": "k_dir_gather/k_dir_resolve+k_bitvector+k_bucket_table", "chunks": "k_scan_invalid+chunk table",
+             "merge_gather": "k_merge_gather"}
 
 
 def survey_b_alg(k: int, pb: int, read_len: int) -> float:
     """SURVEY.md §8d whole-path figure: L/(L-K+1) + 4R + BYTES with R = 16 (K <= 45) or 24."""
-    kb = 2 * k
-    wb = kb + (kb - 1).bit_length()
-    by = (wb - pb + 7) // 8
+    by = word_layout(k, pb)[4]
     R = 16 if k <= 45 else 24
     return read_len / (read_len - k + 1) + 4 * R + by
 
 
-def main():
+def source_hash() -> str:
+    """sha256 over the kernel / host sources of libcblx: ties a committed counter profile to the code it was taken from."""
+    h = hashlib.sha256()
+    files = sorted(os.listdir(os.path.join(ROOT, "cbl_amd", "csrc")))
+    for f in files:
+        if f.endswith((".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(ROOT, "cbl_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--prefix-bits", type=int, default=24)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
-    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="default: cfg2 on 1 GPU, cfg3 on more")
+    ap.add_argument("--k", type=int, default=None)
+    ap.add_argument("--prefix-bits", type=int, default=None)
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--canonical", action="store_true")
+    ap.add_argument("--protocol", choices=["sorted", "words"], default="sorted")
+    ap.add_argument("--slices", type=int, default=4)
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--cpu-full", action="store_true", help="time the CPU oracle on the whole workload (cfg 2: about 4 minutes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (value_h2d_inclusive)")
     ap.add_argument("--force-sharded", action="store_true", help="dev: run the N-GPU code path on a 1-rank RCCL group")
-    args = ap.parse_args()
+    ap.add_argument("--shared-gpu", action="store_true", help="dry run: all ranks on GPU 0, exchange staged through gloo")
+    args = ap.parse_args(argv)
+    if args.config is None:
+        args.config = "cfg2" if args.gpus == 1 else "cfg3"
+    cfg = CONFIGS[args.config]
+    for name in ("k", "prefix_bits", "reads", "read_len"):
+        if getattr(args, name) is None:
+            setattr(args, name, cfg[name])
+    args.kind = cfg["kind"]
+    return args
 
-    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-        del os.environ["NCCL_DEBUG"]  # RCCL prints its banner (and WARN lines) on STDOUT; keep stdout to the one JSON line
-    import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+# ---- launcher: `python bench.py --gpus N` without torchrun -------------------------------------------------------------
+def launch_ranks(args) -> int:
+    """Start N fresh rank processes (this process never initialises a GPU), relay rank 0's stdout, return the worst code."""
+    import __graft_entry__ as ge
+
+    ge.build()  # once, before any rank exists: hipcc / g++ children, dlopen; no HIP call
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", CBLX_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, abs(p.wait()))
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(launch_ranks(args))
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.shared_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torchrun --nproc-per-node {args.gpus}", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        del os.environ["NCCL_DEBUG"]  # RCCL prints its banner (and WARN lines) on STDOUT; keep stdout to the one JSON line
+
+    # build before torch / any GPU call (hipcc and g++ children must not inherit an initialised runtime or a profiler's
+    # preload); under torchrun local rank 0 builds and the others wait on a lock file for it
+    if not os.environ.get("CBLX_BENCH_CHILD"):
+        import fcntl
+
+        import __graft_entry__ as ge
+
+        with open(os.path.join(ROOT, ".build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            ge.build()
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+    import torch
+
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the product has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
     dist = None
+    transport = "none"
     if world > 1 or args.force_sharded:
-        import torch.distributed as dist
+        import torch.distributed as tdist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if world > 1:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.shared_gpu:
+            from cbl_amd.sharded import HostStagedGroup
+
+            tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist = HostStagedGroup(tdist)
+            transport = "gloo, staged through the host (all ranks share GPU 0: dry run)"
         else:
-            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            tdist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist = tdist
+            transport = "RCCL grouped send/recv (torch.distributed nccl backend)"
 
-    import __graft_entry__ as ge
-
-    if rank == 0:
-        ge.build()
-    if dist is not None:
-        dist.barrier()
     import cbl_amd
     from cbl_amd import sharded, synth
 
     K, PB, L, NR = args.k, args.prefix_bits, args.read_len, args.reads
     kmers_per_rank = NR * (L - K + 1)
-    d_bases, d_offsets = synth.reads_torch(42, NR, L, first_read=rank * NR, device=f"cuda:{local_rank}")
-    torch.cuda.synchronize()
-
-    cbl = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank, profile=True)
-    engine = sharded.ShardedBuilder(cbl, dist) if dist is not None else None
-
-    def step():
-        cbl.clear()
-        if engine is None:
-            cbl.insert_seqs_device(d_bases, d_offsets, NR)
-        else:
-            engine.insert_seqs_device(d_bases, d_offsets, NR)
 
     def fence():
         torch.cuda.synchronize()
@@ -133,100 +230,242 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    cbl.stage_times_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    count = cbl.count()
-    if dist is not None:
-        t = torch.tensor([count], dtype=torch.int64, device=f"cuda:{local_rank}")
+    def allreduce_max(x: float) -> float:
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        return float(t.item())
+
+    def allreduce_sum(x: int) -> int:
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
-        count = int(t.item())
+        return int(t.item())
 
-    stages = cbl.stage_times()  # rank 0's stream, HIP events around every launch group, timed steps only
-    total_kmers = kmers_per_rank * world * args.steps
-    value = total_kmers / dt
+    extra = {}
+    engine = None
+    if args.kind == "build":
+        d_bases, d_offsets = synth.reads_torch(42, NR, L, first_read=rank * NR, device=dev)
+        torch.cuda.synchronize()
+        cbl = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank, profile=True)
+        engine = sharded.ShardedBuilder(cbl, dist, slices=args.slices, protocol=args.protocol) if dist is not None else None
 
-    # dominant kernel of the step and its roofline position: ALGORITHMIC bytes per launch / average launch time
-    # (HIP events recorded on the ctx's own stream around every launch of that kernel, timed steps only)
-    alg = stage_alg_bytes(K, PB, L)
-    kernel_of = {"radix_scatter": "k_radix_scatter", "radix_hist": "k_radix_hist", "encode": "k_encode",
-                 "bucket_medium": "k_bucket_msd", "directory": "k_boundaries+k_bitvector+k_bucket_table", "chunks": "k_scan_invalid+chunk table"}
-    cand = {n: ms for n, (ms, _) in stages.items() if n in alg and ms > 0}
-    dom = max(cand, key=cand.get) if cand else None
-    roofline = None
-    if dom:
-        ms_total, launches = stages[dom]
+        def step(_i):
+            cbl.clear()
+            if engine is None:
+                cbl.insert_seqs_device(d_bases, d_offsets, NR)
+            else:
+                engine.insert_seqs_device(d_bases, d_offsets, NR)
+
+        units_per_rank_step = kmers_per_rank
+        alg = stage_alg_bytes(K, PB, L)
+        timed_ctx = cbl
+    else:
+        # `A |= B` (src/cbl.rs:433-449): A from the reads of seed 42, B from seed 43 (SURVEY.md §8d cfg 5). Every step merges B
+        # into a fresh copy of A made before the timed region (the merge changes self).
+        n_copies = args.steps + args.warmup
+        a_bases, a_off = synth.reads_torch(42, NR, L, first_read=rank * NR, device=dev)
+        b_bases, b_off = synth.reads_torch(43, NR, L, first_read=rank * NR, device=dev)
+        if dist is None:
+            A = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank)
+            A.insert_seqs_device(a_bases, a_off, NR)
+            B = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank)
+            B.insert_seqs_device(b_bases, b_off, NR)
+            copies = []
+            for _ in range(n_copies):
+                c = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank, profile=True)
+                c |= A  # merge into an empty index = clone
+                copies.append(c)
+            count_a, count_b = A.count(), B.count()
+
+            def step(i):
+                copies[i] |= B
+
+            last = lambda: copies[n_copies - 1]  # noqa: E731
+        else:
+            A = sharded.ShardedIndex(K, PB, dist, canonical=args.canonical, device=local_rank, slices=args.slices)
+            A.insert_seqs_device(a_bases, a_off, NR)
+            B = sharded.ShardedIndex(K, PB, dist, canonical=args.canonical, device=local_rank, slices=args.slices)
+            B.insert_seqs_device(b_bases, b_off, NR)  # its own quantile bounds
+            copies = [A.clone(profile=True) for _ in range(n_copies)]
+            count_a, count_b = A.local_count(), B.local_count()
+            engine = B  # exchange accounting of the re-shard
+
+            def step(i):
+                copies[i].merge_assign(B.resharded(copies[i].bounds))
+
+            last = lambda: copies[n_copies - 1].cbl  # noqa: E731
+        del a_bases, b_bases
+        torch.cuda.synchronize()
+        units_per_rank_step = count_b  # k-mers of B inserted into A per step (this rank's share)
+        alg = merge_alg_bytes(K, PB)
+        extra["merge"] = {"words_self": allreduce_sum(count_a), "words_other": allreduce_sum(count_b)}
+        timed_ctx = None
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    if args.kind == "build":
+        cbl.stage_times_reset()
+    if engine is not None and hasattr(engine, "reset_stats"):
+        engine.reset_stats()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = allreduce_max(time.perf_counter() - t0)
+
+    if args.kind == "build":
+        count = allreduce_sum(cbl.count())
+        stages = cbl.stage_times()  # rank 0's stream, HIP events around every launch group, timed steps only
+        units_alg = kmers_per_rank * args.steps  # k-mers through the kernels of this rank in the timed region
+    else:
+        count = allreduce_sum(last().count())
+        stages = {}
+        for c in copies[args.warmup:]:
+            cc = c if dist is None else c.cbl
+            for n, (ms, ln) in cc.stage_times().items():
+                a, b = stages.get(n, (0.0, 0))
+                stages[n] = (a + ms, b + ln)
+        units_alg = (count_a + count_b) * args.steps  # words of the merged runs
+        extra["merge"]["words_union"] = count
+    total_units = allreduce_sum(units_per_rank_step) * args.steps
+    value = total_units / dt
+
+    # every kernel group of the step against the HBM roofline: ALGORITHMIC bytes per launch / average launch time (HIP
+    # events recorded on the ctx's own stream around every launch of the group, timed steps only); `dom` = the slowest
+    kernels = []
+    for n, (ms, launches) in stages.items():
+        if ms <= 0 or n not in alg:
+            continue
         launches = max(int(launches), 1)
-        launch_ms = ms_total / launches
-        bytes_per_launch = alg[dom] * kmers_per_rank * args.steps / launches
-        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        bpl = alg[n] * units_alg / launches
+        ach = bpl / (ms / launches * 1e-3) / 1e9 if bpl else 0.0
+        kernels.append({"name": KERNEL_OF.get(n, n), "stage": n, "ms_per_step": round(ms / args.steps, 3), "launches_per_step": launches / args.steps,
+                        "launch_ms_avg": round(ms / launches, 3), "alg_bytes_per_launch": int(bpl), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4)})
+    kernels.sort(key=lambda x: -x["ms_per_step"])
+    roofline = None
+    if kernels:
+        dom = kernels[0]
         traffic = None
-        try:  # HBM bytes per launch from the committed PMC passes of this exact configuration (profiles/)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        try:  # HBM bytes per launch from the committed PMC passes — only if they were taken from exactly these sources
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             c = tj["config"]
-            if (c["k"], c["prefix_bits"], c["reads_per_gpu"], c["read_len"]) == (K, PB, NR, L) and tj["kernel"] == kernel_of.get(dom) and world == 1 and engine is None:
+            if (c["k"], c["prefix_bits"], c["reads_per_gpu"], c["read_len"], c.get("kind", "build")) == (K, PB, NR, L, args.kind) and \
+                    tj["kernel"] == dom["name"] and tj.get("src_sha") == source_hash() and world == 1 and engine is None:
                 traffic = tj["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-        b_alg = survey_b_alg(K, PB, L)
-        roofline = {
-            "bound": "hbm", "kernel": kernel_of.get(dom, dom), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-            "alg_bytes_per_launch": int(bytes_per_launch), "launch_ms_avg": round(launch_ms, 3),
-            "launches_per_step": launches / args.steps,
-            "whole_path": {  # SURVEY.md §8d accounting over the full step (per GPU)
+        roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom["frac"],
+                    "traffic": traffic, "alg_bytes_per_launch": dom["alg_bytes_per_launch"], "launch_ms_avg": dom["launch_ms_avg"],
+                    "launches_per_step": dom["launches_per_step"], "kernels": kernels,
+                    "stage_ms_per_step": {n: round(ms / args.steps, 3) for n, (ms, _) in stages.items() if ms > 0}}
+        if args.kind == "build":
+            b_alg = survey_b_alg(K, PB, L)
+            roofline["whole_path"] = {  # SURVEY.md §8d accounting over the full step (per GPU)
                 "b_alg_per_kmer": round(b_alg, 2),
                 "achieved": round(kmers_per_rank * args.steps / dt * b_alg / 1e9, 1),
-                "frac": round(kmers_per_rank * args.steps / dt * b_alg / 1e9 / HBM_PEAK_GBPS, 4),
-            },
-            "stage_ms_per_step": {n: round(ms / args.steps, 3) for n, (ms, _) in stages.items() if ms > 0},
-        }
+                "frac": round(kmers_per_rank * args.steps / dt * b_alg / 1e9 / HBM_PEAK_GBPS, 4)}
+        else:
+            by = word_layout(K, PB)[4]
+            roofline["whole_path"] = {  # 2 BYTES read + BYTES written per output suffix
+                "b_alg_per_output_word": 3 * by,
+                "achieved": round(count / max(world, 1) * args.steps / dt * 3 * by / 1e9, 1),
+                "frac": round(count / max(world, 1) * args.steps / dt * 3 * by / 1e9 / HBM_PEAK_GBPS, 4)}
+
+    exchange = None
+    if dist is not None and engine is not None and hasattr(engine, "stats"):
+        st = engine.stats
+        vec = torch.tensor([st["sent_bytes"], st["recv_bytes"]], dtype=torch.int64, device=dev)
+        parts = [torch.zeros_like(vec) for _ in range(world)]
+        dist.all_gather(parts, vec)
+        parts = [p.cpu().tolist() for p in parts]
+        out_s = allreduce_max(st["outstanding_s"])
+        sent = [p[0] // args.steps for p in parts]
+        recv = [p[1] // args.steps for p in parts]
+        peers = max(world - 1, 1)
+        exchange = {"world_size": dist.get_world_size(), "transport": transport, "protocol": args.protocol,
+                    "sent_bytes_per_rank_step": sent, "recv_bytes_per_rank_step": recv,
+                    "outstanding_ms_per_step": round(out_s / args.steps * 1e3, 3), "wait_ms_per_step": round(allreduce_max(st["wait_s"]) / args.steps * 1e3, 3),
+                    # bytes one rank pushes to ONE peer / the time its exchanges were in flight (they overlap the kernels of the next slice)
+                    "effective_gbps_per_link": round(max(sent) / peers / max(out_s / args.steps, 1e-9) / 1e9, 2) if out_s > 0 else None}
+
+    # PCIe-inclusive figure ("from bases resident in pinned host memory"): never `value`
+    h2d = None
+    if args.kind == "build" and world == 1 and dist is None and not args.no_h2d:
+        import numpy as np
+
+        hb = torch.empty(NR * L, dtype=torch.uint8, pin_memory=True)
+        ho = torch.empty(NR + 1, dtype=torch.int64, pin_memory=True)
+        hb.copy_(d_bases[: NR * L])
+        ho.copy_(d_offsets)
+        torch.cuda.synchronize()
+        nb_, no_ = hb.numpy(), ho.numpy().view(np.uint64)
+        ts = []
+        for _ in range(3):
+            cbl.clear()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            cbl.insert_seqs(nb_, no_)
+            cbl.flush()
+            ts.append(time.perf_counter() - t1)
+        h2d = {"value": round(kmers_per_rank / min(ts[1:]), 1), "unit": "k-mers/s", "ms_per_step": round(min(ts[1:]) * 1e3, 3),
+               "source": "pinned host memory (torch pin_memory) -> cblx_insert_seqs + cblx_flush, best of 2 after 1 warm-up"}
+        del hb, ho
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.kind == "build":
         from oracle import Oracle
 
-        ns = min(args.cpu_sample_reads, NR)
-        b, o = synth.reads(42, ns, L)
+        ns = NR if args.cpu_full else min(args.cpu_sample_reads, NR)
         orc = Oracle(K, PB, args.canonical)
-        secs = orc.insert_seqs(b, o)
+        secs, done, blk = 0.0, 0, 1_000_000
+        curve = []
+        while done < ns:  # fed in blocks of 1 M reads so that the decline with index size is on record
+            m = min(blk, ns - done)
+            b, o = synth.reads(42, m, L, first_read=done)
+            s1 = orc.insert_seqs(b, o)
+            secs += s1
+            done += m
+            curve.append(round(m * (L - K + 1) / s1 / 1e6, 2))
         cpu = {"value": round(ns * (L - K + 1) / secs, 1), "unit": "k-mers/s", "cores": 1, "kind": "port",
-               "sample": f"first {ns} of the same reads (seed 42), one insert_seq call per read, {secs:.1f} s; "
-                         "throughput falls as the index grows, so the full-size CPU figure is lower",
+               "sample": (f"all {ns} reads" if ns == NR else f"first {ns} of the same reads") + f" (seed 42), one insert_seq call per read, {secs:.1f} s"
+                         + ("" if ns == NR else "; throughput falls as the index grows, so the full-size CPU figure is lower (profiles/ holds a full run)"),
+               "mkmers_per_s_by_1M_read_block": curve if len(curve) > 1 else None,
                "host_cores_available": os.cpu_count()}
 
     out = None
     if rank == 0:
+        wb = word_layout(K, PB)[1]
+        if args.kind == "build":
+            workload = (f"{args.config}: K={K} ({wb}-bit word) PREFIX_BITS={PB} {NR}x{L}bp reads per GPU, "
+                        f"{'canonical' if args.canonical else 'non-canonical'}, build from empty index")
+            par = "1 GPU" if world == 1 else f"{world} GPUs: read-sharded encode + partition, prefix-range exchange ({args.protocol} protocol), per-range bucket insert"
+        else:
+            workload = (f"merge (cfg 5 per-GPU share): K={K} ({wb}-bit word) PREFIX_BITS={PB}, A |= B with A, B = indexes of {NR}x{L}bp reads per GPU each "
+                        f"(seeds 42 / 43); value = k-mers of B merged into A per second")
+            par = "1 GPU" if world == 1 else f"{world} GPUs: both operands prefix-range sharded, B re-sharded to A's bounds, per-rank merge"
         out = {
-            "metric": "k-mers inserted/sec (build index)", "value": round(value, 1), "unit": "k-mers/s", "n_gpus": world,
+            "metric": "k-mers inserted/sec (build index)" if args.kind == "build" else "k-mers inserted/sec (merge: self |= other)",
+            "value": round(value, 1), "unit": "k-mers/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic (iid ACGT reads, splitmix64 seed 42, resident in HBM)",
-            "config": {"workload": f"K={K} (68-bit word) PREFIX_BITS={PB} {NR}x{L}bp reads per GPU, "
-                                   f"{'canonical' if args.canonical else 'non-canonical'}, build from empty index",
-                       "k": K, "prefix_bits": PB, "reads_per_gpu": NR, "read_len": L,
-                       "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: read-sharded encode, prefix-range all-to-all"},
+            "config": {"workload": workload, "name": args.config, "k": K, "prefix_bits": PB, "reads_per_gpu": NR, "read_len": L, "parallelism": par},
             "distinct_kmers_in_index": count,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "value_h2d_inclusive": h2d["value"] if h2d else None, "h2d_inclusive": h2d,
+            "roofline": roofline, "cpu_baseline": cpu, "exchange": exchange,
         }
+        out.update(extra)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        tdist.destroy_process_group()
     if out is not None:  # last thing on stdout, on a line of its own
         sys.stdout.flush()
         sys.stdout.write("\n" + json.dumps(out) + "\n")
         sys.stdout.flush()
-
 
 
 if __name__ == "__main__":

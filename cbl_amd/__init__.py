@@ -36,6 +36,16 @@ class Consts(C.Structure):
                                           "threshold", "hi_bytes")]
 
 
+class ShardInfo(C.Structure):
+    _fields_ = [("header_entries", C.c_uint64), ("local_entries", C.c_uint64), ("begin_off", C.c_uint64), ("end_off", C.c_uint64),
+                ("first_prefix", C.c_uint32), ("last_prefix", C.c_uint32), ("exact", C.c_uint32), ("canonical", C.c_uint32)]
+
+
+class BucketView(C.Structure):
+    _fields_ = [("n_buckets", C.c_uint64), ("n_words", C.c_uint64), ("d_prefix", C.c_void_p), ("d_count", C.c_void_p), ("d_kind", C.c_void_p),
+                ("d_suffix", C.c_void_p)]
+
+
 class BatchView(C.Structure):
     _fields_ = [("n_buckets", C.c_uint64), ("n_words", C.c_uint64), ("d_prefix", C.c_void_p), ("d_count", C.c_void_p), ("d_suffix", C.c_void_p)]
 
@@ -65,6 +75,13 @@ SIGNATURES = {
                                           C.POINTER(C.c_uint64)]),
     "cblx_sorted_batch_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cblx_insert_sorted_batches_device": (C.c_int, [C.c_void_p, C.POINTER(BatchView), C.c_uint32]),
+    "cblx_load_shard_from_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(ShardInfo)]),
+    "cblx_index_shard_cuts": (C.c_int, [C.POINTER(Params), C.c_char_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "cblx_resident_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cblx_resident_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cblx_install_buckets_device": (C.c_int, [C.c_void_p, C.POINTER(BucketView), C.c_uint32]),
+    "cblx_serialized_body_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cblx_write_body_at": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64]),
     "cblx_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_num_buckets": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_is_empty": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
@@ -125,6 +142,24 @@ def _ptr(x):
     if hasattr(x, "ctypes"):
         return x.ctypes.data
     return int(x)
+
+
+def index_shard_cuts(path, k: int, prefix_bits: int, world: int, bounds=None, sequential: bool = False):
+    """Where `world` prefix ranges cut the entries of an index file (host only, no GPU): (byte offsets[world + 1],
+    first prefixes[world + 1], ok)."""
+    import numpy as np
+
+    L = lib()
+    p = Params(k, prefix_bits, 0, -1, 0, 0)
+    b = np.ascontiguousarray(bounds, dtype=np.uint32) if bounds is not None else None
+    offs = np.zeros(world + 1, dtype=np.uint64)
+    first = np.zeros(world + 1, dtype=np.uint32)
+    ok = C.c_int(0)
+    rc = L.cblx_index_shard_cuts(C.byref(p), os.fsencode(path), world, b.ctypes.data if b is not None and len(b) else None, int(sequential),
+                                 offs.ctypes.data, first.ctypes.data, C.byref(ok))
+    if rc != OK:
+        raise CblxError(rc, L.cblx_last_global_error().decode())
+    return offs, first, bool(ok.value)
 
 
 class CBL:
@@ -237,6 +272,48 @@ class CBL:
         for i, (nb, nw, p, c, s) in enumerate(batches):
             arr[i] = BatchView(nb, nw, _ptr(p) if nb else None, _ptr(c) if nb else None, _ptr(s) if nw else None)
         self._chk(self._L.cblx_insert_sorted_batches_device(self._h, arr, len(batches)))
+
+    # ---- prefix-range sharded indexes (include/cblx.h): one rank's share -------------------------------------------------
+    def load_shard_from_file(self, path, rank: int, world: int, bounds=None, sequential: bool = False):
+        """This rank's prefix range of an index file. Returns (info dict, bounds as a numpy uint32 array of world-1 values).
+        The caller checks info["exact"] and the entry counts over all ranks (cbl_amd.sharded.ShardedIndex does)."""
+        import numpy as np
+
+        b = np.ascontiguousarray(bounds, dtype=np.uint32) if bounds is not None else None
+        out = np.zeros(max(world - 1, 1), dtype=np.uint32)
+        info = ShardInfo()
+        self._chk(self._L.cblx_load_shard_from_file(self._h, os.fsencode(path), rank, world, b.ctypes.data if b is not None and len(b) else None,
+                                                    int(sequential), out.ctypes.data, C.byref(info)))
+        return {n: getattr(info, n) for n, _ in ShardInfo._fields_}, out[: world - 1]
+
+    def resident_split(self, bounds, nd: int):
+        """(bucket_split, word_split), nd + 1 entries each: where the bounds cut the resident index."""
+        import numpy as np
+
+        b = np.ascontiguousarray(bounds, dtype=np.uint32)
+        bs = (C.c_uint64 * (nd + 1))()
+        ws = (C.c_uint64 * (nd + 1))()
+        self._chk(self._L.cblx_resident_split(self._h, b.ctypes.data if len(b) else None, nd, bs, ws))
+        return list(bs), list(ws)
+
+    def resident_export(self, d_prefix, d_count, d_kind, d_suffix):
+        self._chk(self._L.cblx_resident_export(self._h, _ptr(d_prefix), _ptr(d_count), _ptr(d_kind), _ptr(d_suffix)))
+
+    def install_buckets_device(self, parts):
+        """parts: [(n_buckets, n_words, d_prefix, d_count, d_kind, d_suffix)], ascending prefixes over the concatenation."""
+        arr = (BucketView * max(len(parts), 1))()
+        for i, (nb, nw, p, c, k, s) in enumerate(parts):
+            arr[i] = BucketView(nb, nw, _ptr(p) if nb else None, _ptr(c) if nb else None, _ptr(k) if nb else None, _ptr(s) if nw else None)
+        self._chk(self._L.cblx_install_buckets_device(self._h, arr, len(parts)))
+
+    def serialized_body_size(self):
+        """(entries, bytes) of the serialized index without its header."""
+        ne, nb = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.cblx_serialized_body_size(self._h, C.byref(ne), C.byref(nb)))
+        return ne.value, nb.value
+
+    def write_body_at(self, path, file_off: int):
+        self._chk(self._L.cblx_write_body_at(self._h, os.fsencode(path), file_off))
 
     def flush(self):
         self._chk(self._L.cblx_flush(self._h))

@@ -5,7 +5,7 @@
 // (/root/reference/src/wordset/mod.rs:18-26: prefix bitvector + rank->bucket directory + suffix containers) held in
 // HBM: bitvector words, popcount-scan rank directory, bucket table indexed by rank, one suffix arena.
 // There is no CPU fallback: every data-path step below is a kernel launch.
-#include "host_index.hpp"
+#include "shard.hpp"
 
 namespace {
 
@@ -24,6 +24,21 @@ template <typename F> int guard(cblx_ctx* c, F&& f) {
         (c ? c->err : g_global_err) = e.what();
         return CBLX_EINVAL;
     }
+}
+
+// CBL::new's asserts (src/cbl.rs:87-91, src/wordset/mod.rs:37-41) and the derived constants (src/cbl.rs:16-32,65-67)
+Consts make_consts(const cblx_params& p) {
+    if (p.k < 5 || p.k > 59 || (p.k & 1) == 0) throw Error(CBLX_EINVAL, "K must be odd and in [5, 59]");
+    Consts P;
+    P.K = p.k; P.PB = p.prefix_bits; P.KB = 2 * p.k; P.POS = ilog2_npo2(P.KB); P.WB = P.KB + P.POS;
+    P.canonical = p.canonical ? 1 : 0;
+    if (P.PB < 1 || P.PB > 32) throw Error(CBLX_EINVAL, "PREFIX_BITS=" + std::to_string(P.PB) + " but it should be in [1, 32]");
+    if (P.PB > 28) throw Error(CBLX_EINVAL, "PREFIX_BITS > 28 is not supported (README.md:130 caps it at 28)");
+    if (P.WB <= P.PB) throw Error(CBLX_EINVAL, "SUFFIX_BITS should be != 0");
+    if (P.WB > 128) throw Error(CBLX_EINVAL, "Cannot fit a K-mer and its length in a 128-bit integer");
+    P.SB = P.WB - P.PB;
+    P.BYTES = (P.SB + 7) / 8;
+    return P;
 }
 
 // words of the k-mers of one host sequence, on the device (KRN-1 over a one-sequence batch)
@@ -125,16 +140,7 @@ int cblx_create(const cblx_params* p, cblx_ctx** out) {
     return guard(nullptr, [&] {
         if (!p || !out) throw Error(CBLX_EINVAL, "null argument");
         *out = nullptr;
-        if (p->k < 5 || p->k > 59 || (p->k & 1) == 0) throw Error(CBLX_EINVAL, "K must be odd and in [5, 59]");
-        Consts P;
-        P.K = p->k; P.PB = p->prefix_bits; P.KB = 2 * p->k; P.POS = ilog2_npo2(P.KB); P.WB = P.KB + P.POS;
-        P.canonical = p->canonical ? 1 : 0;
-        if (P.PB < 1 || P.PB > 32) throw Error(CBLX_EINVAL, "PREFIX_BITS=" + std::to_string(P.PB) + " but it should be in [1, 32]");
-        if (P.PB > 28) throw Error(CBLX_EINVAL, "PREFIX_BITS > 28 is not supported (README.md:130 caps it at 28)");
-        if (P.WB <= P.PB) throw Error(CBLX_EINVAL, "SUFFIX_BITS should be != 0");
-        if (P.WB > 128) throw Error(CBLX_EINVAL, "Cannot fit a K-mer and its length in a 128-bit integer");
-        P.SB = P.WB - P.PB;
-        P.BYTES = (P.SB + 7) / 8;
+        const Consts P = make_consts(*p);
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw Error(CBLX_EDEVICE, "no HIP device available (libcblx has no CPU fallback)");
         int dev = p->device;
@@ -491,6 +497,100 @@ int cblx_load_from_file(cblx_ctx* c, const char* path) {
     const int rc = cblx_load(c, (const u8*)m, len);
     ::munmap(m, len);
     return rc;
+}
+int cblx_load_shard_from_file(cblx_ctx* c, const char* path, uint32_t rank, uint32_t world, const uint32_t* bounds, int sequential, uint32_t* bounds_out,
+                              cblx_shard_info* info) {
+    return guard(c, [&] {
+        if (!path || !info) throw Error(CBLX_EINVAL, "null argument");
+        if (world == 0 || rank >= world) throw Error(CBLX_EINVAL, "rank must be below world");
+        for (u32 d = 0; bounds && d + 2 < world; ++d) if (bounds[d + 1] < bounds[d]) throw Error(CBLX_EINVAL, "bounds must be ascending");
+        std::memset(info, 0, sizeof *info);
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+        ingest_drop(c);
+        c->res = Resident();
+        MappedFile f(path);
+        Src s{f.d, f.d + f.n};
+        const bool canon = s.u8_() != 0;
+        const u64 nb = s.varint();
+        if (nb > (1ull << c->P.PB)) throw Error(CBLX_EFORMAT, "index: more buckets than prefixes (wrong PREFIX_BITS?)");
+        info->header_entries = nb;
+        info->canonical = canon ? 1 : 0;
+        c->P.canonical = canon ? 1 : 0;
+        const u8 *body = s.p, *end = f.d + f.n;
+        auto run = [&](auto ws) {
+            constexpr bool WS = decltype(ws)::value;
+            const ShardCuts cuts = shard_cuts<WS>(body, end, c->P, world, bounds, sequential != 0);
+            info->begin_off = (u64)(cuts.start[rank] - f.d);
+            info->end_off = (u64)(cuts.start[rank + 1] - f.d);
+            for (u32 r = 1; bounds_out && r < world; ++r) bounds_out[r - 1] = bounds ? bounds[r - 1] : cuts.first[r];
+            if (!cuts.ok) { info->exact = 0; return; }
+            bool exact = true;
+            load_range<WS>(c, cuts.start[rank], cuts.start[rank + 1], info->local_entries, exact, info->first_prefix, info->last_prefix);
+            // the loaded prefixes must lie in this rank's range (a speculative start that parsed anyway would not)
+            if (exact && info->local_entries) {
+                const u32 lo_b = rank ? (bounds ? bounds[rank - 1] : cuts.first[rank]) : 0u;
+                const u64 hi_b = rank + 1 < world ? (u64)(bounds ? bounds[rank] : cuts.first[rank + 1]) : (1ull << c->P.PB);
+                if (info->first_prefix < lo_b || (u64)info->last_prefix >= hi_b) exact = false;
+            }
+            if (!exact) { c->res = Resident(); info->local_entries = 0; }
+            info->exact = exact ? 1 : 0;
+        };
+        if (c->P.wide_suffix()) run(std::true_type()); else run(std::false_type());
+    });
+}
+int cblx_index_shard_cuts(const cblx_params* p, const char* path, uint32_t world, const uint32_t* bounds, int sequential, uint64_t* offs, uint32_t* first,
+                          int* ok) {
+    return guard(nullptr, [&] {
+        if (!p || !path || !offs || !first || !ok || world == 0) throw Error(CBLX_EINVAL, "null argument");
+        const Consts P = make_consts(*p);
+        MappedFile f(path);
+        Src s{f.d, f.d + f.n};
+        (void)s.u8_();
+        (void)s.varint();
+        ShardCuts cuts;
+        if (P.wide_suffix()) cuts = shard_cuts<true>(s.p, f.d + f.n, P, world, bounds, sequential != 0);
+        else cuts = shard_cuts<false>(s.p, f.d + f.n, P, world, bounds, sequential != 0);
+        for (u32 r = 0; r <= world; ++r) { offs[r] = (u64)(cuts.start[r] - f.d); first[r] = cuts.first[r]; }
+        *ok = cuts.ok ? 1 : 0;
+    });
+}
+int cblx_resident_split(cblx_ctx* c, const uint32_t* bounds, uint32_t nd, uint64_t* bucket_split, uint64_t* word_split) {
+    return guard(c, [&] {
+        if (nd == 0 || !bucket_split || !word_split || (nd > 1 && !bounds)) throw Error(CBLX_EINVAL, "null argument");
+        for (u32 d = 0; d + 2 < nd; ++d) if (bounds[d + 1] < bounds[d]) throw Error(CBLX_EINVAL, "bounds must be ascending");
+        flush(c);
+        resident_split(c, bounds, nd, bucket_split, word_split);
+    });
+}
+int cblx_resident_export(cblx_ctx* c, uint32_t* d_prefix, uint32_t* d_count, uint8_t* d_kind, uint8_t* d_suffix) {
+    return guard(c, [&] {
+        flush(c);
+        if (c->res.nb && (!d_prefix || !d_count || !d_kind || !d_suffix)) throw Error(CBLX_EINVAL, "null argument");
+        dispatch(c->P, [&](auto cfg) { resident_export<decltype(cfg)>(c, d_prefix, d_count, d_kind, d_suffix); });
+    });
+}
+int cblx_install_buckets_device(cblx_ctx* c, const cblx_bucket_view* parts, uint32_t n_parts) {
+    return guard(c, [&] {
+        if (n_parts && !parts) throw Error(CBLX_EINVAL, "null argument");
+        dispatch(c->P, [&](auto cfg) { install_buckets<decltype(cfg)>(c, parts, n_parts); });
+    });
+}
+int cblx_serialized_body_size(cblx_ctx* c, uint64_t* n_entries, uint64_t* nbytes) {
+    return guard(c, [&] {
+        if (!n_entries || !nbytes) throw Error(CBLX_EINVAL, "null argument");
+        flush(c);
+        BodyImage im;
+        body_image(c, false, im);
+        *n_entries = c->res.nb;
+        *nbytes = im.total - im.hdr;
+    });
+}
+int cblx_write_body_at(cblx_ctx* c, const char* path, uint64_t file_off) {
+    return guard(c, [&] {
+        if (!path) throw Error(CBLX_EINVAL, "null argument");
+        flush(c);
+        write_body_at(c, path, file_off);
+    });
 }
 int cblx_merge_assign(cblx_ctx* self, cblx_ctx* other) {
     return guard(self, [&] {

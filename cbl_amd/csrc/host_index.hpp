@@ -500,10 +500,12 @@ void parse_entry(Src& s, const Consts& P, u64 nprefix, Out& out, u32& prefix_out
             if ((u64)(s.end - s.p) >= (u64)k * (1 + BYTES) + 16) {
                 const u8* q = s.p;
                 bool regular = true;
+                if (STRICT && q[0] != BYTES) throw Error(CBLX_EFORMAT, "index: element length byte");  // recogniser probes fail here, not after k elements
                 for (size_t i = 0; i < k; ++i, q += 1 + BYTES) {
                     regular &= q[0] == BYTES;
                     ol[i] = load_le64(q + 1) & lo_mask;
                     if (WS) oh[i] = load_le64(q + 9) & hi_mask;
+                    if (STRICT && !regular) break;
                 }
                 if (regular) { s.p = q; out.commit_lo(k); if (WS) out.commit_hi(k); left -= k; continue; }
                 if (STRICT) throw Error(CBLX_EFORMAT, "index: element length byte");
@@ -580,41 +582,115 @@ void parse_entry(Src& s, const Consts& P, u64 nprefix, Out& out, u32& prefix_out
 // device buffer. A wrong guess cannot survive: thread t must stop EXACTLY at start_t+1, the entries must add up to the
 // header's count and the prefixes must ascend across regions — anything else sends the whole file down the sequential
 // path (which also owns the error messages).
-template <bool WS> const u8* find_entry_start(const u8* from, const u8* end, const Consts& P, u64 nprefix, NullOut& dry) {
-    const u8* stop = std::min(end, from + (32u << 20));
+// A recognised start may still be a FAKE one: the tail of a Vec entry whose elements end in `00 00 01` reads as the entry
+// `prefix 0, Vec, 1 element` followed by the true entries. Such a fake entry ends exactly where a true one starts (the
+// entries after it parse), so the SECOND entry of a recognised run is a true one: callers only trust boundaries and
+// prefixes from the second entry on, and reach the boundary they want by walking forward from there.
+enum { FIND_OK = 0, FIND_NONE = 1, FIND_GAVE_UP = 2 };
+static const u64 FIND_LIMIT = 64ull << 20;
+struct Found {
+    const u8* at = nullptr;   // recognised start (possibly fake)
+    const u8* at2 = nullptr;  // start of the entry after it (trusted); null when the run has one entry only
+    u32 prefix2 = 0;
+};
+template <bool WS> int find_entry(const u8* from, const u8* end, const Consts& P, u64 nprefix, NullOut& dry, Found& f) {
+    if (from >= end) return FIND_NONE;
+    const u8* stop = std::min(end, from + FIND_LIMIT);
     for (const u8* p = from; p < stop; ++p) {
-        if (*p > 250 && *p != 0xFB && *p != 0xFC) continue;  // a prefix is a varint of at most 32 bits
+        {   // cheap rejection without an exception: a prefix is a varint of at most 32 bits below 2^PREFIX_BITS, the tag is 0 or 1
+            u64 pv = *p;
+            const u8* q = p + 1;
+            if (pv > 250) {
+                const int nbts = pv == 0xFB ? 2 : pv == 0xFC ? 4 : 0;
+                if (!nbts || (u64)(end - q) < (u64)nbts) continue;
+                pv = 0;
+                for (int i = 0; i < nbts; ++i) pv |= (u64)q[i] << (8 * i);
+                q += nbts;
+            }
+            if (pv >= nprefix || q >= end || *q > 1) continue;
+        }
         try {
             Src s{p, end};
-            u32 last = 0, pf, cn;
+            u32 last = 0, pf = 0, cn;
             u8 kd;
             int e = 0;
+            Found g;
+            g.at = p;
             for (; e < 4 && s.p < end; ++e) {
+                const u8* here = s.p;
                 parse_entry<WS, true>(s, P, nprefix, dry, pf, cn, kd);
                 if (e && pf <= last) throw Error(CBLX_EFORMAT, "prefix order");
+                if (e == 1) { g.at2 = here; g.prefix2 = pf; }
                 last = pf;
             }
-            if (e >= 2 || s.p == end) return p;
+            if (e >= 2 || s.p == end) { f = g; return FIND_OK; }
         } catch (const Error&) {
         }
     }
-    return nullptr;
+    return stop == end ? FIND_NONE : FIND_GAVE_UP;
 }
-template <bool WS> bool load_parallel(cblx_ctx* c, const Consts& P, const u8* body, const u8* end, u64 nb, u64 nprefix) {
+
+// strict walk over the entries from a trusted start `from`: first entry start that satisfies pred(offset, prefix), or `end`
+template <bool WS, typename Pred>
+const u8* walk_to(const u8* from, const u8* end, const Consts& P, u64 nprefix, NullOut& dry, Pred&& pred, u32& first_prefix, bool& ok) {
+    try {
+        Src s{from, end};
+        while (s.p < end) {
+            const u8* here = s.p;
+            u32 pf, cn;
+            u8 kd;
+            parse_entry<WS, true>(s, P, nprefix, dry, pf, cn, kd);
+            if (pred(here, pf)) { first_prefix = pf; return here; }
+        }
+    } catch (const Error&) {
+        ok = false;
+    }
+    first_prefix = (u32)std::min<u64>(nprefix, 0xFFFFFFFFull);
+    return end;
+}
+
+// first entry start at or after byte `cut`: synchronise on a run recognised well BEFORE the cut, walk forward from its
+// second entry
+template <bool WS> const u8* seek_offset(const u8* body, const u8* end, const Consts& P, u64 nprefix, const u8* cut, NullOut& dry, u32& first_prefix, bool& ok) {
+    auto pred = [&](const u8* here, u32) { return here >= cut; };
+    for (u64 back = 64u << 10;; back *= 8) {
+        if ((u64)(cut - body) <= back) return walk_to<WS>(body, end, P, nprefix, dry, pred, first_prefix, ok);
+        Found f;
+        const int st = find_entry<WS>(cut - back, end, P, nprefix, dry, f);
+        if (st == FIND_GAVE_UP) { ok = false; return end; }
+        if (st == FIND_NONE) { first_prefix = (u32)std::min<u64>(nprefix, 0xFFFFFFFFull); return end; }  // `cut - back` lies in the last entry
+        if (f.at2 && f.at2 <= cut) return walk_to<WS>(f.at2, end, P, nprefix, dry, pred, first_prefix, ok);
+        if (!f.at2 && f.at < cut) {  // a single (last) entry recognised in front of the cut: nothing starts after the cut
+            first_prefix = (u32)std::min<u64>(nprefix, 0xFFFFFFFFull);
+            return end;
+        }
+        // the trusted boundary lies beyond the cut: look further back
+    }
+}
+
+// nb = NB_UNKNOWN: a byte range of a file whose entry count is not known (sharded load); *n_entries receives the count
+static const u64 NB_UNKNOWN = ~0ull;
+template <bool WS> bool load_parallel(cblx_ctx* c, const Consts& P, const u8* body, const u8* end, u64 nb, u64 nprefix, u64* n_entries = nullptr) {
     const u64 len = (u64)(end - body);
     unsigned hc = std::thread::hardware_concurrency();
     unsigned T = (unsigned)std::min<u64>({16ull, hc ? hc / 2 : 1ull, len / (48ull << 20)});
     if (const char* e = std::getenv("CBLX_LOAD_THREADS")) T = (unsigned)std::strtoul(e, nullptr, 10);
-    if (T < 2 || nb < 8 * (u64)T) return false;
+    if (T < 2 || (nb != NB_UNKNOWN && nb < 8 * (u64)T) || len < 64 * (u64)T) return false;
     std::vector<const u8*> start(T + 1, nullptr);
     start[0] = body;
     start[T] = end;
     {   // entry starts near the even cuts, found in parallel
         std::vector<std::thread> th;
         for (unsigned t = 1; t < T; ++t)
-            th.emplace_back([&, t] { NullOut dry; start[t] = find_entry_start<WS>(body + len / T * t, end, P, nprefix, dry); });
+            th.emplace_back([&, t] {
+                NullOut dry;
+                u32 pf;
+                bool ok = true;
+                const u8* at = seek_offset<WS>(body, end, P, nprefix, body + len / T * t, dry, pf, ok);
+                start[t] = ok ? at : nullptr;
+            });
         for (auto& x : th) x.join();
-        for (unsigned t = 1; t < T; ++t) if (!start[t] || start[t] <= start[t - 1]) return false;
+        for (unsigned t = 1; t < T; ++t) if (!start[t] || start[t] < start[t - 1]) return false;
     }
     struct Part {
         std::vector<u32> prefix, cnt;
@@ -642,7 +718,7 @@ template <bool WS> bool load_parallel(cblx_ctx* c, const Consts& P, const u8* bo
                     u32 pf, cn;
                     u8 kd;
                     while (s.p < start[t + 1]) {
-                        parse_entry<WS, false>(s, P, nprefix, out, pf, cn, kd);
+                        parse_entry<WS, true>(s, P, nprefix, out, pf, cn, kd);
                         pt.prefix.push_back(pf); pt.cnt.push_back(cn); pt.kind.push_back(kd);
                         pt.total += cn;
                     }
@@ -656,17 +732,24 @@ template <bool WS> bool load_parallel(cblx_ctx* c, const Consts& P, const u8* bo
         for (auto& x : th) x.join();
     }
     u64 total = 0, entries = 0;
+    bool have_last = false;
+    u32 last_prefix = 0;
     for (unsigned t = 0; t < T; ++t) {
         if (!part[t].ok) return false;
-        if (t && !part[t].prefix.empty() && !part[t - 1].prefix.empty() && part[t].prefix.front() <= part[t - 1].prefix.back()) return false;
+        if (!part[t].prefix.empty()) {
+            if (have_last && part[t].prefix.front() <= last_prefix) return false;
+            last_prefix = part[t].prefix.back();
+            have_last = true;
+        }
         total += part[t].total;
         entries += part[t].prefix.size();
     }
-    if (entries != nb) return false;
+    if (nb != NB_UNKNOWN && entries != nb) return false;
+    if (n_entries) *n_entries = entries;
     if (total >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "index: more than 2^32 - 16 words (per-GPU limit of this build)");
     std::vector<u32> prefix, cnt;
     std::vector<u8> kind;
-    prefix.reserve(nb); cnt.reserve(nb); kind.reserve(nb);
+    prefix.reserve(entries); cnt.reserve(entries); kind.reserve(entries);
     Buf<u64> a_lo(c->pool, total + 2), a_hi;
     if (WS) a_hi = Buf<u64>(c->pool, total + 2);
     u64 at = 0;
@@ -703,7 +786,7 @@ template <bool WS> void load_stream(cblx_ctx* c, const u8* data, u64 len, bool& 
     StreamOut out{&lo, hi.get()};
     u64 total = 0;
     for (u64 r = 0; r < nb; ++r) {
-        parse_entry<WS, false>(s, P, nprefix, out, prefix[r], cnt[r], kind[r]);
+        parse_entry<WS, true>(s, P, nprefix, out, prefix[r], cnt[r], kind[r]);
         total += cnt[r];
     }
     if (s.p != s.end) throw Error(CBLX_EFORMAT, "index: trailing bytes");  // reject_trailing_bytes

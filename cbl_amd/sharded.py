@@ -25,9 +25,12 @@ concatenated in rank order (`gather_serialized`).
 """
 from __future__ import annotations
 
+import time
+
 import numpy as np
 
 MAX_MSG_BYTES = 256 << 20  # cap of one point-to-point message of the exchange
+MAX_DEST = 16  # cblx.h: the destination partition takes at most 16 prefix ranges
 HIST_BITS = 16      # resolution of the splitter histogram (top bits of the prefix)
 SAMPLE_STRIDE = 61  # every 61st word feeds the histogram
 
@@ -129,7 +132,85 @@ class GpuEngine:
         self.cbl.insert_sorted_batches_device(batches)
 
 
-class ShardedBuilder:
+class _Wire:
+    """The personalised exchange both the sharded build and the re-shard of a sharded index run over the process group,
+    with its accounting."""
+
+    def _wire_init(self, dist):
+        self.dist = dist
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        if self.world > MAX_DEST:
+            raise ValueError(f"at most {MAX_DEST} ranks (the destination partition of libcblx takes <= {MAX_DEST} ranges), got {self.world}")
+        # exchange accounting since the last reset_stats(): bytes that left / reached this rank (own run excluded), the
+        # wall time during which an exchange was outstanding (first issue -> last wait of each call) and the time this
+        # rank spent blocked in those waits
+        self.stats = {"sent_bytes": 0, "recv_bytes": 0, "outstanding_s": 0.0, "wait_s": 0.0, "messages": 0}
+        self._t_first_issue = None
+
+    def _exchange(self, src, dst, send_l, recv_l):
+        """Personalised exchange: src holds the runs for rank 0..W-1 back to back (send_l), dst receives the runs of
+        source rank 0..W-1 back to back (recv_l). Grouped point-to-point (what RCCL's all-to-all is built from), every
+        message capped at MAX_MSG_BYTES: torch/RCCL all_to_all_single was measured here to drop data once a message
+        reaches 2^31 bytes or 2^30 elements (tools/dev_a2a_check.py). The rank's own run is a local copy.
+        Returns the outstanding requests."""
+        dist, W, me = self.dist, self.world, self.rank
+        step = max(1, MAX_MSG_BYTES // src.element_size())
+        soff = [0] * (W + 1)
+        roff = [0] * (W + 1)
+        for r in range(W):
+            soff[r + 1] = soff[r] + send_l[r]
+            roff[r + 1] = roff[r] + recv_l[r]
+        dst[roff[me] : roff[me + 1]].copy_(src[soff[me] : soff[me + 1]])
+        es = src.element_size()
+        self.stats["sent_bytes"] += (soff[W] - send_l[me]) * es
+        self.stats["recv_bytes"] += (roff[W] - recv_l[me]) * es
+        if self._t_first_issue is None:
+            self._t_first_issue = time.perf_counter()
+        ops = []
+        for d in range(1, W):  # ring order keeps the pairing of sends and receives symmetric across ranks
+            to, frm = (me + d) % W, (me - d) % W
+            for o in range(0, send_l[to], step):
+                ops.append(dist.P2POp(dist.isend, src[soff[to] + o : soff[to] + min(o + step, send_l[to])], to))
+            for o in range(0, recv_l[frm], step):
+                ops.append(dist.P2POp(dist.irecv, dst[roff[frm] + o : roff[frm] + min(o + step, recv_l[frm])], frm))
+        self.stats["messages"] += len(ops)
+        return list(dist.batch_isend_irecv(ops)) if ops else []
+
+    def _drain(self, inflight, probe):
+        """Wait for every outstanding exchange of this call, then hand the received buffers over to libcblx's own stream
+        (on the host: the library does not run on torch's stream)."""
+        t0 = time.perf_counter()
+        for works, *_ in inflight:
+            for x in works:
+                x.wait()
+        if probe is not None and getattr(probe, "is_cuda", False):
+            import torch
+
+            torch.cuda.current_stream(probe.device).synchronize()
+        t1 = time.perf_counter()
+        self.stats["wait_s"] += t1 - t0
+        if self._t_first_issue is not None:
+            self.stats["outstanding_s"] += t1 - self._t_first_issue
+            self._t_first_issue = None
+
+    def reset_stats(self):
+        for k in self.stats:
+            self.stats[k] = 0 if isinstance(self.stats[k], int) else 0.0
+
+    def _host_tensor_device(self):
+        return "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+
+    def _all_reduce_ints(self, vals, op="sum"):
+        import torch
+
+        t = torch.tensor(list(vals), dtype=torch.int64, device=self._host_tensor_device())
+        R = self.dist.ReduceOp
+        self.dist.all_reduce(t, op={"sum": R.SUM, "min": R.MIN, "max": R.MAX}[op])
+        return [int(x) for x in t.cpu().tolist()]
+
+
+class ShardedBuilder(_Wire):
     """`insert_seqs_device` over a process group: every rank passes ITS contiguous shard of the reads.
 
     The shard is consumed in `slices` slices so that the all-to-all of slice c overlaps the encode + partition of slice
@@ -139,13 +220,12 @@ class ShardedBuilder:
     """
 
     def __init__(self, cbl, dist, engine=None, slices: int = 4, slack: float = 1.3, protocol: str = "sorted"):
-        self.cbl, self.dist = cbl, dist
+        self.cbl = cbl
         self.engine = engine or GpuEngine(cbl)
         if protocol not in ("sorted", "words"):
             raise ValueError("protocol must be 'sorted' or 'words'")
         self.protocol = protocol if hasattr(self.engine, "sorted_batch_begin") else "words"
-        self.world = dist.get_world_size()
-        self.rank = dist.get_rank()
+        self._wire_init(dist)
         self.slices, self.slack = max(1, slices), slack
         self.bounds = None  # fixed by the first batch so later batches land on the same owners
         self.last_counts = None
@@ -211,11 +291,7 @@ class ShardedBuilder:
             slices_in.append((recv_b, recv_w, prefix_r, count_r, suffix_r))
             send_tot = [x + y for x, y in zip(send_tot, send_w)]
             recv_tot = [x + y for x, y in zip(recv_tot, recv_w)]
-        for works, *_ in inflight:
-            for x in works:
-                x.wait()
-        if slices_in and slices_in[0][2].is_cuda:
-            torch.cuda.current_stream(slices_in[0][2].device).synchronize()  # libcblx runs on its own stream: hand over on the host
+        self._drain(inflight, slices_in[0][2] if slices_in else None)
         inflight = []
         self.last_counts = (send_tot, recv_tot)
         batches = []  # stream order: slice-major, source-rank-minor
@@ -283,41 +359,300 @@ class ShardedBuilder:
             filled += n_recv
             send_tot = [x + y for x, y in zip(send_tot, send_l)]
             recv_tot = [x + y for x, y in zip(recv_tot, recv_l)]
-        for works, *_ in inflight:
-            for x in works:
-                x.wait()
-        if recv_lo is not None and recv_lo.is_cuda:
-            torch.cuda.current_stream(recv_lo.device).synchronize()  # libcblx runs on its own stream: hand over on the host
+        self._drain(inflight, recv_lo)
         inflight = []
         self.last_counts = (send_tot, recv_tot)
         if filled:
             eng.insert_words(recv_lo[:filled], recv_hi[:filled] if recv_hi is not None else None)
 
-    def _exchange(self, src, dst, send_l, recv_l):
-        """Personalised exchange: src holds the runs for rank 0..W-1 back to back (send_l), dst receives the runs of
-        source rank 0..W-1 back to back (recv_l). Grouped point-to-point (what RCCL's all-to-all is built from), every
-        message capped at MAX_MSG_BYTES: torch/RCCL all_to_all_single was measured here to drop data once a message
-        reaches 2^31 bytes or 2^30 elements (tools/dev_a2a_check.py). The rank's own run is a local copy.
-        Returns the outstanding requests."""
-        dist, W, me = self.dist, self.world, self.rank
-        step = max(1, MAX_MSG_BYTES // src.element_size())
-        soff = [0] * (W + 1)
-        roff = [0] * (W + 1)
-        for r in range(W):
-            soff[r + 1] = soff[r] + send_l[r]
-            roff[r + 1] = roff[r] + recv_l[r]
-        dst[roff[me] : roff[me + 1]].copy_(src[soff[me] : soff[me + 1]])
-        ops = []
-        for d in range(1, W):  # ring order keeps the pairing of sends and receives symmetric across ranks
-            to, frm = (me + d) % W, (me - d) % W
-            for o in range(0, send_l[to], step):
-                ops.append(dist.P2POp(dist.isend, src[soff[to] + o : soff[to] + min(o + step, send_l[to])], to))
-            for o in range(0, recv_l[frm], step):
-                ops.append(dist.P2POp(dist.irecv, dst[roff[frm] + o : roff[frm] + min(o + step, recv_l[frm])], frm))
-        return list(dist.batch_isend_irecv(ops)) if ops else []
-
     def reset(self):
         self.bounds = None
+
+
+class GpuShard:
+    """One rank's share of a sharded index on libcblx: the device steps ShardedIndex drives (torch tensors only carry the
+    device memory that crosses the wire)."""
+
+    def __init__(self, cbl, device=None):
+        import torch
+
+        self.cbl, self.torch = cbl, torch
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    def new_like(self, profile: bool = False) -> "GpuShard":
+        from . import CBL
+
+        dev = self.device.index if self.device.index is not None else -1
+        return GpuShard(CBL(self.cbl.k, self.cbl.prefix_bits, canonical=self.cbl.is_canonical(), device=dev, profile=profile), self.device)
+
+    def builder_engine(self):
+        return GpuEngine(self.cbl)
+
+    def count(self) -> int:
+        return self.cbl.count()
+
+    def is_canonical(self) -> bool:
+        return self.cbl.is_canonical()
+
+    def suffix_bytes(self) -> int:
+        return self.cbl.consts()["bytes"]
+
+    def load_shard(self, path, rank, world, bounds, sequential):
+        return self.cbl.load_shard_from_file(path, rank, world, bounds, sequential)
+
+    def split(self, bounds, nd):
+        return self.cbl.resident_split(bounds, nd)
+
+    def export(self):
+        """(prefix int32, count int32, kind uint8, packed suffixes uint8) of the whole resident share, on the device."""
+        t = self.torch
+        nb, nw, B = self.cbl.num_buckets(), self.cbl.count(), self.suffix_bytes()
+        prefix = t.empty(max(nb, 1), dtype=t.int32, device=self.device)
+        count = t.empty(max(nb, 1), dtype=t.int32, device=self.device)
+        kind = t.empty(max(nb, 1), dtype=t.uint8, device=self.device)
+        suffix = t.empty(max(nw * B, 1), dtype=t.uint8, device=self.device)
+        self.cbl.resident_export(prefix, count, kind, suffix)
+        return prefix[:nb], count[:nb], kind[:nb], suffix[: nw * B]
+
+    def empty_like(self, t, n):
+        return self.torch.empty(n, dtype=t.dtype, device=t.device)
+
+    def install(self, parts):
+        self.cbl.install_buckets_device(parts)
+
+    def merge_assign(self, other: "GpuShard"):
+        self.cbl |= other.cbl
+
+    def body_size(self):
+        return self.cbl.serialized_body_size()
+
+    def write_body_at(self, path, off):
+        self.cbl.write_body_at(path, off)
+
+
+class ShardedIndex(_Wire):
+    """One CBL index cut into `world` contiguous prefix ranges, one per rank (rank order = ascending prefixes).
+
+    Carries the reference's build / insert / merge / save surface to N GPUs:
+      insert_seqs_device  the sharded build (ShardedBuilder) into this index
+      load_from_file      every rank reads ITS prefix range of an index file (read_index, /root/reference/examples/cbl.rs:117-130)
+      merge_assign        `self |= other` (/root/reference/src/cbl.rs:433-449) range by range; an operand cut at other bounds
+                          is first re-sharded: each rank exports its share as bucket batches (kinds and stored order kept),
+                          one grouped exchange, install on the new owner
+      save_to_file        header by rank 0, every rank writes its entries at its own offset (write_index, examples/cbl.rs:132-142)
+    `bounds`: world-1 ascending prefix values, rank r owns bounds[r-1] <= prefix < bounds[r]; None while the index is empty.
+    """
+
+    def __init__(self, k=None, prefix_bits=24, dist=None, canonical=False, device=-1, slices=4, protocol="sorted", shard=None, profile=False):
+        if shard is None:
+            from . import CBL
+
+            shard = GpuShard(CBL(k, prefix_bits, canonical=canonical, device=device, profile=profile))
+        self.shard = shard
+        self._wire_init(dist)
+        self.slices, self.protocol = slices, protocol
+        self.bounds = None
+        self._builder = None
+
+    @property
+    def cbl(self):
+        return self.shard.cbl
+
+    # ---- build ---------------------------------------------------------------------------------------------------------
+    def insert_seqs_device(self, d_bases, d_offsets, n):
+        if self._builder is None:
+            self._builder = ShardedBuilder(self.shard.cbl, self.dist, engine=self.shard.builder_engine(), slices=self.slices, protocol=self.protocol)
+            self._builder.stats = self.stats  # one account for the index
+        self._builder.bounds = self.bounds
+        self._builder.insert_seqs_device(d_bases, d_offsets, n)
+        self.bounds = self._builder.bounds
+
+    def local_count(self) -> int:
+        return self.shard.count()
+
+    def count(self) -> int:
+        return self._all_reduce_ints([self.shard.count()])[0]
+
+    def _like(self, shard, bounds):
+        o = ShardedIndex(dist=self.dist, slices=self.slices, protocol=self.protocol, shard=shard)
+        o.bounds = None if bounds is None else np.asarray(bounds, dtype=np.uint32).copy()
+        return o
+
+    def clone(self, profile: bool = False) -> "ShardedIndex":
+        sh = self.shard.new_like(profile=profile)
+        sh.merge_assign(self.shard)  # |= into an empty index clones every bucket as stored (src/trievec/set_ops.rs:43-71)
+        return self._like(sh, self.bounds)
+
+    # ---- files ---------------------------------------------------------------------------------------------------------
+    def load_from_file(self, path, bounds=None):
+        """Replace the contents by the index file at `path` (visible to every rank). bounds=None cuts it into ranges of
+        about equal byte length; passing another index's bounds makes the two mergeable without an exchange."""
+        W = self.world
+        b_in = None if bounds is None else np.asarray(bounds, dtype=np.uint32)
+        for sequential in (False, True):
+            info, b = self.shard.load_shard(path, self.rank, W, b_in, sequential)
+            ok, = self._all_reduce_ints([int(info["exact"])], "min")
+            total, = self._all_reduce_ints([int(info["local_entries"])])
+            if ok and total == info["header_entries"]:
+                break
+        else:
+            raise ValueError(f"{path}: the entries of the {W} prefix ranges do not add up to the header's count (corrupt index file?)")
+        # every rank cut the file with the same deterministic procedure; keep rank 0's word for it anyway
+        bb = self._all_reduce_ints([int(x) for x in b] if self.rank == 0 else [0] * len(b)) if W > 1 else []
+        self.bounds = np.asarray(bb, dtype=np.uint32)
+        self._builder = None
+        return info
+
+    def save_to_file(self, path) -> int:
+        """One index file from the shares of all ranks (one node, one file system). Returns its size."""
+        import torch
+
+        ne, nbytes = self.shard.body_size()
+        canon = int(self.shard.is_canonical())
+        mine = torch.tensor([ne, nbytes, canon], dtype=torch.int64, device=self._host_tensor_device())
+        parts = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        parts = [p.cpu().tolist() for p in parts]
+        if len({p[2] for p in parts}) != 1:
+            raise ValueError("One of the index is canonical while the other isn't")
+        header = bytes([canon]) + _varint(sum(p[0] for p in parts))
+        offset = len(header) + sum(p[1] for p in parts[: self.rank])
+        total = len(header) + sum(p[1] for p in parts)
+        if self.rank == 0:
+            with open(path, "wb") as f:
+                f.write(header)
+                f.truncate(total)
+        self.dist.barrier()
+        self.shard.write_body_at(path, offset)
+        self.dist.barrier()
+        return total
+
+    # ---- re-shard + merge ----------------------------------------------------------------------------------------------
+    def resharded(self, bounds) -> "ShardedIndex":
+        """A copy of this index cut at `bounds` instead of self.bounds (self is left as it is)."""
+        import torch
+
+        W, sh = self.world, self.shard
+        bounds = np.asarray(bounds, dtype=np.uint32)
+        B = sh.suffix_bytes()
+        bs, ws = sh.split(bounds, W)
+        prefix, count, kind, suffix = sh.export()
+        send_b = [int(bs[d + 1] - bs[d]) for d in range(W)]
+        send_w = [int(ws[d + 1] - ws[d]) for d in range(W)]
+        send = torch.tensor([send_b, send_w], dtype=torch.int64, device=prefix.device).t().contiguous()  # [W, 2]
+        recv = torch.empty_like(send)
+        self.dist.all_to_all_single(recv, send)
+        recv_h = recv.cpu().tolist()
+        recv_b, recv_w = [int(x[0]) for x in recv_h], [int(x[1]) for x in recv_h]
+        prefix_r = sh.empty_like(prefix, max(sum(recv_b), 1))
+        count_r = sh.empty_like(count, max(sum(recv_b), 1))
+        kind_r = sh.empty_like(kind, max(sum(recv_b), 1))
+        suffix_r = sh.empty_like(suffix, max(sum(recv_w) * B, 1))
+        works = self._exchange(prefix, prefix_r, send_b, recv_b)
+        works += self._exchange(count, count_r, send_b, recv_b)
+        works += self._exchange(kind, kind_r, send_b, recv_b)
+        works += self._exchange(suffix, suffix_r, [w * B for w in send_w], [w * B for w in recv_w])
+        self._drain([(works,)], prefix_r)
+        parts, bo, wo = [], 0, 0
+        for r in range(W):  # the pieces of my new range, from the ranks that held them, in ascending prefix order
+            if recv_b[r]:
+                parts.append((recv_b[r], recv_w[r], prefix_r[bo : bo + recv_b[r]], count_r[bo : bo + recv_b[r]], kind_r[bo : bo + recv_b[r]],
+                              suffix_r[wo * B : (wo + recv_w[r]) * B]))
+            bo += recv_b[r]
+            wo += recv_w[r]
+        out = sh.new_like()
+        out.install(parts)
+        return self._like(out, bounds)
+
+    def merge_assign(self, other: "ShardedIndex") -> "ShardedIndex":
+        """`self |= other`. When the two are cut at different bounds `other` is re-sharded IN PLACE to self's bounds first
+        (it stays the same set; like the reference's |=, which sorts other's Vec buckets it walks, the call may change how
+        `other` is laid out, never what it contains)."""
+        if other.bounds is None and other.count() == 0:
+            return self
+        if self.bounds is None:
+            self.bounds = None if other.bounds is None else np.asarray(other.bounds, dtype=np.uint32).copy()
+        if self.world > 1 and not np.array_equal(np.asarray(self.bounds), np.asarray(other.bounds)):
+            moved = other.resharded(self.bounds)
+            other.shard, other.bounds, other._builder = moved.shard, moved.bounds, None
+        self.shard.merge_assign(other.shard)
+        self._builder = None
+        return self
+
+    __ior__ = merge_assign
+
+
+class HostStagedGroup:
+    """torch.distributed look-alike whose collectives stage device tensors through the host and a `gloo` group.
+
+    RCCL refuses two ranks on one GPU ("Duplicate GPU detected"), so this is how several ranks of the sharded build run on
+    ONE GPU (dry runs of `bench.py --gpus N --shared-gpu`, the -m gpu shim tests): every device step is the real one,
+    only the wire is gloo instead of RCCL. Not a production transport."""
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    class _Work:
+        def __init__(self, w, dst=None, host=None):
+            self.w, self.dst, self.host = w, dst, host
+
+        def wait(self):
+            self.w.wait()
+            if self.dst is not None:
+                self.dst.copy_(self.host)
+
+    isend, irecv = "isend", "irecv"
+
+    class ReduceOp:
+        SUM, MAX, MIN = "sum", "max", "min"
+
+    def __init__(self, d):
+        self.d = d
+
+    def get_world_size(self):
+        return self.d.get_world_size()
+
+    def get_rank(self):
+        return self.d.get_rank()
+
+    def get_backend(self):
+        return "gloo"
+
+    def barrier(self):
+        self.d.barrier()
+
+    def all_reduce(self, t, op=None):
+        h = t.cpu()
+        rop = {None: self.d.ReduceOp.SUM, "sum": self.d.ReduceOp.SUM, "max": self.d.ReduceOp.MAX, "min": self.d.ReduceOp.MIN}.get(op, op)
+        self.d.all_reduce(h, op=rop)
+        t.copy_(h)
+
+    def all_gather(self, outs, t):
+        hs = [o.cpu() for o in outs]
+        self.d.all_gather(hs, t.cpu())
+        for o, h in zip(outs, hs):
+            o.copy_(h)
+
+    def all_gather_object(self, outs, obj):
+        self.d.all_gather_object(outs, obj)
+
+    def all_to_all_single(self, out, inp):
+        ho, hi = out.cpu(), inp.cpu()
+        self.d.all_to_all_single(ho, hi)
+        out.copy_(ho)
+
+    def batch_isend_irecv(self, ops):
+        import torch
+
+        works = []
+        for o in ops:
+            if o.op == "isend":
+                works.append(self._Work(self.d.isend(o.tensor.cpu().contiguous(), o.peer)))
+            else:
+                h = torch.empty(o.tensor.shape, dtype=o.tensor.dtype)
+                works.append(self._Work(self.d.irecv(h, o.peer), o.tensor, h))
+        return works
 
 
 def _read_varint(b: bytes, pos: int):

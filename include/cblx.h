@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CBLX_ABI_VERSION 1
+#define CBLX_ABI_VERSION 2
 
 enum {
     CBLX_OK = 0,
@@ -123,6 +123,57 @@ int cblx_sorted_batch_export(cblx_ctx* ctx, uint32_t* d_prefix, uint32_t* d_coun
 /* Receiver: WordSet::insert_batch (src/wordset/mod.rs:187-216) over n_batches sorted batches; stream order = batch
  * order (then bucket order is irrelevant, and stream order inside a bucket of a batch is kept). */
 int cblx_insert_sorted_batches_device(cblx_ctx* ctx, const cblx_batch_view* batches, uint32_t n_batches);
+
+/* ---- prefix-range sharded indexes (BASELINE.json cfg 5 on N GPUs; no reference counterpart: the reference is one process) ----
+ * `cbl merge a b -o out` (examples/cbl.rs:270-279) per prefix range: every rank loads ITS range of both files
+ * (read_index, examples/cbl.rs:117-130), merges (src/wordset/set_ops.rs:123-157: buckets are independent by prefix) and
+ * writes its entries at its own offset of the output (write_index, examples/cbl.rs:132-142). Two operands cut at
+ * different bounds are brought to common bounds by moving bucket batches between ranks (export -> exchange -> install). */
+typedef struct cblx_shard_info {
+    uint64_t header_entries;   /* entry count in the file header (the whole index) */
+    uint64_t local_entries;    /* entries this rank loaded */
+    uint64_t begin_off, end_off; /* byte range of the file this rank parsed */
+    uint32_t first_prefix, last_prefix; /* of the loaded entries (when local_entries != 0) */
+    uint32_t exact;            /* 1: the walk over [begin_off, end_off) ended exactly at end_off and nothing looked wrong */
+    uint32_t canonical;        /* the file's canonical flag */
+} cblx_shard_info;
+/* Replaces the ctx's contents by rank `rank`'s share of an index file cut into `world` prefix ranges.
+ *   bounds == NULL: the entries are cut into `world` runs of about equal BYTE length; bounds_out[world-1] receives the first
+ *                   prefix of runs 1..world-1 (2^PREFIX_BITS for an empty tail run): the job's shard bounds.
+ *   bounds != NULL: world-1 ascending prefix values; rank r takes the entries with bounds[r-1] <= prefix < bounds[r].
+ * The format has no lengths to skip by, so entry starts are RECOGNISED speculatively (a bisection over byte offsets);
+ * sequential != 0 walks every entry from the first one instead (always right, reads the file up to the end of the range).
+ * The caller must check over ALL ranks that every info.exact is 1 and that the local_entries add up to header_entries,
+ * and otherwise repeat the call with sequential = 1 on every rank. K / PREFIX_BITS as for cblx_load. */
+int cblx_load_shard_from_file(cblx_ctx* ctx, const char* path, uint32_t rank, uint32_t world, const uint32_t* bounds, int sequential,
+                              uint32_t* bounds_out, cblx_shard_info* info);
+/* Host-only part of the above (no ctx, no GPU): where `world` prefix ranges cut the entries of an index file. offs[world + 1]
+ * = byte offset of every range's first entry ([world] = file size), first[world + 1] = that entry's prefix (2^PREFIX_BITS when
+ * nothing follows), *ok = 0 when the speculative search gave up (use sequential = 1). Only k / prefix_bits of params are read. */
+int cblx_index_shard_cuts(const cblx_params* params, const char* path, uint32_t world, const uint32_t* bounds, int sequential,
+                          uint64_t* offs, uint32_t* first, int* ok);
+/* The resident index as a bucket batch: ascending non-empty prefixes, words per prefix, kind (0 = Vec, 1 = Trie) and the
+ * suffixes packed to cblx_consts.bytes little-endian bytes each, bucket-major, STORED order inside a bucket. */
+typedef struct cblx_bucket_view {
+    uint64_t n_buckets, n_words;
+    const uint32_t* d_prefix; /* device [n_buckets] */
+    const uint32_t* d_count;  /* device [n_buckets] */
+    const uint8_t* d_kind;    /* device [n_buckets] */
+    const uint8_t* d_suffix;  /* device [n_words * suffix_bytes] */
+} cblx_bucket_view;
+/* Where nd-1 ascending prefix bounds (host) cut the resident index: destination d = #{i : bounds[i] <= prefix} owns buckets
+ * [bucket_split[d], bucket_split[d+1]) and words [word_split[d], word_split[d+1]) of the export (host arrays, nd + 1). */
+int cblx_resident_split(cblx_ctx* ctx, const uint32_t* bounds, uint32_t nd, uint64_t* bucket_split, uint64_t* word_split);
+/* Writes the whole resident index to caller-owned device arrays of cblx_num_buckets / cblx_count elements (the index stays). */
+int cblx_resident_export(cblx_ctx* ctx, uint32_t* d_prefix, uint32_t* d_count, uint8_t* d_kind, uint8_t* d_suffix);
+/* Replaces the ctx's contents by the concatenation of n_parts bucket batches (prefixes strictly ascending over the whole
+ * concatenation: the pieces of one prefix range received from ranks 0..W-1 in rank order). Kinds and stored order are kept,
+ * as WordSet's Deserialize keeps them (src/wordset/mod.rs:398-437). */
+int cblx_install_buckets_device(cblx_ctx* ctx, const cblx_bucket_view* parts, uint32_t n_parts);
+/* The entries of the serialized index alone — what follows `canonical u8 | varint(n_entries)` in cblx_serialize's bytes — so
+ * that several ranks can write one file: size first, then the bytes at `file_off` of an existing file (opened write-only). */
+int cblx_serialized_body_size(cblx_ctx* ctx, uint64_t* n_entries, uint64_t* nbytes);
+int cblx_write_body_at(cblx_ctx* ctx, const char* path, uint64_t file_off);
 
 /* CBL::count / is_empty / is_canonical (src/cbl.rs:164-177). */
 int cblx_count(cblx_ctx* ctx, uint64_t* out);

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/cblx.h but not exported by libcblx.so"
     assert sorted(cbl_amd.SIGNATURES) == names
-    assert L.cblx_abi_version() == 1
+    assert L.cblx_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -51,3 +51,46 @@ def test_necklace_host_unit(tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(exe), str(ROOT / "tests" / "host" / "necklace_unit.cpp")], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("k,pb,nreads,L", [(31, 24, 3000, 150), (9, 4, 1500, 100), (59, 28, 400, 250), (15, 6, 1500, 150), (11, 8, 40, 3000)])
+def test_index_shard_cuts_speculative_equals_sequential(k, pb, nreads, L, tmp_path):
+    """Host-only half of cblx_load_shard_from_file: the speculative search for the entry starts of `world` prefix ranges
+    (an entry start can only be recognised; a fake one — the tail of a Vec whose elements end in 00 00 01 — must not be
+    trusted) finds exactly what a walk over every entry finds, for byte-balanced cuts and for given prefix bounds."""
+    import numpy as np
+
+    from cbl_amd import synth
+    from oracle import Oracle
+
+    o = Oracle(k, pb)
+    b, off = synth.reads(5, nreads, L)
+    o.insert_seqs(b, off)
+    path = tmp_path / "x.cbl"
+    path.write_bytes(o.serialize())
+    size = path.stat().st_size
+    for world in (1, 2, 3, 8, 16):
+        a = cbl_amd.index_shard_cuts(path, k, pb, world)
+        s = cbl_amd.index_shard_cuts(path, k, pb, world, sequential=True)
+        assert a[2] and s[2]
+        assert (a[0] == s[0]).all() and (a[1] == s[1]).all()
+        assert s[0][world] == size and all(s[0][i] <= s[0][i + 1] for i in range(world))
+        bounds = s[1][1:world]
+        a2 = cbl_amd.index_shard_cuts(path, k, pb, world, bounds)
+        s2 = cbl_amd.index_shard_cuts(path, k, pb, world, bounds, sequential=True)
+        assert a2[2] and (a2[0] == s2[0]).all() and (a2[1] == s2[1]).all()
+        assert (s2[0] == s[0]).all()  # cutting at the first prefixes of the byte-balanced runs gives the same runs
+        if world > 1:  # bounds between / beyond the stored prefixes
+            odd = np.array(sorted({int(x) + 1 for x in bounds} | {0, (1 << pb) - 1}))[: world - 1].astype(np.uint32)
+            odd = np.pad(odd, (0, world - 1 - len(odd)), constant_values=(1 << pb) - 1)
+            a3 = cbl_amd.index_shard_cuts(path, k, pb, world, odd)
+            s3 = cbl_amd.index_shard_cuts(path, k, pb, world, odd, sequential=True)
+            assert a3[2] and (a3[0] == s3[0]).all() and (a3[1] == s3[1]).all()
+
+
+def test_index_shard_cuts_rejects_garbage(tmp_path):
+    p = tmp_path / "bad.cbl"
+    p.write_bytes(bytes([0, 3]) + bytes(range(200)))
+    with pytest.raises(cbl_amd.CblxError) as e:
+        cbl_amd.index_shard_cuts(p, 31, 24, 2, sequential=True)
+    assert e.value.code == cbl_amd.EFORMAT

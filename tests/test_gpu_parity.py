@@ -392,9 +392,10 @@ def test_checksum_matches_oracle_small():
         assert g.validate() == 0
 
 
-@pytest.mark.parametrize("k,pb,nreads,L", [(31, 24, 10_000_000, 150)])
+@pytest.mark.parametrize("k,pb,nreads,L", [(31, 24, 10_000_000, 150), (31, 28, 12_500_000, 150), (59, 28, 6_250_000, 250)])
 def test_full_size_properties(k, pb, nreads, L):
-    """cfg 2 at full size (1.2 G k-mers): set checksum == checksum of the transformed word stream (no k-mer repeats in
+    """cfg 2 at full size (1.2 G k-mers) and the per-GPU shares of cfg 3 (12.5 M x 150 bp, PREFIX_BITS=28: the fused
+    directory path) and cfg 4 (6.25 M x 250 bp, K=59: 16-byte records, 13-byte suffixes): set checksum == checksum of the transformed word stream (no k-mer repeats in
     this stream, checked via count), buckets structurally sound, sampled reads all present, foreign reads absent,
     re-inserting everything is idempotent (count and checksum unchanged)."""
     _need_gpu()
@@ -427,6 +428,38 @@ def test_full_size_properties(k, pb, nreads, L):
     g.insert_seqs_device(d_b, d_o, nreads)  # idempotence (resident + new through the incremental path)
     assert (g.count(), g.checksum()) == (count, cs)
     assert g.validate() == 0
+
+
+def test_full_size_merge_properties():
+    """cfg 5's per-GPU share at full size: `A |= B` of two indexes of 6.25 M x 150 bp reads (K=31, PB=24) that share the
+    k-mers of 1 M reads. checksum(A | B) = checksum(A) + checksum(B) - checksum(A & B) (the checksum is a sum over the set),
+    count likewise, buckets structurally sound, `other` unchanged as a set, merging again changes nothing."""
+    _need_gpu()
+    k, pb, n, L, shared = 31, 24, 6_250_000, 150, 1_000_000
+    d_a, o_a = synth.reads_torch(42, n, L, device="cuda")
+    d_b, o_b = synth.reads_torch(43, n - shared, L, device="cuda")
+    A, B, S = cbl_amd.CBL(k, pb), cbl_amd.CBL(k, pb), cbl_amd.CBL(k, pb)
+    A.insert_seqs_device(d_a, o_a, n)
+    B.insert_seqs_device(d_b, o_b, n - shared)
+    B.insert_seqs_device(d_a, o_a, shared)       # the first `shared` reads of A's stream
+    S.insert_seqs_device(d_a, o_a, shared)
+    del d_a, d_b
+    M = (1 << 64) - 1
+    ca, cb, cs_ = A.count(), B.count(), S.count()
+    xa, xb, xs = A.checksum(), B.checksum(), S.checksum()
+    assert ca == n * (L - k + 1) and cs_ == shared * (L - k + 1) and cb == ca  # no chance repeats in these streams
+    A |= B
+    assert A.count() == ca + cb - cs_
+    assert A.checksum() == (xa + xb - xs) & M
+    assert A.validate(strict=False) == 0 and B.validate(strict=False) == 0
+    assert (B.count(), B.checksum()) == (cb, xb)
+    before = (A.count(), A.checksum())
+    A |= B
+    assert (A.count(), A.checksum()) == before
+    A |= S
+    assert (A.count(), A.checksum()) == before
+    hb, _ = synth.reads(43, 2, L, first_read=n - shared - 2)
+    assert all(A.contains_seq(hb[:L].tobytes()))
 
 
 # ---- the CLI path: FASTA / FASTQ file -> index file, byte-identical to the oracle's ------------------------------------
@@ -1037,59 +1070,6 @@ def test_parallel_index_loader(k, pb, canonical, threads, monkeypatch):
 
 
 # ---- the N-GPU code path with real device steps on ONE GPU: two processes share cuda:0, the collectives go through gloo ----
-class _GlooShim:
-    """torch.distributed look-alike for ShardedBuilder: device tensors are staged through the host and exchanged over gloo.
-    RCCL refuses two ranks on one GPU ("Duplicate GPU detected"), so this is how the W = 2 exchange of the GPU engine —
-    offsets, slices, empty messages, stream order — gets exercised on a one-GPU box; only RCCL itself is not."""
-
-    class P2POp:
-        def __init__(self, op, tensor, peer):
-            self.op, self.tensor, self.peer = op, tensor, peer
-
-    class _Work:
-        def __init__(self, w, dst=None, host=None):
-            self.w, self.dst, self.host = w, dst, host
-
-        def wait(self):
-            self.w.wait()
-            if self.dst is not None:
-                self.dst.copy_(self.host)
-
-    isend, irecv = "isend", "irecv"
-
-    def __init__(self, d):
-        self.d = d
-
-    def get_world_size(self):
-        return self.d.get_world_size()
-
-    def get_rank(self):
-        return self.d.get_rank()
-
-    def barrier(self):
-        self.d.barrier()
-
-    def all_reduce(self, t):
-        h = t.cpu()
-        self.d.all_reduce(h)
-        t.copy_(h)
-
-    def all_to_all_single(self, out, inp):
-        ho, hi = out.cpu(), inp.cpu()
-        self.d.all_to_all_single(ho, hi)
-        out.copy_(ho)
-
-    def batch_isend_irecv(self, ops):
-        works = []
-        for o in ops:
-            if o.op == "isend":
-                works.append(self._Work(self.d.isend(o.tensor.cpu().contiguous(), o.peer)))
-            else:
-                h = torch.empty(o.tensor.shape, dtype=o.tensor.dtype)
-                works.append(self._Work(self.d.irecv(h, o.peer), o.tensor, h))
-        return works
-
-
 def _two_rank_worker(rank, world, port, k, pb, canonical, protocol, per, L, q):
     import torch.distributed as dist
 
@@ -1100,7 +1080,7 @@ def _two_rank_worker(rank, world, port, k, pb, canonical, protocol, per, L, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g = cbl_amd.CBL(k, pb, canonical=canonical, device=0)
-        sb = sharded.ShardedBuilder(g, _GlooShim(dist), slices=3, protocol=protocol)
+        sb = sharded.ShardedBuilder(g, sharded.HostStagedGroup(dist), slices=3, protocol=protocol)
         for batch, n in enumerate(per[rank]):  # two batches; the second reuses the first one's splitters
             first = sum(per[r][bb] for r in range(world) for bb in range(batch)) + sum(per[r][batch] for r in range(rank))
             d_b, d_o = synth.reads_torch(23, n, L, first_read=first, device="cuda:0")
@@ -1150,3 +1130,233 @@ def test_two_ranks_on_one_gpu_through_a_gloo_shim(world, k, pb, canonical, proto
                     one.insert_seqs(hb, ho)
     assert blob == one.serialize()
     assert len(bounds) == world - 1 and 0 < count0 < one.count()  # rank 0 owns part of the index, not all of it
+
+
+# ---- prefix-range sharded indexes (cfg 5): one rank's share through the C ABI, then N ranks sharing this GPU ---------------
+def _bytes_of_shards(shards, canonical):
+    """header + the bodies of the given ctxs in order (what ShardedIndex.save_to_file writes)."""
+    from cbl_amd.sharded import _varint
+
+    n = sum(g.serialized_body_size()[0] for g in shards)
+    out = bytes([int(canonical)]) + _varint(n)
+    for g in shards:
+        blob = g.serialize()
+        ne, nb = g.serialized_body_size()
+        assert len(blob) - nb in (2, 4, 6, 10) and ne == g.num_buckets()
+        out += blob[len(blob) - nb:]
+    return out
+
+
+@pytest.mark.parametrize("k,pb,canonical,nreads,L", [(31, 24, False, 20000, 150), (11, 8, False, 30, 5000), (59, 28, True, 3000, 250), (15, 6, False, 2000, 150)])
+def test_load_shard_export_install_write_body(k, pb, canonical, nreads, L, tmp_path):
+    """cblx_load_shard_from_file / cblx_resident_split / _export / cblx_install_buckets_device / cblx_write_body_at on one GPU:
+    the shares of W ranks, loaded one after the other, are disjoint, exact, and concatenate to the file; a share exported and
+    installed elsewhere serializes to the same bytes (kinds and stored order kept)."""
+    _need_gpu()
+    hb, ho = synth.reads(9, nreads, L)
+    o = Oracle(k, pb, canonical)
+    o.insert_seqs(hb, ho)
+    blob = o.serialize()
+    path = tmp_path / "whole.cbl"
+    path.write_bytes(blob)
+    for world in (1, 2, 3, 8):
+        for bounds_mode in ("bytes", "given"):
+            for sequential in (False, True):
+                shards, infos, bounds = [], [], None
+                if bounds_mode == "given":
+                    _offs, first, _ok = cbl_amd.index_shard_cuts(path, k, pb, world, sequential=True)
+                    bounds = first[1:world] + (1 if world > 1 else 0)  # between the stored prefixes
+                for r in range(world):
+                    g = cbl_amd.CBL(k, pb)
+                    info, b = g.load_shard_from_file(path, r, world, bounds, sequential)
+                    assert info["exact"] == 1 and info["canonical"] == int(canonical) and g.is_canonical() == canonical
+                    assert info["local_entries"] == g.num_buckets() and g.validate(strict=False) == 0
+                    if bounds is not None:
+                        assert (b == bounds).all()
+                    shards.append(g)
+                    infos.append(info)
+                assert sum(i["local_entries"] for i in infos) == infos[0]["header_entries"] == o.n_buckets()
+                assert all(infos[i]["end_off"] == infos[i + 1]["begin_off"] for i in range(world - 1)) and infos[-1]["end_off"] == len(blob)
+                assert _bytes_of_shards(shards, canonical) == blob
+                # rank-ordered save: header by "rank 0", every share at its own offset
+                out = tmp_path / "out.cbl"
+                from cbl_amd.sharded import _varint
+
+                header = bytes([int(canonical)]) + _varint(o.n_buckets())
+                sizes = [g.serialized_body_size()[1] for g in shards]
+                with open(out, "wb") as f:
+                    f.write(header)
+                    f.truncate(len(header) + sum(sizes))
+                for r in reversed(range(world)):
+                    shards[r].write_body_at(out, len(header) + sum(sizes[:r]))
+                assert out.read_bytes() == blob
+    # export -> split -> install: a whole index re-cut into 3 pieces, each installed in a fresh ctx
+    g = cbl_amd.CBL(k, pb, canonical=canonical)
+    g.load(blob)
+    nb, nw, B = g.num_buckets(), g.count(), g.consts()["bytes"]
+    prefix = torch.empty(nb, dtype=torch.int32, device="cuda")
+    count = torch.empty(nb, dtype=torch.int32, device="cuda")
+    kind = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    suffix = torch.empty(nw * B, dtype=torch.uint8, device="cuda")
+    g.resident_export(prefix, count, kind, suffix)
+    pv = prefix.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    cuts = np.array([int(pv[nb // 3]), int(pv[2 * nb // 3]) + 1], dtype=np.uint32)
+    bs, ws = g.resident_split(cuts, 3)
+    assert bs[0] == ws[0] == 0 and bs[3] == nb and ws[3] == nw
+    assert bs[1] == int((pv < cuts[0]).sum()) and bs[2] == int((pv < cuts[1]).sum())
+    pieces = []
+    for d in range(3):
+        t = cbl_amd.CBL(k, pb, canonical=canonical)
+        t.install_buckets_device([(bs[d + 1] - bs[d], ws[d + 1] - ws[d], prefix[bs[d]: bs[d + 1]], count[bs[d]: bs[d + 1]], kind[bs[d]: bs[d + 1]],
+                                   suffix[ws[d] * B: ws[d + 1] * B])])
+        assert t.validate(strict=False) == 0
+        pieces.append(t)
+    assert _bytes_of_shards(pieces, canonical) == blob
+    whole = cbl_amd.CBL(k, pb, canonical=canonical)  # several parts in one call
+    whole.install_buckets_device([(bs[d + 1] - bs[d], ws[d + 1] - ws[d], prefix[bs[d]: bs[d + 1]], count[bs[d]: bs[d + 1]], kind[bs[d]: bs[d + 1]],
+                                   suffix[ws[d] * B: ws[d + 1] * B]) for d in range(3)])
+    assert whole.serialize() == blob
+    hb2, ho2 = synth.reads(10, 50, L)
+    whole.insert_seqs(hb2, ho2)  # an installed index is a full index
+    o.insert_seqs(hb2, ho2)
+    assert whole.serialize() == o.serialize()
+    with pytest.raises(cbl_amd.CblxError):  # parts out of order
+        cbl_amd.CBL(k, pb).install_buckets_device([(bs[d + 1] - bs[d], ws[d + 1] - ws[d], prefix[bs[d]: bs[d + 1]], count[bs[d]: bs[d + 1]], kind[bs[d]: bs[d + 1]],
+                                                   suffix[ws[d] * B: ws[d + 1] * B]) for d in (1, 0, 2) if bs[d + 1] > bs[d]])
+
+
+def test_load_rejects_malformed_trie_and_empty_vec():
+    """node values out of order / an empty Vec must be CBLX_EFORMAT, not a broken resident index."""
+    _need_gpu()
+    k, pb = 11, 8
+    o = Oracle(k, pb)
+    hb, ho = synth.reads(3, 10, 4000)
+    o.insert_seqs(hb, ho)
+    blob = bytearray(o.serialize())
+    g = cbl_amd.CBL(k, pb)
+    g.load(bytes(blob))
+    kinds = g.bucket_table_np()[2]
+    assert kinds.max() == 1  # there is a Trie entry to damage
+    # first entry: prefix, tag; find the first Trie entry's root node and swap its first two values
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from shard_standin import _rv, parse_index
+
+    ents = parse_index(bytes(blob), g.consts()["bytes"])[1]
+    start = next(e[3] for e in ents if e[1] == 1)
+    _p, q = _rv(blob, start)
+    _t, q = _rv(blob, q)
+    c, q = _rv(blob, q)
+    assert c >= 2
+    blob[q], blob[q + 1] = blob[q + 1], blob[q]
+    with pytest.raises(cbl_amd.CblxError) as e:
+        g.load(bytes(blob))
+    assert e.value.code == cbl_amd.EFORMAT
+    empty_vec = bytes([0, 1, 5, 0, 0])  # one entry: prefix 5, Vec, 0 elements
+    with pytest.raises(cbl_amd.CblxError) as e:
+        g.load(empty_vec)
+    assert e.value.code == cbl_amd.EFORMAT
+
+
+def _sharded_index_worker(rank, world, port, k, pb, canonical, per, L, slices, tmp, q):
+    import sys
+
+    import torch.distributed as dist
+
+    from cbl_amd import sharded
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sharded.MAX_MSG_BYTES = 1 << 16
+    try:
+        grp = sharded.HostStagedGroup(dist)
+
+        def new():
+            return sharded.ShardedIndex(k, pb, grp, canonical=canonical, device=0, slices=slices)
+
+        def feed(idx, seed):
+            d_b, d_o = synth.reads_torch(seed, per, L, first_read=rank * per, device="cuda:0")
+            idx.insert_seqs_device(d_b, d_o, per)
+
+        A, B = new(), new()
+        feed(A, 31)
+        nb = np.asarray(A.bounds, dtype=np.uint64) * 3 // 2 + 1
+        nb[-1] = max(int(nb[-1]), (1 << pb) - 2)
+        B.bounds = np.minimum(nb, (1 << pb) - 1).astype(np.uint32)
+        feed(B, 77)
+        cA, cB = A.count(), B.count()
+        E = A.clone()
+        assert E.count() == cA
+        R = B.resharded(A.bounds)  # B itself is left alone
+        assert R.count() == cB and np.array_equal(R.bounds, A.bounds) and not np.array_equal(B.bounds, A.bounds)
+        A.merge_assign(B)
+        assert np.array_equal(A.bounds, B.bounds) and B.count() == cB
+        pa, pb_, pe = (os.path.join(tmp, n) for n in ("a.cbl", "b.cbl", "e.cbl"))
+        sa = A.save_to_file(pa)
+        B.save_to_file(pb_)
+        E.save_to_file(pe)
+        C, D = new(), new()
+        C.load_from_file(pa)           # byte-balanced ranges, speculative entry starts
+        D.load_from_file(pe, bounds=C.bounds)
+        assert C.count() == A.count() and D.count() == cA
+        pc = os.path.join(tmp, "c.cbl")
+        assert C.save_to_file(pc) == sa
+        D.merge_assign(C)
+        pd = os.path.join(tmp, "d.cbl")
+        D.save_to_file(pd)
+        if rank == 0:
+            q.put({n: open(os.path.join(tmp, n + ".cbl"), "rb").read() for n in "abecd"})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k,pb,canonical,per,L,slices", [(2, 31, 24, False, 3000, 150, 2), (3, 11, 8, False, 6, 7000, 3), (2, 59, 28, True, 600, 250, 1),
+                                                              (4, 31, 24, False, 20000, 150, 4), (8, 15, 10, False, 300, 500, 2)])
+def test_sharded_index_merge_load_save_on_one_gpu(world, k, pb, canonical, per, L, slices, tmp_path):
+    """cfg 5 with `world` ranks sharing this GPU (real device steps, exchange staged through gloo): sharded build of two
+    operands at different bounds, clone, re-shard, `A |= B`, rank-ordered save, per-range load, second merge — all files
+    byte-identical to the one-process oracle's, quirks of the reference's |= included."""
+    _need_gpu()
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from cbl_amd.sharded import ShardedBuilder
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_index_worker, args=(r, world, port, k, pb, canonical, per, L, slices, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    files = q.get(timeout=1200)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+
+    def one_process(seed):
+        o = Oracle(k, pb, canonical)
+        for a, b in ShardedBuilder.slice_bounds(per, slices):
+            for r in range(world):
+                if b > a:
+                    hb, ho = synth.reads(seed, b - a, L, first_read=r * per + a)
+                    o.insert_seqs(hb, ho)
+        return o
+
+    oa, ob = one_process(31), one_process(77)
+    a_before = oa.serialize()
+    oa.merge(ob)
+    assert files["e"] == a_before
+    assert files["a"] == oa.serialize()
+    assert files["b"] == ob.serialize()
+    assert files["c"] == files["a"]
+    od, oc = Oracle(k, pb, canonical), Oracle(k, pb, canonical)
+    od.load(files["e"])
+    oc.load(files["a"])
+    od.merge(oc)
+    assert files["d"] == od.serialize()

@@ -10,106 +10,14 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-class OracleEngine:
-    """CPU stand-in for cbl_amd.sharded.GpuEngine (tests only): same four steps on torch CPU tensors."""
-
-    def __init__(self, orc, k, pb):
-        import torch
-        from oracle.pyref import params
-
-        self.torch, self.o = torch, orc
-        P = params(k, pb)
-        self.sb, self.pb = P["SB"], pb
-
-    def _to_ints(self, lo, hi):
-        lo = lo.numpy().astype(np.uint64)
-        hi = hi.numpy().astype(np.uint64)
-        return [int(a) | (int(b) << 64) for a, b in zip(lo, hi)]
-
-    def _from_ints(self, words):
-        t = self.torch
-        lo = np.array([w & (2**64 - 1) for w in words], dtype=np.uint64).astype(np.int64)
-        hi = np.array([w >> 64 for w in words], dtype=np.uint64).astype(np.int64)
-        return t.from_numpy(lo), t.from_numpy(hi)
-
-    def seq_words(self, bases, offsets, n):
-        b = bases.numpy().tobytes()
-        off = offsets.numpy()
-        words = []
-        for i in range(n):
-            words += self.o.seq_words(b[int(off[i]) : int(off[i + 1])])
-        return self._from_ints(words)
-
-    def sample_hist(self, lo, hi):
-        from cbl_amd.sharded import HIST_BITS, SAMPLE_STRIDE
-
-        hb = min(HIST_BITS, self.pb)
-        keys = [(w >> (self.sb + self.pb - hb)) & ((1 << hb) - 1) for w in self._to_ints(lo, hi)[::SAMPLE_STRIDE]]
-        return self.torch.from_numpy(np.bincount(np.array(keys, dtype=np.int64), minlength=1 << hb).astype(np.int64))
-
-    def partition(self, lo, hi, bounds, nd):
-        words = self._to_ints(lo, hi)
-        dest = [int(np.searchsorted(bounds, (w >> self.sb), side="right")) for w in words]
-        order = sorted(range(len(words)), key=lambda i: dest[i])  # Python's sort is stable
-        plo, phi = self._from_ints([words[i] for i in order])
-        return plo, phi, [dest.count(d) for d in range(nd)]
-
-    def insert_words(self, lo, hi):
-        self.o.insert_words(self._to_ints(lo, hi))
-
-    def empty_like(self, t, n):
-        return self.torch.empty(n, dtype=t.dtype)
-
-    # ---- sorted-batch protocol: same contracts as cblx_sorted_batch_* / cblx_insert_sorted_batches_device ------------
-    def suffix_bytes(self):
-        return (self.sb + 7) // 8
-
-    def sorted_batch_begin(self, bases, offsets, n, bounds, nd):
-        lo, hi = self.seq_words(bases, offsets, n)
-        words = self._to_ints(lo, hi)
-        order = sorted(range(len(words)), key=lambda i: words[i] >> self.sb)  # stable: stream order inside a prefix
-        self._batch = [words[i] for i in order]
-        from collections import Counter
-
-        tally = Counter(w >> self.sb for w in self._batch)
-        uniq = sorted(tally)
-        self._prefix = uniq
-        self._count = [tally[p] for p in uniq]
-        bs, ws = [0], [0]
-        for d in range(1, nd):
-            k = int(np.searchsorted(np.array(uniq, dtype=np.int64), int(bounds[d - 1]), side="left"))
-            bs.append(k)
-            ws.append(sum(self._count[:k]))
-        bs.append(len(uniq))
-        ws.append(len(words))
-        return bs, ws
-
-    def sorted_batch_export(self, n_buckets, n_words):
-        t = self.torch
-        B = self.suffix_bytes()
-        assert n_buckets == len(self._prefix) and n_words == len(self._batch)
-        mask = (1 << self.sb) - 1
-        raw = b"".join((w & mask).to_bytes(B, "little") for w in self._batch)
-        return (t.tensor(self._prefix, dtype=t.int32), t.tensor(self._count, dtype=t.int32),
-                t.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()) if raw else t.empty(0, dtype=t.uint8))
-
-    def insert_sorted_batches(self, batches):
-        B = self.suffix_bytes()
-        for nb, nw, prefix, count, suffix in batches:
-            raw = suffix.numpy().tobytes()
-            words, k = [], 0
-            for p, c in zip(prefix.tolist(), count.tolist()):
-                for _ in range(c):
-                    words.append(((p & 0xFFFFFFFF) << self.sb) | int.from_bytes(raw[k * B : (k + 1) * B], "little"))
-                    k += 1
-            assert k == nw
-            self.o.insert_words(words)
+from shard_standin import OracleEngine  # noqa: E402  (CPU stand-in for cbl_amd.sharded.GpuEngine)
 
 
 def _worker(rank, world, port, k, pb, nreads, L, slices, protocol, q):
-    sys.path.insert(0, ROOT)
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
@@ -209,7 +117,7 @@ def test_choose_bounds_balances_skewed_histogram():
 
 def _worker_ragged(rank, world, port, k, pb, L, counts, protocol, q):
     """Ranks with very different read counts, fewer reads than slices, and a batch in which one rank has nothing."""
-    sys.path.insert(0, ROOT)
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
