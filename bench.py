@@ -141,12 +141,25 @@ def parse_args(argv=None):
     return args
 
 
+def build_in_child():
+    """__graft_entry__.build() in a process of its own, under a lock file (torchrun starts N of us at once). Not in this
+    process: build() dlopens libcblx.so, which would pull in /opt/rocm's HIP runtime before torch loads its bundled copy —
+    two runtimes in one process see no device — and hipcc / g++ children must not inherit a profiler's preload."""
+    import fcntl
+
+    with open(os.path.join(ROOT, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES")}
+            subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], check=True, cwd=ROOT, env=env, stdout=sys.stderr)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
 # ---- launcher: `python bench.py --gpus N` without torchrun -------------------------------------------------------------
 def launch_ranks(args) -> int:
     """Start N fresh rank processes (this process never initialises a GPU), relay rank 0's stdout, return the worst code."""
-    import __graft_entry__ as ge
-
-    ge.build()  # once, before any rank exists: hipcc / g++ children, dlopen; no HIP call
+    build_in_child()  # once, before any rank exists
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -184,14 +197,7 @@ def main():
     # build before torch / any GPU call (hipcc and g++ children must not inherit an initialised runtime or a profiler's
     # preload); under torchrun local rank 0 builds and the others wait on a lock file for it
     if not os.environ.get("CBLX_BENCH_CHILD"):
-        import fcntl
-
-        import __graft_entry__ as ge
-
-        with open(os.path.join(ROOT, ".build.lock"), "w") as lk:
-            fcntl.flock(lk, fcntl.LOCK_EX)
-            ge.build()
-            fcntl.flock(lk, fcntl.LOCK_UN)
+        build_in_child()
 
     import torch
 
@@ -264,39 +270,40 @@ def main():
         timed_ctx = cbl
     else:
         # `A |= B` (src/cbl.rs:433-449): A from the reads of seed 42, B from seed 43 (SURVEY.md §8d cfg 5). Every step merges B
-        # into a fresh copy of A made before the timed region (the merge changes self).
-        n_copies = args.steps + args.warmup
+        # into a copy of A (the merge changes self).
         a_bases, a_off = synth.reads_torch(42, NR, L, first_read=rank * NR, device=dev)
         b_bases, b_off = synth.reads_torch(43, NR, L, first_read=rank * NR, device=dev)
+        # every step works on ONE reusable copy (`work`): clear, clone A into it (|= into an empty index is a device copy of
+        # A's share, a few ms, inside the step), then the merge proper. Fresh contexts per step would time hipMalloc: a new
+        # ctx has a cold allocation cache and a 12 GB arena costs more to map than the merge takes.
         if dist is None:
             A = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank)
             A.insert_seqs_device(a_bases, a_off, NR)
             B = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank)
             B.insert_seqs_device(b_bases, b_off, NR)
-            copies = []
-            for _ in range(n_copies):
-                c = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank, profile=True)
-                c |= A  # merge into an empty index = clone
-                copies.append(c)
+            work = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank, profile=True)
             count_a, count_b = A.count(), B.count()
 
-            def step(i):
-                copies[i] |= B
+            def step(_i):
+                work.clear()
+                work.__ior__(A)
+                work.__ior__(B)
 
-            last = lambda: copies[n_copies - 1]  # noqa: E731
+            last = lambda: work  # noqa: E731
         else:
             A = sharded.ShardedIndex(K, PB, dist, canonical=args.canonical, device=local_rank, slices=args.slices)
             A.insert_seqs_device(a_bases, a_off, NR)
             B = sharded.ShardedIndex(K, PB, dist, canonical=args.canonical, device=local_rank, slices=args.slices)
             B.insert_seqs_device(b_bases, b_off, NR)  # its own quantile bounds
-            copies = [A.clone(profile=True) for _ in range(n_copies)]
+            work = sharded.ShardedIndex(K, PB, dist, canonical=args.canonical, device=local_rank, slices=args.slices, profile=True)
             count_a, count_b = A.local_count(), B.local_count()
             engine = B  # exchange accounting of the re-shard
 
-            def step(i):
-                copies[i].merge_assign(B.resharded(copies[i].bounds))
+            def step(_i):
+                work.copy_from(A)
+                work.merge_assign(B.resharded(work.bounds))  # B itself keeps its own bounds: every step pays the exchange
 
-            last = lambda: copies[n_copies - 1].cbl  # noqa: E731
+            last = lambda: work.cbl  # noqa: E731
         del a_bases, b_bases
         torch.cuda.synchronize()
         units_per_rank_step = count_b  # k-mers of B inserted into A per step (this rank's share)
@@ -307,8 +314,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    if args.kind == "build":
-        cbl.stage_times_reset()
+    (cbl if args.kind == "build" else last()).stage_times_reset()
     if engine is not None and hasattr(engine, "reset_stats"):
         engine.reset_stats()
     t0 = time.perf_counter()
@@ -323,12 +329,7 @@ def main():
         units_alg = kmers_per_rank * args.steps  # k-mers through the kernels of this rank in the timed region
     else:
         count = allreduce_sum(last().count())
-        stages = {}
-        for c in copies[args.warmup:]:
-            cc = c if dist is None else c.cbl
-            for n, (ms, ln) in cc.stage_times().items():
-                a, b = stages.get(n, (0.0, 0))
-                stages[n] = (a + ms, b + ln)
+        stages = last().stage_times()
         units_alg = (count_a + count_b) * args.steps  # words of the merged runs
         extra["merge"]["words_union"] = count
     total_units = allreduce_sum(units_per_rank_step) * args.steps
@@ -445,7 +446,7 @@ def main():
             par = "1 GPU" if world == 1 else f"{world} GPUs: read-sharded encode + partition, prefix-range exchange ({args.protocol} protocol), per-range bucket insert"
         else:
             workload = (f"merge (cfg 5 per-GPU share): K={K} ({wb}-bit word) PREFIX_BITS={PB}, A |= B with A, B = indexes of {NR}x{L}bp reads per GPU each "
-                        f"(seeds 42 / 43); value = k-mers of B merged into A per second")
+                        f"(seeds 42 / 43); a step = device copy of A into a work index + the merge; value = k-mers of B merged per second")
             par = "1 GPU" if world == 1 else f"{world} GPUs: both operands prefix-range sharded, B re-sharded to A's bounds, per-rank merge"
         out = {
             "metric": "k-mers inserted/sec (build index)" if args.kind == "build" else "k-mers inserted/sec (merge: self |= other)",

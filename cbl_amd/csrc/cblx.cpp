@@ -229,15 +229,20 @@ int cblx_insert_words_device(cblx_ctx* c, const uint64_t* d_lo, const void* d_hi
         flush(c);
         if (n == 0) return;
         if (!d_lo || (c->P.has_hi() && !d_hi)) throw Error(CBLX_EINVAL, "null argument");
-        dispatch(c->P, [&](auto cfg) {
-            typedef decltype(cfg) C;
-            Records rec;
-            begin_records<C>(c, rec, n);
-            rec.ext_lo = d_lo;  // the first partition pass reads the caller's arrays in place
-            rec.ext_hi = d_hi;
-            pipeline<C>(c, rec, n);
-            c->kmers_inserted += n;
-        });
+        const size_t hs = hi_elem_size(c->P);
+        const u64 step = 1ull << 31;  // sub-batches (32-bit positions inside one batch; same result, see insert_device)
+        for (u64 a = 0; a < n; a += step) {
+            const u64 m = std::min(step, n - a);
+            dispatch(c->P, [&](auto cfg) {
+                typedef decltype(cfg) C;
+                Records rec;
+                begin_records<C>(c, rec, m);
+                rec.ext_lo = d_lo + a;  // the first partition pass reads the caller's arrays in place
+                rec.ext_hi = hs ? (const void*)((const u8*)d_hi + a * hs) : d_hi;
+                pipeline<C>(c, rec, m);
+                c->kmers_inserted += m;
+            });
+        }
         collect_events(c);
         CBLX_HIP(hipStreamSynchronize(c->stream));
     });
@@ -603,45 +608,41 @@ int cblx_merge_assign(cblx_ctx* self, cblx_ctx* other) {
         flush(other);
         CBLX_HIP(hipSetDevice(self->device));
         if (other->res.count == 0) return;
-        if (self->res.count == 0 && self->device == other->device) {
-            // every bucket is other-only: cloned as stored, kind and order kept (src/trievec/set_ops.rs:43-71) = a deep copy
-            CBLX_HIP(hipStreamSynchronize(other->stream));
+        CBLX_HIP(hipStreamSynchronize(other->stream));
+        // `other` on another GPU (or CBLX_FORCE_PEER_COPY=1: tests): its resident index is copied into self's HBM over the
+        // fabric (hipMemcpyPeer) and the merge runs here on the device like any other; there is no host merge.
+        const char* fp = std::getenv("CBLX_FORCE_PEER_COPY");
+        const bool peer = self->device != other->device || (fp && fp[0] == '1');
+        Resident copy;
+        if (peer || self->res.count == 0) {
             const Resident& o = other->res;
-            Resident nr;
-            nr.nb = o.nb;
-            nr.count = o.count;
+            copy.nb = o.nb;
+            copy.count = o.count;
             auto dup = [&](auto& dst, const auto& src) {
                 typedef typename std::remove_reference<decltype(*src.get())>::type T;
                 if (!src.get()) return;
                 dst = Buf<T>(self->pool, src.n);
-                CBLX_HIP(hipMemcpyAsync(dst.get(), src.get(), src.n * sizeof(T), hipMemcpyDeviceToDevice, self->stream));
+                CBLX_HIP(hipMemcpyPeerAsync(dst.get(), self->device, src.get(), other->device, src.n * sizeof(T), self->stream));
             };
-            dup(nr.bv, o.bv); dup(nr.rank_dir, o.rank_dir); dup(nr.prefix, o.prefix); dup(nr.start, o.start);
-            dup(nr.cnt, o.cnt); dup(nr.kind, o.kind); dup(nr.a_lo, o.a_lo); dup(nr.a_hi, o.a_hi);
+            dup(copy.bv, o.bv); dup(copy.rank_dir, o.rank_dir); dup(copy.prefix, o.prefix); dup(copy.start, o.start);
+            dup(copy.cnt, o.cnt); dup(copy.kind, o.kind); dup(copy.a_lo, o.a_lo); dup(copy.a_hi, o.a_hi);
             CBLX_HIP(hipStreamSynchronize(self->stream));
-            self->res = std::move(nr);
+        }
+        if (self->res.count == 0) {
+            // every bucket is other-only: cloned as stored, kind and order kept (src/trievec/set_ops.rs:43-71) = a deep copy
+            self->res = std::move(copy);
             return;
         }
-        bool on_device = false;
-        if (self->device == other->device && self->res.count != 0 && self->res.count + other->res.count < 0xFFFFFFF0ull) {
-            CBLX_HIP(hipStreamSynchronize(other->stream));
-            dispatch(self->P, [&](auto cfg) { merge_direct<decltype(cfg)>(self, other->res); });
-            on_device = true;
-            collect_events(self);
-        }
-        if (!on_device) {  // indexes on different devices (or self empty): through the host
-            HostIndex a, b, o;
-            CBLX_HIP(hipSetDevice(other->device));
-            download(other, b);
-            CBLX_HIP(hipSetDevice(self->device));
-            download(self, a);
-            const bool other_changed = merge_host(self->P, a, b, o);
-            upload(self, o);
-            if (other_changed) {
-                CBLX_HIP(hipSetDevice(other->device));
-                upload(other, b);
-                CBLX_HIP(hipSetDevice(self->device));
-            }
+        dispatch(self->P, [&](auto cfg) { merge_direct<decltype(cfg)>(self, peer ? copy : other->res); });
+        collect_events(self);
+        CBLX_HIP(hipStreamSynchronize(self->stream));
+        if (peer) {
+            // the reference's |= sorts other's Vec buckets that met a bucket of self (iter_sorted, src/trievec/mod.rs:209-220):
+            // the merge did that to the copy, so the arena goes back to where `other` lives
+            Resident& o = other->res;
+            CBLX_HIP(hipMemcpyPeerAsync(o.a_lo.get(), other->device, copy.a_lo.get(), self->device, o.a_lo.n * sizeof(u64), self->stream));
+            if (o.a_hi.get()) CBLX_HIP(hipMemcpyPeerAsync(o.a_hi.get(), other->device, copy.a_hi.get(), self->device, o.a_hi.n * sizeof(u64), self->stream));
+            CBLX_HIP(hipStreamSynchronize(self->stream));
         }
     });
 }
@@ -805,8 +806,9 @@ int cblx_export_kmers(cblx_ctx* c, uint64_t* lo, uint64_t* hi, uint64_t cap, uin
         Buf<u64> res_off(c->pool, r.nb + 1), d_lo(c->pool, r.count), d_hi(c->pool, hi ? r.count : 1);
         const u64 tot = exclusive_scan<u64>(c, r.cnt.get(), r.nb, res_off.get());
         hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, res_off.get() + r.nb, tot);
-        hipLaunchKernelGGL(k_export_kmers, grid1(tot, 256), dim3(256), 0, c->stream, tot, r.nb, res_off.get(), r.prefix.get(), r.start.get(), r.a_lo.get(),
-                           c->P.wide_suffix() ? r.a_hi.get() : (const u64*)nullptr, c->P, d_lo.get(), hi ? d_hi.get() : (u64*)nullptr);
+        for (u64 e0 = 0; e0 < tot; e0 += 1ull << 31)  // one launch addresses fewer than 2^32 work items
+            hipLaunchKernelGGL(k_export_kmers, grid1(std::min<u64>(1ull << 31, tot - e0), 256), dim3(256), 0, c->stream, e0, tot, r.nb, res_off.get(), r.prefix.get(), r.start.get(),
+                               r.a_lo.get(), c->P.wide_suffix() ? r.a_hi.get() : (const u64*)nullptr, c->P, d_lo.get(), hi ? d_hi.get() : (u64*)nullptr);
         CBLX_HIP(hipGetLastError());
         CBLX_HIP(hipStreamSynchronize(c->stream));
         xfer(c).d2h_copy(lo, d_lo.get(), tot * 8);
@@ -864,8 +866,9 @@ int cblx_validate(cblx_ctx* c, int strict, uint64_t* violations) {
         if (r.nb == 0) return;
         Buf<u64> bad(c->pool, 1);
         CBLX_HIP(hipMemsetAsync(bad.get(), 0, 8, c->stream));
-        hipLaunchKernelGGL(k_validate, grid1(r.nb * 64, 256), dim3(256), 0, c->stream, r.nb, r.start.get(), r.cnt.get(), r.kind.get(), r.a_lo.get(),
-                           c->P.wide_suffix() ? r.a_hi.get() : (const u64*)nullptr, c->P.SB, (u32)(strict != 0), bad.get());
+        for (u64 r0 = 0; r0 < r.nb; r0 += 1ull << 25)  // one wave per bucket, fewer than 2^32 work items per launch
+            hipLaunchKernelGGL(k_validate, grid1(std::min<u64>(1ull << 25, r.nb - r0) * 64, 256), dim3(256), 0, c->stream, r0, r.nb, r.start.get(), r.cnt.get(), r.kind.get(),
+                               r.a_lo.get(), c->P.wide_suffix() ? r.a_hi.get() : (const u64*)nullptr, c->P.SB, (u32)(strict != 0), bad.get());
         CBLX_HIP(hipGetLastError());
         *violations = d2h<u64>(c, bad.get());
     });

@@ -1,6 +1,5 @@
-// host_index.hpp — the index as bytes: host-side copy of the resident index (export, different-device merge), the bincode
-// emitter on the host and its device counterpart's driver (kernels_serde.hpp), the parser, the streaming loader, the host
-// merge. Included by cblx.cpp only.
+// host_index.hpp — the index as bytes: host-side copy of the resident index (export), the bincode emitter on the host and
+// its device counterpart's driver (kernels_serde.hpp), the streaming / parallel loader. Included by cblx.cpp only.
 #pragma once
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -31,50 +30,15 @@ void download(cblx_ctx* c, HostIndex& h) {
     if (n == 0) { h.lo.clear(); h.hi.clear(); return; }
     Buf<u64> d_off(c->pool, r.nb + 1), d_lo(c->pool, n), d_hi(c->pool, c->P.wide_suffix() ? n : 1);
     h2d(c, d_off.get(), h.off.data(), r.nb + 1);
-    hipLaunchKernelGGL(k_gather_dense, grid1(n, 256), dim3(256), 0, c->stream, n, r.nb, d_off.get(), r.start.get(), r.a_lo.get(),
-                       c->P.wide_suffix() ? r.a_hi.get() : (const u64*)nullptr, c->P.SB, d_lo.get(), c->P.wide_suffix() ? d_hi.get() : (u64*)nullptr);
+    for (u64 e0 = 0; e0 < n; e0 += 1ull << 31)  // one launch addresses fewer than 2^32 work items
+        hipLaunchKernelGGL(k_gather_dense, grid1(std::min<u64>(1ull << 31, n - e0), 256), dim3(256), 0, c->stream, e0, n, r.nb, d_off.get(), r.start.get(), r.a_lo.get(),
+                           c->P.wide_suffix() ? r.a_hi.get() : (const u64*)nullptr, c->P.SB, d_lo.get(), c->P.wide_suffix() ? d_hi.get() : (u64*)nullptr);
     CBLX_HIP(hipGetLastError());
     CBLX_HIP(hipStreamSynchronize(c->stream));
     h.lo.resize(n);
     xfer(c).d2h_copy(h.lo.data(), d_lo.get(), n * 8);  // pinned lanes (a pageable hipMemcpy runs at a few GB/s)
     if (c->P.wide_suffix()) { h.hi.resize(n); xfer(c).d2h_copy(h.hi.data(), d_hi.get(), n * 8); } else h.hi.clear();
 }
-// replace the resident index by a host-built one (load / merge): dense arena, directory built on the host
-void upload(cblx_ctx* c, const HostIndex& h) {
-    const Consts& P = c->P;
-    Resident nr;
-    nr.nb = h.prefix.size();
-    const u64 n = h.off.empty() ? 0 : h.off.back();
-    nr.count = n;
-    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
-    std::vector<u64> bv(nwords, 0), rd(nwords + 1, 0);
-    for (u64 i = 0; i < nr.nb; ++i) {
-        if (h.prefix[i] >= nprefix) throw Error(CBLX_EFORMAT, "prefix out of range for PREFIX_BITS");
-        if (i && h.prefix[i] <= h.prefix[i - 1]) throw Error(CBLX_EFORMAT, "prefixes are not strictly ascending");
-        bv[h.prefix[i] >> 6] |= 1ull << (h.prefix[i] & 63);
-    }
-    for (u64 w = 0; w < nwords; ++w) rd[w + 1] = rd[w] + (u64)__builtin_popcountll(bv[w]);
-    nr.bv = Buf<u64>(c->pool, nwords);
-    nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
-    nr.prefix = Buf<u32>(c->pool, nr.nb + 1);
-    nr.start = Buf<u64>(c->pool, nr.nb + 1);
-    nr.cnt = Buf<u32>(c->pool, nr.nb + 1);
-    nr.kind = Buf<u8>(c->pool, nr.nb + 1);
-    nr.a_lo = Buf<u64>(c->pool, n + 2);
-    if (P.wide_suffix()) nr.a_hi = Buf<u64>(c->pool, n + 2);
-    h2d(c, nr.bv.get(), bv.data(), nwords);
-    h2d(c, nr.rank_dir.get(), rd.data(), nwords + 1);
-    h2d(c, nr.prefix.get(), h.prefix.data(), nr.nb);
-    h2d(c, nr.start.get(), h.off.data(), nr.nb + 1);
-    h2d(c, nr.cnt.get(), h.cnt.data(), nr.nb);
-    h2d(c, nr.kind.get(), h.kind.data(), nr.nb);
-    xfer(c).h2d_copy(nr.a_lo.get(), h.lo.data(), n * 8);
-    if (P.wide_suffix()) xfer(c).h2d_copy(nr.a_hi.get(), h.hi.data(), n * 8);
-    xfer(c).sync();
-    CBLX_HIP(hipStreamSynchronize(c->stream));
-    c->res = std::move(nr);
-}
-
 // ---- bincode 1.3 DefaultOptions (varint, little endian): src/cbl.rs:132-135 -----------------------------------
 struct Sink {
     u8* buf;
@@ -321,56 +285,6 @@ struct Src {
         return v;
     }
 };
-void parse_trie(Src& s, u32 depth, u32 BYTES, u128 acc, std::vector<u128>& out) {
-    u64 c = s.varint();
-    if (c > 256) throw Error(CBLX_EFORMAT, "index: trie node with more than 256 entries");
-    u8 vals[256];
-    for (u64 i = 0; i < c; ++i) vals[i] = s.u8_();
-    u64 nc = s.varint();
-    const u32 shift = 8 * (BYTES - 1 - depth);
-    if (depth + 1 == BYTES) {
-        if (nc != 0) throw Error(CBLX_EFORMAT, "index: leaf trie node with children");
-        for (u64 i = 0; i < c; ++i) out.push_back(acc | ((u128)vals[i] << shift));
-        return;
-    }
-    if (nc != c) throw Error(CBLX_EFORMAT, "index: trie node children count mismatch");
-    for (u64 i = 0; i < c; ++i) parse_trie(s, depth + 1, BYTES, acc | ((u128)vals[i] << shift), out);
-}
-void parse_index(const Consts& P, const u8* data, u64 len, HostIndex& h, bool& canonical) {
-    Src s{data, data + len};
-    canonical = s.u8_() != 0;
-    const u64 nb = s.varint();
-    h.off.assign(1, 0);
-    const bool wide = P.wide_suffix();
-    std::vector<u128> tmp;
-    for (u64 r = 0; r < nb; ++r) {
-        h.prefix.push_back((u32)s.varint());
-        const u64 tag = s.varint();
-        if (tag == 0) {
-            const u64 n = s.varint();
-            for (u64 i = 0; i < n; ++i) {
-                const u64 nbts = s.varint();
-                u128 x = 0;
-                for (u64 k = 0; k < nbts; ++k) { u8 b = s.u8_(); if (k < P.BYTES) x |= (u128)b << (8 * k); }
-                h.lo.push_back((u64)x);
-                if (wide) h.hi.push_back((u64)(x >> 64));
-            }
-            h.kind.push_back(KIND_VEC);
-            h.cnt.push_back((u32)n);
-        } else if (tag == 1) {
-            tmp.clear();
-            parse_trie(s, 0, P.BYTES, 0, tmp);
-            const u64 n = s.varint();
-            if (n != tmp.size()) throw Error(CBLX_EFORMAT, "index: trie length field does not match its contents");
-            for (u128 x : tmp) { h.lo.push_back((u64)x); if (wide) h.hi.push_back((u64)(x >> 64)); }
-            h.kind.push_back(KIND_TRIE);
-            h.cnt.push_back((u32)n);
-        } else throw Error(CBLX_EFORMAT, "index: bad TrieOrVec tag");
-        h.off.push_back(h.lo.size());
-    }
-    if (s.p != s.end) throw Error(CBLX_EFORMAT, "index: trailing bytes");  // reject_trailing_bytes
-}
-
 // ---- index bytes -> resident index, streamed (cblx_load): one pass over the bytes, elements go to HBM as they are
 // decoded. The format is a sequential pre-order walk (no lengths to skip by): small files are walked by one host thread
 // with everything around it (pinned double buffering, DMA, directory upload) overlapped; big files are cut speculatively
@@ -746,7 +660,6 @@ template <bool WS> bool load_parallel(cblx_ctx* c, const Consts& P, const u8* bo
     }
     if (nb != NB_UNKNOWN && entries != nb) return false;
     if (n_entries) *n_entries = entries;
-    if (total >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "index: more than 2^32 - 16 words (per-GPU limit of this build)");
     std::vector<u32> prefix, cnt;
     std::vector<u8> kind;
     prefix.reserve(entries); cnt.reserve(entries); kind.reserve(entries);
@@ -790,59 +703,9 @@ template <bool WS> void load_stream(cblx_ctx* c, const u8* data, u64 len, bool& 
         total += cnt[r];
     }
     if (s.p != s.end) throw Error(CBLX_EFORMAT, "index: trailing bytes");  // reject_trailing_bytes
-    if (total >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "index: more than 2^32 - 16 words (per-GPU limit of this build)");
     Buf<u64> a_lo = lo.finish(), a_hi;
     if (WS) a_hi = hi->finish();
     install_index(c, prefix, cnt, kind, std::move(a_lo), std::move(a_hi));
-}
-
-// `self |= other` on host copies (v1): src/wordset/set_ops.rs:123-157 + src/trievec/set_ops.rs:43-71
-// returns true when `b` changed: the reference's |= walks other's bucket with iter_sorted, which sorts a Vec in place
-bool merge_host(const Consts& P, const HostIndex& a, HostIndex& b, HostIndex& o) {
-    bool b_changed = false;
-    const bool wide = P.wide_suffix();
-    auto get = [&](const HostIndex& h, u64 i) -> u128 { return wide ? (((u128)h.hi[i] << 64) | h.lo[i]) : (u128)h.lo[i]; };
-    auto put = [&](u128 x) { o.lo.push_back((u64)x); if (wide) o.hi.push_back((u64)(x >> 64)); };
-    o.off.assign(1, 0);
-    u64 i = 0, j = 0;
-    const u64 na = a.prefix.size(), nb = b.prefix.size();
-    std::vector<u128> sa, sb;
-    while (i < na || j < nb) {
-        if (j >= nb || (i < na && a.prefix[i] < b.prefix[j])) {  // self only: untouched
-            o.prefix.push_back(a.prefix[i]); o.kind.push_back(a.kind[i]); o.cnt.push_back(a.cnt[i]);
-            for (u64 t = a.off[i]; t < a.off[i + 1]; ++t) put(get(a, t));
-            ++i;
-        } else if (i >= na || b.prefix[j] < a.prefix[i]) {       // other only: cloned as stored
-            o.prefix.push_back(b.prefix[j]); o.kind.push_back(b.kind[j]); o.cnt.push_back(b.cnt[j]);
-            for (u64 t = b.off[j]; t < b.off[j + 1]; ++t) put(get(b, t));
-            ++j;
-        } else {                                                  // both: sorted(self) ++ sorted(other \ self) or trie union
-            sa.clear(); sb.clear();
-            for (u64 t = a.off[i]; t < a.off[i + 1]; ++t) sa.push_back(get(a, t));
-            for (u64 t = b.off[j]; t < b.off[j + 1]; ++t) sb.push_back(get(b, t));
-            std::sort(sa.begin(), sa.end());
-            if (!std::is_sorted(sb.begin(), sb.end())) {
-                std::sort(sb.begin(), sb.end());
-                for (u64 t = b.off[j], q = 0; t < b.off[j + 1]; ++t, ++q) { b.lo[t] = (u64)sb[q]; if (wide) b.hi[t] = (u64)(sb[q] >> 64); }
-                b_changed = true;
-            }
-            std::vector<u128> ins;
-            std::set_difference(sb.begin(), sb.end(), sa.begin(), sa.end(), std::back_inserter(ins));
-            u64 n = 0;
-            if (a.kind[i] == KIND_VEC) {
-                for (u128 x : sa) { put(x); ++n; }
-                for (u128 x : ins) { put(x); ++n; }   // pushed at the end; no threshold check (Vec may exceed 1024)
-            } else {
-                std::vector<u128> u;
-                std::merge(sa.begin(), sa.end(), ins.begin(), ins.end(), std::back_inserter(u));
-                for (u128 x : u) { put(x); ++n; }
-            }
-            o.prefix.push_back(a.prefix[i]); o.kind.push_back(a.kind[i]); o.cnt.push_back((u32)n);
-            ++i; ++j;
-        }
-        o.off.push_back(o.lo.size());
-    }
-    return b_changed;
 }
 
 

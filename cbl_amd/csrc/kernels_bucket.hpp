@@ -1134,10 +1134,10 @@ __global__ __launch_bounds__(256) void k_bucket_huge(const BDesc* __restrict__ l
 }
 
 // dense gather of the resident suffixes (for export / serialization): out[res_off[r] + j] = arena[start[r] + j]
-__global__ void k_gather_dense(u64 nelem, u64 nb, const u64* __restrict__ res_off, const u64* __restrict__ start,
+__global__ void k_gather_dense(u64 e0, u64 nelem, u64 nb, const u64* __restrict__ res_off, const u64* __restrict__ start,
                                const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u32 SB, u64* __restrict__ out_lo,
                                u64* __restrict__ out_hi) {
-    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 e = e0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nelem) return;
     u64 l = 0, h = nb;
     while (h - l > 1) {
@@ -1236,10 +1236,10 @@ __global__ void k_checksum_index(u64 nelem, u64 nb, const u64* __restrict__ res_
 }
 // one wave per bucket: Trie buckets strictly ascending (hence distinct), Vec buckets pairwise distinct, kinds consistent
 // with the insert-only rule when `strict` (Vec <= 1024 < Trie). bad[0] += violations.
-__global__ __launch_bounds__(256) void k_validate(u64 nb, const u64* __restrict__ start, const u32* __restrict__ count,
+__global__ __launch_bounds__(256) void k_validate(u64 r0, u64 nb, const u64* __restrict__ start, const u32* __restrict__ count,
                                                   const u8* __restrict__ kind, const u64* __restrict__ a_lo,
                                                   const u64* __restrict__ a_hi, u32 SB, u32 strict, u64* __restrict__ bad) {
-    const u64 r = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u64 r = r0 + (((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const u32 lane = threadIdx.x & 63;
     if (r >= nb) return;
     const u64 s0 = start[r];

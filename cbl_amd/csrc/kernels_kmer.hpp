@@ -190,10 +190,10 @@ __global__ __launch_bounds__(JOIN_THREADS) void k_query_join(u64 nbq, u64 b0, co
 // CBL::iter: element e of the index in iteration order (prefixes ascending, bucket order as stored: a Vec in
 // first-occurrence order, a Trie ascending — src/wordset/mod.rs:298-309, src/trievec/mod.rs:198-206) -> word ->
 // recover_kmer (src/cbl.rs:208-214, revert_necklace_pos src/necklace/mod.rs:29-31).
-__global__ void k_export_kmers(u64 nelem, u64 nb, const u64* __restrict__ res_off, const u32* __restrict__ bucket_prefix,
+__global__ void k_export_kmers(u64 e0, u64 nelem, u64 nb, const u64* __restrict__ res_off, const u32* __restrict__ bucket_prefix,
                                const u64* __restrict__ start, const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, Consts P,
                                u64* __restrict__ out_lo, u64* __restrict__ out_hi) {
-    const u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 e = e0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nelem) return;
     u64 l = 0, h = nb;
     while (h - l > 1) {

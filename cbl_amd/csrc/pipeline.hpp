@@ -20,7 +20,7 @@ struct Records {
 template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA, Resident& nr) {
     typedef typename C::HiT HiT;
     const Consts& P = c->P;
-    if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "more than 2^32-16 words in one index are not supported yet");
+    if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "a single batch takes fewer than 2^32-16 words (callers cut larger inserts into sub-batches)");
     // ping-pong: A = rec.lo/hi, B = rec.lo2/hi2. With an external source pass 0 reads it and writes A.
     const u64* lo = rec.ext_lo ? rec.ext_lo : rec.lo.get();
     const HiT* hi = rec.ext_lo ? (const HiT*)rec.ext_hi : (const HiT*)rec.hi.get();
@@ -316,7 +316,6 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
         return;
     }
     const Resident& s = c->res;
-    if (s.count + N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "more than 2^32-16 words in one index are not supported yet");
     const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
     hipLaunchKernelGGL(k_run_lengths, grid1(nb_.nb, 256), dim3(256), 0, c->stream, nb_.nb, nb_.start.get(), nb_.cnt.get(), nb_.kind.get());
     adopt_arena(nb_);  // the sorted batch plays `other` in the gather below
@@ -443,14 +442,45 @@ void check_aligned16(const void* p, const char* what) {
     if (((uintptr_t)p) & 15) throw Error(CBLX_EINVAL, std::string(what) + " must be 16-byte aligned");
 }
 
+// One call of the kernels takes fewer than 2^32 words (32-bit positions inside a batch: tile tables, start_dense). A larger
+// insert is cut at sequence boundaries into sub-batches that go in one after the other: the result is the same (batch
+// boundaries do not change what an insert-only history builds), the resident index itself has
+// 64-bit positions throughout. CBLX_BATCH_MAX_BASES overrides the cut (tests use a tiny value).
+u64 batch_max_bases() {
+    const char* e = std::getenv("CBLX_BATCH_MAX_BASES");
+    const u64 x = e ? std::strtoull(e, nullptr, 10) : 0;
+    return x ? x : (1ull << 31);
+}
+void insert_device_one(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq);
 void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq) {
     if (nseq == 0) return;
     check_aligned16(d_bases, "d_bases");
+    const u64 cap = batch_max_bases();
+    const u64 first = d2h<u64>(c, d_offsets), last = d2h<u64>(c, d_offsets + nseq);
+    if (last < first) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
+    if (last - first <= cap) { insert_device_one(c, d_bases, d_offsets, nseq); return; }
+    u64 a = 0, oa = first;
+    while (a < nseq) {
+        u64 lo = a + 1, hi = nseq;  // largest b in [a + 1, nseq] with offsets[b] - oa <= cap (a + 1 if even one sequence is longer)
+        if (d2h<u64>(c, d_offsets + hi) - oa <= cap) lo = hi;
+        else {
+            while (hi - lo > 1) {  // offsets[hi] - oa > cap
+                const u64 mid = lo + (hi - lo) / 2;
+                if (d2h<u64>(c, d_offsets + mid) - oa <= cap) lo = mid; else hi = mid;
+            }
+        }
+        insert_device_one(c, d_bases, d_offsets + a, lo - a);
+        a = lo;
+        oa = d2h<u64>(c, d_offsets + a);
+    }
+}
+void insert_device_one(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq) {
     dispatch(c->P, [&](auto cfg) {
         typedef decltype(cfg) C;
         ChunkPlan pl;
         plan_chunks(c, d_bases, d_offsets, nseq, pl);
         if (pl.n_kmers == 0) return;
+        if (pl.n_kmers >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "one sequence of 2^32-16 k-mers or more is not supported");
         Records rec;
         begin_records<C>(c, rec, pl.n_kmers);
         const u64 base = 0;
@@ -662,7 +692,6 @@ template <typename C> void insert_sorted_batches(cblx_ctx* c, const cblx_batch_v
         add += bt[b].n_words;
     }
     if (add == 0) return;
-    if (s.count + add >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "more than 2^32-16 words in one index are not supported yet");
     const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
     Resident nr;
     Buf<u32> raw, m_cs, bad(c->pool, 1);

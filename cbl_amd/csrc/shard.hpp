@@ -143,7 +143,6 @@ template <bool WS> void load_range(cblx_ctx* c, const u8* begin, const u8* end, 
             prefix.push_back(pf); cnt.push_back(cn); kind.push_back(kd);
             total += cn;
         }
-        if (total >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "index: more than 2^32 - 16 words (per-GPU limit of this build)");
         Buf<u64> a_lo = lo.finish(), a_hi;
         if (WS) a_hi = hi->finish();
         n_entries = prefix.size();
@@ -251,7 +250,6 @@ template <typename C> void install_buckets(cblx_ctx* c, const cblx_bucket_view* 
         if (nw) throw Error(CBLX_EINVAL, "bucket batch: words without buckets");
         return;
     }
-    if (nw >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "more than 2^32-16 words in one index are not supported yet");
     Resident nr;
     nr.bv = Buf<u64>(c->pool, nwords);
     nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
@@ -272,9 +270,11 @@ template <typename C> void install_buckets(cblx_ctx* c, const cblx_bucket_view* 
             CBLX_HIP(hipMemcpyAsync(nr.cnt.get() + b0, v.d_count, v.n_buckets * 4, hipMemcpyDeviceToDevice, c->stream));
             CBLX_HIP(hipMemcpyAsync(nr.kind.get() + b0, v.d_kind, v.n_buckets, hipMemcpyDeviceToDevice, c->stream));
         }
-        if (v.n_words)
-            hipLaunchKernelGGL((k_unpack_suffix<WS>), grid1(v.n_words, 256), dim3(256), 0, c->stream, v.n_words, v.d_suffix, P.BYTES, nr.a_lo.get() + w0,
-                               WS ? nr.a_hi.get() + w0 : (u64*)nullptr);
+        for (u64 e0 = 0; e0 < v.n_words; e0 += 1ull << 31) {  // one launch addresses fewer than 2^32 work items
+            const u64 m = std::min<u64>(1ull << 31, v.n_words - e0);
+            hipLaunchKernelGGL((k_unpack_suffix<WS>), grid1(m, 256), dim3(256), 0, c->stream, m, v.d_suffix + e0 * P.BYTES, P.BYTES, nr.a_lo.get() + w0 + e0,
+                               WS ? nr.a_hi.get() + w0 + e0 : (u64*)nullptr);
+        }
         b0 += v.n_buckets;
         w0 += v.n_words;
     }

@@ -31,6 +31,7 @@ import numpy as np
 
 MAX_MSG_BYTES = 256 << 20  # cap of one point-to-point message of the exchange
 MAX_DEST = 16  # cblx.h: the destination partition takes at most 16 prefix ranges
+SLICE_MAX_BASES = 1 << 31  # bases per slice of a rank's shard: one slice = one batch of fewer than 2^32 words
 HIST_BITS = 16      # resolution of the splitter histogram (top bits of the prefix)
 SAMPLE_STRIDE = 61  # every 61st word feeds the histogram
 
@@ -247,6 +248,11 @@ class ShardedBuilder(_Wire):
         return [(cuts[c], cuts[c + 1]) for c in range(slices)]
 
     def insert_seqs_device(self, d_bases, d_offsets, n):
+        # one slice goes through the kernels as ONE batch, and a batch takes fewer than 2^32 words: more slices for a big
+        # shard (the same number on every rank: a slice is also a round of the exchange)
+        nbases = int(d_offsets[n] - d_offsets[0]) if n else 0
+        need = -(-nbases // SLICE_MAX_BASES)
+        self._slices_now = max(self.slices, self._all_reduce_ints([need], "max")[0])
         if self.protocol == "sorted":
             return self._insert_sorted(d_bases, d_offsets, n)
         return self._insert_words(d_bases, d_offsets, n)
@@ -268,7 +274,7 @@ class ShardedBuilder(_Wire):
         slices_in = []  # (recv_b, recv_w, prefix_r, count_r, suffix_r) per slice
         inflight = []
         send_tot, recv_tot = [0] * W, [0] * W
-        for a, b in self.slice_bounds(n, self.slices):
+        for a, b in self.slice_bounds(n, self._slices_now):
             off = d_offsets[a : b + 1]  # offsets stay absolute: no copy of the bases
             if self.bounds is None:
                 self._choose_bounds_from(d_bases, off, b - a)
@@ -315,7 +321,7 @@ class ShardedBuilder(_Wire):
         inflight = []  # (works, send buffers kept alive)
         send_tot = [0] * W
         recv_tot = [0] * W
-        for a, b in self.slice_bounds(n, self.slices):
+        for a, b in self.slice_bounds(n, self._slices_now):
             off = d_offsets[a : b + 1]  # offsets stay absolute: no copy of the bases
             if self.bounds is None or not hasattr(eng, "seq_words_partitioned"):
                 lo, hi = eng.seq_words(d_bases, off, b - a)
@@ -387,6 +393,9 @@ class GpuShard:
 
     def builder_engine(self):
         return GpuEngine(self.cbl)
+
+    def clear(self):
+        self.cbl.clear()
 
     def count(self) -> int:
         return self.cbl.count()
@@ -482,6 +491,14 @@ class ShardedIndex(_Wire):
         sh = self.shard.new_like(profile=profile)
         sh.merge_assign(self.shard)  # |= into an empty index clones every bucket as stored (src/trievec/set_ops.rs:43-71)
         return self._like(sh, self.bounds)
+
+    def copy_from(self, other: "ShardedIndex") -> "ShardedIndex":
+        """Make this index a copy of `other` (same bounds), reusing this rank's context and its cached device memory."""
+        self.shard.clear()
+        self.shard.merge_assign(other.shard)
+        self.bounds = None if other.bounds is None else np.asarray(other.bounds, dtype=np.uint32).copy()
+        self._builder = None
+        return self
 
     # ---- files ---------------------------------------------------------------------------------------------------------
     def load_from_file(self, path, bounds=None):

@@ -211,6 +211,11 @@ class OracleShard:
     def builder_engine(self):
         return OracleEngine(self.o, self.k, self.pb)
 
+    def clear(self):
+        from oracle import Oracle
+
+        self.o = Oracle(self.k, self.pb, self.canonical)
+
     def count(self):
         return self.o.count()
 

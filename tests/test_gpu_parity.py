@@ -259,6 +259,32 @@ def test_merge_matches_oracle():
         _check_index(g1, o1)
 
 
+def test_merge_through_the_peer_copy_path(monkeypatch):
+    """`|=` of indexes on different GPUs copies other's resident index over the fabric (hipMemcpyPeer) and merges on the
+    device; CBLX_FORCE_PEER_COPY=1 takes that path on one GPU. Same bytes as the oracle for self and other, quirks included,
+    also into an empty self."""
+    _need_gpu()
+    monkeypatch.setenv("CBLX_FORCE_PEER_COPY", "1")
+    rng = random.Random(22)
+    for k, pb, n, canonical in ((31, 24, 20000, False), (11, 8, 60000, False), (13, 10, 150000, True), (59, 28, 30000, True), (35, 6, 3000, False)):
+        s1, s2 = _rand_seq(rng, n), _rand_seq(rng, n // 2) + _rand_seq(rng, 64)
+        if n >= 100000:
+            s2 = s2 + s1[n // 3: n // 3 + n // 4]
+        g1, g2 = cbl_amd.CBL(k, pb, canonical=canonical), cbl_amd.CBL(k, pb, canonical=canonical)
+        o1, o2 = Oracle(k, pb, canonical), Oracle(k, pb, canonical)
+        g1.insert_seq(s1), o1.insert_seq(s1)
+        g2.insert_seq(s2), o2.insert_seq(s2)
+        e, oe = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
+        e |= g2
+        oe.merge(o2)
+        _check_index(e, oe)
+        g1 |= g2
+        o1.merge(o2)
+        _check_index(g1, o1)
+        _check_index(g2, o2)
+        assert g1.validate(strict=False) == 0 and g2.validate(strict=False) == 0
+
+
 def test_contains_seq():
     _need_gpu()
     rng = random.Random(3)
@@ -460,6 +486,69 @@ def test_full_size_merge_properties():
     assert (A.count(), A.checksum()) == before
     hb, _ = synth.reads(43, 2, L, first_read=n - shared - 2)
     assert all(A.contains_seq(hb[:L].tobytes()))
+
+
+def test_sub_batches_equal_one_shot(monkeypatch):
+    """An insert larger than one batch is cut at sequence boundaries into sub-batches (cblx.h: a batch takes < 2^32 words);
+    forced here with a tiny cut: same bytes as the oracle, for host and device inputs, incl. a sequence longer than the cut."""
+    _need_gpu()
+    monkeypatch.setenv("CBLX_BATCH_MAX_BASES", "5000")
+    rng = random.Random(12)
+    for k, pb, canonical in ((31, 24, False), (59, 28, True), (11, 6, False)):
+        seqs = [_rand_seq(rng, n) for n in [150] * 200 + [12000, 150, 150, 7000] + [300] * 40]
+        bases, offsets = _concat(seqs)
+        o = Oracle(k, pb, canonical)
+        o.insert_seqs(bases, offsets)
+        g = cbl_amd.CBL(k, pb, canonical=canonical)
+        pad = (-len(bases)) % 16 + 16
+        d_b = torch.from_numpy(np.concatenate([bases, np.zeros(pad, np.uint8)])).cuda()
+        d_o = torch.from_numpy(offsets.astype(np.int64)).cuda()
+        g.insert_seqs_device(d_b, d_o, len(seqs))
+        _check_index(g, o)
+        h = cbl_amd.CBL(k, pb, canonical=canonical)
+        h.insert_seqs(bases, offsets)
+        _check_index(h, o)
+
+
+def test_more_than_2_pow_32_words_in_one_index():
+    """36 M x 150 bp reads = 4.32 G k-mers (> 2^32) in ONE index on one GPU: three sub-batches through the incremental path;
+    then `|=` of two 2.4 G-word indexes. Size-independent properties: count, checksum == checksum of the word stream,
+    structure, membership, idempotence of a re-insert of the last batch."""
+    _need_gpu()
+    k, pb, L = 31, 24, 150
+    n = 36_000_000
+    n_kmers = n * (L - k + 1)
+    assert n_kmers > 1 << 32
+    d_b, d_o = synth.reads_torch(42, n, L, device="cuda")
+    g = cbl_amd.CBL(k, pb)
+    g.insert_seqs_device(d_b, d_o, n)
+    assert g.count() == n_kmers  # no chance repeats in this stream
+    cs = g.checksum()
+    lo = torch.empty(n_kmers + 1, dtype=torch.int64, device="cuda")
+    hi = _hi_tensor(g, n_kmers + 1)
+    assert g.seq_words_device(d_b, d_o, n, lo, hi, n_kmers) == n_kmers
+    assert cs == g.checksum_words_device(lo, hi, n_kmers)
+    del lo, hi
+    assert g.validate() == 0
+    hb, _ = synth.reads(42, 2, L, first_read=n - 2)
+    assert all(g.contains_seq(hb[:L].tobytes())) and all(g.contains_seq(hb[L:].tobytes()))
+    fb, _ = synth.reads(4242, 1, L)
+    assert not any(g.contains_seq(fb.tobytes()))
+    assert g.serialized_size() > 7 * n_kmers
+    g.insert_seqs_device(d_b, d_o[n - 1_000_000:], 1_000_000)  # 1 M reads again: nothing new
+    assert (g.count(), g.checksum()) == (n_kmers, cs)
+    del g
+    half = 20_000_000
+    A, B = cbl_amd.CBL(k, pb), cbl_amd.CBL(k, pb)
+    A.insert_seqs_device(d_b, d_o, half)
+    e_b, e_o = synth.reads_torch(43, half, L, device="cuda")
+    B.insert_seqs_device(e_b, e_o, half)
+    del d_b, e_b
+    ca, cb, xa, xb = A.count(), B.count(), A.checksum(), B.checksum()
+    assert ca + cb > 1 << 32
+    A |= B
+    assert A.count() == ca + cb and A.checksum() == (xa + xb) & ((1 << 64) - 1)
+    assert A.validate(strict=False) == 0 and (B.count(), B.checksum()) == (cb, xb)
 
 
 # ---- the CLI path: FASTA / FASTQ file -> index file, byte-identical to the oracle's ------------------------------------
@@ -1289,6 +1378,9 @@ def _sharded_index_worker(rank, world, port, k, pb, canonical, per, L, slices, t
         cA, cB = A.count(), B.count()
         E = A.clone()
         assert E.count() == cA
+        F = new()
+        feed(F, 5)
+        assert F.copy_from(A).count() == cA and np.array_equal(F.bounds, A.bounds)
         R = B.resharded(A.bounds)  # B itself is left alone
         assert R.count() == cB and np.array_equal(R.bounds, A.bounds) and not np.array_equal(B.bounds, A.bounds)
         A.merge_assign(B)

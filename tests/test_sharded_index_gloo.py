@@ -61,6 +61,9 @@ def _worker(rank, world, port, k, pb, canonical, per, L, slices, tmp, q):
         E = new()
         E.merge_assign(A)  # empty |= A: a clone at A's bounds
         assert E.count() == cA and np.array_equal(E.bounds, A.bounds)
+        F = new()
+        feed(F, 5)
+        assert F.copy_from(A).count() == cA and np.array_equal(F.bounds, A.bounds)
         A.merge_assign(B)
         assert np.array_equal(A.bounds, B.bounds)  # B was re-sharded in place
         assert B.count() == cB and A.stats["messages"] > 0
