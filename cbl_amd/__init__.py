@@ -63,6 +63,9 @@ SIGNATURES = {
     "cblx_insert_seqs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "cblx_insert_seqs_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "cblx_insert_fastx_file": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]),
+    "cblx_stage_fastx_blocks": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cblx_stage_release": (C.c_int, [C.c_void_p]),
     "cblx_flush": (C.c_int, [C.c_void_p]),
     "cblx_insert_words_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "cblx_seq_words_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -216,6 +219,23 @@ class CBL:
         n = C.c_uint64(0)
         self._chk(self._L.cblx_insert_fastx_file(self._h, os.fsencode(path), C.byref(n)))
         return n.value
+
+    def count_fastx_records(self, path) -> int:
+        n = C.c_uint64(0)
+        self._chk(self._L.cblx_stage_fastx_blocks(self._h, os.fsencode(path), 0, 0, 1, None, None, None, C.byref(n)))
+        return n.value
+
+    def stage_fastx_blocks(self, path, block: int, rank: int, world: int):
+        """Parse a FASTA/FASTQ(.gz) file and stage this rank's block-cyclic share in HBM without inserting it. Returns
+        (device address of the bases, device address of the n + 1 uint64 offsets, n staged, records in the file); the arrays
+        stay valid until stage_release()."""
+        pb, po = C.c_void_p(), C.c_void_p()
+        n, tot = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.cblx_stage_fastx_blocks(self._h, os.fsencode(path), block, rank, world, C.byref(pb), C.byref(po), C.byref(n), C.byref(tot)))
+        return pb.value or 0, po.value or 0, n.value, tot.value
+
+    def stage_release(self):
+        self._chk(self._L.cblx_stage_release(self._h))
 
     def insert_seqs_device(self, d_bases, d_offsets, n: int):
         """Same with inputs resident in HBM (torch uint8 / int64 CUDA tensors or raw device addresses)."""

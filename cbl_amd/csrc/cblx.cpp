@@ -78,14 +78,23 @@ template <typename C> void words_of_host_kmers(cblx_ctx* c, const uint64_t* lo, 
     if (d2h<u32>(c, bad.get())) throw Error(CBLX_EINVAL, "k-mer has bits set above 2K (not an IntKmer<K>)");
 }
 
-void read_fastx_into_queue(cblx_ctx* c, const char* path, uint64_t* n_records) {
+// which records of a file a reader keeps: all (block = 0), or the ones block-cyclic dealing gives `rank` of `world` — record i
+// (file order, 0-based) belongs to rank (i / block) % world. count_only: keep none, just count.
+struct RecordFilter {
+    u64 block = 0;
+    u32 rank = 0, world = 1;
+    bool count_only = false;
+    bool mine(u64 i) const { return !count_only && (block == 0 || (i / block) % world == rank); }
+};
+void read_fastx_into_queue(cblx_ctx* c, const char* path, uint64_t* n_records, const RecordFilter* filt = nullptr) {
     {
         if (n_records) *n_records = 0;
         if (!path) throw Error(CBLX_EINVAL, "null argument");
-        {   // large plain files: parallel reader; anything it does not take is read sequentially below
+        if (!filt) {   // large plain files: parallel reader; anything it does not take is read sequentially below
             u64 npar = 0;
             if (fastx_parallel(c, path, &npar)) { if (n_records) *n_records = npar; return; }
         }
+        auto mine = [&](u64 i) { return !filt || filt->mine(i); };
         ByteSource src;
         src.open(path);
         LineReader lr(src);
@@ -97,15 +106,15 @@ void read_fastx_into_queue(cblx_ctx* c, const char* path, uint64_t* n_records) {
         while ((have_line = lr.next(p, n)) && n == 0) {}
         if (!have_line) return;
         if (p[0] != '>' && p[0] != '@') throw Error(CBLX_EFORMAT, "not a FASTA/FASTQ file (first record does not start with '>' or '@')");
-        const u64 flush_at = std::min<u64>(1ull << 30, ingest_flush_bytes());
+        const u64 flush_at = filt ? ~0ull : std::min<u64>(1ull << 30, ingest_flush_bytes());  // staged records are never inserted here
         try {
         if (p[0] == '>') {
             bool open_rec = true;  // the header line has been consumed
             while (lr.next(p, n)) {
-                if (n && p[0] == '>') { ingest_end_seq(c, flush_at); ++nrec; continue; }
-                if (n) ingest_bases(c, p, n);
+                if (n && p[0] == '>') { if (mine(nrec)) ingest_end_seq(c, flush_at); ++nrec; continue; }
+                if (n && mine(nrec)) ingest_bases(c, p, n);
             }
-            if (open_rec) { ingest_end_seq(c, flush_at); ++nrec; }
+            if (open_rec) { if (mine(nrec)) ingest_end_seq(c, flush_at); ++nrec; }
         } else {
             for (;;) {
                 if (n == 0) { if (!lr.next(p, n)) break; continue; }  // blank line between records
@@ -113,11 +122,11 @@ void read_fastx_into_queue(cblx_ctx* c, const char* path, uint64_t* n_records) {
                 const u8 *sq, *pl, *ql;
                 size_t ns, npl, nq;
                 if (!lr.next(sq, ns)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
-                if (ns) ingest_bases(c, sq, ns);  // the buffer may move on the next call: consume the line first
+                if (ns && mine(nrec)) ingest_bases(c, sq, ns);  // the buffer may move on the next call: consume the line first
                 if (!lr.next(pl, npl)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
                 if (npl == 0 || pl[0] != '+') throw Error(CBLX_EFORMAT, "FASTQ: expected '+' separator");
                 if (!lr.next(ql, nq)) throw Error(CBLX_EFORMAT, "FASTQ: truncated record");
-                ingest_end_seq(c, flush_at);
+                if (mine(nrec)) ingest_end_seq(c, flush_at);
                 ++nrec;
                 if (!lr.next(p, n)) break;
             }
@@ -224,6 +233,34 @@ int cblx_query_fastx_file(cblx_ctx* c, const char* path, uint64_t* n_records, ui
     });
 }
 
+int cblx_stage_fastx_blocks(cblx_ctx* c, const char* path, uint64_t block, uint32_t rank, uint32_t world, const uint8_t** d_bases,
+                            const uint64_t** d_offsets, uint64_t* n_staged, uint64_t* n_in_file) {
+    return guard(c, [&] {
+        if (!path || !n_in_file) throw Error(CBLX_EINVAL, "null argument");
+        if (block && (world == 0 || rank >= world)) throw Error(CBLX_EINVAL, "rank must be below world");
+        if (block && (!d_bases || !d_offsets || !n_staged)) throw Error(CBLX_EINVAL, "null argument");
+        flush(c);  // whatever was enqueued for this index goes in first: the queue changes hands
+        Ingest& g = c->ing;
+        if (g.staged) throw Error(CBLX_EINVAL, "records are staged in this context already: call cblx_stage_release first");
+        RecordFilter f;
+        f.block = block; f.rank = rank; f.world = world; f.count_only = block == 0;
+        try {
+            read_fastx_into_queue(c, path, n_in_file, &f);
+        } catch (...) { ingest_drop(c); throw; }
+        if (block == 0) return;
+        if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
+        if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));
+        ingest_wait(c);
+        if (g.nseq == 0) ingest_reserve(c, 0, 0);  // a rank without records still gets valid (empty) arrays
+        g.staged = true;
+        *d_bases = g.d_bases.get();
+        *d_offsets = g.d_off.get();
+        *n_staged = g.nseq;
+    });
+}
+int cblx_stage_release(cblx_ctx* c) {
+    return guard(c, [&] { if (c->ing.staged) ingest_drop(c); });
+}
 int cblx_insert_words_device(cblx_ctx* c, const uint64_t* d_lo, const void* d_hi, uint64_t n) {
     return guard(c, [&] {
         flush(c);

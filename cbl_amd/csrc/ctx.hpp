@@ -111,7 +111,9 @@ struct Ingest {
     Writer wb, wo;
     hipStream_t s = nullptr;
     std::unique_ptr<Xfer> xfer;
-    // consumer of the queue: the insert pipeline, or (cblx_query_fastx_file) the membership query with these tallies
+    // consumer of the queue: the insert pipeline, or (cblx_query_fastx_file) the membership query with these tallies, or
+    // (cblx_stage_fastx_blocks) the caller, who borrows the staged buffers until cblx_stage_release
+    bool staged = false;
     bool query = false;
     u64 q_total = 0, q_positive = 0;
 };

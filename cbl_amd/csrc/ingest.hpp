@@ -80,6 +80,7 @@ void flush(cblx_ctx* c);
 // a piece of the sequence being enqueued (a FASTA record arrives line by line), then its end
 void ingest_bases(cblx_ctx* c, const u8* p, u64 len) {
     Ingest& g = c->ing;
+    if (g.staged) throw Error(CBLX_EINVAL, "records are staged in this context: call cblx_stage_release first");
     ingest_reserve(c, len, 1);
     writer_put(c, g.wb, Ingest::BASES_BLK, g.d_bases.get(), p, len);
     g.nbytes += len;
@@ -126,6 +127,7 @@ void ingest_seqs(cblx_ctx* c, const u8* bases, const u64* offsets, u64 n) {
         for (u64 i = 0; i < n; ++i) ingest_seq(c, bases + offsets[i], offsets[i + 1] - offsets[i]);
         return;
     }
+    if (g.staged) throw Error(CBLX_EINVAL, "records are staged in this context: call cblx_stage_release first");
     ingest_reserve(c, len, n);
     if (!g.s) CBLX_HIP(hipStreamCreateWithFlags(&g.s, hipStreamNonBlocking));
     if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
@@ -150,6 +152,7 @@ void ingest_drop(cblx_ctx* c) {  // forget everything enqueued (clear / load)
     ingest_wait(c);
     for (Ingest::Writer* w : {&g.wb, &g.wo}) { w->fill = 0; w->issued = 0; w->busy[0] = w->busy[1] = false; }
     g.nbytes = g.nseq = g.last_end = 0;
+    g.staged = false;
 }
 void ingest_destroy(cblx_ctx* c) {
     Ingest& g = c->ing;
@@ -170,7 +173,7 @@ void ingest_destroy(cblx_ctx* c) {
 void flush(cblx_ctx* c) {
     Ingest& g = c->ing;
     const u64 nseq = g.nseq;
-    if (nseq == 0) return;
+    if (nseq == 0 || g.staged) return;  // staged records belong to the caller (cblx_stage_fastx_blocks), not to this index
     CBLX_HIP(hipSetDevice(c->device));
     if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
     if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));

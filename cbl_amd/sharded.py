@@ -51,6 +51,13 @@ def choose_bounds(hist: np.ndarray, world: int, prefix_bits: int, hist_bits: int
     return np.asarray(bounds, dtype=np.uint32)
 
 
+class _DeviceArray:
+    """Device memory owned by libcblx, viewed through __cuda_array_interface__ (torch.as_tensor makes a no-copy view)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (n,), "typestr": typestr, "version": 2, "strides": None}
+
+
 class GpuEngine:
     """The three device steps of the sharded build, on libcblx (torch tensors only carry the device memory)."""
 
@@ -109,6 +116,24 @@ class GpuEngine:
 
     def insert_words(self, lo, hi):
         self.cbl.insert_words_device(lo, hi, int(lo.numel()))
+
+    # ---- one file, file-order parity ------------------------------------------------------------------------------------
+    def count_fastx_records(self, path):
+        return self.cbl.count_fastx_records(path)
+
+    def stage_fastx_blocks(self, path, block, rank, world):
+        """This rank's block-cyclic share of the file's records, staged in HBM by libcblx, as torch views (no copy)."""
+        torch = self.torch
+        pb, po, n, n_file = self.cbl.stage_fastx_blocks(path, block, rank, world)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        offsets = torch.as_tensor(_DeviceArray(po, n + 1, "<i8"), device=dev)
+        nbytes = int(offsets[n]) if n else 0
+        bases = torch.as_tensor(_DeviceArray(pb, max(nbytes, 1), "|u1"), device=dev)
+        self.device = dev
+        return bases, offsets, n, n_file
+
+    def stage_release(self):
+        self.cbl.stage_release()
 
     def empty_like(self, t, n):
         return self.torch.empty(n, dtype=t.dtype, device=t.device)
@@ -247,15 +272,39 @@ class ShardedBuilder(_Wire):
             cuts.append(n * acc // tot)
         return [(cuts[c], cuts[c + 1]) for c in range(slices)]
 
-    def insert_seqs_device(self, d_bases, d_offsets, n):
-        # one slice goes through the kernels as ONE batch, and a batch takes fewer than 2^32 words: more slices for a big
-        # shard (the same number on every rank: a slice is also a round of the exchange)
-        nbases = int(d_offsets[n] - d_offsets[0]) if n else 0
-        need = -(-nbases // SLICE_MAX_BASES)
-        self._slices_now = max(self.slices, self._all_reduce_ints([need], "max")[0])
+    def insert_seqs_device(self, d_bases, d_offsets, n, slice_list=None):
+        """slice_list: explicit read ranges [(a, b), ...] of the slices (the same NUMBER of slices on every rank) instead of
+        the default cut of the shard into `slices` pieces."""
+        if slice_list is None:
+            # one slice goes through the kernels as ONE batch, and a batch takes fewer than 2^32 words: more slices for a
+            # big shard (the same number on every rank: a slice is also a round of the exchange)
+            nbases = int(d_offsets[n] - d_offsets[0]) if n else 0
+            need = -(-nbases // SLICE_MAX_BASES)
+            slice_list = self.slice_bounds(n, max(self.slices, self._all_reduce_ints([need], "max")[0]))
+        self._slice_list = list(slice_list)
         if self.protocol == "sorted":
             return self._insert_sorted(d_bases, d_offsets, n)
         return self._insert_words(d_bases, d_offsets, n)
+
+    def insert_fastx_file(self, path, block: int = 0) -> int:
+        """Sharded build from ONE FASTA / FASTQ(.gz) file every rank can read, with the stream order of the file: the
+        records are dealt to the ranks in blocks of `block` records, block-cyclically (block j -> rank j % W, where it is
+        that rank's slice j // W), so slice-major / rank-minor order IS file order and the gathered index is byte-identical
+        to `cbl build` of the file (/root/reference/examples/cbl.rs:154-166). block = 0: sized so that every rank gets
+        about `slices` blocks. Returns the number of records in the file."""
+        eng, W = self.engine, self.world
+        if block <= 0:
+            n_file = eng.count_fastx_records(path)
+            block = max(1, -(-n_file // (W * self.slices)))
+        bases, offsets, n, n_file = eng.stage_fastx_blocks(path, block, self.rank, W)
+        try:
+            nblocks = -(-n_file // block)
+            rounds = -(-nblocks // W)  # the blocks of the file are dealt W at a time
+            sl = [(min(c * block, n), min((c + 1) * block, n)) for c in range(max(rounds, 1))]
+            self.insert_seqs_device(bases, offsets, n, slice_list=sl)
+        finally:
+            eng.stage_release()
+        return n_file
 
     def _choose_bounds_from(self, d_bases, off, n):
         """First batch only: quantile ranges from a sampled, all-reduced prefix histogram of the first slice."""
@@ -274,7 +323,7 @@ class ShardedBuilder(_Wire):
         slices_in = []  # (recv_b, recv_w, prefix_r, count_r, suffix_r) per slice
         inflight = []
         send_tot, recv_tot = [0] * W, [0] * W
-        for a, b in self.slice_bounds(n, self._slices_now):
+        for a, b in self._slice_list:
             off = d_offsets[a : b + 1]  # offsets stay absolute: no copy of the bases
             if self.bounds is None:
                 self._choose_bounds_from(d_bases, off, b - a)
@@ -321,7 +370,7 @@ class ShardedBuilder(_Wire):
         inflight = []  # (works, send buffers kept alive)
         send_tot = [0] * W
         recv_tot = [0] * W
-        for a, b in self.slice_bounds(n, self._slices_now):
+        for a, b in self._slice_list:
             off = d_offsets[a : b + 1]  # offsets stay absolute: no copy of the bases
             if self.bounds is None or not hasattr(eng, "seq_words_partitioned"):
                 lo, hi = eng.seq_words(d_bases, off, b - a)
@@ -475,6 +524,16 @@ class ShardedIndex(_Wire):
         self._builder.bounds = self.bounds
         self._builder.insert_seqs_device(d_bases, d_offsets, n)
         self.bounds = self._builder.bounds
+
+    def insert_fastx_file(self, path, block: int = 0) -> int:
+        """`cbl build` / `cbl insert` of one file on all ranks, stream order = file order (ShardedBuilder.insert_fastx_file)."""
+        if self._builder is None:
+            self._builder = ShardedBuilder(self.shard.cbl, self.dist, engine=self.shard.builder_engine(), slices=self.slices, protocol=self.protocol)
+            self._builder.stats = self.stats
+        self._builder.bounds = self.bounds
+        n = self._builder.insert_fastx_file(path, block)
+        self.bounds = self._builder.bounds
+        return n
 
     def local_count(self) -> int:
         return self.shard.count()

@@ -74,6 +74,18 @@ int cblx_insert_fastx_file(cblx_ctx* ctx, const char* path, uint64_t* n_records)
 /* Materialise everything enqueued so far into the resident index (idempotent). */
 int cblx_flush(cblx_ctx* ctx);
 
+/* The reader loop of examples/cbl.rs:154-163 for a multi-GPU build from ONE file with file-order parity: parses the file like
+ * cblx_insert_fastx_file but INSERTS NOTHING; the records that block-cyclic dealing gives this rank — record i (file order,
+ * 0-based) belongs to rank (i / block) % world — are staged in HBM, in file order, and lent to the caller as device arrays
+ * (bases, n_staged + 1 offsets, d_offsets[0] = 0; d_bases 16-byte aligned) until cblx_stage_release. Local block c (records
+ * [c * block, (c + 1) * block) of the staged list) is block c * world + rank of the file, so a sharded build that feeds local
+ * block c as slice c has the stream order of the file. *n_in_file = records in the whole file. block = 0: count only.
+ * While records are staged the ctx takes no cblx_insert_seq* calls; its index can be read and inserted into by the
+ * *_device entry points. A record shorter than K is CBLX_ESHORT on the rank that owns it. */
+int cblx_stage_fastx_blocks(cblx_ctx* ctx, const char* path, uint64_t block, uint32_t rank, uint32_t world, const uint8_t** d_bases,
+                            const uint64_t** d_offsets, uint64_t* n_staged, uint64_t* n_in_file);
+int cblx_stage_release(cblx_ctx* ctx);
+
 /* Device word arrays (all *_words_device entry points): word i = (hi[i] << 64) | lo[i]. `lo` is uint64_t[]; the element
  * type of `hi` follows from K like the reference's T (build.rs:34-41) and is reported by cblx_consts.hi_bytes:
  *   0 -> no hi array (2K + POS_BITS <= 64; pass NULL), 1 -> uint8_t[] (K = 31: 68-bit words), 8 -> uint64_t[] (K >= 33). */

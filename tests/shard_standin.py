@@ -136,6 +136,37 @@ class OracleEngine:
     def insert_words(self, lo, hi):
         self.o.insert_words(self._to_ints(lo, hi))
 
+    # ---- one file, file-order parity: same contract as cblx_stage_fastx_blocks (include/cblx.h) ----------------------------
+    @staticmethod
+    def _fasta_records(path):
+        recs, cur = [], None
+        for line in open(path, "rb").read().split(b"\n"):
+            line = line.rstrip(b"\r")
+            if line.startswith(b">"):
+                if cur is not None:
+                    recs.append(b"".join(cur))
+                cur = []
+            elif line and cur is not None:
+                cur.append(line)
+        if cur is not None:
+            recs.append(b"".join(cur))
+        return recs
+
+    def count_fastx_records(self, path):
+        return len(self._fasta_records(path))
+
+    def stage_fastx_blocks(self, path, block, rank, world):
+        t = self.torch
+        recs = self._fasta_records(path)
+        mine = [r for i, r in enumerate(recs) if (i // block) % world == rank]
+        offs = np.zeros(len(mine) + 1, dtype=np.int64)
+        offs[1:] = np.cumsum([len(r) for r in mine])
+        raw = b"".join(mine)
+        return (t.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()) if raw else t.empty(0, dtype=t.uint8), t.from_numpy(offs), len(mine), len(recs))
+
+    def stage_release(self):
+        pass
+
     def empty_like(self, t, n):
         return self.torch.empty(n, dtype=t.dtype)
 

@@ -522,13 +522,19 @@ def test_more_than_2_pow_32_words_in_one_index():
     d_b, d_o = synth.reads_torch(42, n, L, device="cuda")
     g = cbl_amd.CBL(k, pb)
     g.insert_seqs_device(d_b, d_o, n)
-    assert g.count() == n_kmers  # no chance repeats in this stream
-    cs = g.checksum()
-    lo = torch.empty(n_kmers + 1, dtype=torch.int64, device="cuda")
-    hi = _hi_tensor(g, n_kmers + 1)
-    assert g.seq_words_device(d_b, d_o, n, lo, hi, n_kmers) == n_kmers
-    assert cs == g.checksum_words_device(lo, hi, n_kmers)
-    del lo, hi
+    count, cs = g.count(), g.checksum()
+    # 4.3 G draws from 4^31 k-mers: about two chance repeats are expected ((4.3e9)^2 / (2 * 4^31)), so the count is not exact
+    assert n_kmers - 20 <= count <= n_kmers
+    # the same reads in two calls (other sub-batch boundaries): the same set
+    g2 = cbl_amd.CBL(k, pb)
+    g2.insert_seqs_device(d_b, d_o, n // 2)
+    g2.insert_seqs_device(d_b, d_o[n // 2:], n - n // 2)
+    assert (g2.count(), g2.checksum()) == (count, cs)
+    del g2
+    # every k-mer of the reads is found (a query batch takes fewer than 2^32 k-mers: two halves)
+    half_k = (n // 2) * (L - k + 1)
+    assert g.contains_seqs_device(d_b, d_o, n // 2) == (half_k, half_k)
+    assert g.contains_seqs_device(d_b, d_o[n // 2:], n - n // 2) == (n_kmers - half_k, n_kmers - half_k)
     assert g.validate() == 0
     hb, _ = synth.reads(42, 2, L, first_read=n - 2)
     assert all(g.contains_seq(hb[:L].tobytes())) and all(g.contains_seq(hb[L:].tobytes()))
@@ -536,7 +542,7 @@ def test_more_than_2_pow_32_words_in_one_index():
     assert not any(g.contains_seq(fb.tobytes()))
     assert g.serialized_size() > 7 * n_kmers
     g.insert_seqs_device(d_b, d_o[n - 1_000_000:], 1_000_000)  # 1 M reads again: nothing new
-    assert (g.count(), g.checksum()) == (n_kmers, cs)
+    assert (g.count(), g.checksum()) == (count, cs)
     del g
     half = 20_000_000
     A, B = cbl_amd.CBL(k, pb), cbl_amd.CBL(k, pb)
@@ -547,8 +553,13 @@ def test_more_than_2_pow_32_words_in_one_index():
     ca, cb, xa, xb = A.count(), B.count(), A.checksum(), B.checksum()
     assert ca + cb > 1 << 32
     A |= B
-    assert A.count() == ca + cb and A.checksum() == (xa + xb) & ((1 << 64) - 1)
+    assert ca + cb - 20 <= A.count() <= ca + cb  # chance repeats between the two read sets aside
+    if A.count() == ca + cb:
+        assert A.checksum() == (xa + xb) & ((1 << 64) - 1)
     assert A.validate(strict=False) == 0 and (B.count(), B.checksum()) == (cb, xb)
+    before = (A.count(), A.checksum())
+    A |= B
+    assert (A.count(), A.checksum()) == before
 
 
 # ---- the CLI path: FASTA / FASTQ file -> index file, byte-identical to the oracle's ------------------------------------
@@ -1452,3 +1463,109 @@ def test_sharded_index_merge_load_save_on_one_gpu(world, k, pb, canonical, per, 
     oc.load(files["a"])
     od.merge(oc)
     assert files["d"] == od.serialize()
+
+
+# ---- one file on N ranks: staged block-cyclic reader, file-order parity -------------------------------------------------------
+def _ragged_fasta(path, seed, nrec, fastq=False):
+    rng = random.Random(seed)
+    recs = []
+    with open(path, "wb") as f:
+        for i in range(nrec):
+            n = rng.choice([64, 150, 151, 300, 777, 2500, 5000])
+            s = _rand_seq(rng, n)
+            recs.append(s)
+            if fastq:
+                f.write(b"@r%d\n" % i + s + b"\n+\n" + b"I" * n + b"\n")
+            else:
+                f.write(b">r%d some text\n" % i)
+                w = rng.choice([60, 80, 10_000])
+                for a in range(0, n, w):
+                    f.write(s[a: a + w] + (b"\r\n" if i % 7 == 3 else b"\n"))
+    return recs
+
+
+@pytest.mark.parametrize("fastq", [False, True])
+def test_stage_fastx_blocks(tmp_path, fastq):
+    """cblx_stage_fastx_blocks: the staged arrays hold exactly the records block-cyclic dealing gives the rank, in file
+    order; nothing is inserted; the ctx keeps working for device inserts and refuses host inserts until the release."""
+    _need_gpu()
+    path = tmp_path / ("r.fq" if fastq else "r.fa")
+    recs = _ragged_fasta(path, 3, 41, fastq)
+    g = cbl_amd.CBL(31, 24)
+    assert g.count_fastx_records(path) == 41 and g.count() == 0
+    from cbl_amd.sharded import GpuEngine
+
+    eng = GpuEngine(g)
+    for world, block in ((1, 7), (3, 4), (4, 1), (2, 100)):
+        for rank in range(world):
+            bases, offsets, n, n_file = eng.stage_fastx_blocks(str(path), block, rank, world)
+            mine = [r for i, r in enumerate(recs) if (i // block) % world == rank]
+            assert n_file == 41 and n == len(mine)
+            off = offsets.cpu().numpy()
+            assert off[0] == 0 and list(np.diff(off)) == [len(r) for r in mine]
+            assert bases[: int(off[-1])].cpu().numpy().tobytes() == b"".join(mine)
+            assert g.count() == 0  # observers do not consume what is staged
+            with pytest.raises(cbl_amd.CblxError):
+                g.insert_seq(recs[0])
+            if n:
+                t = cbl_amd.CBL(31, 24)
+                t.insert_seqs_device(bases, offsets, n)
+                o = Oracle(31, 24)
+                for r in mine:
+                    o.insert_seq(r)
+                assert t.serialize() == o.serialize()
+            eng.stage_release()
+    g.insert_seq(recs[0])
+    assert g.count() == len(recs[0]) - 30
+
+
+def _file_order_worker(rank, world, port, k, pb, canonical, path, block, protocol, q):
+    import torch.distributed as dist
+
+    from cbl_amd import sharded
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        idx = sharded.ShardedIndex(k, pb, sharded.HostStagedGroup(dist), canonical=canonical, device=0, slices=3, protocol=protocol)
+        n = idx.insert_fastx_file(path, block)
+        n2 = idx.insert_fastx_file(path)  # again, block size chosen by the builder: nothing new
+        out = path + ".cbl"
+        idx.save_to_file(out)
+        if rank == 0:
+            q.put((open(out, "rb").read(), n, n2))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k,pb,canonical,nrec,block,protocol", [(2, 31, 24, False, 200, 16, "sorted"), (3, 31, 24, True, 61, 1, "words"), (4, 59, 28, False, 90, 7, "sorted"),
+                                                                    (2, 25, 12, False, 3, 50, "sorted")])
+def test_sharded_build_of_one_file_has_file_order_on_one_gpu(world, k, pb, canonical, nrec, block, protocol, tmp_path):
+    """`cbl build file` on N ranks sharing this GPU (exchange staged through gloo): records dealt block-cyclically, so the
+    job's stream order is the file's and the saved index is byte-identical to the one-process build in file order."""
+    _need_gpu()
+    import socket
+
+    import torch.multiprocessing as mp
+
+    path = str(tmp_path / "reads.fa")
+    recs = _ragged_fasta(path, nrec, nrec)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_file_order_worker, args=(r, world, port, k, pb, canonical, path, block, protocol, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    blob, n, n2 = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert n == n2 == nrec
+    one = Oracle(k, pb, canonical)
+    for r in recs:
+        one.insert_seq(r)
+    assert blob == one.serialize()

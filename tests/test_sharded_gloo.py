@@ -179,3 +179,72 @@ def test_sharded_build_with_ragged_and_empty_shards(protocol):
                     one.insert_seqs(bases, offsets)
         first += sum(batch)
     assert blob == one.serialize()
+
+
+# ---- one FASTA file, all ranks: block-cyclic dealing gives the stream order of the file ---------------------------------
+def _write_fasta(path, seed, nrec):
+    """ragged records (some multi-line, CRLF here and there), deterministic"""
+    import random
+
+    rng = random.Random(seed)
+    recs = []
+    with open(path, "wb") as f:
+        for i in range(nrec):
+            n = rng.choice([40, 64, 150, 151, 300, 777, 2500])
+            s = bytes(rng.choice(b"ACGT") for _ in range(n))
+            recs.append(s)
+            f.write(b">r%d some text\n" % i)
+            w = rng.choice([60, 80, 10_000])
+            for a in range(0, n, w):
+                f.write(s[a : a + w] + (b"\r\n" if i % 7 == 3 else b"\n"))
+    return recs
+
+
+def _worker_file(rank, world, port, k, pb, path, block, protocol, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from cbl_amd import sharded
+    from oracle import Oracle
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = Oracle(k, pb)
+
+        class _Cbl:
+            prefix_bits = pb
+
+        sb = sharded.ShardedBuilder(_Cbl(), dist, engine=OracleEngine(orc, k, pb), slices=3, protocol=protocol)
+        n = sb.insert_fastx_file(path, block)
+        n2 = sb.insert_fastx_file(path, 0)  # again (nothing new), block size chosen by the builder
+        blob = sharded.gather_serialized(orc.serialize(), dist)
+        if rank == 0:
+            q.put((blob, n, n2))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k,pb,nrec,block,protocol", [(2, 31, 24, 57, 5, "sorted"), (3, 15, 8, 40, 1, "words"), (2, 31, 24, 9, 100, "sorted"), (3, 25, 12, 2, 1, "sorted")])
+def test_sharded_build_from_one_file_has_file_order(world, k, pb, nrec, block, protocol, tmp_path):
+    import torch.multiprocessing as mp
+
+    from oracle import Oracle
+
+    path = str(tmp_path / "reads.fa")
+    recs = _write_fasta(path, 5 + nrec, nrec)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_file, args=(r, world, port, k, pb, path, block, protocol, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    blob, n, n2 = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert n == n2 == nrec
+    one = Oracle(k, pb)
+    for s in recs:  # FILE order, one insert_seq per record: what `cbl build` does
+        one.insert_seq(s)
+    assert blob == one.serialize()
