@@ -13,7 +13,7 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libcblx.so"
+LIB_PATH = Path(os.environ["CBLX_LIB_PATH"]) if os.environ.get("CBLX_LIB_PATH") else _HERE / "libcblx.so"  # override: tuning variants (tools/)
 _LIB = None
 
 OK, EINVAL, ESHORT, EFORMAT, EDEVICE, ENOMEM, ERANGE = range(7)

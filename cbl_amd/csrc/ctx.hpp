@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -23,37 +24,62 @@ inline u32 ilog2_npo2(u32 v) { u32 l = 0; while ((1u << l) < v) ++l; return l; }
 inline u64 ceil_div(u64 a, u64 b) { return (a + b - 1) / b; }
 
 // ------------------------------------------------------------------------------------------------
-// cached device allocations (hipMalloc is kept out of the hot path between flushes)
+// cached device allocations (hipMalloc is kept out of the hot path between flushes). One pool per ctx; when the device
+// runs out of memory every pool of the process gives its idle blocks back before the allocation is retried (an index
+// that was built earlier keeps tens of GB of idle workspace cached).
 struct Pool {
     struct Blk { void* p; size_t sz; bool used; };
     std::vector<Blk> blks;
+    std::mutex mu;  // a ctx is single-owner, but another ctx's thread may trim this pool under memory pressure
+    static std::mutex& reg_mu() { static std::mutex m; return m; }
+    static std::vector<Pool*>& registry() { static std::vector<Pool*> r; return r; }
+    Pool() { std::lock_guard<std::mutex> g(reg_mu()); registry().push_back(this); }
+    Pool(const Pool&) = delete;
+    Pool& operator=(const Pool&) = delete;
     void* alloc(size_t sz) {
         if (sz == 0) sz = 256;
         sz = (sz + 255) & ~(size_t)255;
-        int best = -1;
-        for (size_t i = 0; i < blks.size(); ++i)
-            if (!blks[i].used && blks[i].sz >= sz && blks[i].sz <= sz + sz / 2 + 4096 && (best < 0 || blks[i].sz < blks[best].sz)) best = (int)i;
-        if (best >= 0) { blks[best].used = true; return blks[best].p; }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            int best = -1;
+            for (size_t i = 0; i < blks.size(); ++i)
+                if (!blks[i].used && blks[i].sz >= sz && blks[i].sz <= sz + sz / 2 + 4096 && (best < 0 || blks[i].sz < blks[best].sz)) best = (int)i;
+            if (best >= 0) { blks[best].used = true; return blks[best].p; }
+        }
         void* p = nullptr;
         hipError_t e = hipMalloc(&p, sz);
         if (e != hipSuccess) {
-            trim();
+            (void)hipGetLastError();  // the failed call must not surface at the next hipGetLastError() after a launch
+            trim_all();
             e = hipMalloc(&p, sz);
-            if (e != hipSuccess) throw Error(CBLX_ENOMEM, "hipMalloc(" + std::to_string(sz) + ") failed: " + hipGetErrorString(e));
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                throw Error(CBLX_ENOMEM, "hipMalloc(" + std::to_string(sz) + ") failed: " + hipGetErrorString(e));
+            }
         }
+        std::lock_guard<std::mutex> g(mu);
         blks.push_back({p, sz, true});
         return p;
     }
     void release(void* p) {
         if (!p) return;
+        std::lock_guard<std::mutex> g(mu);
         for (auto& b : blks) if (b.p == p) { b.used = false; return; }
     }
     void trim() {
+        std::lock_guard<std::mutex> g(mu);
         std::vector<Blk> keep;
         for (auto& b : blks) { if (b.used) keep.push_back(b); else (void)hipFree(b.p); }
         blks.swap(keep);
     }
-    ~Pool() { for (auto& b : blks) (void)hipFree(b.p); }
+    static void trim_all() {
+        std::lock_guard<std::mutex> g(reg_mu());
+        for (Pool* p : registry()) p->trim();
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> g(reg_mu()); auto& r = registry(); r.erase(std::remove(r.begin(), r.end(), this), r.end()); }
+        for (auto& b : blks) (void)hipFree(b.p);
+    }
 };
 
 template <typename T> struct Buf {  // RAII view on a pool allocation

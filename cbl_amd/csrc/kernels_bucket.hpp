@@ -675,6 +675,9 @@ static const u32 PK_BITS = 12;  // CAP <= 4096
 #define CBLX_MSD_TRIP 3  // measured at cfg 2: 2 -> 6.87 ms, 3 -> 6.66 ms, 4 -> 6.86 ms, 8 -> +0.8 ms
 #endif
 static const int MSD_TRIP = CBLX_MSD_TRIP;  // sub-bucket entries read per trip of the ranking loop (<= the 4 slack entries)
+#ifndef CBLX_MSD_REUSE_BASE
+#define CBLX_MSD_REUSE_BASE 1
+#endif
 #ifndef CBLX_MSD_WAVES
 #define CBLX_MSD_WAVES 7  // waves per SIMD the register allocation aims at (LDS allows 7 workgroups of the 256-thread class; 76 -> 72 VGPRs: 7.28 -> 7.10 ms)
 #endif
@@ -785,7 +788,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     u32 wave_heads = 0;
     u32 sa[ITEMS], sb[ITEMS];  // sub-bucket bounds of every item, fetched in one batch of independent LDS reads
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) { sa[j] = s_off[sub[j]]; sb[j] = s_off[sub[j] + 1]; }
+    for (int j = 0; j < ITEMS; ++j) {
+#if CBLX_MSD_REUSE_BASE
+        sa[j] = sbase[j];  // the offsets did not change since the scatter read them: one LDS read per item less
+#else
+        sa[j] = s_off[sub[j]];
+#endif
+        sb[j] = s_off[sub[j] + 1];
+    }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         head[j] = false;

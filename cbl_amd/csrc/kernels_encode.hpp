@@ -28,6 +28,12 @@ template <typename HiT> __device__ __forceinline__ void st_hi(HiT* p, u64 i, u64
     if constexpr (HiTraits<HiT>::has) p[i] = (HiT)v;
 }
 
+#ifndef CBLX_ENC_UNIFORM
+#define CBLX_ENC_UNIFORM 1
+#endif
+#ifndef CBLX_ENC_HIST_RUNS
+#define CBLX_ENC_HIST_RUNS 1
+#endif
 static const u32 ENC_TILE_BYTES = 4096;
 static const u32 ENC_THREADS = 256;
 static const u32 ENC_MAX_CHUNKS = 1024;                                    // >= 4096 / min chunk length (K >= 5)
@@ -264,6 +270,18 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
     }
     __syncthreads();
     const u32 Q = s_koff[nc];
+#if CBLX_ENC_UNIFORM
+    // Reads of one length back to back (the common input): every chunk of the tile has nk0 k-mers and starts len0 bases
+    // after its predecessor, so chunk and position of k-mer q follow from q by arithmetic and the k-mer loop never reads
+    // the chunk tables.
+    const u32 nk0 = s_koff[1], cs0 = s_cstart[0], len0 = nc > 1 ? s_cstart[1] - s_cstart[0] : 0u;
+    bool uni = nk0 != 0 && !(cs0 >> 31);
+    for (u32 i = tid; i < nc; i += ENC_THREADS) uni = uni && s_koff[i + 1] == (i + 1) * nk0 && s_cstart[i] == cs0 + i * len0;
+    const bool uniform = __syncthreads_and(uni ? 1 : 0) != 0;
+#else
+    const bool uniform = false;
+    const u32 nk0 = 1, cs0 = 0, len0 = 0;
+#endif
 
     auto find_chunk = [&](u32 q) -> u32 {  // last i with s_koff[i] <= q
         u32 lo = 0, hi = nc;
@@ -312,27 +330,60 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
         constexpr u32 KC = decltype(kc)::value;
         Consts PK = P;
         if constexpr (KC != 0) { PK.K = KC; PK.KB = 2 * KC; PK.POS = 32 - __builtin_clz(2 * KC - 1); }
-        u32 ci = tid < Q ? find_chunk(tid) : 0u;
-        for (u32 q = tid; q < Q; q += ENC_THREADS) {
-            while (q >= s_koff[ci + 1]) ++ci;  // q only grows: walk forward from the previous chunk instead of searching again
-            const u32 cs = s_cstart[ci];
-            if (cs >> 31) continue;
-            const u32 j = q - s_koff[ci];
+        const u64 obase = out_base + kbase;
+        const u32 hbase = (u32)(obase & (ENC_HIST_WINDOW - 1));  // (obase + i) / WINDOW - win0 == (hbase + i) / WINDOW
+        auto body = [&](u32 q, u32 ci, u32 cs, u32 j, u32 koff) {
             T x = extract_kmer<WIDE>(s_codes, cs + j, PK.K);
-            u64 dst = out_base + kbase + q;
+            u32 drel = q;  // output slot relative to obase
             bool rc = false;
             if (P.canonical) {
                 const u32 cb = s_cfwd[ci];
                 const u32 nfwd = s_cfwd[ci + 1] - cb;
                 const u32 rf = cum_fwd(q) - cb;
                 rc = !kmer_is_fwd<WIDE>(x);
-                dst = out_base + kbase + s_koff[ci] + (rc ? (nfwd + (j - rf)) : rf);
+                drel = koff + (rc ? (nfwd + (j - rf)) : rf);
             }
             u64 lo, hi;
             kmer_word<WIDE>(x, PK, rc, lo, hi);
-            out_lo[dst] = lo;
-            st_hi<HiT>(out_hi, dst, hi);
-            if (eh.counts) atomicAdd(&s_hist[(u32)(dst / ENC_HIST_WINDOW - win0) * 256 + eh.digit(lo, hi)], 1u);
+            out_lo[obase + drel] = lo;
+            st_hi<HiT>(out_hi, obase + drel, hi);
+            if (eh.counts) {
+                const u32 key = ((hbase + drel) / ENC_HIST_WINDOW) * 256 + eh.digit(lo, hi);
+#if CBLX_ENC_HIST_RUNS
+                // Neighbouring lanes hold consecutive k-mers of a read: their necklaces share the leading bits, and the
+                // first-pass digit is the skewed one — a wave's 64 updates hit a handful of counters, which the LDS
+                // serialises address by address. One update per RUN of equal keys instead: the first lane of a run adds
+                // the run's length (lanes that sit this iteration out break a run).
+                const u64 act = __ballot(true);
+                const u32 lane = tid & 63u;
+                const u32 prev = (u32)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                const bool lead = lane == 0 || !((act >> (lane - 1)) & 1ull) || prev != key;
+                const u64 leaders = __ballot(lead);
+                if (lead) {
+                    const u64 above = lane == 63 ? 0ull : ((leaders | ~act) >> (lane + 1));  // next leader or inactive lane ends the run
+                    const u32 len = above ? (u32)__builtin_ctzll(above) + 1u : 64u - lane;
+                    atomicAdd(&s_hist[key], len);
+                }
+#else
+                atomicAdd(&s_hist[key], 1u);
+#endif
+            }
+        };
+        if (uniform) {
+            u32 ci = tid / nk0, j = tid - ci * nk0;
+            for (u32 q = tid; q < Q; q += ENC_THREADS) {
+                body(q, ci, cs0 + ci * len0, j, ci * nk0);
+                j += ENC_THREADS;
+                while (j >= nk0) { j -= nk0; ++ci; }
+            }
+        } else {
+            u32 ci = tid < Q ? find_chunk(tid) : 0u;
+            for (u32 q = tid; q < Q; q += ENC_THREADS) {
+                while (q >= s_koff[ci + 1]) ++ci;  // q only grows: walk forward from the previous chunk instead of searching again
+                const u32 cs = s_cstart[ci];
+                if (cs >> 31) continue;
+                body(q, ci, cs, q - s_koff[ci], s_koff[ci]);
+            }
         }
     };
     // the K of BASELINE.json's configurations get their own copy of the loop; any other K reads it from P

@@ -550,6 +550,7 @@ def test_more_than_2_pow_32_words_in_one_index():
     e_b, e_o = synth.reads_torch(43, half, L, device="cuda")
     B.insert_seqs_device(e_b, e_o, half)
     del d_b, e_b
+    torch.cuda.empty_cache()
     ca, cb, xa, xb = A.count(), B.count(), A.checksum(), B.checksum()
     assert ca + cb > 1 << 32
     A |= B
