@@ -266,6 +266,9 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify_merge(u64 nb, u32
         ks = m_skind[r];
         if (co == 0) { out_count[r] = cs; out_kind[r] = ks; }
         else if (cs == 0) { out_count[r] = co; out_kind[r] = m_okind[r]; }
+        else if (c <= 16 * MED_ITEMS) cls = CLS_M16;   // workgroup size follows the run length, as in k_classify
+        else if (c <= 64 * MED_ITEMS) cls = CLS_M64;
+        else if (c <= 128 * MED_ITEMS) cls = CLS_M128;
         else if (c <= 256 * MED_ITEMS) cls = CLS_M256;
         else if (c <= 512 * MED_ITEMS) cls = CLS_M512;
         else if (c <= 1024 * MED_ITEMS && med_max_threads >= 1024) cls = CLS_M1024;
@@ -676,7 +679,7 @@ static const u32 PK_BITS = 12;  // CAP <= 4096
 #endif
 static const int MSD_TRIP = CBLX_MSD_TRIP;  // sub-bucket entries read per trip of the ranking loop (<= the 4 slack entries)
 #ifndef CBLX_MSD_REUSE_BASE
-#define CBLX_MSD_REUSE_BASE 1
+#define CBLX_MSD_REUSE_BASE 0  // measured (profiles/r02_variants.md): +0.15 ms — eight more live registers cost more than the LDS read
 #endif
 #ifndef CBLX_MSD_WAVES
 #define CBLX_MSD_WAVES 7  // waves per SIMD the register allocation aims at (LDS allows 7 workgroups of the 256-thread class; 76 -> 72 VGPRs: 7.28 -> 7.10 ms)
@@ -686,7 +689,7 @@ template <int THREADS, int CAP, bool PACKED, bool WS, typename HiT>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MSD_WAVES, 8))) void k_bucket_msd(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
                                                         u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
                                                         u32* __restrict__ out_count, u8* __restrict__ out_kind,
-                                                        BDesc* __restrict__ retry, u32* __restrict__ retry_n) {
+                                                        BDesc* __restrict__ retry, u32* __restrict__ retry_n, MergeArgs mg = MergeArgs{}) {
     static_assert(!(PACKED && WS), "packed elements need a narrow suffix");
     static_assert(CAP <= (1 << PK_BITS), "stream index must fit PK_BITS");
     constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
@@ -713,7 +716,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     u32 nbits = 32 - __builtin_clz(c - 1 > 0 ? c - 1 : 1);  // ceil(log2 c)
     if (nbits > SB) nbits = SB;
     const u32 NB = 1u << nbits;  // <= CAP because c <= CAP
-    const bool vec_only = c <= VEC_THRESHOLD && !res_trie;  // no sorted output needed: sub-buckets by hash
+    // `self |= other` (mg.cs set): the run is [self's suffixes][other's], both parts distinct; every outcome needs the sorted
+    // order, so the sub-buckets are always by the top bits
+    const bool merging = mg.cs != nullptr;
+    const bool vec_only = c <= VEC_THRESHOLD && !res_trie && !merging;  // no sorted output needed: sub-buckets by hash
 
     for (u32 i = tid; i < NB / 2 + 1; i += THREADS) s_off32[i] = 0;
     if (tid == 0) s_max = 0;
@@ -857,6 +863,99 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
             head[j] = !dup;
         }
         wave_heads += (u32)__builtin_popcountll(__ballot(head[j]));
+    }
+    if (merging) {
+        // Every element goes to its rank by (suffix, index) with its index: the slots then hold the run sorted, self's copy
+        // of a suffix in front of other's (index < cs = came from self), and the rules of src/trievec/set_ops.rs:43-71 are
+        // ordered compactions of slot subsets, as in k_bucket_medium's merge epilogue.
+        __syncthreads();  // every read of the sub-bucket order is done
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (valid[j]) {
+                const u32 e = w * EPW + j * 64 + lane;
+                if constexpr (PACKED) {
+                    s_klo[fin[j]] = (key[j].lo << PK_BITS) | e;
+                } else {
+                    s_klo[fin[j]] = key[j].lo;
+                    if constexpr (WS) s_khi[fin[j]] = key[j].hi;
+                    s_idx[fin[j]] = (u16)e;
+                }
+            }
+        }
+        __syncthreads();
+        const u32 cs = mg.cs[r];
+        u32 idx[ITEMS];
+        u32 wh = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 p = w * EPW + j * 64 + lane;
+            const bool live = (u32)j < R && p < c;
+            const u32 pc = live ? p : 0u, pp = (live && p) ? p - 1 : 0u;
+            Sfx<WS> prev;
+            if constexpr (PACKED) {
+                const u64 v = s_klo[pc], u = s_klo[pp];
+                key[j].lo = v >> PK_BITS;
+                idx[j] = (u32)v & ((1u << PK_BITS) - 1u);
+                prev.lo = u >> PK_BITS;
+            } else {
+                key[j].lo = s_klo[pc];
+                prev.lo = s_klo[pp];
+                if constexpr (WS) { key[j].hi = s_khi[pc]; prev.hi = s_khi[pp]; }
+                idx[j] = s_idx[pc];
+            }
+            valid[j] = live;
+            head[j] = live && (p == 0 || prev != key[j]);
+            wh += (u32)__builtin_popcountll(__ballot(head[j]));
+        }
+        if (lane == 0) s_wtot[w] = wh;
+        __syncthreads();
+        u32 d = 0;
+        for (int ww = 0; ww < NW; ++ww) d += s_wtot[ww];
+        // ordered compaction of the slots selected by `sel` to dst[base + rank]
+        auto compact = [&](const bool (&sel)[ITEMS], u64* dlo, u64* dhi, u64 base) {
+            u32 wk = 0;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) wk += (u32)__builtin_popcountll(__ballot(sel[j]));
+            __syncthreads();
+            if (lane == 0) s_wtot[w] = wk;
+            __syncthreads();
+            u32 run = 0;
+            for (u32 ww = 0; ww < w; ++ww) run += s_wtot[ww];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const u64 bal = __ballot(sel[j]);
+                if (sel[j]) {
+                    dlo[base + run + mbcnt(bal)] = key[j].lo;
+                    if constexpr (WS) dhi[base + run + mbcnt(bal)] = key[j].hi;
+                }
+                run += (u32)__builtin_popcountll(bal);
+            }
+        };
+        bool sel[ITEMS];
+        if (mg.okind[r] == KIND_VEC) {  // the reference's iter_sorted leaves other's Vec sorted
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) sel[j] = valid[j] && idx[j] >= cs;
+            compact(sel, mg.o_lo, mg.o_hi, mg.ostart[r]);
+        }
+        u64* slo = lo;
+        u64* shi = reinterpret_cast<u64*>(hi);
+        if (res_trie) {  // Trie |= anything: sorted union
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) sel[j] = head[j];
+            compact(sel, slo, shi, s0);
+        } else {         // Vec |= anything: sorted(self) ++ sorted(other \ self); every self element is a head
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) sel[j] = head[j] && idx[j] < cs;
+            compact(sel, slo, shi, s0);
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) sel[j] = head[j] && idx[j] >= cs;
+            compact(sel, slo, shi, s0 + cs);
+        }
+        if (tid == 0) {
+            out_count[r] = d;
+            out_kind[r] = res_trie ? KIND_TRIE : KIND_VEC;
+        }
+        return;
     }
     if (lane == 0) s_wtot[w] = wave_heads;
     __syncthreads();  // also: every read of the sub-bucket order is done

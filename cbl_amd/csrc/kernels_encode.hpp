@@ -32,7 +32,7 @@ template <typename HiT> __device__ __forceinline__ void st_hi(HiT* p, u64 i, u64
 #define CBLX_ENC_UNIFORM 1
 #endif
 #ifndef CBLX_ENC_HIST_RUNS
-#define CBLX_ENC_HIST_RUNS 1
+#define CBLX_ENC_HIST_RUNS 0  // measured (profiles/r02_variants.md): +0.3 ms — the kernel is VALU-bound, the dozen instructions cost more than the serialised atomics
 #endif
 static const u32 ENC_TILE_BYTES = 4096;
 static const u32 ENC_THREADS = 256;

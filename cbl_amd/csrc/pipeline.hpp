@@ -819,16 +819,42 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
     HiT* a_hi = WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr;
     {
         StageTimer t(c, ST_BMED);
-        if (ln[CLS_M256])
-            hipLaunchKernelGGL((k_bucket_medium<256, WS, HiT>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb, list_n.get() + CLS_M256,
-                               a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
-        if (ln[CLS_M512])
-            hipLaunchKernelGGL((k_bucket_medium<512, WS, HiT>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb, list_n.get() + CLS_M512,
-                               a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
+        // both-sided buckets: counting sort on the top suffix bits + ranking inside the sub-buckets (k_bucket_msd in its
+        // merge mode); a bucket with a crowded sub-bucket comes back through `retry` and takes the LDS radix sort
+        Buf<BDesc> retry(c->pool, std::max<u64>(nb, 1));
+        Buf<u32> retry_n(c->pool, 1);
+        CBLX_HIP(hipMemsetAsync(retry_n.get(), 0, 4, c->stream));
+        auto msd = [&](auto packed_tag) {
+            constexpr bool PK = decltype(packed_tag)::value;
+            if (ln[CLS_M16])
+                hipLaunchKernelGGL((k_bucket_msd<64, 128, PK, WS, HiT>), dim3(ln[CLS_M16]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M16 * nb, list_n.get() + CLS_M16,
+                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
+            if (ln[CLS_M64])
+                hipLaunchKernelGGL((k_bucket_msd<64, 512, PK, WS, HiT>), dim3(ln[CLS_M64]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M64 * nb, list_n.get() + CLS_M64,
+                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
+            if (ln[CLS_M128])
+                hipLaunchKernelGGL((k_bucket_msd<128, 1024, PK, WS, HiT>), dim3(ln[CLS_M128]), dim3(128), 0, c->stream, lists.get() + (size_t)CLS_M128 * nb, list_n.get() + CLS_M128,
+                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
+            if (ln[CLS_M256])
+                hipLaunchKernelGGL((k_bucket_msd<256, 2048, PK, WS, HiT>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb, list_n.get() + CLS_M256,
+                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
+            if (ln[CLS_M512])
+                hipLaunchKernelGGL((k_bucket_msd<512, 4096, PK, WS, HiT>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb, list_n.get() + CLS_M512,
+                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
+        };
+        if constexpr (!WS) {
+            if (P.SB + PK_BITS <= 64) msd(std::true_type()); else msd(std::false_type());
+        } else {
+            msd(std::false_type());
+        }
+        const u32 nretry = (ln[CLS_M16] || ln[CLS_M64] || ln[CLS_M128] || ln[CLS_M256] || ln[CLS_M512]) ? d2h<u32>(c, retry_n.get()) : 0u;
+        if (nretry)
+            hipLaunchKernelGGL((k_bucket_medium<512, WS, HiT>), dim3(nretry), dim3(512), 0, c->stream, retry.get(), retry_n.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
         if constexpr (!WS) if (ln[CLS_M1024])
             hipLaunchKernelGGL((k_bucket_medium<1024, WS, HiT>), dim3(ln[CLS_M1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)CLS_M1024 * nb,
                                list_n.get() + CLS_M1024, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
         CBLX_HIP(hipGetLastError());
+        CBLX_HIP(hipStreamSynchronize(c->stream));  // retry buffers die here
     }
     if (ln[CLS_HUGE]) {
         StageTimer t(c, ST_BHUGE);
