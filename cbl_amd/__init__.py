@@ -46,6 +46,19 @@ class BucketView(C.Structure):
                 ("d_suffix", C.c_void_p)]
 
 
+class ExchangeStats(C.Structure):
+    _fields_ = [("sent_bytes", C.c_uint64), ("recv_bytes", C.c_uint64), ("messages", C.c_uint64)]
+
+
+_ALL_REDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64)
+_ALL_TO_ALL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64)
+_EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64))
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_reduce_sum_u64", _ALL_REDUCE_CB), ("all_to_all_u64", _ALL_TO_ALL_CB), ("exchange", _EXCHANGE_CB)]
+
+
 class BatchView(C.Structure):
     _fields_ = [("n_buckets", C.c_uint64), ("n_words", C.c_uint64), ("d_prefix", C.c_void_p), ("d_count", C.c_void_p), ("d_suffix", C.c_void_p)]
 
@@ -85,6 +98,14 @@ SIGNATURES = {
     "cblx_install_buckets_device": (C.c_int, [C.c_void_p, C.POINTER(BucketView), C.c_uint32]),
     "cblx_serialized_body_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cblx_write_body_at": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64]),
+    "cblx_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "cblx_comm_init_rccl": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32]),
+    "cblx_comm_init_transport": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Transport), C.c_uint32, C.c_uint32, C.c_int32]),
+    "cblx_comm_destroy": (None, [C.c_void_p]),
+    "cblx_comm_last_error": (C.c_char_p, [C.c_void_p]),
+    "cblx_comm_stats": (C.c_int, [C.c_void_p, C.POINTER(ExchangeStats), C.c_int]),
+    "cblx_sharded_insert_seqs_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                  C.POINTER(C.c_int)]),
     "cblx_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_num_buckets": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_is_empty": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
@@ -163,6 +184,119 @@ def index_shard_cuts(path, k: int, prefix_bits: int, world: int, bounds=None, se
     if rc != OK:
         raise CblxError(rc, L.cblx_last_global_error().decode())
     return offs, first, bool(ok.value)
+
+
+class Comm:
+    """One rank's communicator of the multi-GPU build behind the C ABI (include/cblx.h: cblx_comm).
+
+    `Comm.rccl(id, rank, world, device)`: RCCL over xGMI, `id` = Comm.unique_id() of rank 0 shipped to every rank by the host
+    program. `Comm.over_group(dist, rank, world, device)`: host callbacks that move the bytes through a torch.distributed-like
+    group, staged through the host (how several ranks share one GPU in the tests; not a production transport)."""
+
+    def __init__(self, handle, keep=None):
+        self._L, self._h, self._keep = lib(), handle, keep
+
+    @staticmethod
+    def unique_id() -> bytes:
+        L = lib()
+        buf = (C.c_uint8 * 128)()
+        rc = L.cblx_comm_unique_id(buf)
+        if rc != OK:
+            raise CblxError(rc, L.cblx_last_global_error().decode())
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, uid: bytes, rank: int, world: int, device: int = -1) -> "Comm":
+        L = lib()
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        rc = L.cblx_comm_init_rccl(C.byref(h), buf, rank, world, device)
+        if rc != OK:
+            raise CblxError(rc, L.cblx_last_global_error().decode())
+        return cls(h)
+
+    @classmethod
+    def over_group(cls, dist, rank: int, world: int, device: int = -1) -> "Comm":
+        import numpy as np
+        import torch
+
+        dev = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
+
+        def view(ptr, n):
+            from .sharded import _DeviceArray
+
+            return torch.as_tensor(_DeviceArray(ptr, n, "|u1"), device=dev)
+
+        def all_reduce(_u, vals, n):
+            try:
+                a = np.ctypeslib.as_array(vals, (n,))
+                t = torch.from_numpy(a.astype(np.int64))
+                dist.all_reduce(t)
+                a[:] = t.numpy().astype(np.uint64)
+                return 0
+            except Exception:  # noqa: BLE001 - must not unwind into C
+                return 1
+
+        def all_to_all(_u, send, recv, per):
+            try:
+                s = torch.from_numpy(np.ctypeslib.as_array(send, (per * world,)).astype(np.int64))
+                r = torch.empty_like(s)
+                dist.all_to_all_single(r, s)
+                np.ctypeslib.as_array(recv, (per * world,))[:] = r.numpy().astype(np.uint64)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 1
+
+        def exchange(_u, d_src, so, d_dst, ro):
+            try:
+                so = [int(so[i]) for i in range(world + 1)]
+                ro = [int(ro[i]) for i in range(world + 1)]
+                src = view(d_src, max(so[world], 1)) if so[world] else None
+                dst = view(d_dst, max(ro[world], 1)) if ro[world] else None
+                if so[rank + 1] > so[rank]:
+                    dst[ro[rank]: ro[rank + 1]].copy_(src[so[rank]: so[rank + 1]])
+                works, landing = [], []
+                for k in range(1, world):
+                    to, frm = (rank + k) % world, (rank - k) % world
+                    if so[to + 1] > so[to]:
+                        works.append(dist.isend(src[so[to]: so[to + 1]].cpu().contiguous(), to))
+                    if ro[frm + 1] > ro[frm]:
+                        h = torch.empty(ro[frm + 1] - ro[frm], dtype=torch.uint8)
+                        works.append(dist.irecv(h, frm))
+                        landing.append((frm, h))
+                for w in works:
+                    w.wait()
+                for frm, h in landing:
+                    dst[ro[frm]: ro[frm + 1]].copy_(h)
+                torch.cuda.synchronize(dev)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 1
+
+        cbs = (_ALL_REDUCE_CB(all_reduce), _ALL_TO_ALL_CB(all_to_all), _EXCHANGE_CB(exchange))
+        t = Transport(None, *cbs)
+        L = lib()
+        h = C.c_void_p()
+        rc = L.cblx_comm_init_transport(C.byref(h), C.byref(t), rank, world, device)
+        if rc != OK:
+            raise CblxError(rc, L.cblx_last_global_error().decode())
+        return cls(h, keep=cbs)
+
+    def stats(self, reset: bool = False) -> dict:
+        st = ExchangeStats()
+        self._L.cblx_comm_stats(self._h, C.byref(st), int(reset))
+        return {"sent_bytes": st.sent_bytes, "recv_bytes": st.recv_bytes, "messages": st.messages}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cblx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class CBL:
@@ -334,6 +468,19 @@ class CBL:
 
     def write_body_at(self, path, file_off: int):
         self._chk(self._L.cblx_write_body_at(self._h, os.fsencode(path), file_off))
+
+    def sharded_insert_seqs_device(self, comm: "Comm", d_bases, d_offsets, n: int, slice_cuts, bounds, bounds_valid: bool):
+        """The multi-GPU build step behind the ABI (cblx_sharded_insert_seqs_device): every rank calls it with its shard.
+        `bounds`: numpy uint32 array of world - 1 entries, updated in place when bounds_valid is False. Returns True
+        (the bounds are valid from now on)."""
+        import numpy as np
+
+        cuts = np.ascontiguousarray(slice_cuts, dtype=np.uint64)
+        assert bounds.dtype == np.uint32 and bounds.flags["C_CONTIGUOUS"]
+        bv = C.c_int(int(bounds_valid))
+        self._chk(self._L.cblx_sharded_insert_seqs_device(self._h, comm._h, _ptr(d_bases), _ptr(d_offsets), n, cuts.ctypes.data, len(cuts) - 1,
+                                                          bounds.ctypes.data if len(bounds) else None, C.byref(bv)))
+        return bool(bv.value)
 
     def flush(self):
         self._chk(self._L.cblx_flush(self._h))

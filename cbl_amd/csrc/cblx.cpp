@@ -5,7 +5,7 @@
 // (/root/reference/src/wordset/mod.rs:18-26: prefix bitvector + rank->bucket directory + suffix containers) held in
 // HBM: bitvector words, popcount-scan rank directory, bucket table indexed by rank, one suffix arena.
 // There is no CPU fallback: every data-path step below is a kernel launch.
-#include "shard.hpp"
+#include "comm.hpp"
 
 namespace {
 
@@ -430,6 +430,63 @@ int cblx_insert_sorted_batches_device(cblx_ctx* c, const cblx_batch_view* batche
     });
 }
 
+int cblx_comm_unique_id(uint8_t* id) {
+    return guard(nullptr, [&] {
+        if (!id) throw Error(CBLX_EINVAL, "null argument");
+        Id128 uid;
+        CBLX_RCCL(rccl().GetUniqueId(&uid));
+        std::memcpy(id, uid.internal, sizeof uid.internal);
+    });
+}
+int cblx_comm_init_rccl(cblx_comm** out, const uint8_t* id, uint32_t rank, uint32_t world, int32_t device) {
+    return guard(nullptr, [&] {
+        if (!out || !id) throw Error(CBLX_EINVAL, "null argument");
+        *out = nullptr;
+        if (world == 0 || rank >= world || world > MAX_DEST) throw Error(CBLX_EINVAL, "rank must be below world, world at most " + std::to_string(MAX_DEST));
+        int dev = device;
+        if (dev < 0) CBLX_HIP(hipGetDevice(&dev));
+        std::unique_ptr<cblx_comm> cm(new cblx_comm());
+        cm->device = dev;
+        cm->t.reset(new RcclTransport(id, rank, world, dev));
+        *out = cm.release();
+    });
+}
+int cblx_comm_init_transport(cblx_comm** out, const cblx_transport* t, uint32_t rank, uint32_t world, int32_t device) {
+    return guard(nullptr, [&] {
+        if (!out || !t || !t->all_reduce_sum_u64 || !t->all_to_all_u64 || !t->exchange) throw Error(CBLX_EINVAL, "null argument");
+        *out = nullptr;
+        if (world == 0 || rank >= world || world > MAX_DEST) throw Error(CBLX_EINVAL, "rank must be below world, world at most " + std::to_string(MAX_DEST));
+        int dev = device;
+        if (dev < 0) CBLX_HIP(hipGetDevice(&dev));
+        std::unique_ptr<cblx_comm> cm(new cblx_comm());
+        cm->device = dev;
+        cm->t.reset(new CallbackTransport(*t, rank, world));
+        *out = cm.release();
+    });
+}
+void cblx_comm_destroy(cblx_comm* cm) { delete cm; }
+const char* cblx_comm_last_error(const cblx_comm* cm) { return cm ? cm->err.c_str() : g_global_err.c_str(); }
+int cblx_comm_stats(cblx_comm* cm, cblx_exchange_stats* out, int reset) {
+    if (!cm || !out) return CBLX_EINVAL;
+    out->sent_bytes = cm->t->sent_bytes; out->recv_bytes = cm->t->recv_bytes; out->messages = cm->t->messages;
+    if (reset) cm->t->sent_bytes = cm->t->recv_bytes = cm->t->messages = 0;
+    return CBLX_OK;
+}
+int cblx_sharded_insert_seqs_device(cblx_ctx* c, cblx_comm* cm, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n, const uint64_t* slice_cuts,
+                                    uint32_t n_slices, uint32_t* bounds, int* bounds_valid) {
+    return guard(c, [&] {
+        if (!cm || !slice_cuts || !bounds_valid || (cm->t->world > 1 && !bounds) || (n && (!d_bases || !d_offsets))) throw Error(CBLX_EINVAL, "null argument");
+        if (n_slices == 0) throw Error(CBLX_EINVAL, "at least one slice (an empty one still takes part in the exchange)");
+        if (c->device != cm->device) throw Error(CBLX_EINVAL, "ctx and communicator live on different devices");
+        if (n) check_aligned16(d_bases, "d_bases");
+        flush(c);  // keep stream order with anything enqueued earlier
+        u32 dummy = 0;
+        try {
+            dispatch(c->P, [&](auto cfg) { sharded_insert<decltype(cfg)>(c, *cm->t, d_bases, d_offsets, n, slice_cuts, n_slices, bounds ? bounds : &dummy, bounds_valid); });
+        } catch (const Error& e) { cm->err = e.what(); throw; }
+        collect_events(c);
+    });
+}
 int cblx_count(cblx_ctx* c, uint64_t* out) { return guard(c, [&] { flush(c); *out = c->res.count; }); }
 int cblx_num_buckets(cblx_ctx* c, uint64_t* out) { return guard(c, [&] { flush(c); *out = c->res.nb; }); }
 int cblx_is_empty(cblx_ctx* c, int* out) { return guard(c, [&] { flush(c); *out = c->res.nb == 0; }); }

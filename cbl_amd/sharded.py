@@ -245,12 +245,15 @@ class ShardedBuilder(_Wire):
     i.e. file order when the file is dealt to the ranks block-cyclically; with slices=1 it is plain rank order.
     """
 
-    def __init__(self, cbl, dist, engine=None, slices: int = 4, slack: float = 1.3, protocol: str = "sorted"):
+    def __init__(self, cbl, dist, engine=None, slices: int = 4, slack: float = 1.3, protocol: str = "sorted", comm=None):
+        """comm: a cbl_amd.Comm — the whole insert then runs inside libcblx (cblx_sharded_insert_seqs_device: "sorted"
+        protocol, exchange on RCCL directly); `dist` is still used for the few host-side agreements (slice counts)."""
         self.cbl = cbl
         self.engine = engine or GpuEngine(cbl)
         if protocol not in ("sorted", "words"):
             raise ValueError("protocol must be 'sorted' or 'words'")
         self.protocol = protocol if hasattr(self.engine, "sorted_batch_begin") else "words"
+        self.comm = comm
         self._wire_init(dist)
         self.slices, self.slack = max(1, slices), slack
         self.bounds = None  # fixed by the first batch so later batches land on the same owners
@@ -282,6 +285,8 @@ class ShardedBuilder(_Wire):
             need = -(-nbases // SLICE_MAX_BASES)
             slice_list = self.slice_bounds(n, max(self.slices, self._all_reduce_ints([need], "max")[0]))
         self._slice_list = list(slice_list)
+        if self.comm is not None:
+            return self._insert_native(d_bases, d_offsets, n)
         if self.protocol == "sorted":
             return self._insert_sorted(d_bases, d_offsets, n)
         return self._insert_words(d_bases, d_offsets, n)
@@ -305,6 +310,22 @@ class ShardedBuilder(_Wire):
         finally:
             eng.stage_release()
         return n_file
+
+    def _insert_native(self, d_bases, d_offsets, n):
+        sl = self._slice_list
+        cuts = [sl[0][0]] + [b for _a, b in sl]
+        assert all(sl[i][1] == sl[i + 1][0] for i in range(len(sl) - 1)), "slices must be contiguous"
+        have = self.bounds is not None
+        bounds = np.ascontiguousarray(self.bounds, dtype=np.uint32).copy() if have else np.zeros(max(self.world - 1, 0), dtype=np.uint32)
+        before = self.comm.stats()
+        t0 = time.perf_counter()
+        self.cbl.sharded_insert_seqs_device(self.comm, d_bases, d_offsets, n, cuts, bounds, have)
+        dt = time.perf_counter() - t0
+        after = self.comm.stats()
+        self.bounds = bounds
+        for k in ("sent_bytes", "recv_bytes", "messages"):
+            self.stats[k] += after[k] - before[k]
+        self.stats["outstanding_s"] += dt  # the exchange overlaps the kernels inside the call: the whole call is the window
 
     def _choose_bounds_from(self, d_bases, off, n):
         """First batch only: quantile ranges from a sampled, all-reduced prefix histogram of the first slice."""

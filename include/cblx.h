@@ -187,6 +187,42 @@ int cblx_install_buckets_device(cblx_ctx* ctx, const cblx_bucket_view* parts, ui
 int cblx_serialized_body_size(cblx_ctx* ctx, uint64_t* n_entries, uint64_t* nbytes);
 int cblx_write_body_at(cblx_ctx* ctx, const char* path, uint64_t file_off);
 
+/* ---- the multi-GPU build behind this ABI (no reference counterpart; BASELINE.json north_star: prefix space partitioned over the
+ * GPUs of a node, one exchange over xGMI after the radix step) -------------------------------------------------------------
+ * One process (or thread) per GPU, each with its own cblx_ctx and one cblx_comm. The communicator is RCCL (librccl.so.1 is
+ * looked up at run time; rank 0 makes the id with cblx_comm_unique_id and the host program hands it to the other ranks by
+ * whatever means it has), or a set of host callbacks that move the bytes (tests; fabrics RCCL does not drive). */
+typedef struct cblx_comm cblx_comm;
+#define CBLX_COMM_ID_BYTES 128
+typedef struct cblx_transport {
+    void* user;
+    /* in place: vals[i] = sum over ranks of vals[i] (host memory), on every rank */
+    int (*all_reduce_sum_u64)(void* user, uint64_t* vals, uint64_t n);
+    /* send[d * per_rank ..] goes to rank d, recv[s * per_rank ..] comes from rank s (host memory) */
+    int (*all_to_all_u64)(void* user, const uint64_t* send, uint64_t* recv, uint64_t per_rank);
+    /* personalised exchange of byte runs in DEVICE memory: bytes [send_off[d], send_off[d+1]) of d_src go to rank d, the bytes
+     * from rank s land at [recv_off[s], recv_off[s+1]) of d_dst (world + 1 host offsets each; the rank's own run included).
+     * Complete on return. */
+    int (*exchange)(void* user, const uint8_t* d_src, const uint64_t* send_off, uint8_t* d_dst, const uint64_t* recv_off);
+} cblx_transport;
+int cblx_comm_unique_id(uint8_t id[CBLX_COMM_ID_BYTES]);
+int cblx_comm_init_rccl(cblx_comm** out, const uint8_t* id, uint32_t rank, uint32_t world, int32_t device);
+int cblx_comm_init_transport(cblx_comm** out, const cblx_transport* t, uint32_t rank, uint32_t world, int32_t device);
+void cblx_comm_destroy(cblx_comm* comm);
+const char* cblx_comm_last_error(const cblx_comm* comm);
+typedef struct cblx_exchange_stats { uint64_t sent_bytes, recv_bytes, messages; } cblx_exchange_stats; /* own runs excluded */
+int cblx_comm_stats(cblx_comm* comm, cblx_exchange_stats* out, int reset);
+/* CBL::insert_seq for every sequence of THIS rank's shard, into an index sharded by prefix range over the ranks of `comm`
+ * (every rank makes the same call with its own shard). The shard is consumed in n_slices slices, reads
+ * [slice_cuts[s], slice_cuts[s+1]) (n_slices + 1 ascending values, the same NUMBER of slices on every rank): the exchange of
+ * a slice overlaps the kernels of the next one, and the job's stream order is slice-major, rank-minor — the order of the file
+ * when its blocks were dealt to the ranks cyclically (cblx_stage_fastx_blocks). bounds[world - 1]: the shard bounds (rank r
+ * owns bounds[r-1] <= prefix < bounds[r]); *bounds_valid = 0 on the first call lets the ranks choose them together (quantiles
+ * of a sampled prefix histogram: necklace prefixes are heavily skewed) and sets it to 1. Afterwards the ctx of rank r holds
+ * range r of the index: count / serialize / cblx_write_body_at work per range. */
+int cblx_sharded_insert_seqs_device(cblx_ctx* ctx, cblx_comm* comm, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n,
+                                    const uint64_t* slice_cuts, uint32_t n_slices, uint32_t* bounds, int* bounds_valid);
+
 /* CBL::count / is_empty / is_canonical (src/cbl.rs:164-177). */
 int cblx_count(cblx_ctx* ctx, uint64_t* out);
 int cblx_num_buckets(cblx_ctx* ctx, uint64_t* out); /* tiered.len() = number of non-empty prefixes */

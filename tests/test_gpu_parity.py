@@ -1570,3 +1570,107 @@ def test_sharded_build_of_one_file_has_file_order_on_one_gpu(world, k, pb, canon
     for r in recs:
         one.insert_seq(r)
     assert blob == one.serialize()
+
+
+# ---- the multi-GPU build behind the C ABI: cblx_comm + cblx_sharded_insert_seqs_device ----------------------------------------
+def test_native_sharded_insert_single_rank_rccl():
+    """One rank, the REAL RCCL communicator (librccl looked up at run time, unique id, comm init, grouped send/recv to self):
+    cblx_sharded_insert_seqs_device == the direct insert, slices and repeated batches included."""
+    _need_gpu()
+    uid = cbl_amd.Comm.unique_id()
+    assert len(uid) == 128
+    comm = cbl_amd.Comm.rccl(uid, 0, 1, 0)
+    for k, pb, canonical in ((31, 24, False), (59, 28, True), (25, 12, False)):
+        d_b, d_o = synth.reads_torch(42, 3000, 150, device="cuda")
+        a, b = cbl_amd.CBL(k, pb, canonical=canonical), cbl_amd.CBL(k, pb, canonical=canonical)
+        a.insert_seqs_device(d_b, d_o, 3000)
+        bounds = np.zeros(0, dtype=np.uint32)
+        assert b.sharded_insert_seqs_device(comm, d_b, d_o, 3000, [0, 700, 700, 2999, 3000], bounds, False)
+        assert b.serialize() == a.serialize()
+        b.sharded_insert_seqs_device(comm, d_b, d_o, 3000, [0, 3000], bounds, True)  # again: nothing new
+        assert b.serialize() == a.serialize()
+        hb, ho = synth.reads(42, 3000, 150)
+        o = Oracle(k, pb, canonical)
+        o.insert_seqs(hb, ho)
+        assert b.serialize() == o.serialize()
+    st = comm.stats()
+    assert st["sent_bytes"] == 0 and st["recv_bytes"] == 0  # one rank: its own runs only
+    comm.close()
+
+
+def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q):
+    import torch.distributed as dist
+
+    from cbl_amd import sharded
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = cbl_amd.Comm.over_group(dist, rank, world, 0)  # host callbacks: the ranks share this GPU
+        g = cbl_amd.CBL(k, pb, canonical=canonical, device=0)
+        sb = sharded.ShardedBuilder(g, dist, slices=3, comm=comm)
+        for batch, n in enumerate(per[rank]):  # two batches; the second reuses the first one's splitters
+            first = sum(per[r][bb] for r in range(world) for bb in range(batch)) + sum(per[r][batch] for r in range(rank))
+            d_b, d_o = synth.reads_torch(23, n, L, first_read=first, device="cuda:0")
+            sb.insert_seqs_device(d_b, d_o, n)
+        blob = sharded.gather_serialized(g.serialize(), dist)
+        fblob = None
+        if path:
+            h = cbl_amd.CBL(k, pb, canonical=canonical, device=0)
+            sf = sharded.ShardedBuilder(h, dist, slices=3, comm=comm)
+            sf.insert_fastx_file(path, 5)
+            fblob = sharded.gather_serialized(h.serialize(), dist)
+        if rank == 0:
+            q.put((blob, [int(x) for x in sb.bounds], g.count(), fblob, sb.stats["sent_bytes"]))
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k,pb,canonical", [(2, 31, 24, False), (3, 59, 28, True), (4, 25, 12, False), (8, 31, 24, False)])
+def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canonical, tmp_path):
+    """The C++ orchestration of the multi-GPU build (slices, splitter choice, count exchange, grouped exchange, batch merge)
+    with `world` ranks sharing this GPU and the bytes moved by host callbacks over gloo: byte-identical to the one-process
+    oracle in the job's stream order (slice-major, rank-minor), and to the file's order for a file dealt block-cyclically."""
+    _need_gpu()
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from cbl_amd.sharded import ShardedBuilder
+
+    L = 150 if k < 59 else 250
+    per = [(700, 2), (300, 450), (1, 600), (512, 0), (64, 64), (0, 900), (333, 5), (90, 90)][:world]
+    path = str(tmp_path / "reads.fa")
+    recs = _ragged_fasta(path, 77, 43)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, k, pb, canonical, per, L, path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    blob, bounds, count0, fblob, sent = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    one = Oracle(k, pb, canonical)
+    for batch in range(2):
+        first = sum(per[r][bb] for r in range(world) for bb in range(batch))
+        starts = [first + sum(per[rr][batch] for rr in range(r)) for r in range(world)]
+        sl = [ShardedBuilder.slice_bounds(per[r][batch], 3) for r in range(world)]
+        for c in range(3):
+            for r in range(world):
+                a, b = sl[r][c]
+                if b > a:
+                    hb, ho = synth.reads(23, b - a, L, first_read=starts[r] + a)
+                    one.insert_seqs(hb, ho)
+    assert blob == one.serialize()
+    assert len(bounds) == world - 1 and 0 < count0 < one.count() and sent > 0
+    of = Oracle(k, pb, canonical)
+    for r in recs:
+        of.insert_seq(r)
+    assert fblob == of.serialize()
