@@ -124,6 +124,8 @@ def parse_args(argv=None):
     ap.add_argument("--canonical", action="store_true")
     ap.add_argument("--protocol", choices=["sorted", "words"], default="sorted")
     ap.add_argument("--slices", type=int, default=4)
+    ap.add_argument("--transport", choices=["torch", "native"], default="torch",
+                    help="N > 1: exchange driven from Python over torch.distributed, or the whole sharded insert inside libcblx on RCCL directly")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--cpu-full", action="store_true", help="time the CPU oracle on the whole workload (cfg 2: about 4 minutes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -256,7 +258,17 @@ def main():
         d_bases, d_offsets = synth.reads_torch(42, NR, L, first_read=rank * NR, device=dev)
         torch.cuda.synchronize()
         cbl = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank, profile=True)
-        engine = sharded.ShardedBuilder(cbl, dist, slices=args.slices, protocol=args.protocol) if dist is not None else None
+        comm = None
+        if dist is not None and args.transport == "native":
+            if args.shared_gpu:
+                comm = cbl_amd.Comm.over_group(tdist, rank, world, local_rank)
+                transport = "libcblx sharded insert, host callbacks over gloo (all ranks share GPU 0: dry run)"
+            else:
+                box = [cbl_amd.Comm.unique_id() if rank == 0 else None]
+                tdist.broadcast_object_list(box, src=0)
+                comm = cbl_amd.Comm.rccl(box[0], rank, world, local_rank)
+                transport = "libcblx sharded insert on RCCL (ncclSend / ncclRecv groups on a side stream)"
+        engine = sharded.ShardedBuilder(cbl, dist, slices=args.slices, protocol=args.protocol, comm=comm) if dist is not None else None
 
         def step(_i):
             cbl.clear()

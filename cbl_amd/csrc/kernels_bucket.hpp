@@ -323,19 +323,46 @@ __device__ __forceinline__ u64 rank_of(const u64* __restrict__ bv, const u64* __
     const u64 w = bv[p >> 6];
     return rank_dir[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
 }
-// sorted records -> packed suffixes (one thread per word)
+// sorted records -> packed suffixes. A workgroup packs a tile of PACK_TILE words into LDS (BYTES bytes each, 16-bit pieces
+// when BYTES is even) and writes the tile out as aligned dwords: one thread per word storing its bytes straight to global
+// memory ran at byte-store speed (BYTES partial stores per word).
+static const u32 PACK_THREADS = 256, PACK_ITEMS = 8, PACK_TILE = PACK_THREADS * PACK_ITEMS;
 template <bool WS, typename HiT>
-__global__ void k_batch_pack(u64 n, const u64* __restrict__ lo, const HiT* __restrict__ hi, u32 SB, u32 BYTES, u8* __restrict__ out) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const Sfx<WS> s = load_sfx<WS, HiT>(lo, hi, i, SB);
-    u8* o = out + i * BYTES;
-    for (u32 k = 0; k < BYTES; ++k) {
-        u32 b;
-        if constexpr (WS) b = k < 8 ? (u32)(s.lo >> (8 * k)) : (u32)(s.hi >> (8 * (k - 8)));
-        else b = (u32)(s.lo >> (8 * k));
-        o[k] = (u8)b;
+__global__ __launch_bounds__(PACK_THREADS) void k_batch_pack(u64 n, const u64* __restrict__ lo, const HiT* __restrict__ hi, u32 SB, u32 BYTES, u8* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) u8 s_b[PACK_TILE * 16];
+    const u64 t0 = (u64)blockIdx.x * PACK_TILE;
+    const u32 nt = (u32)((n - t0) < (u64)PACK_TILE ? (n - t0) : (u64)PACK_TILE);
+#pragma unroll
+    for (u32 j = 0; j < PACK_ITEMS; ++j) {
+        const u32 i = j * PACK_THREADS + threadIdx.x;
+        if (i < nt) {
+            const Sfx<WS> s = load_sfx<WS, HiT>(lo, hi, t0 + i, SB);
+            if ((BYTES & 1u) == 0) {
+                u16* o = reinterpret_cast<u16*>(s_b + i * BYTES);
+                for (u32 k = 0; k < BYTES / 2; ++k) {
+                    u32 v;
+                    if constexpr (WS) v = k < 4 ? (u32)(s.lo >> (16 * k)) : (u32)(s.hi >> (16 * (k - 4)));
+                    else v = (u32)(s.lo >> (16 * k));
+                    o[k] = (u16)v;
+                }
+            } else {
+                u8* o = s_b + i * BYTES;
+                for (u32 k = 0; k < BYTES; ++k) {
+                    u32 v;
+                    if constexpr (WS) v = k < 8 ? (u32)(s.lo >> (8 * k)) : (u32)(s.hi >> (8 * (k - 8)));
+                    else v = (u32)(s.lo >> (8 * k));
+                    o[k] = (u8)v;
+                }
+            }
+        }
     }
+    __syncthreads();
+    const u32 nbytes = nt * BYTES;            // the tile starts at byte t0 * BYTES: a multiple of 4 (PACK_TILE is)
+    u8* g = out + t0 * BYTES;
+    const u32* sw = reinterpret_cast<const u32*>(s_b);
+    u32* gw = reinterpret_cast<u32*>(g);
+    for (u32 w = threadIdx.x; w < nbytes / 4; w += PACK_THREADS) gw[w] = sw[w];
+    for (u32 b = (nbytes & ~3u) + threadIdx.x; b < nbytes; b += PACK_THREADS) g[b] = s_b[b];
 }
 __global__ void k_batch_counts(u64 nb, const u64* __restrict__ start, u32* __restrict__ cnt) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
