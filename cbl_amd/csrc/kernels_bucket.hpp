@@ -357,12 +357,12 @@ __global__ __launch_bounds__(PACK_THREADS) void k_batch_pack(u64 n, const u64* _
         }
     }
     __syncthreads();
-    const u32 nbytes = nt * BYTES;            // the tile starts at byte t0 * BYTES: a multiple of 4 (PACK_TILE is)
+    const u32 nbytes = nt * BYTES;            // the tile starts at byte t0 * BYTES: a multiple of 16 (PACK_TILE is)
     u8* g = out + t0 * BYTES;
-    const u32* sw = reinterpret_cast<const u32*>(s_b);
-    u32* gw = reinterpret_cast<u32*>(g);
-    for (u32 w = threadIdx.x; w < nbytes / 4; w += PACK_THREADS) gw[w] = sw[w];
-    for (u32 b = (nbytes & ~3u) + threadIdx.x; b < nbytes; b += PACK_THREADS) g[b] = s_b[b];
+    const uint4* sw = reinterpret_cast<const uint4*>(s_b);
+    uint4* gw = reinterpret_cast<uint4*>(g);
+    for (u32 w = threadIdx.x; w < nbytes / 16; w += PACK_THREADS) gw[w] = sw[w];
+    for (u32 b = (nbytes & ~15u) + threadIdx.x; b < nbytes; b += PACK_THREADS) g[b] = s_b[b];
 }
 __global__ void k_batch_counts(u64 nb, const u64* __restrict__ start, u32* __restrict__ cnt) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -404,6 +404,13 @@ __global__ void k_batch_offsets(u64 nbk, const u32* __restrict__ prefix, const u
     off_in_run[i] = o;
     run_len[r] = o + cnt[i];
 }
+// where in the arena each bucket of a batch goes (start of its merged run + its offset inside the run): computed once per
+// bucket here so that the gather below starts from three independent loads instead of a chain of five
+__global__ void k_batch_dst(u64 nbk, const u32* __restrict__ prefix, const u32* __restrict__ off_in_run, const u64* __restrict__ bv,
+                            const u64* __restrict__ rank_dir, const u64* __restrict__ start, u64* __restrict__ dst) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nbk) dst[i] = start[rank_of(bv, rank_dir, prefix[i])] + off_in_run[i];
+}
 // resident suffixes (stored order) to the front of their merged runs; one wave per merged bucket
 template <bool WS>
 __global__ __launch_bounds__(256) void k_gather_resident(u64 nb, const u64* __restrict__ start, const u32* __restrict__ m_cs, const u64* __restrict__ m_sstart,
@@ -420,14 +427,13 @@ __global__ __launch_bounds__(256) void k_gather_resident(u64 nb, const u64* __re
 }
 // one batch's packed suffixes into the merged runs; one wave per bucket of the batch
 template <bool WS>
-__global__ __launch_bounds__(256) void k_gather_packed(u64 nbk, const u32* __restrict__ prefix, const u32* __restrict__ cnt, const u64* __restrict__ src_off,
-                                                       const u32* __restrict__ off_in_run, const u8* __restrict__ packed, u64 packed_bytes, u32 BYTES,
-                                                       const u64* __restrict__ bv, const u64* __restrict__ rank_dir, const u64* __restrict__ start,
-                                                       u64* __restrict__ out_lo, u64* __restrict__ out_hi) {
+__global__ __launch_bounds__(256) void k_gather_packed(u64 nbk, const u32* __restrict__ cnt, const u64* __restrict__ src_off, const u64* __restrict__ dst,
+                                                       const u8* __restrict__ packed, u64 packed_bytes, u32 BYTES, u64* __restrict__ out_lo,
+                                                       u64* __restrict__ out_hi) {
     const u64 i = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= nbk) return;
     const u32 lane = threadIdx.x & 63, c = cnt[i];
-    const u64 d0 = start[rank_of(bv, rank_dir, prefix[i])] + off_in_run[i];
+    const u64 d0 = dst[i];
     const u64 e0 = src_off[i];
     const u64 lo_mask = BYTES >= 8 ? ~0ull : ((1ull << (8 * BYTES)) - 1ull);
     const u64 hi_mask = BYTES >= 16 ? ~0ull : (BYTES > 8 ? ((1ull << (8 * (BYTES - 8))) - 1ull) : 0ull);

@@ -749,11 +749,17 @@ template <typename C> void insert_sorted_batches(cblx_ctx* c, const cblx_batch_v
         if (s.count)
             hipLaunchKernelGGL((k_gather_resident<WS>), dim3((unsigned)ceil_div(nr.nb, 4)), dim3(256), 0, c->stream, nr.nb, nr.start.get(), m_cs.get(), m_sstart.get(),
                                s.a_lo.get(), s.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
-        for (u32 b = 0; b < nbt; ++b)
-            if (bt[b].n_buckets)
-                hipLaunchKernelGGL((k_gather_packed<WS>), dim3((unsigned)ceil_div(bt[b].n_buckets, 4)), dim3(256), 0, c->stream, bt[b].n_buckets, bt[b].d_prefix,
-                                   bt[b].d_count, src_off[b].get(), off_in_run[b].get(), bt[b].d_suffix, bt[b].n_words * P.BYTES, P.BYTES, nr.bv.get(), nr.rank_dir.get(), nr.start.get(),
-                                   nr.a_lo.get(), nr.a_hi.get());
+        std::vector<Buf<u64>> dst(nbt);  // released after the bucket stage below has synchronised
+        for (u32 b = 0; b < nbt; ++b) {
+            if (!bt[b].n_buckets) continue;
+            dst[b] = Buf<u64>(c->pool, bt[b].n_buckets);
+            hipLaunchKernelGGL(k_batch_dst, grid1(bt[b].n_buckets, 256), dim3(256), 0, c->stream, bt[b].n_buckets, bt[b].d_prefix, off_in_run[b].get(), nr.bv.get(),
+                               nr.rank_dir.get(), nr.start.get(), dst[b].get());
+            hipLaunchKernelGGL((k_gather_packed<WS>), dim3((unsigned)ceil_div(bt[b].n_buckets, 4)), dim3(256), 0, c->stream, bt[b].n_buckets, bt[b].d_count, src_off[b].get(),
+                               dst[b].get(), bt[b].d_suffix, bt[b].n_words * P.BYTES, P.BYTES, nr.a_lo.get(), nr.a_hi.get());
+        }
+        CBLX_HIP(hipGetLastError());
+        CBLX_HIP(hipStreamSynchronize(c->stream));
         CBLX_HIP(hipGetLastError());
     }
     bucket_stage<C>(c, nr, nr.a_lo.get(), WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr, s.view());
