@@ -148,7 +148,17 @@ def build_in_child():
     process: build() dlopens libcblx.so, which would pull in /opt/rocm's HIP runtime before torch loads its bundled copy —
     two runtimes in one process see no device — and hipcc / g++ children must not inherit a profiler's preload."""
     import fcntl
+    from pathlib import Path
 
+    # nothing to do (the usual case, and the only one allowed under a profiler: a process whose GPU runtime a preloaded
+    # profiler library has initialised must not start children) -> no child at all
+    csrc = Path(ROOT) / "cbl_amd" / "csrc"
+    lib = Path(ROOT) / "cbl_amd" / "libcblx.so"
+    srcs = list(csrc.glob("*.cpp")) + list(csrc.glob("*.hpp")) + [Path(ROOT) / "include" / "cblx.h"]
+    orc = list((Path(ROOT) / "oracle" / "_build").glob("*/liboracle.so"))
+    osrc = [Path(ROOT) / "oracle" / "cbl_oracle_capi.cpp", Path(ROOT) / "oracle" / "cbl_oracle.hpp"]
+    if lib.exists() and all(lib.stat().st_mtime >= f.stat().st_mtime for f in srcs) and orc and all(orc[0].stat().st_mtime >= f.stat().st_mtime for f in osrc):
+        return
     with open(os.path.join(ROOT, ".build.lock"), "w") as lk:
         fcntl.flock(lk, fcntl.LOCK_EX)
         try:

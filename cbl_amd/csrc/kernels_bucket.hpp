@@ -329,7 +329,7 @@ __device__ __forceinline__ u64 rank_of(const u64* __restrict__ bv, const u64* __
 static const u32 PACK_THREADS = 256, PACK_ITEMS = 8, PACK_TILE = PACK_THREADS * PACK_ITEMS;
 template <bool WS, typename HiT>
 __global__ __launch_bounds__(PACK_THREADS) void k_batch_pack(u64 n, const u64* __restrict__ lo, const HiT* __restrict__ hi, u32 SB, u32 BYTES, u8* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) u8 s_b[PACK_TILE * 16];
+    extern __shared__ __attribute__((aligned(16))) u8 s_b[];  // PACK_TILE * BYTES bytes (launch parameter): 12 KB at K=31 / PB=24 keeps 32 waves per CU
     const u64 t0 = (u64)blockIdx.x * PACK_TILE;
     const u32 nt = (u32)((n - t0) < (u64)PACK_TILE ? (n - t0) : (u64)PACK_TILE);
 #pragma unroll

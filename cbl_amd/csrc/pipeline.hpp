@@ -672,7 +672,7 @@ template <typename C> void sorted_batch_export(cblx_ctx* c, u32* d_prefix, u32* 
         CBLX_HIP(hipMemcpyAsync(d_prefix, b.prefix.get(), b.nb * 4, hipMemcpyDeviceToDevice, c->stream));
         hipLaunchKernelGGL(k_batch_counts, grid1(b.nb, 256), dim3(256), 0, c->stream, b.nb, b.start.get(), d_count);
         // the hi part matters only for suffixes wider than 64 bits (then it was carried through every pass)
-        hipLaunchKernelGGL((k_batch_pack<C::WS, HiT>), dim3((unsigned)ceil_div(b.n, PACK_TILE)), dim3(PACK_THREADS), 0, c->stream, b.n, b.lo.get(),
+        hipLaunchKernelGGL((k_batch_pack<C::WS, HiT>), dim3((unsigned)ceil_div(b.n, PACK_TILE)), dim3(PACK_THREADS), (size_t)PACK_TILE * c->P.BYTES, c->stream, b.n, b.lo.get(),
                            C::WS ? (const HiT*)b.hi.get() : (const HiT*)nullptr, c->P.SB, c->P.BYTES, d_suffix);
         CBLX_HIP(hipGetLastError());
         CBLX_HIP(hipStreamSynchronize(c->stream));

@@ -2,8 +2,12 @@
 """Turn gpurun_out/<tag>/ (made by tools/collect_profiles.sh on the GPU box) into the committed profiles/<round>_* files.
 Usage: tools/write_profiles.py <tag> <round>      e.g.  tools/write_profiles.py r01h r01"""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash  # noqa: E402
 
 tag, rnd = sys.argv[1], sys.argv[2]
 base = f"gpurun_out/{tag}/"
@@ -29,8 +33,9 @@ ll = {"fetch_kb_raw": f[kL][2], "write_kb_raw": w[kL][2], "alg_bytes": int(16.5 
 hbm = lambda d: (2 * d["fetch_kb_raw"] + d["write_kb_raw"]) * 1024
 avg = (hbm(la) + 2 * hbm(ll)) / 3
 tr = {
-    "config": {k: bl["config"][k] for k in ("k", "prefix_bits", "reads_per_gpu", "read_len")},
+    "config": {**{k: bl["config"][k] for k in ("k", "prefix_bits", "reads_per_gpu", "read_len")}, "kind": "build"},
     "kernel": "k_radix_scatter",
+    "src_sha": source_hash(),  # bench.py reports `traffic` only while cbl_amd/csrc still hashes to this
     "launches": {"k_radix_scatter<u8,NoHi> (pass A: 9 B in, 8 B + 1 B digit out)": la,
                  "k_radix_scatter<NoHi,NoHi> (LSD passes, x2: 8 B in, 8 B (+1 B digit) out)": ll},
     "hbm_bytes_per_launch": int(avg),
@@ -39,6 +44,7 @@ tr = {
               "FETCH doubled per the gfx950 note); average over the 3 scatter launches of a step",
 }
 json.dump(tr, open(f"profiles/{rnd}_traffic.json", "w"), indent=1)
+json.dump(tr, open("profiles/traffic.json", "w"), indent=1)  # the copy bench.py reads
 hdr = (f"# {rnd} (final) — rocprofv3 --kernel-trace --stats, bench.py --steps 3 --warmup 1 (cfg 2: K=31, PB=24, 10M x 150 bp, 1 x MI355X)\n\n"
        f"Command: `bash tools/collect_profiles.sh {tag}` on the GPU box (`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 "
        f"--no-cpu-baseline`; 4 steps incl. warm-up; averages are per launch). Same build and box: profiles/{rnd}_bench_line.json "
