@@ -232,19 +232,19 @@ __global__ void k_merge_table(u64 nprefix, const u64* __restrict__ bv, const u64
     m_skind[r] = ks;
     m_okind[r] = ko;
 }
-// one wave per merged bucket: self's stored suffixes then other's, copied into the merged run
-template <bool WS>
+// LPB lanes per merged bucket: self's stored suffixes then other's, copied into the merged run
+template <bool WS, int LPB>
 __global__ __launch_bounds__(256) void k_merge_gather(u64 nb, const u64* __restrict__ start, const u32* __restrict__ m_cs, const u64* __restrict__ m_sstart,
                                                       const u64* __restrict__ m_ostart, const u64* __restrict__ s_lo, const u64* __restrict__ s_hi,
                                                       const u64* __restrict__ o_lo, const u64* __restrict__ o_hi, u64* __restrict__ out_lo,
                                                       u64* __restrict__ out_hi) {
-    const u64 r = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u64 r = ((u64)blockIdx.x * 256 + threadIdx.x) / LPB;
     if (r >= nb) return;
-    const u32 lane = threadIdx.x & 63;
+    const u32 lane = threadIdx.x & (LPB - 1);
     const u64 d0 = start[r];
     const u32 c = (u32)(start[r + 1] - d0), cs = m_cs[r];
     const u64 ss = m_sstart[r], os = m_ostart[r];
-    for (u32 j = lane; j < c; j += 64) {
+    for (u32 j = lane; j < c; j += LPB) {
         const bool from_self = j < cs;
         const u64 src = from_self ? ss + j : os + (j - cs);
         out_lo[d0 + j] = from_self ? s_lo[src] : o_lo[src];
@@ -387,7 +387,18 @@ __global__ void k_batch_bits(u64 nbk, const u32* __restrict__ prefix, const u32*
     const u32 p = prefix[i];
     // out of range / not strictly ascending / an empty bucket (would leave a set bit without words)
     if (p >= nprefix || (i > 0 && prefix[i - 1] >= p) || cnt[i] == 0) { atomicAdd(bad, 1u); return; }
-    atomicOr((unsigned long long*)&bv[p >> 6], 1ull << (p & 63));
+    // The prefixes of a batch ascend, so the buckets of one bitvector word are neighbours: the first of them ORs the bits of
+    // all (a plain read-modify-write: the batches of a call are applied by successive launches, and within a launch a word
+    // has one writer — unless the batch is malformed, which `bad` reports and the caller rejects). One atomic per bucket
+    // cost 1 ms per batch at PREFIX_BITS = 28.
+    if (i > 0 && (prefix[i - 1] >> 6) == (p >> 6)) return;
+    u64 bits = 1ull << (p & 63);
+    for (u64 j = i + 1; j < nbk && j < i + 64; ++j) {
+        const u32 q = prefix[j];
+        if ((q >> 6) != (p >> 6)) break;
+        bits |= 1ull << (q & 63);
+    }
+    bv[p >> 6] |= bits;
 }
 __global__ void k_popc_words(u64 nwords, const u64* __restrict__ bv, u32* __restrict__ popc) {
     const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -411,33 +422,34 @@ __global__ void k_batch_dst(u64 nbk, const u32* __restrict__ prefix, const u32* 
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nbk) dst[i] = start[rank_of(bv, rank_dir, prefix[i])] + off_in_run[i];
 }
-// resident suffixes (stored order) to the front of their merged runs; one wave per merged bucket
-template <bool WS>
+// resident suffixes (stored order) to the front of their merged runs; LPB lanes per merged bucket
+template <bool WS, int LPB>
 __global__ __launch_bounds__(256) void k_gather_resident(u64 nb, const u64* __restrict__ start, const u32* __restrict__ m_cs, const u64* __restrict__ m_sstart,
                                                          const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, u64* __restrict__ out_lo,
                                                          u64* __restrict__ out_hi) {
-    const u64 r = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u64 r = ((u64)blockIdx.x * 256 + threadIdx.x) / LPB;
     if (r >= nb) return;
-    const u32 lane = threadIdx.x & 63, cs = m_cs[r];
+    const u32 lane = threadIdx.x & (LPB - 1), cs = m_cs[r];
     const u64 d0 = start[r], ss = m_sstart[r];
-    for (u32 j = lane; j < cs; j += 64) {
+    for (u32 j = lane; j < cs; j += LPB) {
         out_lo[d0 + j] = s_lo[ss + j];
         if constexpr (WS) out_hi[d0 + j] = s_hi[ss + j];
     }
 }
-// one batch's packed suffixes into the merged runs; one wave per bucket of the batch
-template <bool WS>
+// one batch's packed suffixes into the merged runs; LPB lanes per bucket of the batch (a wave per bucket leaves most lanes
+// idle once the buckets are short: PREFIX_BITS = 28 spreads a slice over buckets of a few dozen words)
+template <bool WS, int LPB>
 __global__ __launch_bounds__(256) void k_gather_packed(u64 nbk, const u32* __restrict__ cnt, const u64* __restrict__ src_off, const u64* __restrict__ dst,
                                                        const u8* __restrict__ packed, u64 packed_bytes, u32 BYTES, u64* __restrict__ out_lo,
                                                        u64* __restrict__ out_hi) {
-    const u64 i = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u64 i = ((u64)blockIdx.x * 256 + threadIdx.x) / LPB;
     if (i >= nbk) return;
-    const u32 lane = threadIdx.x & 63, c = cnt[i];
+    const u32 lane = threadIdx.x & (LPB - 1), c = cnt[i];
     const u64 d0 = dst[i];
     const u64 e0 = src_off[i];
     const u64 lo_mask = BYTES >= 8 ? ~0ull : ((1ull << (8 * BYTES)) - 1ull);
     const u64 hi_mask = BYTES >= 16 ? ~0ull : (BYTES > 8 ? ((1ull << (8 * (BYTES - 8))) - 1ull) : 0ull);
-    for (u32 j = lane; j < c; j += 64) {
+    for (u32 j = lane; j < c; j += LPB) {
         const u64 byte0 = (e0 + j) * BYTES;
         const u8* q = packed + byte0;
         u64 lo = 0, hi = 0;

@@ -281,6 +281,15 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, ty
     }
 }
 
+// lanes per bucket of the per-bucket copy kernels, from the average run length (words / buckets)
+template <typename F> void with_lpb(u64 words, u64 buckets, F&& f) {
+    const u64 avg = buckets ? words / buckets : 0;
+    if (avg >= 48) f(std::integral_constant<int, 64>());
+    else if (avg >= 12) f(std::integral_constant<int, 16>());
+    else f(std::integral_constant<int, 4>());
+}
+inline dim3 lpb_grid(u64 buckets, int lpb) { return dim3((unsigned)std::max<u64>(1, ceil_div(buckets * (u64)lpb, 256))); }
+
 // rows of k_merge_table's `other` side for a freshly partitioned batch: every run is a Vec of its raw length
 __global__ void k_run_lengths(u64 nb, const u64* __restrict__ start, u32* __restrict__ cnt, u8* __restrict__ kind) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -353,8 +362,11 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
     if (WS) nr.a_hi = Buf<u64>(c->pool, T + 2);
     {
         StageTimer t(c, ST_EXPAND);
-        hipLaunchKernelGGL((k_merge_gather<WS>), dim3((unsigned)ceil_div(nr.nb, 4)), dim3(256), 0, c->stream, nr.nb, nr.start.get(), m_cs.get(), m_sstart.get(), m_ostart.get(),
-                           s.a_lo.get(), s.a_hi.get(), nb_.a_lo.get(), nb_.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
+        with_lpb(T, nr.nb, [&](auto lpb) {
+            constexpr int LPB = decltype(lpb)::value;
+            hipLaunchKernelGGL((k_merge_gather<WS, LPB>), lpb_grid(nr.nb, LPB), dim3(256), 0, c->stream, nr.nb, nr.start.get(), m_cs.get(), m_sstart.get(), m_ostart.get(),
+                               s.a_lo.get(), s.a_hi.get(), nb_.a_lo.get(), nb_.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
+        });
         CBLX_HIP(hipGetLastError());
     }
     bucket_stage<C>(c, nr, nr.a_lo.get(), WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr, s.view());
@@ -747,16 +759,22 @@ template <typename C> void insert_sorted_batches(cblx_ctx* c, const cblx_batch_v
     {
         StageTimer t(c, ST_EXPAND);
         if (s.count)
-            hipLaunchKernelGGL((k_gather_resident<WS>), dim3((unsigned)ceil_div(nr.nb, 4)), dim3(256), 0, c->stream, nr.nb, nr.start.get(), m_cs.get(), m_sstart.get(),
-                               s.a_lo.get(), s.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
+            with_lpb(s.count, s.nb, [&](auto lpb) {
+                constexpr int LPB = decltype(lpb)::value;
+                hipLaunchKernelGGL((k_gather_resident<WS, LPB>), lpb_grid(nr.nb, LPB), dim3(256), 0, c->stream, nr.nb, nr.start.get(), m_cs.get(), m_sstart.get(),
+                                   s.a_lo.get(), s.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
+            });
         std::vector<Buf<u64>> dst(nbt);  // released after the bucket stage below has synchronised
         for (u32 b = 0; b < nbt; ++b) {
             if (!bt[b].n_buckets) continue;
             dst[b] = Buf<u64>(c->pool, bt[b].n_buckets);
             hipLaunchKernelGGL(k_batch_dst, grid1(bt[b].n_buckets, 256), dim3(256), 0, c->stream, bt[b].n_buckets, bt[b].d_prefix, off_in_run[b].get(), nr.bv.get(),
                                nr.rank_dir.get(), nr.start.get(), dst[b].get());
-            hipLaunchKernelGGL((k_gather_packed<WS>), dim3((unsigned)ceil_div(bt[b].n_buckets, 4)), dim3(256), 0, c->stream, bt[b].n_buckets, bt[b].d_count, src_off[b].get(),
-                               dst[b].get(), bt[b].d_suffix, bt[b].n_words * P.BYTES, P.BYTES, nr.a_lo.get(), nr.a_hi.get());
+            with_lpb(bt[b].n_words, bt[b].n_buckets, [&](auto lpb) {
+                constexpr int LPB = decltype(lpb)::value;
+                hipLaunchKernelGGL((k_gather_packed<WS, LPB>), lpb_grid(bt[b].n_buckets, LPB), dim3(256), 0, c->stream, bt[b].n_buckets, bt[b].d_count, src_off[b].get(),
+                                   dst[b].get(), bt[b].d_suffix, bt[b].n_words * P.BYTES, P.BYTES, nr.a_lo.get(), nr.a_hi.get());
+            });
         }
         CBLX_HIP(hipGetLastError());
         CBLX_HIP(hipStreamSynchronize(c->stream));
@@ -810,8 +828,11 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
     if (WS) nr.a_hi = Buf<u64>(c->pool, N + 2);
     {
         StageTimer t(c, ST_EXPAND);
-        hipLaunchKernelGGL((k_merge_gather<WS>), dim3((unsigned)ceil_div(nb, 4)), dim3(256), 0, c->stream, nb, nr.start.get(), m_cs.get(), m_sstart.get(), m_ostart.get(),
-                           s.a_lo.get(), s.a_hi.get(), o.a_lo.get(), o.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
+        with_lpb(N, nb, [&](auto lpb) {
+            constexpr int LPB = decltype(lpb)::value;
+            hipLaunchKernelGGL((k_merge_gather<WS, LPB>), lpb_grid(nb, LPB), dim3(256), 0, c->stream, nb, nr.start.get(), m_cs.get(), m_sstart.get(), m_ostart.get(),
+                               s.a_lo.get(), s.a_hi.get(), o.a_lo.get(), o.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
+        });
     }
     Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
     Buf<u32> list_n(c->pool, CLS_N);
