@@ -54,7 +54,26 @@ public:
             CBLX_HIP(hipMemcpyAsync((u8*)d_dst + off, l.slot[k], n, hipMemcpyHostToDevice, l.s));
         });
     }
+    // true when the runtime knows the host range as pinned (hipHostMalloc / hipHostRegister, e.g. a torch pin_memory tensor)
+    static bool is_pinned(const void* p) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }  // pageable memory is simply unknown
+        return a.type == hipMemoryTypeHost;
+    }
     void h2d_copy(void* d_dst, const void* h_src, size_t bytes) {
+        if (bytes >= PARALLEL_MIN && is_pinned(h_src) && is_pinned((const u8*)h_src + bytes - 1)) {
+            // the caller's buffer is pinned already: DMA straight from it (no trip through the lanes' slots), split over the
+            // lanes' streams so that several copy engines work; complete after sync() like every h2d
+            const int L = lanes_for(bytes);
+            ensure(L);
+            const size_t per = ((bytes + (size_t)L - 1) / (size_t)L + 4095) & ~(size_t)4095;
+            for (int i = 0; i < L; ++i) {
+                const size_t off = (size_t)i * per;
+                if (off >= bytes) break;
+                CBLX_HIP(hipMemcpyAsync((u8*)d_dst + off, (const u8*)h_src + off, std::min(per, bytes - off), hipMemcpyHostToDevice, lanes_[(size_t)i].s));
+            }
+            return;
+        }
         h2d(d_dst, bytes, [&](u8* dst, size_t off, size_t n) { std::memcpy(dst, (const u8*)h_src + off, n); });
     }
     // device -> host: drain(src_pinned, off, n) consumes bytes [off, off+n). Complete on return.

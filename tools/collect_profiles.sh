@@ -7,11 +7,12 @@ TAG=${1:-prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
+python3 -c "import sys; sys.path.insert(0, '$R'); from bench import source_hash; print(source_hash())" > $OUT/src_sha.txt
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 5 --warmup 2 --cpu-sample-reads 1000000 > $OUT/bench_line.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o r -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o r -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o r -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/write.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o r -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-h2d > $OUT/stats_bench.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o r -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-h2d > /dev/null 2> $OUT/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o r -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-h2d > /dev/null 2> $OUT/write.err
 cd $R
 python3 tools/rocpd_summary.py $OUT/stats/r_results.db > $OUT/kernel_stats.md
 python3 tools/rocpd_summary.py $OUT/fetch/r_results.db | sed -n '/counter/,$p' > $OUT/pmc_fetch.md

@@ -35,7 +35,9 @@ avg = (hbm(la) + 2 * hbm(ll)) / 3
 tr = {
     "config": {**{k: bl["config"][k] for k in ("k", "prefix_bits", "reads_per_gpu", "read_len")}, "kind": "build"},
     "kernel": "k_radix_scatter",
-    "src_sha": source_hash(),  # bench.py reports `traffic` only while cbl_amd/csrc still hashes to this
+    # hash of cbl_amd/csrc AS IT WAS ON THE GPU BOX when the counters were taken; bench.py reports `traffic` only while the
+    # tree still hashes to this
+    "src_sha": (open(base + "src_sha.txt").read().strip() if os.path.exists(base + "src_sha.txt") else source_hash()),
     "launches": {"k_radix_scatter<u8,NoHi> (pass A: 9 B in, 8 B + 1 B digit out)": la,
                  "k_radix_scatter<NoHi,NoHi> (LSD passes, x2: 8 B in, 8 B (+1 B digit) out)": ll},
     "hbm_bytes_per_launch": int(avg),
