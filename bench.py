@@ -77,6 +77,7 @@ def stage_alg_bytes(k: int, pb: int, read_len: int):
         "bucket_medium": 2 * sfx,                              # read the run, write the distinct suffixes
         "bucket_small": 2 * sfx,
         "bucket_huge": 2 * sfx,
+        "bucket_big": 2 * sfx,
         "merge_gather": 2 * sfx,
     }
 
@@ -84,11 +85,11 @@ def stage_alg_bytes(k: int, pb: int, read_len: int):
 # `A |= B`: bytes per word of the merged runs (|A| + |B| words)
 def merge_alg_bytes(k: int, pb: int):
     _, _, _, sfx, _ = word_layout(k, pb)
-    return {"merge_gather": 2 * sfx, "bucket_medium": 2 * sfx, "bucket_huge": 2 * sfx, "directory": 0.0}
+    return {"merge_gather": 2 * sfx, "bucket_medium": 2 * sfx, "bucket_huge": 2 * sfx, "bucket_big": 2 * sfx, "directory": 0.0}
 
 
 KERNEL_OF = {"radix_scatter": "k_radix_scatter", "radix_hist": "k_radix_hist_bytes", "radix_scan": "k_colscan_*+k_seg_*", "encode": "k_encode",
-             "bucket_medium": "k_bucket_msd", "bucket_small": "k_bucket_small", "bucket_huge": "k_bucket_huge",
+             "bucket_medium": "k_bucket_msd", "bucket_small": "k_bucket_small", "bucket_huge": "k_bucket_huge", "bucket_big": "k_big_split+k_bucket_msd+k_big_collect",
              "directory": "k_dir_gather/k_dir_resolve+k_bitvector+k_bucket_table", "chunks": "k_scan_invalid+chunk table",
              "merge_gather": "k_merge_gather"}
 

@@ -113,9 +113,9 @@ struct Resident {
 };
 
 struct Stage { const char* name; double ms = 0; u64 launches = 0; };
-enum { ST_CHUNKS, ST_ENCODE, ST_HIST, ST_SCAN, ST_SCATTER, ST_DIR, ST_BSMALL, ST_BMED, ST_BHUGE, ST_EXPAND, ST_N };
+enum { ST_CHUNKS, ST_ENCODE, ST_HIST, ST_SCAN, ST_SCATTER, ST_DIR, ST_BSMALL, ST_BMED, ST_BHUGE, ST_EXPAND, ST_BBIG, ST_N };
 const char* kStageNames[ST_N] = {"chunks", "encode", "radix_hist", "radix_scan", "radix_scatter", "directory",
-                                 "bucket_small", "bucket_medium", "bucket_huge", "merge_gather"};
+                                 "bucket_small", "bucket_medium", "bucket_huge", "merge_gather", "bucket_big"};
 
 // Sequences enqueued by cblx_insert_seq / cblx_insert_seqs / the FASTA reader. They are staged straight into HBM
 // while the caller keeps enqueueing: small appends fill pinned write blocks that are DMA'd as they fill up, bulk

@@ -119,7 +119,17 @@ __device__ __forceinline__ bool dir_lookup(const DirView& d, u32 p, u64& rank) {
 }
 
 // ---- classification of buckets by run length -----------------------------------------------------------
-enum { CLS_M16 = 0, CLS_M64 = 1, CLS_M128 = 2, CLS_M256 = 3, CLS_M512 = 4, CLS_M1024 = 5, CLS_HUGE = 6, CLS_S16 = 7, CLS_S32 = 8, CLS_N = 9 };
+enum { CLS_M16 = 0, CLS_M64 = 1, CLS_M128 = 2, CLS_M256 = 3, CLS_M512 = 4, CLS_M1024 = 5, CLS_HUGE = 6, CLS_S16 = 7, CLS_S32 = 8, CLS_BIG = 9, CLS_N = 10 };
+// Runs longer than one workgroup's LDS sort takes (> 4096) and up to BIG_MAX: split by the top suffix bits into sub-ranges of
+// about a thousand words in scratch, each sorted + deduplicated by k_bucket_msd, then collected in order (k_big_*). Such
+// buckets are the rule, not the exception, once an index holds tens of millions of reads at PREFIX_BITS = 24 (one rank of an
+// 8-GPU cfg 5 job owns 70 716 buckets of 10 635 words on average).
+static const u32 BIG_MAX = 1u << 18, BIG_SUB = 1024, BIG_VCAP = 2048, BIG_SENT = 0xFFFFFFFFu;
+__host__ __device__ inline u32 big_bits(u32 c) {  // sub-ranges of a big run: 2^bits, about BIG_SUB words each
+    u32 b = 1;
+    while (b < 8 && ((c - 1) >> b) >= BIG_SUB) ++b;
+    return b;
+}
 static const u32 SMALL_MAX = 32;  // all-pairs in a slice of a wave up to here; counting-sort kernels above
 static const u32 MED_ITEMS = 8;
 
@@ -184,9 +194,10 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify(u64 nb, u32 med_m
         else if (c <= 128 * MED_ITEMS) cls = CLS_M128;
         else if (c <= 256 * MED_ITEMS) cls = CLS_M256;
         else if (c <= 512 * MED_ITEMS) cls = CLS_M512;
-        else if (c <= 1024 * MED_ITEMS && med_max_threads >= 1024) cls = CLS_M1024;
+        else if (c <= BIG_MAX) cls = CLS_BIG;
         else cls = CLS_HUGE;
     }
+    (void)med_max_threads;
     const u32 slot = block_append<CLASSIFY_THREADS, CLS_N>(cls, list_n);
     if (cls >= 0) lists[(u64)cls * nb + slot] = BDesc{raw_start[r], (u32)c | (rk == KIND_TRIE ? BDESC_TRIE : 0u), (u32)r};
 }
@@ -271,6 +282,7 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify_merge(u64 nb, u32
         else if (c <= 128 * MED_ITEMS) cls = CLS_M128;
         else if (c <= 256 * MED_ITEMS) cls = CLS_M256;
         else if (c <= 512 * MED_ITEMS) cls = CLS_M512;
+        else if (ks == KIND_TRIE && m_okind[r] == KIND_TRIE && c <= BIG_MAX) cls = CLS_BIG;  // Trie |= Trie: the sorted union, nothing else
         else if (c <= 1024 * MED_ITEMS && med_max_threads >= 1024) cls = CLS_M1024;
         else cls = CLS_HUGE;
     }
@@ -756,6 +768,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     const u32 c = dsc.c & ~BDESC_TRIE;
     const bool res_trie = (dsc.c & BDESC_TRIE) != 0;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    if (c == 0) {  // an empty sub-range of a big run (k_big_split)
+        if (tid == 0) { out_count[r] = 0; out_kind[r] = KIND_TRIE; }
+        return;
+    }
     const u32 R = (c + THREADS - 1) / THREADS;
     const u32 EPW = 64 * R;  // wave-contiguous slices: ballots then compact in stream order
     u32 nbits = 32 - __builtin_clz(c - 1 > 0 ? c - 1 : 1);  // ceil(log2 c)
@@ -1072,6 +1088,134 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     if (tid == 0) {
         out_count[r] = d;
         out_kind[r] = trie ? KIND_TRIE : KIND_VEC;
+    }
+}
+
+// ---- KRN-3 big: runs of 4097 .. BIG_MAX words -------------------------------------------------------------------------
+// per list entry: its length and its number of sub-ranges (scanned by the host side into scratch / virtual-bucket offsets)
+__global__ void k_big_plan(const BDesc* __restrict__ list, u32 n, u32* __restrict__ len, u32* __restrict__ nv) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 c = list[i].c & ~BDESC_TRIE;
+    len[i] = c;
+    nv[i] = 1u << big_bits(c);
+}
+// One workgroup per big run: stable counting sort by the top big_bits(c) suffix bits into scratch; one descriptor per
+// sub-range (a "virtual bucket" for k_bucket_msd, always asked for the sorted distinct list). A sub-range that outgrows the
+// sort kernel marks itself BIG_SENT - 1 in v_count: the whole run then takes the general kernel.
+template <bool WS, typename HiT>
+__global__ __launch_bounds__(256) void k_big_split(const BDesc* __restrict__ list, const u32* __restrict__ list_n, const u64* __restrict__ so_,
+                                                   const u64* __restrict__ vb_, const u64* __restrict__ lo, const HiT* __restrict__ hi, u32 SB,
+                                                   u64* __restrict__ s_lo, u64* __restrict__ s_hi, BDesc* __restrict__ vlist, u32* __restrict__ v_count,
+                                                   u32 v_dummy) {
+    constexpr int THREADS = 256, ITEMS = 8, TILE = THREADS * ITEMS;
+    __shared__ u32 s_wcnt[(THREADS / 64) * 256];
+    __shared__ u32 s_dbase[256];
+    __shared__ u32 s_scan[THREADS / 64 + 1];
+    __shared__ u32 s_hist[256];
+    __shared__ u32 s_run[256];
+    if (blockIdx.x >= *list_n) return;
+    const BDesc dsc = list[blockIdx.x];
+    const u64 s0 = dsc.start, so = so_[blockIdx.x], vb = vb_[blockIdx.x];
+    const u32 c = dsc.c & ~BDESC_TRIE;
+    const u32 B = big_bits(c), V = 1u << B;
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    s_hist[tid] = 0;
+    __syncthreads();
+    for (u32 e = tid; e < c; e += THREADS) atomicAdd(&s_hist[sfx_top_bits<WS>(load_sfx<WS, HiT>(lo, hi, s0 + e, SB), SB, B)], 1u);
+    __syncthreads();
+    const u32 hv = s_hist[tid];
+    const u32 ex = block_exclusive_scan<THREADS, u32>(hv, s_scan, nullptr);
+    s_run[tid] = ex;
+    if (tid < V) {
+        // BIG_SENT: not sorted yet (the sort kernel overwrites it). A sub-range the sort kernel cannot take is handed to it as
+        // an empty one reporting to a dummy slot, and keeps BIG_SENT - 1.
+        const bool fits = hv <= BIG_VCAP;
+        vlist[vb + tid] = BDesc{so + ex, (fits ? hv : 0u) | BDESC_TRIE, fits ? (u32)(vb + tid) : v_dummy};
+        v_count[vb + tid] = fits ? BIG_SENT : BIG_SENT - 1;
+    }
+    __syncthreads();
+    const u32 ntile = (c + TILE - 1) / TILE;
+    for (u32 t = 0; t < ntile; ++t) {
+        Sfx<WS> key[ITEMS];
+        u32 digit[ITEMS], pos[ITEMS];
+        bool valid[ITEMS];
+        const u32 tb = t * TILE;
+        const u32 n_tile = c - tb < (u32)TILE ? c - tb : (u32)TILE;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 e = w * (64 * ITEMS) + j * 64 + lane;
+            valid[j] = e < n_tile;
+            digit[j] = 255;  // tail slots: last
+            key[j].lo = 0;
+            if constexpr (WS) key[j].hi = 0;
+            if (valid[j]) {
+                key[j] = load_sfx<WS, HiT>(lo, hi, s0 + tb + e, SB);
+                digit[j] = sfx_top_bits<WS>(key[j], SB, B);
+            }
+        }
+        tile_rank<THREADS, ITEMS>(digit, pos, s_wcnt, s_dbase, s_scan, ITEMS);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (valid[j]) {
+                const u64 dst = so + s_run[digit[j]] + (pos[j] - s_dbase[digit[j]]);
+                s_lo[dst] = key[j].lo;
+                if constexpr (WS) s_hi[dst] = key[j].hi;
+            }
+        }
+        __syncthreads();
+        {   // advance the running starts by this tile's digit counts (tail slots sit in digit 255 and are not counted)
+            const u32 nxt = tid == 255 ? n_tile : s_dbase[tid + 1];
+            const u32 cur = s_dbase[tid] < n_tile ? s_dbase[tid] : n_tile;
+            s_run[tid] += (nxt < n_tile ? nxt : n_tile) - cur;
+        }
+        __syncthreads();
+    }
+}
+// One workgroup per big run: the sorted distinct sub-ranges, in order, back into the run's arena slot. A run that must stay a
+// Vec (at most 1024 distinct and no resident Trie: heavy duplication) or whose sort gave up goes to `fb` for the general kernel
+// (the arena run is untouched until here).
+template <bool WS, typename HiT>
+__global__ __launch_bounds__(256) void k_big_collect(const BDesc* __restrict__ list, const u32* __restrict__ list_n, const u64* __restrict__ vb_,
+                                                     const BDesc* __restrict__ vlist, const u32* __restrict__ v_count, const u64* __restrict__ s_lo,
+                                                     const u64* __restrict__ s_hi, u64* __restrict__ lo, HiT* __restrict__ hi, u32* __restrict__ out_count,
+                                                     u8* __restrict__ out_kind, BDesc* __restrict__ fb, u32* __restrict__ fb_n) {
+    __shared__ u32 s_scan[256 / 64 + 1];
+    __shared__ u32 s_off[257];
+    __shared__ u32 s_fail;
+    if (blockIdx.x >= *list_n) return;
+    const BDesc dsc = list[blockIdx.x];
+    const u64 s0 = dsc.start, vb = vb_[blockIdx.x];
+    const u32 c = dsc.c & ~BDESC_TRIE;
+    const bool res_trie = (dsc.c & BDESC_TRIE) != 0;
+    const u32 V = 1u << big_bits(c), tid = threadIdx.x;
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    u32 cnt = 0;
+    if (tid < V) {
+        cnt = v_count[vb + tid];
+        if (cnt >= BIG_SENT - 1) { atomicOr(&s_fail, 1u); cnt = 0; }
+    }
+    u32 d;
+    const u32 ex = block_exclusive_scan<256, u32>(cnt, s_scan, &d);
+    s_off[tid] = ex;
+    if (tid == 0) s_off[256] = d;
+    __syncthreads();
+    if (s_fail || (!res_trie && d <= VEC_THRESHOLD)) {
+        if (tid == 0) fb[atomicAdd(fb_n, 1u)] = dsc;
+        return;
+    }
+    for (u32 v = 0; v < V; ++v) {
+        const u32 n = s_off[v + 1] - s_off[v];
+        const u64 src = vlist[vb + v].start, dst = s0 + s_off[v];
+        for (u32 e = tid; e < n; e += 256) {
+            lo[dst + e] = s_lo[src + e];
+            if constexpr (WS) st_hi<HiT>(hi, dst + e, s_hi[src + e]);
+        }
+    }
+    if (tid == 0) {
+        out_count[dsc.r] = d;
+        out_kind[dsc.r] = KIND_TRIE;
     }
 }
 

@@ -194,6 +194,67 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
     }
 }
 
+// general kernel for runs of any length (and the fallback of the big path): one workgroup per run, LSD radix in global scratch
+template <typename C> void huge_stage(cblx_ctx* c, const BDesc* d_list, const u32* d_list_n, u32 nh, u64* a_lo, typename C::HiT* a_hi, Resident& nr, const MergeArgs& ma) {
+    typedef typename C::HiT HiT;
+    if (nh == 0) return;
+    StageTimer t(c, ST_BHUGE);
+    std::vector<BDesc> hl = d2h_vec<BDesc>(c, d_list, nh);
+    std::vector<u64> so(nh);
+    u64 tot = 0;
+    for (u32 i = 0; i < nh; ++i) { so[i] = tot; tot += hl[i].c & ~BDESC_TRIE; }
+    Buf<u64> d_so(c->pool, nh), s_alo(c->pool, tot), s_blo(c->pool, tot), s_ahi(c->pool, C::WS ? tot : 1), s_bhi(c->pool, C::WS ? tot : 1);
+    Buf<u32> s_aidx(c->pool, tot), s_bidx(c->pool, tot);
+    h2d(c, d_so.get(), so.data(), nh);
+    hipLaunchKernelGGL((k_bucket_huge<C::WS, HiT>), dim3(nh), dim3(256), 0, c->stream, d_list, d_list_n, d_so.get(), a_lo, a_hi, c->P.SB, s_alo.get(), s_ahi.get(),
+                       s_aidx.get(), s_blo.get(), s_bhi.get(), s_bidx.get(), nr.cnt.get(), nr.kind.get(), ma);
+    CBLX_HIP(hipGetLastError());
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+}
+// runs of 4097 .. BIG_MAX words (kernels_bucket.hpp: k_big_*): split into sub-ranges in scratch, sort + dedup each with
+// k_bucket_msd, collect in order; what cannot be finished that way takes the general kernel
+template <typename C> void big_stage(cblx_ctx* c, const BDesc* d_list, const u32* d_list_n, u32 nbig, u64* a_lo, typename C::HiT* a_hi, Resident& nr, const MergeArgs& ma) {
+    typedef typename C::HiT HiT;
+    constexpr bool WS = C::WS;
+    if (nbig == 0) return;
+    const Consts& P = c->P;
+    Buf<BDesc> fb(c->pool, nbig);
+    Buf<u32> fb_n(c->pool, 1);
+    {
+        StageTimer t(c, ST_BBIG);
+        Buf<u32> len(c->pool, nbig), nv(c->pool, nbig), vtot_d(c->pool, 1);
+        Buf<u64> so(c->pool, nbig + 1), vb(c->pool, nbig + 1);
+        hipLaunchKernelGGL(k_big_plan, grid1(nbig, 256), dim3(256), 0, c->stream, d_list, nbig, len.get(), nv.get());
+        const u64 tot = exclusive_scan<u64>(c, len.get(), nbig, so.get());
+        const u64 vtot = exclusive_scan<u64>(c, nv.get(), nbig, vb.get());
+        Buf<u64> s_lo(c->pool, tot + 2), s_hi(c->pool, WS ? tot + 2 : 1);
+        Buf<BDesc> vlist(c->pool, vtot);
+        Buf<u32> v_count(c->pool, vtot + 1);
+        Buf<u8> v_kind(c->pool, vtot + 1);
+        Buf<BDesc> retry(c->pool, vtot);  // sub-ranges the sort gives up on (crowded sub-bucket): their runs fall back as a whole
+        Buf<u32> retry_n(c->pool, 1);
+        const u32 vt32 = (u32)vtot;
+        h2d(c, vtot_d.get(), &vt32, 1);
+        CBLX_HIP(hipMemsetAsync(retry_n.get(), 0, 4, c->stream));
+        CBLX_HIP(hipMemsetAsync(fb_n.get(), 0, 4, c->stream));
+        hipLaunchKernelGGL((k_big_split<WS, HiT>), dim3(nbig), dim3(256), 0, c->stream, d_list, d_list_n, so.get(), vb.get(), (const u64*)a_lo, (const HiT*)a_hi, P.SB, s_lo.get(),
+                           s_hi.get(), vlist.get(), v_count.get(), vt32);
+        HiT* sh = WS ? (HiT*)s_hi.get() : (HiT*)nullptr;
+        auto sort = [&](auto pk) {
+            hipLaunchKernelGGL((k_bucket_msd<256, BIG_VCAP, decltype(pk)::value, WS, HiT>), dim3(vt32), dim3(256), 0, c->stream, vlist.get(), vtot_d.get(), s_lo.get(), sh, P.SB,
+                               v_count.get(), v_kind.get(), retry.get(), retry_n.get(), MergeArgs{});
+        };
+        if constexpr (!WS) { if (P.SB + PK_BITS <= 64) sort(std::true_type()); else sort(std::false_type()); }
+        else sort(std::false_type());
+        hipLaunchKernelGGL((k_big_collect<WS, HiT>), dim3(nbig), dim3(256), 0, c->stream, d_list, d_list_n, vb.get(), vlist.get(), v_count.get(), s_lo.get(), s_hi.get(), a_lo, a_hi,
+                           nr.cnt.get(), nr.kind.get(), fb.get(), fb_n.get());
+        CBLX_HIP(hipGetLastError());
+        CBLX_HIP(hipStreamSynchronize(c->stream));  // scratch dies here
+    }
+    const u32 nfb = d2h<u32>(c, fb_n.get());
+    huge_stage<C>(c, fb.get(), fb_n.get(), nfb, a_lo, a_hi, nr, ma);
+}
+
 // KRN-3 over the runs of `nr` (run of a prefix = [its resident suffixes as stored][the new words in stream order]) in the
 // arena a_lo / a_hi: per-bucket dedup / sort by size class; fills nr.cnt, nr.kind, nr.count. `old` = the resident index
 // the runs were built against (tells which buckets are untouched and which are Tries already).
@@ -251,26 +312,10 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, ty
         const u32 nretry = (ln[CLS_M16] || ln[CLS_M64] || ln[CLS_M128] || ln[CLS_M256] || ln[CLS_M512]) ? d2h<u32>(c, retry_n.get()) : 0u;
         if (nretry)
             hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(nretry), dim3(512), 0, c->stream, retry.get(), retry_n.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
-        if constexpr (!C::WS) if (ln[CLS_M1024])  // 128-bit suffixes: 8192 keys + indices exceed the 160 KiB LDS, such runs go to the huge path
-            hipLaunchKernelGGL((k_bucket_medium<1024, C::WS, HiT>), dim3(ln[CLS_M1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)CLS_M1024 * nb,
-                               list_n.get() + CLS_M1024, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
         CBLX_HIP(hipStreamSynchronize(c->stream));  // retry buffers die here
     }
-    if (ln[CLS_HUGE]) {
-        StageTimer t(c, ST_BHUGE);
-        const u32 nh = ln[CLS_HUGE];
-        std::vector<BDesc> hl = d2h_vec<BDesc>(c, lists.get() + (size_t)CLS_HUGE * nb, nh);
-        std::vector<u64> so(nh);
-        u64 tot = 0;
-        for (u32 i = 0; i < nh; ++i) { so[i] = tot; tot += hl[i].c & ~BDESC_TRIE; }
-        Buf<u64> d_so(c->pool, nh), s_alo(c->pool, tot), s_blo(c->pool, tot), s_ahi(c->pool, C::WS ? tot : 1), s_bhi(c->pool, C::WS ? tot : 1);
-        Buf<u32> s_aidx(c->pool, tot), s_bidx(c->pool, tot);
-        h2d(c, d_so.get(), so.data(), nh);
-        hipLaunchKernelGGL((k_bucket_huge<C::WS, HiT>), dim3(nh), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE,
-                           d_so.get(), a_lo, a_hi, P.SB, s_alo.get(), s_ahi.get(), s_aidx.get(), s_blo.get(), s_bhi.get(),
-                           s_bidx.get(), nr.cnt.get(), nr.kind.get(), MergeArgs{});
-        CBLX_HIP(hipStreamSynchronize(c->stream));
-    }
+    big_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], a_lo, a_hi, nr, MergeArgs{});
+    huge_stage<C>(c, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE, ln[CLS_HUGE], a_lo, a_hi, nr, MergeArgs{});
     }
     CBLX_HIP(hipGetLastError());
     {
@@ -883,21 +928,8 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
         CBLX_HIP(hipGetLastError());
         CBLX_HIP(hipStreamSynchronize(c->stream));  // retry buffers die here
     }
-    if (ln[CLS_HUGE]) {
-        StageTimer t(c, ST_BHUGE);
-        const u32 nh = ln[CLS_HUGE];
-        std::vector<BDesc> hl = d2h_vec<BDesc>(c, lists.get() + (size_t)CLS_HUGE * nb, nh);
-        std::vector<u64> so(nh);
-        u64 tot = 0;
-        for (u32 i = 0; i < nh; ++i) { so[i] = tot; tot += hl[i].c & ~BDESC_TRIE; }
-        Buf<u64> d_so(c->pool, nh), s_alo(c->pool, tot), s_blo(c->pool, tot), s_ahi(c->pool, WS ? tot : 1), s_bhi(c->pool, WS ? tot : 1);
-        Buf<u32> s_aidx(c->pool, tot), s_bidx(c->pool, tot);
-        h2d(c, d_so.get(), so.data(), nh);
-        hipLaunchKernelGGL((k_bucket_huge<WS, HiT>), dim3(nh), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE, d_so.get(), a_lo, a_hi,
-                           P.SB, s_alo.get(), s_ahi.get(), s_aidx.get(), s_blo.get(), s_bhi.get(), s_bidx.get(), nr.cnt.get(), nr.kind.get(), ma);
-        CBLX_HIP(hipGetLastError());
-        CBLX_HIP(hipStreamSynchronize(c->stream));
-    }
+    big_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], a_lo, a_hi, nr, ma);
+    huge_stage<C>(c, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE, ln[CLS_HUGE], a_lo, a_hi, nr, ma);
     {
         Buf<u64> total(c->pool, 1);
         CBLX_HIP(hipMemsetAsync(total.get(), 0, 8, c->stream));

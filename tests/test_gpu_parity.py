@@ -182,6 +182,50 @@ def test_threshold_and_big_buckets(k, pb, n, canonical):
     assert 1 in kinds
 
 
+@pytest.mark.parametrize("k,pb,nreads,L,canonical", [(31, 10, 30000, 150, False), (31, 6, 20000, 150, True), (59, 12, 12000, 250, False), (25, 8, 30000, 150, False),
+                                                    (15, 4, 40000, 100, False)])
+def test_deep_buckets_take_the_split_path(k, pb, nreads, L, canonical):
+    """Runs of 4097 .. 262144 words (what one rank of an 8-GPU job holds per prefix at PREFIX_BITS = 24): split by the top
+    suffix bits in scratch, sub-ranges sorted by the counting-sort kernel, collected in order (k_big_*). Build, incremental
+    insert on top, every read twice (a big run that must STAY a Vec falls back to the general kernel), and `|=` of two such
+    indexes (Trie |= Trie through the same path) — all byte-identical to the oracle."""
+    _need_gpu()
+    hb, ho = synth.reads(61, nreads, L)
+    g, o = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
+    g.insert_seqs(hb, ho)
+    o.insert_seqs(hb, ho)
+    _check_index(g, o)
+    _p, ln, kind = g.bucket_table_np()
+    assert ln.max() > 4096 and kind.max() == 1, "shape does not reach the big path"
+    hb2, ho2 = synth.reads(62, nreads // 3, L)
+    g.insert_seqs(hb2, ho2)  # resident Tries + new words: big runs again
+    o.insert_seqs(hb2, ho2)
+    _check_index(g, o)
+    g.insert_seqs(hb, ho)    # everything again: no change
+    o.insert_seqs(hb, ho)
+    _check_index(g, o)
+    assert g.validate() == 0
+    g2, o2 = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
+    hb3, ho3 = synth.reads(63, nreads, L)
+    g2.insert_seqs(hb3, ho3)
+    g2.insert_seqs(hb, ho[: nreads // 4 + 1])  # a shared part
+    o2.insert_seqs(hb3, ho3)
+    o2.insert_seqs(hb, ho[: nreads // 4 + 1])
+    g |= g2
+    o.merge(o2)
+    _check_index(g, o)
+    _check_index(g2, o2)
+    # few distinct words repeated many times: the run is long, the bucket stays a Vec (first-occurrence order)
+    rng = random.Random(5)
+    motif = [_rand_seq(rng, k + 40) for _ in range(6)]
+    seqs = [motif[i % 6] for i in range(3000)]
+    d, od = cbl_amd.CBL(k, 2, canonical=canonical), Oracle(k, 2, canonical)
+    for sq in seqs:
+        d.insert_seq(sq)
+        od.insert_seq(sq)
+    _check_index(d, od)
+
+
 def test_duplicate_heavy_reads_keep_first_occurrence_order():
     """30x coverage of a small genome: every k-mer arrives many times; Vec buckets must keep stream order."""
     _need_gpu()
