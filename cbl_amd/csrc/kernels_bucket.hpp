@@ -140,6 +140,8 @@ struct BDesc {
     u32 r;      // bucket rank
 };
 static const u32 BDESC_TRIE = 0x80000000u;
+// sub-ranges of a big run (k_big_split) tell the sort kernel how many leading suffix bits all their words share: bits 27..30
+static const u32 BDESC_SKIP_SHIFT = 27, BDESC_SKIP_MASK = 15u << 27, BDESC_LEN_MASK = (1u << 27) - 1u;
 
 // Slot of this thread in the list of class `cls` (cls < 0: none). The lanes of a class take consecutive slots; ONE atomic
 // per (workgroup, class) reserves them (per-wave atomics on the handful of list counters were the whole cost of the
@@ -710,6 +712,16 @@ template <bool WS> __device__ __forceinline__ u32 sfx_top_bits(const Sfx<WS>& k,
         return (u32)(k.lo >> (SB - nbits));
     }
 }
+// the nbits below the top `skip` suffix bits (skip + nbits <= SB, nbits <= 16)
+template <bool WS> __device__ __forceinline__ u32 sfx_bits_below(const Sfx<WS>& k, u32 SB, u32 skip, u32 nbits) {
+    const u32 sh = SB - skip - nbits;
+    if constexpr (WS) {
+        const u128 v = ((u128)k.hi << 64) | k.lo;
+        return (u32)(v >> sh) & ((1u << nbits) - 1u);
+    } else {
+        return (u32)(k.lo >> sh) & ((1u << nbits) - 1u);
+    }
+}
 // Sub-bucket of a bucket that can only end up a Vec (run length <= threshold, not a Trie yet): any function of the suffix
 // will do, and a hash of ALL its bits spreads what the top bits do not — consecutive k-mers of a read tend to share the
 // leading bits of their necklace, prefix and top suffix bits alike (the locality CBL is built on).
@@ -765,7 +777,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     const BDesc dsc = list[blockIdx.x];
     const u32 r = dsc.r;
     const u64 s0 = dsc.start;
-    const u32 c = dsc.c & ~BDESC_TRIE;
+    const u32 c = dsc.c & BDESC_LEN_MASK;
+    const u32 skip = (dsc.c & BDESC_SKIP_MASK) >> BDESC_SKIP_SHIFT;  // leading suffix bits shared by the whole run (sub-range of a big run)
     const bool res_trie = (dsc.c & BDESC_TRIE) != 0;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     if (c == 0) {  // an empty sub-range of a big run (k_big_split)
@@ -775,7 +788,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     const u32 R = (c + THREADS - 1) / THREADS;
     const u32 EPW = 64 * R;  // wave-contiguous slices: ballots then compact in stream order
     u32 nbits = 32 - __builtin_clz(c - 1 > 0 ? c - 1 : 1);  // ceil(log2 c)
-    if (nbits > SB) nbits = SB;
+    if (nbits > SB - skip) nbits = SB - skip;
     const u32 NB = 1u << nbits;  // <= CAP because c <= CAP
     // `self |= other` (mg.cs set): the run is [self's suffixes][other's], both parts distinct; every outcome needs the sorted
     // order, so the sub-buckets are always by the top bits
@@ -798,7 +811,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        sub[j] = vec_only ? sfx_hash_bits<WS>(key[j], nbits) : sfx_top_bits<WS>(key[j], SB, nbits);
+        sub[j] = vec_only ? sfx_hash_bits<WS>(key[j], nbits) : sfx_bits_below<WS>(key[j], SB, skip, nbits);
         arr[j] = 0;
         if (valid[j]) arr[j] = atomicAdd(&s_off32[sub[j] >> 1], 1u << ((sub[j] & 1u) * 16u));  // raw dword; the field is cut out below
     }
@@ -1131,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_big_split(const BDesc* __restrict__ lis
         // BIG_SENT: not sorted yet (the sort kernel overwrites it). A sub-range the sort kernel cannot take is handed to it as
         // an empty one reporting to a dummy slot, and keeps BIG_SENT - 1.
         const bool fits = hv <= BIG_VCAP;
-        vlist[vb + tid] = BDesc{so + ex, (fits ? hv : 0u) | BDESC_TRIE, fits ? (u32)(vb + tid) : v_dummy};
+        vlist[vb + tid] = BDesc{so + ex, (fits ? hv : 0u) | BDESC_TRIE | (B << BDESC_SKIP_SHIFT), fits ? (u32)(vb + tid) : v_dummy};
         v_count[vb + tid] = fits ? BIG_SENT : BIG_SENT - 1;
     }
     __syncthreads();
