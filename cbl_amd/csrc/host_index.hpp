@@ -198,14 +198,26 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
             std::vector<HostIndex> hb(nh);
             const u64 lo_mask = P.SB >= 64 ? ~0ull : ((1ull << P.SB) - 1ull);
             const u64 hi_mask = WS ? (P.SB >= 128 ? ~0ull : ((1ull << (P.SB - 64)) - 1ull)) : 0ull;
+            // many such buckets (a deep index: one rank of a multi-GPU job at PREFIX_BITS = 24): one download of the tables
+            // instead of four synchronous 4-byte reads per bucket
+            std::vector<u32> all_prefix, all_cnt;
+            std::vector<u8> all_kind;
+            std::vector<u64> all_start;
+            const bool bulk = nh > 64;
+            if (bulk) {
+                all_prefix = d2h_vec<u32>(c, r.prefix.get(), nb);
+                all_cnt = d2h_vec<u32>(c, r.cnt.get(), nb);
+                all_kind = d2h_vec<u8>(c, r.kind.get(), nb);
+                all_start = d2h_vec<u64>(c, r.start.get(), nb);
+            }
             for (size_t i = 0; i < nh; ++i) {
                 const u32 rr = host_r[i];
                 HostIndex& h = hb[i];
-                h.prefix = {d2h<u32>(c, r.prefix.get() + rr)};
-                h.cnt = {d2h<u32>(c, r.cnt.get() + rr)};
-                h.kind = {d2h<u8>(c, r.kind.get() + rr)};
+                h.prefix = {bulk ? all_prefix[rr] : d2h<u32>(c, r.prefix.get() + rr)};
+                h.cnt = {bulk ? all_cnt[rr] : d2h<u32>(c, r.cnt.get() + rr)};
+                h.kind = {bulk ? all_kind[rr] : d2h<u8>(c, r.kind.get() + rr)};
                 h.off = {0, h.cnt[0]};
-                const u64 st = d2h<u64>(c, r.start.get() + rr);
+                const u64 st = bulk ? all_start[rr] : d2h<u64>(c, r.start.get() + rr);
                 h.lo.resize(h.cnt[0]);
                 xfer(c).d2h_copy(h.lo.data(), a_lo + st, (size_t)h.cnt[0] * 8);
                 for (u64& x : h.lo) x &= lo_mask;
@@ -237,10 +249,17 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
                 for (auto& x : th) x.join();
             }
             if (too_big) return false;  // an entry of 4 GiB or more: the all-host emitter (64-bit sizes) takes the call
-            for (size_t i = 0; i < nh; ++i) {
-                const u32 sz = (u32)host_bytes[i].size();
-                CBLX_HIP(hipMemcpyAsync(size.get() + host_r[i], &sz, 4, hipMemcpyHostToDevice, c->stream));
-                CBLX_HIP(hipStreamSynchronize(c->stream));  // `sz` is a stack variable
+            if (bulk) {  // the size table goes down, gets its host-emitted entries, and comes back: two copies instead of nh
+                std::vector<u32> sz = d2h_vec<u32>(c, size.get(), nb);
+                for (size_t i = 0; i < nh; ++i) sz[host_r[i]] = (u32)host_bytes[i].size();
+                h2d(c, size.get(), sz.data(), nb);
+                CBLX_HIP(hipStreamSynchronize(c->stream));
+            } else {
+                for (size_t i = 0; i < nh; ++i) {
+                    const u32 sz = (u32)host_bytes[i].size();
+                    CBLX_HIP(hipMemcpyAsync(size.get() + host_r[i], &sz, 4, hipMemcpyHostToDevice, c->stream));
+                    CBLX_HIP(hipStreamSynchronize(c->stream));  // `sz` is a stack variable
+                }
             }
         }
         buckets(std::false_type(), nullptr);
@@ -255,8 +274,10 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
         hipLaunchKernelGGL((k_serde_tiny<WS, true>), grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
                            P.SB, P.BYTES, size.get(), off.get(), body, (u32*)nullptr, (u32*)nullptr);
         buckets(std::true_type(), body);
+        std::vector<u64> all_off;
+        if (host_r.size() > 64) all_off = d2h_vec<u64>(c, off.get(), nb);
         for (size_t i = 0; i < host_r.size(); ++i) {
-            const u64 o = d2h<u64>(c, off.get() + host_r[i]);
+            const u64 o = all_off.empty() ? d2h<u64>(c, off.get() + host_r[i]) : all_off[host_r[i]];
             xfer(c).h2d_copy(body + o, host_bytes[i].data(), host_bytes[i].size());
         }
         if (!host_r.empty()) xfer(c).sync();
