@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--prefix-bits", type=int, default=24)
     ap.add_argument("--merge", action="store_true")
+    ap.add_argument("--serialize", action="store_true", help="also time the serialized size and the index bytes into a host buffer")
     a = ap.parse_args()
     out = {"config": vars(a)}
     g, bounds, ts, tr, nw = build_share(a.k, a.prefix_bits, a.world, a.rank, a.reads, a.read_len, 42)
@@ -70,6 +71,14 @@ def main():
                     "bucket_len_max": int(ln.max()), "share_over_4096": float(ln[ln > 4096].sum() / ln.sum()), "share_over_8192": float(ln[ln > 8192].sum() / ln.sum()),
                     "senders_ms_total": ts * 1e3, "receiver_ms": tr * 1e3, "receiver_stage_ms": {n: round(ms, 3) for n, (ms, _) in g.stage_times().items() if ms > 0},
                     "validate": g.validate()}
+    if a.serialize:
+        t0 = time.perf_counter()
+        nbytes = g.serialized_size()
+        t1 = time.perf_counter()
+        blob = g.serialize_np()
+        t2 = time.perf_counter()
+        out["serialize"] = {"bytes": int(nbytes), "size_s": round(t1 - t0, 3), "bytes_to_host_s": round(t2 - t1, 3)}
+        del blob
     if a.merge:
         h, _, _, _, _ = build_share(a.k, a.prefix_bits, a.world, a.rank, a.reads, a.read_len, 43, bounds=bounds, profile=False)
         work = cbl_amd.CBL(a.k, a.prefix_bits, profile=True)
