@@ -165,6 +165,24 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
     std::vector<u32> ln(SER_NCLS, 0), host_r;
     std::vector<std::vector<u8>> host_bytes;
     const u64 *a_lo = r.a_lo.get(), *a_hi = WS ? r.a_hi.get() : (const u64*)nullptr;
+    u32 nsplit = 0;
+    Buf<u64> vstart, voff;
+    Buf<u32> vcnt, vsize, vlists, vlist_n, split_bad;
+    std::vector<u32> vln(3, 0);
+    auto sub_buckets = [&](auto em, u8* outp) {  // the sub-ranges of split Tries: sizes (em = false) or bytes at body + voff
+        constexpr bool EM = decltype(em)::value;
+        const u64 nv = (u64)nsplit * 256;
+        if (vln[0])
+            hipLaunchKernelGGL((k_serde_bucket<64, 16, WS, EM, true>), dim3(vln[0]), dim3(64), 0, c->stream, vlists.get(), vlist_n.get(), (const u32*)nullptr, vstart.get(), vcnt.get(),
+                               (const u8*)nullptr, a_lo, a_hi, P.SB, P.BYTES, vsize.get(), voff.get(), outp);
+        if (vln[1])
+            hipLaunchKernelGGL((k_serde_bucket<256, 16, WS, EM, true>), dim3(vln[1]), dim3(256), 0, c->stream, vlists.get() + nv, vlist_n.get() + 1, (const u32*)nullptr, vstart.get(),
+                               vcnt.get(), (const u8*)nullptr, a_lo, a_hi, P.SB, P.BYTES, vsize.get(), voff.get(), outp);
+        if (vln[2])
+            hipLaunchKernelGGL((k_serde_bucket<1024, 8, WS, EM, true>), dim3(vln[2]), dim3(1024), 0, c->stream, vlists.get() + 2 * nv, vlist_n.get() + 2, (const u32*)nullptr, vstart.get(),
+                               vcnt.get(), (const u8*)nullptr, a_lo, a_hi, P.SB, P.BYTES, vsize.get(), voff.get(), outp);
+        CBLX_HIP(hipGetLastError());
+    };
     auto buckets = [&](auto em, u8* body) {
         constexpr bool EM = decltype(em)::value;
         if (ln[SER_C64])
@@ -188,6 +206,29 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
                            P.SB, P.BYTES, size.get(), (const u64*)nullptr, (u8*)nullptr, lists.get(), list_n.get());
         CBLX_HIP(hipGetLastError());
         ln = d2h_vec<u32>(c, list_n.get(), SER_NCLS);
+        if (ln[SER_SPLIT]) {
+            // long Tries, cut at the root: sub-ranges by top byte ("virtual buckets"), sized here by the workgroup kernels
+            nsplit = ln[SER_SPLIT];
+            const u64 nv = (u64)nsplit * 256;
+            vstart = Buf<u64>(c->pool, nv);
+            voff = Buf<u64>(c->pool, nv);
+            vcnt = Buf<u32>(c->pool, nv);
+            vsize = Buf<u32>(c->pool, nv);
+            vlists = Buf<u32>(c->pool, 3 * nv);
+            vlist_n = Buf<u32>(c->pool, 3);
+            split_bad = Buf<u32>(c->pool, nsplit);
+            CBLX_HIP(hipMemsetAsync(vlist_n.get(), 0, 12, c->stream));
+            hipLaunchKernelGGL((k_serde_split_plan<WS>), dim3(nsplit), dim3(256), 0, c->stream, lists.get() + (size_t)SER_SPLIT * nb, list_n.get() + SER_SPLIT, r.start.get(),
+                               r.cnt.get(), a_lo, a_hi, P.SB, P.BYTES, nb, vstart.get(), vcnt.get(), vsize.get(), vlists.get(), nv, vlist_n.get(), split_bad.get(),
+                               lists.get() + (size_t)SER_HOST * nb, list_n.get() + SER_HOST);
+            CBLX_HIP(hipGetLastError());
+            ln = d2h_vec<u32>(c, list_n.get(), SER_NCLS);  // the plan may have handed buckets to the host emitter
+            vln = d2h_vec<u32>(c, vlist_n.get(), 3);
+            sub_buckets(std::false_type(), nullptr);
+            hipLaunchKernelGGL(k_serde_split_size, dim3(nsplit), dim3(256), 0, c->stream, lists.get() + (size_t)SER_SPLIT * nb, list_n.get() + SER_SPLIT, r.prefix.get(), r.cnt.get(),
+                               vcnt.get(), vsize.get(), split_bad.get(), size.get());
+            CBLX_HIP(hipGetLastError());
+        }
         if (ln[SER_HOST]) {
             // Buckets longer than one workgroup's emitter takes (low-complexity k-mers, tiny PREFIX_BITS): their entries
             // are emitted by host threads from a download of just those buckets and patched into the device-emitted
@@ -274,6 +315,12 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
         hipLaunchKernelGGL((k_serde_tiny<WS, true>), grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
                            P.SB, P.BYTES, size.get(), off.get(), body, (u32*)nullptr, (u32*)nullptr);
         buckets(std::true_type(), body);
+        if (nsplit) {  // split Tries: header / root / length by one kernel, then every sub-trie at its absolute offset (voff is relative to the blob)
+            hipLaunchKernelGGL(k_serde_split_emit, dim3(nsplit), dim3(256), 0, c->stream, lists.get() + (size_t)SER_SPLIT * nb, list_n.get() + SER_SPLIT, r.prefix.get(), r.cnt.get(),
+                               vcnt.get(), vsize.get(), split_bad.get(), off.get(), voff.get(), body);
+            CBLX_HIP(hipGetLastError());
+            sub_buckets(std::true_type(), body);
+        }
         std::vector<u64> all_off;
         if (host_r.size() > 64) all_off = d2h_vec<u64>(c, off.get(), nb);
         for (size_t i = 0; i < host_r.size(); ++i) {

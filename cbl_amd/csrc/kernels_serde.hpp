@@ -53,7 +53,12 @@ template <bool WS> __device__ __forceinline__ u32 top_diff_byte(const Sfx<WS>& a
     return (63u - (u32)__builtin_clzll(a.lo ^ b.lo)) / 8u;
 }
 
-enum { SER_C64 = 0, SER_C256 = 1, SER_C1024 = 2, SER_HOST = 3, SER_NCLS = 4 };
+enum { SER_C64 = 0, SER_C256 = 1, SER_C1024 = 2, SER_HOST = 3, SER_SPLIT = 4, SER_NCLS = 5 };
+// A Trie longer than one workgroup takes (SER_CAP1024) is cut at its ROOT: the children of the root are the distinct top bytes,
+// the sub-trie under each is the trie of the (contiguous, sorted) sub-range that shares the byte, and pre-order puts the
+// sub-tries one after the other behind the root's header — so every sub-range of <= SER_CAP1024 words is emitted by the same
+// workgroup kernel started at level 1 ("virtual bucket"), and the entry is header | root | sub-tries | varint(len).
+static const u32 SER_SPLIT_MAX = 1u << 21;
 static const u32 SER_CAP64 = 64 * 16, SER_CAP256 = 256 * 16, SER_CAP1024 = 1024 * 8;  // bucket lengths per workgroup shape
 static const u32 SER_TINY = 32;  // Vec buckets up to this length are written by one thread each
 
@@ -90,30 +95,34 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_serde_tiny(u64 nb, const u
     }
     if constexpr (!EMIT) {
         int cls = -1;
-        if (live && !tiny) cls = n <= SER_CAP64 ? SER_C64 : n <= SER_CAP256 ? SER_C256 : n <= SER_CAP1024 ? SER_C1024 : SER_HOST;
+        if (live && !tiny)
+            cls = n <= SER_CAP64 ? SER_C64 : n <= SER_CAP256 ? SER_C256 : n <= SER_CAP1024 ? SER_C1024 : (kind[r] == KIND_TRIE && n <= SER_SPLIT_MAX && BYTES > 1) ? SER_SPLIT : SER_HOST;
         const u32 slot = block_append<CLASSIFY_THREADS, SER_NCLS>(cls, list_n);
         if (cls >= 0) lists[(u64)cls * nb + slot] = (u32)r;
     }
 }
 
 // One workgroup per listed bucket (n <= THREADS * ITEMS).
-template <int THREADS, int ITEMS, bool WS, bool EMIT>
+// SUB: the listed ids are sub-ranges of split Tries (start / cnt = the sub-range's arena start and length, `size` / `off` its
+// own byte size and absolute output offset): levels 1.. of the sub-range only, no entry header, no length field.
+template <int THREADS, int ITEMS, bool WS, bool EMIT, bool SUB = false>
 __global__ __launch_bounds__(THREADS) void k_serde_bucket(const u32* __restrict__ list, const u32* __restrict__ list_n, const u32* __restrict__ prefix,
                                                           const u64* __restrict__ start, const u32* __restrict__ cnt, const u8* __restrict__ kind,
                                                           const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u32 SB, u32 BYTES,
                                                           u32* __restrict__ size, const u64* __restrict__ off, u8* __restrict__ out) {
     constexpr int NW = THREADS / 64, EPW = 64 * ITEMS, CAP = THREADS * ITEMS;
+    constexpr u32 D0 = SUB ? 1u : 0u;            // first level this workgroup emits
     __shared__ u32 s_wtot[NW + 1];
     __shared__ u16 s_ns[CAP + 2];                // X_d at the start of node k (+ sentinel)
     __shared__ u32 s_np[EMIT ? CAP : 1];         // where node k's child bytes start (relative to the entry)
     if (blockIdx.x >= *list_n) return;
     const u32 r = list[blockIdx.x];
-    const u32 n = cnt[r], pfx = prefix[r];
+    const u32 n = cnt[r], pfx = SUB ? 0u : prefix[r];
     const u64 s0 = start[r];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const u32 hdr = vlen(pfx) + 1;
+    const u32 hdr = SUB ? 0u : vlen(pfx) + 1;
     u8* o = EMIT ? out + off[r] : nullptr;
-    if (kind[r] == KIND_VEC) {                   // varint(n) then n x (varint(BYTES) | BYTES little-endian bytes), stored order
+    if (!SUB && kind[r] == KIND_VEC) {           // varint(n) then n x (varint(BYTES) | BYTES little-endian bytes), stored order
         if constexpr (!EMIT) {
             if (tid == 0) size[r] = hdr + vlen(n) + n * (1 + BYTES);
         } else {
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(THREADS) void k_serde_bucket(const u32* __restrict_
         if constexpr (WS) x[i].hi = 0;
         if (e < n) {
             x[i] = arena_sfx<WS>(a_lo, a_hi, s0 + e, SB);
-            if (e == 0) lcp[i] = -1;
+            if (e == 0) lcp[i] = (int)D0 - 1;   // the first word opens a node at every level this workgroup emits
             else {
                 const Sfx<WS> p = arena_sfx<WS>(a_lo, a_hi, s0 + e - 1, SB);
                 lcp[i] = (int)(BYTES - 1) - (int)top_diff_byte<WS>(x[i], p);
@@ -172,9 +181,9 @@ __global__ __launch_bounds__(THREADS) void k_serde_bucket(const u32* __restrict_
         bool tprev[ITEMS], tcur[ITEMS];
         u32 xprev[ITEMS], xcur[ITEMS];
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) tprev[i] = lcp[i] < 0;
-        u32 nodes = rank_flags(tprev, xprev);  // level 0: the root
-        for (u32 d = 0; d < BYTES; ++d) {
+        for (int i = 0; i < ITEMS; ++i) tprev[i] = lcp[i] < (int)D0;
+        u32 nodes = rank_flags(tprev, xprev);  // level D0: the root (of the sub-range)
+        for (u32 d = D0; d < BYTES; ++d) {
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) tcur[i] = lcp[i] <= (int)d;
             const u32 tot = rank_flags(tcur, xcur);
@@ -233,14 +242,100 @@ __global__ __launch_bounds__(THREADS) void k_serde_bucket(const u32* __restrict_
 #pragma unroll
     for (int ww = 0; ww < NW; ++ww) { const u32 t = s_wtot[ww]; if ((u32)ww < w) wbase += t; total += t; }
     if constexpr (!EMIT) {
-        if (tid == 0) size[r] = hdr + total + vlen(n);
+        if (tid == 0) size[r] = SUB ? total : hdr + total + vlen(n);
     } else {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) { base[i] += wbase + hdr; E[i] = 0; }
-        if (tid == 0) { put_varint(o, pfx); o[hdr - 1] = 1; put_varint(o + hdr + total, n); }  // TrieOrVec::Trie(.., len)
+        if constexpr (!SUB) if (tid == 0) { put_varint(o, pfx); o[hdr - 1] = 1; put_varint(o + hdr + total, n); }  // TrieOrVec::Trie(.., len)
         levels(std::true_type(), E, base);
     }
+}
+
+// ---- split Tries: plan (children of the root = sub-ranges), size, emit of header / root / length ----------------------------
+// One workgroup per split bucket, thread t = top byte value t: the sub-range [lower_bound(t), lower_bound(t + 1)). Sub-ranges
+// go to the list of their workgroup shape; a bucket with a sub-range no shape takes is handed to the host emitter.
+template <bool WS>
+__global__ __launch_bounds__(256) void k_serde_split_plan(const u32* __restrict__ list, const u32* __restrict__ list_n, const u64* __restrict__ start,
+                                                          const u32* __restrict__ cnt, const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u32 SB,
+                                                          u32 BYTES, u64 nb, u64* __restrict__ vstart, u32* __restrict__ vcnt, u32* __restrict__ vsize,
+                                                          u32* __restrict__ vlists, u64 vcap, u32* __restrict__ vlist_n, u32* __restrict__ bad,
+                                                          u32* __restrict__ host_list, u32* __restrict__ host_n) {
+    __shared__ u32 s_lb[257];
+    __shared__ u32 s_bad;
+    const u32 i = blockIdx.x, t = threadIdx.x;
+    int cls = -1;
+    if (i < *list_n) {
+        const u32 r = list[i], n = cnt[r];
+        const u64 s0 = start[r];
+        u32 lo = 0, hi = n;  // first element whose top byte is >= t
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (sfx_byte_le<WS>(arena_sfx<WS>(a_lo, a_hi, s0 + mid, SB), BYTES - 1) < t) lo = mid + 1; else hi = mid;
+        }
+        s_lb[t] = lo;
+        if (t == 0) { s_lb[256] = n; s_bad = 0; }
+        __syncthreads();
+        const u32 c = s_lb[t + 1] - s_lb[t];
+        const u64 v = (u64)i * 256 + t;
+        vstart[v] = s0 + s_lb[t];
+        vcnt[v] = c;
+        vsize[v] = 0;
+        if (c > SER_CAP1024) atomicOr(&s_bad, 1u);
+        __syncthreads();
+        if (s_bad) {
+            if (t == 0) { bad[i] = 1; host_list[atomicAdd(host_n, 1u)] = r; }
+        } else {
+            if (t == 0) bad[i] = 0;
+            if (c) cls = c <= SER_CAP64 ? 0 : c <= SER_CAP256 ? 1 : 2;
+        }
+    }
+    const u32 slot = block_append<256, 3>(cls, vlist_n);
+    if (cls >= 0) vlists[(u64)cls * vcap + slot] = (u32)((u64)i * 256 + t);
+    (void)nb;
+}
+// size of a split entry: header | varint(c0) c0 bytes varint(c0) | sub-tries | varint(n)
+__global__ __launch_bounds__(256) void k_serde_split_size(const u32* __restrict__ list, const u32* __restrict__ list_n, const u32* __restrict__ prefix,
+                                                          const u32* __restrict__ cnt, const u32* __restrict__ vcnt, const u32* __restrict__ vsize,
+                                                          const u32* __restrict__ bad, u32* __restrict__ size) {
+    __shared__ u32 s_scan[256 / 64 + 1];
+    const u32 i = blockIdx.x, t = threadIdx.x;
+    if (i >= *list_n || bad[i]) return;  // a bad one is sized by the host emitter
+    const u64 v = (u64)i * 256 + t;
+    u32 tot_c, tot_s;
+    (void)block_exclusive_scan<256, u32>(vcnt[v] ? 1u : 0u, s_scan, &tot_c);
+    (void)block_exclusive_scan<256, u32>(vsize[v], s_scan, &tot_s);
+    if (t == 0) {
+        const u32 r = list[i];
+        size[r] = vlen(prefix[r]) + 1 + vlen(tot_c) + tot_c + vlen(tot_c) + tot_s + vlen(cnt[r]);
+    }
+}
+// header, root node and length field of a split entry; absolute output offset of every sub-trie
+__global__ __launch_bounds__(256) void k_serde_split_emit(const u32* __restrict__ list, const u32* __restrict__ list_n, const u32* __restrict__ prefix,
+                                                          const u32* __restrict__ cnt, const u32* __restrict__ vcnt, const u32* __restrict__ vsize,
+                                                          const u32* __restrict__ bad, const u64* __restrict__ off, u64* __restrict__ voff,
+                                                          u8* __restrict__ out) {
+    __shared__ u32 s_scan[256 / 64 + 1];
+    const u32 i = blockIdx.x, t = threadIdx.x;
+    if (i >= *list_n || bad[i]) return;
+    const u32 r = list[i];
+    const u64 v = (u64)i * 256 + t;
+    const bool present = vcnt[v] != 0;
+    u32 c0, tot_s;
+    const u32 rk = block_exclusive_scan<256, u32>(present ? 1u : 0u, s_scan, &c0);
+    const u32 so = block_exclusive_scan<256, u32>(vsize[v], s_scan, &tot_s);
+    const u32 pfx = prefix[r], hdr = vlen(pfx) + 1;
+    u8* o = out + off[r];
+    const u32 root = vlen(c0) + c0 + vlen(c0);
+    if (t == 0) {
+        put_varint(o, pfx);
+        o[hdr - 1] = 1;  // TrieOrVec::Trie
+        put_varint(o + hdr, c0);
+        put_varint(o + hdr + vlen(c0) + c0, c0);
+        put_varint(o + hdr + root + tot_s, cnt[r]);
+    }
+    if (present) o[hdr + vlen(c0) + rk] = (u8)t;
+    voff[v] = off[r] + hdr + root + so;
 }
 
 }  // namespace cblx
