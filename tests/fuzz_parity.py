@@ -45,94 +45,104 @@ def main():
         for step in range(rng.randint(1, 5)):
             op = rng.choice(["seq", "seqs", "seqs", "merge", "roundtrip", "sorted", "kmers", "query", "file"])
             ops.append(op)
-            if op == "seq":
-                for _ in range(rng.randint(1, 5)):
-                    s = rand_seq(rng, rng.randint(k, k + rng.choice([0, 1, 5, 300, 5000])), alphabet)
-                    g.insert_seq(s), o.insert_seq(s)
-            elif op == "seqs":
-                seqs = [rand_seq(rng, rng.randint(k, k + rng.choice([0, 3, 100, 2500])), alphabet) for _ in range(rng.randint(1, 60))]
-                bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
-                offsets = np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64)
-                g.insert_seqs(bases, offsets), o.insert_seqs(bases, offsets)
-                if rng.random() < 0.5:
-                    g.flush()
-            elif op == "merge":
-                g2, o2 = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
-                for _ in range(rng.randint(1, 20)):
-                    s = rand_seq(rng, rng.randint(k, k + 2000), alphabet)
-                    g2.insert_seq(s), o2.insert_seq(s)
-                g |= g2
-                o.merge(o2)
-                assert g2.serialize() == o2.serialize(), desc + " (other after |=) " + str(ops)
-            elif op == "roundtrip":
-                blob = g.serialize()
-                assert blob == o.serialize(), desc + " (before round trip) " + str(ops)
-                g = cbl_amd.CBL(k, pb, canonical=canonical)
-                g.load(blob)
-            elif op == "kmers":  # single-k-mer inserts: return values and final state
-                pool = [rng.getrandbits(2 * k) for _ in range(rng.randint(1, 200))]
-                batch = [rng.choice(pool) for _ in range(rng.randint(1, 400))]
-                got = g.insert_kmers(batch).tolist()
-                assert got == [o.insert_kmer(x) for x in batch], desc + " (insert_kmers) " + str(ops)
-                probe = batch[:50] + [rng.getrandbits(2 * k) for _ in range(50)]
-                assert g.contains_kmers(probe).tolist() == [o.contains_kmer(x) for x in probe], desc + " (contains_kmers) " + str(ops)
-            elif op == "query":
-                seqs = [rand_seq(rng, rng.randint(k, k + rng.choice([0, 7, 500, 3000])), alphabet) for _ in range(rng.randint(1, 30))]
-                bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
-                offsets = np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64)
-                flags, tot, pos = g.contains_seqs(bases, offsets)
-                want = [o.contains_word(w) for s in seqs for w in o.seq_words(s)]
-                assert flags.tolist() == want and tot == len(want) and pos == sum(want), desc + " (query) " + str(ops)
-                assert g.contains_seqs(bases, offsets, flags=False)[1:] == (tot, pos), desc + " (query by join) " + str(ops)
-                if rng.random() < 0.3:
-                    assert [o.kmer_of_word(w) for w in o.iter_words()] == list(g.iter()), desc + " (iter) " + str(ops)
-            elif op == "file":  # FASTA in (multi-line, mixed case), index file out and back in, the file query loop
-                import tempfile
+            prev_blob = o.serialize() if os.environ.get("CBLX_FUZZ_DIAG") else None
+            try:
+                if op == "seq":
+                    for _ in range(rng.randint(1, 5)):
+                        s = rand_seq(rng, rng.randint(k, k + rng.choice([0, 1, 5, 300, 5000])), alphabet)
+                        g.insert_seq(s), o.insert_seq(s)
+                elif op == "seqs":
+                    seqs = [rand_seq(rng, rng.randint(k, k + rng.choice([0, 3, 100, 2500])), alphabet) for _ in range(rng.randint(1, 60))]
+                    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+                    offsets = np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64)
+                    g.insert_seqs(bases, offsets), o.insert_seqs(bases, offsets)
+                    if rng.random() < 0.5:
+                        g.flush()
+                elif op == "merge":
+                    g2, o2 = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
+                    for _ in range(rng.randint(1, 20)):
+                        s = rand_seq(rng, rng.randint(k, k + 2000), alphabet)
+                        g2.insert_seq(s), o2.insert_seq(s)
+                    g |= g2
+                    o.merge(o2)
+                    assert g2.serialize() == o2.serialize(), desc + " (other after |=) " + str(ops)
+                elif op == "roundtrip":
+                    blob = g.serialize()
+                    assert blob == o.serialize(), desc + " (before round trip) " + str(ops)
+                    g = cbl_amd.CBL(k, pb, canonical=canonical)
+                    g.load(blob)
+                elif op == "kmers":  # single-k-mer inserts: return values and final state
+                    pool = [rng.getrandbits(2 * k) for _ in range(rng.randint(1, 200))]
+                    batch = [rng.choice(pool) for _ in range(rng.randint(1, 400))]
+                    got = g.insert_kmers(batch).tolist()
+                    assert got == [o.insert_kmer(x) for x in batch], desc + " (insert_kmers) " + str(ops)
+                    probe = batch[:50] + [rng.getrandbits(2 * k) for _ in range(50)]
+                    assert g.contains_kmers(probe).tolist() == [o.contains_kmer(x) for x in probe], desc + " (contains_kmers) " + str(ops)
+                elif op == "query":
+                    seqs = [rand_seq(rng, rng.randint(k, k + rng.choice([0, 7, 500, 3000])), alphabet) for _ in range(rng.randint(1, 30))]
+                    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+                    offsets = np.cumsum([0] + [len(s) for s in seqs]).astype(np.uint64)
+                    flags, tot, pos = g.contains_seqs(bases, offsets)
+                    want = [o.contains_word(w) for s in seqs for w in o.seq_words(s)]
+                    assert flags.tolist() == want and tot == len(want) and pos == sum(want), desc + " (query) " + str(ops)
+                    assert g.contains_seqs(bases, offsets, flags=False)[1:] == (tot, pos), desc + " (query by join) " + str(ops)
+                    if rng.random() < 0.3:
+                        assert [o.kmer_of_word(w) for w in o.iter_words()] == list(g.iter()), desc + " (iter) " + str(ops)
+                elif op == "file":  # FASTA in (multi-line, mixed case), index file out and back in, the file query loop
+                    import tempfile
 
-                seqs = [rand_seq(rng, rng.randint(k, k + rng.choice([0, 9, 400, 2600])), alphabet) for _ in range(rng.randint(1, 25))]
-                with tempfile.TemporaryDirectory() as td:
-                    fa, ix = os.path.join(td, "in.fa"), os.path.join(td, "x.cbl")
-                    width = rng.choice([60, 70, 10_000])
-                    with open(fa, "wb") as f:
-                        for i, sq in enumerate(seqs):
-                            f.write(b">r%d some text\n" % i)
-                            for j in range(0, len(sq), width):
-                                f.write(sq[j : j + width] + (b"\r\n" if width == 70 else b"\n"))
-                    assert g.insert_fastx_file(fa) == len(seqs), desc + " (records) " + str(ops)
-                    for sq in seqs:
-                        o.insert_seq(sq)
-                    g.save_to_file(ix)
-                    with open(ix, "rb") as f:
-                        assert f.read() == o.serialize(), desc + " (index file) " + str(ops)
-                    g = cbl_amd.CBL.load_from_file(ix, k, pb)
-                    want = [o.contains_word(w) for sq in seqs for w in o.seq_words(sq)]
-                    assert g.query_fastx_file(fa) == (len(seqs), len(want), sum(want)), desc + " (file query) " + str(ops)
-                    assert g.contains_all(seqs[0]) == all(o.contains_word(w) for w in o.seq_words(seqs[0])), desc + " (contains_all) " + str(ops)
-                sizes = {}
-                sbits = g.consts()["suffix_bits"]
-                for w in o.iter_words():
-                    sizes[w >> sbits] = sizes.get(w >> sbits, 0) + 1
-                assert g.buckets_sizes() == sorted(sizes.items()), desc + " (buckets_sizes) " + str(ops)
-            elif op == "sorted":
-                seqs = [rand_seq(rng, rng.randint(k, k + 800), b"ACGT") for _ in range(rng.randint(1, 40))]
-                hb = np.frombuffer(b"".join(seqs), dtype=np.uint8)
-                ho = np.cumsum([0] + [len(s) for s in seqs]).astype(np.int64)
-                d_b = torch.from_numpy(np.concatenate([hb, np.zeros(32, np.uint8)])).cuda()
-                d_o = torch.from_numpy(ho).cuda()
-                nd = rng.randint(1, 5)
-                bounds = np.sort(np.array([rng.randrange(1 << pb) for _ in range(nd - 1)], dtype=np.uint32))
-                snd = cbl_amd.CBL(k, pb, canonical=canonical)
-                bs, ws = snd.sorted_batch_begin(d_b, d_o, len(seqs), bounds, nd)
-                B = snd.consts()["bytes"]
-                pfx = torch.empty(max(bs[nd], 1), dtype=torch.int32, device="cuda")
-                cnt = torch.empty(max(bs[nd], 1), dtype=torch.int32, device="cuda")
-                sfx = torch.empty(max(ws[nd] * B, 1), dtype=torch.uint8, device="cuda")
-                snd.sorted_batch_export(pfx, cnt, sfx)
-                batches = [(bs[d + 1] - bs[d], ws[d + 1] - ws[d], pfx[bs[d] : bs[d + 1]], cnt[bs[d] : bs[d + 1]], sfx[ws[d] * B : ws[d + 1] * B])
-                           for d in range(nd) if ws[d + 1] > ws[d]]
-                g.insert_sorted_batches_device(batches)
-                for s in seqs:
-                    o.insert_seq(s)
+                    seqs = [rand_seq(rng, rng.randint(k, k + rng.choice([0, 9, 400, 2600])), alphabet) for _ in range(rng.randint(1, 25))]
+                    with tempfile.TemporaryDirectory() as td:
+                        fa, ix = os.path.join(td, "in.fa"), os.path.join(td, "x.cbl")
+                        width = rng.choice([60, 70, 10_000])
+                        with open(fa, "wb") as f:
+                            for i, sq in enumerate(seqs):
+                                f.write(b">r%d some text\n" % i)
+                                for j in range(0, len(sq), width):
+                                    f.write(sq[j : j + width] + (b"\r\n" if width == 70 else b"\n"))
+                        assert g.insert_fastx_file(fa) == len(seqs), desc + " (records) " + str(ops)
+                        for sq in seqs:
+                            o.insert_seq(sq)
+                        g.save_to_file(ix)
+                        with open(ix, "rb") as f:
+                            assert f.read() == o.serialize(), desc + " (index file) " + str(ops)
+                        g = cbl_amd.CBL.load_from_file(ix, k, pb)
+                        want = [o.contains_word(w) for sq in seqs for w in o.seq_words(sq)]
+                        assert g.query_fastx_file(fa) == (len(seqs), len(want), sum(want)), desc + " (file query) " + str(ops)
+                        assert g.contains_all(seqs[0]) == all(o.contains_word(w) for w in o.seq_words(seqs[0])), desc + " (contains_all) " + str(ops)
+                    sizes = {}
+                    sbits = g.consts()["suffix_bits"]
+                    for w in o.iter_words():
+                        sizes[w >> sbits] = sizes.get(w >> sbits, 0) + 1
+                    assert g.buckets_sizes() == sorted(sizes.items()), desc + " (buckets_sizes) " + str(ops)
+                elif op == "sorted":
+                    seqs = [rand_seq(rng, rng.randint(k, k + 800), b"ACGT") for _ in range(rng.randint(1, 40))]
+                    hb = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+                    ho = np.cumsum([0] + [len(s) for s in seqs]).astype(np.int64)
+                    d_b = torch.from_numpy(np.concatenate([hb, np.zeros(32, np.uint8)])).cuda()
+                    d_o = torch.from_numpy(ho).cuda()
+                    nd = rng.randint(1, 5)
+                    bounds = np.sort(np.array([rng.randrange(1 << pb) for _ in range(nd - 1)], dtype=np.uint32))
+                    snd = cbl_amd.CBL(k, pb, canonical=canonical)
+                    bs, ws = snd.sorted_batch_begin(d_b, d_o, len(seqs), bounds, nd)
+                    B = snd.consts()["bytes"]
+                    pfx = torch.empty(max(bs[nd], 1), dtype=torch.int32, device="cuda")
+                    cnt = torch.empty(max(bs[nd], 1), dtype=torch.int32, device="cuda")
+                    sfx = torch.empty(max(ws[nd] * B, 1), dtype=torch.uint8, device="cuda")
+                    snd.sorted_batch_export(pfx, cnt, sfx)
+                    batches = [(bs[d + 1] - bs[d], ws[d + 1] - ws[d], pfx[bs[d] : bs[d + 1]], cnt[bs[d] : bs[d + 1]], sfx[ws[d] * B : ws[d + 1] * B])
+                               for d in range(nd) if ws[d + 1] > ws[d]]
+                    g.insert_sorted_batches_device(batches)
+                    for s in seqs:
+                        o.insert_seq(s)
+            except cbl_amd.CblxError as e:  # report what led here, and whether the index was still sound before the failing call
+                print("FAIL", desc, ops, "error:", e, file=sys.stderr, flush=True)
+                if prev_blob is not None:
+                    try:
+                        print("  state before the op == oracle's:", g.serialize() == prev_blob, "validate:", g.validate(strict=False), "count", g.count(), file=sys.stderr, flush=True)
+                    except Exception as e2:  # noqa: BLE001
+                        print("  (state not readable:", e2, ")", file=sys.stderr)
+                raise
             assert g.count() == o.count(), desc + f" count after {ops}"
         assert g.serialize() == o.serialize(), desc + " " + str(ops)
         assert g.validate(strict=False) == 0, desc
