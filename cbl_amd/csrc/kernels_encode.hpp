@@ -276,7 +276,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
     // the chunk tables.
     const u32 nk0 = s_koff[1], cs0 = s_cstart[0], len0 = nc > 1 ? s_cstart[1] - s_cstart[0] : 0u;
     bool uni = nk0 != 0 && !(cs0 >> 31);
-    for (u32 i = tid; i < nc; i += ENC_THREADS) uni = uni && s_koff[i + 1] == (i + 1) * nk0 && s_cstart[i] == cs0 + i * len0;
+    // (a dirty chunk carries bit 31 in s_cstart: chunk 1 must be tested for it explicitly, len0 is defined by its start)
+    for (u32 i = tid; i < nc; i += ENC_THREADS) uni = uni && s_koff[i + 1] == (i + 1) * nk0 && s_cstart[i] == cs0 + i * len0 && !(s_cstart[i] >> 31);
     const bool uniform = __syncthreads_and(uni ? 1 : 0) != 0;
 #else
     const bool uniform = false;

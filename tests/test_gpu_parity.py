@@ -120,6 +120,30 @@ def test_words_multichunk_non_acgt_and_degenerate(k, canonical):
     assert _gpu_words(g, seqs) == _oracle_words(o, seqs)
 
 
+def test_dirty_chunk_next_to_clean_ones_of_the_same_shape():
+    """Regression (found by the fuzzer, round 2): the encode kernel's fast path for tiles whose chunks all have one shape
+    must not take a tile whose SECOND chunk holds a non-ACGT byte — that chunk is written by the scalar kernel, and counting
+    it twice in the fused first-pass histogram corrupted the partition of the NEXT insert's batch."""
+    _need_gpu()
+    rng = random.Random(9)
+    for k, pb in ((15, 25), (31, 24), (25, 12)):
+        L = k + 37
+        reads = [_rand_seq(rng, L) for _ in range(40)]
+        # a dirty read with as many k-mers as a clean one: one N in front of the first K bytes' worth... the k-mer count of a
+        # dirty chunk is 1 + valid bytes after the first K, so put the invalid byte among the first K and add one base
+        for pos in (1, 5, 9, 17, 33):
+            r = bytearray(_rand_seq(rng, L + 1))
+            r[2] = ord("N")
+            reads[pos] = bytes(r)
+        g, o = cbl_amd.CBL(k, pb), Oracle(k, pb)
+        for _ in range(3):  # the second and third inserts go through the incremental path
+            bases, offsets = _concat(reads)
+            g.insert_seqs(bases, offsets)
+            o.insert_seqs(bases, offsets)
+            _check_index(g, o)
+            reads = [_rand_seq(rng, L) for _ in range(10)] + reads[:20]
+
+
 def test_short_sequence_rejected():
     _need_gpu()
     g = cbl_amd.CBL(31, 24)
