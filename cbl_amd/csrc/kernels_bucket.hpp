@@ -754,7 +754,9 @@ static const int MSD_TRIP = CBLX_MSD_TRIP;  // sub-bucket entries read per trip 
 #define CBLX_MSD_WAVES 7  // waves per SIMD the register allocation aims at (LDS allows 7 workgroups of the 256-thread class; 76 -> 72 VGPRs: 7.28 -> 7.10 ms)
 #endif
 
-template <int THREADS, int CAP, bool PACKED, bool WS, typename HiT>
+// MERGE: the instantiation `self |= other` launches (its epilogue keeps a dozen more registers live, which the build's
+// instantiation must not pay for: 6.8 -> 7.0 ms at cfg 2 when the two shared one kernel)
+template <int THREADS, int CAP, bool PACKED, bool WS, typename HiT, bool MERGE = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MSD_WAVES, 8))) void k_bucket_msd(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
                                                         u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
                                                         u32* __restrict__ out_count, u8* __restrict__ out_kind,
@@ -792,7 +794,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     const u32 NB = 1u << nbits;  // <= CAP because c <= CAP
     // `self |= other` (mg.cs set): the run is [self's suffixes][other's], both parts distinct; every outcome needs the sorted
     // order, so the sub-buckets are always by the top bits
-    const bool merging = mg.cs != nullptr;
+    const bool merging = MERGE && mg.cs != nullptr;
     const bool vec_only = c <= VEC_THRESHOLD && !res_trie && !merging;  // no sorted output needed: sub-buckets by hash
 
     for (u32 i = tid; i < NB / 2 + 1; i += THREADS) s_off32[i] = 0;
@@ -938,7 +940,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
         }
         wave_heads += (u32)__builtin_popcountll(__ballot(head[j]));
     }
-    if (merging) {
+    if constexpr (MERGE) if (merging) {
         // Every element goes to its rank by (suffix, index) with its index: the slots then hold the run sorted, self's copy
         // of a suffix in front of other's (index < cs = came from self), and the rules of src/trievec/set_ops.rs:43-71 are
         // ordered compactions of slot subsets, as in k_bucket_medium's merge epilogue.

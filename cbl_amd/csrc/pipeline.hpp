@@ -899,19 +899,19 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
         auto msd = [&](auto packed_tag) {
             constexpr bool PK = decltype(packed_tag)::value;
             if (ln[CLS_M16])
-                hipLaunchKernelGGL((k_bucket_msd<64, 128, PK, WS, HiT>), dim3(ln[CLS_M16]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M16 * nb, list_n.get() + CLS_M16,
+                hipLaunchKernelGGL((k_bucket_msd<64, 128, PK, WS, HiT, true>), dim3(ln[CLS_M16]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M16 * nb, list_n.get() + CLS_M16,
                                    a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
             if (ln[CLS_M64])
-                hipLaunchKernelGGL((k_bucket_msd<64, 512, PK, WS, HiT>), dim3(ln[CLS_M64]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M64 * nb, list_n.get() + CLS_M64,
+                hipLaunchKernelGGL((k_bucket_msd<64, 512, PK, WS, HiT, true>), dim3(ln[CLS_M64]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M64 * nb, list_n.get() + CLS_M64,
                                    a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
             if (ln[CLS_M128])
-                hipLaunchKernelGGL((k_bucket_msd<128, 1024, PK, WS, HiT>), dim3(ln[CLS_M128]), dim3(128), 0, c->stream, lists.get() + (size_t)CLS_M128 * nb, list_n.get() + CLS_M128,
+                hipLaunchKernelGGL((k_bucket_msd<128, 1024, PK, WS, HiT, true>), dim3(ln[CLS_M128]), dim3(128), 0, c->stream, lists.get() + (size_t)CLS_M128 * nb, list_n.get() + CLS_M128,
                                    a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
             if (ln[CLS_M256])
-                hipLaunchKernelGGL((k_bucket_msd<256, 2048, PK, WS, HiT>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb, list_n.get() + CLS_M256,
+                hipLaunchKernelGGL((k_bucket_msd<256, 2048, PK, WS, HiT, true>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb, list_n.get() + CLS_M256,
                                    a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
             if (ln[CLS_M512])
-                hipLaunchKernelGGL((k_bucket_msd<512, 4096, PK, WS, HiT>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb, list_n.get() + CLS_M512,
+                hipLaunchKernelGGL((k_bucket_msd<512, 4096, PK, WS, HiT, true>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb, list_n.get() + CLS_M512,
                                    a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
         };
         if constexpr (!WS) {
