@@ -437,14 +437,15 @@ struct ChunkPlan {
     Buf<u32> chunk_len, tile_first;
     Buf<u8> dirty;
 };
-void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq, ChunkPlan& pl) {
+// `ends`: offsets[0] and offsets[nseq] when the caller has read them already (each read is a host round trip)
+void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq, ChunkPlan& pl, const u64* ends = nullptr) {
     StageTimer t(c, ST_CHUNKS);
     const Consts& P = c->P;
     // offsets may start anywhere in the buffer (a slice of a larger batch): work relative to the 16-byte aligned
     // position below offsets[0] so that the tile grid and the validity scan cover only this slice
-    const u64 first = d2h<u64>(c, d_offsets);
+    const u64 first = ends ? ends[0] : d2h<u64>(c, d_offsets);
     pl.bias = first & ~(u64)15;
-    const u64 last = d2h<u64>(c, d_offsets + nseq);
+    const u64 last = ends ? ends[1] : d2h<u64>(c, d_offsets + nseq);
     if (last < first) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
     pl.total_bases = last - pl.bias;
     d_bases += pl.bias;
@@ -508,14 +509,18 @@ u64 batch_max_bases() {
     const u64 x = e ? std::strtoull(e, nullptr, 10) : 0;
     return x ? x : (1ull << 31);
 }
-void insert_device_one(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq);
+void insert_device_one(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq, const u64* ends = nullptr);
 void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq) {
     if (nseq == 0) return;
     check_aligned16(d_bases, "d_bases");
     const u64 cap = batch_max_bases();
     const u64 first = d2h<u64>(c, d_offsets), last = d2h<u64>(c, d_offsets + nseq);
     if (last < first) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
-    if (last - first <= cap) { insert_device_one(c, d_bases, d_offsets, nseq); return; }
+    if (last - first <= cap) {
+        const u64 ends[2] = {first, last};
+        insert_device_one(c, d_bases, d_offsets, nseq, ends);
+        return;
+    }
     u64 a = 0, oa = first;
     while (a < nseq) {
         u64 lo = a + 1, hi = nseq;  // largest b in [a + 1, nseq] with offsets[b] - oa <= cap (a + 1 if even one sequence is longer)
@@ -531,11 +536,11 @@ void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nse
         oa = d2h<u64>(c, d_offsets + a);
     }
 }
-void insert_device_one(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq) {
+void insert_device_one(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq, const u64* ends) {
     dispatch(c->P, [&](auto cfg) {
         typedef decltype(cfg) C;
         ChunkPlan pl;
-        plan_chunks(c, d_bases, d_offsets, nseq, pl);
+        plan_chunks(c, d_bases, d_offsets, nseq, pl, ends);
         if (pl.n_kmers == 0) return;
         if (pl.n_kmers >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "one sequence of 2^32-16 k-mers or more is not supported");
         Records rec;

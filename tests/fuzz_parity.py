@@ -43,7 +43,7 @@ def main():
         ops = []
         print("START", desc, file=sys.stderr, flush=True)
         for step in range(rng.randint(1, 5)):
-            op = rng.choice(["seq", "seqs", "seqs", "merge", "roundtrip", "sorted", "kmers", "query", "file"])
+            op = rng.choice(["seq", "seqs", "seqs", "merge", "roundtrip", "sorted", "kmers", "query", "file", "shards"])
             ops.append(op)
             prev_blob = o.serialize() if os.environ.get("CBLX_FUZZ_DIAG") else None
             try:
@@ -115,6 +115,48 @@ def main():
                     for w in o.iter_words():
                         sizes[w >> sbits] = sizes.get(w >> sbits, 0) + 1
                     assert g.buckets_sizes() == sorted(sizes.items()), desc + " (buckets_sizes) " + str(ops)
+                elif op == "shards":  # the index as W prefix-range shares of its file, and as re-cut bucket batches
+                    import tempfile
+
+                    from cbl_amd.sharded import _varint
+
+                    blob = g.serialize()
+                    assert blob == o.serialize(), desc + " (before shards) " + str(ops)
+                    if g.num_buckets():
+                        W = rng.randint(1, 5)
+                        with tempfile.TemporaryDirectory() as td:
+                            ix = os.path.join(td, "x.cbl")
+                            with open(ix, "wb") as f:
+                                f.write(blob)
+                            bounds = None
+                            if rng.random() < 0.5 and W > 1:
+                                bounds = np.sort(np.array([rng.randrange(1 << pb) for _ in range(W - 1)], dtype=np.uint32))
+                            seqm = rng.random() < 0.3
+                            shares, ents = [], 0
+                            for r in range(W):
+                                sh = cbl_amd.CBL(k, pb)
+                                info, _b = sh.load_shard_from_file(ix, r, W, bounds, seqm)
+                                assert info["exact"] == 1, desc + " (shard not exact) " + str(ops)
+                                ents += info["local_entries"]
+                                shares.append(sh)
+                            assert ents == g.num_buckets(), desc + " (shard entries) " + str(ops)
+                            body = b"".join(s_.serialize()[len(s_.serialize()) - s_.serialized_body_size()[1]:] for s_ in shares)
+                            assert bytes([blob[0]]) + _varint(ents) + body == blob, desc + " (shares != file) " + str(ops)
+                        nb, nw, B = g.num_buckets(), g.count(), g.consts()["bytes"]
+                        pfx = torch.empty(nb, dtype=torch.int32, device="cuda")
+                        cnt = torch.empty(nb, dtype=torch.int32, device="cuda")
+                        knd = torch.empty(nb, dtype=torch.uint8, device="cuda")
+                        sfx = torch.empty(nw * B, dtype=torch.uint8, device="cuda")
+                        g.resident_export(pfx, cnt, knd, sfx)
+                        nd = rng.randint(1, 4)
+                        cuts = np.sort(np.array([rng.randrange(1 << pb) for _ in range(nd - 1)], dtype=np.uint32))
+                        bs, ws = g.resident_split(cuts, nd)
+                        parts = [(bs[d + 1] - bs[d], ws[d + 1] - ws[d], pfx[bs[d]: bs[d + 1]], cnt[bs[d]: bs[d + 1]], knd[bs[d]: bs[d + 1]], sfx[ws[d] * B: ws[d + 1] * B])
+                                 for d in range(nd) if bs[d + 1] > bs[d]]
+                        g2 = cbl_amd.CBL(k, pb, canonical=canonical)
+                        g2.install_buckets_device(parts)
+                        assert g2.serialize() == blob, desc + " (export -> install) " + str(ops)
+                        g = g2  # carry on with the installed copy
                 elif op == "sorted":
                     seqs = [rand_seq(rng, rng.randint(k, k + 800), b"ACGT") for _ in range(rng.randint(1, 40))]
                     hb = np.frombuffer(b"".join(seqs), dtype=np.uint8)
