@@ -750,6 +750,15 @@ static const int MSD_TRIP = CBLX_MSD_TRIP;  // sub-bucket entries read per trip 
 #ifndef CBLX_MSD_REUSE_BASE
 #define CBLX_MSD_REUSE_BASE 0  // measured (profiles/r02_variants.md): +0.15 ms — eight more live registers cost more than the LDS read
 #endif
+#ifndef CBLX_MSD_SKIP_SELF
+#define CBLX_MSD_SKIP_SELF 0  // measured (cfg 2): 6.73 -> 8.23 ms — per-read lane masks cost more issue time than the bank conflicts they avoid
+#endif
+#ifndef CBLX_MSD_SKIP_SINGLE
+#define CBLX_MSD_SKIP_SINGLE 1  // a lane alone in its sub-bucket does not enter the ranking loop
+#endif
+#ifndef CBLX_MSD_PROBE
+#define CBLX_MSD_PROBE 0  // > 0: timing probes that leave phases out (tools/variants.sh); never in the product build
+#endif
 #ifndef CBLX_MSD_WAVES
 #define CBLX_MSD_WAVES 7  // waves per SIMD the register allocation aims at (LDS allows 7 workgroups of the 256-thread class; 76 -> 72 VGPRs: 7.28 -> 7.10 ms)
 #endif
@@ -842,6 +851,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
         if (tid == 0) retry[atomicAdd(retry_n, 1u)] = dsc;
         return;
     }
+#if CBLX_MSD_PROBE >= 3  // timing probe only: loads, counting atomics and scan alone
+    if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_VEC; }
+    if (key[0].lo != 0x1234567ull) return;
+#endif
     if (tid == 0) s_off[NB] = (u16)c;
     if constexpr (PACKED) { if (tid < 4) s_klo[c + tid] = ~0ull; }  // the slack the ranking loop may read compares greater than every element
     // scatter into sub-bucket order (arrival order inside a sub-bucket is arbitrary); the offsets are fetched for all
@@ -851,9 +864,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     for (int j = 0; j < ITEMS; ++j) sbase[j] = s_off[sub[j]];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
+#if CBLX_MSD_SKIP_SELF
+        arr[j] += sbase[j];  // the element's own slot, kept for the ranking loop (same register as the arrival order)
+#endif
         if (valid[j]) {
             const u32 e = w * EPW + j * 64 + lane;
+#if CBLX_MSD_SKIP_SELF
+            const u32 p = arr[j];
+#else
             const u32 p = sbase[j] + arr[j];
+#endif
             if constexpr (PACKED) {
                 s_klo[p] = (key[j].lo << PK_BITS) | e;
             } else {
@@ -884,13 +904,41 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
         fin[j] = 0;
         if (valid[j]) {
             const u32 e = w * EPW + j * 64 + lane;
-            const u32 a = sa[j], b = sb[j];
+#if CBLX_MSD_PROBE >= 1  // timing probe only (wrong order): no ranking reads
+            const u32 b = sb[j], a = b;
+            const u32 a0 = sa[j];
+#elif CBLX_MSD_SKIP_SINGLE
+            const u32 b = sb[j], a = (b - sa[j] > 1u) ? sa[j] : b;  // alone: rank 0, no duplicate, nothing to read
+            const u32 a0 = sa[j];
+#else
+            const u32 a = sa[j], b = sb[j], a0 = a;
+#endif
             u32 rank = 0;
             bool dup = false;
             // four entries per trip: the reads are independent, so a sub-bucket (1.5 elements on average, 4-5 for the
             // slowest lane of a wave) costs one LDS round trip instead of one per element
             if constexpr (PACKED) {
                 const u64 me = (key[j].lo << PK_BITS) | e;
+#if CBLX_MSD_SKIP_SELF
+                // only the OTHER entries of the sub-bucket are read, under the lane's own mask: a lane alone in its
+                // sub-bucket (about half of them) issues no LDS access at all, one with a single mate issues one — the
+                // kernel is bound by the bank conflicts of these random reads (profiles/r02_sq_counters.md)
+                for (u32 q = a; q < b; q += MSD_TRIP) {
+                    u64 o[MSD_TRIP];
+#pragma unroll
+                    for (int k = 0; k < MSD_TRIP; ++k) {
+                        const u32 ix = q + k;
+                        o[k] = ~0ull;  // compares greater than every element
+                        if (ix < b && ix != arr[j]) o[k] = s_klo[ix];
+                    }
+#pragma unroll
+                    for (int k = 0; k < MSD_TRIP; ++k) {
+                        const bool less = o[k] < me;
+                        rank += less ? 1u : 0u;
+                        dup |= less && ((o[k] >> PK_BITS) == key[j].lo);
+                    }
+                }
+#else
                 if (vec_only) {  // hashed sub-buckets: what follows a sub-bucket is unrelated, entries past b are masked
                     for (u32 q = a; q < b; q += MSD_TRIP) {
                         u64 o[MSD_TRIP];
@@ -917,6 +965,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
                         }
                     }
                 }
+#endif
             } else {
                 for (u32 q = a; q < b; q += 2) {
                     Sfx<WS> o[2];
@@ -935,7 +984,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
                     }
                 }
             }
-            fin[j] = a + rank;
+            fin[j] = a0 + rank;
             head[j] = !dup;
         }
         wave_heads += (u32)__builtin_popcountll(__ballot(head[j]));
@@ -1042,7 +1091,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     }
     __syncthreads();
     const u32 d = s_wtot[NW];
+#if CBLX_MSD_PROBE >= 2  // timing probe only: no sorted write-back
+    const bool trie = false;
+#else
     const bool trie = d > VEC_THRESHOLD || res_trie;
+#endif
     if (!trie) {
         // Vec: first occurrences in stream order, straight from registers (slots are in stream order). Without a
         // duplicate (d == c) every element already sits in its slot and nothing is written.

@@ -167,6 +167,9 @@ __global__ void k_tile_first_chunk(const u64* __restrict__ chunk_start, u64 nchu
     tile_first[t] = (u32)lo;
 }
 
+#ifndef CBLX_ENC_PROBE
+#define CBLX_ENC_PROBE 0
+#endif
 // ---- word of one k-mer ---------------------------------------------------------------------------------
 template <bool WIDE> struct KmerT;
 template <> struct KmerT<false> { typedef u64 type; };
@@ -346,8 +349,12 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
             }
             u64 lo, hi;
             kmer_word<WIDE>(x, PK, rc, lo, hi);
+#if CBLX_ENC_PROBE  // timing probe only (tools/dev_encode_probe.py): one byte per k-mer instead of the word
+            reinterpret_cast<u8*>(out_lo)[obase + drel] = (u8)lo ^ (u8)hi;
+#else
             out_lo[obase + drel] = lo;
             st_hi<HiT>(out_hi, obase + drel, hi);
+#endif
             if (eh.counts) {
                 const u32 key = ((hbase + drel) / ENC_HIST_WINDOW) * 256 + eh.digit(lo, hi);
 #if CBLX_ENC_HIST_RUNS

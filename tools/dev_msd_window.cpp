@@ -45,7 +45,10 @@ int main(int argc, char** argv) {
     u32 *t_start = dalloc<u32>(nt), *t_count = dalloc<u32>(nt), *seg_first = dalloc<u32>(65538), *seg_start = dalloc<u32>(65538);
     u16* t_seg = dalloc<u16>(nt);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const DigitBits d{44, 8}, nd{52, 8};
+    // argv[2] = digit width (default 8): narrower digits = longer runs per (tile, bin) = fewer partial lines
+    const u32 nb = argc > 2 ? (u32)atoi(argv[2]) : 8u;
+    const DigitBits d{44, nb}, nd{52, 8};
+    printf("digit width %u bits (%u bins, runs of %u records)\n", nb, 1u << nb, RDX_TILE >> nb);
     for (u32 S : {8192u, 36u}) {
         const u32 nseg = (nt + S - 1) / S;
         if (nseg > 65535) { printf("S=%u: too many segments\n", S); continue; }
