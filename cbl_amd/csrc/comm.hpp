@@ -87,8 +87,14 @@ struct RcclTransport : Transport {
         Id128 uid;
         std::memcpy(uid.internal, id, sizeof uid.internal);
         CBLX_RCCL(rccl().CommInitRank(&comm, (int)w, uid, (int)r));
-        CBLX_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        CBLX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        try {
+            CBLX_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            CBLX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        } catch (...) {  // a constructor that throws does not run the destructor
+            if (cs) (void)hipStreamDestroy(cs);
+            (void)rccl().CommDestroy(comm);
+            throw;
+        }
     }
     ~RcclTransport() override {
         (void)hipSetDevice(device);
@@ -100,9 +106,10 @@ struct RcclTransport : Transport {
     }
     u64* small(size_t n) {
         if (small_cap < n) {
-            if (d_small) CBLX_HIP(hipFree(d_small));
-            small_cap = std::max<size_t>(n, 1u << 16);
-            CBLX_HIP(hipMalloc((void**)&d_small, small_cap * 8));
+            if (d_small) { u64* old = d_small; d_small = nullptr; small_cap = 0; CBLX_HIP(hipFree(old)); }
+            const size_t cap = std::max<size_t>(n, 1u << 16);
+            CBLX_HIP(hipMalloc((void**)&d_small, cap * 8));
+            small_cap = cap;
         }
         return d_small;
     }
@@ -212,6 +219,8 @@ void sharded_insert(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_o
         std::vector<u64> rb, rw;   // received buckets / words per source rank
     };
     std::vector<Slice> sl(nslices);
+    // an error between two slices must not hand the buffers of an exchange that is still running back to the pool
+    struct Drain { Transport& t; ~Drain() { try { t.wait(); } catch (...) {} } } drain{T};
     for (u32 s = 0; s < nslices; ++s) {
         const u64 a = cuts[s], b = cuts[s + 1];
         if (b < a || b > n) throw Error(CBLX_EINVAL, "slice cuts must be ascending and at most n");

@@ -31,6 +31,9 @@ template <typename HiT> __device__ __forceinline__ void st_hi(HiT* p, u64 i, u64
 #ifndef CBLX_ENC_UNIFORM
 #define CBLX_ENC_UNIFORM 1
 #endif
+#ifndef CBLX_ENC_HIST_VOTE
+#define CBLX_ENC_HIST_VOTE 0  // measured (cfg 2): encode 4.69 -> 7.10 ms — the scalar vote loop is a serial dependency chain per wave
+#endif
 #ifndef CBLX_ENC_HIST_RUNS
 #define CBLX_ENC_HIST_RUNS 0  // measured (profiles/r02_variants.md): +0.3 ms — the kernel is VALU-bound, the dozen instructions cost more than the serialised atomics
 #endif
@@ -357,7 +360,19 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
 #endif
             if (eh.counts) {
                 const u32 key = ((hbase + drel) / ENC_HIST_WINDOW) * 256 + eh.digit(lo, hi);
-#if CBLX_ENC_HIST_RUNS
+#if CBLX_ENC_HIST_VOTE
+                // The first-pass digit is the skewed one: a wave's 64 keys are a handful of distinct values (2-3 on
+                // average), which per-lane LDS atomics serialise address by address. Instead the wave votes value by
+                // value on the scalar unit: broadcast the first unsettled lane's key, ballot who shares it, one lane adds
+                // the count. The loop is scalar work plus one compare per round.
+                u64 todo = __ballot(true);
+                while (todo) {
+                    const u32 k0 = (u32)__builtin_amdgcn_readlane((int)key, (int)__builtin_ctzll(todo));
+                    const u64 same = __ballot(key == k0);
+                    if ((tid & 63u) == (u32)__builtin_ctzll(todo)) atomicAdd(&s_hist[k0], (u32)__builtin_popcountll(same));
+                    todo &= ~same;
+                }
+#elif CBLX_ENC_HIST_RUNS
                 // Neighbouring lanes hold consecutive k-mers of a read: their necklaces share the leading bits, and the
                 // first-pass digit is the skewed one — a wave's 64 updates hit a handful of counters, which the LDS
                 // serialises address by address. One update per RUN of equal keys instead: the first lane of a run adds
