@@ -44,9 +44,18 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
     {
         const u32 ntiles = (u32)ceil_div(N, RDX_TILE), nt_max = ntiles + 256;
         const u32 npassL = (RB + 7) / 8, nseg = 1u << nA;
+        // Digit widths of the LSD passes. Up to two passes: 8 bits, then the rest (the group-cut tiles below are built for
+        // that shape). Three passes (PREFIX_BITS > 24): the bits are spread evenly — 20 bits go as 7 + 7 + 6 instead of
+        // 8 + 8 + 4: a pass costs nearly the same whatever its width (4.0 ms at 4 bits, 4.4 at 8 on 1.2 G records), but one
+        // that also writes the digit side channel costs 5.15 ms at 8 bits and 4.45 at 7 (narrower digits).
+        u32 wid[4] = {0, 0, 0, 0}, sh[5] = {0, 0, 0, 0, 0};
+        for (u32 i = 0; i < npassL; ++i) {
+            wid[i] = npassL <= 2 ? std::min(8u, RB - 8 * i) : RB / npassL + (i < RB % npassL ? 1u : 0u);
+            sh[i + 1] = sh[i] + wid[i];
+        }
         // The last LSD pass cuts its tiles at (segment x lower digits) groups when there are few enough of them; the
         // bucket directory then comes from that pass's tables (k_dir_gather) instead of a scan of the sorted records.
-        const u32 low_bits = npassL ? 8 * (npassL - 1) : 0, last_bits = RB - low_bits;
+        const u32 low_bits = npassL ? sh[npassL - 1] : 0, last_bits = RB - low_bits;
         const bool tbl_dir = npassL >= 1 && nA + low_bits <= 16;
         const bool grp_tiles = tbl_dir && low_bits > 0;  // low_bits = 0: the groups are the segments (existing tile table)
         const u32 G = nseg << low_bits, nt_maxC = grp_tiles ? ntiles + G + 256 : nt_max;
@@ -72,7 +81,7 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
         bool have_dig = false;
         auto next_digit = [&](u32 next_pass) -> DigitBits {
             if (next_pass >= npassL) return DigitBits{0, 0};
-            return DigitBits{P.SB + 8 * next_pass, std::min(8u, RB - 8 * next_pass)};
+            return DigitBits{P.SB + sh[next_pass], wid[next_pass]};
         };
         if (next_digit(0).nbits) dig = Buf<u8>(c->pool, N + 64);
         {   // pass A
@@ -103,7 +112,7 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
         const TileView tvL{t_start.get(), t_count.get(), t_seg.get(), nt_dev.get(), nt_max, N};
         const TileView tvC{t_startC.get(), t_countC.get(), t_segC.get(), nt_devC.get(), nt_maxC, N};
         for (u32 pass = 0; pass < npassL; ++pass) {
-            const DigitBits dfn{P.SB + 8 * pass, std::min(8u, RB - 8 * pass)};
+            const DigitBits dfn{P.SB + sh[pass], wid[pass]};
             const bool last = pass + 1 == npassL;
             const bool cut = last && grp_tiles;  // this pass runs on the group-cut tiles
             const TileView& tv = cut ? tvC : tvL;
