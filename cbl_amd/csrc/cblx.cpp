@@ -187,15 +187,16 @@ int cblx_insert_seqs(cblx_ctx* c, const uint8_t* bases, const uint64_t* offsets,
     return guard(c, [&] {
         if (n == 0) return;
         if (!bases || !offsets) throw Error(CBLX_EINVAL, "null argument");
-        bool mono = true;
-        u64 minlen = ~0ull;
-        for (u64 i = 0; i < n; ++i) {  // branch-free scan; the offender is looked up only on failure
-            mono &= offsets[i + 1] >= offsets[i];
-            minlen = std::min(minlen, offsets[i + 1] - offsets[i]);
-        }
-        if (!mono) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
-        if (minlen < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(minlen) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
-        ingest_seqs(c, bases, offsets, n);
+        ingest_seqs(c, bases, offsets, n, [&] {
+            bool mono = true;
+            u64 minlen = ~0ull;
+            for (u64 i = 0; i < n; ++i) {  // branch-free scan; the offender is looked up only on failure
+                mono &= offsets[i + 1] >= offsets[i];
+                minlen = std::min(minlen, offsets[i + 1] - offsets[i]);
+            }
+            if (!mono) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
+            if (minlen < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(minlen) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
+        });
     });
 }
 int cblx_insert_seqs_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n) {

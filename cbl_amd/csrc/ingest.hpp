@@ -11,6 +11,9 @@
 
 #include <cstring>
 
+#include <chrono>
+#include <cstdio>
+
 #include "pipeline.hpp"
 
 namespace {
@@ -119,11 +122,13 @@ void ingest_seq(cblx_ctx* c, const u8* seq, u64 len) {
     ingest_bases(c, seq, len);
     ingest_end_seq(c);
 }
-// n sequences at once (offsets already validated)
-void ingest_seqs(cblx_ctx* c, const u8* bases, const u64* offsets, u64 n) {
+// n sequences at once. `validate` (offsets ascending, no sequence shorter than K: throws otherwise) runs while the bases are
+// on their way over PCIe; nothing is enqueued when it throws.
+template <typename V> void ingest_seqs(cblx_ctx* c, const u8* bases, const u64* offsets, u64 n, V&& validate) {
     Ingest& g = c->ing;
-    const u64 len = offsets[n] - offsets[0];
+    const u64 len = offsets[n] >= offsets[0] ? offsets[n] - offsets[0] : 0;
     if (len < (1u << 20)) {
+        validate();
         for (u64 i = 0; i < n; ++i) ingest_seq(c, bases + offsets[i], offsets[i + 1] - offsets[i]);
         return;
     }
@@ -134,6 +139,7 @@ void ingest_seqs(cblx_ctx* c, const u8* bases, const u64* offsets, u64 n) {
     if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));
     Xfer& x = xfer(c);
     x.h2d_copy(g.d_bases.get() + g.nbytes, bases + offsets[0], len);
+    try { validate(); } catch (...) { x.sync(); throw; }  // the queue's counters were not advanced: the bytes just copied are ignored
     const u64 base = g.nbytes, o0 = offsets[0];
     x.h2d(g.d_off.get() + 1 + g.nseq, n * 8, [&](u8* dst, size_t off, size_t nb) {
         u64* d = (u64*)dst;
@@ -280,7 +286,6 @@ struct FastxRegion {
     size_t beg = 0, end = 0;
     u64 nrec = 0, nbases = 0;
     bool bad = false;
-    std::vector<u64> ends;  // pass 2: end of every record, relative to the region's first base
 };
 inline const u8* fx_line_end(const u8* p, const u8* end) {
     const u8* nl = (const u8*)std::memchr(p, '\n', (size_t)(end - p));
@@ -359,6 +364,7 @@ bool fastx_parallel(cblx_ctx* c, const char* path, u64* nrec_out) {
         return v ? (size_t)v : dflt;
     };
     const size_t MIN_BYTES = env_bytes("CBLX_FASTX_PARALLEL_MIN", 32u << 20), REGION = env_bytes("CBLX_FASTX_REGION_BYTES", 16u << 20);
+    const auto t_entry = std::chrono::steady_clock::now();
     const int fd = ::open(path, O_RDONLY);
     if (fd < 0) return false;
     struct stat st;
@@ -367,7 +373,15 @@ bool fastx_parallel(cblx_ctx* c, const char* path, u64* nrec_out) {
     const u8* d = (const u8*)::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
     ::close(fd);
     if (d == (const u8*)MAP_FAILED) return false;
-    struct Unmap { const u8* d; size_t n; ~Unmap() { ::munmap((void*)d, n); } } unmap{d, size};
+    // Tearing down the page tables of a multi-GB mapping takes tens of milliseconds (30 ms for 1.7 GB): a helper thread does
+    // it while the caller goes on to the insert
+    struct Unmap {
+        const u8* d; size_t n;
+        ~Unmap() {
+            const u8* dd = d; const size_t nn = n;
+            try { std::thread([dd, nn] { ::munmap((void*)dd, nn); }).detach(); } catch (...) { ::munmap((void*)dd, nn); }
+        }
+    } unmap{d, size};
     (void)::madvise((void*)d, size, MADV_SEQUENTIAL);
     if (d[0] == 0x1f && d[1] == 0x8b) return false;  // gzip: sequential reader
     size_t first = 0;
@@ -386,9 +400,14 @@ bool fastx_parallel(cblx_ctx* c, const char* path, u64* nrec_out) {
     }
     const int T = (int)std::min<size_t>((size_t)Xfer::max_parallel(), regs.size());
     const u32 K = c->P.K;
+    const bool trace = std::getenv("CBLX_INGEST_TRACE") != nullptr;  // phase times on stderr (tuning)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    auto t_phase = t_entry;
+    auto lap = [&](const char* what) { if (trace) { std::fprintf(stderr, "[fastx] %-16s %8.2f ms\n", what, ms_since(t_phase)); } t_phase = now(); };
     auto parallel_for = [&](auto&& fn) {  // counting needs no lanes: use more threads than pass 2 may
         const unsigned hc = std::thread::hardware_concurrency();
-        const int TC = (int)std::min<size_t>(std::max(1u, std::min(32u, hc ? hc / 2 : 2u)), regs.size());
+        const int TC = (int)std::min<size_t>(std::max(1u, std::min(2u * (unsigned)Xfer::max_parallel(), hc ? hc / 2 : 2u)), regs.size());
         std::atomic<size_t> next{0};
         std::vector<std::thread> th;
         auto body = [&] { for (size_t i; (i = next.fetch_add(1)) < regs.size();) fn(regs[i]); };
@@ -396,6 +415,7 @@ bool fastx_parallel(cblx_ctx* c, const char* path, u64* nrec_out) {
         body();
         for (auto& x : th) x.join();
     };
+    lap("map + regions");
     // pass 1: count
     struct Count { u64 nrec = 0, nbases = 0; void seq(const u8*, size_t n) { nbases += n; } void rec_end() { ++nrec; } };
     parallel_for([&](FastxRegion& r) {
@@ -405,6 +425,7 @@ bool fastx_parallel(cblx_ctx* c, const char* path, u64* nrec_out) {
         r.nbases = cnt.nbases;
     });
     for (auto& r : regs) if (r.bad) return false;
+    lap("count pass");
     // pass 2, in windows of about 1 GiB of bases (the sequential reader's flush cadence)
     const u64 flush_at = std::min<u64>(1ull << 30, ingest_flush_bytes());
     Ingest& g = c->ing;
@@ -414,12 +435,16 @@ bool fastx_parallel(cblx_ctx* c, const char* path, u64* nrec_out) {
         u64 wb = 0, wr = 0;
         while (w1 < regs.size() && (w1 == w0 || wb + regs[w1].nbases <= flush_at)) { wb += regs[w1].nbases; wr += regs[w1].nrec; ++w1; }
         if (wr) {
+            lap("window setup");
             ingest_reserve(c, wb, wr);
+            lap("reserve");
             if (!g.s) CBLX_HIP(hipStreamCreateWithFlags(&g.s, hipStreamNonBlocking));
             if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
             if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));
-            std::vector<u64> base(w1 - w0 + 1, g.nbytes);
-            for (size_t i = w0; i < w1; ++i) base[i - w0 + 1] = base[i - w0] + regs[i].nbases;
+            std::vector<u64> base(w1 - w0 + 1, g.nbytes), rec0(w1 - w0 + 1, 0);
+            for (size_t i = w0; i < w1; ++i) { base[i - w0 + 1] = base[i - w0] + regs[i].nbases; rec0[i - w0 + 1] = rec0[i - w0] + regs[i].nrec; }
+            // record ends as absolute positions in the pending queue, written by the parsing threads straight to their place
+            std::unique_ptr<u64[]> ends(new u64[wr]);
             Xfer& x = xfer(c);
             std::atomic<size_t> next{w0};
             std::atomic<bool> failed{false};
@@ -430,37 +455,34 @@ bool fastx_parallel(cblx_ctx* c, const char* path, u64* nrec_out) {
                     Xfer::LaneWriter lw(x, t, g.d_bases.get() + base[i - w0]);
                     struct Copy {
                         Xfer::LaneWriter& lw;
-                        std::vector<u64>& ends;
-                        void seq(const u8* p, size_t n) { lw.put(p, n); }
-                        void rec_end() { ends.push_back(lw.written()); }
-                    } cp{lw, r.ends};
-                    r.ends.reserve(r.nrec);
-                    if (!fx_walk(d, r, fmt, K, cp) || lw.written() != r.nbases || r.ends.size() != r.nrec) failed = true;
+                        u64* out;       // this region's slots of `ends`
+                        u64 cap, n, b0;
+                        void seq(const u8* p, size_t len) { lw.put(p, len); }
+                        void rec_end() { if (n < cap) out[n] = b0 + lw.written(); ++n; }
+                    } cp{lw, ends.get() + rec0[i - w0], r.nrec, 0, base[i - w0]};
+                    if (!fx_walk(d, r, fmt, K, cp) || lw.written() != r.nbases || cp.n != r.nrec) failed = true;
                     lw.finish();
                 }
             });
+            lap("parse + copy");
             x.sync();
+            lap("dma drain");
             if (failed) throw Error(CBLX_EDEVICE, "fastx: the file changed while it was being read");
-            // record ends -> absolute positions in the pending queue, appended to the offsets
-            std::vector<u64> ends;
-            ends.reserve(wr);
-            for (size_t i = w0; i < w1; ++i) {
-                for (u64 e : regs[i].ends) ends.push_back(base[i - w0] + e);
-                std::vector<u64>().swap(regs[i].ends);
-            }
-            x.h2d_copy(g.d_off.get() + 1 + g.nseq, ends.data(), ends.size() * 8);
+            x.h2d_copy(g.d_off.get() + 1 + g.nseq, ends.get(), (size_t)wr * 8);
             x.sync();
+            lap("offsets upload");
             g.nbytes += wb;
             g.nseq += wr;
             g.last_end = g.nbytes;
             g.wb.issued = g.nbytes;
             g.wo.issued = g.nseq * 8;
             total_rec += wr;
-            if (g.nbytes >= flush_at) flush(c);
+            if (g.nbytes >= flush_at) { flush(c); lap("flush (insert)"); }
         }
         w0 = w1;
     }
     if (nrec_out) *nrec_out = total_rec;
+    lap("tail");
     return true;
 }
 

@@ -11,12 +11,17 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <thread>
 #include <vector>
 
 #include "common.hpp"
+
+#ifndef CBLX_PARSE_THREADS_DEFAULT
+#define CBLX_PARSE_THREADS_DEFAULT 16u
+#endif
 
 namespace cblx {
 
@@ -115,8 +120,14 @@ public:
     // threads; thread t may open LaneWriters on lane t only. A LaneWriter is an append-only stream into device memory:
     // put() copies into the lane's pinned slots and DMAs every full slot to d_dst + (bytes put so far).
     static int max_parallel() {  // producers are CPU-bound (parsing): more lanes than a plain copy needs to fill the link
-        unsigned hc = std::thread::hardware_concurrency();
-        return (int)std::max(1u, std::min(16u, hc ? hc / 2 : 2u));
+        static const int v = [] {
+            const char* e = std::getenv("CBLX_PARSE_THREADS");  // override (tests, tuning)
+            const int x = e ? std::atoi(e) : 0;
+            if (x > 0) return std::min(x, 64);
+            const unsigned hc = std::thread::hardware_concurrency();
+            return (int)std::max(1u, std::min(CBLX_PARSE_THREADS_DEFAULT, hc ? hc / 2 : 2u));
+        }();
+        return v;
     }
     template <typename W> void with_lanes(int T, W&& work) {
         ensure(T);
