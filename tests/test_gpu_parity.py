@@ -154,6 +154,31 @@ def test_short_sequence_rejected():
         cbl_amd.CBL(30, 24)  # K must be odd (build.rs:18-24)
 
 
+def test_bad_offsets_in_a_big_host_batch_enqueue_nothing():
+    """cblx_insert_seqs on a batch large enough for the bulk path (>= 1 MiB of bases): the offsets are validated while the
+    bases are already on the wire; a short sequence or a descending offset must still leave the index and its pending queue
+    exactly as they were (src/cbl.rs:329-334 panics before anything is inserted)."""
+    _need_gpu()
+    k, L, n = 31, 150, 20_000
+    bases, offsets = synth.reads(7, n, L)
+    g = cbl_amd.CBL(k, 24)
+    o = Oracle(k, 24)
+    short = offsets.copy()
+    short[n // 2 + 1:] -= np.uint64(L - 10)  # sequence n/2 keeps 10 bases
+    with pytest.raises(cbl_amd.CblxError, match="smaller than K") as e:
+        g.insert_seqs(bases, short)
+    assert e.value.code == cbl_amd.ESHORT
+    desc = offsets.copy()
+    desc[100] = desc[99] - np.uint64(1)
+    with pytest.raises(cbl_amd.CblxError, match="non-decreasing"):
+        g.insert_seqs(bases, desc)
+    g.flush()
+    assert g.count() == 0
+    g.insert_seqs(bases, offsets)  # the same buffers, valid offsets: the whole batch goes in
+    o.insert_seqs(bases, offsets)
+    _check_index(g, o)
+
+
 # ---- whole path: bucket contents, order, serialized bytes -------------------------------------------------
 @pytest.mark.parametrize(
     "k,pb,nreads,L,canonical",
