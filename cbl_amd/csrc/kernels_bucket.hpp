@@ -759,6 +759,9 @@ static const int MSD_TRIP = CBLX_MSD_TRIP;  // sub-bucket entries read per trip 
 #ifndef CBLX_MSD_PROBE
 #define CBLX_MSD_PROBE 0  // > 0: timing probes that leave phases out (tools/variants.sh); never in the product build
 #endif
+#if (CBLX_MSD_PROBE || CBLX_ENC_PROBE) && !defined(CBLX_TIMING_PROBES)
+#error "CBLX_MSD_PROBE / CBLX_ENC_PROBE leave phases out and produce wrong results: timing builds only (-DCBLX_TIMING_PROBES)"
+#endif
 #ifndef CBLX_MSD_WAVES
 #define CBLX_MSD_WAVES 7  // waves per SIMD the register allocation aims at (LDS allows 7 workgroups of the 256-thread class; 76 -> 72 VGPRs: 7.28 -> 7.10 ms)
 #endif
