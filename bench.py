@@ -45,6 +45,9 @@ CONFIGS = {
     "cfg3": dict(k=31, prefix_bits=28, reads=12_500_000, read_len=150, kind="build"),
     "cfg4": dict(k=59, prefix_bits=28, reads=6_250_000, read_len=250, kind="build"),
     "merge": dict(k=31, prefix_bits=24, reads=6_250_000, read_len=150, kind="merge"),
+    # SURVEY.md §8d's duplicate-heavy variant: reads sampled at 30x coverage from a 40 Mbp random genome (every k-mer arrives
+    # about 24 times in ONE batch): the deduplication and first-occurrence logic carry the load here, not the partition
+    "dup": dict(k=31, prefix_bits=24, reads=8_000_000, read_len=150, kind="build", genome=40_000_000),
 }
 
 
@@ -89,7 +92,7 @@ def merge_alg_bytes(k: int, pb: int):
 
 
 KERNEL_OF = {"radix_scatter": "k_radix_scatter", "radix_hist": "k_radix_hist_bytes", "radix_scan": "k_colscan_*+k_seg_*", "encode": "k_encode",
-             "bucket_medium": "k_bucket_msd", "bucket_small": "k_bucket_small", "bucket_huge": "k_bucket_huge", "bucket_big": "k_big_split+k_bucket_msd+k_big_collect",
+             "bucket_medium": "k_bucket_msd (+ k_bucket_claim for runs full of repeats)", "bucket_small": "k_bucket_small", "bucket_huge": "k_bucket_huge", "bucket_big": "k_big_split+k_bucket_msd+k_big_collect",
              "directory": "k_dir_gather/k_dir_resolve+k_bitvector+k_bucket_table", "chunks": "k_scan_invalid+chunk table",
              "merge_gather": "k_merge_gather"}
 
@@ -141,6 +144,7 @@ def parse_args(argv=None):
         if getattr(args, name) is None:
             setattr(args, name, cfg[name])
     args.kind = cfg["kind"]
+    args.genome = cfg.get("genome", 0)
     return args
 
 
@@ -266,7 +270,18 @@ def main():
     extra = {}
     engine = None
     if args.kind == "build":
-        d_bases, d_offsets = synth.reads_torch(42, NR, L, first_read=rank * NR, device=dev)
+        if args.genome:
+            # reads = windows of one random genome (splitmix64 seed 4242) at uniform random positions (torch generator seed 7 + rank)
+            gen, _ = synth.reads_torch(4242, 1, args.genome, device=dev)
+            gtor = torch.Generator(device=dev)
+            gtor.manual_seed(7 + rank)
+            pos = torch.randint(0, args.genome - L, (NR,), device=dev, dtype=torch.int64, generator=gtor)
+            ar = torch.arange(L, device=dev)
+            d_bases = torch.cat([gen[(pos[a:a + 1_000_000, None] + ar[None, :]).reshape(-1)] for a in range(0, NR, 1_000_000)])
+            d_offsets = torch.arange(0, (NR + 1) * L, L, device=dev, dtype=torch.int64)
+            del gen, pos
+        else:
+            d_bases, d_offsets = synth.reads_torch(42, NR, L, first_read=rank * NR, device=dev)
         torch.cuda.synchronize()
         cbl = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank, profile=True)
         comm = None
@@ -450,6 +465,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.kind == "build":
+        import numpy as np_
         from oracle import Oracle
 
         ns = NR if args.cpu_full else min(args.cpu_sample_reads, NR)
@@ -458,7 +474,11 @@ def main():
         curve = []
         while done < ns:  # fed in blocks of 1 M reads so that the decline with index size is on record
             m = min(blk, ns - done)
-            b, o = synth.reads(42, m, L, first_read=done)
+            if args.genome:  # the same reads the GPU got
+                b = d_bases[done * L:(done + m) * L].cpu().numpy()
+                o = (np_.arange(m + 1, dtype=np_.uint64) * np_.uint64(L))
+            else:
+                b, o = synth.reads(42, m, L, first_read=done)
             s1 = orc.insert_seqs(b, o)
             secs += s1
             done += m
@@ -474,7 +494,8 @@ def main():
         wb = word_layout(K, PB)[1]
         if args.kind == "build":
             workload = (f"{args.config}: K={K} ({wb}-bit word) PREFIX_BITS={PB} {NR}x{L}bp reads per GPU, "
-                        f"{'canonical' if args.canonical else 'non-canonical'}, build from empty index")
+                        + (f"{NR * L // args.genome}x coverage of a {args.genome} bp genome, " if args.genome else "")
+                        + f"{'canonical' if args.canonical else 'non-canonical'}, build from empty index")
             par = "1 GPU" if world == 1 else f"{world} GPUs: read-sharded encode + partition, prefix-range exchange ({args.protocol} protocol), per-range bucket insert"
         else:
             workload = (f"merge (cfg 5 per-GPU share): K={K} ({wb}-bit word) PREFIX_BITS={PB}, A |= B with A, B = indexes of {NR}x{L}bp reads per GPU each "
@@ -485,7 +506,8 @@ def main():
             "value": round(value, 1), "unit": "k-mers/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
-            "data": "synthetic (iid ACGT reads, splitmix64 seed 42, resident in HBM)",
+            "data": (f"synthetic (reads = windows at uniform random positions of one iid ACGT genome of {args.genome} bp, resident in HBM)" if args.genome
+                     else "synthetic (iid ACGT reads, splitmix64 seed 42, resident in HBM)"),
             "config": {"workload": workload, "name": args.config, "k": K, "prefix_bits": PB, "reads_per_gpu": NR, "read_len": L, "parallelism": par},
             "distinct_kmers_in_index": count,
             "value_h2d_inclusive": h2d["value"] if h2d else None, "h2d_inclusive": h2d,

@@ -702,7 +702,7 @@ __global__ __launch_bounds__(THREADS) void k_bucket_medium(const BDesc* __restri
 // itself inside its sub-bucket by (suffix, stream index) with a handful of compares. O(c) LDS work instead of
 // SUFFIX_BITS/8 radix passes. A bucket whose largest sub-bucket exceeds MSD_LIMIT (heavy duplication / repeats) is
 // handed to the radix kernel through `retry` untouched. -------------------------------------------------------------
-static const u32 MSD_LIMIT = 48;
+static const u32 MSD_LIMIT = 48, MSD_LIMIT_HASHED = 16;
 
 template <bool WS> __device__ __forceinline__ u32 sfx_top_bits(const Sfx<WS>& k, u32 SB, u32 nbits) {
     if constexpr (WS) {
@@ -772,7 +772,8 @@ template <int THREADS, int CAP, bool PACKED, bool WS, typename HiT, bool MERGE =
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MSD_WAVES, 8))) void k_bucket_msd(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
                                                         u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
                                                         u32* __restrict__ out_count, u8* __restrict__ out_kind,
-                                                        BDesc* __restrict__ retry, u32* __restrict__ retry_n, MergeArgs mg = MergeArgs{}) {
+                                                        BDesc* __restrict__ retry, u32* __restrict__ retry_n, MergeArgs mg = MergeArgs{},
+                                                        u8* __restrict__ bail_flag = nullptr, u32* __restrict__ bail_any = nullptr) {
     static_assert(!(PACKED && WS), "packed elements need a narrow suffix");
     static_assert(CAP <= (1 << PK_BITS), "stream index must fit PK_BITS");
     constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
@@ -808,6 +809,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     // order, so the sub-buckets are always by the top bits
     const bool merging = MERGE && mg.cs != nullptr;
     const bool vec_only = c <= VEC_THRESHOLD && !res_trie && !merging;  // no sorted output needed: sub-buckets by hash
+    // Largest sub-bucket the ranking loop is worth running on. Hashed sub-buckets of distinct suffixes stay below 10
+    // entries, so more than MSD_LIMIT_HASHED means repeats (every copy of a value lands in its sub-bucket): such runs are
+    // deduplicated far cheaper by the claim table. Top-bit sub-buckets reach 45 entries without a single repeat (necklace
+    // clusters) and give up later. A compile-time constant per length class: the runs of the classes up to
+    // 1024 words are the hashed ones (a Trie that short only comes out of a loaded file; as a run-time value the limit cost
+    // the 2048-slot instantiation four spilled registers and cfg 2 0.3 ms).
+    constexpr u32 crowd = (CAP <= (int)VEC_THRESHOLD && !MERGE) ? MSD_LIMIT_HASHED : MSD_LIMIT;
 
     for (u32 i = tid; i < NB / 2 + 1; i += THREADS) s_off32[i] = 0;
     if (tid == 0) s_max = 0;
@@ -842,7 +850,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
             sum += cnt[k];
             mx = cnt[k] > mx ? cnt[k] : mx;
         }
-        if (mx > MSD_LIMIT) atomicMax(&s_max, mx);
+        if (mx > crowd) atomicMax(&s_max, mx);
         u32 ex = block_exclusive_scan<THREADS, u32>(sum, s_scan, nullptr);
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
@@ -850,8 +858,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
         }
     }
     __syncthreads();
-    if (s_max > MSD_LIMIT) {  // skewed bucket: leave it to the radix kernel
-        if (tid == 0) retry[atomicAdd(retry_n, 1u)] = dsc;
+    if (s_max > crowd) {  // crowded sub-bucket: the run goes to the claim-table kernel (build) / the radix kernel (merge, sub-ranges)
+        // (a batch at high coverage sends nearly EVERY run this way: a million appends to one list counter serialise in the
+        // L2 — 3 ms — so the build marks the list entry instead and the next kernel walks the same list)
+        if (tid == 0) {
+            if (bail_flag) { bail_flag[blockIdx.x] = 1; *bail_any = 1u; }
+            else retry[atomicAdd(retry_n, 1u)] = dsc;
+        }
         return;
     }
 #if CBLX_MSD_PROBE >= 3  // timing probe only: loads, counting atomics and scan alone
@@ -1159,6 +1172,127 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     if (tid == 0) {
         out_count[r] = d;
         out_kind[r] = trie ? KIND_TRIE : KIND_VEC;
+    }
+}
+
+// ---- KRN-3 for runs full of repeats (one batch at high coverage: every k-mer arrives dozens of times). The counting sort
+// above gives up on them — a sub-bucket holds ALL copies of its values and every element would read them all — and the LDS
+// radix sort it used to hand them to costs 5x the time per word. Here equal suffixes meet in ONE slot of an open-addressing
+// table of element indices (twice as many slots as elements: short probe sequences whatever the data), atomicMin leaves
+// the smallest index = the first occurrence (TrieVec::insert in Vec mode keeps exactly that one,
+// /root/reference/src/trievec/mod.rs:72-99), and the distinct elements are compacted in stream order. A run that needs
+// the sorted layout (more than 1024 distinct suffixes, or a bucket that is a Trie already) goes on to the radix kernel
+// through `retry`, untouched.
+template <int THREADS, int CAP, bool WS, typename HiT>
+__global__ __launch_bounds__(THREADS) void k_bucket_claim(const BDesc* __restrict__ list, const u32* __restrict__ list_n, u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
+                                                          u32* __restrict__ out_count, u8* __restrict__ out_kind, BDesc* __restrict__ retry, u32* __restrict__ retry_n,
+                                                          const u8* __restrict__ only /* null: every list entry; else only the marked ones */) {
+    constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
+    constexpr u32 TS = 2 * CAP;
+    __shared__ u64 s_klo[CAP];
+    __shared__ u64 s_khi[WS ? CAP : 1];
+    __shared__ u32 s_tab[TS];
+    __shared__ u32 s_wtot[NW + 1];
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const u32 nlist = *list_n;
+    // `only` set (the marked entries of a class list, possibly very few of them): one workgroup looks at 64 entries — every
+    // wave loads the same 64 marks — and takes the marked ones one after the other. (One workgroup per entry that exits when
+    // its entry is not marked costs 0.2 ms of launches per half a million entries.)
+    const u32 first = only ? blockIdx.x * 64u : blockIdx.x;
+    u64 todo = 1;
+    if (only) todo = __ballot(first + lane < nlist && only[first + lane] != 0);
+    else if (first >= nlist) todo = 0;
+    while (todo) {
+    const u32 li = first + (u32)__builtin_ctzll(todo);
+    todo &= todo - 1;
+    const BDesc dsc = list[li];
+    const u32 r = dsc.r;
+    const u64 s0 = dsc.start;
+    const u32 c = dsc.c & BDESC_LEN_MASK;
+    const bool res_trie = (dsc.c & BDESC_TRIE) != 0;
+    const u32 R = (c + THREADS - 1) / THREADS;
+    const u32 EPW = 64 * R;  // wave-contiguous slices: ballots then compact in stream order
+    u32 tbits = 33 - __builtin_clz(c > 1 ? c - 1 : 1);  // 2^tbits >= 2 c
+    if (tbits < 6) tbits = 6;
+    const u32 mask = (1u << tbits) - 1u;  // <= TS - 1 because c <= CAP
+    for (u32 i = tid; i <= mask; i += THREADS) s_tab[i] = EMPTY32;
+    Sfx<WS> key[ITEMS];
+    bool valid[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {  // all loads first (slots past the run re-read its first element)
+        const u32 e = w * EPW + j * 64 + lane;
+        valid[j] = (u32)j < R && e < c;
+        key[j] = load_sfx<WS, HiT>(lo, hi, s0 + (valid[j] ? e : 0u), SB);
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 e = w * EPW + j * 64 + lane;
+        if (valid[j]) {
+            s_klo[e] = key[j].lo;
+            if constexpr (WS) s_khi[e] = key[j].hi;
+        }
+    }
+    __syncthreads();
+    u32 slot[ITEMS], old[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {  // the first probe of every item at once: independent atomics in flight instead of one round trip after the other
+        const u32 e = w * EPW + j * 64 + lane;
+        slot[j] = sfx_hash_bits<WS>(key[j], tbits);
+        old[j] = valid[j] ? atomicCAS(&s_tab[slot[j]], EMPTY32, e) : EMPTY32;
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 e = w * EPW + j * 64 + lane;
+        if (old[j] != EMPTY32) {  // the slot was taken (EMPTY32: the value's first arrival, the slot is its own from now on)
+            u32 h = slot[j], o_e = old[j];
+            for (;;) {
+                Sfx<WS> o;
+                o.lo = s_klo[o_e];
+                if constexpr (WS) o.hi = s_khi[o_e];
+                if (o == key[j]) { atomicMin(&s_tab[h], e); break; }  // whoever holds the slot has this suffix: keep the earlier index
+                h = (h + 1u) & mask;
+                o_e = atomicCAS(&s_tab[h], EMPTY32, e);
+                if (o_e == EMPTY32) break;
+            }
+            slot[j] = h;
+        }
+    }
+    __syncthreads();
+    bool head[ITEMS];
+    u32 wave_heads = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 e = w * EPW + j * 64 + lane;
+        head[j] = valid[j] && s_tab[slot[j]] == e;
+        wave_heads += (u32)__builtin_popcountll(__ballot(head[j]));
+    }
+    if (lane == 0) s_wtot[w] = wave_heads;
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (int ww = 0; ww < NW; ++ww) { const u32 t = s_wtot[ww]; s_wtot[ww] = run; run += t; }
+        s_wtot[NW] = run;
+    }
+    __syncthreads();
+    const u32 d = s_wtot[NW];
+    if (d > VEC_THRESHOLD || res_trie) {  // sorted layout needed: nothing has been written, the radix kernel takes the run as it is
+        if (tid == 0) retry[atomicAdd(retry_n, 1u)] = dsc;
+    } else {
+    u32 run = s_wtot[w];
+    if (d != c) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u64 bal = __ballot(head[j]);
+            if (head[j]) store_sfx<WS, HiT>(lo, hi, s0 + run + mbcnt(bal), key[j]);
+            run += (u32)__builtin_popcountll(bal);
+        }
+    }
+    if (tid == 0) {
+        out_count[r] = d;
+        out_kind[r] = KIND_VEC;
+    }
+    }
+    __syncthreads();  // the table and the staged keys are reused by the next entry
     }
 }
 

@@ -4,6 +4,10 @@
 #include "ctx.hpp"
 #include "kernels_kmer.hpp"
 
+#ifndef CBLX_CLAIM_FIRST
+#define CBLX_CLAIM_FIRST 0  // measured: the claim table as FIRST kernel of the runs <= 1024 words costs cfg 2 (no repeats) +0.25 ms and saves the 30x-coverage workload 2.4 ms
+#endif
+
 namespace {
 
 // ---- the sort + directory + per-bucket pipeline over N records (lo/hi), resident records first -------------
@@ -291,36 +295,65 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, ty
     }
     {
         StageTimer t(c, ST_BMED);
-        // fast path (counting sort on the top suffix bits + in-sub-bucket ranking); skewed buckets come back via `retry`
-        Buf<BDesc> retry(c->pool, std::max<u64>(nb, 1));
-        Buf<u32> retry_n(c->pool, 1);
-        CBLX_HIP(hipMemsetAsync(retry_n.get(), 0, 4, c->stream));
+        // fast path (counting sort on the top suffix bits + in-sub-bucket ranking); a run with a crowded sub-bucket marks its
+        // list entry and takes the claim-table kernel of its length class (runs full of repeats); what needs the sorted layout
+        // after that goes to the LDS radix sort
+        static const int MCLS[5] = {CLS_M16, CLS_M64, CLS_M128, CLS_M256, CLS_M512};
+        u64 roff[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 5; ++k) roff[k + 1] = roff[k] + ln[MCLS[k]];
+        Buf<u8> bail(c->pool, roff[5] + 8);
+        Buf<u32> bail_any(c->pool, 6);  // one word per class, then the radix kernel's list counter
+        Buf<BDesc> retry2(c->pool, std::max<u64>(roff[5], 1));
+        CBLX_HIP(hipMemsetAsync(bail.get(), 0, roff[5] + 8, c->stream));
+        CBLX_HIP(hipMemsetAsync(bail_any.get(), 0, 6 * 4, c->stream));
+        u32* r2n = bail_any.get() + 5;
         auto msd = [&](auto packed_tag) {
             constexpr bool PK = decltype(packed_tag)::value;
-            if (ln[CLS_M16])
-                hipLaunchKernelGGL((k_bucket_msd<64, 128, PK, C::WS, HiT>), dim3(ln[CLS_M16]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M16 * nb,
-                                   list_n.get() + CLS_M16, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
-            if (ln[CLS_M64])
-                hipLaunchKernelGGL((k_bucket_msd<64, 512, PK, C::WS, HiT>), dim3(ln[CLS_M64]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M64 * nb,
-                                   list_n.get() + CLS_M64, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
-            if (ln[CLS_M128])
-                hipLaunchKernelGGL((k_bucket_msd<128, 1024, PK, C::WS, HiT>), dim3(ln[CLS_M128]), dim3(128), 0, c->stream, lists.get() + (size_t)CLS_M128 * nb,
-                                   list_n.get() + CLS_M128, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
-            if (ln[CLS_M256])
-                hipLaunchKernelGGL((k_bucket_msd<256, 2048, PK, C::WS, HiT>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb,
-                                   list_n.get() + CLS_M256, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
-            if (ln[CLS_M512])
-                hipLaunchKernelGGL((k_bucket_msd<512, 4096, PK, C::WS, HiT>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb,
-                                   list_n.get() + CLS_M512, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get());
+            auto go = [&](auto thr, auto cap, int k) {
+                constexpr int T = decltype(thr)::value, CAPV = decltype(cap)::value;
+                const int cls = MCLS[k];
+                if (!ln[cls]) return;
+#if CBLX_CLAIM_FIRST
+                if (CAPV <= (int)VEC_THRESHOLD) {  // can only end as a Vec: the claim table is the first and only kernel
+                    hipLaunchKernelGGL((k_bucket_claim<T, CAPV, C::WS, HiT>), dim3(ln[cls]), dim3(T), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls, a_lo, a_hi, P.SB,
+                                       nr.cnt.get(), nr.kind.get(), retry2.get(), r2n, (const u8*)nullptr);
+                    return;
+                }
+#endif
+                hipLaunchKernelGGL((k_bucket_msd<T, CAPV, PK, C::WS, HiT>), dim3(ln[cls]), dim3(T), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls, a_lo, a_hi, P.SB,
+                                   nr.cnt.get(), nr.kind.get(), (BDesc*)nullptr, (u32*)nullptr, MergeArgs{}, bail.get() + roff[k], bail_any.get() + k);
+            };
+            go(std::integral_constant<int, 64>(), std::integral_constant<int, 128>(), 0);
+            go(std::integral_constant<int, 64>(), std::integral_constant<int, 512>(), 1);
+            go(std::integral_constant<int, 128>(), std::integral_constant<int, 1024>(), 2);
+            go(std::integral_constant<int, 256>(), std::integral_constant<int, 2048>(), 3);
+            go(std::integral_constant<int, 512>(), std::integral_constant<int, 4096>(), 4);
         };
         if constexpr (!C::WS) {
             if (P.SB + PK_BITS <= 64) msd(std::true_type()); else msd(std::false_type());
         } else {
             msd(std::false_type());
         }
-        const u32 nretry = (ln[CLS_M16] || ln[CLS_M64] || ln[CLS_M128] || ln[CLS_M256] || ln[CLS_M512]) ? d2h<u32>(c, retry_n.get()) : 0u;
-        if (nretry)
-            hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(nretry), dim3(512), 0, c->stream, retry.get(), retry_n.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
+        if (roff[5]) {
+            const std::vector<u32> any = d2h_vec<u32>(c, bail_any.get(), 5);
+            auto claim = [&](auto thr, auto cap, int k) {
+                constexpr int T = decltype(thr)::value, CAPV = decltype(cap)::value;
+                const int cls = MCLS[k];
+                if (!any[k]) return;
+                hipLaunchKernelGGL((k_bucket_claim<T, CAPV, C::WS, HiT>), dim3((ln[cls] + 63) / 64), dim3(T), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls, a_lo, a_hi,
+                                   P.SB, nr.cnt.get(), nr.kind.get(), retry2.get(), r2n, (const u8*)(bail.get() + roff[k]));
+            };
+            claim(std::integral_constant<int, 64>(), std::integral_constant<int, 128>(), 0);
+            claim(std::integral_constant<int, 64>(), std::integral_constant<int, 512>(), 1);
+            claim(std::integral_constant<int, 128>(), std::integral_constant<int, 1024>(), 2);
+            claim(std::integral_constant<int, 256>(), std::integral_constant<int, 2048>(), 3);
+            claim(std::integral_constant<int, 512>(), std::integral_constant<int, 4096>(), 4);
+            if (CBLX_CLAIM_FIRST || (any[0] | any[1] | any[2] | any[3] | any[4])) {
+                const u32 n2 = d2h<u32>(c, r2n);
+                if (n2)
+                    hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(n2), dim3(512), 0, c->stream, retry2.get(), r2n, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
+            }
+        }
         CBLX_HIP(hipStreamSynchronize(c->stream));  // retry buffers die here
     }
     big_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], a_lo, a_hi, nr, MergeArgs{});

@@ -292,6 +292,41 @@ def test_duplicate_heavy_reads_keep_first_occurrence_order():
         _check_index(g, o)
 
 
+@pytest.mark.parametrize("k,pb,canonical,glen", [(15, 6, False, 3000), (31, 8, False, 6000), (31, 8, True, 6000), (45, 10, False, 8000), (21, 4, False, 1500)])
+def test_repeat_heavy_runs_take_the_claim_kernel(k, pb, canonical, glen):
+    """Runs of a few thousand words in which every suffix occurs dozens of times (one batch at 30x coverage with few
+    prefixes): the counting sort gives up on them (crowded sub-buckets) and the claim-table kernel deduplicates them; the
+    buckets must keep the first-occurrence order of the stream. Second batch: the buckets that became Tries meanwhile take
+    the same route and end in the radix kernel (sorted layout)."""
+    _need_gpu()
+    rng = random.Random(1000 * k + pb)
+    genome = _rand_seq(rng, glen)
+    reads = []
+    for _ in range(glen * 30 // 100):
+        p = rng.randrange(0, len(genome) - 100)
+        reads.append(genome[p : p + 100])
+    bases, offsets = _concat(reads)
+    g, o = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
+    g.insert_seqs(bases, offsets)
+    o.insert_seqs(bases, offsets)
+    _check_index(g, o)
+    # grow some buckets past the threshold with distinct words, then the same repeats again plus repeats of a second genome
+    extra = [_rand_seq(rng, 400) for _ in range(60 << max(0, pb - 6))]
+    b2, o2 = _concat(extra)
+    g.insert_seqs(b2, o2)
+    o.insert_seqs(b2, o2)
+    _check_index(g, o)
+    genome2 = _rand_seq(rng, glen // 2)
+    reads2 = reads[: len(reads) // 2]
+    for _ in range(glen // 2 * 30 // 100):
+        p = rng.randrange(0, len(genome2) - 100)
+        reads2.append(genome2[p : p + 100])
+    b3, o3 = _concat(reads2)
+    g.insert_seqs(b3, o3)
+    o.insert_seqs(b3, o3)
+    _check_index(g, o)
+
+
 def test_incremental_flushes_equal_one_shot():
     """Batch boundaries must not change the result (SURVEY.md §7 hard part 6)."""
     _need_gpu()
@@ -601,6 +636,43 @@ def test_sub_batches_equal_one_shot(monkeypatch):
         h = cbl_amd.CBL(k, pb, canonical=canonical)
         h.insert_seqs(bases, offsets)
         _check_index(h, o)
+
+
+def test_full_size_repeat_heavy_batch_properties():
+    """SURVEY.md §8d's duplicate-heavy workload at full size: 8 M x 150 bp reads sampled at 30x coverage from a 40 Mbp random
+    genome, ONE batch (every k-mer arrives ~24 times: the claim-table kernel carries the bucket stage). Size-independent
+    properties against the index of the genome itself: subset, membership of every read k-mer, idempotence, union."""
+    _need_gpu()
+    k, pb, L, G = 31, 24, 150, 40_000_000
+    n = G * 30 // L
+    gen, _ = synth.reads_torch(4242, 1, G, device="cuda")
+    gtor = torch.Generator(device="cuda")
+    gtor.manual_seed(7)
+    pos = torch.randint(0, G - L, (n,), device="cuda", dtype=torch.int64, generator=gtor)
+    ar = torch.arange(L, device="cuda")
+    d_b = torch.cat([gen[(pos[a:a + 1_000_000, None] + ar[None, :]).reshape(-1)] for a in range(0, n, 1_000_000)])
+    d_o = torch.arange(0, (n + 1) * L, L, device="cuda", dtype=torch.int64)
+    nk = n * (L - k + 1)
+    g = cbl_amd.CBL(k, pb)
+    g.insert_seqs_device(d_b, d_o, n)
+    assert g.validate() == 0
+    cnt, cs = g.count(), g.checksum()
+    assert cnt <= G - k + 1
+    g.insert_seqs_device(d_b, d_o, n)  # the whole batch again: nothing new
+    assert (g.count(), g.checksum()) == (cnt, cs)
+    # two halves instead of one batch: the same set (the second half meets resident buckets)
+    h = cbl_amd.CBL(k, pb)
+    h.insert_seqs_device(d_b, d_o, n // 2)
+    h.insert_seqs_device(d_b, d_o[n // 2:], n - n // 2)
+    assert (h.count(), h.checksum()) == (cnt, cs) and h.validate() == 0
+    del h
+    ref = cbl_amd.CBL(k, pb)
+    ref.insert_seqs_device(gen, torch.tensor([0, G], device="cuda", dtype=torch.int64), 1)
+    assert cnt <= ref.count()
+    assert ref.contains_seqs_device(d_b, d_o, n) == (nk, nk)
+    assert g.contains_seqs_device(d_b, d_o, n) == (nk, nk)
+    g |= ref
+    assert (g.count(), g.checksum()) == (ref.count(), ref.checksum())
 
 
 def test_more_than_2_pow_32_words_in_one_index():
