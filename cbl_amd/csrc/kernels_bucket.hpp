@@ -1296,6 +1296,136 @@ __global__ __launch_bounds__(THREADS) void k_bucket_claim(const BDesc* __restric
     }
 }
 
+// ---- runs LONGER than one workgroup's LDS that are full of repeats (one batch at very high coverage: a bucket of ten
+// thousand arrivals holds a few dozen distinct suffixes). Sorting such a run — split by the top suffix bits, sub-ranges
+// through k_bucket_msd, which finds every sub-bucket crowded, then the global-memory radix kernel — cost 25..38 ms per
+// 960 M words at 300x..1000x coverage. This pre-pass shrinks the run to its first occurrences instead, in place and in
+// stream order, before anything is sorted: an LDS table of SUFFIXES (64-bit compare-and-swap claims a slot for a value)
+// with the smallest index seen per slot (atomicMin); the run streams through in tiles twice — claim, then emit the heads.
+// A run with more distinct suffixes than half the table (or whose first 512 words are mostly distinct) is passed on untouched
+// to the sort it would have had. Narrow suffixes below 64 bits only (the all-ones pattern marks a free slot).
+static const u32 BCL_THREADS = 256, BCL_ITEMS = 8, BCL_TILE = BCL_THREADS * BCL_ITEMS, BCL_SLOTS = 4096, BCL_PROBE = 512, BCL_PROBE_MAX = 358;
+template <typename HiT>
+__global__ __launch_bounds__(BCL_THREADS) void k_big_claim(const BDesc* __restrict__ list, const u32* __restrict__ list_n, u64* __restrict__ lo, u32 SB,
+                                                           u32* __restrict__ out_count, u8* __restrict__ out_kind, BDesc* __restrict__ next, u32* __restrict__ next_n,
+                                                           BDesc* __restrict__ sorted, u32* __restrict__ sorted_n) {
+    constexpr u32 NW = BCL_THREADS / 64, MASK = BCL_SLOTS - 1;
+    constexpr u64 FREE = ~0ull;
+    __shared__ u64 s_key[BCL_SLOTS];
+    __shared__ u32 s_idx[BCL_SLOTS];
+    __shared__ u32 s_w[NW + 1];
+    __shared__ u32 s_new;
+    if (blockIdx.x >= *list_n) return;
+    const BDesc dsc = list[blockIdx.x];
+    const u32 r = dsc.r;
+    const u64 s0 = dsc.start;
+    const u32 c = dsc.c & ~BDESC_TRIE;
+    const bool res_trie = (dsc.c & BDESC_TRIE) != 0;
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const u64 smask = (1ull << SB) - 1ull;
+    for (u32 i = tid; i < BCL_SLOTS; i += BCL_THREADS) { s_key[i] = FREE; s_idx[i] = EMPTY32; }
+    if (tid == 0) s_new = 0;
+    __syncthreads();
+    auto slot_hash = [&](u64 key) -> u32 {
+        u64 v = key ^ (key >> 32);
+        v *= 0x9E3779B97F4A7C15ull;
+        return (u32)(v >> 52);  // 12 bits = BCL_SLOTS
+    };
+    static_assert(BCL_SLOTS == 4096, "slot_hash takes 12 bits");
+    auto claim = [&](u64 key, u32 e) -> u32 {  // 1: the value is new
+        u32 h = slot_hash(key), fresh = 0;
+        for (u32 probes = 0; probes < BCL_SLOTS; ++probes) {
+            const u64 old = atomicCAS((unsigned long long*)&s_key[h], (unsigned long long)FREE, (unsigned long long)key);
+            if (old == FREE) { fresh = 1; break; }
+            if (old == key) break;
+            h = (h + 1u) & MASK;
+        }
+        atomicMin(&s_idx[h], e);
+        return fresh;
+    };
+    {   // a look at the first BCL_PROBE words decides whether this is a run of repeats at all (a long run of distinct words
+        // — the receiving side of an 8-GPU build has 70 000 of them — leaves after 512 claims instead of 2048 .. 4096)
+        u32 fresh = 0;
+        for (u32 e = tid; e < BCL_PROBE && e < c; e += BCL_THREADS) fresh += claim(lo[s0 + e] & smask, e);
+        if (fresh) atomicAdd(&s_new, fresh);
+        __syncthreads();
+        const u32 distinct = s_new;
+        __syncthreads();
+        if (distinct > BCL_PROBE_MAX) {
+            if (tid == 0) next[atomicAdd(next_n, 1u)] = dsc;
+            return;
+        }
+    }
+    // phase 1: every suffix claims its slot; the slot remembers the smallest index that asked for it
+    for (u32 t0 = 0; t0 < c; t0 += BCL_TILE) {
+        u64 key[BCL_ITEMS];
+#pragma unroll
+        for (int j = 0; j < (int)BCL_ITEMS; ++j) {
+            const u32 e = t0 + j * BCL_THREADS + tid;
+            key[j] = e < c ? (lo[s0 + e] & smask) : FREE;
+        }
+        u32 fresh = 0;
+#pragma unroll
+        for (int j = 0; j < (int)BCL_ITEMS; ++j) {
+            const u32 e = t0 + j * BCL_THREADS + tid;
+            if (e < c) fresh += claim(key[j], e);
+        }
+        if (fresh) atomicAdd(&s_new, fresh);
+        __syncthreads();
+        const u32 distinct = s_new;
+        __syncthreads();
+        if (distinct > BCL_SLOTS / 2) {  // too many distinct words for the table: the sort it would have had
+            if (tid == 0) next[atomicAdd(next_n, 1u)] = dsc;
+            return;
+        }
+    }
+    // phase 2: the first occurrences in stream order, written over the front of the run (never past the tile being read)
+    u32 base = 0;
+    for (u32 t0 = 0; t0 < c; t0 += BCL_TILE) {
+        u64 key[BCL_ITEMS];
+        bool head[BCL_ITEMS];
+        u32 wave_heads = 0;
+#pragma unroll
+        for (int j = 0; j < (int)BCL_ITEMS; ++j) {
+            const u32 e = t0 + w * (64 * BCL_ITEMS) + j * 64 + lane;  // wave-contiguous slices: ballots compact in stream order
+            key[j] = e < c ? (lo[s0 + e] & smask) : FREE;
+        }
+#pragma unroll
+        for (int j = 0; j < (int)BCL_ITEMS; ++j) {
+            const u32 e = t0 + w * (64 * BCL_ITEMS) + j * 64 + lane;
+            head[j] = false;
+            if (e < c) {
+                u32 h = slot_hash(key[j]);
+                while (s_key[h] != key[j]) h = (h + 1u) & MASK;  // it is there
+                head[j] = s_idx[h] == e;
+            }
+            wave_heads += (u32)__builtin_popcountll(__ballot(head[j]));
+        }
+        if (lane == 0) s_w[w] = wave_heads;
+        __syncthreads();  // every load of the tile is done: the stores below may land inside it
+        u32 run = base;
+        for (u32 ww = 0; ww < w; ++ww) run += s_w[ww];
+        u32 tile_heads = 0;
+        for (u32 ww = 0; ww < NW; ++ww) tile_heads += s_w[ww];
+#pragma unroll
+        for (int j = 0; j < (int)BCL_ITEMS; ++j) {
+            const u64 bal = __ballot(head[j]);
+            if (head[j]) lo[s0 + run + mbcnt(bal)] = key[j];
+            run += (u32)__builtin_popcountll(bal);
+        }
+        base += tile_heads;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (base <= VEC_THRESHOLD && !res_trie) {
+            out_count[r] = base;
+            out_kind[r] = KIND_VEC;
+        } else {  // distinct now, at most BCL_SLOTS / 2 words: one workgroup sorts it
+            sorted[atomicAdd(sorted_n, 1u)] = BDesc{s0, base | (res_trie ? BDESC_TRIE : 0u), r};
+        }
+    }
+}
+
 // ---- KRN-3 big: runs of 4097 .. BIG_MAX words -------------------------------------------------------------------------
 // per list entry: its length and its number of sub-ranges (scanned by the host side into scratch / virtual-bucket offsets)
 __global__ void k_big_plan(const BDesc* __restrict__ list, u32 n, u32* __restrict__ len, u32* __restrict__ nv) {
@@ -1772,6 +1902,18 @@ __global__ __launch_bounds__(256) void k_validate(u64 r0, u64 nb, const u64* __r
 
 // grid-stride sum: one atomic per workgroup (launch with sum_grid(n) workgroups of 256)
 __global__ __launch_bounds__(256) void k_sum_u32(const u32* __restrict__ v, u64 n, u64* __restrict__ out) {
+    __shared__ u64 sm[4];
+    u64 s = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) s += v[i];
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u64 t = sm[0] + sm[1] + sm[2] + sm[3];
+        if (t) atomicAdd((unsigned long long*)out, (unsigned long long)t);
+    }
+}
+__global__ __launch_bounds__(256) void k_sum_u8(const u8* __restrict__ v, u64 n, u64* __restrict__ out) {
     __shared__ u64 sm[4];
     u64 s = 0;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) s += v[i];

@@ -271,6 +271,11 @@ template <typename C> void big_stage(cblx_ctx* c, const BDesc* d_list, const u32
 // KRN-3 over the runs of `nr` (run of a prefix = [its resident suffixes as stored][the new words in stream order]) in the
 // arena a_lo / a_hi: per-bucket dedup / sort by size class; fills nr.cnt, nr.kind, nr.count. `old` = the resident index
 // the runs were built against (tells which buckets are untouched and which are Tries already).
+// CBLX_REPEAT_PREPASS=0 switches the pre-pass of the long runs off (tests compare both routes); read per call
+bool repeat_prepass() {
+    const char* e = std::getenv("CBLX_REPEAT_PREPASS");
+    return !(e && e[0] == '0');
+}
 template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, typename C::HiT* a_hi, const DirView& old) {
     typedef typename C::HiT HiT;
     const Consts& P = c->P;
@@ -293,6 +298,10 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, ty
             hipLaunchKernelGGL((k_bucket_small<32, C::WS, HiT>), grid1((u64)ln[CLS_S32] * 32, 256), dim3(256), 0, c->stream,
                                lists.get() + (size_t)CLS_S32 * nb, list_n.get() + CLS_S32, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get());
     }
+    // whether the batch looks like one full of repeats: some shorter run gave up in the counting sort (unknown = yes when
+    // there are no shorter runs at all). Long runs of distinct words — the receiving side of a many-GPU build — then skip
+    // the pre-pass below altogether.
+    bool saw_repeats = true;
     {
         StageTimer t(c, ST_BMED);
         // fast path (counting sort on the top suffix bits + in-sub-bucket ranking); a run with a crowded sub-bucket marks its
@@ -336,6 +345,13 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, ty
         }
         if (roff[5]) {
             const std::vector<u32> any = d2h_vec<u32>(c, bail_any.get(), 5);
+            saw_repeats = false;
+            if ((ln[CLS_BIG] | ln[CLS_HUGE]) && (any[0] | any[1] | any[2] | any[3] | any[4])) {  // (a few runs give up without a single repeat — necklace clusters: a sizeable share must)
+                Buf<u64> nbail(c->pool, 1);
+                CBLX_HIP(hipMemsetAsync(nbail.get(), 0, 8, c->stream));
+                hipLaunchKernelGGL(k_sum_u8, dim3((unsigned)std::min<u64>(1024, ceil_div(roff[5], 256))), dim3(256), 0, c->stream, bail.get(), roff[5], nbail.get());
+                saw_repeats = d2h<u64>(c, nbail.get()) * 8 >= roff[5];
+            }
             auto claim = [&](auto thr, auto cap, int k) {
                 constexpr int T = decltype(thr)::value, CAPV = decltype(cap)::value;
                 const int cls = MCLS[k];
@@ -356,8 +372,48 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, ty
         }
         CBLX_HIP(hipStreamSynchronize(c->stream));  // retry buffers die here
     }
-    big_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], a_lo, a_hi, nr, MergeArgs{});
-    huge_stage<C>(c, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE, ln[CLS_HUGE], a_lo, a_hi, nr, MergeArgs{});
+    bool long_done = false;
+    if constexpr (!C::WS) {
+        if (P.SB < 64 && ln[CLS_BIG] + ln[CLS_HUGE] > 0 && saw_repeats && repeat_prepass()) {
+            // runs too long for one workgroup's sort: first the pre-pass that shrinks the ones full of repeats to their first
+            // occurrences (k_big_claim); what it passes on takes the paths below, what it shrank to more than 1024 distinct
+            // words is sorted by one workgroup
+            const u32 nbig = ln[CLS_BIG], nhuge = ln[CLS_HUGE];
+            Buf<BDesc> next_big(c->pool, std::max<u32>(nbig, 1)), next_huge(c->pool, std::max<u32>(nhuge, 1)), srt(c->pool, (size_t)nbig + nhuge), retry(c->pool, (size_t)nbig + nhuge);
+            Buf<u32> cnts(c->pool, 4);  // next_big, next_huge, sorted, retry
+            std::vector<u32> cn;
+            {
+            StageTimer t(c, ST_BBIG);
+            CBLX_HIP(hipMemsetAsync(cnts.get(), 0, 16, c->stream));
+            if (nbig)
+                hipLaunchKernelGGL((k_big_claim<HiT>), dim3(nbig), dim3(BCL_THREADS), 0, c->stream, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, a_lo, P.SB, nr.cnt.get(),
+                                   nr.kind.get(), next_big.get(), cnts.get() + 0, srt.get(), cnts.get() + 2);
+            if (nhuge)
+                hipLaunchKernelGGL((k_big_claim<HiT>), dim3(nhuge), dim3(BCL_THREADS), 0, c->stream, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE, a_lo, P.SB, nr.cnt.get(),
+                                   nr.kind.get(), next_huge.get(), cnts.get() + 1, srt.get(), cnts.get() + 2);
+            cn = d2h_vec<u32>(c, cnts.get(), 3);
+            if (cn[2]) {
+                auto sort = [&](auto pk) {
+                    hipLaunchKernelGGL((k_bucket_msd<256, 2048, decltype(pk)::value, false, HiT>), dim3(cn[2]), dim3(256), 0, c->stream, srt.get(), cnts.get() + 2, a_lo, a_hi, P.SB,
+                                       nr.cnt.get(), nr.kind.get(), retry.get(), cnts.get() + 3, MergeArgs{});
+                };
+                if (P.SB + PK_BITS <= 64) sort(std::true_type()); else sort(std::false_type());
+                const u32 nre = d2h<u32>(c, cnts.get() + 3);
+                if (nre)
+                    hipLaunchKernelGGL((k_bucket_medium<512, false, HiT>), dim3(nre), dim3(512), 0, c->stream, retry.get(), cnts.get() + 3, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
+            }
+            CBLX_HIP(hipGetLastError());
+            }
+            big_stage<C>(c, next_big.get(), cnts.get() + 0, cn[0], a_lo, a_hi, nr, MergeArgs{});
+            huge_stage<C>(c, next_huge.get(), cnts.get() + 1, cn[1], a_lo, a_hi, nr, MergeArgs{});
+            CBLX_HIP(hipStreamSynchronize(c->stream));  // the lists die here
+            long_done = true;
+        }
+    }
+    if (!long_done) {
+        big_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], a_lo, a_hi, nr, MergeArgs{});
+        huge_stage<C>(c, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE, ln[CLS_HUGE], a_lo, a_hi, nr, MergeArgs{});
+    }
     }
     CBLX_HIP(hipGetLastError());
     {

@@ -292,8 +292,19 @@ def test_duplicate_heavy_reads_keep_first_occurrence_order():
         _check_index(g, o)
 
 
-@pytest.mark.parametrize("k,pb,canonical,glen", [(15, 6, False, 3000), (31, 8, False, 6000), (31, 8, True, 6000), (45, 10, False, 8000), (21, 4, False, 1500)])
-def test_repeat_heavy_runs_take_the_claim_kernel(k, pb, canonical, glen):
+@pytest.mark.parametrize(
+    "k,pb,canonical,glen,cov",
+    [
+        (15, 6, False, 3000, 30), (31, 8, False, 6000, 30), (31, 8, True, 6000, 30), (45, 10, False, 8000, 30), (21, 4, False, 1500, 30),
+        # runs longer than one workgroup's sort (> 4096 arrivals): the pre-pass of the long runs (k_big_claim) ...
+        (15, 4, False, 2500, 200),   # ... ending as Vecs (<= 1024 distinct per bucket, tens of thousands of arrivals)
+        (15, 2, False, 2000, 60),    # ... or shrunk to 1025..2048 distinct words (1981 here), then sorted by one workgroup
+        (15, 2, True, 4000, 60),     # ... or passed on untouched (3977 distinct: more than half the table)
+        (17, 1, False, 1500, 400),   # ... and runs above 262144 arrivals (the class of the global-memory kernel)
+        (31, 3, False, 3000, 120),   # 68-bit words (hi byte dropped after the first pass)
+    ],
+)
+def test_repeat_heavy_runs_take_the_claim_kernel(k, pb, canonical, glen, cov):
     """Runs of a few thousand words in which every suffix occurs dozens of times (one batch at 30x coverage with few
     prefixes): the counting sort gives up on them (crowded sub-buckets) and the claim-table kernel deduplicates them; the
     buckets must keep the first-occurrence order of the stream. Second batch: the buckets that became Tries meanwhile take
@@ -302,7 +313,7 @@ def test_repeat_heavy_runs_take_the_claim_kernel(k, pb, canonical, glen):
     rng = random.Random(1000 * k + pb)
     genome = _rand_seq(rng, glen)
     reads = []
-    for _ in range(glen * 30 // 100):
+    for _ in range(glen * cov // 100):
         p = rng.randrange(0, len(genome) - 100)
         reads.append(genome[p : p + 100])
     bases, offsets = _concat(reads)
@@ -318,7 +329,7 @@ def test_repeat_heavy_runs_take_the_claim_kernel(k, pb, canonical, glen):
     _check_index(g, o)
     genome2 = _rand_seq(rng, glen // 2)
     reads2 = reads[: len(reads) // 2]
-    for _ in range(glen // 2 * 30 // 100):
+    for _ in range(glen // 2 * cov // 100):
         p = rng.randrange(0, len(genome2) - 100)
         reads2.append(genome2[p : p + 100])
     b3, o3 = _concat(reads2)

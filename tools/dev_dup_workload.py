@@ -8,8 +8,9 @@ import cbl_amd
 from cbl_amd import synth
 
 K, PB, L = 31, 24, 150
-G, COV = 40_000_000, 30
-n = G * COV // L
+COV = int(sys.argv[1]) if len(sys.argv) > 1 else 30  # coverage; the read count stays 8 M
+n = 8_000_000
+G = n * L // COV
 gen, _ = synth.reads_torch(4242, 1, G, device="cuda")  # the genome: one 40 Mbp sequence
 torch.manual_seed(7)
 pos = torch.randint(0, G - L, (n,), device="cuda", dtype=torch.int64)
