@@ -127,7 +127,7 @@ __device__ inline void mark_dirty(u64 b, const u64* chunk_start, const u32* chun
         u64 c = lo - k;
         if (chunk_start[c] <= b && b < chunk_start[c] + chunk_len[c]) {
             dirty[c] = 1;  // benign race: every writer stores 1
-            atomicAdd(ndirty, 1u);
+            *ndirty = 1u;  // a flag, not a count (one atomicAdd per invalid byte on this word cost 25 ms when every read had an N)
         }
     }
 }
@@ -145,16 +145,39 @@ __global__ void k_scan_invalid(const u8* __restrict__ bases, u64 total, const u6
     for (u64 b = b0; b < b0 + 16 && b < total; ++b)
         if (!nuc_valid(bases[b])) mark_dirty(b, chunk_start, chunk_len, nchunks, dirty, ndirty);
 }
-// exact k-mer count of dirty chunks: 1 + #valid bytes in chunk[K..] (src/cbl.rs:277-287 filter_map)
-__global__ void k_dirty_count(const u8* __restrict__ bases, const u64* __restrict__ chunk_start,
-                              const u32* __restrict__ chunk_len, const u8* __restrict__ dirty, u64 nchunks, u32 K,
-                              u32* __restrict__ chunk_nk) {
-    u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchunks || !dirty[c]) return;
+// The dirty chunks as a list (any order), so that the kernels below put a whole wave on every one of them: one THREAD per
+// dirty chunk walking its 150 .. 2100 bytes alone, among 63 idle lanes, cost 2 ms per 82 000 dirty chunks (1 % of the reads
+// with an N) and 130 ms when every read had one.
+static const u32 DIRTY_LIST_THREADS = 256;
+__global__ __launch_bounds__(DIRTY_LIST_THREADS) void k_dirty_list(const u8* __restrict__ dirty, u64 nchunks, u32* __restrict__ list, u32* __restrict__ list_n) {
+    __shared__ u32 s_cnt[DIRTY_LIST_THREADS / 64];
+    __shared__ u32 s_base;
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool d = c < nchunks && dirty[c];
+    const u64 bal = __ballot(d);
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_cnt[w] = (u32)__builtin_popcountll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (u32 i = 0; i < DIRTY_LIST_THREADS / 64; ++i) { const u32 t = s_cnt[i]; s_cnt[i] = run; run += t; }
+        s_base = run ? atomicAdd(list_n, run) : 0u;
+    }
+    __syncthreads();
+    if (d) list[s_base + s_cnt[w] + mbcnt(bal)] = (u32)c;
+}
+// exact k-mer count of a dirty chunk: 1 + #valid bytes in chunk[K..] (src/cbl.rs:277-287 filter_map), one wave per chunk
+__global__ __launch_bounds__(256) void k_dirty_count_wave(const u8* __restrict__ bases, const u64* __restrict__ chunk_start, const u32* __restrict__ chunk_len,
+                                                          const u32* __restrict__ list, u32 nlist, u32 K, u32* __restrict__ chunk_nk) {
+    const u32 li = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (li >= nlist) return;
+    const u32 c = list[li];
     const u8* s = bases + chunk_start[c];
-    u32 len = chunk_len[c], m = 0;
-    for (u32 i = K; i < len; ++i) m += nuc_valid(s[i]) ? 1u : 0u;
-    chunk_nk[c] = 1 + m;
+    const u32 len = chunk_len[c];
+    u32 m = 0;
+    for (u32 i = K + lane; i < len; i += 64) m += nuc_valid(s[i]) ? 1u : 0u;
+    m = (u32)wave_reduce_sum((u64)m);
+    if (lane == 0) chunk_nk[c] = 1 + m;
 }
 
 // first chunk of every 4 KiB tile of the base stream (lower_bound over chunk_start)
@@ -427,53 +450,108 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
     }
 }
 
-// ---- dirty chunks: one thread per chunk, the reference's skip semantics verbatim ------------------------
+// ---- dirty chunks (a byte outside ACGTacgt): the reference's skip semantics ----------------------------------------------
 // words = K-windows of  zeros(K - n0) ++ valid(chunk[0..K]) ++ valid(chunk[K..])   (src/kmer.rs:133-135: the first
 // k-mer is folded from the valid bases among the first K BYTES; src/cbl.rs:283 filter_map on the rest).
+// One WAVE per dirty chunk (list from k_dirty_list). The chunk's words are the K-windows of a cleaned base string
+// — zeros(K - n0) ++ its valid bases — so the wave first compacts the valid bases into LDS (ballot + prefix per 64 bytes),
+// packs them 16 to a dword like the main kernel's code stream, and then every lane takes k-mers lane, lane + 64, .. from it
+// with the main kernel's own extract / word functions. Canonical order (forward-strand words of the chunk first) from a
+// first sweep that only takes the strand flags.
+static const u32 DIRTY_MAX_BASES = CHUNK_KMERS + 64 + 64;  // a chunk spans at most CHUNK_KMERS + K - 1 bytes, K <= 59
 template <bool WIDE, typename HiT>
-__global__ void k_encode_dirty(const u8* __restrict__ bases, const u64* __restrict__ chunk_start,
-                               const u32* __restrict__ chunk_len, const u64* __restrict__ kmer_off,
-                               const u8* __restrict__ dirty, u64 nchunks, Consts P, u64* __restrict__ out_lo,
-                               HiT* __restrict__ out_hi, u64 out_base, EncHist eh) {
+__global__ __launch_bounds__(256) void k_encode_dirty_wave(const u8* __restrict__ bases, const u64* __restrict__ chunk_start, const u32* __restrict__ chunk_len,
+                                                           const u64* __restrict__ kmer_off, const u32* __restrict__ list, u32 nlist, Consts P,
+                                                           u64* __restrict__ out_lo, HiT* __restrict__ out_hi, u64 out_base, EncHist eh) {
     typedef typename KmerT<WIDE>::type T;
-    u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchunks || !dirty[c]) return;
+    constexpr u32 NWV = 4, CW = DIRTY_MAX_BASES / 16 + 8, PW = DIRTY_MAX_BASES / 64 + 2;
+    __shared__ u8 s_cb_all[NWV][DIRTY_MAX_BASES + 16];
+    __shared__ u32 s_codes_all[NWV][CW];
+    __shared__ u64 s_par_all[NWV][PW];
+    __shared__ u32 s_hist_all[NWV][2 * 256];  // the chunk's outputs are contiguous and at most 2048 + K: two histogram windows
+    const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 li = blockIdx.x * NWV + wv;
+    if (li >= nlist) return;  // no workgroup barrier below: waves are on their own
+    u8* s_cb = s_cb_all[wv];
+    u32* s_codes = s_codes_all[wv];
+    u64* s_par = s_par_all[wv];
+    u32* s_hist = s_hist_all[wv];
+    if (eh.counts)
+        for (u32 i = lane; i < 2 * 256; i += 64) s_hist[i] = 0;
+    const u32 c = list[li];
     const u8* s = bases + chunk_start[c];
-    const u32 len = chunk_len[c];
-    const T MASK = (((T)1) << P.KB) - 1;
+    const u32 len = chunk_len[c], K = P.K;
     const u64 o0 = out_base + kmer_off[c];
-    const u32 nk = (u32)(kmer_off[c + 1] - kmer_off[c]);
+    // cleaned string: zeros(K - n0), then the valid bases in order (src/kmer.rs:133-135, src/cbl.rs:283)
+    const u64 first = __ballot(lane < K && lane < len && nuc_valid(s[lane]));
+    const u32 n0 = (u32)__builtin_popcountll(first), Z = K - n0;
+    for (u32 i = lane; i < Z; i += 64) s_cb[i] = 0;
+    u32 fill = Z;
+    for (u32 i0 = 0; i0 < len; i0 += 64) {
+        const u32 i = i0 + lane;
+        const u8 b = i < len ? s[i] : (u8)0;
+        const bool ok = i < len && nuc_valid(b);
+        const u64 bal = __ballot(ok);
+        if (ok) s_cb[fill + mbcnt(bal)] = (u8)nuc_code(b);
+        fill += (u32)__builtin_popcountll(bal);
+    }
+    const u32 nk = fill - K + 1;  // = kmer_off[c + 1] - kmer_off[c] (k_dirty_count_wave); fill >= K always
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const u32 nw = (fill + 15) / 16;
+    for (u32 w = lane; w < nw + 6 && w < CW; w += 64) {
+        u32 packed = 0;
+        if (w < nw)
+            for (u32 k = 0; k < 16 && w * 16 + k < fill; ++k) packed |= (u32)s_cb[w * 16 + k] << (30 - 2 * k);
+        s_codes[w] = packed;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
     u32 nfwd = 0;
-    if (P.canonical) {  // pass 1: count forward-strand k-mers
-        T x = 0;
-        for (u32 i = 0; i < P.K; ++i) if (nuc_valid(s[i])) x = (x << 2) | (T)nuc_code(s[i]);
-        nfwd += kmer_is_fwd<WIDE>(x) ? 1u : 0u;
-        for (u32 i = P.K; i < len; ++i) {
-            if (!nuc_valid(s[i])) continue;
-            x = ((x << 2) | (T)nuc_code(s[i])) & MASK;
-            nfwd += kmer_is_fwd<WIDE>(x) ? 1u : 0u;
+    if (P.canonical) {  // strand flags of every k-mer, 64 per word; nfwd = forward-strand k-mers of the chunk
+        for (u32 j0 = 0; j0 < nk; j0 += 64) {
+            const u32 j = j0 + lane;
+            const bool fwd = j < nk && kmer_is_fwd<WIDE>(extract_kmer<WIDE>(s_codes, j, K));
+            const u64 bal = __ballot(fwd);
+            if (lane == 0) s_par[j0 >> 6] = bal;
+            nfwd += (u32)__builtin_popcountll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+    const u64 win0 = o0 / ENC_HIST_WINDOW;
+    u32 fwd_before = 0;  // forward-strand k-mers in front of this 64-k-mer step
+    for (u32 j0 = 0; j0 < nk; j0 += 64) {
+        const u32 j = j0 + lane;
+        u64 fbal = 0;
+        if (P.canonical) fbal = s_par[j0 >> 6];
+        if (j < nk) {
+            const T x = extract_kmer<WIDE>(s_codes, j, K);
+            bool rc = false;
+            u64 dst = o0 + j;
+            if (P.canonical) {
+                rc = !((fbal >> lane) & 1ull);
+                const u32 fb = fwd_before + mbcnt(fbal);  // forward-strand k-mers of the chunk in front of k-mer j
+                dst = rc ? o0 + nfwd + (j - fb) : o0 + fb;
+            }
+            u64 lo, hi;
+            kmer_word<WIDE>(x, P, rc, lo, hi);
+            out_lo[dst] = lo;
+            st_hi<HiT>(out_hi, dst, hi);
+            // (one device atomic per k-mer on the count matrix — neighbours share their digit, hence their address — was
+            // most of this kernel's time; per wave an LDS histogram, flushed below)
+            if (eh.counts) atomicAdd(&s_hist[(u32)(dst / ENC_HIST_WINDOW - win0) * 256 + eh.digit(lo, hi)], 1u);
+        }
+        fwd_before += (u32)__builtin_popcountll(fbal);
+    }
+    if (eh.counts) {
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        for (u32 i = lane; i < 2 * 256; i += 64) {
+            const u32 v = s_hist[i];
+            if (v) atomicAdd(&eh.counts[(win0 + (i >> 8)) * 256 + (i & 255u)], v);
         }
     }
-    u32 kf = 0, kr = 0, j = 0;
-    T x = 0;
-    auto emit = [&]() {
-        bool rc = P.canonical && !kmer_is_fwd<WIDE>(x);
-        u64 dst = P.canonical ? (rc ? o0 + nfwd + kr++ : o0 + kf++) : o0 + j;
-        ++j;
-        u64 lo, hi;
-        kmer_word<WIDE>(x & MASK, P, rc, lo, hi);
-        out_lo[dst] = lo;
-        st_hi<HiT>(out_hi, dst, hi);
-        if (eh.counts) atomicAdd(&eh.counts[(dst / ENC_HIST_WINDOW) * 256 + eh.digit(lo, hi)], 1u);
-    };
-    for (u32 i = 0; i < P.K; ++i) if (nuc_valid(s[i])) x = (x << 2) | (T)nuc_code(s[i]);
-    emit();
-    for (u32 i = P.K; i < len; ++i) {
-        if (!nuc_valid(s[i])) continue;
-        x = ((x << 2) | (T)nuc_code(s[i])) & MASK;
-        emit();
-    }
-    (void)nk;
 }
 
 }  // namespace cblx

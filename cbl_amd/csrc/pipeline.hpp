@@ -534,6 +534,7 @@ struct ChunkPlan {
     Buf<u64> chunk_start, kmer_off;
     Buf<u32> chunk_len, tile_first;
     Buf<u8> dirty;
+    Buf<u32> dirty_list;  // the dirty chunks, any order (ndirty of them)
 };
 // `ends`: offsets[0] and offsets[nseq] when the caller has read them already (each read is a host round trip)
 void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq, ChunkPlan& pl, const u64* ends = nullptr) {
@@ -567,10 +568,15 @@ void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq
     CBLX_HIP(hipMemsetAsync(ndirty.get(), 0, 4, c->stream));
     hipLaunchKernelGGL(k_scan_invalid, grid1(ceil_div(pl.total_bases, 16), 256), dim3(256), 0, c->stream, d_bases, pl.total_bases,
                        pl.chunk_start.get(), pl.chunk_len.get(), pl.nchunks, pl.dirty.get(), ndirty.get());
-    pl.ndirty = d2h<u32>(c, ndirty.get());
-    if (pl.ndirty)
-        hipLaunchKernelGGL(k_dirty_count, grid1(pl.nchunks, 256), dim3(256), 0, c->stream, d_bases, pl.chunk_start.get(), pl.chunk_len.get(),
-                           pl.dirty.get(), pl.nchunks, P.K, chunk_nk.get());
+    pl.ndirty = d2h<u32>(c, ndirty.get());  // a flag so far
+    if (pl.ndirty) {
+        pl.dirty_list = Buf<u32>(c->pool, pl.nchunks + 1);
+        CBLX_HIP(hipMemsetAsync(ndirty.get(), 0, 4, c->stream));
+        hipLaunchKernelGGL(k_dirty_list, grid1(pl.nchunks, DIRTY_LIST_THREADS), dim3(DIRTY_LIST_THREADS), 0, c->stream, pl.dirty.get(), pl.nchunks, pl.dirty_list.get(), ndirty.get());
+        pl.ndirty = d2h<u32>(c, ndirty.get());  // the number of dirty chunks
+        hipLaunchKernelGGL(k_dirty_count_wave, dim3((pl.ndirty + 3) / 4), dim3(256), 0, c->stream, d_bases, pl.chunk_start.get(), pl.chunk_len.get(), pl.dirty_list.get(), pl.ndirty, P.K,
+                           chunk_nk.get());
+    }
     pl.kmer_off = Buf<u64>(c->pool, pl.nchunks + 1);
     pl.n_kmers = exclusive_scan<u64>(c, chunk_nk.get(), pl.nchunks, pl.kmer_off.get());
     hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, pl.kmer_off.get() + pl.nchunks, pl.n_kmers);
@@ -589,8 +595,8 @@ template <typename C> void encode(cblx_ctx* c, const u8* d_bases, const ChunkPla
         hipLaunchKernelGGL((k_encode<C::WIDE, HiT>), dim3((unsigned)ntiles), dim3(ENC_THREADS), 0, c->stream, d_bases, pl.total_bases, pl.chunk_start.get(),
                            pl.chunk_len.get(), pl.kmer_off.get(), pl.ndirty ? pl.dirty.get() : (const u8*)nullptr, pl.tile_first.get(), c->P, out_lo, out_hi, out_base, eh);
     if (pl.ndirty)
-        hipLaunchKernelGGL((k_encode_dirty<C::WIDE, HiT>), grid1(pl.nchunks, 64), dim3(64), 0, c->stream, d_bases, pl.chunk_start.get(), pl.chunk_len.get(),
-                           pl.kmer_off.get(), pl.dirty.get(), pl.nchunks, c->P, out_lo, out_hi, out_base, eh);
+        hipLaunchKernelGGL((k_encode_dirty_wave<C::WIDE, HiT>), dim3((pl.ndirty + 3) / 4), dim3(256), 0, c->stream, d_bases, pl.chunk_start.get(), pl.chunk_len.get(),
+                           pl.kmer_off.get(), pl.dirty_list.get(), pl.ndirty, c->P, out_lo, out_hi, out_base, eh);
     CBLX_HIP(hipGetLastError());
 }
 
