@@ -432,10 +432,13 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
             }
         }
     };
-    // the K of BASELINE.json's configurations get their own copy of the loop; any other K reads it from P
+    // the K of BASELINE.json's configurations (and the other common choices, 21 and 27) get their own copy of the loop; any
+    // other K reads it from P
     if constexpr (!WIDE) {
         if (P.K == 31) kmer_loop(std::integral_constant<u32, 31>());
         else if (P.K == 25) kmer_loop(std::integral_constant<u32, 25>());
+        else if (P.K == 21) kmer_loop(std::integral_constant<u32, 21>());
+        else if (P.K == 27) kmer_loop(std::integral_constant<u32, 27>());
         else kmer_loop(std::integral_constant<u32, 0>());
     } else {
         if (P.K == 59) kmer_loop(std::integral_constant<u32, 59>());
