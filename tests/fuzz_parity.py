@@ -43,7 +43,7 @@ def main():
         ops = []
         print("START", desc, file=sys.stderr, flush=True)
         for step in range(rng.randint(1, 5)):
-            op = rng.choice(["seq", "seqs", "seqs", "merge", "roundtrip", "sorted", "kmers", "query", "file", "shards"])
+            op = rng.choice(["seq", "seqs", "seqs", "merge", "roundtrip", "sorted", "kmers", "query", "file", "shards", "repeats"])
             ops.append(op)
             prev_blob = o.serialize() if os.environ.get("CBLX_FUZZ_DIAG") else None
             try:
@@ -58,6 +58,16 @@ def main():
                     g.insert_seqs(bases, offsets), o.insert_seqs(bases, offsets)
                     if rng.random() < 0.5:
                         g.flush()
+                elif op == "repeats":  # one batch at high coverage of a short "genome": runs full of repeats (claim-table kernels)
+                    genome = rand_seq(rng, rng.randint(k + 50, k + rng.choice([200, 1500, 6000])), alphabet)
+                    rl = rng.randint(k, min(len(genome), k + 120))
+                    seqs = []
+                    for _ in range(len(genome) * rng.choice([8, 30, 100]) // rl):
+                        p0 = rng.randrange(0, len(genome) - rl + 1)
+                        seqs.append(genome[p0:p0 + rl])
+                    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+                    offsets = np.cumsum([0] + [len(s_) for s_ in seqs]).astype(np.uint64)
+                    g.insert_seqs(bases, offsets), o.insert_seqs(bases, offsets)
                 elif op == "merge":
                     g2, o2 = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
                     for _ in range(rng.randint(1, 20)):

@@ -1,6 +1,6 @@
 """A short, fixed slice of the differential fuzzer (tests/fuzz_parity.py) in the GPU suite: 60 cases of seed 401. The fuzzer
 (random K / PREFIX_BITS / alphabets / operation sequences incl. load, merge, sorted batches, shard loads, bucket-batch export /
-install) caught the round-2 encode regression every shape-based test had missed (test_dirty_chunk_next_to_clean_ones_...).
+install, batches at high coverage of a short genome) caught the round-2 encode regression every shape-based test had missed (test_dirty_chunk_next_to_clean_ones_...).
 The full fuzzer (hundreds of cases per seed) is run by hand on the GPU box."""
 import os
 import subprocess
