@@ -837,26 +837,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
         arr[j] = 0;
         if (valid[j]) arr[j] = atomicAdd(&s_off32[sub[j] >> 1], 1u << ((sub[j] & 1u) * 16u));  // raw dword; the field is cut out below
     }
+    bool crowded = false;  // an arrival number of `crowd` = a sub-bucket of more than `crowd` entries
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) arr[j] = (arr[j] >> ((sub[j] & 1u) * 16u)) & 0xFFFFu;
-    __syncthreads();
-    {   // exclusive scan of the NB counts; each thread owns `per` consecutive entries
-        const u32 per = (NB + THREADS - 1) / THREADS;  // <= ITEMS
-        const u32 b0 = tid * per;
-        u32 sum = 0, mx = 0, cnt[ITEMS];
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {  // counts stay in registers: the write-back below does not re-read them
-            cnt[k] = ((u32)k < per && b0 + k < NB) ? s_off[b0 + k] : 0u;
-            sum += cnt[k];
-            mx = cnt[k] > mx ? cnt[k] : mx;
-        }
-        if (mx > crowd) atomicMax(&s_max, mx);
-        u32 ex = block_exclusive_scan<THREADS, u32>(sum, s_scan, nullptr);
-#pragma unroll
-        for (int k = 0; k < ITEMS; ++k) {
-            if ((u32)k < per && b0 + k < NB) { s_off[b0 + k] = (u16)ex; ex += cnt[k]; }
-        }
+    for (int j = 0; j < ITEMS; ++j) {
+        arr[j] = (arr[j] >> ((sub[j] & 1u) * 16u)) & 0xFFFFu;
+        crowded |= arr[j] >= crowd;  // (slots past the run keep arr = 0)
     }
+    if (crowded) s_max = crowd + 1u;  // benign race: every writer stores the same value
     __syncthreads();
     if (s_max > crowd) {  // crowded sub-bucket: the run goes to the claim-table kernel (build) / the radix kernel (merge, sub-ranges)
         // (a batch at high coverage sends nearly EVERY run this way: a million appends to one list counter serialise in the
@@ -867,6 +854,22 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
         }
         return;
     }
+    {   // exclusive scan of the NB counts; each thread owns `per` consecutive entries
+        const u32 per = (NB + THREADS - 1) / THREADS;  // <= ITEMS
+        const u32 b0 = tid * per;
+        u32 sum = 0, cnt[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {  // counts stay in registers: the write-back below does not re-read them
+            cnt[k] = ((u32)k < per && b0 + k < NB) ? s_off[b0 + k] : 0u;
+            sum += cnt[k];
+        }
+        u32 ex = block_exclusive_scan<THREADS, u32>(sum, s_scan, nullptr);
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            if ((u32)k < per && b0 + k < NB) { s_off[b0 + k] = (u16)ex; ex += cnt[k]; }
+        }
+    }
+    __syncthreads();
 #if CBLX_MSD_PROBE >= 3  // timing probe only: loads, counting atomics and scan alone
     if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_VEC; }
     if (key[0].lo != 0x1234567ull) return;
