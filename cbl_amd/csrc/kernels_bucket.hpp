@@ -1184,8 +1184,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
 // table of element indices (twice as many slots as elements: short probe sequences whatever the data), atomicMin leaves
 // the smallest index = the first occurrence (TrieVec::insert in Vec mode keeps exactly that one,
 // /root/reference/src/trievec/mod.rs:72-99), and the distinct elements are compacted in stream order. A run that needs
-// the sorted layout (more than 1024 distinct suffixes, or a bucket that is a Trie already) goes on to the radix kernel
-// through `retry`, untouched.
+// the sorted layout (more than 1024 distinct suffixes, or a bucket that is a Trie already) is listed in `retry` with its
+// new length: distinct words now, which the counting sort takes in its stride.
 template <int THREADS, int CAP, bool WS, typename HiT>
 __global__ __launch_bounds__(THREADS) void k_bucket_claim(const BDesc* __restrict__ list, const u32* __restrict__ list_n, u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
                                                           u32* __restrict__ out_count, u8* __restrict__ out_kind, BDesc* __restrict__ retry, u32* __restrict__ retry_n,
@@ -1278,11 +1278,8 @@ __global__ __launch_bounds__(THREADS) void k_bucket_claim(const BDesc* __restric
     }
     __syncthreads();
     const u32 d = s_wtot[NW];
-    if (d > VEC_THRESHOLD || res_trie) {  // sorted layout needed: nothing has been written, the radix kernel takes the run as it is
-        if (tid == 0) retry[atomicAdd(retry_n, 1u)] = dsc;
-    } else {
     u32 run = s_wtot[w];
-    if (d != c) {
+    if (d != c) {  // the first occurrences, in stream order, over the front of the run (every load is done)
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const u64 bal = __ballot(head[j]);
@@ -1291,9 +1288,12 @@ __global__ __launch_bounds__(THREADS) void k_bucket_claim(const BDesc* __restric
         }
     }
     if (tid == 0) {
-        out_count[r] = d;
-        out_kind[r] = KIND_VEC;
-    }
+        if (d > VEC_THRESHOLD || res_trie) {  // sorted layout needed: the run, now d DISTINCT words, goes on to the counting sort
+            retry[atomicAdd(retry_n, 1u)] = BDesc{s0, d | (res_trie ? BDESC_TRIE : 0u), r};
+        } else {
+            out_count[r] = d;
+            out_kind[r] = KIND_VEC;
+        }
     }
     __syncthreads();  // the table and the staged keys are reused by the next entry
     }

@@ -316,46 +316,41 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, ty
         CBLX_HIP(hipMemsetAsync(bail.get(), 0, roff[5] + 8, c->stream));
         CBLX_HIP(hipMemsetAsync(bail_any.get(), 0, 6 * 4, c->stream));
         u32* r2n = bail_any.get() + 5;
-        auto msd = [&](auto packed_tag) {
+        // The classes up to 1024 words (hashed sub-buckets) never give up without repeats in the batch: when they did, the two
+        // longer classes start with the claim table as well (`repeat_mode`) instead of a counting sort that is going to give up.
+        bool repeat_mode = false;
+        std::vector<u32> any(5, 0u);
+        bool used_msd[5] = {false, false, false, false, false};
+        auto stage = [&](auto packed_tag) {
             constexpr bool PK = decltype(packed_tag)::value;
             auto go = [&](auto thr, auto cap, int k) {
                 constexpr int T = decltype(thr)::value, CAPV = decltype(cap)::value;
                 const int cls = MCLS[k];
                 if (!ln[cls]) return;
-#if CBLX_CLAIM_FIRST
-                if (CAPV <= (int)VEC_THRESHOLD) {  // can only end as a Vec: the claim table is the first and only kernel
+                if ((CBLX_CLAIM_FIRST && CAPV <= (int)VEC_THRESHOLD) || (repeat_mode && CAPV > (int)VEC_THRESHOLD)) {
                     hipLaunchKernelGGL((k_bucket_claim<T, CAPV, C::WS, HiT>), dim3(ln[cls]), dim3(T), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls, a_lo, a_hi, P.SB,
                                        nr.cnt.get(), nr.kind.get(), retry2.get(), r2n, (const u8*)nullptr);
                     return;
                 }
-#endif
+                used_msd[k] = true;
                 hipLaunchKernelGGL((k_bucket_msd<T, CAPV, PK, C::WS, HiT>), dim3(ln[cls]), dim3(T), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls, a_lo, a_hi, P.SB,
                                    nr.cnt.get(), nr.kind.get(), (BDesc*)nullptr, (u32*)nullptr, MergeArgs{}, bail.get() + roff[k], bail_any.get() + k);
             };
             go(std::integral_constant<int, 64>(), std::integral_constant<int, 128>(), 0);
             go(std::integral_constant<int, 64>(), std::integral_constant<int, 512>(), 1);
             go(std::integral_constant<int, 128>(), std::integral_constant<int, 1024>(), 2);
+            if ((ln[CLS_M256] | ln[CLS_M512]) && (used_msd[0] | used_msd[1] | used_msd[2])) {
+                const std::vector<u32> a3 = d2h_vec<u32>(c, bail_any.get(), 3);
+                repeat_mode = (a3[0] | a3[1] | a3[2]) != 0;
+            }
             go(std::integral_constant<int, 256>(), std::integral_constant<int, 2048>(), 3);
             go(std::integral_constant<int, 512>(), std::integral_constant<int, 4096>(), 4);
-        };
-        if constexpr (!C::WS) {
-            if (P.SB + PK_BITS <= 64) msd(std::true_type()); else msd(std::false_type());
-        } else {
-            msd(std::false_type());
-        }
-        if (roff[5]) {
-            const std::vector<u32> any = d2h_vec<u32>(c, bail_any.get(), 5);
-            saw_repeats = false;
-            if ((ln[CLS_BIG] | ln[CLS_HUGE]) && (any[0] | any[1] | any[2] | any[3] | any[4])) {  // (a few runs give up without a single repeat — necklace clusters: a sizeable share must)
-                Buf<u64> nbail(c->pool, 1);
-                CBLX_HIP(hipMemsetAsync(nbail.get(), 0, 8, c->stream));
-                hipLaunchKernelGGL(k_sum_u8, dim3((unsigned)std::min<u64>(1024, ceil_div(roff[5], 256))), dim3(256), 0, c->stream, bail.get(), roff[5], nbail.get());
-                saw_repeats = d2h<u64>(c, nbail.get()) * 8 >= roff[5];
-            }
+            if (!roff[5]) return;
+            any = d2h_vec<u32>(c, bail_any.get(), 5);
             auto claim = [&](auto thr, auto cap, int k) {
                 constexpr int T = decltype(thr)::value, CAPV = decltype(cap)::value;
                 const int cls = MCLS[k];
-                if (!any[k]) return;
+                if (!used_msd[k] || !any[k]) return;
                 hipLaunchKernelGGL((k_bucket_claim<T, CAPV, C::WS, HiT>), dim3((ln[cls] + 63) / 64), dim3(T), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls, a_lo, a_hi,
                                    P.SB, nr.cnt.get(), nr.kind.get(), retry2.get(), r2n, (const u8*)(bail.get() + roff[k]));
             };
@@ -364,11 +359,35 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, ty
             claim(std::integral_constant<int, 128>(), std::integral_constant<int, 1024>(), 2);
             claim(std::integral_constant<int, 256>(), std::integral_constant<int, 2048>(), 3);
             claim(std::integral_constant<int, 512>(), std::integral_constant<int, 4096>(), 4);
-            if (CBLX_CLAIM_FIRST || (any[0] | any[1] | any[2] | any[3] | any[4])) {
+            if (CBLX_CLAIM_FIRST || repeat_mode || (any[0] | any[1] | any[2] | any[3] | any[4])) {
+                // what the claim tables left for the sorted layout: distinct words now, at most 4096 per run
                 const u32 n2 = d2h<u32>(c, r2n);
-                if (n2)
-                    hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(n2), dim3(512), 0, c->stream, retry2.get(), r2n, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
+                if (n2) {
+                    Buf<BDesc> retry3(c->pool, n2);
+                    Buf<u32> r3n(c->pool, 1);
+                    CBLX_HIP(hipMemsetAsync(r3n.get(), 0, 4, c->stream));
+                    hipLaunchKernelGGL((k_bucket_msd<512, 4096, PK, C::WS, HiT>), dim3(n2), dim3(512), 0, c->stream, retry2.get(), r2n, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(),
+                                       retry3.get(), r3n.get(), MergeArgs{});
+                    const u32 n3 = d2h<u32>(c, r3n.get());
+                    if (n3)
+                        hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(n3), dim3(512), 0, c->stream, retry3.get(), r3n.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
+                    CBLX_HIP(hipStreamSynchronize(c->stream));  // retry3 dies here
+                }
             }
+        };
+        if constexpr (!C::WS) {
+            if (P.SB + PK_BITS <= 64) stage(std::true_type()); else stage(std::false_type());
+        } else {
+            stage(std::false_type());
+        }
+        saw_repeats = roff[5] ? repeat_mode : true;  // no shorter runs at all: unknown = yes
+        if (roff[5] && !repeat_mode && (ln[CLS_BIG] | ln[CLS_HUGE]) && (any[0] | any[1] | any[2] | any[3] | any[4])) {
+            // no shorter hashed runs to tell: a sizeable share of the runs that went through the counting sort must have given up
+            // (a few do without a single repeat — necklace clusters)
+            Buf<u64> nbail(c->pool, 1);
+            CBLX_HIP(hipMemsetAsync(nbail.get(), 0, 8, c->stream));
+            hipLaunchKernelGGL(k_sum_u8, dim3((unsigned)std::min<u64>(1024, ceil_div(roff[5], 256))), dim3(256), 0, c->stream, bail.get(), roff[5], nbail.get());
+            saw_repeats = d2h<u64>(c, nbail.get()) * 8 >= roff[5];
         }
         CBLX_HIP(hipStreamSynchronize(c->stream));  // retry buffers die here
     }
