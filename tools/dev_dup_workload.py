@@ -7,7 +7,7 @@ import torch
 import cbl_amd
 from cbl_amd import synth
 
-K, PB, L = 31, 24, 150
+K, PB, L = int(os.environ.get("DUP_K", 31)), int(os.environ.get("DUP_PB", 24)), int(os.environ.get("DUP_L", 150))
 COV = int(sys.argv[1]) if len(sys.argv) > 1 else 30  # coverage; the read count stays 8 M
 n = 8_000_000
 G = n * L // COV
