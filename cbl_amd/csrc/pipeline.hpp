@@ -316,8 +316,9 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, ty
         CBLX_HIP(hipMemsetAsync(bail.get(), 0, roff[5] + 8, c->stream));
         CBLX_HIP(hipMemsetAsync(bail_any.get(), 0, 6 * 4, c->stream));
         u32* r2n = bail_any.get() + 5;
-        // The classes up to 1024 words (hashed sub-buckets) never give up without repeats in the batch: when they did, the two
-        // longer classes start with the claim table as well (`repeat_mode`) instead of a counting sort that is going to give up.
+        // The classes up to 1024 words (hashed sub-buckets) never give up without repeats in the batch: once one of them did
+        // — the shortest is asked first — the classes after it start with the claim table (`repeat_mode`) instead of a
+        // counting sort that is going to give up.
         bool repeat_mode = false;
         std::vector<u32> any(5, 0u);
         bool used_msd[5] = {false, false, false, false, false};
@@ -327,7 +328,7 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, ty
                 constexpr int T = decltype(thr)::value, CAPV = decltype(cap)::value;
                 const int cls = MCLS[k];
                 if (!ln[cls]) return;
-                if ((CBLX_CLAIM_FIRST && CAPV <= (int)VEC_THRESHOLD) || (repeat_mode && CAPV > (int)VEC_THRESHOLD)) {
+                if ((CBLX_CLAIM_FIRST && CAPV <= (int)VEC_THRESHOLD) || repeat_mode) {
                     hipLaunchKernelGGL((k_bucket_claim<T, CAPV, C::WS, HiT>), dim3(ln[cls]), dim3(T), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls, a_lo, a_hi, P.SB,
                                        nr.cnt.get(), nr.kind.get(), retry2.get(), r2n, (const u8*)nullptr);
                     return;
@@ -337,9 +338,11 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, ty
                                    nr.cnt.get(), nr.kind.get(), (BDesc*)nullptr, (u32*)nullptr, MergeArgs{}, bail.get() + roff[k], bail_any.get() + k);
             };
             go(std::integral_constant<int, 64>(), std::integral_constant<int, 128>(), 0);
+            if (used_msd[0] && (ln[CLS_M64] | ln[CLS_M128] | ln[CLS_M256] | ln[CLS_M512]))  // the shortest class is the cheapest witness
+                repeat_mode = d2h<u32>(c, bail_any.get() + 0) != 0;
             go(std::integral_constant<int, 64>(), std::integral_constant<int, 512>(), 1);
             go(std::integral_constant<int, 128>(), std::integral_constant<int, 1024>(), 2);
-            if ((ln[CLS_M256] | ln[CLS_M512]) && (used_msd[0] | used_msd[1] | used_msd[2])) {
+            if (!repeat_mode && (ln[CLS_M256] | ln[CLS_M512]) && (used_msd[1] | used_msd[2])) {
                 const std::vector<u32> a3 = d2h_vec<u32>(c, bail_any.get(), 3);
                 repeat_mode = (a3[0] | a3[1] | a3[2]) != 0;
             }
