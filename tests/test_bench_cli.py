@@ -1,0 +1,42 @@
+"""bench.py's command line and accounting tables (no GPU): every --config resolves to a complete workload, the defaults are
+the ones the contract names, and the per-stage algorithmic bytes add up to what DESIGN.md §4 states for cfg 2."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def test_every_config_resolves():
+    for name, cfg in bench.CONFIGS.items():
+        a = bench.parse_args(["--config", name])
+        assert (a.k, a.prefix_bits, a.reads, a.read_len) == (cfg["k"], cfg["prefix_bits"], cfg["reads"], cfg["read_len"])
+        assert a.kind in ("build", "merge")
+        assert a.genome == cfg.get("genome", 0)
+    assert bench.parse_args(["--config", "dup"]).genome == 40_000_000
+
+
+def test_defaults_follow_the_contract():
+    a = bench.parse_args([])
+    assert (a.gpus, a.config, a.kind) == (1, "cfg2", "build")
+    assert bench.parse_args(["--gpus", "8"]).config == "cfg3"  # BASELINE.json's multi-GPU configuration
+    a = bench.parse_args(["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert (a.steps, a.warmup) == (3, 1)
+
+
+def test_algorithmic_bytes_of_cfg2():
+    alg = bench.stage_alg_bytes(31, 24, 150)
+    assert alg["radix_scatter"] == 18 + 17 + 16  # pass A reads 9 + writes 8 (+1 side channel), B 8 + 8 + 1, C 8 + 8
+    assert alg["encode"] == 150 / 120 + 9
+    assert alg["bucket_medium"] == 16 and alg["radix_hist"] == 2.0
+    kb, wb, hi, sfx, nbytes = bench.word_layout(31, 24)
+    assert (kb, wb, hi, sfx, nbytes) == (62, 68, 1, 8, 6)
+    assert bench.word_layout(59, 28)[1:] == (125, 8, 16, 13)
+
+
+def test_source_hash_is_stable_and_covers_csrc():
+    h = bench.source_hash()
+    assert len(h) == 16 and h == bench.source_hash()
