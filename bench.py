@@ -126,9 +126,10 @@ def parse_args(argv=None):
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--canonical", action="store_true")
-    ap.add_argument("--protocol", choices=["sorted", "words"], default="sorted")
+    ap.add_argument("--protocol", choices=["bins", "sorted", "words"], default=None,
+                    help="N > 1: what crosses the links. native transport: bins (default) or sorted; torch transport: sorted (default) or words")
     ap.add_argument("--slices", type=int, default=4)
-    ap.add_argument("--transport", choices=["torch", "native"], default="torch",
+    ap.add_argument("--transport", choices=["torch", "native"], default="native",
                     help="N > 1: exchange driven from Python over torch.distributed, or the whole sharded insert inside libcblx on RCCL directly")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--cpu-full", action="store_true", help="time the CPU oracle on the whole workload (cfg 2: about 4 minutes)")
@@ -139,6 +140,8 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     if args.config is None:
         args.config = "cfg2" if args.gpus == 1 else "cfg3"
+    if args.protocol is None:
+        args.protocol = "bins" if args.transport == "native" else "sorted"
     cfg = CONFIGS[args.config]
     for name in ("k", "prefix_bits", "reads", "read_len"):
         if getattr(args, name) is None:

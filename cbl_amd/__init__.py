@@ -104,6 +104,7 @@ SIGNATURES = {
     "cblx_comm_destroy": (None, [C.c_void_p]),
     "cblx_comm_last_error": (C.c_char_p, [C.c_void_p]),
     "cblx_comm_stats": (C.c_int, [C.c_void_p, C.POINTER(ExchangeStats), C.c_int]),
+    "cblx_comm_set_protocol": (C.c_int, [C.c_void_p, C.c_uint32]),
     "cblx_sharded_insert_seqs_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
                                                   C.POINTER(C.c_int)]),
     "cblx_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -283,6 +284,15 @@ class Comm:
         if rc != OK:
             raise CblxError(rc, L.cblx_last_global_error().decode())
         return cls(h, keep=cbs)
+
+    PROTOCOLS = {"sorted": 0, "bins": 1}  # CBLX_PROTO_SORTED / CBLX_PROTO_BINS (include/cblx.h)
+
+    def set_protocol(self, name: str):
+        """What crosses the links in sharded_insert_seqs_device: "bins" (default; exchange between the first and the second
+        partition pass) or "sorted" (full partition on the sender, packed suffixes on the wire). The same on every rank."""
+        rc = self._L.cblx_comm_set_protocol(self._h, self.PROTOCOLS[name])
+        if rc != OK:
+            raise CblxError(rc, "cblx_comm_set_protocol")
 
     def stats(self, reset: bool = False) -> dict:
         st = ExchangeStats()

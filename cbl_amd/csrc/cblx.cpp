@@ -473,6 +473,11 @@ int cblx_comm_stats(cblx_comm* cm, cblx_exchange_stats* out, int reset) {
     if (reset) cm->t->sent_bytes = cm->t->recv_bytes = cm->t->messages = 0;
     return CBLX_OK;
 }
+int cblx_comm_set_protocol(cblx_comm* cm, uint32_t protocol) {
+    if (!cm || (protocol != CBLX_PROTO_SORTED && protocol != CBLX_PROTO_BINS)) return CBLX_EINVAL;
+    cm->protocol = protocol;
+    return CBLX_OK;
+}
 int cblx_sharded_insert_seqs_device(cblx_ctx* c, cblx_comm* cm, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n, const uint64_t* slice_cuts,
                                     uint32_t n_slices, uint32_t* bounds, int* bounds_valid) {
     return guard(c, [&] {
@@ -483,7 +488,7 @@ int cblx_sharded_insert_seqs_device(cblx_ctx* c, cblx_comm* cm, const uint8_t* d
         flush(c);  // keep stream order with anything enqueued earlier
         u32 dummy = 0;
         try {
-            dispatch(c->P, [&](auto cfg) { sharded_insert<decltype(cfg)>(c, *cm->t, d_bases, d_offsets, n, slice_cuts, n_slices, bounds ? bounds : &dummy, bounds_valid); });
+            dispatch(c->P, [&](auto cfg) { sharded_insert<decltype(cfg)>(c, cm, d_bases, d_offsets, n, slice_cuts, n_slices, bounds ? bounds : &dummy, bounds_valid); });
         } catch (const Error& e) { cm->err = e.what(); throw; }
         collect_events(c);
     });

@@ -174,6 +174,7 @@ struct CallbackTransport : Transport {
 struct cblx_comm {
     std::unique_ptr<Transport> t;
     int device = 0;
+    u32 protocol = CBLX_PROTO_BINS;
     std::string err;
 };
 
@@ -208,8 +209,39 @@ std::vector<u32> choose_bounds(const std::vector<u64>& hist, u32 world, u32 PB, 
     return b;
 }
 
+// first batch only: quantile ranges from the all-reduced, sampled prefix histogram of one slice's words
 template <typename C>
-void sharded_insert(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, u32* bounds, int* bounds_valid) {
+void choose_bounds_from_slice(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 nseq, u32* bounds) {
+    typedef typename C::HiT HiT;
+    const Consts& P = c->P;
+    const u32 hb = std::min(SPLIT_HIST_BITS, P.PB);
+    std::vector<u64> hist((size_t)1 << hb, 0);
+    if (nseq) {
+        ChunkPlan pl;
+        const u8* pb = d_bases;
+        plan_chunks(c, pb, d_offsets, nseq, pl);
+        if (pl.n_kmers) {
+            Buf<u64> w_lo(c->pool, pl.n_kmers + 2);
+            Buf<u8> w_hi(c->pool, (pl.n_kmers + 2) * std::max<size_t>(1, hi_elem_size(P)));
+            Buf<u32> d_hist(c->pool, (size_t)1 << hb);
+            CBLX_HIP(hipMemsetAsync(d_hist.get(), 0, ((size_t)1 << hb) * 4, c->stream));
+            encode<C>(c, pb, pl, w_lo.get(), (HiT*)w_hi.get(), 0);
+            hipLaunchKernelGGL(k_sample_hist<HiT>, grid1(ceil_div(pl.n_kmers, SPLIT_STRIDE), 256), dim3(256), 0, c->stream, w_lo.get(), (const HiT*)w_hi.get(), pl.n_kmers,
+                               SPLIT_STRIDE, P.SB + P.PB - hb, hb, d_hist.get());
+            CBLX_HIP(hipGetLastError());
+            std::vector<u32> h32 = d2h_vec<u32>(c, d_hist.get(), (size_t)1 << hb);
+            for (size_t i = 0; i < h32.size(); ++i) hist[i] = h32[i];
+        }
+    }
+    T.all_reduce_sum_u64(hist.data(), hist.size());
+    const std::vector<u32> bb = choose_bounds(hist, T.world, P.PB, hb);
+    for (u32 d = 0; d + 1 < T.world; ++d) bounds[d] = bb[d];
+}
+
+// ---- protocol "sorted": the sender partitions completely; prefixes, counts and packed suffixes on the wire; the receiver
+// merges the batches run by run (fewest bytes per word: the choice when the links are the bound, world <= 4) ----------------
+template <typename C>
+void sharded_insert_sorted(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, u32* bounds, int* bounds_valid) {
     typedef typename C::HiT HiT;
     const Consts& P = c->P;
     const u32 W = T.world, B = P.BYTES;
@@ -225,29 +257,7 @@ void sharded_insert(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_o
         const u64 a = cuts[s], b = cuts[s + 1];
         if (b < a || b > n) throw Error(CBLX_EINVAL, "slice cuts must be ascending and at most n");
         if (!*bounds_valid) {
-            // first batch only: quantile ranges from the all-reduced, sampled prefix histogram of this slice's words
-            const u32 hb = std::min(SPLIT_HIST_BITS, P.PB);
-            std::vector<u64> hist((size_t)1 << hb, 0);
-            if (b > a) {
-                ChunkPlan pl;
-                const u8* pb = d_bases;
-                plan_chunks(c, pb, d_offsets + a, b - a, pl);
-                if (pl.n_kmers) {
-                    Buf<u64> w_lo(c->pool, pl.n_kmers + 2);
-                    Buf<u8> w_hi(c->pool, (pl.n_kmers + 2) * std::max<size_t>(1, hi_elem_size(P)));
-                    Buf<u32> d_hist(c->pool, (size_t)1 << hb);
-                    CBLX_HIP(hipMemsetAsync(d_hist.get(), 0, ((size_t)1 << hb) * 4, c->stream));
-                    encode<C>(c, pb, pl, w_lo.get(), (HiT*)w_hi.get(), 0);
-                    hipLaunchKernelGGL(k_sample_hist<HiT>, grid1(ceil_div(pl.n_kmers, SPLIT_STRIDE), 256), dim3(256), 0, c->stream, w_lo.get(), (const HiT*)w_hi.get(), pl.n_kmers,
-                                       SPLIT_STRIDE, P.SB + P.PB - hb, hb, d_hist.get());
-                    CBLX_HIP(hipGetLastError());
-                    std::vector<u32> h32 = d2h_vec<u32>(c, d_hist.get(), (size_t)1 << hb);
-                    for (size_t i = 0; i < h32.size(); ++i) hist[i] = h32[i];
-                }
-            }
-            T.all_reduce_sum_u64(hist.data(), hist.size());
-            const std::vector<u32> bb = choose_bounds(hist, W, P.PB, hb);
-            for (u32 d = 0; d + 1 < W; ++d) bounds[d] = bb[d];
+            choose_bounds_from_slice<C>(c, T, d_bases, d_offsets + a, b - a, bounds);
             *bounds_valid = 1;
         }
         std::vector<u64> bs(W + 1), ws(W + 1);
@@ -289,6 +299,231 @@ void sharded_insert(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_o
     }
     if (!views.empty()) insert_sorted_batches<C>(c, views.data(), (u32)views.size());
     CBLX_HIP(hipStreamSynchronize(c->stream));
+}
+
+// ---- protocol "bins": the exchange rides between the first and the second partition pass ------------------------------------
+// The sender runs KRN-1 and pass A only — on BINS (DigitBin: the pass-A segment refined by the destination rank), so its output
+// is contiguous per destination and, inside a destination, per segment; the records of its own range go straight into its
+// receive arena (OwnWindow), the others leave as they are: 8-byte records (the hi byte of a 65..72-bit word is implied by the
+// segment, as on one GPU) plus the 1-byte digit side channel of the next pass. The receiver keeps the arena as the input of
+// the remaining passes: a piece table (slice, source, segment) -> tile table of the first LSD pass (k_piece_tables), after
+// which the one-GPU pipeline continues unchanged. No pass is added to the one-GPU path and no record is copied: per rank the
+// job costs what the direct build costs plus the slices' fixed costs.
+struct BinMap {
+    u32 v_of[256], d_of[256];  // bin -> segment, destination (0xFFFFFFFF: no such bin)
+    bool ok = true;
+};
+inline BinMap make_bin_map(const Consts& P, const u32* bounds, u32 W) {
+    BinMap M;
+    for (u32 i = 0; i < 256; ++i) M.v_of[i] = M.d_of[i] = 0xFFFFFFFFu;
+    const u32 RB = P.PB - 8;
+    auto dest = [&](u64 p) { u32 d = 0; for (u32 i = 0; i + 1 < W; ++i) d += bounds[i] <= p ? 1u : 0u; return d; };
+    for (u32 i = 0; i + 1 < W; ++i) if ((u64)bounds[i] > (255ull << RB)) M.ok = false;  // the all-ones segment must belong to one rank
+    for (u32 v = 0; v < 128; ++v)
+        for (u32 d = dest((u64)v << RB); d <= dest((((u64)v + 1) << RB) - 1); ++d) { M.v_of[v + d] = v; M.d_of[v + d] = d; }
+    M.v_of[255] = 255; M.d_of[255] = W - 1;
+    return M;
+}
+inline bool bins_protocol_fits(const Consts& P, const u32* bounds, u32 W) { return P.PB >= 9 && make_bin_map(P, bounds, W).ok; }
+
+template <typename C>
+void sharded_insert_bins(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, const u32* bounds) {
+    typedef typename C::HiT HiT;
+    constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
+    typedef typename std::conditional<DROP_HI, NoHi, HiT>::type OutH;  // record layout behind pass A
+    constexpr size_t OHS = HiTraits<OutH>::has ? sizeof(u64) : 0;       // bytes of the hi part on the wire (u64 or none)
+    const Consts& P = c->P;
+    const u32 W = T.world, me = T.rank, RB = P.PB - 8;
+    const BinMap M = make_bin_map(P, bounds, W);
+    const LsdPlan LP = lsd_plan(P);
+    const DigitBits nextd{P.SB + LP.sh[0], LP.wid[0]};
+    DigitBin fn;
+    fn.SB = P.SB; fn.PB = P.PB; fn.RB = RB; fn.nd = W;
+    EncHist eh0{};
+    eh0.nd = W; eh0.SB = P.SB; eh0.PB = P.PB; eh0.binRB = RB;
+    for (u32 i = 0; i < MAX_DEST - 1; ++i) { fn.bounds[i] = i + 1 < W ? bounds[i] : 0xFFFFFFFFu; eh0.bounds[i] = fn.bounds[i]; }
+
+    // receive arena: the slices land back to back; capacity from the job's k-mer count (an upper bound: bases - (K - 1) per
+    // sequence), the rank's share of it with slack for uneven ranges; it grows when a slice does not fit
+    for (u32 s = 0; s < nslices; ++s) if (cuts[s + 1] < cuts[s] || cuts[s + 1] > n) throw Error(CBLX_EINVAL, "slice cuts must be ascending and at most n");
+    const u64 n0 = cuts[0], n1 = cuts[nslices];
+    u64 mine = 0;
+    if (n1 > n0) {
+        const u64 first = d2h<u64>(c, d_offsets + n0), last = d2h<u64>(c, d_offsets + n1);
+        if (last < first) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
+        const u64 sub = (n1 - n0) * (u64)(P.K - 1);
+        mine = last - first > sub ? last - first - sub : 0;
+    }
+    u64 job = mine;
+    T.all_reduce_sum_u64(&job, 1);
+    const u64 LIMIT = 0xFFFFFFF0ull - 2 * RDX_TILE;  // one round = one batch of the pipeline (32-bit positions)
+    const bool trace = std::getenv("CBLX_TRACE_SHARDED") != nullptr;
+    u64 cap = W == 1 ? mine : std::min<u64>(job, job / W + job / (4 * W) + (1u << 20));
+    cap = std::min<u64>(std::max<u64>(cap, 1024), LIMIT);
+    Buf<u64> a_lo;
+    Buf<u8> a_hi, a_dig;
+    auto alloc_arena = [&](u64 ncap, Buf<u64>& lo, Buf<u8>& hi, Buf<u8>& dg) {
+        lo = Buf<u64>(c->pool, ncap + 2);
+        hi = Buf<u8>(c->pool, OHS ? (ncap + 2) * OHS : 8);
+        dg = Buf<u8>(c->pool, ncap + 64);
+    };
+    struct Sent { Buf<u64> lo; Buf<u8> hi, dig; };
+    std::vector<Sent> sent;            // send buffers of the round's exchanges (alive until they have completed)
+    std::vector<u32> pcnt, pbase;      // piece table of the round: [piece][256] counts, arena position of every piece
+    u64 filled = 0;
+    struct Drain { Transport& t; ~Drain() { try { t.wait(); } catch (...) {} } } drain{T};
+    auto grow = [&](u64 need) {
+        T.wait();
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+        const u64 ncap = std::min<u64>(LIMIT, need + need / 4 + 4096);
+        Buf<u64> lo;
+        Buf<u8> hi, dg;
+        alloc_arena(ncap, lo, hi, dg);
+        if (filled) {
+            CBLX_HIP(hipMemcpyAsync(lo.get(), a_lo.get(), filled * 8, hipMemcpyDeviceToDevice, c->stream));
+            if (OHS) CBLX_HIP(hipMemcpyAsync(hi.get(), a_hi.get(), filled * OHS, hipMemcpyDeviceToDevice, c->stream));
+            CBLX_HIP(hipMemcpyAsync(dg.get(), a_dig.get(), filled, hipMemcpyDeviceToDevice, c->stream));
+            CBLX_HIP(hipStreamSynchronize(c->stream));
+        }
+        a_lo = std::move(lo); a_hi = std::move(hi); a_dig = std::move(dg);
+        cap = ncap;
+    };
+    // what has been received so far goes through the rest of the pipeline (end of the call, or the arena would pass 2^32 records)
+    auto finish_round = [&]() {
+        T.wait();
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+        sent.clear();
+        if (trace) fprintf(stderr, "[cblx bins] rank %u round ends: filled=%llu pieces=%zu\n", me, (unsigned long long)filled, pbase.size());
+        if (filled) {
+            Records rec;
+            rec.lo = std::move(a_lo);
+            rec.hi = std::move(a_hi);
+            rec.lo2 = Buf<u64>(c->pool, filled + 2);
+            rec.hi2 = Buf<u8>(c->pool, OHS ? (filled + 2) * OHS : 8);
+            PieceInput pin;
+            pin.np = (u32)pbase.size();
+            pin.cnt = pcnt.data();
+            pin.pbase = pbase.data();
+            pin.dig = &a_dig;
+            pipeline<C>(c, rec, filled, Buf<u32>(), &pin);
+            c->kmers_inserted += filled;
+        }
+        a_lo.reset(); a_hi.reset(); a_dig.reset();
+        pcnt.clear(); pbase.clear();
+        filled = 0;
+    };
+    for (u32 s = 0; s < nslices; ++s) {
+        const u64 a = cuts[s], b = cuts[s + 1];
+        // -- KRN-1 with the bin histogram fused in, column prefixes of pass A
+        ChunkPlan pl;
+        const u8* pb = d_bases;
+        u64 N = 0;
+        if (b > a) { plan_chunks(c, pb, d_offsets + a, b - a, pl); N = pl.n_kmers; }
+        if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "one slice takes fewer than 2^32-16 words (use more slices)");
+        const u32 ntiles = (u32)ceil_div(N, RDX_TILE);
+        Buf<u64> t_lo;
+        Buf<u8> t_hi;
+        Buf<u32> counts, colpre, scratch, coltot(c->pool, 256), adj(c->pool, 256);
+        std::vector<u32> tot(256, 0u);
+        if (N) {
+            const size_t hs = hi_elem_size(P);
+            t_lo = Buf<u64>(c->pool, N + 2);
+            t_hi = Buf<u8>(c->pool, hs ? (N + 2) * hs : 8);
+            counts = Buf<u32>(c->pool, (size_t)256 * (ntiles + 2));
+            colpre = Buf<u32>(c->pool, (size_t)256 * ntiles);
+            CBLX_HIP(hipMemsetAsync(counts.get(), 0, (size_t)256 * (ntiles + 2) * 4, c->stream));
+            EncHist eh = eh0;
+            eh.counts = counts.get();
+            encode<C>(c, pb, pl, t_lo.get(), (HiT*)t_hi.get(), 0, eh);
+            { StageTimer t(c, ST_SCAN);
+              colscan(c, counts.get(), nullptr, ntiles, colpre.get(), coltot.get(), scratch);
+              hipLaunchKernelGGL(k_seg_adjust, dim3(1), dim3(256), 0, c->stream, colpre.get(), coltot.get(), (const u32*)nullptr, (const u32*)nullptr,
+                                 (const u32*)nullptr, ntiles, 1u, adj.get()); }
+            CBLX_HIP(hipGetLastError());
+            tot = d2h_vec<u32>(c, coltot.get(), 256);
+        }
+        // -- what goes where: per destination the word count and the count of every segment (header of the exchange)
+        const size_t HDR = 257;
+        std::vector<u64> send((size_t)W * HDR, 0), recv((size_t)W * HDR, 0);
+        for (u32 bin = 0; bin < 256; ++bin) {
+            if (!tot[bin]) continue;
+            if (M.v_of[bin] == 0xFFFFFFFFu) throw Error(CBLX_EDEVICE, "sharded build: a word fell into a bin no prefix maps to (internal error)");
+            send[(size_t)M.d_of[bin] * HDR] += tot[bin];
+            send[(size_t)M.d_of[bin] * HDR + 1 + M.v_of[bin]] += tot[bin];
+        }
+        {
+            u64 sum = 0;
+            for (u32 d = 0; d < W; ++d) sum += send[(size_t)d * HDR];
+            if (sum != N) throw Error(CBLX_EDEVICE, "sharded build: the bin histogram counts " + std::to_string(sum) + " words, the slice has " + std::to_string(N) + " (internal error)");
+        }
+        T.all_to_all_u64(send.data(), recv.data(), HDR);
+        u64 own_a = 0, incoming = 0;
+        for (u32 d = 0; d < me; ++d) own_a += send[(size_t)d * HDR];
+        const u64 own = send[(size_t)me * HDR], own_b = own_a + own;
+        if (recv[(size_t)me * HDR] != own) throw Error(CBLX_EDEVICE, "sharded build: the count exchange returned another own count (transport error)");
+        for (u32 r = 0; r < W; ++r) incoming += recv[(size_t)r * HDR];
+        if (incoming >= LIMIT) throw Error(CBLX_ERANGE, "one slice of the job sends this rank 2^32 words or more (use more slices)");
+        if (trace) fprintf(stderr, "[cblx bins] rank %u slice %u: N=%llu own=%llu incoming=%llu filled=%llu cap=%llu mine=%llu job=%llu\n", me, s, (unsigned long long)N, (unsigned long long)own,
+                           (unsigned long long)incoming, (unsigned long long)filled, (unsigned long long)cap, (unsigned long long)mine, (unsigned long long)job);
+        if (filled + incoming > LIMIT) finish_round();
+        if (!a_lo.get()) alloc_arena(cap, a_lo, a_hi, a_dig);
+        if (filled + incoming > cap) grow(filled + incoming);
+        // -- arena layout of the slice: the own piece first (pass A writes it there), then the other sources in rank order;
+        //    the piece table keeps the logical order (slice-major, source-minor)
+        std::vector<u64> so(W + 1, 0), ro(W + 1, 0);  // record positions in the send buffer / behind the own piece
+        for (u32 d = 0; d < W; ++d) {
+            so[d + 1] = so[d] + (d == me ? 0 : send[(size_t)d * HDR]);
+            ro[d + 1] = ro[d] + (d == me ? 0 : recv[(size_t)d * HDR]);
+        }
+        for (u32 r = 0; r < W; ++r) {
+            pbase.push_back((u32)(r == me ? filled : filled + own + ro[r]));
+            for (u32 v = 0; v < 256; ++v) pcnt.push_back((u32)recv[(size_t)r * HDR + 1 + v]);
+        }
+        Sent S;
+        const u64 nsend = N - own;
+        S.lo = Buf<u64>(c->pool, nsend + 2);
+        S.hi = Buf<u8>(c->pool, OHS ? (nsend + 2) * OHS : 8);
+        S.dig = Buf<u8>(c->pool, nsend + 64);
+        if (N) {
+            const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
+            const OwnWindow ow{own_a, own_b, a_lo.get() + filled, OHS ? (void*)(a_hi.get() + filled * OHS) : nullptr, a_dig.get() + filled};
+            StageTimer t(c, ST_SCATTER);
+            hipLaunchKernelGGL((k_radix_scatter<HiT, OutH, DigitBin, true>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, (const u64*)t_lo.get(), (const HiT*)t_hi.get(), tv, fn,
+                               (const u32*)colpre.get(), (const u32*)adj.get(), S.lo.get(), (OutH*)S.hi.get(), nextd, S.dig.get(), (u32*)nullptr, 0u, 0u, 0u, (u32*)nullptr, 0u, ow);
+            CBLX_HIP(hipGetLastError());
+        }
+        // -- the exchange (on the transport's stream, behind pass A): records, hi parts, digits
+        u8* dst_lo = (u8*)(a_lo.get() + filled + own);
+        std::vector<u64> sob(W + 1), rob(W + 1);
+        auto xchg = [&](const u8* src, u8* dst, size_t es) {
+            for (u32 d = 0; d <= W; ++d) { sob[d] = so[d] * es; rob[d] = ro[d] * es; }
+            T.exchange(src, sob.data(), dst, rob.data(), c->stream);
+        };
+        if (W > 1) {
+            xchg((const u8*)S.lo.get(), dst_lo, 8);
+            if (OHS) xchg(S.hi.get(), a_hi.get() + (filled + own) * OHS, OHS);
+            xchg(S.dig.get(), a_dig.get() + filled + own, 1);
+        }
+        filled += incoming;
+        sent.push_back(std::move(S));
+        CBLX_HIP(hipStreamSynchronize(c->stream));  // the slice's workspace (words, count matrix) goes back to the pool here
+    }
+    finish_round();
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+}
+
+template <typename C>
+void sharded_insert(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, u32* bounds, int* bounds_valid) {
+    Transport& T = *cm->t;
+    if (nslices && !*bounds_valid) {
+        if (cuts[1] < cuts[0] || cuts[1] > n) throw Error(CBLX_EINVAL, "slice cuts must be ascending and at most n");
+        choose_bounds_from_slice<C>(c, T, d_bases, d_offsets + cuts[0], cuts[1] - cuts[0], bounds);
+        *bounds_valid = 1;
+    }
+    if (cm->protocol == CBLX_PROTO_BINS && bins_protocol_fits(c->P, bounds, T.world))
+        sharded_insert_bins<C>(c, T, d_bases, d_offsets, n, cuts, nslices, bounds);
+    else
+        sharded_insert_sorted<C>(c, T, d_bases, d_offsets, n, cuts, nslices, bounds, bounds_valid);
 }
 
 }  // namespace

@@ -48,14 +48,19 @@ static const u32 ENC_MAX_KMERS = ENC_MAX_BASES;                            // k-
 static const u32 ENC_HIST_WINDOW = 4096;
 static const u32 ENC_HIST_WINDOWS = ENC_MAX_KMERS / ENC_HIST_WINDOW + 2;
 struct EncHist {
-    u32* counts;  // null: no fused histogram
+    u32* counts;                  // null: no fused histogram
     u32 shift, nbits;             // digit = bit field of the word ...
     u32 nd, SB, PB, bounds[15];   // ... or, when nd != 0, the destination rank of its prefix: #{i < nd-1 : bounds[i] <= prefix}
+    u32 binRB;                    // ... or, when nd != 0 and binRB != 0, the sender's pass-A BIN (DigitBin, kernels_radix.hpp): (prefix >> binRB) + rank
     __device__ __forceinline__ u32 digit(u64 lo, u64 hi) const {
         if (nd == 0) return get_bits(lo, hi, shift, nbits);
         const u32 p = get_bits(lo, hi, SB, PB);
         u32 d = 0;
         for (u32 i = 0; i + 1 < nd; ++i) d += bounds[i] <= p ? 1u : 0u;  // nd is uniform: nd - 1 scalar-bound compares
+        if (binRB) {
+            const u32 v = p >> binRB, b = v + d;
+            return v >= 255u ? 255u : (b < 254u ? b : 254u);
+        }
         return d;
     }
 };

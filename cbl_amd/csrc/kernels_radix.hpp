@@ -224,6 +224,32 @@ struct DigitDest {
     }
 };
 
+// ... or (sender side of the multi-GPU build, comm.hpp) the BIN of its prefix: the value of the top prefix bits pass A sorts
+// by, refined by the destination rank, bin = (prefix >> RB) + #{i : bounds[i] <= prefix}. Monotone in the prefix, so a pass on
+// it leaves the records contiguous per destination AND per pass-A segment inside every destination. It fits 8 bits: a
+// necklace with its top bit set is all ones (every bit comes to the top under some rotation, and the necklace is the
+// smallest rotation), so the top-8 values 128..254 never occur and 0..127 + (nd - 1 <= 15) stays below 255, which is left
+// to the all-ones word.
+struct DigitBin {
+    u32 SB, PB, RB, nd;
+    u32 bounds[MAX_DEST - 1];
+    __device__ __forceinline__ u32 operator()(u64 lo, u64 hi) const {
+        const u32 p = get_bits(lo, hi, SB, PB);
+        u32 d = 0;
+        for (u32 i = 0; i + 1 < nd; ++i) d += bounds[i] <= p ? 1u : 0u;
+        const u32 v = p >> RB, b = v + d;
+        return v >= 255u ? 255u : (b < 254u ? b : 254u);
+    }
+};
+// Where the records of the sender's OWN destination go: positions [a, b) of the pass's output order leave for other arrays
+// (position - a); what lies behind them moves down by b - a, so the send buffer holds the other ranks' records only.
+struct OwnWindow {
+    u64 a, b;
+    u64* lo;
+    void* hi;
+    u8* next;
+};
+
 // XCD-aware workgroup -> tile map. The dispatcher is observed to place workgroup b on XCD b % 8 (speed only, never
 // relied on for correctness): XCD x then walks the CONTIGUOUS tile range [x * per, (x + 1) * per) in order, so the runs
 // that neighbouring tiles append to the same bin are written through the same L2 close in time and their partial
@@ -365,14 +391,14 @@ __global__ __launch_bounds__(64 * HISTB_WAVES) void k_radix_hist_bytes(const u8*
 // scatter. colpre[tile * 256 + d] = records with digit d in earlier tiles (pure column prefix); adj[seg * 256 + d] turns it
 // into a global position (k_seg_adjust). OutHiT = NoHi drops the hi part on the way out (first pass of 65..72-bit words:
 // the bits it held are implied by the segment from then on).
-template <typename HiT, typename OutHiT, typename DigitFn>
+template <typename HiT, typename OutHiT, typename DigitFn, bool REDIR = false>
 __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT>::has) ? 4 : 8) void k_radix_scatter(const u64* __restrict__ lo, const HiT* __restrict__ hi, TileView tv,
                                                                DigitFn dfn, const u32* __restrict__ colpre,
                                                                const u32* __restrict__ adj, u64* __restrict__ out_lo,
                                                                OutHiT* __restrict__ out_hi, DigitBits next_dfn = DigitBits{0, 0},
                                                                u8* __restrict__ out_next = nullptr, u32* __restrict__ start_dense = nullptr,
                                                                u32 pfx_shift = 0, u32 pfx_bits = 0, u32 grp_bits = 0, u32* __restrict__ amb = nullptr,
-                                                               u32 amb_stride = 0) {
+                                                               u32 amb_stride = 0, OwnWindow ow = OwnWindow{0, 0, nullptr, nullptr, nullptr}) {
     constexpr bool STAGE_HI = HiTraits<HiT>::has && HiTraits<OutHiT>::has;
     __shared__ u64 s_lo[RDX_TILE];
     __shared__ typename std::conditional<STAGE_HI, HiT, u8>::type s_hi[STAGE_HI ? RDX_TILE : 1];
@@ -431,12 +457,23 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
             u32 d;
             if constexpr (STAGE_HI) { b = (u64)s_hi[s]; d = dfn(a, b); }
             else d = s_dig[s];
-            const u64 dst = s_gbase[d] + s;
+            u64 dst = s_gbase[d] + s;
+            if constexpr (REDIR) {  // multi-GPU sender: the records of its own prefix range go straight to the receive arena
+                const bool own = dst >= ow.a && dst < ow.b;
+                dst -= own ? ow.a : (dst >= ow.b ? ow.b - ow.a : 0ull);
+                u64* pl = own ? ow.lo : out_lo;
+                OutHiT* ph = own ? (OutHiT*)ow.hi : out_hi;
+                u8* pn = own ? ow.next : out_next;
+                pl[dst] = a;
+                st_hi<OutHiT>(ph, dst, b);
+                if (pn) pn[dst] = (u8)next_dfn(a, b);
+            } else {
             out_lo[dst] = a;
             st_hi<OutHiT>(out_hi, dst, b);
             // side channel: the next pass's histogram reads 1 byte per record instead of the record (measured: packing four
             // digits of a run into one unaligned dword store is slower than the byte stores — the extra LDS pass costs more)
             if (out_next) out_next[dst] = (u8)next_dfn(a, b);
+            }
             // LAST pass, bucket directory on the fly: the tile (sorted by this digit, and by the lower digits before that)
             // is in final order, so a record whose prefix differs from its predecessor's starts a bucket — unless an
             // earlier tile holds the same prefix, which can only be for the GROUP (value of the lower digits) the tile
@@ -645,6 +682,63 @@ __global__ __launch_bounds__(256) void k_boundaries_cold(const u64* __restrict__
         const u32 p = get_bits(lo[i], (u64)ld_hi<HiT>(hi, i), SB, R);
         if (i == a || get_bits(lo[i - 1], (u64)ld_hi<HiT>(hi, i - 1), SB, R) != p) start_dense[(s << R) | p] = i;
     }
+}
+
+// ---- tiles of the first LSD pass over records that ARRIVE in pieces (receiver of the multi-GPU build) ------------------
+// A piece = what one (slice, source rank) sent: its records for this rank, already sorted by the pass-A segment (segment
+// = top prefix bits), cnt[piece][256] records per segment, first record at arena position pbase[piece]. Stream order
+// inside a segment = piece order, so the tiles of a segment are the tiles of its pieces in piece order; a tile never
+// straddles a piece. Everything behind this pass sees one contiguous array again (the pass writes to seg_start-based
+// positions).
+//   k_piece_tables (one workgroup, thread v = segment): seg_start / seg_first / tile count, and per (segment, piece) the
+//   first tile (pfirst) and the arena position (ppos).   k_piece_tile_table: one thread per tile.
+__global__ __launch_bounds__(256) void k_piece_tables(const u32* __restrict__ cnt /* [np][256] */, const u32* __restrict__ pbase /* [np] */, u32 np,
+                                                      u32* __restrict__ seg_start /* 257 */, u32* __restrict__ seg_first /* 257 */, u32* __restrict__ ntiles_dev,
+                                                      u32* __restrict__ pfirst /* [256][np] */, u32* __restrict__ ppos /* [256][np] */,
+                                                      u32* __restrict__ seg_tot /* 256: what pass A's column totals would be */) {
+    __shared__ u32 sm[256 / 64 + 1];
+    const u32 v = threadIdx.x;
+    u32 tot = 0, tiles = 0;
+    for (u32 p = 0; p < np; ++p) {
+        const u32 c = cnt[p * 256 + v];
+        const u32 ex = block_exclusive_scan<256, u32>(c, sm, nullptr);  // records of the piece in earlier segments
+        ppos[v * np + p] = pbase[p] + ex;
+        tot += c;
+        tiles += (c + RDX_TILE - 1) / RDX_TILE;
+    }
+    u32 all, tall;
+    const u32 st = block_exclusive_scan<256, u32>(tot, sm, &all);
+    const u32 ft = block_exclusive_scan<256, u32>(tiles, sm, &tall);
+    seg_start[v] = st;
+    seg_first[v] = ft;
+    seg_tot[v] = tot;
+    if (v == 255) { seg_start[256] = all; seg_first[256] = tall; *ntiles_dev = tall; }
+    u32 run = ft;
+    for (u32 p = 0; p < np; ++p) {
+        pfirst[v * np + p] = run;
+        run += (cnt[p * 256 + v] + RDX_TILE - 1) / RDX_TILE;
+    }
+}
+__global__ void k_piece_tile_table(const u32* __restrict__ cnt, u32 np, const u32* __restrict__ seg_first, const u32* __restrict__ ntiles_dev,
+                                   const u32* __restrict__ pfirst, const u32* __restrict__ ppos, u32* __restrict__ t_start, u32* __restrict__ t_count,
+                                   u16* __restrict__ t_seg) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *ntiles_dev) return;
+    u32 lo = 0, hi = 256;  // last segment with seg_first[s] <= t (segments without tiles share their successor's first tile)
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (seg_first[mid] <= t) lo = mid; else hi = mid;
+    }
+    const u32* pf = pfirst + lo * np;
+    u32 a = 0, b = np;     // last piece of the segment with pfirst <= t
+    while (b - a > 1) {
+        const u32 mid = (a + b) >> 1;
+        if (pf[mid] <= t) a = mid; else b = mid;
+    }
+    const u32 off = (t - pf[a]) * RDX_TILE, c = cnt[a * 256 + lo];
+    t_start[t] = ppos[lo * np + a] + off;
+    t_count[t] = c - off < (u32)RDX_TILE ? c - off : (u32)RDX_TILE;
+    t_seg[t] = (u16)lo;
 }
 
 }  // namespace cblx

@@ -18,10 +18,37 @@ struct Records {
     const void* ext_hi = nullptr;
 };
 
+// Records that arrive with the first partition pass already done and in PIECES (receiver of the multi-GPU build, comm.hpp):
+// rec.lo (and rec.hi for words that keep their hi part) is the receive arena; piece p = what one (slice, source rank) sent,
+// sorted by the pass-A segment, cnt[p][256] records per segment from arena position pbase[p]; stream order = piece order.
+struct PieceInput {
+    u32 np = 0;
+    const u32* cnt = nullptr;    // host [np][256]
+    const u32* pbase = nullptr;  // host [np]
+    Buf<u8>* dig = nullptr;      // the first LSD pass's digit of every record (same positions), owned by the caller; reused as the side channel
+};
+
+// the LSD passes behind pass A: digit widths and shifts (relative to SUFFIX_BITS) of the RB = PB - min(8, PB) remaining prefix bits
+struct LsdPlan { u32 npass = 0, wid[4] = {0, 0, 0, 0}, sh[5] = {0, 0, 0, 0, 0}; };
+inline LsdPlan lsd_plan(const Consts& P) {
+    // Up to two passes: 8 bits, then the rest (the group-cut tiles of the last pass are built for that shape). Three passes
+    // (PREFIX_BITS > 24): the bits are spread evenly — 20 bits go as 7 + 7 + 6 instead of 8 + 8 + 4: a pass costs nearly the
+    // same whatever its width (4.0 ms at 4 bits, 4.4 at 8 on 1.2 G records), but one that also writes the digit side channel
+    // costs 5.15 ms at 8 bits and 4.45 at 7 (narrower digits).
+    LsdPlan L;
+    const u32 RB = P.PB - std::min(8u, P.PB);
+    L.npass = (RB + 7) / 8;
+    for (u32 i = 0; i < L.npass; ++i) {
+        L.wid[i] = L.npass <= 2 ? std::min(8u, RB - 8 * i) : RB / L.npass + (i < RB % L.npass ? 1u : 0u);
+        L.sh[i + 1] = L.sh[i] + L.wid[i];
+    }
+    return L;
+}
+
 // KRN-2 + KRN-4 over N records: stable partition by prefix, then the directory (bitvector, rank directory, bucket table
 // with the RAW run of every prefix; nr.cnt / nr.kind are allocated, not filled). The sorted records end up in rec.lo/hi.
 // `countsA`: histogram of the first pass already accumulated by KRN-1 (empty Buf = compute it here)
-template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA, Resident& nr) {
+template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA, Resident& nr, const PieceInput* pin = nullptr) {
     typedef typename C::HiT HiT;
     const Consts& P = c->P;
     if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "a single batch takes fewer than 2^32-16 words (callers cut larger inserts into sub-batches)");
@@ -46,17 +73,13 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
     Buf<u32> start_dense(c->pool, nprefix);
     bool have_dense = false;
     {
-        const u32 ntiles = (u32)ceil_div(N, RDX_TILE), nt_max = ntiles + 256;
-        const u32 npassL = (RB + 7) / 8, nseg = 1u << nA;
-        // Digit widths of the LSD passes. Up to two passes: 8 bits, then the rest (the group-cut tiles below are built for
-        // that shape). Three passes (PREFIX_BITS > 24): the bits are spread evenly — 20 bits go as 7 + 7 + 6 instead of
-        // 8 + 8 + 4: a pass costs nearly the same whatever its width (4.0 ms at 4 bits, 4.4 at 8 on 1.2 G records), but one
-        // that also writes the digit side channel costs 5.15 ms at 8 bits and 4.45 at 7 (narrower digits).
-        u32 wid[4] = {0, 0, 0, 0}, sh[5] = {0, 0, 0, 0, 0};
-        for (u32 i = 0; i < npassL; ++i) {
-            wid[i] = npassL <= 2 ? std::min(8u, RB - 8 * i) : RB / npassL + (i < RB % npassL ? 1u : 0u);
-            sh[i + 1] = sh[i] + wid[i];
-        }
+        // pieces: every (segment, piece) may end in a partly filled tile
+        const u32 ntiles = (u32)ceil_div(N, RDX_TILE), nt_max = ntiles + 256 * (pin ? std::max(1u, pin->np) : 1u);
+        const LsdPlan LP = lsd_plan(P);
+        const u32 npassL = LP.npass, nseg = 1u << nA;
+        const u32 (&wid)[4] = LP.wid;
+        const u32 (&sh)[5] = LP.sh;
+        if (pin && (npassL == 0 || nA != 8)) throw Error(CBLX_EINVAL, "records in pieces need PREFIX_BITS >= 9 (internal error)");
         // The last LSD pass cuts its tiles at (segment x lower digits) groups when there are few enough of them; the
         // bucket directory then comes from that pass's tables (k_dir_gather) instead of a scan of the sorted records.
         const u32 low_bits = npassL ? sh[npassL - 1] : 0, last_bits = RB - low_bits;
@@ -82,13 +105,29 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
         // digit side channel: a scatter also writes the NEXT pass's digit of every record (1 byte, same order). (When the
         // hi byte is dropped by pass A the remaining digits all lie in the lo word: the word has <= 72 bits.)
         Buf<u8> dig;
+        Buf<u32> seg_tot;  // pieces: records per pass-A segment
         bool have_dig = false;
         auto next_digit = [&](u32 next_pass) -> DigitBits {
             if (next_pass >= npassL) return DigitBits{0, 0};
             return DigitBits{P.SB + sh[next_pass], wid[next_pass]};
         };
-        if (next_digit(0).nbits) dig = Buf<u8>(c->pool, N + 64);
-        {   // pass A
+        if (pin && pin->dig) { dig = std::move(*pin->dig); have_dig = dig.get() != nullptr; }
+        else if (next_digit(0).nbits) dig = Buf<u8>(c->pool, N + 64);
+        if (pin) {
+            // pass A ran on the senders: segment and tile tables of the first LSD pass from the piece table
+            StageTimer t(c, ST_SCAN);
+            const u32 np = pin->np;
+            seg_tot = Buf<u32>(c->pool, 256);
+            Buf<u32> d_cnt(c->pool, (size_t)np * 256), d_pbase(c->pool, np), pfirst(c->pool, (size_t)np * 256), ppos(c->pool, (size_t)np * 256);
+            h2d(c, d_cnt.get(), pin->cnt, (size_t)np * 256);
+            h2d(c, d_pbase.get(), pin->pbase, np);
+            hipLaunchKernelGGL(k_piece_tables, dim3(1), dim3(256), 0, c->stream, d_cnt.get(), d_pbase.get(), np, seg_start.get(), seg_first.get(), nt_dev.get(), pfirst.get(), ppos.get(),
+                               seg_tot.get());
+            hipLaunchKernelGGL(k_piece_tile_table, grid1(nt_max, 256), dim3(256), 0, c->stream, d_cnt.get(), np, seg_first.get(), nt_dev.get(), pfirst.get(), ppos.get(), t_start.get(),
+                               t_count.get(), t_seg.get());
+            CBLX_HIP(hipGetLastError());
+            CBLX_HIP(hipStreamSynchronize(c->stream));  // the piece tables are released here
+        } else {   // pass A
             const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
             const DigitBits dfn{P.SB + RB, nA};
             const DigitBits nd = next_digit(0);
@@ -162,6 +201,13 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
                     have_dense = true;
                 }
                 have_dig = ndp != nullptr;
+                if (pin && pass == 0 && !last) {
+                    // the piece tiles described the arena; from here on the segments are contiguous: the plain tile table
+                    // (the column totals of the pass that made the segments were kept aside: this pass's scan overwrote coltot)
+                    StageTimer t(c, ST_SCAN);
+                    hipLaunchKernelGGL(k_seg_table, dim3(1), dim3(256), 0, c->stream, (const u32*)seg_tot.get(), seg_start.get(), seg_first.get(), nt_dev.get());
+                    hipLaunchKernelGGL(k_tile_table, grid1(nt_max, 256), dim3(256), 0, c->stream, seg_start.get(), seg_first.get(), nt_dev.get(), t_start.get(), t_count.get(), t_seg.get());
+                }
                 if (last && tbl_dir) {
                     StageTimer t(c, ST_DIR);
                     hipLaunchKernelGGL(k_dir_gather, dim3(G), dim3(256), 0, c->stream, low_bits, last_bits, grp_tiles ? grp_first.get() : seg_first.get(), seg_start.get(), ntd,
@@ -468,12 +514,12 @@ __global__ void k_run_lengths(u64 nb, const u64* __restrict__ start, u32* __rest
 //   Non-empty index: only the NEW words are partitioned; the resident buckets are already grouped by prefix, so the merged
 //   directory is the OR of the two bitvectors and every merged run = [resident suffixes as stored][new words of the
 //   prefix] is gathered straight from the two arrays (the resident words are never expanded and re-partitioned).
-template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA = Buf<u32>()) {
+template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA = Buf<u32>(), const PieceInput* pin = nullptr) {
     typedef typename C::HiT HiT;
     constexpr bool WS = C::WS;
     const Consts& P = c->P;
     Resident nb_;  // directory of the batch
-    partition_and_directory<C>(c, rec, N, std::move(countsA), nb_);
+    partition_and_directory<C>(c, rec, N, std::move(countsA), nb_, pin);
     auto adopt_arena = [&](Resident& nr) {
         nr.a_lo = std::move(rec.lo);
         if (WS) {  // arena hi lives in the records' hi buffer (u64 elements in this configuration)

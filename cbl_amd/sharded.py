@@ -245,15 +245,21 @@ class ShardedBuilder(_Wire):
     i.e. file order when the file is dealt to the ranks block-cyclically; with slices=1 it is plain rank order.
     """
 
-    def __init__(self, cbl, dist, engine=None, slices: int = 4, slack: float = 1.3, protocol: str = "sorted", comm=None):
-        """comm: a cbl_amd.Comm — the whole insert then runs inside libcblx (cblx_sharded_insert_seqs_device: "sorted"
-        protocol, exchange on RCCL directly); `dist` is still used for the few host-side agreements (slice counts)."""
+    def __init__(self, cbl, dist, engine=None, slices: int = 4, slack: float = 1.3, protocol: str | None = None, comm=None):
+        """comm: a cbl_amd.Comm — the whole insert then runs inside libcblx (cblx_sharded_insert_seqs_device, exchange on
+        RCCL directly; protocol "bins" (default there: the exchange sits between the first and the second partition pass,
+        nothing is partitioned twice or copied) or "sorted"); `dist` is still used for the few host-side agreements (slice
+        counts). Without comm the device steps are driven from here over torch.distributed: "sorted" (default) or "words"."""
         self.cbl = cbl
         self.engine = engine or GpuEngine(cbl)
-        if protocol not in ("sorted", "words"):
-            raise ValueError("protocol must be 'sorted' or 'words'")
-        self.protocol = protocol if hasattr(self.engine, "sorted_batch_begin") else "words"
+        if protocol is None:
+            protocol = "bins" if comm is not None else "sorted"
+        if protocol not in (("sorted", "bins") if comm is not None else ("sorted", "words")):
+            raise ValueError("protocol must be 'sorted' or 'bins' with a native communicator, 'sorted' or 'words' without")
+        self.protocol = protocol if (comm is not None or hasattr(self.engine, "sorted_batch_begin")) else "words"
         self.comm = comm
+        if comm is not None:
+            comm.set_protocol(self.protocol)
         self._wire_init(dist)
         self.slices, self.slack = max(1, slices), slack
         self.bounds = None  # fixed by the first batch so later batches land on the same owners

@@ -212,6 +212,18 @@ void cblx_comm_destroy(cblx_comm* comm);
 const char* cblx_comm_last_error(const cblx_comm* comm);
 typedef struct cblx_exchange_stats { uint64_t sent_bytes, recv_bytes, messages; } cblx_exchange_stats; /* own runs excluded */
 int cblx_comm_stats(cblx_comm* comm, cblx_exchange_stats* out, int reset);
+/* What crosses the links in cblx_sharded_insert_seqs_device (every rank of a job sets the same):
+ *   CBLX_PROTO_BINS (default): the exchange sits between the first and the second partition pass. The sender runs KRN-1 and
+ *     the first pass on bins that refine that pass's digit by the destination rank; 8-byte records (16 for words that keep
+ *     a 64-bit hi part) + 1 digit byte per word cross the links, the receiver runs the remaining passes and the bucket
+ *     kernels on what arrived. No pass is added to the one-GPU pipeline and nothing is copied: the choice when the kernels
+ *     are the bound (8 GPUs). Needs PREFIX_BITS >= 9, else SORTED is used.
+ *   CBLX_PROTO_SORTED: the sender partitions completely; non-empty prefixes, counts and the suffixes packed to
+ *     cblx_consts.bytes cross the links (6.1 B per word at K = 31 / PREFIX_BITS = 24), the receiver merges the batches run
+ *     by run (one more pass over the words): the choice when the links are the bound (2-4 GPUs). */
+#define CBLX_PROTO_SORTED 0u
+#define CBLX_PROTO_BINS 1u
+int cblx_comm_set_protocol(cblx_comm* comm, uint32_t protocol);
 /* CBL::insert_seq for every sequence of THIS rank's shard, into an index sharded by prefix range over the ranks of `comm`
  * (every rank makes the same call with its own shard). The shard is consumed in n_slices slices, reads
  * [slice_cuts[s], slice_cuts[s+1]) (n_slices + 1 ascending values, the same NUMBER of slices on every rank): the exchange of

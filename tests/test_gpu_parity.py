@@ -1756,7 +1756,9 @@ def test_native_sharded_insert_single_rank_rccl():
     uid = cbl_amd.Comm.unique_id()
     assert len(uid) == 128
     comm = cbl_amd.Comm.rccl(uid, 0, 1, 0)
-    for k, pb, canonical in ((31, 24, False), (59, 28, True), (25, 12, False)):
+    for k, pb, canonical, proto in ((31, 24, False, "bins"), (59, 28, True, "bins"), (25, 12, False, "bins"), (31, 24, True, "sorted"), (27, 8, False, "bins"),
+                                    (59, 28, False, "sorted"), (31, 28, True, "bins"), (15, 20, False, "bins")):
+        comm.set_protocol(proto)  # "bins" at PREFIX_BITS = 8 falls back to "sorted" inside the library
         d_b, d_o = synth.reads_torch(42, 3000, 150, device="cuda")
         a, b = cbl_amd.CBL(k, pb, canonical=canonical), cbl_amd.CBL(k, pb, canonical=canonical)
         a.insert_seqs_device(d_b, d_o, 3000)
@@ -1774,7 +1776,7 @@ def test_native_sharded_insert_single_rank_rccl():
     comm.close()
 
 
-def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q):
+def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q, protocol="bins"):
     import torch.distributed as dist
 
     from cbl_amd import sharded
@@ -1785,7 +1787,7 @@ def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q):
     try:
         comm = cbl_amd.Comm.over_group(dist, rank, world, 0)  # host callbacks: the ranks share this GPU
         g = cbl_amd.CBL(k, pb, canonical=canonical, device=0)
-        sb = sharded.ShardedBuilder(g, dist, slices=3, comm=comm)
+        sb = sharded.ShardedBuilder(g, dist, slices=3, comm=comm, protocol=protocol)
         for batch, n in enumerate(per[rank]):  # two batches; the second reuses the first one's splitters
             first = sum(per[r][bb] for r in range(world) for bb in range(batch)) + sum(per[r][batch] for r in range(rank))
             d_b, d_o = synth.reads_torch(23, n, L, first_read=first, device="cuda:0")
@@ -1794,7 +1796,7 @@ def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q):
         fblob = None
         if path:
             h = cbl_amd.CBL(k, pb, canonical=canonical, device=0)
-            sf = sharded.ShardedBuilder(h, dist, slices=3, comm=comm)
+            sf = sharded.ShardedBuilder(h, dist, slices=3, comm=comm, protocol=protocol)
             sf.insert_fastx_file(path, 5)
             fblob = sharded.gather_serialized(h.serialize(), dist)
         if rank == 0:
@@ -1804,8 +1806,10 @@ def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k,pb,canonical", [(2, 31, 24, False), (3, 59, 28, True), (4, 25, 12, False), (8, 31, 24, False)])
-def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canonical, tmp_path):
+@pytest.mark.parametrize("world,k,pb,canonical,protocol", [(2, 31, 24, False, "bins"), (3, 59, 28, True, "bins"), (4, 25, 12, False, "bins"), (8, 31, 24, False, "bins"),
+                                                           (3, 31, 28, True, "bins"), (2, 21, 16, False, "bins"), (5, 59, 28, False, "bins"),
+                                                           (2, 31, 24, False, "sorted"), (3, 59, 28, True, "sorted"), (8, 31, 24, False, "sorted")])
+def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canonical, protocol, tmp_path):
     """The C++ orchestration of the multi-GPU build (slices, splitter choice, count exchange, grouped exchange, batch merge)
     with `world` ranks sharing this GPU and the bytes moved by host callbacks over gloo: byte-identical to the one-process
     oracle in the job's stream order (slice-major, rank-minor), and to the file's order for a file dealt block-cyclically."""
@@ -1826,7 +1830,7 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_native_worker, args=(r, world, port, k, pb, canonical, per, L, path, q)) for r in range(world)]
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, k, pb, canonical, per, L, path, q, protocol)) for r in range(world)]
     for p in procs:
         p.start()
     blob, bounds, count0, fblob, sent = q.get(timeout=900)

@@ -71,7 +71,8 @@ def _worker(rank, world, port, k, pb, canonical, protocol, native, per, L, q):
 
 
 @pytest.mark.parametrize("world,k,pb,canonical,protocol,native", [(2, 31, 24, False, "sorted", False), (2, 31, 24, True, "words", False), (2, 59, 28, False, "sorted", True),
-                                                                  (4, 31, 24, False, "sorted", True), (8, 31, 28, False, "sorted", False)])
+                                                                  (4, 31, 24, False, "sorted", True), (8, 31, 28, False, "sorted", False),
+                                                                  (2, 31, 24, False, "bins", True), (4, 59, 28, True, "bins", True), (8, 31, 28, False, "bins", True)])
 def test_sharded_build_and_merge_on_real_rccl(world, k, pb, canonical, protocol, native):
     if _ngpu() < world:
         pytest.skip(f"needs {world} GPUs in one box, {_ngpu()} visible (RCCL refuses two ranks on one GPU)")
