@@ -70,13 +70,14 @@ def stage_alg_bytes(k: int, pb: int, read_len: int):
     # digit side channel: a scatter also writes the next pass's digit (1 B); that pass's histogram then reads 1 B per
     # record instead of the record
     side = lsd
-    tbl_dir = lsd >= 1 and n_a + 8 * (lsd - 1) <= 16      # bucket directory from the last pass's tables (no record scan)
     return {
         "chunks": read_len / (read_len - k + 1),             # validity scan reads every base once
         "encode": read_len / (read_len - k + 1) + r_in,        # read bases, write one record (+ fused first-pass histogram)
         "radix_hist": float(side),                             # pass A's histogram is fused in KRN-1; the others read the side channel
         "radix_scatter": (r_in + r_out) + lsd * 2 * r_out + side,  # every pass reads + writes every record once
-        "directory": 0.0 if tbl_dir else r_out,                # boundary detection reads the sorted records only when the tables cannot give it
+        # bucket starts: from the last pass's tables (k_dir_gather) or stored by the last scatter itself (PREFIX_BITS > 24,
+        # k_dir_resolve); the sorted records are re-read for them only when there is no LSD pass at all (PREFIX_BITS <= 8)
+        "directory": 0.0 if lsd >= 1 else r_out,
         "bucket_medium": 2 * sfx,                              # read the run, write the distinct suffixes
         "bucket_small": 2 * sfx,
         "bucket_huge": 2 * sfx,
@@ -131,9 +132,11 @@ def parse_args(argv=None):
     ap.add_argument("--slices", type=int, default=4)
     ap.add_argument("--transport", choices=["torch", "native"], default="native",
                     help="N > 1: exchange driven from Python over torch.distributed, or the whole sharded insert inside libcblx on RCCL directly")
-    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=None,
+                    help="reads of the CPU leg (default: about 20-30 s of CPU work: 1 M at PREFIX_BITS <= 24, 125 k at 28, 60 k at K = 59)")
     ap.add_argument("--cpu-full", action="store_true", help="time the CPU oracle on the whole workload (cfg 2: about 4 minutes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-serialize", action="store_true", help="skip the serialize leg (index bytes into a host buffer)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (value_h2d_inclusive)")
     ap.add_argument("--force-sharded", action="store_true", help="dev: run the N-GPU code path on a 1-rank RCCL group")
     ap.add_argument("--shared-gpu", action="store_true", help="dry run: all ranks on GPU 0, exchange staged through gloo")
@@ -148,6 +151,8 @@ def parse_args(argv=None):
             setattr(args, name, cfg[name])
     args.kind = cfg["kind"]
     args.genome = cfg.get("genome", 0)
+    if args.cpu_sample_reads is None:  # the oracle slows down with PREFIX_BITS (2^28-bit Fenwick bitvector) and word width
+        args.cpu_sample_reads = 60_000 if args.k > 45 else (125_000 if args.prefix_bits > 24 else 1_000_000)
     return args
 
 
@@ -174,6 +179,38 @@ def build_in_child():
             subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], check=True, cwd=ROOT, env=env, stdout=sys.stderr)
         finally:
             fcntl.flock(lk, fcntl.LOCK_UN)
+
+
+def cpu_baseline_leg(args, genome_reads=None):
+    """The CPU oracle (C++ port of the reference algorithm, oracle/) on a bounded sample of the same reads, 1 thread: one
+    insert_seq call per read. Needs no GPU and no process group: at N > 1 rank 0 runs it BEFORE the group is formed (the other
+    ranks wait in the rendezvous), so every line of a scaling run carries it."""
+    import numpy as np_
+
+    from cbl_amd import synth
+    from oracle import Oracle
+
+    K, PB, L, NR = args.k, args.prefix_bits, args.read_len, args.reads
+    ns = NR if args.cpu_full else min(args.cpu_sample_reads, NR)
+    orc = Oracle(K, PB, args.canonical)
+    secs, done, blk = 0.0, 0, 1_000_000
+    curve = []
+    while done < ns:  # fed in blocks of 1 M reads so that the decline with index size is on record
+        m = min(blk, ns - done)
+        if genome_reads is not None:
+            b, _ = genome_reads(done, m)
+            o = (np_.arange(m + 1, dtype=np_.uint64) * np_.uint64(L))
+        else:
+            b, o = synth.reads(42, m, L, first_read=done)
+        s1 = orc.insert_seqs(b, o)
+        secs += s1
+        done += m
+        curve.append(round(m * (L - K + 1) / s1 / 1e6, 2))
+    return {"value": round(ns * (L - K + 1) / secs, 1), "unit": "k-mers/s", "cores": 1, "kind": "port",
+            "sample": (f"all {ns} reads" if ns == NR else f"first {ns} of rank 0's reads") + f" (seed 42), one insert_seq call per read, {secs:.1f} s"
+                      + ("" if ns == NR else "; throughput falls as the index grows, so the full-size CPU figure is lower (profiles/ holds a full run)"),
+            "mkmers_per_s_by_1M_read_block": curve if len(curve) > 1 else None,
+            "host_cores_available": os.cpu_count()}
 
 
 # ---- launcher: `python bench.py --gpus N` without torchrun -------------------------------------------------------------
@@ -218,6 +255,11 @@ def main():
     # preload); under torchrun local rank 0 builds and the others wait on a lock file for it
     if not os.environ.get("CBLX_BENCH_CHILD"):
         build_in_child()
+
+    # the CPU leg first: no GPU, no process group (rank 0 only; at N > 1 the other ranks wait for it in the rendezvous)
+    cpu_early = None
+    if rank == 0 and not args.no_cpu_baseline and args.kind == "build" and not args.genome:
+        cpu_early = cpu_baseline_leg(args)
 
     import torch
 
@@ -426,6 +468,42 @@ def main():
                 "achieved": round(count / max(world, 1) * args.steps / dt * 3 * by / 1e9, 1),
                 "frac": round(count / max(world, 1) * args.steps / dt * 3 * by / 1e9 / HBM_PEAK_GBPS, 4)}
 
+    # what the N-GPU code path costs a rank over the direct build of the same reads (no exchange, no slices): the direct steps
+    # run AFTER the timed region, each rank on its own reads
+    if args.kind == "build" and engine is not None:
+        cbl.clear()
+        cbl.insert_seqs_device(d_bases, d_offsets, NR)  # warm-up of the direct path's allocations
+        fence()
+        cbl.stage_times_reset()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            cbl.clear()
+            cbl.insert_seqs_device(d_bases, d_offsets, NR)
+        torch.cuda.synchronize()
+        d_dt = time.perf_counter() - t1
+        d_stages = cbl.stage_times()
+        sh_ms, di_ms = dt / args.steps * 1e3, d_dt / args.steps * 1e3
+        extra["sharded_overhead"] = {
+            "direct_ms": round(di_ms, 3), "sharded_ms": round(sh_ms, 3), "ratio": round(sh_ms / di_ms, 4),
+            "direct_stage_ms": {n: round(ms / args.steps, 3) for n, (ms, _) in d_stages.items() if ms > 0},
+            "sharded_stage_ms": {n: round(ms / args.steps, 3) for n, (ms, _) in stages.items() if ms > 0},
+            "note": "rank 0, same reads: cblx_insert_seqs_device (direct) against the sharded insert; at N = 1 the exchange is a 1-rank group, "
+                    "so sharded - direct = slices, bins / batches, receive arena, piece tables"}
+        fence()
+
+    # SURVEY.md §8d "also with serialization": the index bytes of this rank's share — size pass, then into a host buffer
+    if args.kind == "build" and not args.no_serialize:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nbytes = cbl.serialized_size()
+        t2 = time.perf_counter()
+        blob = cbl.serialize_np()
+        t3 = time.perf_counter()
+        extra["serialize"] = {"bytes": int(nbytes), "size_ms": round((t2 - t1) * 1e3, 3), "to_host_ms": round((t3 - t2) * 1e3, 3),
+                              "gbps_to_host": round(nbytes / max(t3 - t2, 1e-9) / 1e9, 2),
+                              "note": "rank 0's share: device emitter (kernels_serde.hpp) + pinned download lanes into a pageable host buffer; not part of `value`"}
+        del blob
+
     exchange = None
     if dist is not None and engine is not None and hasattr(engine, "stats"):
         st = engine.stats
@@ -466,31 +544,9 @@ def main():
                "source": "pinned host memory (torch pin_memory) -> cblx_insert_seqs + cblx_flush, best of 2 after 1 warm-up"}
         del hb, ho
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.kind == "build":
-        import numpy as np_
-        from oracle import Oracle
-
-        ns = NR if args.cpu_full else min(args.cpu_sample_reads, NR)
-        orc = Oracle(K, PB, args.canonical)
-        secs, done, blk = 0.0, 0, 1_000_000
-        curve = []
-        while done < ns:  # fed in blocks of 1 M reads so that the decline with index size is on record
-            m = min(blk, ns - done)
-            if args.genome:  # the same reads the GPU got
-                b = d_bases[done * L:(done + m) * L].cpu().numpy()
-                o = (np_.arange(m + 1, dtype=np_.uint64) * np_.uint64(L))
-            else:
-                b, o = synth.reads(42, m, L, first_read=done)
-            s1 = orc.insert_seqs(b, o)
-            secs += s1
-            done += m
-            curve.append(round(m * (L - K + 1) / s1 / 1e6, 2))
-        cpu = {"value": round(ns * (L - K + 1) / secs, 1), "unit": "k-mers/s", "cores": 1, "kind": "port",
-               "sample": (f"all {ns} reads" if ns == NR else f"first {ns} of the same reads") + f" (seed 42), one insert_seq call per read, {secs:.1f} s"
-                         + ("" if ns == NR else "; throughput falls as the index grows, so the full-size CPU figure is lower (profiles/ holds a full run)"),
-               "mkmers_per_s_by_1M_read_block": curve if len(curve) > 1 else None,
-               "host_cores_available": os.cpu_count()}
+    cpu = cpu_early
+    if cpu is None and rank == 0 and not args.no_cpu_baseline and args.kind == "build" and args.genome:
+        cpu = cpu_baseline_leg(args, lambda done, m: (d_bases[done * L:(done + m) * L].cpu().numpy(), None))  # the same reads the GPU got
 
     out = None
     if rank == 0:

@@ -37,6 +37,23 @@ def test_algorithmic_bytes_of_cfg2():
     assert bench.word_layout(59, 28)[1:] == (125, 8, 16, 13)
 
 
+def test_no_stage_is_priced_for_work_it_does_not_do():
+    # PREFIX_BITS > 24: the last scatter stores the bucket starts itself, the directory stage reads no records
+    for k, pb, L in ((31, 28, 150), (59, 28, 250), (31, 24, 150), (25, 24, 150)):
+        assert bench.stage_alg_bytes(k, pb, L)["directory"] == 0.0
+    assert bench.stage_alg_bytes(31, 8, 150)["directory"] == 8  # no LSD pass at all: boundaries from a scan of the sorted records
+
+
+def test_multi_gpu_defaults_take_the_native_bins_path():
+    a = bench.parse_args(["--gpus", "8"])
+    assert (a.transport, a.protocol) == ("native", "bins")
+    assert bench.parse_args(["--gpus", "8", "--transport", "torch"]).protocol == "sorted"
+    # the CPU leg stays bounded (about 20-30 s) whatever the configuration
+    assert bench.parse_args(["--config", "cfg3"]).cpu_sample_reads == 125_000
+    assert bench.parse_args(["--config", "cfg4"]).cpu_sample_reads == 60_000
+    assert bench.parse_args([]).cpu_sample_reads == 1_000_000
+
+
 def test_source_hash_is_stable_and_covers_csrc():
     h = bench.source_hash()
     assert len(h) == 16 and h == bench.source_hash()
