@@ -702,7 +702,10 @@ __global__ __launch_bounds__(THREADS) void k_bucket_medium(const BDesc* __restri
 // itself inside its sub-bucket by (suffix, stream index) with a handful of compares. O(c) LDS work instead of
 // SUFFIX_BITS/8 radix passes. A bucket whose largest sub-bucket exceeds MSD_LIMIT (heavy duplication / repeats) is
 // handed to the radix kernel through `retry` untouched. -------------------------------------------------------------
-static const u32 MSD_LIMIT = 48, MSD_LIMIT_HASHED = 16;
+#ifndef CBLX_MSD_LIMIT
+#define CBLX_MSD_LIMIT 48
+#endif
+static const u32 MSD_LIMIT = CBLX_MSD_LIMIT, MSD_LIMIT_HASHED = 16;
 
 template <bool WS> __device__ __forceinline__ u32 sfx_top_bits(const Sfx<WS>& k, u32 SB, u32 nbits) {
     if constexpr (WS) {
@@ -1430,94 +1433,63 @@ __global__ __launch_bounds__(BCL_THREADS) void k_big_claim(const BDesc* __restri
 }
 
 // ---- KRN-3 big: runs of 4097 .. BIG_MAX words -------------------------------------------------------------------------
-// per list entry: its length and its number of sub-ranges (scanned by the host side into scratch / virtual-bucket offsets)
-__global__ void k_big_plan(const BDesc* __restrict__ list, u32 n, u32* __restrict__ len, u32* __restrict__ nv) {
+// The long runs get ONE more pass of the partition kernels (k_radix_hist / k_radix_scatter with the runs as segments): a stable
+// sort on the top suffix bits, out of the arena into a TWIN buffer at the same positions. A run then is a sequence of
+// sub-ranges sharing their leading suffix bits; k_bucket_msd sorts + deduplicates every sub-range in place in the twin; and
+// k_big_finish adds up a run's distinct counts (closing the gaps duplicates left). The finished runs are never copied back:
+// the arena becomes whichever of the two buffers holds more words and the other side's buckets move over (pipeline.hpp,
+// finish_twin) — on the receiving side of a many-GPU build, where every run is long, nothing is copied at all. The arena run
+// stays untouched, so a run that must stay a Vec (<= 1024 distinct words and no resident Trie: a few words repeated
+// thousands of times) or whose sort gave up still finds its original there (k_bucket_huge).
+__host__ __device__ inline u32 big_digit_bits(u32 SB) { return SB < 8 ? SB : 8; }  // width of the pass's digit: the top suffix bits
+// per list entry: its tiles and its number of sub-ranges (2^bits, about BIG_SUB words each; never finer than the pass's digit)
+__global__ void k_big_plan(const BDesc* __restrict__ list, u32 n, u32 SB, u32* __restrict__ ntile, u32* __restrict__ nv) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const u32 c = list[i].c & ~BDESC_TRIE;
-    len[i] = c;
-    nv[i] = 1u << big_bits(c);
+    const u32 c = list[i].c & ~BDESC_TRIE, DB = big_digit_bits(SB), B = big_bits(c) < DB ? big_bits(c) : DB;
+    ntile[i] = (c + RDX_TILE - 1) / RDX_TILE;
+    nv[i] = 1u << B;
 }
-// One workgroup per big run: stable counting sort by the top big_bits(c) suffix bits into scratch; one descriptor per
-// sub-range (a "virtual bucket" for k_bucket_msd, always asked for the sorted distinct list). A sub-range that outgrows the
-// sort kernel marks itself BIG_SENT - 1 in v_count: the whole run then takes the general kernel.
-template <bool WS, typename HiT>
-__global__ __launch_bounds__(256) void k_big_split(const BDesc* __restrict__ list, const u32* __restrict__ list_n, const u64* __restrict__ so_,
-                                                   const u64* __restrict__ vb_, const u64* __restrict__ lo, const HiT* __restrict__ hi, u32 SB,
-                                                   u64* __restrict__ s_lo, u64* __restrict__ s_hi, BDesc* __restrict__ vlist, u32* __restrict__ v_count,
-                                                   u32 v_dummy) {
-    constexpr int THREADS = 256, ITEMS = 8, TILE = THREADS * ITEMS;
-    __shared__ u32 s_wcnt[(THREADS / 64) * 256];
-    __shared__ u32 s_dbase[256];
-    __shared__ u32 s_scan[THREADS / 64 + 1];
-    __shared__ u32 s_hist[256];
-    __shared__ u32 s_run[256];
-    if (blockIdx.x >= *list_n) return;
-    const BDesc dsc = list[blockIdx.x];
-    const u64 s0 = dsc.start, so = so_[blockIdx.x], vb = vb_[blockIdx.x];
-    const u32 c = dsc.c & ~BDESC_TRIE;
-    const u32 B = big_bits(c), V = 1u << B;
-    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    s_hist[tid] = 0;
-    __syncthreads();
-    for (u32 e = tid; e < c; e += THREADS) atomicAdd(&s_hist[sfx_top_bits<WS>(load_sfx<WS, HiT>(lo, hi, s0 + e, SB), SB, B)], 1u);
-    __syncthreads();
-    const u32 hv = s_hist[tid];
-    const u32 ex = block_exclusive_scan<THREADS, u32>(hv, s_scan, nullptr);
-    s_run[tid] = ex;
-    if (tid < V) {
-        // BIG_SENT: not sorted yet (the sort kernel overwrites it). A sub-range the sort kernel cannot take is handed to it as
-        // an empty one reporting to a dummy slot, and keeps BIG_SENT - 1.
-        const bool fits = hv <= BIG_VCAP;
-        vlist[vb + tid] = BDesc{so + ex, (fits ? hv : 0u) | BDESC_TRIE | (B << BDESC_SKIP_SHIFT), fits ? (u32)(vb + tid) : v_dummy};
-        v_count[vb + tid] = fits ? BIG_SENT : BIG_SENT - 1;
+__global__ void k_big_tile_table(const BDesc* __restrict__ list, u32 nruns, const u32* __restrict__ tile_first /* nruns + 1 */, u64* __restrict__ t_start,
+                                 u32* __restrict__ t_count, u32* __restrict__ t_seg, u64* __restrict__ run_start) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nruns) run_start[t] = list[t].start;
+    if (t >= tile_first[nruns]) return;
+    u32 lo = 0, hi = nruns;  // last run with tile_first[i] <= t (every run has a tile)
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (tile_first[mid] <= t) lo = mid; else hi = mid;
     }
-    __syncthreads();
-    const u32 ntile = (c + TILE - 1) / TILE;
-    for (u32 t = 0; t < ntile; ++t) {
-        Sfx<WS> key[ITEMS];
-        u32 digit[ITEMS], pos[ITEMS];
-        bool valid[ITEMS];
-        const u32 tb = t * TILE;
-        const u32 n_tile = c - tb < (u32)TILE ? c - tb : (u32)TILE;
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const u32 e = w * (64 * ITEMS) + j * 64 + lane;
-            valid[j] = e < n_tile;
-            digit[j] = 255;  // tail slots: last
-            key[j].lo = 0;
-            if constexpr (WS) key[j].hi = 0;
-            if (valid[j]) {
-                key[j] = load_sfx<WS, HiT>(lo, hi, s0 + tb + e, SB);
-                digit[j] = sfx_top_bits<WS>(key[j], SB, B);
-            }
-        }
-        tile_rank<THREADS, ITEMS>(digit, pos, s_wcnt, s_dbase, s_scan, ITEMS);
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            if (valid[j]) {
-                const u64 dst = so + s_run[digit[j]] + (pos[j] - s_dbase[digit[j]]);
-                s_lo[dst] = key[j].lo;
-                if constexpr (WS) s_hi[dst] = key[j].hi;
-            }
-        }
-        __syncthreads();
-        {   // advance the running starts by this tile's digit counts (tail slots sit in digit 255 and are not counted)
-            const u32 nxt = tid == 255 ? n_tile : s_dbase[tid + 1];
-            const u32 cur = s_dbase[tid] < n_tile ? s_dbase[tid] : n_tile;
-            s_run[tid] += (nxt < n_tile ? nxt : n_tile) - cur;
-        }
-        __syncthreads();
-    }
+    const u32 off = (t - tile_first[lo]) * RDX_TILE, c = list[lo].c & ~BDESC_TRIE;
+    t_start[t] = list[lo].start + off;
+    t_count[t] = c - off < (u32)RDX_TILE ? c - off : (u32)RDX_TILE;
+    t_seg[t] = lo;
 }
-// One workgroup per big run: the sorted distinct sub-ranges, in order, back into the run's arena slot. A run that must stay a
-// Vec (at most 1024 distinct and no resident Trie: heavy duplication) or whose sort gave up goes to `fb` for the general kernel
-// (the arena run is untouched until here).
-template <bool WS, typename HiT>
-__global__ __launch_bounds__(256) void k_big_collect(const BDesc* __restrict__ list, const u32* __restrict__ list_n, const u64* __restrict__ vb_,
-                                                     const BDesc* __restrict__ vlist, const u32* __restrict__ v_count, const u64* __restrict__ s_lo,
-                                                     const u64* __restrict__ s_hi, u64* __restrict__ lo, HiT* __restrict__ hi, u32* __restrict__ out_count,
-                                                     u8* __restrict__ out_kind, BDesc* __restrict__ fb, u32* __restrict__ fb_n) {
+// One descriptor per sub-range (a "virtual bucket" for k_bucket_msd, always asked for the sorted distinct list): sub-range v of
+// run i = the digits [v << (DB - B), (v + 1) << (DB - B)) of the pass, contiguous in the twin from rel[i][v << (DB - B)]
+// (k_seg_adjust's grp_start, relative to the run). A sub-range that outgrows the sort kernel marks itself BIG_SENT - 1 in
+// v_count and is handed over empty, reporting to a dummy slot: the whole run then takes the general kernel.
+__global__ void k_big_vlist(const BDesc* __restrict__ list, u32 nruns, const u64* __restrict__ vb_, const u32* __restrict__ rel /* [nruns][256] */, u32 SB,
+                            BDesc* __restrict__ vlist, u32* __restrict__ v_count, u32 v_dummy) {
+    const u32 i = blockIdx.x, v = threadIdx.x;
+    if (i >= nruns) return;
+    const BDesc dsc = list[i];
+    const u32 c = dsc.c & ~BDESC_TRIE, DB = big_digit_bits(SB), B = big_bits(c) < DB ? big_bits(c) : DB, V = 1u << B, sh = DB - B;
+    if (v >= V) return;
+    const u32 a = rel[(u64)i * 256 + (v << sh)], b = v + 1 < V ? rel[(u64)i * 256 + ((v + 1) << sh)] : c;
+    const u32 hv = b - a;
+    const bool fits = hv <= BIG_VCAP;
+    const u64 vb = vb_[i];
+    vlist[vb + v] = BDesc{dsc.start + a, (fits ? hv : 0u) | BDESC_TRIE | (B << BDESC_SKIP_SHIFT), fits ? (u32)(vb + v) : v_dummy};
+    v_count[vb + v] = fits ? BIG_SENT : BIG_SENT - 1;
+}
+// One workgroup per big run: its distinct count = the sum over its sorted sub-ranges, which move down over the gaps the
+// duplicates left (in the twin). A run that must stay a Vec or whose sort gave up goes to `fb` for the general kernel.
+template <bool WS>
+__global__ __launch_bounds__(256) void k_big_finish(const BDesc* __restrict__ list, const u32* __restrict__ list_n, const u64* __restrict__ vb_,
+                                                    const BDesc* __restrict__ vlist, const u32* __restrict__ v_count, u32 SB, u64* __restrict__ t_lo,
+                                                    u64* __restrict__ t_hi, u32* __restrict__ out_count, u8* __restrict__ out_kind, u8* __restrict__ in_twin,
+                                                    BDesc* __restrict__ fb, u32* __restrict__ fb_n) {
     __shared__ u32 s_scan[256 / 64 + 1];
     __shared__ u32 s_off[257];
     __shared__ u32 s_fail;
@@ -1526,7 +1498,7 @@ __global__ __launch_bounds__(256) void k_big_collect(const BDesc* __restrict__ l
     const u64 s0 = dsc.start, vb = vb_[blockIdx.x];
     const u32 c = dsc.c & ~BDESC_TRIE;
     const bool res_trie = (dsc.c & BDESC_TRIE) != 0;
-    const u32 V = 1u << big_bits(c), tid = threadIdx.x;
+    const u32 DB = big_digit_bits(SB), B = big_bits(c) < DB ? big_bits(c) : DB, V = 1u << B, tid = threadIdx.x;
     if (tid == 0) s_fail = 0;
     __syncthreads();
     u32 cnt = 0;
@@ -1543,17 +1515,38 @@ __global__ __launch_bounds__(256) void k_big_collect(const BDesc* __restrict__ l
         if (tid == 0) fb[atomicAdd(fb_n, 1u)] = dsc;
         return;
     }
-    for (u32 v = 0; v < V; ++v) {
-        const u32 n = s_off[v + 1] - s_off[v];
-        const u64 src = vlist[vb + v].start, dst = s0 + s_off[v];
-        for (u32 e = tid; e < n; e += 256) {
-            lo[dst + e] = s_lo[src + e];
-            if constexpr (WS) st_hi<HiT>(hi, dst + e, s_hi[src + e]);
+    if (d != c) {
+        for (u32 v = 0; v < V; ++v) {
+            const u32 n = s_off[v + 1] - s_off[v];
+            const u64 src = vlist[vb + v].start, dst = s0 + s_off[v];  // dst <= src: chunk by chunk, every chunk read before it is written
+            if (src == dst) continue;
+            for (u32 e0 = 0; e0 < n; e0 += 256) {
+                const u32 e = e0 + tid;
+                u64 a = 0, b = 0;
+                if (e < n) { a = t_lo[src + e]; if constexpr (WS) b = t_hi[src + e]; }
+                __syncthreads();
+                if (e < n) { t_lo[dst + e] = a; if constexpr (WS) t_hi[dst + e] = b; }
+                __syncthreads();
+            }
         }
     }
     if (tid == 0) {
         out_count[dsc.r] = d;
         out_kind[dsc.r] = KIND_TRIE;
+        in_twin[dsc.r] = 1;
+    }
+}
+// the buckets whose in_twin flag equals `want`: their count[r] words from src to dst at the same positions; LPB lanes per bucket
+template <bool WS, int LPB>
+__global__ __launch_bounds__(256) void k_copy_buckets(u64 nb, const u64* __restrict__ start, const u32* __restrict__ count, const u8* __restrict__ in_twin, u32 want,
+                                                      const u64* __restrict__ src_lo, const u64* __restrict__ src_hi, u64* __restrict__ dst_lo, u64* __restrict__ dst_hi) {
+    const u64 r = ((u64)blockIdx.x * 256 + threadIdx.x) / LPB;
+    if (r >= nb || in_twin[r] != want) return;
+    const u32 lane = threadIdx.x & (LPB - 1), c = count[r];
+    const u64 s0 = start[r];
+    for (u32 j = lane; j < c; j += LPB) {
+        dst_lo[s0 + j] = src_lo[s0 + j];
+        if constexpr (WS) dst_hi[s0 + j] = src_hi[s0 + j];
     }
 }
 

@@ -278,13 +278,21 @@ struct TileView {
     const u32* ntiles_dev;  // null: ntiles below
     u32 ntiles;
     u64 n;
+    // tiles anywhere in a resident arena (the long runs of the bucket stage, kernels_bucket.hpp: k_big_*): 64-bit starts and
+    // 32-bit segment numbers instead of start / seg
+    const u64* start64 = nullptr;
+    const u32* seg32 = nullptr;
 };
 __device__ __forceinline__ bool tile_get(const TileView& tv, u32 b, u32& tile, u64& tbase, u32& n_tile, u32& seg) {
     const u32 nt = tv.ntiles_dev ? *tv.ntiles_dev : tv.ntiles;
     if ((b >> 3) >= (nt + 7u) / 8u) return false;  // the grid may be sized for an upper bound of the tile count
     tile = xcd_tile(b, nt);
     if (tile >= nt) return false;
-    if (tv.start) {
+    if (tv.start64) {
+        tbase = tv.start64[tile];
+        n_tile = tv.count[tile];
+        seg = tv.seg32[tile];
+    } else if (tv.start) {
         tbase = tv.start[tile];
         n_tile = tv.count[tile];
         seg = tv.seg[tile];
@@ -398,7 +406,8 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
                                                                OutHiT* __restrict__ out_hi, DigitBits next_dfn = DigitBits{0, 0},
                                                                u8* __restrict__ out_next = nullptr, u32* __restrict__ start_dense = nullptr,
                                                                u32 pfx_shift = 0, u32 pfx_bits = 0, u32 grp_bits = 0, u32* __restrict__ amb = nullptr,
-                                                               u32 amb_stride = 0, OwnWindow ow = OwnWindow{0, 0, nullptr, nullptr, nullptr}) {
+                                                               u32 amb_stride = 0, OwnWindow ow = OwnWindow{0, 0, nullptr, nullptr, nullptr},
+                                                               const u64* __restrict__ seg_base = nullptr /* adj is relative to the segment's own start */) {
     constexpr bool STAGE_HI = HiTraits<HiT>::has && HiTraits<OutHiT>::has;
     __shared__ u64 s_lo[RDX_TILE];
     __shared__ typename std::conditional<STAGE_HI, HiT, u8>::type s_hi[STAGE_HI ? RDX_TILE : 1];
@@ -433,7 +442,12 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
         digit[j] = valid ? dfn(klo[j], (u64)khi[j]) : 255u;
     }
     tile_rank_packed<RDX_THREADS, RDX_ITEMS>(digit, s_wcnt, s_dbase, s_scan, RDX_ITEMS);  // digit[j] = digit << 16 | position
-    if (tid < 256) s_gbase[tid] = (u64)adj[seg * 256 + tid] + colpre[(u64)tile * 256 + tid] - s_dbase[tid];
+    if (tid < 256) {
+        // seg_base: adj is relative to the segment's own start and may be "negative" (the column prefix counts the digit in
+        // the tiles of EARLIER segments too): 32-bit modular arithmetic, sign-extended (a segment is shorter than 2^31)
+        if (seg_base) s_gbase[tid] = seg_base[seg] + (u64)(long long)(int)(adj[(u64)seg * 256 + tid] + colpre[(u64)tile * 256 + tid] - s_dbase[tid]);
+        else s_gbase[tid] = (u64)adj[(u64)seg * 256 + tid] + colpre[(u64)tile * 256 + tid] - s_dbase[tid];
+    }
     __syncthreads();  // every wave is done with the rank counters before records are staged over them
     u32 g_first = 0;
     if (start_dense) {  // fused directory (last pass): group the tile starts in; its row of parked candidates starts empty
@@ -566,9 +580,9 @@ __global__ __launch_bounds__(256) void k_seg_adjust(const u32* __restrict__ colp
     const u32 p0 = f0 < nt ? colpre[(u64)f0 * 256 + d] : coltot[d];
     const u32 p1 = f1 < nt ? colpre[(u64)f1 * 256 + d] : coltot[d];
     const u32 ex = block_exclusive_scan<256, u32>(p1 - p0, sm, nullptr);
-    adj[s * 256 + d] = (seg_start ? seg_start[s] : 0u) + ex - p0;
+    adj[(u64)s * 256 + d] = (seg_start ? seg_start[s] : 0u) + ex - p0;
     // where digit d of segment s starts after this pass: the (segment, digit) GROUPS the next pass may cut its tiles at
-    if (grp_start) grp_start[s * 256 + d] = (seg_start ? seg_start[s] : 0u) + ex;
+    if (grp_start) grp_start[(u64)s * 256 + d] = (seg_start ? seg_start[s] : 0u) + ex;
     (void)nseg;
 }
 // Segments of the remaining passes from the first pass's column totals: seg_start (exclusive scan of the totals),

@@ -270,48 +270,134 @@ template <typename C> void huge_stage(cblx_ctx* c, const BDesc* d_list, const u3
     CBLX_HIP(hipGetLastError());
     CBLX_HIP(hipStreamSynchronize(c->stream));
 }
-// runs of 4097 .. BIG_MAX words (kernels_bucket.hpp: k_big_*): split into sub-ranges in scratch, sort + dedup each with
-// k_bucket_msd, collect in order; what cannot be finished that way takes the general kernel
-template <typename C> void big_stage(cblx_ctx* c, const BDesc* d_list, const u32* d_list_n, u32 nbig, u64* a_lo, typename C::HiT* a_hi, Resident& nr, const MergeArgs& ma) {
+// lanes per bucket of the per-bucket copy kernels, from the average run length (words / buckets)
+template <typename F> void with_lpb(u64 words, u64 buckets, F&& f) {
+    const u64 avg = buckets ? words / buckets : 0;
+    if (avg >= 48) f(std::integral_constant<int, 64>());
+    else if (avg >= 12) f(std::integral_constant<int, 16>());
+    else f(std::integral_constant<int, 4>());
+}
+inline dim3 lpb_grid(u64 buckets, int lpb) { return dim3((unsigned)std::max<u64>(1, ceil_div(buckets * (u64)lpb, 256))); }
+
+__global__ void k_sum_bdesc_len(const BDesc* __restrict__ list, u32 n, u64* __restrict__ out) {
+    u64 s = 0;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += list[i].c & ~BDESC_TRIE;
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd((unsigned long long*)out, (unsigned long long)s);
+}
+// runs of 4097 .. BIG_MAX words (kernels_bucket.hpp: k_big_*): one more partition pass on the top suffix bits with the runs as
+// segments, out of the arena into a twin buffer at the same positions; sub-ranges sorted + deduplicated in place there by
+// k_bucket_msd; what cannot be finished that way takes the general kernel on the (untouched) arena run. The finished runs stay
+// in the twin: finish_twin decides which buffer becomes the arena.
+struct Twin {
+    Buf<u64> lo, hi;   // same positions as the arena; hi only for suffixes wider than 64 bits
+    Buf<u8> in_twin;   // per bucket rank: 1 = its final words are in the twin
+    u64 arrivals = 0;  // words of the runs that went through the twin
+    bool used() const { return lo.get() != nullptr; }
+};
+__global__ void k_set_u32(u32* p, u32 v) { *p = v; }
+template <typename C> void big_stage(cblx_ctx* c, const BDesc* d_list, const u32* d_list_n, u32 nbig, Resident& nr, const MergeArgs& ma, Twin& tw) {
     typedef typename C::HiT HiT;
     constexpr bool WS = C::WS;
+    typedef typename std::conditional<WS, u64, NoHi>::type AH;  // hi part of an arena element as the partition kernels see it
     if (nbig == 0) return;
     const Consts& P = c->P;
+    u64* a_lo = nr.a_lo.get();
+    HiT* a_hi = WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr;
     Buf<BDesc> fb(c->pool, nbig);
     Buf<u32> fb_n(c->pool, 1);
     {
         StageTimer t(c, ST_BBIG);
-        Buf<u32> len(c->pool, nbig), nv(c->pool, nbig), vtot_d(c->pool, 1);
-        Buf<u64> so(c->pool, nbig + 1), vb(c->pool, nbig + 1);
-        hipLaunchKernelGGL(k_big_plan, grid1(nbig, 256), dim3(256), 0, c->stream, d_list, nbig, len.get(), nv.get());
-        const u64 tot = exclusive_scan<u64>(c, len.get(), nbig, so.get());
+        if (!tw.used()) {
+            const u64 T = d2h<u64>(c, nr.start.get() + nr.nb);  // every run position lies below the total arrival count
+            tw.lo = Buf<u64>(c->pool, T + 2);
+            if (WS) tw.hi = Buf<u64>(c->pool, T + 2);
+            tw.in_twin = Buf<u8>(c->pool, nr.nb + 1);
+            CBLX_HIP(hipMemsetAsync(tw.in_twin.get(), 0, nr.nb + 1, c->stream));
+        }
+        Buf<u32> ntile(c->pool, nbig), nv(c->pool, nbig), tile_first(c->pool, nbig + 1), vtot_d(c->pool, 1);
+        Buf<u64> vb(c->pool, nbig + 1), run_start(c->pool, nbig);
+        hipLaunchKernelGGL(k_big_plan, grid1(nbig, 256), dim3(256), 0, c->stream, d_list, nbig, P.SB, ntile.get(), nv.get());
+        const u64 nt64 = exclusive_scan<u32>(c, ntile.get(), nbig, tile_first.get());
         const u64 vtot = exclusive_scan<u64>(c, nv.get(), nbig, vb.get());
-        Buf<u64> s_lo(c->pool, tot + 2), s_hi(c->pool, WS ? tot + 2 : 1);
+        if (nt64 >= 0xFFFFFF00ull / 256) throw Error(CBLX_ERANGE, "too many tiles in the long runs of one batch");
+        const u32 nt = (u32)nt64, vt32 = (u32)vtot;
+        hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, c->stream, tile_first.get() + nbig, nt);
+        Buf<u64> t_start(c->pool, nt);
+        Buf<u32> t_count(c->pool, nt), t_seg(c->pool, nt), counts(c->pool, (size_t)256 * nt), colpre(c->pool, (size_t)256 * nt), scratch, coltot(c->pool, 256),
+            adj(c->pool, (size_t)256 * nbig), rel(c->pool, (size_t)256 * nbig);
+        hipLaunchKernelGGL(k_big_tile_table, grid1(std::max<u64>(nt, nbig), 256), dim3(256), 0, c->stream, d_list, nbig, tile_first.get(), t_start.get(), t_count.get(), t_seg.get(),
+                           run_start.get());
+        TileView tv{nullptr, t_count.get(), nullptr, nullptr, nt, 0};
+        tv.start64 = t_start.get();
+        tv.seg32 = t_seg.get();
+        const u32 DB = big_digit_bits(P.SB);
+        const DigitBits dfn{P.SB - DB, DB};
+        const AH* in_hi = (const AH*)a_hi;
+        AH* out_hi = (AH*)tw.hi.get();
+        hipLaunchKernelGGL((k_radix_hist<AH, DigitBits>), dim3(xcd_grid(nt)), dim3(RDX_THREADS), 0, c->stream, (const u64*)a_lo, in_hi, tv, dfn, counts.get());
+        colscan(c, counts.get(), nullptr, nt, colpre.get(), coltot.get(), scratch);
+        hipLaunchKernelGGL(k_seg_adjust, dim3(nbig), dim3(256), 0, c->stream, colpre.get(), coltot.get(), (const u32*)tile_first.get(), (const u32*)nullptr, (const u32*)nullptr, nt, nbig,
+                           adj.get(), rel.get());
+        hipLaunchKernelGGL((k_radix_scatter<AH, AH, DigitBits>), dim3(xcd_grid(nt)), dim3(RDX_THREADS), 0, c->stream, (const u64*)a_lo, in_hi, tv, dfn, (const u32*)colpre.get(),
+                           (const u32*)adj.get(), tw.lo.get(), out_hi, DigitBits{0, 0}, (u8*)nullptr, (u32*)nullptr, 0u, 0u, 0u, (u32*)nullptr, 0u,
+                           OwnWindow{0, 0, nullptr, nullptr, nullptr}, (const u64*)run_start.get());
         Buf<BDesc> vlist(c->pool, vtot);
         Buf<u32> v_count(c->pool, vtot + 1);
         Buf<u8> v_kind(c->pool, vtot + 1);
         Buf<BDesc> retry(c->pool, vtot);  // sub-ranges the sort gives up on (crowded sub-bucket): their runs fall back as a whole
         Buf<u32> retry_n(c->pool, 1);
-        const u32 vt32 = (u32)vtot;
         h2d(c, vtot_d.get(), &vt32, 1);
         CBLX_HIP(hipMemsetAsync(retry_n.get(), 0, 4, c->stream));
         CBLX_HIP(hipMemsetAsync(fb_n.get(), 0, 4, c->stream));
-        hipLaunchKernelGGL((k_big_split<WS, HiT>), dim3(nbig), dim3(256), 0, c->stream, d_list, d_list_n, so.get(), vb.get(), (const u64*)a_lo, (const HiT*)a_hi, P.SB, s_lo.get(),
-                           s_hi.get(), vlist.get(), v_count.get(), vt32);
-        HiT* sh = WS ? (HiT*)s_hi.get() : (HiT*)nullptr;
+        hipLaunchKernelGGL(k_big_vlist, dim3(nbig), dim3(256), 0, c->stream, d_list, nbig, vb.get(), rel.get(), P.SB, vlist.get(), v_count.get(), vt32);
+        HiT* th = WS ? (HiT*)tw.hi.get() : (HiT*)nullptr;
         auto sort = [&](auto pk) {
-            hipLaunchKernelGGL((k_bucket_msd<256, BIG_VCAP, decltype(pk)::value, WS, HiT>), dim3(vt32), dim3(256), 0, c->stream, vlist.get(), vtot_d.get(), s_lo.get(), sh, P.SB,
+            hipLaunchKernelGGL((k_bucket_msd<256, BIG_VCAP, decltype(pk)::value, WS, HiT>), dim3(vt32), dim3(256), 0, c->stream, vlist.get(), vtot_d.get(), tw.lo.get(), th, P.SB,
                                v_count.get(), v_kind.get(), retry.get(), retry_n.get(), MergeArgs{});
         };
         if constexpr (!WS) { if (P.SB + PK_BITS <= 64) sort(std::true_type()); else sort(std::false_type()); }
         else sort(std::false_type());
-        hipLaunchKernelGGL((k_big_collect<WS, HiT>), dim3(nbig), dim3(256), 0, c->stream, d_list, d_list_n, vb.get(), vlist.get(), v_count.get(), s_lo.get(), s_hi.get(), a_lo, a_hi,
-                           nr.cnt.get(), nr.kind.get(), fb.get(), fb_n.get());
+        hipLaunchKernelGGL((k_big_finish<WS>), dim3(nbig), dim3(256), 0, c->stream, d_list, d_list_n, vb.get(), vlist.get(), v_count.get(), P.SB, tw.lo.get(), tw.hi.get(), nr.cnt.get(),
+                           nr.kind.get(), tw.in_twin.get(), fb.get(), fb_n.get());
         CBLX_HIP(hipGetLastError());
-        CBLX_HIP(hipStreamSynchronize(c->stream));  // scratch dies here
+        CBLX_HIP(hipStreamSynchronize(c->stream));  // the pass tables die here
+    }
+    {   // arrivals of the runs that went through the twin = their lengths (the fallback runs are few)
+        Buf<u64> tot(c->pool, 1);
+        CBLX_HIP(hipMemsetAsync(tot.get(), 0, 8, c->stream));
+        hipLaunchKernelGGL(k_sum_bdesc_len, dim3((unsigned)std::min<u64>(1024, ceil_div(nbig, 256))), dim3(256), 0, c->stream, d_list, nbig, tot.get());
+        tw.arrivals += d2h<u64>(c, tot.get());
     }
     const u32 nfb = d2h<u32>(c, fb_n.get());
     huge_stage<C>(c, fb.get(), fb_n.get(), nfb, a_lo, a_hi, nr, ma);
+}
+// After every bucket kernel of the stage: the finished long runs sit in the twin, everything else in the arena. The buffer that
+// holds more words becomes the arena; the other side's buckets are copied over (count[r] words at the same positions).
+template <typename C> void finish_twin(cblx_ctx* c, Resident& nr, Twin& tw) {
+    constexpr bool WS = C::WS;
+    if (!tw.used()) return;
+    StageTimer t(c, ST_BBIG);
+    const u64 T = d2h<u64>(c, nr.start.get() + nr.nb);
+    const bool to_twin = tw.arrivals * 2 > T;
+    const u64* src_lo = to_twin ? nr.a_lo.get() : tw.lo.get();
+    const u64* src_hi = to_twin ? nr.a_hi.get() : tw.hi.get();
+    u64* dst_lo = to_twin ? tw.lo.get() : nr.a_lo.get();
+    u64* dst_hi = to_twin ? tw.hi.get() : nr.a_hi.get();
+    // lanes per bucket: the long runs take a wave each; the others follow the average bucket length
+    auto copy = [&](auto lpb) {
+        constexpr int LPB = decltype(lpb)::value;
+        hipLaunchKernelGGL((k_copy_buckets<WS, LPB>), lpb_grid(nr.nb, LPB), dim3(256), 0, c->stream, nr.nb, nr.start.get(), nr.cnt.get(), tw.in_twin.get(), to_twin ? 0u : 1u, src_lo, src_hi,
+                           dst_lo, dst_hi);
+    };
+    if (to_twin) with_lpb(T - tw.arrivals, nr.nb, copy); else copy(std::integral_constant<int, 64>());
+    CBLX_HIP(hipGetLastError());
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    if (to_twin) {
+        nr.a_lo = std::move(tw.lo);
+        if (WS) nr.a_hi = std::move(tw.hi);
+    }
+    tw = Twin();
 }
 
 // KRN-3 over the runs of `nr` (run of a prefix = [its resident suffixes as stored][the new words in stream order]) in the
@@ -322,9 +408,12 @@ bool repeat_prepass() {
     const char* e = std::getenv("CBLX_REPEAT_PREPASS");
     return !(e && e[0] == '0');
 }
-template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, typename C::HiT* a_hi, const DirView& old) {
+template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView& old) {
     typedef typename C::HiT HiT;
     const Consts& P = c->P;
+    u64* a_lo = nr.a_lo.get();  // the arena (the long runs may move it to a twin buffer at the end: finish_twin)
+    HiT* a_hi = C::WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr;
+    Twin tw;
     {
     const u64 nb = nr.nb;
     Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
@@ -472,18 +561,19 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, ty
             }
             CBLX_HIP(hipGetLastError());
             }
-            big_stage<C>(c, next_big.get(), cnts.get() + 0, cn[0], a_lo, a_hi, nr, MergeArgs{});
+            big_stage<C>(c, next_big.get(), cnts.get() + 0, cn[0], nr, MergeArgs{}, tw);
             huge_stage<C>(c, next_huge.get(), cnts.get() + 1, cn[1], a_lo, a_hi, nr, MergeArgs{});
             CBLX_HIP(hipStreamSynchronize(c->stream));  // the lists die here
             long_done = true;
         }
     }
     if (!long_done) {
-        big_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], a_lo, a_hi, nr, MergeArgs{});
+        big_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], nr, MergeArgs{}, tw);
         huge_stage<C>(c, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE, ln[CLS_HUGE], a_lo, a_hi, nr, MergeArgs{});
     }
     }
     CBLX_HIP(hipGetLastError());
+    finish_twin<C>(c, nr, tw);
     {
         Buf<u64> total(c->pool, 1);
         CBLX_HIP(hipMemsetAsync(total.get(), 0, 8, c->stream));
@@ -491,15 +581,6 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, u64* a_lo, ty
         nr.count = d2h<u64>(c, total.get());
     }
 }
-
-// lanes per bucket of the per-bucket copy kernels, from the average run length (words / buckets)
-template <typename F> void with_lpb(u64 words, u64 buckets, F&& f) {
-    const u64 avg = buckets ? words / buckets : 0;
-    if (avg >= 48) f(std::integral_constant<int, 64>());
-    else if (avg >= 12) f(std::integral_constant<int, 16>());
-    else f(std::integral_constant<int, 4>());
-}
-inline dim3 lpb_grid(u64 buckets, int lpb) { return dim3((unsigned)std::max<u64>(1, ceil_div(buckets * (u64)lpb, 256))); }
 
 // rows of k_merge_table's `other` side for a freshly partitioned batch: every run is a Vec of its raw length
 __global__ void k_run_lengths(u64 nb, const u64* __restrict__ start, u32* __restrict__ cnt, u8* __restrict__ kind) {
@@ -530,8 +611,8 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
         }
     };
     if (c->res.count == 0) {
-        bucket_stage<C>(c, nb_, rec.lo.get(), (HiT*)rec.hi.get(), c->res.view());
         adopt_arena(nb_);
+        bucket_stage<C>(c, nb_, c->res.view());
         c->res = std::move(nb_);
         return;
     }
@@ -580,7 +661,7 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
         });
         CBLX_HIP(hipGetLastError());
     }
-    bucket_stage<C>(c, nr, nr.a_lo.get(), WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr, s.view());
+    bucket_stage<C>(c, nr, s.view());
     CBLX_HIP(hipStreamSynchronize(c->stream));  // the batch and the table buffers are released at scope exit
     c->res = std::move(nr);
 }
@@ -1002,7 +1083,7 @@ template <typename C> void insert_sorted_batches(cblx_ctx* c, const cblx_batch_v
         CBLX_HIP(hipStreamSynchronize(c->stream));
         CBLX_HIP(hipGetLastError());
     }
-    bucket_stage<C>(c, nr, nr.a_lo.get(), WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr, s.view());
+    bucket_stage<C>(c, nr, s.view());
     CBLX_HIP(hipStreamSynchronize(c->stream));
     c->res = std::move(nr);
     c->kmers_inserted += add;
@@ -1105,8 +1186,12 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
         CBLX_HIP(hipGetLastError());
         CBLX_HIP(hipStreamSynchronize(c->stream));  // retry buffers die here
     }
-    big_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], a_lo, a_hi, nr, ma);
-    huge_stage<C>(c, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE, ln[CLS_HUGE], a_lo, a_hi, nr, ma);
+    {
+        Twin tw;
+        big_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], nr, ma, tw);
+        huge_stage<C>(c, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE, ln[CLS_HUGE], a_lo, a_hi, nr, ma);
+        finish_twin<C>(c, nr, tw);
+    }
     {
         Buf<u64> total(c->pool, 1);
         CBLX_HIP(hipMemsetAsync(total.get(), 0, 8, c->stream));

@@ -29,6 +29,47 @@ def test_library_exports_every_declared_symbol():
     assert L.cblx_abi_version() == 2
 
 
+def test_rust_sys_crate_declares_every_symbol():
+    """rust/cblx-sys/src/lib.rs (shipped as source: no Rust toolchain in this image) binds exactly the functions of the header, with
+    the same number of parameters each, and repeats its constants."""
+    header = (ROOT / "include" / "cblx.h").read_text()
+    header_nc = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    rs = (ROOT / "rust" / "cblx-sys" / "src" / "lib.rs").read_text()
+    rs_nc = re.sub(r"//.*", "", rs)
+    extern = rs_nc[rs_nc.index('extern "C" {'):]
+    rust_fns = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (cblx_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", extern, flags=re.S)}
+    assert sorted(rust_fns) == _header_functions()
+
+    def nparams(arglist):
+        arglist = arglist.strip()
+        if arglist in ("", "void"):
+            return 0
+        depth, n = 0, 1
+        for ch in arglist:  # commas at depth 0 (callback types nest parentheses)
+            depth += ch in "(<["
+            depth -= ch in ")>]"
+            n += ch == "," and depth == 0
+        return n - (1 if arglist.rstrip().endswith(",") else 0)
+
+    for name, rargs in rust_fns.items():
+        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, header_nc, flags=re.S)
+        assert m, name
+        assert nparams(m.group(1)) == nparams(rargs), f"{name}: the header and the Rust binding disagree on the number of parameters"
+    for cname, val in re.findall(r"#define (CBLX_[A-Z_]+) (\d+)u?\b", header_nc):
+        assert re.search(r"pub const %s: \w+ = %s;" % (cname, val), rs), f"{cname} = {val} missing from the Rust crate"
+    for cname, val in re.findall(r"(CBLX_E[A-Z]+|CBLX_OK) = (\d+)", header_nc):
+        assert re.search(r"pub const %s: c_int = %s;" % (cname, val), rs), cname
+    # the facade binds only functions that exist
+    facade = (ROOT / "rust" / "cbl-gpu" / "src" / "lib.rs").read_text()
+    used = set(re.findall(r"sys::(cblx_[a-z0-9_]+)\(", facade))
+    assert used and used <= set(rust_fns)
+    # ... and carries every method of the reference surface for this path (src/cbl.rs:71-79,127-177,219-228,293-339,358-385,433-449)
+    for meth in ("new", "new_canonical", "save_to_file", "load_from_file", "is_canonical", "count", "is_empty", "contains", "insert", "contains_all", "contains_seq",
+                 "insert_seq", "iter", "prefix_load", "buckets_sizes", "buckets_size_count", "buckets_load_repartition"):
+        assert re.search(r"pub fn %s\b" % meth, facade), meth
+    assert "BitOrAssign<&mut Self>" in facade and "impl<const K: usize, T: PackedInt, const PREFIX_BITS: usize> Drop" in facade
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
 

@@ -18,6 +18,49 @@ import cbl_amd
 from cbl_amd import sharded, synth
 
 
+def build_share_words(k, pb, W, rank, NR, L, seed, bounds=None, profile=True):
+    """The same share through the WORDS of the rank's range (KRN-1 + one destination pass per sender, the direct pipeline on the
+    receiver): passes B / C, the directory and the bucket kernels then see exactly what the receiver of the "bins" protocol sees
+    (which gets its words with pass A already done: subtract one scatter pass from radix_scatter)."""
+    work = cbl_amd.CBL(k, pb)
+    eng = sharded.GpuEngine(work)
+    los, his = [], []
+    for s in range(W):
+        d_b, d_o = synth.reads_torch(seed, NR, L, first_read=s * NR, device="cuda")
+        if bounds is None:
+            lo, hi = eng.seq_words(d_b, d_o, NR)
+            hist = eng.sample_hist(lo, hi)
+            bounds = sharded.choose_bounds(hist.cpu().numpy(), W, pb, min(sharded.HIST_BITS, pb))
+            del lo, hi
+        plo, phi, counts = eng.seq_words_partitioned(d_b, d_o, NR, bounds, W)
+        a = int(sum(counts[:rank])); b = a + int(counts[rank])
+        los.append(plo[a:b].clone())
+        if phi is not None:
+            his.append(phi[a:b].clone())
+        del plo, phi, d_b, d_o
+    work.close()
+    lo = torch.cat(los); del los
+    hi = torch.cat(his) if his else None
+    del his
+    torch.cuda.empty_cache()
+    g = cbl_amd.CBL(k, pb, profile=profile)
+    g.insert_words_device(lo[:4096], hi[:4096] if hi is not None else None, 4096)  # warm the context (first launches, small allocations)
+    g.clear(); g.stage_times_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.insert_words_device(lo, hi, int(lo.numel()))
+    torch.cuda.synchronize()
+    t_recv = time.perf_counter() - t0
+    t1 = []
+    for _ in range(2):  # warm allocations: the steady-state figure
+        g.clear(); g.stage_times_reset(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g.insert_words_device(lo, hi, int(lo.numel()))
+        torch.cuda.synchronize()
+        t1.append(time.perf_counter() - t0)
+    return g, bounds, 0.0, min(t1 + [t_recv]), int(lo.numel())
+
+
 def build_share(k, pb, W, rank, NR, L, seed, bounds=None, profile=True):
     work = cbl_amd.CBL(k, pb)  # the senders' side (one ctx plays all W ranks in turn)
     eng = sharded.GpuEngine(work)
@@ -62,10 +105,12 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--prefix-bits", type=int, default=24)
     ap.add_argument("--merge", action="store_true")
+    ap.add_argument("--protocol", choices=["sorted", "words"], default="sorted", help="words: the receiver runs the direct pipeline on the words of its range (what the bins protocol's receiver sees, plus pass A)")
     ap.add_argument("--serialize", action="store_true", help="also time the serialized size and the index bytes into a host buffer")
     a = ap.parse_args()
     out = {"config": vars(a)}
-    g, bounds, ts, tr, nw = build_share(a.k, a.prefix_bits, a.world, a.rank, a.reads, a.read_len, 42)
+    share = build_share_words if a.protocol == "words" else build_share
+    g, bounds, ts, tr, nw = share(a.k, a.prefix_bits, a.world, a.rank, a.reads, a.read_len, 42)
     _p, ln, kind = g.bucket_table_np()
     out["build"] = {"words_received": nw, "distinct": g.count(), "buckets": int(len(ln)), "bucket_len_mean": float(ln.mean()), "bucket_len_p99": float(np.percentile(ln, 99)),
                     "bucket_len_max": int(ln.max()), "share_over_4096": float(ln[ln > 4096].sum() / ln.sum()), "share_over_8192": float(ln[ln > 8192].sum() / ln.sum()),
@@ -80,7 +125,7 @@ def main():
         out["serialize"] = {"bytes": int(nbytes), "size_s": round(t1 - t0, 3), "bytes_to_host_s": round(t2 - t1, 3)}
         del blob
     if a.merge:
-        h, _, _, _, _ = build_share(a.k, a.prefix_bits, a.world, a.rank, a.reads, a.read_len, 43, bounds=bounds, profile=False)
+        h, _, _, _, _ = share(a.k, a.prefix_bits, a.world, a.rank, a.reads, a.read_len, 43, bounds=bounds, profile=False)
         work = cbl_amd.CBL(a.k, a.prefix_bits, profile=True)
         ts_ = []
         for _ in range(3):
