@@ -170,7 +170,7 @@ template <int THREADS, int NCLS> __device__ __forceinline__ u32 block_append(int
 }
 static const int CLASSIFY_THREADS = 1024;
 
-__global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify(u64 nb, u32 med_max_threads, const u32* __restrict__ bucket_prefix, const u64* __restrict__ raw_start,
+__global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify(u64 nb, u32 lds_max /* longest run one workgroup sorts in LDS */, const u32* __restrict__ bucket_prefix, const u64* __restrict__ raw_start,
                                                                 DirView old, u32* __restrict__ res_count, u8* __restrict__ res_kind, u32* __restrict__ out_count,
                                                                 u8* __restrict__ out_kind, BDesc* __restrict__ lists /* [CLS_N][nb] */, u32* __restrict__ list_n) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -194,12 +194,11 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify(u64 nb, u32 med_m
         else if (c <= 16 * MED_ITEMS) cls = CLS_M16;
         else if (c <= 64 * MED_ITEMS) cls = CLS_M64;    // workgroup size follows the run length: THREADS = CAP / 8
         else if (c <= 128 * MED_ITEMS) cls = CLS_M128;
-        else if (c <= 256 * MED_ITEMS) cls = CLS_M256;
-        else if (c <= 512 * MED_ITEMS) cls = CLS_M512;
+        else if (c <= 256 * MED_ITEMS && c <= lds_max) cls = CLS_M256;
+        else if (c <= 512 * MED_ITEMS && c <= lds_max) cls = CLS_M512;
         else if (c <= BIG_MAX) cls = CLS_BIG;
         else cls = CLS_HUGE;
     }
-    (void)med_max_threads;
     const u32 slot = block_append<CLASSIFY_THREADS, CLS_N>(cls, list_n);
     if (cls >= 0) lists[(u64)cls * nb + slot] = BDesc{raw_start[r], (u32)c | (rk == KIND_TRIE ? BDESC_TRIE : 0u), (u32)r};
 }
@@ -705,7 +704,9 @@ __global__ __launch_bounds__(THREADS) void k_bucket_medium(const BDesc* __restri
 #ifndef CBLX_MSD_LIMIT
 #define CBLX_MSD_LIMIT 48
 #endif
-static const u32 MSD_LIMIT = CBLX_MSD_LIMIT, MSD_LIMIT_HASHED = 16;
+// (suffixes wider than 64 bits — K >= 57 or so — come with longer reads and clusters of up to K mates: their fallback is a radix sort
+// of 13 passes, so they give up later: cfg 4 at the bucket depth of an 8-GPU job 87 -> 73 ms)
+static const u32 MSD_LIMIT = CBLX_MSD_LIMIT, MSD_LIMIT_WIDE = 2 * CBLX_MSD_LIMIT, MSD_LIMIT_HASHED = 16;
 
 template <bool WS> __device__ __forceinline__ u32 sfx_top_bits(const Sfx<WS>& k, u32 SB, u32 nbits) {
     if constexpr (WS) {
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     // clusters) and give up later. A compile-time constant per length class: the runs of the classes up to
     // 1024 words are the hashed ones (a Trie that short only comes out of a loaded file; as a run-time value the limit cost
     // the 2048-slot instantiation four spilled registers and cfg 2 0.3 ms).
-    constexpr u32 crowd = (CAP <= (int)VEC_THRESHOLD && !MERGE) ? MSD_LIMIT_HASHED : MSD_LIMIT;
+    constexpr u32 crowd = (CAP <= (int)VEC_THRESHOLD && !MERGE) ? MSD_LIMIT_HASHED : (WS ? MSD_LIMIT_WIDE : MSD_LIMIT);
 
     for (u32 i = tid; i < NB / 2 + 1; i += THREADS) s_off32[i] = 0;
     if (tid == 0) s_max = 0;
@@ -1467,21 +1468,28 @@ __global__ void k_big_tile_table(const BDesc* __restrict__ list, u32 nruns, cons
 }
 // One descriptor per sub-range (a "virtual bucket" for k_bucket_msd, always asked for the sorted distinct list): sub-range v of
 // run i = the digits [v << (DB - B), (v + 1) << (DB - B)) of the pass, contiguous in the twin from rel[i][v << (DB - B)]
-// (k_seg_adjust's grp_start, relative to the run). A sub-range that outgrows the sort kernel marks itself BIG_SENT - 1 in
-// v_count and is handed over empty, reporting to a dummy slot: the whole run then takes the general kernel.
-__global__ void k_big_vlist(const BDesc* __restrict__ list, u32 nruns, const u64* __restrict__ vb_, const u32* __restrict__ rel /* [nruns][256] */, u32 SB,
-                            BDesc* __restrict__ vlist, u32* __restrict__ v_count, u32 v_dummy) {
+// (k_seg_adjust's grp_start, relative to the run), listed by length class for the sort kernel. A sub-range that outgrows the
+// sort kernel marks itself BIG_SENT - 1 in v_count and is not listed: the whole run then takes the general kernel.
+__global__ __launch_bounds__(256) void k_big_vlist(const BDesc* __restrict__ list, u32 nruns, const u64* __restrict__ vb_, const u32* __restrict__ rel /* [nruns][256] */, u32 SB,
+                                                   BDesc* __restrict__ vlist, u32* __restrict__ v_count, BDesc* __restrict__ cls_lists /* [2][vtot]: <= 1024 words, <= BIG_VCAP */,
+                                                   u32* __restrict__ cls_n, u64 vtot) {
     const u32 i = blockIdx.x, v = threadIdx.x;
-    if (i >= nruns) return;
     const BDesc dsc = list[i];
     const u32 c = dsc.c & ~BDESC_TRIE, DB = big_digit_bits(SB), B = big_bits(c) < DB ? big_bits(c) : DB, V = 1u << B, sh = DB - B;
-    if (v >= V) return;
-    const u32 a = rel[(u64)i * 256 + (v << sh)], b = v + 1 < V ? rel[(u64)i * 256 + ((v + 1) << sh)] : c;
-    const u32 hv = b - a;
-    const bool fits = hv <= BIG_VCAP;
-    const u64 vb = vb_[i];
-    vlist[vb + v] = BDesc{dsc.start + a, (fits ? hv : 0u) | BDESC_TRIE | (B << BDESC_SKIP_SHIFT), fits ? (u32)(vb + v) : v_dummy};
-    v_count[vb + v] = fits ? BIG_SENT : BIG_SENT - 1;
+    int cls = -1;
+    BDesc d{0, 0, 0};
+    if (v < V) {
+        const u32 a = rel[(u64)i * 256 + (v << sh)], b = v + 1 < V ? rel[(u64)i * 256 + ((v + 1) << sh)] : c;
+        const u32 hv = b - a;
+        const bool fits = hv <= BIG_VCAP;
+        const u64 vb = vb_[i];
+        d = BDesc{dsc.start + a, hv | BDESC_TRIE | (B << BDESC_SKIP_SHIFT), (u32)(vb + v)};
+        vlist[vb + v] = d;
+        v_count[vb + v] = fits ? (hv ? BIG_SENT : 0u) : BIG_SENT - 1;  // an empty sub-range is finished
+        if (fits && hv) cls = hv <= 1024 ? 0 : 1;  // the sort kernel's workgroup follows the sub-range's length
+    }
+    const u32 slot = block_append<256, 2>(cls, cls_n);
+    if (cls >= 0) cls_lists[(u64)cls * vtot + slot] = d;
 }
 // One workgroup per big run: its distinct count = the sum over its sorted sub-ranges, which move down over the gaps the
 // duplicates left (in the twin). A run that must stay a Vec or whose sort gave up goes to `fb` for the general kernel.

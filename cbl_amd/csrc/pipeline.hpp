@@ -293,6 +293,7 @@ struct Twin {
     Buf<u64> lo, hi;   // same positions as the arena; hi only for suffixes wider than 64 bits
     Buf<u8> in_twin;   // per bucket rank: 1 = its final words are in the twin
     u64 arrivals = 0;  // words of the runs that went through the twin
+    u64 runs = 0;      // ... and their number
     bool used() const { return lo.get() != nullptr; }
 };
 __global__ void k_set_u32(u32* p, u32 v) { *p = v; }
@@ -315,13 +316,13 @@ template <typename C> void big_stage(cblx_ctx* c, const BDesc* d_list, const u32
             tw.in_twin = Buf<u8>(c->pool, nr.nb + 1);
             CBLX_HIP(hipMemsetAsync(tw.in_twin.get(), 0, nr.nb + 1, c->stream));
         }
-        Buf<u32> ntile(c->pool, nbig), nv(c->pool, nbig), tile_first(c->pool, nbig + 1), vtot_d(c->pool, 1);
+        Buf<u32> ntile(c->pool, nbig), nv(c->pool, nbig), tile_first(c->pool, nbig + 1);
         Buf<u64> vb(c->pool, nbig + 1), run_start(c->pool, nbig);
         hipLaunchKernelGGL(k_big_plan, grid1(nbig, 256), dim3(256), 0, c->stream, d_list, nbig, P.SB, ntile.get(), nv.get());
         const u64 nt64 = exclusive_scan<u32>(c, ntile.get(), nbig, tile_first.get());
         const u64 vtot = exclusive_scan<u64>(c, nv.get(), nbig, vb.get());
         if (nt64 >= 0xFFFFFF00ull / 256) throw Error(CBLX_ERANGE, "too many tiles in the long runs of one batch");
-        const u32 nt = (u32)nt64, vt32 = (u32)vtot;
+        const u32 nt = (u32)nt64;
         hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, c->stream, tile_first.get() + nbig, nt);
         Buf<u64> t_start(c->pool, nt);
         Buf<u32> t_count(c->pool, nt), t_seg(c->pool, nt), counts(c->pool, (size_t)256 * nt), colpre(c->pool, (size_t)256 * nt), scratch, coltot(c->pool, 256),
@@ -342,19 +343,27 @@ template <typename C> void big_stage(cblx_ctx* c, const BDesc* d_list, const u32
         hipLaunchKernelGGL((k_radix_scatter<AH, AH, DigitBits>), dim3(xcd_grid(nt)), dim3(RDX_THREADS), 0, c->stream, (const u64*)a_lo, in_hi, tv, dfn, (const u32*)colpre.get(),
                            (const u32*)adj.get(), tw.lo.get(), out_hi, DigitBits{0, 0}, (u8*)nullptr, (u32*)nullptr, 0u, 0u, 0u, (u32*)nullptr, 0u,
                            OwnWindow{0, 0, nullptr, nullptr, nullptr}, (const u64*)run_start.get());
-        Buf<BDesc> vlist(c->pool, vtot);
-        Buf<u32> v_count(c->pool, vtot + 1);
+        Buf<BDesc> vlist(c->pool, vtot), cls_lists(c->pool, 2 * vtot);
+        Buf<u32> v_count(c->pool, vtot + 1), cls_n(c->pool, 2);
         Buf<u8> v_kind(c->pool, vtot + 1);
         Buf<BDesc> retry(c->pool, vtot);  // sub-ranges the sort gives up on (crowded sub-bucket): their runs fall back as a whole
         Buf<u32> retry_n(c->pool, 1);
-        h2d(c, vtot_d.get(), &vt32, 1);
         CBLX_HIP(hipMemsetAsync(retry_n.get(), 0, 4, c->stream));
+        CBLX_HIP(hipMemsetAsync(cls_n.get(), 0, 8, c->stream));
         CBLX_HIP(hipMemsetAsync(fb_n.get(), 0, 4, c->stream));
-        hipLaunchKernelGGL(k_big_vlist, dim3(nbig), dim3(256), 0, c->stream, d_list, nbig, vb.get(), rel.get(), P.SB, vlist.get(), v_count.get(), vt32);
+        hipLaunchKernelGGL(k_big_vlist, dim3(nbig), dim3(256), 0, c->stream, d_list, nbig, vb.get(), rel.get(), P.SB, vlist.get(), v_count.get(), cls_lists.get(), cls_n.get(), vtot);
+        const std::vector<u32> cn = d2h_vec<u32>(c, cls_n.get(), 2);
         HiT* th = WS ? (HiT*)tw.hi.get() : (HiT*)nullptr;
+        // sub-ranges of up to 1024 words take the 128-thread workgroup — its `self |= other` instantiation without merge
+        // arguments: that one keeps the top-bit sub-bucket limit (the build's 1024-word class assumes hashed sub-buckets)
         auto sort = [&](auto pk) {
-            hipLaunchKernelGGL((k_bucket_msd<256, BIG_VCAP, decltype(pk)::value, WS, HiT>), dim3(vt32), dim3(256), 0, c->stream, vlist.get(), vtot_d.get(), tw.lo.get(), th, P.SB,
-                               v_count.get(), v_kind.get(), retry.get(), retry_n.get(), MergeArgs{});
+            constexpr bool PK = decltype(pk)::value;
+            if (cn[0])
+                hipLaunchKernelGGL((k_bucket_msd<128, 1024, PK, WS, HiT, true>), dim3(cn[0]), dim3(128), 0, c->stream, cls_lists.get(), cls_n.get() + 0, tw.lo.get(), th, P.SB, v_count.get(),
+                                   v_kind.get(), retry.get(), retry_n.get(), MergeArgs{});
+            if (cn[1])
+                hipLaunchKernelGGL((k_bucket_msd<256, BIG_VCAP, PK, WS, HiT>), dim3(cn[1]), dim3(256), 0, c->stream, cls_lists.get() + vtot, cls_n.get() + 1, tw.lo.get(), th, P.SB, v_count.get(),
+                                   v_kind.get(), retry.get(), retry_n.get(), MergeArgs{});
         };
         if constexpr (!WS) { if (P.SB + PK_BITS <= 64) sort(std::true_type()); else sort(std::false_type()); }
         else sort(std::false_type());
@@ -370,6 +379,7 @@ template <typename C> void big_stage(cblx_ctx* c, const BDesc* d_list, const u32
         tw.arrivals += d2h<u64>(c, tot.get());
     }
     const u32 nfb = d2h<u32>(c, fb_n.get());
+    tw.runs += nbig - nfb;
     huge_stage<C>(c, fb.get(), fb_n.get(), nfb, a_lo, a_hi, nr, ma);
 }
 // After every bucket kernel of the stage: the finished long runs sit in the twin, everything else in the arena. The buffer that
@@ -390,7 +400,7 @@ template <typename C> void finish_twin(cblx_ctx* c, Resident& nr, Twin& tw) {
         hipLaunchKernelGGL((k_copy_buckets<WS, LPB>), lpb_grid(nr.nb, LPB), dim3(256), 0, c->stream, nr.nb, nr.start.get(), nr.cnt.get(), tw.in_twin.get(), to_twin ? 0u : 1u, src_lo, src_hi,
                            dst_lo, dst_hi);
     };
-    if (to_twin) with_lpb(T - tw.arrivals, nr.nb, copy); else copy(std::integral_constant<int, 64>());
+    if (to_twin) with_lpb(T - tw.arrivals, nr.nb - std::min<u64>(tw.runs, nr.nb), copy); else copy(std::integral_constant<int, 64>());
     CBLX_HIP(hipGetLastError());
     CBLX_HIP(hipStreamSynchronize(c->stream));
     if (to_twin) {
@@ -421,7 +431,12 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
     Buf<u32> res_count(c->pool, nb + 1);
     Buf<u8> res_kind(c->pool, nb + 1);
     CBLX_HIP(hipMemsetAsync(list_n.get(), 0, CLS_N * 4, c->stream));
-    hipLaunchKernelGGL(k_classify, grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, C::WS ? 512u : 1024u, nr.prefix.get(), nr.start.get(), old,
+    // (suffixes wider than 64 bits: an element takes 18 bytes of LDS, the 4096-word workgroup 82 KB = one per CU, and the Trie
+    // classes cost 60 ps per word on 2000-word buckets against 10 on short ones. Sending runs over 2048 / 1024 words down the
+    // long-run path instead was measured — CBLX_LDS_MAX_WS — and is slower: 134 -> 143 / 165 ms per 1.2 G words at K = 59, the
+    // cost is the ranking inside clusters of up to K mates, whatever the workgroup)
+    static const u32 lds_max_ws = [] { const char* e = std::getenv("CBLX_LDS_MAX_WS"); const u32 v = e ? (u32)std::strtoul(e, nullptr, 10) : 0; return v ? v : 4096u; }();
+    hipLaunchKernelGGL(k_classify, grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, C::WS ? lds_max_ws : 4096u, nr.prefix.get(), nr.start.get(), old,
                        res_count.get(), res_kind.get(), nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get());
     std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
     if (ln[CLS_S32] | ln[CLS_S16]) {
