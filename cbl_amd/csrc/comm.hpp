@@ -10,6 +10,8 @@
 #pragma once
 #include <dlfcn.h>
 
+#include <chrono>
+
 #include "shard.hpp"
 
 namespace {
@@ -326,8 +328,10 @@ inline BinMap make_bin_map(const Consts& P, const u32* bounds, u32 W) {
 }
 inline bool bins_protocol_fits(const Consts& P, const u32* bounds, u32 W) { return P.PB >= 9 && make_bin_map(P, bounds, W).ok; }
 
-template <typename C>
-void sharded_insert_bins(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, const u32* bounds) {
+// `before_slice` (optional): called before slice s is touched — where a caller whose slices are still arriving (a batch on its way
+// over PCIe, flush()) makes the ctx's stream wait for slice s; before_slice(~0u) precedes the first read of the offsets.
+template <typename C, typename Hook>
+void sharded_insert_bins(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, const u32* bounds, Hook&& before_slice) {
     typedef typename C::HiT HiT;
     constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
     typedef typename std::conditional<DROP_HI, NoHi, HiT>::type OutH;  // record layout behind pass A
@@ -348,6 +352,7 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const u8* d_bases, const u64
     for (u32 s = 0; s < nslices; ++s) if (cuts[s + 1] < cuts[s] || cuts[s + 1] > n) throw Error(CBLX_EINVAL, "slice cuts must be ascending and at most n");
     const u64 n0 = cuts[0], n1 = cuts[nslices];
     u64 mine = 0;
+    before_slice(~0u);
     if (n1 > n0) {
         const u64 first = d2h<u64>(c, d_offsets + n0), last = d2h<u64>(c, d_offsets + n1);
         if (last < first) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
@@ -414,6 +419,7 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const u8* d_bases, const u64
     };
     for (u32 s = 0; s < nslices; ++s) {
         const u64 a = cuts[s], b = cuts[s + 1];
+        before_slice(s);
         // -- KRN-1 with the bin histogram fused in, column prefixes of pass A
         ChunkPlan pl;
         const u8* pb = d_bases;
@@ -521,9 +527,54 @@ void sharded_insert(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_
         *bounds_valid = 1;
     }
     if (cm->protocol == CBLX_PROTO_BINS && bins_protocol_fits(c->P, bounds, T.world))
-        sharded_insert_bins<C>(c, T, d_bases, d_offsets, n, cuts, nslices, bounds);
+        sharded_insert_bins<C>(c, T, d_bases, d_offsets, n, cuts, nslices, bounds, [](u32) {});
     else
         sharded_insert_sorted<C>(c, T, d_bases, d_offsets, n, cuts, nslices, bounds, bounds_valid);
+}
+
+// ---- one GPU, a batch that is still arriving: the same slice-by-slice path on a one-rank "group" ---------------------------------
+struct LocalTransport : Transport {
+    LocalTransport() { rank = 0; world = 1; }
+    void all_reduce_sum_u64(u64*, size_t) override {}
+    void all_to_all_u64(const u64* send, u64* recv, size_t per) override { std::memcpy(recv, send, per * 8); }
+    void exchange(const u8*, const u64*, u8*, const u64*, hipStream_t) override {}
+    void wait() override {}
+};
+}  // namespace (reopened below: insert_device_streamed is declared in ingest.hpp)
+
+namespace {
+// flush() of a batch sent from pinned host memory in slices (ingest_seqs): KRN-1 and the first partition pass of slice k run
+// as soon as the slice has landed, while the later slices are still crossing PCIe; when the last one is in, what is left is
+// the remaining passes and the bucket kernels. Same result as insert_device (the slices are pieces of the pass-A segments in
+// stream order, exactly what the receiver of the multi-GPU build gets from its senders).
+void insert_device_streamed(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq, const Ingest::Streamed& plan) {
+    const u32 ns = (u32)plan.seq_cuts.size() - 1;
+    auto wait_for = [&](const std::vector<hipEvent_t>& evs) { for (hipEvent_t e : evs) CBLX_HIP(hipStreamWaitEvent(c->stream, e, 0)); };
+    if (c->P.PB < 9 || nseq == 0) {  // no LSD pass behind pass A: the plain path, once everything is there
+        wait_for(plan.offsets_ready);
+        for (auto& v : plan.ready) wait_for(v);
+        insert_device(c, d_bases, d_offsets, nseq);
+        return;
+    }
+    check_aligned16(d_bases, "d_bases");
+    LocalTransport T;
+    u32 none = 0;
+    const bool trace = std::getenv("CBLX_TRACE_H2D") != nullptr;  // dev: when every slice had landed / was handed to the kernels
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    dispatch(c->P, [&](auto cfg) {
+        sharded_insert_bins<decltype(cfg)>(c, T, d_bases, d_offsets, nseq, plan.seq_cuts.data(), ns, &none, [&](u32 s) {
+            if (s == ~0u) { wait_for(plan.offsets_ready); return; }
+            if (trace) {
+                const double a = ms();
+                for (hipEvent_t e : plan.ready[s]) CBLX_HIP(hipEventSynchronize(e));
+                fprintf(stderr, "[cblx h2d] slice %u: host arrives %.2f ms, landed %.2f ms\n", s, a, ms());
+            }
+            wait_for(plan.ready[s]);
+        });
+    });
+    if (trace) { CBLX_HIP(hipStreamSynchronize(c->stream)); fprintf(stderr, "[cblx h2d] done %.2f ms\n", ms()); }
+    collect_events(c);
 }
 
 }  // namespace

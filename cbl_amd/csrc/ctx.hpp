@@ -140,6 +140,19 @@ struct Ingest {
     std::unique_ptr<Xfer> xfer;
     // consumer of the queue: the insert pipeline, or (cblx_query_fastx_file) the membership query with these tallies, or
     // (cblx_stage_fastx_blocks) the caller, who borrows the staged buffers until cblx_stage_release
+    // one big batch from pinned host memory, on the wire in slices that land front to back (ingest_seqs): flush() then runs
+    // KRN-1 and the first partition pass of slice k while the later slices are still crossing PCIe
+    struct Streamed {
+        std::vector<u64> seq_cuts;                        // sequence index where every slice starts (+ the end)
+        std::vector<std::vector<hipEvent_t>> ready;       // per slice: one event per transfer lane
+        std::vector<hipEvent_t> offsets_ready;            // the offsets array has landed
+        bool active() const { return !seq_cuts.empty(); }
+        void clear() {
+            for (auto& v : ready) for (hipEvent_t e : v) (void)hipEventDestroy(e);
+            for (hipEvent_t e : offsets_ready) (void)hipEventDestroy(e);
+            ready.clear(); offsets_ready.clear(); seq_cuts.clear();
+        }
+    } streamed;
     bool staged = false;
     bool query = false;
     u64 q_total = 0, q_positive = 0;

@@ -79,11 +79,20 @@ void ingest_reserve(cblx_ctx* c, u64 add_bytes, u64 add_seqs) {
     }
 }
 void flush(cblx_ctx* c);
+// (comm.hpp) insert of device-resident sequences in slices, slice k as soon as ready[k] has fired
+void insert_device_streamed(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq, const Ingest::Streamed& plan);
+// slices of a batch that is streamed from pinned host memory (CBLX_H2D_SLICES overrides; 1 = no streaming)
+inline u32 h2d_slices() {
+    const char* e = std::getenv("CBLX_H2D_SLICES");
+    const u32 v = e ? (u32)std::strtoul(e, nullptr, 10) : 0;
+    return v ? std::min(v, 64u) : 16u;
+}
 // one sequence (the cblx_insert_seq / FASTA-record granularity)
 // a piece of the sequence being enqueued (a FASTA record arrives line by line), then its end
 void ingest_bases(cblx_ctx* c, const u8* p, u64 len) {
     Ingest& g = c->ing;
     if (g.staged) throw Error(CBLX_EINVAL, "records are staged in this context: call cblx_stage_release first");
+    g.streamed.clear();  // more than the one streamed batch in the queue: flush() waits for all of it
     ingest_reserve(c, len, 1);
     writer_put(c, g.wb, Ingest::BASES_BLK, g.d_bases.get(), p, len);
     g.nbytes += len;
@@ -138,14 +147,53 @@ template <typename V> void ingest_seqs(cblx_ctx* c, const u8* bases, const u64* 
     if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
     if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));
     Xfer& x = xfer(c);
-    x.h2d_copy(g.d_bases.get() + g.nbytes, bases + offsets[0], len);
-    try { validate(); } catch (...) { x.sync(); throw; }  // the queue's counters were not advanced: the bytes just copied are ignored
     const u64 base = g.nbytes, o0 = offsets[0];
-    x.h2d(g.d_off.get() + 1 + g.nseq, n * 8, [&](u8* dst, size_t off, size_t nb) {
-        u64* d = (u64*)dst;
-        const u64* src = offsets + off / 8 + 1;
-        for (size_t j = 0; j < nb / 8; ++j) d[j] = base + (src[j] - o0);
-    });
+    auto send_offsets = [&] {
+        x.h2d(g.d_off.get() + 1 + g.nseq, n * 8, [&](u8* dst, size_t off, size_t nb) {
+            u64* d = (u64*)dst;
+            const u64* src = offsets + off / 8 + 1;
+            for (size_t j = 0; j < nb / 8; ++j) d[j] = base + (src[j] - o0);
+        });
+    };
+    // A batch that is the whole queue, comes from pinned memory and goes into the insert pipeline is sent in slices that
+    // land front to back (offsets first): flush() works on slice k while the later ones are on the wire.
+    const u32 S = h2d_slices();
+    const bool stream = S > 1 && g.nseq == 0 && g.nbytes == 0 && !g.query && len >= (64u << 20) && n >= 4 * (u64)S && len < ingest_flush_bytes() &&
+                        Xfer::is_pinned(bases + o0) && Xfer::is_pinned(bases + o0 + len - 1);
+    if (stream) {
+        g.streamed.clear();
+        // offsets first (slice 0 cannot be planned without them): straight from the caller's array when it is pinned and
+        // starts at 0 (the copy IS the transform then), else through the lanes' slots; then the bases, slice after slice;
+        // the checks of the offsets run on the host while all of that is on the wire
+        if (o0 == 0 && Xfer::is_pinned(offsets) && Xfer::is_pinned(offsets + n)) {
+            hipEvent_t e;
+            x.h2d_pinned_lane0(g.d_off.get() + 1, offsets + 1, n * 8, e);
+            g.streamed.offsets_ready.push_back(e);
+        } else {
+            send_offsets();
+            x.mark(g.streamed.offsets_ready);
+        }
+        std::vector<size_t> bcuts(1, 0);
+        g.streamed.seq_cuts.assign(1, 0);
+        bool mono = true;
+        for (u32 k = 1; k <= S && mono; ++k) {  // slice k ends at the first sequence boundary at or behind k / S of the bytes
+            const u64 want = o0 + len * k / S;
+            const u64 i = k == S ? n : (u64)(std::lower_bound(offsets, offsets + n + 1, want) - offsets);
+            if (i <= g.streamed.seq_cuts.back()) continue;
+            mono = offsets[i] >= o0 + bcuts.back() && offsets[i] - o0 <= len;  // (unsorted offsets: validate() reports them below)
+            g.streamed.seq_cuts.push_back(i);
+            bcuts.push_back((size_t)(offsets[i] - o0));
+        }
+        if (mono) x.h2d_pinned_sliced(g.d_bases.get(), bases + o0, bcuts, g.streamed.ready);
+        try {
+            validate();
+            if (!mono) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
+        } catch (...) { x.sync(); g.streamed.clear(); throw; }  // the queue's counters were not advanced: what was copied is ignored
+    } else {
+        x.h2d_copy(g.d_bases.get() + g.nbytes, bases + offsets[0], len);
+        try { validate(); } catch (...) { x.sync(); throw; }  // the queue's counters were not advanced: the bytes just copied are ignored
+        send_offsets();
+    }
     g.nbytes += len;
     g.nseq += n;
     g.last_end = g.nbytes;
@@ -159,6 +207,7 @@ void ingest_drop(cblx_ctx* c) {  // forget everything enqueued (clear / load)
     for (Ingest::Writer* w : {&g.wb, &g.wo}) { w->fill = 0; w->issued = 0; w->busy[0] = w->busy[1] = false; }
     g.nbytes = g.nseq = g.last_end = 0;
     g.staged = false;
+    g.streamed.clear();
 }
 void ingest_destroy(cblx_ctx* c) {
     Ingest& g = c->ing;
@@ -183,11 +232,15 @@ void flush(cblx_ctx* c) {
     CBLX_HIP(hipSetDevice(c->device));
     if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
     if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));
-    ingest_wait(c);
+    const bool streamed = g.streamed.active() && !g.query && g.streamed.seq_cuts.back() == nseq;
+    if (!streamed) ingest_wait(c);
     // the pending queue is consumed even if the insert fails (the reference would have panicked)
     for (Ingest::Writer* w : {&g.wb, &g.wo}) { w->issued = 0; w->busy[0] = w->busy[1] = false; }
     g.nbytes = g.nseq = g.last_end = 0;
-    if (g.query) {  // examples/cbl.rs:205-228: contains_seq per record, tallies only
+    if (streamed) {
+        struct Done { cblx_ctx* c; ~Done() { try { ingest_wait(c); } catch (...) {} c->ing.streamed.clear(); } } done{c};
+        insert_device_streamed(c, g.d_bases.get(), g.d_off.get(), nseq, g.streamed);
+    } else if (g.query) {  // examples/cbl.rs:205-228: contains_seq per record, tallies only
         u64 tot = 0, pos = 0;
         query_device(c, g.d_bases.get(), g.d_off.get(), nseq, nullptr, 0, &tot, &pos);
         g.q_total += tot;

@@ -81,6 +81,49 @@ public:
         }
         h2d(d_dst, bytes, [&](u8* dst, size_t off, size_t n) { std::memcpy(dst, (const u8*)h_src + off, n); });
     }
+    // A pinned source in SLICES that land front to back: slice k = bytes [cuts[k], cuts[k + 1]) is split over the lanes'
+    // streams, which take their pieces in slice order; ready[k] receives one event per lane, recorded behind the slice's
+    // pieces — a consumer stream that waits on them may read the slice (and everything in front of it) while the
+    // later slices are still on the wire. The caller destroys the events.
+    void h2d_pinned_sliced(void* d_dst, const void* h_src, const std::vector<size_t>& cuts, std::vector<std::vector<hipEvent_t>>& ready) {
+        const size_t bytes = cuts.empty() ? 0 : cuts.back();
+        // few streams: the runtime maps streams onto a handful of hardware queues, and a consumer stream that shares its
+        // queue with a copy stream runs BEHIND the copies queued there (measured: 8 copy streams made the sliced insert
+        // slower than the one-shot copy); CBLX_H2D_LANES overrides
+        static const int want = [] { const char* e = std::getenv("CBLX_H2D_LANES"); const int v = e ? std::atoi(e) : 0; return v > 0 ? std::min(v, 8) : 2; }();
+        const int L = std::min(want, lanes_for(bytes));
+        ensure(L);
+        ready.assign(cuts.size() ? cuts.size() - 1 : 0, std::vector<hipEvent_t>());
+        for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+            const size_t a = cuts[k], n = cuts[k + 1] - a;
+            const size_t per = ((n + (size_t)L - 1) / (size_t)L + 4095) & ~(size_t)4095;
+            for (int i = 0; i < L; ++i) {
+                const size_t off = (size_t)i * per;
+                if (off < n) CBLX_HIP(hipMemcpyAsync((u8*)d_dst + a + off, (const u8*)h_src + a + off, std::min(per, n - off), hipMemcpyHostToDevice, lanes_[(size_t)i].s));
+                hipEvent_t e;
+                CBLX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ready[k].push_back(e);
+                CBLX_HIP(hipEventRecord(e, lanes_[(size_t)i].s));
+            }
+        }
+    }
+    // a pinned source, whole, at the front of lane 0's queue; `done` fires when it has landed (the caller destroys it)
+    void h2d_pinned_lane0(void* d_dst, const void* h_src, size_t bytes, hipEvent_t& done) {
+        ensure(1);
+        if (bytes) CBLX_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, lanes_[0].s));
+        CBLX_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        CBLX_HIP(hipEventRecord(done, lanes_[0].s));
+    }
+    // one event per active lane, recorded behind everything issued so far (the caller destroys them)
+    void mark(std::vector<hipEvent_t>& evs) {
+        for (auto& l : lanes_) {
+            if (!l.s) continue;
+            hipEvent_t e;
+            CBLX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            evs.push_back(e);
+            CBLX_HIP(hipEventRecord(e, l.s));
+        }
+    }
     // device -> host: drain(src_pinned, off, n) consumes bytes [off, off+n). Complete on return.
     template <typename F> void d2h(const void* d_src, size_t bytes, F&& drain) {
         // software pipeline per lane: issue chunk j, then drain chunk j-1 while j is in flight

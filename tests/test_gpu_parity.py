@@ -356,6 +356,48 @@ def test_incremental_flushes_equal_one_shot():
         assert inc.serialize() == one.serialize() == o.serialize()
 
 
+@pytest.mark.parametrize("k,pb,canonical,nreads,L,dirty", [(31, 24, False, 600_000, 150, False), (59, 28, True, 300_000, 250, True), (25, 12, False, 700_000, 120, True),
+                                                          (31, 8, False, 500_000, 150, False)])
+def test_streamed_insert_from_pinned_host_memory_equals_one_shot(k, pb, canonical, nreads, L, dirty, monkeypatch):
+    """A big batch handed over in PINNED host memory crosses PCIe in slices that land front to back; flush() runs KRN-1 and the
+    first partition pass of slice c while the later slices are on the wire (cblx_insert_seqs + cblx_flush). Same index bytes as
+    the insert of the same reads from device memory, as the same call with streaming switched off, and on top of a non-empty
+    index; reads with N (dirty chunks), a ragged last slice, PREFIX_BITS = 8 (no pass behind pass A: the plain path)."""
+    _need_gpu()
+    d_b, d_o = synth.reads_torch(99, nreads, L, device="cuda")
+    if dirty:
+        d_b = d_b.clone()
+        d_b[torch.arange(7, d_b.numel(), 9973, device="cuda")] = ord("N")
+    hb = torch.empty(d_b.numel(), dtype=torch.uint8, pin_memory=True)
+    ho = torch.empty(d_o.numel(), dtype=torch.int64, pin_memory=True)
+    hb.copy_(d_b)
+    ho.copy_(d_o)
+    torch.cuda.synchronize()
+    nb_, no_ = hb.numpy(), ho.numpy().view(np.uint64)
+    ref = cbl_amd.CBL(k, pb, canonical=canonical)
+    ref.insert_seqs_device(d_b, d_o, nreads)
+    want = ref.serialize()
+    for slices in ("12", "5", "1"):
+        monkeypatch.setenv("CBLX_H2D_SLICES", slices)
+        g = cbl_amd.CBL(k, pb, canonical=canonical)
+        g.insert_seqs(nb_, no_)
+        g.flush()
+        assert g.count() == ref.count()
+        assert g.serialize() == want, slices
+        g.close()
+    # on top of a resident index (the incremental path behind the pieces), then the same batch again: nothing new
+    monkeypatch.setenv("CBLX_H2D_SLICES", "7")
+    half = nreads // 2
+    g = cbl_amd.CBL(k, pb, canonical=canonical)
+    g.insert_seqs_device(d_b, d_o, half)
+    g.insert_seqs(nb_[int(no_[half]):], (no_[half:] - no_[half]))
+    assert g.serialize() == want
+    g.insert_seqs(nb_, no_)
+    assert g.serialize() == want
+    g.close()
+    ref.close()
+
+
 def test_load_then_insert_is_cbl_insert():
     """`cbl insert` (examples/cbl.rs:230-249): read_index, insert_seq per record, write_index."""
     _need_gpu()
