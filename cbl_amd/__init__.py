@@ -78,6 +78,8 @@ SIGNATURES = {
     "cblx_insert_fastx_file": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]),
     "cblx_stage_fastx_blocks": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cblx_stage_fastx_blocks_comm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cblx_stage_release": (C.c_int, [C.c_void_p]),
     "cblx_flush": (C.c_int, [C.c_void_p]),
     "cblx_insert_words_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
@@ -379,6 +381,14 @@ class CBL:
         n, tot = C.c_uint64(0), C.c_uint64(0)
         self._chk(self._L.cblx_stage_fastx_blocks(self._h, os.fsencode(path), block, rank, world, C.byref(pb), C.byref(po), C.byref(n), C.byref(tot)))
         return pb.value or 0, po.value or 0, n.value, tot.value
+
+    def stage_fastx_blocks_comm(self, comm, path, block: int = 0, slices: int = 4):
+        """The same staging with the parse shared between the ranks of `comm` (every rank reads 1 / world of the file). Returns
+        (device address of the bases, of the offsets, n staged, records in the file, block size used)."""
+        pb, po = C.c_void_p(), C.c_void_p()
+        n, tot, blk = C.c_uint64(0), C.c_uint64(0), C.c_uint64(block)
+        self._chk(self._L.cblx_stage_fastx_blocks_comm(self._h, comm._h, os.fsencode(path), C.byref(blk), slices, C.byref(pb), C.byref(po), C.byref(n), C.byref(tot)))
+        return pb.value or 0, po.value or 0, n.value, tot.value, blk.value
 
     def stage_release(self):
         self._chk(self._L.cblx_stage_release(self._h))

@@ -478,6 +478,38 @@ int cblx_comm_set_protocol(cblx_comm* cm, uint32_t protocol) {
     cm->protocol = protocol;
     return CBLX_OK;
 }
+int cblx_stage_fastx_blocks_comm(cblx_ctx* c, cblx_comm* cm, const char* path, uint64_t* block, uint32_t slices, const uint8_t** d_bases, const uint64_t** d_offsets,
+                                 uint64_t* n_staged, uint64_t* n_in_file) {
+    return guard(c, [&] {
+        if (!cm || !path || !block || !d_bases || !d_offsets || !n_staged || !n_in_file) throw Error(CBLX_EINVAL, "null argument");
+        flush(c);  // whatever was enqueued for this index goes in first: the queue changes hands
+        Ingest& g = c->ing;
+        if (g.staged) throw Error(CBLX_EINVAL, "records are staged in this context already: call cblx_stage_release first");
+        Transport& T = *cm->t;
+        bool shared = false;
+        try {
+            shared = fastx_stage_distributed(c, path, *block, slices, T.rank, T.world, [&](u64* v, size_t n) { T.all_reduce_sum_u64(v, n); }, n_staged, n_in_file);
+        } catch (...) { ingest_drop(c); throw; }
+        if (!shared) {  // every rank parses the file (the sequential reader's cases), keeping its own blocks
+            RecordFilter f;
+            if (*block == 0) {
+                f.count_only = true;
+                try { read_fastx_into_queue(c, path, n_in_file, &f); } catch (...) { ingest_drop(c); throw; }
+                *block = std::max<u64>(1, ceil_div(*n_in_file, (u64)T.world * std::max(1u, slices)));
+            }
+            f.block = *block; f.rank = T.rank; f.world = T.world; f.count_only = false;
+            try { read_fastx_into_queue(c, path, n_in_file, &f); } catch (...) { ingest_drop(c); throw; }
+            if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
+            if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));
+        }
+        ingest_wait(c);
+        if (g.nseq == 0) ingest_reserve(c, 0, 0);  // a rank without records still gets valid (empty) arrays
+        g.staged = true;
+        *d_bases = g.d_bases.get();
+        *d_offsets = g.d_off.get();
+        *n_staged = g.nseq;
+    });
+}
 int cblx_sharded_insert_seqs_device(cblx_ctx* c, cblx_comm* cm, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n, const uint64_t* slice_cuts,
                                     uint32_t n_slices, uint32_t* bounds, int* bounds_valid) {
     return guard(c, [&] {

@@ -410,87 +410,92 @@ template <typename Sink> bool fx_walk(const u8* d, const FastxRegion& r, char fm
     }
     return true;
 }
-bool fastx_parallel(cblx_ctx* c, const char* path, u64* nrec_out) {
-    auto env_bytes = [](const char* name, size_t dflt) {  // test hooks: small files through the parallel path
-        const char* e = std::getenv(name);
-        const unsigned long long v = e ? std::strtoull(e, nullptr, 10) : 0;
-        return v ? (size_t)v : dflt;
-    };
-    const size_t MIN_BYTES = env_bytes("CBLX_FASTX_PARALLEL_MIN", 32u << 20), REGION = env_bytes("CBLX_FASTX_REGION_BYTES", 16u << 20);
-    const auto t_entry = std::chrono::steady_clock::now();
-    const int fd = ::open(path, O_RDONLY);
-    if (fd < 0) return false;
-    struct stat st;
-    if (::fstat(fd, &st) != 0 || (size_t)st.st_size < MIN_BYTES) { ::close(fd); return false; }
-    const size_t size = (size_t)st.st_size;
-    const u8* d = (const u8*)::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    ::close(fd);
-    if (d == (const u8*)MAP_FAILED) return false;
-    // Tearing down the page tables of a multi-GB mapping takes tens of milliseconds (30 ms for 1.7 GB): a helper thread does
-    // it while the caller goes on to the insert
-    struct Unmap {
-        const u8* d; size_t n;
-        ~Unmap() {
-            const u8* dd = d; const size_t nn = n;
-            try { std::thread([dd, nn] { ::munmap((void*)dd, nn); }).detach(); } catch (...) { ::munmap((void*)dd, nn); }
-        }
-    } unmap{d, size};
-    (void)::madvise((void*)d, size, MADV_SEQUENTIAL);
-    if (d[0] == 0x1f && d[1] == 0x8b) return false;  // gzip: sequential reader
-    size_t first = 0;
-    while (first < size && (d[first] == '\n' || d[first] == '\r')) ++first;
-    if (first == size || (d[first] != '>' && d[first] != '@')) return false;
-    const char fmt = (char)d[first];
-    // regions
-    std::vector<FastxRegion> regs;
-    for (size_t pos = first; pos < size;) {
-        const size_t nxt = pos + REGION < size ? fx_next_record(d, size, pos + REGION, fmt) : size;
+// a plain FASTA / FASTQ file mapped for the parallel readers
+struct FastxMap {
+    const u8* d = nullptr;
+    size_t size = 0, first = 0;
+    char fmt = 0;
+    ~FastxMap() {
+        // tearing down the page tables of a multi-GB mapping takes tens of milliseconds (30 ms for 1.7 GB): a helper thread
+        // does it while the caller goes on
+        if (!d) return;
+        const u8* dd = d; const size_t nn = size;
+        try { std::thread([dd, nn] { ::munmap((void*)dd, nn); }).detach(); } catch (...) { ::munmap((void*)dd, nn); }
+    }
+    // false: not a file these readers take (small, gzip, unreadable, no record at the start) — the sequential reader's case
+    bool open(const char* path, size_t min_bytes) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (::fstat(fd, &st) != 0 || (size_t)st.st_size < std::max<size_t>(min_bytes, 2)) { ::close(fd); return false; }
+        size = (size_t)st.st_size;
+        const u8* m = (const u8*)::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == (const u8*)MAP_FAILED) return false;
+        d = m;
+        (void)::madvise((void*)d, size, MADV_SEQUENTIAL);
+        if (d[0] == 0x1f && d[1] == 0x8b) return false;  // gzip
+        while (first < size && (d[first] == '\n' || d[first] == '\r')) ++first;
+        if (first == size || (d[first] != '>' && d[first] != '@')) return false;
+        fmt = (char)d[first];
+        return true;
+    }
+};
+inline size_t fastx_env_bytes(const char* name, size_t dflt) {  // test hooks: small files through the parallel paths
+    const char* e = std::getenv(name);
+    const unsigned long long v = e ? std::strtoull(e, nullptr, 10) : 0;
+    return v ? (size_t)v : dflt;
+}
+// [beg, end) (beg at a record start) cut into regions of about `region` bytes at record starts
+inline void fx_make_regions(const FastxMap& m, size_t beg, size_t end, size_t region, std::vector<FastxRegion>& regs) {
+    for (size_t pos = beg; pos < end;) {
+        size_t nxt = pos + region < end ? fx_next_record(m.d, m.size, pos + region, m.fmt) : end;
+        if (nxt > end) nxt = end;
         FastxRegion r;
         r.beg = pos;
         r.end = nxt;
         regs.push_back(std::move(r));
         pos = nxt;
     }
+}
+// pass 1: records and bases of every region (threads; counting needs no transfer lanes). false: something irregular
+inline bool fx_count_regions(const FastxMap& m, std::vector<FastxRegion>& regs, u32 K) {
+    if (regs.empty()) return true;
+    const unsigned hc = std::thread::hardware_concurrency();
+    const int TC = (int)std::min<size_t>(std::max(1u, std::min(2u * (unsigned)Xfer::max_parallel(), hc ? hc / 2 : 2u)), regs.size());
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    struct Count { u64 nrec = 0, nbases = 0; void seq(const u8*, size_t n) { nbases += n; } void rec_end() { ++nrec; } };
+    auto body = [&] {
+        for (size_t i; (i = next.fetch_add(1)) < regs.size();) {
+            Count cnt;
+            regs[i].bad = !fx_walk(m.d, regs[i], m.fmt, K, cnt);
+            regs[i].nrec = cnt.nrec;
+            regs[i].nbases = cnt.nbases;
+        }
+    };
+    for (int t = 1; t < TC; ++t) th.emplace_back(body);
+    body();
+    for (auto& x : th) x.join();
+    for (auto& r : regs) if (r.bad) return false;
+    return true;
+}
+// pass 2 over counted regions, in windows of about `window` bytes of bases: the sequence lines go through one transfer lane per
+// thread straight to their place in the pending queue. flush_windows: insert every full window (the build from a file);
+// else everything stays in the queue (staging). Returns the records copied.
+inline u64 fx_copy_regions(cblx_ctx* c, const FastxMap& m, std::vector<FastxRegion>& regs, u64 window, bool flush_windows) {
     const int T = (int)std::min<size_t>((size_t)Xfer::max_parallel(), regs.size());
     const u32 K = c->P.K;
-    const bool trace = std::getenv("CBLX_INGEST_TRACE") != nullptr;  // phase times on stderr (tuning)
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
-    auto t_phase = t_entry;
-    auto lap = [&](const char* what) { if (trace) { std::fprintf(stderr, "[fastx] %-16s %8.2f ms\n", what, ms_since(t_phase)); } t_phase = now(); };
-    auto parallel_for = [&](auto&& fn) {  // counting needs no lanes: use more threads than pass 2 may
-        const unsigned hc = std::thread::hardware_concurrency();
-        const int TC = (int)std::min<size_t>(std::max(1u, std::min(2u * (unsigned)Xfer::max_parallel(), hc ? hc / 2 : 2u)), regs.size());
-        std::atomic<size_t> next{0};
-        std::vector<std::thread> th;
-        auto body = [&] { for (size_t i; (i = next.fetch_add(1)) < regs.size();) fn(regs[i]); };
-        for (int t = 1; t < TC; ++t) th.emplace_back(body);
-        body();
-        for (auto& x : th) x.join();
-    };
-    lap("map + regions");
-    // pass 1: count
-    struct Count { u64 nrec = 0, nbases = 0; void seq(const u8*, size_t n) { nbases += n; } void rec_end() { ++nrec; } };
-    parallel_for([&](FastxRegion& r) {
-        Count cnt;
-        r.bad = !fx_walk(d, r, fmt, K, cnt);
-        r.nrec = cnt.nrec;
-        r.nbases = cnt.nbases;
-    });
-    for (auto& r : regs) if (r.bad) return false;
-    lap("count pass");
-    // pass 2, in windows of about 1 GiB of bases (the sequential reader's flush cadence)
-    const u64 flush_at = std::min<u64>(1ull << 30, ingest_flush_bytes());
+    const u8* d = m.d;
+    const char fmt = m.fmt;
     Ingest& g = c->ing;
     u64 total_rec = 0;
     for (size_t w0 = 0; w0 < regs.size();) {
         size_t w1 = w0;
         u64 wb = 0, wr = 0;
-        while (w1 < regs.size() && (w1 == w0 || wb + regs[w1].nbases <= flush_at)) { wb += regs[w1].nbases; wr += regs[w1].nrec; ++w1; }
+        while (w1 < regs.size() && (w1 == w0 || wb + regs[w1].nbases <= window)) { wb += regs[w1].nbases; wr += regs[w1].nrec; ++w1; }
         if (wr) {
-            lap("window setup");
             ingest_reserve(c, wb, wr);
-            lap("reserve");
             if (!g.s) CBLX_HIP(hipStreamCreateWithFlags(&g.s, hipStreamNonBlocking));
             if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
             if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));
@@ -517,25 +522,97 @@ bool fastx_parallel(cblx_ctx* c, const char* path, u64* nrec_out) {
                     lw.finish();
                 }
             });
-            lap("parse + copy");
             x.sync();
-            lap("dma drain");
             if (failed) throw Error(CBLX_EDEVICE, "fastx: the file changed while it was being read");
             x.h2d_copy(g.d_off.get() + 1 + g.nseq, ends.get(), (size_t)wr * 8);
             x.sync();
-            lap("offsets upload");
             g.nbytes += wb;
             g.nseq += wr;
             g.last_end = g.nbytes;
             g.wb.issued = g.nbytes;
             g.wo.issued = g.nseq * 8;
             total_rec += wr;
-            if (g.nbytes >= flush_at) { flush(c); lap("flush (insert)"); }
+            if (flush_windows && g.nbytes >= window) flush(c);
         }
         w0 = w1;
     }
-    if (nrec_out) *nrec_out = total_rec;
-    lap("tail");
+    return total_rec;
+}
+bool fastx_parallel(cblx_ctx* c, const char* path, u64* nrec_out) {
+    const size_t MIN_BYTES = fastx_env_bytes("CBLX_FASTX_PARALLEL_MIN", 32u << 20), REGION = fastx_env_bytes("CBLX_FASTX_REGION_BYTES", 16u << 20);
+    FastxMap m;
+    if (!m.open(path, MIN_BYTES)) return false;
+    std::vector<FastxRegion> regs;
+    fx_make_regions(m, m.first, m.size, REGION, regs);
+    if (!fx_count_regions(m, regs, c->P.K)) return false;
+    // pass 2, in windows of about 1 GiB of bases (the sequential reader's flush cadence)
+    const u64 total = fx_copy_regions(c, m, regs, std::min<u64>(1ull << 30, ingest_flush_bytes()), true);
+    if (nrec_out) *nrec_out = total;
+    return true;
+}
+
+// ---- one file, W ranks, every rank touches 1 / W of it (the sharded build from a file, cblx_stage_fastx_blocks_comm) -------
+// The blocks of the file are dealt to the ranks cyclically (block j -> rank j % W), so a rank needs the byte range of ITS
+// blocks — which only a walk over the records can tell. That walk is shared: rank r counts the records of bytes
+// [r, r + 1) * size / W (cut at record starts); the counts are summed over the ranks; every rank then knows the record number its
+// range starts with, finds the byte offset of every block start INSIDE its range (a second, partial walk) and the offsets are
+// summed again (each is known to exactly one rank). Pass 2 reads only the rank's own blocks through the pinned lanes.
+// `reduce(vals, n)`: in-place sum over the ranks (the communicator's all-reduce). Returns false when the file is not one
+// these readers take — decided from the file alone or from the summed flags, so every rank returns the same.
+template <typename Reduce>
+bool fastx_stage_distributed(cblx_ctx* c, const char* path, u64& block, u32 target_slices, u32 rank, u32 world, Reduce&& reduce, u64* n_staged, u64* n_in_file) {
+    const size_t REGION = fastx_env_bytes("CBLX_FASTX_REGION_BYTES", 16u << 20);
+    FastxMap m;
+    u64 flag = m.open(path, 0) ? 0 : 1;
+    const u32 K = c->P.K;
+    // pass 1: the records of my byte range
+    std::vector<FastxRegion> regs;
+    size_t cut0 = 0, cut1 = 0;
+    if (!flag) {
+        auto cut = [&](u32 r) { return r == 0 ? m.first : (r >= world ? m.size : fx_next_record(m.d, m.size, std::max<size_t>(m.first, (size_t)((unsigned __int128)m.size * r / world)), m.fmt)); };
+        cut0 = cut(rank);
+        cut1 = cut(rank + 1);
+        fx_make_regions(m, cut0, cut1, REGION, regs);
+        if (!fx_count_regions(m, regs, K)) flag = 1;
+    }
+    std::vector<u64> v(world + 1, 0);
+    u64 mine = 0;
+    for (auto& r : regs) mine += r.nrec;
+    v[rank] = flag ? 0 : mine;
+    v[world] = flag;
+    reduce(v.data(), v.size());
+    if (v[world]) return false;  // some rank met something irregular (a record shorter than K, a malformed FASTQ record, gzip)
+    u64 n_file = 0, g0 = 0;
+    for (u32 r = 0; r < world; ++r) { if (r < rank) g0 += v[r]; n_file += v[r]; }
+    *n_in_file = n_file;
+    if (block == 0) block = std::max<u64>(1, ceil_div(n_file, (u64)world * std::max(1u, target_slices)));
+    const u64 nblocks = ceil_div(n_file, block);
+    // byte offset of every block start inside my range
+    std::vector<u64> boff(nblocks + 1, 0);
+    {
+        size_t ri = 0;
+        u64 rfirst = g0;  // global number of region ri's first record
+        for (u64 j = ceil_div(g0, block); j < nblocks && j * block < g0 + mine; ++j) {
+            const u64 want = j * block;
+            while (ri < regs.size() && rfirst + regs[ri].nrec <= want) { rfirst += regs[ri].nrec; ++ri; }
+            size_t pos = regs[ri].beg;
+            for (u64 k = rfirst; k < want; ++k) pos = fx_next_record(m.d, regs[ri].end, pos + 1, m.fmt);  // skip want - rfirst records
+            boff[j] = pos;
+        }
+    }
+    if (nblocks) reduce(boff.data(), nblocks);  // (the last entry is the same everywhere)
+    boff[nblocks] = m.size;
+    // pass 2: my blocks j = rank, rank + W, ... in order
+    std::vector<FastxRegion> mine_regs;
+    u64 expect = 0;
+    for (u64 j = rank; j < nblocks; j += world) {
+        fx_make_regions(m, (size_t)boff[j], (size_t)boff[j + 1], REGION, mine_regs);
+        expect += std::min<u64>(block, n_file - j * block);
+    }
+    if (!fx_count_regions(m, mine_regs, K)) throw Error(CBLX_EDEVICE, "fastx: the file changed while it was being read");
+    const u64 got = fx_copy_regions(c, m, mine_regs, ~0ull >> 1, false);
+    if (got != expect) throw Error(CBLX_EDEVICE, "fastx: the file changed while it was being read");
+    *n_staged = got;
     return true;
 }
 

@@ -132,6 +132,17 @@ class GpuEngine:
         self.device = dev
         return bases, offsets, n, n_file
 
+    def stage_fastx_blocks_comm(self, comm, path, block, slices):
+        """The same with the parse shared between the ranks of a native communicator: every rank reads 1 / world of the file."""
+        torch = self.torch
+        pb, po, n, n_file, block = self.cbl.stage_fastx_blocks_comm(comm, path, block, slices)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        offsets = torch.as_tensor(_DeviceArray(po, n + 1, "<i8"), device=dev)
+        nbytes = int(offsets[n]) if n else 0
+        bases = torch.as_tensor(_DeviceArray(pb, max(nbytes, 1), "|u1"), device=dev)
+        self.device = dev
+        return bases, offsets, n, n_file, block
+
     def stage_release(self):
         self.cbl.stage_release()
 
@@ -304,10 +315,14 @@ class ShardedBuilder(_Wire):
         to `cbl build` of the file (/root/reference/examples/cbl.rs:154-166). block = 0: sized so that every rank gets
         about `slices` blocks. Returns the number of records in the file."""
         eng, W = self.engine, self.world
-        if block <= 0:
-            n_file = eng.count_fastx_records(path)
-            block = max(1, -(-n_file // (W * self.slices)))
-        bases, offsets, n, n_file = eng.stage_fastx_blocks(path, block, self.rank, W)
+        if self.comm is not None and hasattr(eng, "stage_fastx_blocks_comm"):
+            # the parse is shared: every rank scans 1 / W of the file and reads only the bytes of its own blocks
+            bases, offsets, n, n_file, block = eng.stage_fastx_blocks_comm(self.comm, path, max(block, 0), self.slices)
+        else:
+            if block <= 0:
+                n_file = eng.count_fastx_records(path)
+                block = max(1, -(-n_file // (W * self.slices)))
+            bases, offsets, n, n_file = eng.stage_fastx_blocks(path, block, self.rank, W)
         try:
             nblocks = -(-n_file // block)
             rounds = -(-nblocks // W)  # the blocks of the file are dealt W at a time

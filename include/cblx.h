@@ -85,6 +85,15 @@ int cblx_flush(cblx_ctx* ctx);
 int cblx_stage_fastx_blocks(cblx_ctx* ctx, const char* path, uint64_t block, uint32_t rank, uint32_t world, const uint8_t** d_bases,
                             const uint64_t** d_offsets, uint64_t* n_staged, uint64_t* n_in_file);
 int cblx_stage_release(cblx_ctx* ctx);
+/* The same staging for the ranks of a communicator (rank / world are the communicator's), with the parse SHARED between them:
+ * rank r counts the records of bytes [r, r + 1) * size / world of the file, the counts and the byte offsets of the block starts
+ * are summed over the ranks, and every rank then reads only the bytes of ITS blocks — host time per rank ~ 1 / world instead of
+ * one whole-file parse per rank. *block: records per block; 0 = chosen here so that every rank gets about `slices` blocks
+ * (written back). A file the parallel readers do not take (gzip, a record shorter than K, a malformed FASTQ record) falls back
+ * to cblx_stage_fastx_blocks on every rank. Collective: every rank of the communicator calls it with the same path. */
+struct cblx_comm;
+int cblx_stage_fastx_blocks_comm(cblx_ctx* ctx, struct cblx_comm* comm, const char* path, uint64_t* block, uint32_t slices,
+                                 const uint8_t** d_bases, const uint64_t** d_offsets, uint64_t* n_staged, uint64_t* n_in_file);
 
 /* Device word arrays (all *_words_device entry points): word i = (hi[i] << 64) | lo[i]. `lo` is uint64_t[]; the element
  * type of `hi` follows from K like the reference's T (build.rs:34-41) and is reported by cblx_consts.hi_bytes:

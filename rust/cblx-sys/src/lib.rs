@@ -138,6 +138,17 @@ extern "C" {
         n_in_file: *mut u64,
     ) -> c_int;
     pub fn cblx_stage_release(ctx: *mut cblx_ctx) -> c_int;
+    pub fn cblx_stage_fastx_blocks_comm(
+        ctx: *mut cblx_ctx,
+        comm: *mut cblx_comm,
+        path: *const c_char,
+        block: *mut u64,
+        slices: u32,
+        d_bases: *mut *const u8,
+        d_offsets: *mut *const u64,
+        n_staged: *mut u64,
+        n_in_file: *mut u64,
+    ) -> c_int;
 
     pub fn cblx_insert_words_device(ctx: *mut cblx_ctx, d_lo: *const u64, d_hi: *const c_void, n: u64) -> c_int;
     pub fn cblx_seq_words_device(

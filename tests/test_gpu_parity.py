@@ -1837,10 +1837,19 @@ def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q, protoco
         blob = sharded.gather_serialized(g.serialize(), dist)
         fblob = None
         if path:
-            h = cbl_amd.CBL(k, pb, canonical=canonical, device=0)
-            sf = sharded.ShardedBuilder(h, dist, slices=3, comm=comm, protocol=protocol)
-            sf.insert_fastx_file(path, 5)
-            fblob = sharded.gather_serialized(h.serialize(), dist)
+            # one file, the parse shared between the ranks (cblx_stage_fastx_blocks_comm): regions of 3000 bytes so that even this
+            # small file is cut into many; a given block size, then the library's choice (block = 0), then a FASTQ file
+            os.environ["CBLX_FASTX_REGION_BYTES"] = "3000"
+            fblob = []
+            for pth, blk in ((path, 5), (path, 0), (path + ".fq", 0), (path + ".short", 4)):
+                h = cbl_amd.CBL(k, pb, canonical=canonical, device=0)
+                sf = sharded.ShardedBuilder(h, dist, slices=3, comm=comm, protocol=protocol)
+                try:
+                    nrec = sf.insert_fastx_file(pth, blk)
+                    fblob.append((nrec, sharded.gather_serialized(h.serialize(), dist)))
+                except cbl_amd.CblxError as e:  # the file with a record shorter than K: ESHORT on the rank that owns it
+                    fblob.append(("error", e.code))
+                    break
         if rank == 0:
             q.put((blob, [int(x) for x in sb.bounds], g.count(), fblob, sb.stats["sent_bytes"]))
         comm.close()
@@ -1866,6 +1875,10 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
     per = [(700, 2), (300, 450), (1, 600), (512, 0), (64, 64), (0, 900), (333, 5), (90, 90)][:world]
     path = str(tmp_path / "reads.fa")
     recs = _ragged_fasta(path, 77, 43)
+    qrecs = _ragged_fasta(path + ".fq", 78, 29, fastq=True)
+    with open(path + ".short", "wb") as f:  # record 9 is shorter than K: every rank falls back to the sequential reader, its owner reports it
+        for i, r in enumerate(recs[:12]):
+            f.write(b">s%d\n" % i + (r[:20] if i == 9 else r) + b"\n")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -1892,7 +1905,10 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
                     one.insert_seqs(hb, ho)
     assert blob == one.serialize()
     assert len(bounds) == world - 1 and 0 < count0 < one.count() and sent > 0
-    of = Oracle(k, pb, canonical)
+    of, oq = Oracle(k, pb, canonical), Oracle(k, pb, canonical)
     for r in recs:
         of.insert_seq(r)
-    assert fblob == of.serialize()
+    for r in qrecs:
+        oq.insert_seq(r)
+    assert fblob[0] == (len(recs), of.serialize()) and fblob[1] == (len(recs), of.serialize())
+    assert fblob[2] == (len(qrecs), oq.serialize())
