@@ -562,6 +562,13 @@ bool fastx_parallel(cblx_ctx* c, const char* path, u64* nrec_out) {
 template <typename Reduce>
 bool fastx_stage_distributed(cblx_ctx* c, const char* path, u64& block, u32 target_slices, u32 rank, u32 world, Reduce&& reduce, u64* n_staged, u64* n_in_file) {
     const size_t REGION = fastx_env_bytes("CBLX_FASTX_REGION_BYTES", 16u << 20);
+    const bool trace = std::getenv("CBLX_INGEST_TRACE") != nullptr;  // phase times on stderr (tuning)
+    auto t_phase = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto t = std::chrono::steady_clock::now();
+        if (trace) std::fprintf(stderr, "[fastx rank %u/%u] %-22s %8.2f ms\n", rank, world, what, std::chrono::duration<double, std::milli>(t - t_phase).count());
+        t_phase = t;
+    };
     FastxMap m;
     u64 flag = m.open(path, 0) ? 0 : 1;
     const u32 K = c->P.K;
@@ -580,7 +587,9 @@ bool fastx_stage_distributed(cblx_ctx* c, const char* path, u64& block, u32 targ
     for (auto& r : regs) mine += r.nrec;
     v[rank] = flag ? 0 : mine;
     v[world] = flag;
+    lap("map + count my range");
     reduce(v.data(), v.size());
+    lap("sum of the counts");
     if (v[world]) return false;  // some rank met something irregular (a record shorter than K, a malformed FASTQ record, gzip)
     u64 n_file = 0, g0 = 0;
     for (u32 r = 0; r < world; ++r) { if (r < rank) g0 += v[r]; n_file += v[r]; }
@@ -600,7 +609,9 @@ bool fastx_stage_distributed(cblx_ctx* c, const char* path, u64& block, u32 targ
             boff[j] = pos;
         }
     }
+    lap("block starts in my range");
     if (nblocks) reduce(boff.data(), nblocks);  // (the last entry is the same everywhere)
+    lap("sum of the offsets");
     boff[nblocks] = m.size;
     // pass 2: my blocks j = rank, rank + W, ... in order
     std::vector<FastxRegion> mine_regs;
@@ -610,7 +621,9 @@ bool fastx_stage_distributed(cblx_ctx* c, const char* path, u64& block, u32 targ
         expect += std::min<u64>(block, n_file - j * block);
     }
     if (!fx_count_regions(m, mine_regs, K)) throw Error(CBLX_EDEVICE, "fastx: the file changed while it was being read");
+    lap("count my blocks");
     const u64 got = fx_copy_regions(c, m, mine_regs, ~0ull >> 1, false);
+    lap("copy my blocks to HBM");
     if (got != expect) throw Error(CBLX_EDEVICE, "fastx: the file changed while it was being read");
     *n_staged = got;
     return true;
