@@ -449,6 +449,10 @@ def main():
             if (c["k"], c["prefix_bits"], c["reads_per_gpu"], c["read_len"], c.get("kind", "build")) == (K, PB, NR, L, args.kind) and \
                     tj["kernel"] == dom["name"] and tj.get("src_sha") == source_hash() and world == 1 and engine is None:
                 traffic = tj["hbm_bytes_per_launch"]
+                for row in kernels:  # the other kernel groups the counter passes covered: HBM bytes per launch of the group
+                    kt = tj.get("kernels", {}).get(row["stage"])
+                    if kt and row["launches_per_step"]:
+                        row["traffic"] = int(kt["hbm_bytes_per_step"] / row["launches_per_step"])
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "hbm", "kernel": dom["name"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom["frac"],

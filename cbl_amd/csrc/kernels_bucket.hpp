@@ -772,6 +772,16 @@ static const int MSD_TRIP = CBLX_MSD_TRIP;  // sub-bucket entries read per trip 
 
 // MERGE: the instantiation `self |= other` launches (its epilogue keeps a dozen more registers live, which the build's
 // instantiation must not pay for: 6.8 -> 7.0 ms at cfg 2 when the two shared one kernel)
+// WIDE PACKED (suffixes wider than 64 bits, SUFFIX_BITS + 12 <= 128): an element is ONE 16-byte LDS slot = suffix << 12 | stream
+// index, read with one ds_read_b128 and compared as a 128-bit number — instead of three arrays (lo, hi, 16-bit index) and three
+// LDS reads per comparison. 16 instead of 18 bytes per slot also lets two 4096-slot workgroups share a CU instead of one.
+struct __attribute__((aligned(16))) W128 { u64 lo, hi; };
+__device__ __forceinline__ W128 w128_pack(const Sfx<true>& k, u32 idx) { return W128{(k.lo << 12u) | idx, (k.hi << 12u) | (k.lo >> (64 - 12u))}; }
+__device__ __forceinline__ Sfx<true> w128_sfx(const W128& w) { Sfx<true> s; s.lo = (w.lo >> 12u) | (w.hi << (64 - 12u)); s.hi = w.hi >> 12u; return s; }
+__device__ __forceinline__ bool w128_less(const W128& a, const W128& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+__device__ __forceinline__ bool w128_same_sfx(const W128& a, const W128& b) { return a.hi == b.hi && ((a.lo ^ b.lo) >> 12u) == 0; }
+template <bool WS> __host__ __device__ inline bool msd_takes(u32 SB) { return !WS || SB + 12u <= 128; }  // else: the LDS radix kernel
+
 template <int THREADS, int CAP, bool PACKED, bool WS, typename HiT, bool MERGE = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MSD_WAVES, 8))) void k_bucket_msd(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
                                                         u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
@@ -781,9 +791,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     static_assert(!(PACKED && WS), "packed elements need a narrow suffix");
     static_assert(CAP <= (1 << PK_BITS), "stream index must fit PK_BITS");
     constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
-    __shared__ u64 s_klo[CAP + 4];  // + slack: the ranking loop reads up to 3 entries past a sub-bucket
-    __shared__ u64 s_khi[WS ? CAP + 4 : 1];
-    __shared__ u16 s_idx[PACKED ? 1 : CAP + 4];
+    constexpr bool WP = WS;  // wide suffixes: 16-byte packed elements (callers route SUFFIX_BITS > 116 to the radix kernel: msd_takes)
+    __shared__ u64 s_klo[WP ? 1 : CAP + 4];  // + slack: the ranking loop reads up to 3 entries past a sub-bucket
+    __shared__ W128 s_kw[WP ? CAP + 4 : 1];
+    __shared__ u16 s_idx[(PACKED || WP) ? 1 : CAP + 4];
     // sub-bucket counts, then exclusive offsets: 16-bit entries (values <= CAP), counted with 32-bit LDS atomics on the
     // containing dword (LDS is what bounds residency here)
     __shared__ u32 s_off32[CAP / 2 + 2];
@@ -880,6 +891,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
 #endif
     if (tid == 0) s_off[NB] = (u16)c;
     if constexpr (PACKED) { if (tid < 4) s_klo[c + tid] = ~0ull; }  // the slack the ranking loop may read compares greater than every element
+    if constexpr (WP) { if (tid < 4) s_kw[c + tid] = W128{~0ull, ~0ull}; }
     // scatter into sub-bucket order (arrival order inside a sub-bucket is arbitrary); the offsets are fetched for all
     // slots at once, outside the per-slot branches (sub[] is in range for unused slots too)
     u32 sbase[ITEMS];
@@ -899,9 +911,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
 #endif
             if constexpr (PACKED) {
                 s_klo[p] = (key[j].lo << PK_BITS) | e;
+            } else if constexpr (WP) {
+                s_kw[p] = w128_pack(key[j], e);
             } else {
                 s_klo[p] = key[j].lo;
-                if constexpr (WS) s_khi[p] = key[j].hi;
                 s_idx[p] = (u16)e;
             }
         }
@@ -989,6 +1002,33 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
                     }
                 }
 #endif
+            } else if constexpr (WP) {
+                const W128 me = w128_pack(key[j], e);
+                if (vec_only) {  // hashed sub-buckets: what follows a sub-bucket is unrelated, entries past b are masked
+                    for (u32 q = a; q < b; q += 2) {
+                        W128 o[2];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) o[k] = s_kw[q + k];  // 4 slack entries
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const bool less = (q + k < b) && w128_less(o[k], me);
+                            rank += less ? 1u : 0u;
+                            dup |= less && w128_same_sfx(o[k], me);
+                        }
+                    }
+                } else {  // ascending sub-buckets: whatever follows b (the next sub-bucket, or the all-ones slack) is greater than `me`
+                    for (u32 q = a; q < b; q += 2) {
+                        W128 o[2];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) o[k] = s_kw[q + k];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const bool less = w128_less(o[k], me);
+                            rank += less ? 1u : 0u;
+                            dup |= less && w128_same_sfx(o[k], me);
+                        }
+                    }
+                }
             } else {
                 for (u32 q = a; q < b; q += 2) {
                     Sfx<WS> o[2];
@@ -996,7 +1036,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         o[k].lo = s_klo[q + k];
-                        if constexpr (WS) o[k].hi = s_khi[q + k];
                         oi[k] = (u32)s_idx[q + k];
                     }
 #pragma unroll
@@ -1023,9 +1062,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
                 const u32 e = w * EPW + j * 64 + lane;
                 if constexpr (PACKED) {
                     s_klo[fin[j]] = (key[j].lo << PK_BITS) | e;
+                } else if constexpr (WP) {
+                    s_kw[fin[j]] = w128_pack(key[j], e);
                 } else {
                     s_klo[fin[j]] = key[j].lo;
-                    if constexpr (WS) s_khi[fin[j]] = key[j].hi;
                     s_idx[fin[j]] = (u16)e;
                 }
             }
@@ -1045,10 +1085,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
                 key[j].lo = v >> PK_BITS;
                 idx[j] = (u32)v & ((1u << PK_BITS) - 1u);
                 prev.lo = u >> PK_BITS;
+            } else if constexpr (WP) {
+                const W128 v = s_kw[pc], u = s_kw[pp];
+                key[j] = w128_sfx(v);
+                idx[j] = (u32)v.lo & ((1u << PK_BITS) - 1u);
+                prev = w128_sfx(u);
             } else {
                 key[j].lo = s_klo[pc];
                 prev.lo = s_klo[pp];
-                if constexpr (WS) { key[j].hi = s_khi[pc]; prev.hi = s_khi[pp]; }
                 idx[j] = s_idx[pc];
             }
             valid[j] = live;
@@ -1138,9 +1182,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
             if (valid[j]) {
                 if constexpr (PACKED) {
                     s_klo[fin[j]] = (key[j].lo << 1) | (head[j] ? 1ull : 0ull);
+                } else if constexpr (WP) {
+                    s_kw[fin[j]] = w128_pack(key[j], head[j] ? 1u : 0u);
                 } else {
                     s_klo[fin[j]] = key[j].lo;
-                    if constexpr (WS) s_khi[fin[j]] = key[j].hi;
                     s_idx[fin[j]] = head[j] ? 1 : 0;
                 }
             }
@@ -1157,9 +1202,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
                 const u64 v = s_klo[pc];
                 head[j] = live && (v & 1ull);
                 key[j].lo = v >> 1;
+            } else if constexpr (WP) {
+                const W128 v = s_kw[pc];
+                head[j] = live && (v.lo & 1ull);
+                key[j] = w128_sfx(v);
             } else {
                 key[j].lo = s_klo[pc];
-                if constexpr (WS) key[j].hi = s_khi[pc];
                 head[j] = live && s_idx[pc] != 0;
             }
         }

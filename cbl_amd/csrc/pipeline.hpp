@@ -472,8 +472,19 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
         bool repeat_mode = false;
         std::vector<u32> any(5, 0u);
         bool used_msd[5] = {false, false, false, false, false};
+        // suffixes too wide for the counting-sort kernel's 16-byte elements (SUFFIX_BITS > 116: K >= 57 with a handful of prefix
+        // bits): every class takes the LDS radix kernel
+        const bool radix_only = !msd_takes<C::WS>(P.SB);
+        if (radix_only) {
+            for (int k = 0; k < 5; ++k)
+                if (ln[MCLS[k]])
+                    hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(ln[MCLS[k]]), dim3(512), 0, c->stream, lists.get() + (size_t)MCLS[k] * nb, list_n.get() + MCLS[k], a_lo, a_hi,
+                                       P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
+            CBLX_HIP(hipGetLastError());
+        }
         auto stage = [&](auto packed_tag) {
             constexpr bool PK = decltype(packed_tag)::value;
+            if (radix_only) return;
             auto go = [&](auto thr, auto cap, int k) {
                 constexpr int T = decltype(thr)::value, CAPV = decltype(cap)::value;
                 const int cls = MCLS[k];
@@ -583,7 +594,8 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
         }
     }
     if (!long_done) {
-        big_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], nr, MergeArgs{}, tw);
+        if (msd_takes<C::WS>(P.SB)) big_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], nr, MergeArgs{}, tw);
+        else huge_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], a_lo, a_hi, nr, MergeArgs{});
         huge_stage<C>(c, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE, ln[CLS_HUGE], a_lo, a_hi, nr, MergeArgs{});
     }
     }
@@ -1190,7 +1202,12 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
         if constexpr (!WS) {
             if (P.SB + PK_BITS <= 64) msd(std::true_type()); else msd(std::false_type());
         } else {
-            msd(std::false_type());
+            if (msd_takes<WS>(P.SB)) msd(std::false_type());
+            else  // (see bucket_stage) every class to the LDS radix kernel
+                for (int cls : {CLS_M16, CLS_M64, CLS_M128, CLS_M256, CLS_M512})
+                    if (ln[cls])
+                        hipLaunchKernelGGL((k_bucket_medium<512, WS, HiT>), dim3(ln[cls]), dim3(512), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls, a_lo, a_hi, P.SB,
+                                           nr.cnt.get(), nr.kind.get(), ma);
         }
         const u32 nretry = (ln[CLS_M16] || ln[CLS_M64] || ln[CLS_M128] || ln[CLS_M256] || ln[CLS_M512]) ? d2h<u32>(c, retry_n.get()) : 0u;
         if (nretry)
@@ -1203,7 +1220,8 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
     }
     {
         Twin tw;
-        big_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], nr, ma, tw);
+        if (msd_takes<WS>(P.SB)) big_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], nr, ma, tw);
+        else huge_stage<C>(c, lists.get() + (size_t)CLS_BIG * nb, list_n.get() + CLS_BIG, ln[CLS_BIG], a_lo, a_hi, nr, ma);
         huge_stage<C>(c, lists.get() + (size_t)CLS_HUGE * nb, list_n.get() + CLS_HUGE, ln[CLS_HUGE], a_lo, a_hi, nr, ma);
         finish_twin<C>(c, nr, tw);
     }

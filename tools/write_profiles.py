@@ -32,6 +32,24 @@ la = {"fetch_kb_raw": f[kA][2], "write_kb_raw": w[kA][2], "alg_bytes": 18 * NK}
 ll = {"fetch_kb_raw": f[kL][2], "write_kb_raw": w[kL][2], "alg_bytes": int(16.5 * NK)}
 hbm = lambda d: (2 * d["fetch_kb_raw"] + d["write_kb_raw"]) * 1024
 avg = (hbm(la) + 2 * hbm(ll)) / 3
+def group(pred):
+    """sum over the launches of a step of every kernel whose name satisfies pred: (launches, fetch KB, write KB)"""
+    ks = [k for k in f if pred(k)]
+    return sum(f[k][0] for k in ks), sum(f[k][1] for k in ks), sum(w[k][1] for k in ks if k in w)
+
+
+K_, PB_, L_ = bl["config"]["k"], bl["config"]["prefix_bits"], bl["config"]["read_len"]
+sys.path.insert(0, ".")
+import bench as _b  # noqa: E402  (the price list the line uses)
+
+alg = _b.stage_alg_bytes(K_, PB_, L_)
+per_kernel = {}
+for stage, pred in (("encode", lambda k: "k_encode<" in k), ("bucket_medium", lambda k: "k_bucket_msd<" in k or "k_bucket_claim<" in k),
+                    ("radix_scatter", lambda k: "k_radix_scatter<" in k), ("radix_hist", lambda k: "k_radix_hist" in k)):
+    n, fk, wk = group(pred)
+    if n:
+        per_kernel[stage] = {"launches_per_step": n, "fetch_kb_raw_per_step": fk, "write_kb_raw_per_step": wk,
+                             "hbm_bytes_per_step": int((2 * fk + wk) * 1024), "algorithmic_bytes_per_step": int(alg[stage] * NK)}
 tr = {
     "config": {**{k: bl["config"][k] for k in ("k", "prefix_bits", "reads_per_gpu", "read_len")}, "kind": "build"},
     "kernel": "k_radix_scatter",
@@ -42,6 +60,8 @@ tr = {
                  "k_radix_scatter<NoHi,NoHi> (LSD passes, x2: 8 B in, 8 B (+1 B digit) out)": ll},
     "hbm_bytes_per_launch": int(avg),
     "algorithmic_bytes_per_launch": int(51 * NK / 3),
+    # the same counters for the other kernel groups that matter, per STEP (all launches of the group): roofline.kernels[].traffic
+    "kernels": per_kernel,
     "source": f"profiles/{rnd}_pmc_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE in separate passes, KB per dispatch x 1024; "
               "FETCH doubled per the gfx950 note); average over the 3 scatter launches of a step",
 }
