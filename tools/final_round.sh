@@ -1,13 +1,18 @@
 #!/bin/bash
 # End-of-round evidence on the GPU box: the -m gpu suite, kernel stats + HBM traffic of the default workload, the SQ counter
-# passes, and the bench line of every workload. Usage: gpurun -- 'bash tools/final_round.sh <tag>'
+# passes, the bench line of every workload, the per-rank cost of the N-GPU code path, the emulated 8-GPU rank.
+# Usage: gpurun -- 'bash tools/final_round.sh <tag>'
 TAG=${1:-final}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 python3 -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-timeout 3000 python -m pytest tests -m gpu -x -q --durations=8 > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest.log
+timeout 3000 python -m pytest tests -x -q -m gpu --durations=8 > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest.log
 bash tools/collect_profiles.sh $TAG
 bash tools/collect_counters.sh ${TAG}_sq cfg2
-for c in cfg3 cfg4 merge dup; do timeout 900 python bench.py --config $c --steps 5 --warmup 2 > $OUT/bench_$c.json 2> $OUT/bench_$c.err; echo "bench $c rc=$?"; done
-timeout 900 python tools/emulate_rank.py --merge --serialize > $OUT/emul_cfg5.json 2> $OUT/emul_cfg5.err; echo "emul rc=$?"
+bash tools/r3_lines.sh $TAG configs sharded
+for w in "--reads 10000000" "" "--reads 12500000 --prefix-bits 28" "--k 59 --prefix-bits 28 --reads 6250000 --read-len 250"; do
+  n=$(echo "$w" | tr -d ' -' | cut -c1-24); [ -z "$n" ] && n=cfg5
+  m=""; case "$n" in reads10000000|cfg5) m="--merge";; esac
+  timeout 900 python tools/emulate_rank.py --protocol words $m $w > $OUT/emul_$n.json 2> $OUT/emul_$n.err; echo "emul [$w] rc=$?"
+done

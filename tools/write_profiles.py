@@ -26,7 +26,7 @@ def parse(md):
 
 f, w = parse(base + "pmc_fetch.md"), parse(base + "pmc_write.md")
 kA = [k for k in f if "k_radix_scatter<unsigned char" in k][0]
-kL = [k for k in f if "k_radix_scatter<cblx::NoHi, cblx::NoHi, cblx::DigitBits>" in k][0]
+kL = [k for k in f if "k_radix_scatter<cblx::NoHi, cblx::NoHi, cblx::DigitBits" in k][0]
 NK = bl["config"]["reads_per_gpu"] * (bl["config"]["read_len"] - bl["config"]["k"] + 1)
 la = {"fetch_kb_raw": f[kA][2], "write_kb_raw": w[kA][2], "alg_bytes": 18 * NK}
 ll = {"fetch_kb_raw": f[kL][2], "write_kb_raw": w[kL][2], "alg_bytes": int(16.5 * NK)}
