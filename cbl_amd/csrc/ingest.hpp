@@ -233,7 +233,7 @@ void flush(cblx_ctx* c) {
     if (g.wb.blk[0]) writer_issue(c, g.wb, g.d_bases.get());
     if (g.wo.blk[0]) writer_issue(c, g.wo, (u8*)(g.d_off.get() + 1));
     const bool streamed = g.streamed.active() && !g.query && g.streamed.seq_cuts.back() == nseq;
-    if (!streamed) ingest_wait(c);
+    if (!streamed) { ingest_wait(c); g.streamed.clear(); }
     // the pending queue is consumed even if the insert fails (the reference would have panicked)
     for (Ingest::Writer* w : {&g.wb, &g.wo}) { w->issued = 0; w->busy[0] = w->busy[1] = false; }
     g.nbytes = g.nseq = g.last_end = 0;

@@ -305,17 +305,26 @@ template <typename C> void big_stage(cblx_ctx* c, const BDesc* d_list, const u32
     const Consts& P = c->P;
     u64* a_lo = nr.a_lo.get();
     HiT* a_hi = WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr;
+    if (!tw.used()) {
+        const u64 T = d2h<u64>(c, nr.start.get() + nr.nb);  // every run position lies below the total arrival count
+        try {
+            tw.lo = Buf<u64>(c->pool, T + 2);
+            if (WS) tw.hi = Buf<u64>(c->pool, T + 2);
+            tw.in_twin = Buf<u8>(c->pool, nr.nb + 1);
+        } catch (const Error& e) {
+            // no room for a second arena (an index that fills most of the HBM): the long runs take the general kernel, whose
+            // scratch is only as large as the runs themselves
+            if (e.code != CBLX_ENOMEM) throw;
+            tw = Twin();
+            huge_stage<C>(c, d_list, d_list_n, nbig, a_lo, a_hi, nr, ma);
+            return;
+        }
+        CBLX_HIP(hipMemsetAsync(tw.in_twin.get(), 0, nr.nb + 1, c->stream));
+    }
     Buf<BDesc> fb(c->pool, nbig);
     Buf<u32> fb_n(c->pool, 1);
     {
         StageTimer t(c, ST_BBIG);
-        if (!tw.used()) {
-            const u64 T = d2h<u64>(c, nr.start.get() + nr.nb);  // every run position lies below the total arrival count
-            tw.lo = Buf<u64>(c->pool, T + 2);
-            if (WS) tw.hi = Buf<u64>(c->pool, T + 2);
-            tw.in_twin = Buf<u8>(c->pool, nr.nb + 1);
-            CBLX_HIP(hipMemsetAsync(tw.in_twin.get(), 0, nr.nb + 1, c->stream));
-        }
         Buf<u32> ntile(c->pool, nbig), nv(c->pool, nbig), tile_first(c->pool, nbig + 1);
         Buf<u64> vb(c->pool, nbig + 1), run_start(c->pool, nbig);
         hipLaunchKernelGGL(k_big_plan, grid1(nbig, 256), dim3(256), 0, c->stream, d_list, nbig, P.SB, ntile.get(), nv.get());
