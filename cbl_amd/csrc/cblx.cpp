@@ -187,16 +187,33 @@ int cblx_insert_seqs(cblx_ctx* c, const uint8_t* bases, const uint64_t* offsets,
     return guard(c, [&] {
         if (n == 0) return;
         if (!bases || !offsets) throw Error(CBLX_EINVAL, "null argument");
-        ingest_seqs(c, bases, offsets, n, [&] {
-            bool mono = true;
-            u64 minlen = ~0ull;
-            for (u64 i = 0; i < n; ++i) {  // branch-free scan; the offender is looked up only on failure
-                mono &= offsets[i + 1] >= offsets[i];
-                minlen = std::min(minlen, offsets[i + 1] - offsets[i]);
-            }
-            if (!mono) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
-            if (minlen < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(minlen) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
-        });
+        auto validate = [&] {
+            // branch-free scan (on several threads when there are millions of offsets); the offender is looked up only on failure
+            const unsigned hc = std::thread::hardware_concurrency();
+            const u64 T = n >= (1u << 20) ? std::max(1u, std::min(16u, hc / 2)) : 1;
+            std::vector<u8> mono(T, 1);
+            std::vector<u64> minlen(T, ~0ull);
+            auto part = [&](u64 t) {
+                bool m = true;
+                u64 ml = ~0ull;
+                for (u64 i = n * t / T, e = n * (t + 1) / T; i < e; ++i) {
+                    m &= offsets[i + 1] >= offsets[i];
+                    ml = std::min(ml, offsets[i + 1] - offsets[i]);
+                }
+                mono[t] = m;
+                minlen[t] = ml;
+            };
+            std::vector<std::thread> th;
+            for (u64 t = 1; t < T; ++t) th.emplace_back(part, t);
+            part(0);
+            for (auto& x : th) x.join();
+            for (u64 t = 0; t < T; ++t) if (!mono[t]) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
+            const u64 ml = *std::min_element(minlen.begin(), minlen.end());
+            if (ml < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(ml) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
+        };
+        // a big batch into an empty queue crosses PCIe as bit planes and is inserted right behind the transfer (comm.hpp)
+        if (ingest_seqs_planes(c, bases, offsets, n, validate)) return;
+        ingest_seqs(c, bases, offsets, n, validate);
     });
 }
 int cblx_insert_seqs_device(cblx_ctx* c, const uint8_t* d_bases, const uint64_t* d_offsets, uint64_t n) {

@@ -11,6 +11,8 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <atomic>
 
 #include "shard.hpp"
 
@@ -331,7 +333,7 @@ inline bool bins_protocol_fits(const Consts& P, const u32* bounds, u32 W) { retu
 // `before_slice` (optional): called before slice s is touched — where a caller whose slices are still arriving (a batch on its way
 // over PCIe, flush()) makes the ctx's stream wait for slice s; before_slice(~0u) precedes the first read of the offsets.
 template <typename C, typename Hook>
-void sharded_insert_bins(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, const u32* bounds, Hook&& before_slice) {
+void sharded_insert_bins(cblx_ctx* c, Transport& T, const BaseView& d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, const u32* bounds, Hook&& before_slice) {
     typedef typename C::HiT HiT;
     constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
     typedef typename std::conditional<DROP_HI, NoHi, HiT>::type OutH;  // record layout behind pass A
@@ -375,6 +377,13 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const u8* d_bases, const u64
     struct Sent { Buf<u64> lo; Buf<u8> hi, dig; };
     std::vector<Sent> sent;            // send buffers of the round's exchanges (alive until they have completed)
     std::vector<u32> pcnt, pbase;      // piece table of the round: [piece][256] counts, arena position of every piece
+    // one rank (a batch arriving over PCIe, insert_device_sliced): everything is the rank's own, nothing has to be agreed per slice —
+    // the bin counts of a slice stay on the device until the round ends, and the slices run without a host round trip between
+    // KRN-1 and pass A
+    struct Deferred { size_t piece; u64 n; Buf<u32> coltot; };
+    struct Work { ChunkPlan pl; Buf<u64> t_lo; Buf<u8> t_hi; Buf<u32> counts, colpre, scratch, adj; };  // workspace of one slice
+    Work prev_work;
+    std::vector<Deferred> deferred;
     u64 filled = 0;
     struct Drain { Transport& t; ~Drain() { try { t.wait(); } catch (...) {} } } drain{T};
     auto grow = [&](u64 need) {
@@ -399,6 +408,18 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const u8* d_bases, const u64
         CBLX_HIP(hipStreamSynchronize(c->stream));
         sent.clear();
         if (trace) fprintf(stderr, "[cblx bins] rank %u round ends: filled=%llu pieces=%zu\n", me, (unsigned long long)filled, pbase.size());
+        for (Deferred& d : deferred) {
+            const std::vector<u32> t = d2h_vec<u32>(c, d.coltot.get(), 256);
+            u64 sum = 0;
+            for (u32 bin = 0; bin < 256; ++bin) {
+                if (!t[bin]) continue;
+                if (M.v_of[bin] == 0xFFFFFFFFu) throw Error(CBLX_EDEVICE, "sharded build: a word fell into a bin no prefix maps to (internal error)");
+                pcnt[d.piece * 256 + M.v_of[bin]] += t[bin];
+                sum += t[bin];
+            }
+            if (sum != d.n) throw Error(CBLX_EDEVICE, "sharded build: the bin histogram counts " + std::to_string(sum) + " words, the slice has " + std::to_string(d.n) + " (internal error)");
+        }
+        deferred.clear();
         if (filled) {
             Records rec;
             rec.lo = std::move(a_lo);
@@ -422,14 +443,21 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const u8* d_bases, const u64
         before_slice(s);
         // -- KRN-1 with the bin histogram fused in, column prefixes of pass A
         ChunkPlan pl;
-        const u8* pb = d_bases;
+        BaseView pb = d_bases;
         u64 N = 0;
-        if (b > a) { plan_chunks(c, pb, d_offsets + a, b - a, pl); N = pl.n_kmers; }
+        if (b > a) { plan_chunks(c, pb, d_offsets + a, b - a, pl); N = pl.n_kmers; }  // (ends with a stream synchronisation)
+        else CBLX_HIP(hipStreamSynchronize(c->stream));
+        prev_work = Work();  // the previous slice's kernels are done: its workspace goes back to the pool
         if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "one slice takes fewer than 2^32-16 words (use more slices)");
         const u32 ntiles = (u32)ceil_div(N, RDX_TILE);
-        Buf<u64> t_lo;
-        Buf<u8> t_hi;
-        Buf<u32> counts, colpre, scratch, coltot(c->pool, 256), adj(c->pool, 256);
+        Work wk;
+        Buf<u64>& t_lo = wk.t_lo;
+        Buf<u8>& t_hi = wk.t_hi;
+        Buf<u32>&counts = wk.counts, &colpre = wk.colpre, &scratch = wk.scratch, &adj = wk.adj;
+        Buf<u32> coltot(c->pool, 256);
+        adj = Buf<u32>(c->pool, 256);
+        wk.pl = std::move(pl);
+        const ChunkPlan& plr = wk.pl;
         std::vector<u32> tot(256, 0u);
         if (N) {
             const size_t hs = hi_elem_size(P);
@@ -440,17 +468,19 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const u8* d_bases, const u64
             CBLX_HIP(hipMemsetAsync(counts.get(), 0, (size_t)256 * (ntiles + 2) * 4, c->stream));
             EncHist eh = eh0;
             eh.counts = counts.get();
-            encode<C>(c, pb, pl, t_lo.get(), (HiT*)t_hi.get(), 0, eh);
+            encode<C>(c, pb, plr, t_lo.get(), (HiT*)t_hi.get(), 0, eh);
             { StageTimer t(c, ST_SCAN);
               colscan(c, counts.get(), nullptr, ntiles, colpre.get(), coltot.get(), scratch);
               hipLaunchKernelGGL(k_seg_adjust, dim3(1), dim3(256), 0, c->stream, colpre.get(), coltot.get(), (const u32*)nullptr, (const u32*)nullptr,
                                  (const u32*)nullptr, ntiles, 1u, adj.get()); }
             CBLX_HIP(hipGetLastError());
-            tot = d2h_vec<u32>(c, coltot.get(), 256);
+            if (W > 1) tot = d2h_vec<u32>(c, coltot.get(), 256);
         }
         // -- what goes where: per destination the word count and the count of every segment (header of the exchange)
         const size_t HDR = 257;
         std::vector<u64> send((size_t)W * HDR, 0), recv((size_t)W * HDR, 0);
+        if (W == 1) { send[0] = N; recv[0] = N; }  // (the segment counts follow at the end of the round: `deferred`)
+        else
         for (u32 bin = 0; bin < 256; ++bin) {
             if (!tot[bin]) continue;
             if (M.v_of[bin] == 0xFFFFFFFFu) throw Error(CBLX_EDEVICE, "sharded build: a word fell into a bin no prefix maps to (internal error)");
@@ -462,7 +492,7 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const u8* d_bases, const u64
             for (u32 d = 0; d < W; ++d) sum += send[(size_t)d * HDR];
             if (sum != N) throw Error(CBLX_EDEVICE, "sharded build: the bin histogram counts " + std::to_string(sum) + " words, the slice has " + std::to_string(N) + " (internal error)");
         }
-        T.all_to_all_u64(send.data(), recv.data(), HDR);
+        if (W > 1) T.all_to_all_u64(send.data(), recv.data(), HDR);
         u64 own_a = 0, incoming = 0;
         for (u32 d = 0; d < me; ++d) own_a += send[(size_t)d * HDR];
         const u64 own = send[(size_t)me * HDR], own_b = own_a + own;
@@ -485,6 +515,7 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const u8* d_bases, const u64
             pbase.push_back((u32)(r == me ? filled : filled + own + ro[r]));
             for (u32 v = 0; v < 256; ++v) pcnt.push_back((u32)recv[(size_t)r * HDR + 1 + v]);
         }
+        if (W == 1 && N) deferred.push_back(Deferred{pbase.size() - 1, N, std::move(coltot)});
         Sent S;
         const u64 nsend = N - own;
         S.lo = Buf<u64>(c->pool, nsend + 2);
@@ -512,7 +543,9 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const u8* d_bases, const u64
         }
         filled += incoming;
         sent.push_back(std::move(S));
-        CBLX_HIP(hipStreamSynchronize(c->stream));  // the slice's workspace (words, count matrix) goes back to the pool here
+        // the slice's workspace (chunk plan, words, count matrix) stays until the next slice's chunk plan has synchronised the
+        // stream: the host queues the next slice's first kernels while this slice's pass A is still running
+        prev_work = std::move(wk);
     }
     finish_round();
     CBLX_HIP(hipStreamSynchronize(c->stream));
@@ -527,7 +560,7 @@ void sharded_insert(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_
         *bounds_valid = 1;
     }
     if (cm->protocol == CBLX_PROTO_BINS && bins_protocol_fits(c->P, bounds, T.world))
-        sharded_insert_bins<C>(c, T, d_bases, d_offsets, n, cuts, nslices, bounds, [](u32) {});
+        sharded_insert_bins<C>(c, T, ascii_view(d_bases), d_offsets, n, cuts, nslices, bounds, [](u32) {});
     else
         sharded_insert_sorted<C>(c, T, d_bases, d_offsets, n, cuts, nslices, bounds, bounds_valid);
 }
@@ -547,8 +580,17 @@ namespace {
 // as soon as the slice has landed, while the later slices are still crossing PCIe; when the last one is in, what is left is
 // the remaining passes and the bucket kernels. Same result as insert_device (the slices are pieces of the pass-A segments in
 // stream order, exactly what the receiver of the multi-GPU build gets from its senders).
+// `ready(s)`: returns once the ctx's stream may read slice s (s = ~0u: the offsets) — it makes the stream wait on the transfer's
+// events, blocking the host first if they are not recorded yet
+template <typename Ready>
+void insert_device_sliced(cblx_ctx* c, const BaseView& bases, const u64* d_offsets, u64 nseq, const std::vector<u64>& seq_cuts, Ready&& ready) {
+    const u32 ns = (u32)seq_cuts.size() - 1;
+    LocalTransport T;
+    u32 none = 0;
+    dispatch(c->P, [&](auto cfg) { sharded_insert_bins<decltype(cfg)>(c, T, bases, d_offsets, nseq, seq_cuts.data(), ns, &none, ready); });
+    collect_events(c);
+}
 void insert_device_streamed(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq, const Ingest::Streamed& plan) {
-    const u32 ns = (u32)plan.seq_cuts.size() - 1;
     auto wait_for = [&](const std::vector<hipEvent_t>& evs) { for (hipEvent_t e : evs) CBLX_HIP(hipStreamWaitEvent(c->stream, e, 0)); };
     if (c->P.PB < 9 || nseq == 0) {  // no LSD pass behind pass A: the plain path, once everything is there
         wait_for(plan.offsets_ready);
@@ -557,24 +599,150 @@ void insert_device_streamed(cblx_ctx* c, const u8* d_bases, const u64* d_offsets
         return;
     }
     check_aligned16(d_bases, "d_bases");
-    LocalTransport T;
-    u32 none = 0;
     const bool trace = std::getenv("CBLX_TRACE_H2D") != nullptr;  // dev: when every slice had landed / was handed to the kernels
     const auto t0 = std::chrono::steady_clock::now();
     auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-    dispatch(c->P, [&](auto cfg) {
-        sharded_insert_bins<decltype(cfg)>(c, T, d_bases, d_offsets, nseq, plan.seq_cuts.data(), ns, &none, [&](u32 s) {
-            if (s == ~0u) { wait_for(plan.offsets_ready); return; }
-            if (trace) {
-                const double a = ms();
-                for (hipEvent_t e : plan.ready[s]) CBLX_HIP(hipEventSynchronize(e));
-                fprintf(stderr, "[cblx h2d] slice %u: host arrives %.2f ms, landed %.2f ms\n", s, a, ms());
-            }
-            wait_for(plan.ready[s]);
-        });
+    insert_device_sliced(c, ascii_view(d_bases), d_offsets, nseq, plan.seq_cuts, [&](u32 s) {
+        if (s == ~0u) { wait_for(plan.offsets_ready); return; }
+        if (trace) {
+            const double a = ms();
+            for (hipEvent_t e : plan.ready[s]) CBLX_HIP(hipEventSynchronize(e));
+            fprintf(stderr, "[cblx h2d] slice %u: host arrives %.2f ms, landed %.2f ms\n", s, a, ms());
+        }
+        wait_for(plan.ready[s]);
     });
     if (trace) { CBLX_HIP(hipStreamSynchronize(c->stream)); fprintf(stderr, "[cblx h2d] done %.2f ms\n", ms()); }
-    collect_events(c);
+}
+
+// A big host batch as BIT PLANES (3 bits per base over PCIe instead of 8: the link is the bound of the host-input path). Host
+// threads pack the caller's ASCII bases unit by unit (xfer.hpp: pack_planes) into pinned staging, an issuer thread copies every
+// finished unit to the device on two streams, and THIS thread runs the sliced insert right behind them: slice s = the sequences
+// that end inside the units landed so far. The index is built when the call returns (the caller's buffers are borrowed for the call
+// only). Pageable or pinned source alike. Returns false when the batch does not qualify (the caller takes the other paths).
+template <typename V> bool ingest_seqs_planes(cblx_ctx* c, const u8* bases, const u64* offsets, u64 n, V&& validate) {
+    Ingest& g = c->ing;
+    const u64 o0 = offsets[0], len = offsets[n] >= o0 ? offsets[n] - o0 : 0;
+    const char* pk = std::getenv("CBLX_H2D_PACK");  // 0 off, 1 on, default: by core count (read per call: tests switch it)
+    const int mode = pk ? std::atoi(pk) : -1;
+    const unsigned hc = std::thread::hardware_concurrency();
+    if (mode == 0 || (mode < 0 && hc < 16)) return false;
+    if (g.nseq || g.nbytes || g.query || g.staged || c->P.PB < 9 || len < (64u << 20) || n < 1024 || len >= ingest_flush_bytes()) return false;
+    validate();  // (a scan of the offsets: nothing has been touched yet)
+    // transfer units = slices of the insert. Few: the planes are on the device within a dozen milliseconds, so the kernels are the
+    // bound from the first unit on, and every slice costs fixed work (chunk plan, column scans, piece). Measured at cfg 2:
+    // 4 / 6 / 8 / 12 / 16 / 32 units 38.8 / 37.6 / 37.8 / 39.2 / 40.5 / 46.5 ms
+    const char* eu = std::getenv("CBLX_H2D_UNITS");
+    const u32 NU = eu && std::atoi(eu) > 0 ? (u32)std::min(std::atoi(eu), 64) : 6u;
+    const u64 U = ((len + NU - 1) / NU + 1023) & ~(u64)1023;             // bases per unit (a multiple of 16)
+    const u64 ng = (len + 15) / 16;                                      // groups of 16 bases
+    const u32 nu = (u32)((len + U - 1) / U);
+    // device planes, offsets, pinned staging (kept between calls)
+    if (g.d_codes.n < ng + 8) g.d_codes = Buf<u32>(c->pool, ng + 8);
+    if (g.d_valid.n < ng + 8) g.d_valid = Buf<u16>(c->pool, ng + 8);
+    ingest_reserve(c, 0, n);
+    const size_t need = (size_t)(ng + 8) * 6;
+    if (g.pin_cap < need) {
+        if (g.pin) { u8* old = g.pin; g.pin = nullptr; g.pin_cap = 0; CBLX_HIP(hipHostFree(old)); }
+        CBLX_HIP(hipHostMalloc((void**)&g.pin, need, hipHostMallocDefault));
+        g.pin_cap = need;
+    }
+    u32* h_codes = (u32*)g.pin;
+    u16* h_valid = (u16*)(g.pin + (size_t)(ng + 8) * 4);
+    Xfer& x = xfer(c);
+    hipStream_t cs[2] = {x.lane_stream(0), x.lane_stream(1)};
+    // offsets (relative to the batch's first base): straight from the caller's array when pinned and zero-based, else transformed
+    hipEvent_t off_ev = nullptr;
+    if (o0 == 0 && Xfer::is_pinned(offsets) && Xfer::is_pinned(offsets + n)) x.h2d_pinned_lane0(g.d_off.get() + 1, offsets + 1, n * 8, off_ev);
+    else {
+        x.h2d(g.d_off.get() + 1, n * 8, [&](u8* dst, size_t off, size_t nb) {
+            u64* d = (u64*)dst;
+            const u64* src = offsets + off / 8 + 1;
+            for (size_t j = 0; j < nb / 8; ++j) d[j] = src[j] - o0;
+        });
+        x.sync();
+    }
+    // slices: slice k = the sequences that end inside units 0 .. k
+    std::vector<u64> cuts(1, 0);
+    std::vector<u32> unit_of;  // the last unit a slice needs
+    for (u32 k = 0; k < nu; ++k) {
+        const u64 lim = k + 1 == nu ? len : (u64)(k + 1) * U;
+        const u64 i = k + 1 == nu ? n : (u64)(std::upper_bound(offsets + 1, offsets + n + 1, o0 + lim) - (offsets + 1));
+        if (i > cuts.back()) { cuts.push_back(i); unit_of.push_back(k); }
+    }
+    // packers: sub-blocks of a unit in order, so that the units complete one after the other
+    const u64 SB = 2u << 20;  // bases per sub-block (a multiple of 16)
+    const u64 nsb = (len + SB - 1) / SB;
+    std::vector<std::atomic<u32>> left(nu);
+    for (u32 k = 0; k < nu; ++k) {
+        const u64 a = (u64)k * U, b = std::min<u64>(len, a + U);
+        left[k].store((u32)((b + SB - 1) / SB - a / SB) , std::memory_order_relaxed);
+    }
+    static_assert(true, "");
+    // (U is a multiple of SB only by accident: a sub-block may straddle two units — it then counts for both)
+    std::atomic<u64> next_sb{0};
+    std::atomic<u32> issued{0};
+    std::atomic<bool> failed{false};
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<hipEvent_t> ev(nu, nullptr);
+    const int T = (int)std::max(2u, std::min(32u, hc / 2));
+    auto pack_worker = [&] {
+        for (u64 sb; (sb = next_sb.fetch_add(1)) < nsb;) {
+            const u64 a = sb * SB, b = std::min<u64>(len, a + SB);
+            pack_planes(bases + o0 + a, b - a, h_codes + a / 16, h_valid + a / 16);
+            for (u64 k = a / U; k <= (b - 1) / U; ++k)
+                if (left[k].fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> l(mu); cv.notify_all(); }
+        }
+    };
+    auto issuer = [&] {
+        try {
+            CBLX_HIP(hipSetDevice(c->device));
+            for (u32 k = 0; k < nu; ++k) {
+                { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return left[k].load(std::memory_order_acquire) == 0; }); }
+                const u64 g0 = (u64)k * U / 16, g1 = std::min<u64>(ng, (u64)(k + 1) * U / 16);
+                CBLX_HIP(hipMemcpyAsync(g.d_codes.get() + g0, h_codes + g0, (g1 - g0) * 4, hipMemcpyHostToDevice, cs[k & 1]));
+                CBLX_HIP(hipMemcpyAsync(g.d_valid.get() + g0, h_valid + g0, (g1 - g0) * 2, hipMemcpyHostToDevice, cs[k & 1]));
+                hipEvent_t e;
+                CBLX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                CBLX_HIP(hipEventRecord(e, cs[k & 1]));
+                ev[k] = e;
+                { std::lock_guard<std::mutex> l(mu); issued.store(k + 1, std::memory_order_release); }
+                cv.notify_all();
+            }
+        } catch (...) {
+            { std::lock_guard<std::mutex> l(mu); failed = true; issued.store(nu, std::memory_order_release); }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(pack_worker);
+    th.emplace_back(issuer);
+    struct Join {
+        std::vector<std::thread>& th; std::vector<hipEvent_t>& ev; hipEvent_t& off_ev; Xfer& x;
+        ~Join() {
+            for (auto& t : th) if (t.joinable()) t.join();
+            try { x.sync(); } catch (...) {}
+            for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+            if (off_ev) (void)hipEventDestroy(off_ev);
+        }
+    } join{th, ev, off_ev, x};
+    const bool trace = std::getenv("CBLX_TRACE_H2D") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    const BaseView view{nullptr, g.d_codes.get(), g.d_valid.get()};
+    insert_device_sliced(c, view, g.d_off.get(), n, cuts, [&](u32 s) {
+        if (s == ~0u) { if (off_ev) CBLX_HIP(hipStreamWaitEvent(c->stream, off_ev, 0)); return; }
+        const u32 k = unit_of[s];
+        const double a = trace ? ms() : 0;
+        { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return issued.load(std::memory_order_acquire) > k; }); }
+        if (failed) throw Error(CBLX_EDEVICE, "host-to-device transfer of the batch failed");
+        CBLX_HIP(hipStreamWaitEvent(c->stream, ev[k], 0));               // units are copied in order on two streams:
+        if (k) CBLX_HIP(hipStreamWaitEvent(c->stream, ev[k - 1], 0));    // the last one on each of them
+        if (trace) fprintf(stderr, "[cblx h2d planes] slice %u (unit %u): host arrives %.2f ms, issued %.2f ms\n", s, k, a, ms());
+    });
+    if (trace) { CBLX_HIP(hipStreamSynchronize(c->stream)); fprintf(stderr, "[cblx h2d planes] done %.2f ms\n", ms()); }
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    return true;
 }
 
 }  // namespace

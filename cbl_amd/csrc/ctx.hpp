@@ -133,6 +133,11 @@ struct Ingest {
     };
     Buf<u8> d_bases;   // capacity >= nbytes + 64
     Buf<u64> d_off;    // capacity >= nseq + 1; d_off[0] = 0
+    // a big host batch that crosses PCIe as bit planes (ingest_seqs_planes): device planes and the pinned staging they are packed into
+    Buf<u32> d_codes;
+    Buf<u16> d_valid;
+    u8* pin = nullptr;
+    size_t pin_cap = 0;
     u64 nbytes = 0, nseq = 0;
     u64 last_end = 0;  // nbytes at the end of the last complete sequence
     Writer wb, wo;

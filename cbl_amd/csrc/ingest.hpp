@@ -212,6 +212,8 @@ void ingest_drop(cblx_ctx* c) {  // forget everything enqueued (clear / load)
 void ingest_destroy(cblx_ctx* c) {
     Ingest& g = c->ing;
     if (g.s) (void)hipStreamSynchronize(g.s);
+    g.streamed.clear();
+    if (g.pin) { (void)hipHostFree(g.pin); g.pin = nullptr; g.pin_cap = 0; }
     g.xfer.reset();
     for (Ingest::Writer* w : {&g.wb, &g.wo})
         for (int k = 0; k < 2; ++k) {

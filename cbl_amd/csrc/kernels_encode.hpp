@@ -28,6 +28,39 @@ template <typename HiT> __device__ __forceinline__ void st_hi(HiT* p, u64 i, u64
     if constexpr (HiTraits<HiT>::has) p[i] = (HiT)v;
 }
 
+// Where the bases of a batch live. The caller's format is one ASCII byte per base; a big host batch crosses PCIe as three BIT
+// PLANES instead (xfer.hpp: pack_planes, 3 bits per base instead of 8 — the link is the bound of the host-input path): per 16
+// bases one dword of code planes — bit i = ASCII bit 1 of base i (code bit 0), bit 16 + i = ASCII bit 2 (code bit 1), the code
+// being (b >> 1) & 3 (src/kmer.rs:11-24) — and one 16-bit word of validity (bit i = base i is one of ACGTacgt).
+struct BaseView {
+    const u8* ascii;   // null: planes
+    const u32* codes;
+    const u16* valid;
+    __host__ __device__ void advance16(u64 bytes /* multiple of 16 */) {
+        if (ascii) ascii += bytes; else { codes += bytes >> 4; valid += bytes >> 4; }
+    }
+};
+inline BaseView ascii_view(const u8* p) { return BaseView{p, nullptr, nullptr}; }
+__device__ __forceinline__ bool bv_valid(const BaseView& B, u64 i) {
+    return B.ascii ? nuc_valid(B.ascii[i]) : ((B.valid[i >> 4] >> (i & 15u)) & 1u) != 0;
+}
+__device__ __forceinline__ u32 bv_code(const BaseView& B, u64 i) {
+    if (B.ascii) return nuc_code(B.ascii[i]);
+    const u32 w = B.codes[i >> 4] >> (i & 15u);
+    return (w & 1u) | ((w >> 15) & 2u);
+}
+// one dword of code planes -> the 16 2-bit codes of the tile's packed stream (first base in bits 31:30, like pack16)
+__device__ __forceinline__ u32 planes_to_codes(u32 w) {
+    auto spread = [](u32 x) {  // bit j -> bit 2 j (x < 2^16)
+        x = (x | (x << 8)) & 0x00FF00FFu;
+        x = (x | (x << 4)) & 0x0F0F0F0Fu;
+        x = (x | (x << 2)) & 0x33333333u;
+        return (x | (x << 1)) & 0x55555555u;
+    };
+    const u32 r0 = __brev(w << 16) & 0xFFFFu, r1 = __brev(w & 0xFFFF0000u);  // base i at bit 15 - i of each plane
+    return spread(r0) | (spread(r1) << 1);
+}
+
 #ifndef CBLX_ENC_UNIFORM
 #define CBLX_ENC_UNIFORM 1
 #endif
@@ -136,19 +169,30 @@ __device__ inline void mark_dirty(u64 b, const u64* chunk_start, const u32* chun
         }
     }
 }
-__global__ void k_scan_invalid(const u8* __restrict__ bases, u64 total, const u64* __restrict__ chunk_start,
+__global__ void k_scan_invalid(BaseView B, u64 total, const u64* __restrict__ chunk_start,
                                const u32* __restrict__ chunk_len, u64 nchunks, u8* __restrict__ dirty,
                                u32* __restrict__ ndirty) {
     u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 b0 = g * 16;
     if (b0 >= total) return;
-    if (b0 + 16 <= total) {
-        uint4 v = *reinterpret_cast<const uint4*>(bases + b0);
-        u32 m = valid_mask4(v.x) & valid_mask4(v.y) & valid_mask4(v.z) & valid_mask4(v.w);
-        if (m == 0x80808080u) return;
+    if (B.ascii) {
+        const u8* __restrict__ bases = B.ascii;
+        if (b0 + 16 <= total) {
+            uint4 v = *reinterpret_cast<const uint4*>(bases + b0);
+            u32 m = valid_mask4(v.x) & valid_mask4(v.y) & valid_mask4(v.z) & valid_mask4(v.w);
+            if (m == 0x80808080u) return;
+        }
+        for (u64 b = b0; b < b0 + 16 && b < total; ++b)
+            if (!nuc_valid(bases[b])) mark_dirty(b, chunk_start, chunk_len, nchunks, dirty, ndirty);
+    } else {
+        const u32 n = total - b0 < 16 ? (u32)(total - b0) : 16u;
+        u32 bad = ~(u32)B.valid[g] & ((1u << n) - 1u);  // the packer leaves the bits past the end of the batch clear
+        while (bad) {
+            const u32 k = (u32)__builtin_ctz(bad);
+            bad &= bad - 1u;
+            mark_dirty(b0 + k, chunk_start, chunk_len, nchunks, dirty, ndirty);
+        }
     }
-    for (u64 b = b0; b < b0 + 16 && b < total; ++b)
-        if (!nuc_valid(bases[b])) mark_dirty(b, chunk_start, chunk_len, nchunks, dirty, ndirty);
 }
 // The dirty chunks as a list (any order), so that the kernels below put a whole wave on every one of them: one THREAD per
 // dirty chunk walking its 150 .. 2100 bytes alone, among 63 idle lanes, cost 2 ms per 82 000 dirty chunks (1 % of the reads
@@ -172,15 +216,15 @@ __global__ __launch_bounds__(DIRTY_LIST_THREADS) void k_dirty_list(const u8* __r
     if (d) list[s_base + s_cnt[w] + mbcnt(bal)] = (u32)c;
 }
 // exact k-mer count of a dirty chunk: 1 + #valid bytes in chunk[K..] (src/cbl.rs:277-287 filter_map), one wave per chunk
-__global__ __launch_bounds__(256) void k_dirty_count_wave(const u8* __restrict__ bases, const u64* __restrict__ chunk_start, const u32* __restrict__ chunk_len,
+__global__ __launch_bounds__(256) void k_dirty_count_wave(BaseView B, const u64* __restrict__ chunk_start, const u32* __restrict__ chunk_len,
                                                           const u32* __restrict__ list, u32 nlist, u32 K, u32* __restrict__ chunk_nk) {
     const u32 li = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (li >= nlist) return;
     const u32 c = list[li];
-    const u8* s = bases + chunk_start[c];
+    const u64 s0 = chunk_start[c];
     const u32 len = chunk_len[c];
     u32 m = 0;
-    for (u32 i = K + lane; i < len; i += 64) m += nuc_valid(s[i]) ? 1u : 0u;
+    for (u32 i = K + lane; i < len; i += 64) m += bv_valid(B, s0 + i) ? 1u : 0u;
     m = (u32)wave_reduce_sum((u64)m);
     if (lane == 0) chunk_nk[c] = 1 + m;
 }
@@ -256,7 +300,7 @@ __device__ __forceinline__ u32 pack16(uint4 v) {  // 16 ASCII bases -> 16 2-bit 
 
 // ---- main encode kernel: one workgroup per 4 KiB tile of the base stream --------------------------------
 template <bool WIDE, typename HiT>
-__global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ bases, u64 total_bases,
+__global__ __launch_bounds__(ENC_THREADS) void k_encode(BaseView B, u64 total_bases,
                                                         const u64* __restrict__ chunk_start,
                                                         const u32* __restrict__ chunk_len,
                                                         const u64* __restrict__ kmer_off /* nchunks+1 */,
@@ -294,10 +338,12 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
         u64 b = A0 + (u64)i * 16;
         u32 packed = 0;
         if (i < nwords) {
-            if (b + 16 <= total_bases) {
-                packed = pack16(*reinterpret_cast<const uint4*>(bases + b));
+            if (!B.ascii) {
+                if (b < total_bases) packed = planes_to_codes(B.codes[b >> 4]);  // (bits past the end of the batch are clear)
+            } else if (b + 16 <= total_bases) {
+                packed = pack16(*reinterpret_cast<const uint4*>(B.ascii + b));
             } else {
-                for (u32 k = 0; k < 16 && b + k < total_bases; ++k) packed |= nuc_code(bases[b + k]) << (30 - 2 * k);
+                for (u32 k = 0; k < 16 && b + k < total_bases; ++k) packed |= nuc_code(B.ascii[b + k]) << (30 - 2 * k);
             }
         }
         s_codes[i] = packed;
@@ -468,7 +514,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(const u8* __restrict__ b
 // first sweep that only takes the strand flags.
 static const u32 DIRTY_MAX_BASES = CHUNK_KMERS + 64 + 64;  // a chunk spans at most CHUNK_KMERS + K - 1 bytes, K <= 59
 template <bool WIDE, typename HiT>
-__global__ __launch_bounds__(256) void k_encode_dirty_wave(const u8* __restrict__ bases, const u64* __restrict__ chunk_start, const u32* __restrict__ chunk_len,
+__global__ __launch_bounds__(256) void k_encode_dirty_wave(BaseView B, const u64* __restrict__ chunk_start, const u32* __restrict__ chunk_len,
                                                            const u64* __restrict__ kmer_off, const u32* __restrict__ list, u32 nlist, Consts P,
                                                            u64* __restrict__ out_lo, HiT* __restrict__ out_hi, u64 out_base, EncHist eh) {
     typedef typename KmerT<WIDE>::type T;
@@ -487,20 +533,19 @@ __global__ __launch_bounds__(256) void k_encode_dirty_wave(const u8* __restrict_
     if (eh.counts)
         for (u32 i = lane; i < 2 * 256; i += 64) s_hist[i] = 0;
     const u32 c = list[li];
-    const u8* s = bases + chunk_start[c];
+    const u64 s0 = chunk_start[c];
     const u32 len = chunk_len[c], K = P.K;
     const u64 o0 = out_base + kmer_off[c];
     // cleaned string: zeros(K - n0), then the valid bases in order (src/kmer.rs:133-135, src/cbl.rs:283)
-    const u64 first = __ballot(lane < K && lane < len && nuc_valid(s[lane]));
+    const u64 first = __ballot(lane < K && lane < len && bv_valid(B, s0 + lane));
     const u32 n0 = (u32)__builtin_popcountll(first), Z = K - n0;
     for (u32 i = lane; i < Z; i += 64) s_cb[i] = 0;
     u32 fill = Z;
     for (u32 i0 = 0; i0 < len; i0 += 64) {
         const u32 i = i0 + lane;
-        const u8 b = i < len ? s[i] : (u8)0;
-        const bool ok = i < len && nuc_valid(b);
+        const bool ok = i < len && bv_valid(B, s0 + i);
         const u64 bal = __ballot(ok);
-        if (ok) s_cb[fill + mbcnt(bal)] = (u8)nuc_code(b);
+        if (ok) s_cb[fill + mbcnt(bal)] = (u8)bv_code(B, s0 + i);
         fill += (u32)__builtin_popcountll(bal);
     }
     const u32 nk = fill - K + 1;  // = kmer_off[c + 1] - kmer_off[c] (k_dirty_count_wave); fill >= K always

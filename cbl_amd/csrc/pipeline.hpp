@@ -722,7 +722,8 @@ struct ChunkPlan {
     Buf<u32> dirty_list;  // the dirty chunks, any order (ndirty of them)
 };
 // `ends`: offsets[0] and offsets[nseq] when the caller has read them already (each read is a host round trip)
-void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq, ChunkPlan& pl, const u64* ends = nullptr) {
+// `B`: where the bases live (ASCII bytes, or the bit planes a big host batch crossed PCIe as); advanced to the slice's aligned start
+void plan_chunks(cblx_ctx* c, BaseView& d_bases, const u64* d_offsets, u64 nseq, ChunkPlan& pl, const u64* ends = nullptr) {
     StageTimer t(c, ST_CHUNKS);
     const Consts& P = c->P;
     // offsets may start anywhere in the buffer (a slice of a larger batch): work relative to the 16-byte aligned
@@ -732,7 +733,7 @@ void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq
     const u64 last = ends ? ends[1] : d2h<u64>(c, d_offsets + nseq);
     if (last < first) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
     pl.total_bases = last - pl.bias;
-    d_bases += pl.bias;
+    d_bases.advance16(pl.bias);
     Buf<u32> nch(c->pool, nseq + 1);
     Buf<u64> err(c->pool, 2), chunk_base(c->pool, nseq + 1);
     CBLX_HIP(hipMemsetAsync(err.get(), 0, 16, c->stream));
@@ -771,7 +772,12 @@ void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq
     CBLX_HIP(hipGetLastError());
     CBLX_HIP(hipStreamSynchronize(c->stream));  // temporaries (nch, err, chunk_base, chunk_nk, ndirty) die here
 }
-template <typename C> void encode(cblx_ctx* c, const u8* d_bases, const ChunkPlan& pl, u64* out_lo, typename C::HiT* out_hi, u64 out_base,
+void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq, ChunkPlan& pl, const u64* ends = nullptr) {
+    BaseView B = ascii_view(d_bases);
+    plan_chunks(c, B, d_offsets, nseq, pl, ends);
+    d_bases = B.ascii;
+}
+template <typename C> void encode(cblx_ctx* c, const BaseView& d_bases, const ChunkPlan& pl, u64* out_lo, typename C::HiT* out_hi, u64 out_base,
                                   EncHist eh = EncHist{}) {
     typedef typename C::HiT HiT;
     StageTimer t(c, ST_ENCODE);
@@ -783,6 +789,10 @@ template <typename C> void encode(cblx_ctx* c, const u8* d_bases, const ChunkPla
         hipLaunchKernelGGL((k_encode_dirty_wave<C::WIDE, HiT>), dim3((pl.ndirty + 3) / 4), dim3(256), 0, c->stream, d_bases, pl.chunk_start.get(), pl.chunk_len.get(),
                            pl.kmer_off.get(), pl.dirty_list.get(), pl.ndirty, c->P, out_lo, out_hi, out_base, eh);
     CBLX_HIP(hipGetLastError());
+}
+template <typename C> void encode(cblx_ctx* c, const u8* d_bases, const ChunkPlan& pl, u64* out_lo, typename C::HiT* out_hi, u64 out_base,
+                                  EncHist eh = EncHist{}) {
+    encode<C>(c, ascii_view(d_bases), pl, out_lo, out_hi, out_base, eh);
 }
 
 void check_aligned16(const void* p, const char* what) {

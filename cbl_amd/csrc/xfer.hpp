@@ -19,11 +19,70 @@
 
 #include "common.hpp"
 
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#define CBLX_HAVE_SSE2 1
+#else
+#define CBLX_HAVE_SSE2 0
+#endif
+
 #ifndef CBLX_PARSE_THREADS_DEFAULT
 #define CBLX_PARSE_THREADS_DEFAULT 16u
 #endif
 
 namespace cblx {
+
+// n ASCII bases (n a multiple of 16, or the tail of a batch) -> the bit planes of kernels_encode.hpp's BaseView: per 16 bases one
+// dword of code planes (bit i = ASCII bit 1 of base i, bit 16 + i = ASCII bit 2: the nucleotide code is (b >> 1) & 3) and one
+// 16-bit validity word (bit i = base i is one of ACGTacgt). 3 bits cross PCIe per base instead of 8; bits past n stay clear.
+#if CBLX_HAVE_SSE2
+// 32 bases per step where the host has AVX2 (checked once at run time: the library is built on another machine than it runs on)
+__attribute__((target("avx2"))) inline size_t pack_planes_avx2(const u8* src, size_t ng /* groups of 16 */, u32* codes, u16* valid) {
+    const __m256i up = _mm256_set1_epi8((char)0xDF), cA = _mm256_set1_epi8('A'), cC = _mm256_set1_epi8('C'), cG = _mm256_set1_epi8('G'), cT = _mm256_set1_epi8('T');
+    size_t g = 0;
+    for (; g + 2 <= ng; g += 2) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + 16 * g));
+        const __m256i u = _mm256_and_si256(v, up);
+        const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, cA), _mm256_cmpeq_epi8(u, cC)), _mm256_or_si256(_mm256_cmpeq_epi8(u, cG), _mm256_cmpeq_epi8(u, cT)));
+        const u32 p0 = (u32)_mm256_movemask_epi8(_mm256_slli_epi16(v, 6));
+        const u32 p1 = (u32)_mm256_movemask_epi8(_mm256_slli_epi16(v, 5));
+        const u32 vm = (u32)_mm256_movemask_epi8(ok);
+        codes[g] = (p0 & 0xFFFFu) | (p1 << 16);
+        codes[g + 1] = (p0 >> 16) | (p1 & 0xFFFF0000u);
+        valid[g] = (u16)vm;
+        valid[g + 1] = (u16)(vm >> 16);
+    }
+    return g;
+}
+#endif
+inline void pack_planes(const u8* src, size_t n, u32* codes, u16* valid) {
+    size_t g = 0;
+    const size_t ng = n / 16;
+#if CBLX_HAVE_SSE2
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) g = pack_planes_avx2(src, ng, codes, valid);
+    const __m128i up = _mm_set1_epi8((char)0xDF), cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
+    for (; g < ng; ++g) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + 16 * g));
+        const __m128i u = _mm_and_si128(v, up);
+        const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(u, cA), _mm_cmpeq_epi8(u, cC)), _mm_or_si128(_mm_cmpeq_epi8(u, cG), _mm_cmpeq_epi8(u, cT)));
+        const u32 p0 = (u32)_mm_movemask_epi8(_mm_slli_epi16(v, 6));  // ASCII bit 1 of every byte -> its bit 7
+        const u32 p1 = (u32)_mm_movemask_epi8(_mm_slli_epi16(v, 5));  // ASCII bit 2
+        codes[g] = p0 | (p1 << 16);
+        valid[g] = (u16)_mm_movemask_epi8(ok);
+    }
+#endif
+    for (; g * 16 < n; ++g) {
+        u32 c = 0, ok = 0;
+        for (size_t i = 0; i < 16 && g * 16 + i < n; ++i) {
+            const u8 b = src[g * 16 + i], uc = b & 0xDF;
+            c |= (u32)((b >> 1) & 1u) << i | (u32)((b >> 2) & 1u) << (16 + i);
+            ok |= (u32)(uc == 'A' || uc == 'C' || uc == 'G' || uc == 'T') << i;
+        }
+        codes[g] = c;
+        valid[g] = (u16)ok;
+    }
+}
 
 class Xfer {
     struct Lane {
@@ -114,6 +173,7 @@ public:
         CBLX_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
         CBLX_HIP(hipEventRecord(done, lanes_[0].s));
     }
+    hipStream_t lane_stream(int i) { ensure(i + 1); return lanes_[(size_t)i].s; }
     // one event per active lane, recorded behind everything issued so far (the caller destroys them)
     void mark(std::vector<hipEvent_t>& evs) {
         for (auto& l : lanes_) {

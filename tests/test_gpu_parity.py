@@ -377,6 +377,7 @@ def test_streamed_insert_from_pinned_host_memory_equals_one_shot(k, pb, canonica
     ref = cbl_amd.CBL(k, pb, canonical=canonical)
     ref.insert_seqs_device(d_b, d_o, nreads)
     want = ref.serialize()
+    monkeypatch.setenv("CBLX_H2D_PACK", "0")  # the ASCII bytes themselves cross the link, in slices
     for slices in ("12", "5", "1"):
         monkeypatch.setenv("CBLX_H2D_SLICES", slices)
         g = cbl_amd.CBL(k, pb, canonical=canonical)
@@ -385,16 +386,29 @@ def test_streamed_insert_from_pinned_host_memory_equals_one_shot(k, pb, canonica
         assert g.count() == ref.count()
         assert g.serialize() == want, slices
         g.close()
+    # the batch as bit planes (host threads pack 3 bits per base, the insert runs right behind the transfer): from the pinned
+    # buffer, from a pageable copy, and with offsets that do not start at 0
+    monkeypatch.setenv("CBLX_H2D_PACK", "1")
+    pageable = np.array(nb_, copy=True)
+    shifted = np.concatenate([np.full(37, ord("A"), dtype=np.uint8), pageable])
+    for bases, offs in ((nb_, no_), (pageable, no_), (shifted, no_ + np.uint64(37))):
+        g = cbl_amd.CBL(k, pb, canonical=canonical)
+        g.insert_seqs(bases, offs)
+        assert g.count() == ref.count()
+        assert g.serialize() == want
+        g.close()
     # on top of a resident index (the incremental path behind the pieces), then the same batch again: nothing new
-    monkeypatch.setenv("CBLX_H2D_SLICES", "7")
-    half = nreads // 2
-    g = cbl_amd.CBL(k, pb, canonical=canonical)
-    g.insert_seqs_device(d_b, d_o, half)
-    g.insert_seqs(nb_[int(no_[half]):], (no_[half:] - no_[half]))
-    assert g.serialize() == want
-    g.insert_seqs(nb_, no_)
-    assert g.serialize() == want
-    g.close()
+    for pack in ("0", "1"):
+        monkeypatch.setenv("CBLX_H2D_PACK", pack)
+        monkeypatch.setenv("CBLX_H2D_SLICES", "7")
+        half = nreads // 2
+        g = cbl_amd.CBL(k, pb, canonical=canonical)
+        g.insert_seqs_device(d_b, d_o, half)
+        g.insert_seqs(nb_[int(no_[half]):], (no_[half:] - no_[half]))
+        assert g.serialize() == want
+        g.insert_seqs(nb_, no_)
+        assert g.serialize() == want
+        g.close()
     ref.close()
 
 
