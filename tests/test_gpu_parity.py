@@ -357,7 +357,7 @@ def test_incremental_flushes_equal_one_shot():
 
 
 @pytest.mark.parametrize("k,pb,canonical,nreads,L,dirty", [(31, 24, False, 600_000, 150, False), (59, 28, True, 300_000, 250, True), (25, 12, False, 700_000, 120, True),
-                                                          (31, 8, False, 500_000, 150, False)])
+                                                          (31, 8, False, 500_000, 150, False), (27, 20, True, 600_000, 130, "mixed")])
 def test_streamed_insert_from_pinned_host_memory_equals_one_shot(k, pb, canonical, nreads, L, dirty, monkeypatch):
     """A big batch handed over in PINNED host memory crosses PCIe in slices that land front to back; flush() runs KRN-1 and the
     first partition pass of slice c while the later slices are on the wire (cblx_insert_seqs + cblx_flush). Same index bytes as
@@ -368,6 +368,14 @@ def test_streamed_insert_from_pinned_host_memory_equals_one_shot(k, pb, canonica
     if dirty:
         d_b = d_b.clone()
         d_b[torch.arange(7, d_b.numel(), 9973, device="cuda")] = ord("N")
+        if dirty == "mixed":  # lower case (valid), other letters and bytes above 127 (skipped), runs of N
+            gen = torch.Generator(device="cuda")
+            gen.manual_seed(5)
+            pos = torch.randint(0, d_b.numel(), (d_b.numel() // 50,), device="cuda", generator=gen)
+            d_b[pos] = d_b[pos] | 0x20
+            pos = torch.randint(0, d_b.numel(), (d_b.numel() // 400,), device="cuda", generator=gen)
+            d_b[pos] = torch.tensor(list(b"nRYx-\xe9*"), dtype=torch.uint8, device="cuda")[torch.randint(0, 7, (pos.numel(),), device="cuda", generator=gen)]
+            d_b[1000:1400] = ord("N")
     hb = torch.empty(d_b.numel(), dtype=torch.uint8, pin_memory=True)
     ho = torch.empty(d_o.numel(), dtype=torch.int64, pin_memory=True)
     hb.copy_(d_b)
