@@ -94,6 +94,15 @@ def test_necklace_host_unit(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_pack_planes_host_unit(tmp_path):
+    """The host packer of the bit planes (3 bits per base over PCIe, cbl_amd/csrc/xfer.hpp) against the scalar definition."""
+    exe = tmp_path / "pack_planes_unit"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-o", str(exe), str(ROOT / "tests" / "host" / "pack_planes_unit.cpp")], check=True,
+                   capture_output=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("k,pb,nreads,L", [(31, 24, 3000, 150), (9, 4, 1500, 100), (59, 28, 400, 250), (15, 6, 1500, 150), (11, 8, 40, 3000)])
 def test_index_shard_cuts_speculative_equals_sequential(k, pb, nreads, L, tmp_path):
     """Host-only half of cblx_load_shard_from_file: the speculative search for the entry starts of `world` prefix ranges
