@@ -90,8 +90,9 @@ void read_fastx_into_queue(cblx_ctx* c, const char* path, uint64_t* n_records, c
     {
         if (n_records) *n_records = 0;
         if (!path) throw Error(CBLX_EINVAL, "null argument");
-        if (!filt) {   // large plain files: parallel reader; anything it does not take is read sequentially below
+        if (!filt) {   // large plain files: parallel readers; anything they do not take is read sequentially below
             u64 npar = 0;
+            if (fastx_parallel_planes(c, path, &npar)) { if (n_records) *n_records = npar; return; }  // (comm.hpp) bit planes, the insert behind the parse
             if (fastx_parallel(c, path, &npar)) { if (n_records) *n_records = npar; return; }
         }
         auto mine = [&](u64 i) { return !filt || filt->mine(i); };

@@ -745,4 +745,211 @@ template <typename V> bool ingest_seqs_planes(cblx_ctx* c, const u8* bases, cons
     return true;
 }
 
+// ---- a plain FASTA / FASTQ file as bit planes: the parser threads pack the sequence lines themselves -------------------------------
+// The file path was bound by its host side: every region's sequence lines were copied into pinned slots and sent as ASCII (1.5 GB
+// for cfg 2, 65 - 97 ms), then inserted window by window. Here a region's thread appends its lines to the batch's bit planes IN
+// PLACE (PlaneSink: 16 bytes -> three 16-bit words by SSE2 movemask, shifted to the region's bit offset; only the first and the last
+// word of a region are shared with its neighbours and take an atomic OR), the slices (groups of consecutive regions) are copied as
+// they complete, and the calling thread runs the sliced insert right behind them, as ingest_seqs_planes does for a host batch.
+struct PlaneSink {
+    u32* codes; u16* valid;   // pinned staging of the window, indexed by group of 16 bases
+    u64 pos;                  // bases written so far + the region's first base
+    u64 a0 = 0, a1 = 0, av = 0;
+    u32 nb;                   // bits waiting in the accumulators (the low `nb` bits)
+    u64 gcur;                 // group the accumulators' low bits belong to
+    bool shared = true;       // the next word to leave is the region's first: shared with the previous region
+    u64* ends; u64 nrec = 0, cap;
+    PlaneSink(u32* c, u16* v, u64 first_base, u64* e, u64 ecap) : codes(c), valid(v), pos(first_base), nb((u32)(first_base & 15)), gcur(first_base >> 4), ends(e), cap(ecap) {}
+    void word_out(bool last) {
+        const u32 w = (u32)(a0 & 0xFFFFu) | ((u32)(a1 & 0xFFFFu) << 16);
+        const u16 vw = (u16)(av & 0xFFFFu);
+        if (shared || last) {  // a word another region also writes into (zeroed before the threads started)
+            __atomic_fetch_or(&codes[gcur], w, __ATOMIC_RELAXED);
+            __atomic_fetch_or(&valid[gcur], vw, __ATOMIC_RELAXED);
+            shared = false;
+        } else {
+            codes[gcur] = w;
+            valid[gcur] = vw;
+        }
+        a0 >>= 16; a1 >>= 16; av >>= 16;
+        ++gcur;
+    }
+    void put(u32 p0, u32 p1, u32 v, u32 k) {  // k <= 16 bases as plane bits
+        a0 |= (u64)p0 << nb; a1 |= (u64)p1 << nb; av |= (u64)v << nb;
+        nb += k;
+        if (nb >= 16) { word_out(false); nb -= 16; }
+    }
+    void seq(const u8* p, size_t n) {
+        size_t i = 0;
+#if CBLX_HAVE_SSE2
+        const __m128i up = _mm_set1_epi8((char)0xDF), cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
+        auto planes16 = [&](const __m128i v, u32& p0, u32& p1, u32& ok) {
+            const __m128i u = _mm_and_si128(v, up);
+            const __m128i m = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(u, cA), _mm_cmpeq_epi8(u, cC)), _mm_or_si128(_mm_cmpeq_epi8(u, cG), _mm_cmpeq_epi8(u, cT)));
+            p0 = (u32)_mm_movemask_epi8(_mm_slli_epi16(v, 6));
+            p1 = (u32)_mm_movemask_epi8(_mm_slli_epi16(v, 5));
+            ok = (u32)_mm_movemask_epi8(m);
+        };
+        for (; i + 16 <= n; i += 16) {
+            u32 p0, p1, ok;
+            planes16(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p + i)), p0, p1, ok);
+            put(p0, p1, ok, 16);
+        }
+        if (i < n) {  // the line's tail through a local copy (a 16-byte load could run past the end of the mapping)
+            alignas(16) u8 tmp[16] = {0};
+            std::memcpy(tmp, p + i, n - i);
+            u32 p0, p1, ok;
+            planes16(_mm_load_si128(reinterpret_cast<const __m128i*>(tmp)), p0, p1, ok);
+            const u32 k = (u32)(n - i), mk = (1u << k) - 1u;
+            put(p0 & mk, p1 & mk, ok & mk, k);
+        }
+#else
+        for (; i < n; ++i) {
+            const u8 b = p[i], uc = b & 0xDF;
+            put((b >> 1) & 1u, (b >> 2) & 1u, (u32)(uc == 'A' || uc == 'C' || uc == 'G' || uc == 'T'), 1);
+        }
+#endif
+        pos += n;
+    }
+    void rec_end() { if (nrec < cap) ends[nrec] = pos; ++nrec; }
+    void finish() { if (nb) { word_out(true); nb = 0; } }
+};
+
+bool fastx_parallel_planes(cblx_ctx* c, const char* path, u64* nrec_out) {
+    Ingest& g = c->ing;
+    const char* pk = std::getenv("CBLX_H2D_PACK");
+    const int mode = pk ? std::atoi(pk) : -1;
+    const unsigned hc = std::thread::hardware_concurrency();
+    if (mode == 0 || (mode < 0 && hc < 16)) return false;
+    if (g.nseq || g.nbytes || g.query || g.staged || c->P.PB < 9) return false;
+    const size_t MIN_BYTES = fastx_env_bytes("CBLX_FASTX_PARALLEL_MIN", 32u << 20), REGION = fastx_env_bytes("CBLX_FASTX_REGION_BYTES", 16u << 20);
+    const bool trace = std::getenv("CBLX_INGEST_TRACE") != nullptr;
+    const auto t00 = std::chrono::steady_clock::now();
+    auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t00).count(); };
+    FastxMap m;
+    if (!m.open(path, MIN_BYTES)) return false;
+    std::vector<FastxRegion> regs;
+    fx_make_regions(m, m.first, m.size, REGION, regs);
+    if (trace) fprintf(stderr, "[fastx planes] mapped, %zu regions at %.2f ms\n", regs.size(), ms());
+    const unsigned TP = (unsigned)fastx_env_bytes("CBLX_FASTX_THREADS", std::min(32u, std::max(2u, hc / 2)));  // parser threads (both passes)
+    if (!fx_count_regions(m, regs, c->P.K, TP)) return false;
+    if (trace) fprintf(stderr, "[fastx planes] counted at %.2f ms\n", ms());
+    const u32 K = c->P.K;
+    const u64 window = std::min<u64>(ingest_flush_bytes(), 0x78000000ull);  // bases per batch (one batch = fewer than 2^32 words)
+    u64 total_rec = 0;
+    Xfer& x = xfer(c);
+    hipStream_t cs[2] = {x.lane_stream(0), x.lane_stream(1)};
+    for (size_t w0 = 0; w0 < regs.size();) {
+        size_t w1 = w0;
+        u64 nbases = 0, nrec = 0;
+        while (w1 < regs.size() && (w1 == w0 || nbases + regs[w1].nbases <= window)) { nbases += regs[w1].nbases; nrec += regs[w1].nrec; ++w1; }
+        const size_t nr = w1 - w0;
+        if (nrec == 0) { w0 = w1; continue; }
+        const u64 ng = (nbases + 15) / 16;
+        if (g.d_codes.n < ng + 8) g.d_codes = Buf<u32>(c->pool, ng + 8);
+        if (g.d_valid.n < ng + 8) g.d_valid = Buf<u16>(c->pool, ng + 8);
+        ingest_reserve(c, 0, nrec);
+        const size_t need = (size_t)(ng + 8) * 6 + (size_t)nrec * 8 + 64;
+        if (g.pin_cap < need) {
+            if (g.pin) { u8* old = g.pin; g.pin = nullptr; g.pin_cap = 0; CBLX_HIP(hipHostFree(old)); }
+            CBLX_HIP(hipHostMalloc((void**)&g.pin, need, hipHostMallocDefault));
+            g.pin_cap = need;
+        }
+        u32* h_codes = (u32*)g.pin;
+        u16* h_valid = (u16*)(g.pin + (size_t)(ng + 8) * 4);
+        u64* h_ends = (u64*)(g.pin + (((size_t)(ng + 8) * 6 + 63) & ~(size_t)63));
+        std::vector<u64> base(nr + 1, 0), rec0(nr + 1, 0);
+        for (size_t i = 0; i < nr; ++i) { base[i + 1] = base[i] + regs[w0 + i].nbases; rec0[i + 1] = rec0[i] + regs[w0 + i].nrec; }
+        for (size_t i = 0; i <= nr; ++i) {  // the words two regions share start from zero (they are OR-ed into)
+            const u64 b = base[i];
+            for (u64 gq : {b >> 4, (b ? b - 1 : 0) >> 4}) if (gq < ng + 8) { h_codes[gq] = 0; h_valid[gq] = 0; }
+        }
+        // slices = groups of consecutive regions of about 1 / NS of the bases
+        const u32 NS = 6;
+        std::vector<size_t> sl(1, 0);
+        for (u32 k = 1; k <= NS; ++k) {
+            size_t i = sl.back();
+            while (i < nr && base[i] < nbases * k / NS) ++i;
+            if (k == NS) i = nr;
+            if (i > sl.back()) sl.push_back(i);
+        }
+        const u32 ns = (u32)sl.size() - 1;
+        std::vector<u64> cuts(ns + 1);
+        for (u32 k = 0; k <= ns; ++k) cuts[k] = rec0[sl[k]];
+        std::vector<u32> slice_of(nr);
+        std::vector<std::atomic<u32>> left(ns);
+        for (u32 k = 0; k < ns; ++k) { left[k].store((u32)(sl[k + 1] - sl[k])); for (size_t i = sl[k]; i < sl[k + 1]; ++i) slice_of[i] = k; }
+        std::atomic<size_t> next{0};
+        std::atomic<u32> issued{0};
+        std::atomic<bool> failed{false};
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<hipEvent_t> ev(ns, nullptr);
+        const u8* d = m.d;
+        const char fmt = m.fmt;
+        auto worker = [&] {
+            for (size_t i; (i = next.fetch_add(1)) < nr;) {
+                const FastxRegion& r = regs[w0 + i];
+                PlaneSink sink(h_codes, h_valid, base[i], h_ends + rec0[i], r.nrec);
+                if (!fx_walk(d, r, fmt, K, sink) || sink.pos != base[i + 1] || sink.nrec != r.nrec) failed = true;
+                sink.finish();
+                if (left[slice_of[i]].fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> l(mu); cv.notify_all(); }
+            }
+        };
+        auto issuer = [&] {
+            try {
+                CBLX_HIP(hipSetDevice(c->device));
+                for (u32 k = 0; k < ns; ++k) {
+                    { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return left[k].load(std::memory_order_acquire) == 0; }); }
+                    // the slice's groups (its last, possibly shared word included: the next slice copies it again, complete) and record ends
+                    const u64 g0 = base[sl[k]] >> 4, g1 = std::min<u64>(ng, (base[sl[k + 1]] + 15) >> 4);
+                    hipStream_t st = cs[k & 1];
+                    if (g1 > g0) {
+                        CBLX_HIP(hipMemcpyAsync(g.d_codes.get() + g0, h_codes + g0, (g1 - g0) * 4, hipMemcpyHostToDevice, st));
+                        CBLX_HIP(hipMemcpyAsync(g.d_valid.get() + g0, h_valid + g0, (g1 - g0) * 2, hipMemcpyHostToDevice, st));
+                    }
+                    if (cuts[k + 1] > cuts[k]) CBLX_HIP(hipMemcpyAsync(g.d_off.get() + 1 + cuts[k], h_ends + cuts[k], (cuts[k + 1] - cuts[k]) * 8, hipMemcpyHostToDevice, st));
+                    hipEvent_t e;
+                    CBLX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    CBLX_HIP(hipEventRecord(e, st));
+                    ev[k] = e;
+                    { std::lock_guard<std::mutex> l(mu); issued.store(k + 1, std::memory_order_release); }
+                    cv.notify_all();
+                }
+            } catch (...) {
+                { std::lock_guard<std::mutex> l(mu); failed = true; issued.store(ns, std::memory_order_release); }
+                cv.notify_all();
+            }
+        };
+        const int T = (int)std::max<size_t>(1, std::min<size_t>(TP, nr));
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(worker);
+        th.emplace_back(issuer);
+        struct Join {
+            std::vector<std::thread>& th; std::vector<hipEvent_t>& ev; Xfer& x;
+            ~Join() {
+                for (auto& t : th) if (t.joinable()) t.join();
+                try { x.sync(); } catch (...) {}
+                for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+            }
+        } join{th, ev, x};
+        const BaseView view{nullptr, g.d_codes.get(), g.d_valid.get()};
+        insert_device_sliced(c, view, g.d_off.get(), nrec, cuts, [&](u32 s) {
+            if (s == ~0u) s = 0;  // the offsets of a slice travel with it: the first read needs slice 0
+            { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return issued.load(std::memory_order_acquire) > s; }); }
+            if (failed) throw Error(CBLX_EDEVICE, "fastx: the file changed while it was being read");
+            CBLX_HIP(hipStreamWaitEvent(c->stream, ev[s], 0));
+            if (s) CBLX_HIP(hipStreamWaitEvent(c->stream, ev[s - 1], 0));
+            if (trace) fprintf(stderr, "[fastx planes] slice %u handed over at %.2f ms\n", s, ms());
+        });
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+        if (failed) throw Error(CBLX_EDEVICE, "fastx: the file changed while it was being read");
+        total_rec += nrec;
+        if (trace) fprintf(stderr, "[fastx planes] window of %llu records done at %.2f ms\n", (unsigned long long)nrec, ms());
+        w0 = w1;
+    }
+    if (nrec_out) *nrec_out = total_rec;
+    return true;
+}
+
 }  // namespace

@@ -461,10 +461,10 @@ inline void fx_make_regions(const FastxMap& m, size_t beg, size_t end, size_t re
     }
 }
 // pass 1: records and bases of every region (threads; counting needs no transfer lanes). false: something irregular
-inline bool fx_count_regions(const FastxMap& m, std::vector<FastxRegion>& regs, u32 K) {
+inline bool fx_count_regions(const FastxMap& m, std::vector<FastxRegion>& regs, u32 K, unsigned threads = 0) {
     if (regs.empty()) return true;
     const unsigned hc = std::thread::hardware_concurrency();
-    const int TC = (int)std::min<size_t>(std::max(1u, std::min(2u * (unsigned)Xfer::max_parallel(), hc ? hc / 2 : 2u)), regs.size());
+    const int TC = (int)std::min<size_t>(threads ? threads : std::max(1u, std::min(2u * (unsigned)Xfer::max_parallel(), hc ? hc / 2 : 2u)), regs.size());
     std::atomic<size_t> next{0};
     std::vector<std::thread> th;
     struct Count { u64 nrec = 0, nbases = 0; void seq(const u8*, size_t n) { nbases += n; } void rec_end() { ++nrec; } };

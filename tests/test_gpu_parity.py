@@ -1126,10 +1126,12 @@ def test_sorted_batch_protocol_matches_oracle():
         assert g.serialize() == before
 
 
-def test_parallel_fastx_reader(tmp_path):
+@pytest.mark.parametrize("planes", ["1", "0"])
+def test_parallel_fastx_reader(tmp_path, planes):
     """Large plain FASTA / FASTQ files are read by several threads (regions cut at record starts, two passes). With the
     thresholds lowered (child process) small files take that path: many regions, several flush windows; irregular input
-    falls back to the sequential reader and fails exactly as it does."""
+    falls back to the sequential reader and fails exactly as it does. planes = 1: the parser threads pack the lines into bit
+    planes and the insert runs behind them (comm.hpp fastx_parallel_planes); 0: ASCII through the transfer lanes."""
     _need_gpu()
     import subprocess
     import sys
@@ -1143,6 +1145,9 @@ from oracle import Oracle
 k, pb = 31, 24
 tmp = %r
 bases, offsets = synth.reads(77, 12000, 150)
+rng = np.random.default_rng(5)
+hit = rng.random(bases.size)
+bases = np.where(hit < 0.0004, ord("N"), np.where(hit < 0.3, bases | 0x20, bases)).astype(np.uint8)  # some N, 30%% lower case
 o = Oracle(k, pb); o.insert_seqs(bases, offsets); want = o.serialize()
 seqs = [bases[int(offsets[i]):int(offsets[i + 1])].tobytes() for i in range(len(offsets) - 1)]
 files = {
@@ -1169,7 +1174,7 @@ n_before = files["a.fa"][:200000].rsplit(b">", 1)[0].count(b">")
 o2 = Oracle(k, pb); o2.insert_seqs(bases[: n_before * 150], offsets[: n_before + 1]); assert g.serialize() == o2.serialize()
 print("ok")
 """ % (ROOT, str(tmp_path))
-    env = dict(os.environ, CBLX_FASTX_PARALLEL_MIN="1000", CBLX_FASTX_REGION_BYTES="90000", CBLX_INGEST_FLUSH_BYTES="500000")
+    env = dict(os.environ, CBLX_FASTX_PARALLEL_MIN="1000", CBLX_FASTX_REGION_BYTES="90000", CBLX_INGEST_FLUSH_BYTES="500000", CBLX_H2D_PACK=planes)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
