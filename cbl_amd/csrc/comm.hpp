@@ -751,70 +751,6 @@ template <typename V> bool ingest_seqs_planes(cblx_ctx* c, const u8* bases, cons
 // PLACE (PlaneSink: 16 bytes -> three 16-bit words by SSE2 movemask, shifted to the region's bit offset; only the first and the last
 // word of a region are shared with its neighbours and take an atomic OR), the slices (groups of consecutive regions) are copied as
 // they complete, and the calling thread runs the sliced insert right behind them, as ingest_seqs_planes does for a host batch.
-struct PlaneSink {
-    u32* codes; u16* valid;   // pinned staging of the window, indexed by group of 16 bases
-    u64 pos;                  // bases written so far + the region's first base
-    u64 a0 = 0, a1 = 0, av = 0;
-    u32 nb;                   // bits waiting in the accumulators (the low `nb` bits)
-    u64 gcur;                 // group the accumulators' low bits belong to
-    bool shared = true;       // the next word to leave is the region's first: shared with the previous region
-    u64* ends; u64 nrec = 0, cap;
-    PlaneSink(u32* c, u16* v, u64 first_base, u64* e, u64 ecap) : codes(c), valid(v), pos(first_base), nb((u32)(first_base & 15)), gcur(first_base >> 4), ends(e), cap(ecap) {}
-    void word_out(bool last) {
-        const u32 w = (u32)(a0 & 0xFFFFu) | ((u32)(a1 & 0xFFFFu) << 16);
-        const u16 vw = (u16)(av & 0xFFFFu);
-        if (shared || last) {  // a word another region also writes into (zeroed before the threads started)
-            __atomic_fetch_or(&codes[gcur], w, __ATOMIC_RELAXED);
-            __atomic_fetch_or(&valid[gcur], vw, __ATOMIC_RELAXED);
-            shared = false;
-        } else {
-            codes[gcur] = w;
-            valid[gcur] = vw;
-        }
-        a0 >>= 16; a1 >>= 16; av >>= 16;
-        ++gcur;
-    }
-    void put(u32 p0, u32 p1, u32 v, u32 k) {  // k <= 16 bases as plane bits
-        a0 |= (u64)p0 << nb; a1 |= (u64)p1 << nb; av |= (u64)v << nb;
-        nb += k;
-        if (nb >= 16) { word_out(false); nb -= 16; }
-    }
-    void seq(const u8* p, size_t n) {
-        size_t i = 0;
-#if CBLX_HAVE_SSE2
-        const __m128i up = _mm_set1_epi8((char)0xDF), cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
-        auto planes16 = [&](const __m128i v, u32& p0, u32& p1, u32& ok) {
-            const __m128i u = _mm_and_si128(v, up);
-            const __m128i m = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(u, cA), _mm_cmpeq_epi8(u, cC)), _mm_or_si128(_mm_cmpeq_epi8(u, cG), _mm_cmpeq_epi8(u, cT)));
-            p0 = (u32)_mm_movemask_epi8(_mm_slli_epi16(v, 6));
-            p1 = (u32)_mm_movemask_epi8(_mm_slli_epi16(v, 5));
-            ok = (u32)_mm_movemask_epi8(m);
-        };
-        for (; i + 16 <= n; i += 16) {
-            u32 p0, p1, ok;
-            planes16(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p + i)), p0, p1, ok);
-            put(p0, p1, ok, 16);
-        }
-        if (i < n) {  // the line's tail through a local copy (a 16-byte load could run past the end of the mapping)
-            alignas(16) u8 tmp[16] = {0};
-            std::memcpy(tmp, p + i, n - i);
-            u32 p0, p1, ok;
-            planes16(_mm_load_si128(reinterpret_cast<const __m128i*>(tmp)), p0, p1, ok);
-            const u32 k = (u32)(n - i), mk = (1u << k) - 1u;
-            put(p0 & mk, p1 & mk, ok & mk, k);
-        }
-#else
-        for (; i < n; ++i) {
-            const u8 b = p[i], uc = b & 0xDF;
-            put((b >> 1) & 1u, (b >> 2) & 1u, (u32)(uc == 'A' || uc == 'C' || uc == 'G' || uc == 'T'), 1);
-        }
-#endif
-        pos += n;
-    }
-    void rec_end() { if (nrec < cap) ends[nrec] = pos; ++nrec; }
-    void finish() { if (nb) { word_out(true); nb = 0; } }
-};
-
 bool fastx_parallel_planes(cblx_ctx* c, const char* path, u64* nrec_out) {
     Ingest& g = c->ing;
     const char* pk = std::getenv("CBLX_H2D_PACK");
@@ -860,10 +796,7 @@ bool fastx_parallel_planes(cblx_ctx* c, const char* path, u64* nrec_out) {
         u64* h_ends = (u64*)(g.pin + (((size_t)(ng + 8) * 6 + 63) & ~(size_t)63));
         std::vector<u64> base(nr + 1, 0), rec0(nr + 1, 0);
         for (size_t i = 0; i < nr; ++i) { base[i + 1] = base[i] + regs[w0 + i].nbases; rec0[i + 1] = rec0[i] + regs[w0 + i].nrec; }
-        for (size_t i = 0; i <= nr; ++i) {  // the words two regions share start from zero (they are OR-ed into)
-            const u64 b = base[i];
-            for (u64 gq : {b >> 4, (b ? b - 1 : 0) >> 4}) if (gq < ng + 8) { h_codes[gq] = 0; h_valid[gq] = 0; }
-        }
+        fx_planes_prezero(base, ng + 8, h_codes, h_valid);
         // slices = groups of consecutive regions of about 1 / NS of the bases
         const u32 NS = 6;
         std::vector<size_t> sl(1, 0);

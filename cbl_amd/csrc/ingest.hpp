@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstdio>
 
+#include "fastx_parse.hpp"
 #include "pipeline.hpp"
 
 namespace {
@@ -337,150 +338,10 @@ struct LineReader {
 // pending queue, pass 2 copies the sequence lines through one Xfer lane per thread straight to that place. Anything
 // irregular (a record shorter than K, a malformed FASTQ record, gzip, a small file) leaves it to the sequential reader
 // above, which then reproduces the reference's behaviour record by record.
-struct FastxRegion {
-    size_t beg = 0, end = 0;
-    u64 nrec = 0, nbases = 0;
-    bool bad = false;
-};
-inline const u8* fx_line_end(const u8* p, const u8* end) {
-    const u8* nl = (const u8*)std::memchr(p, '\n', (size_t)(end - p));
-    return nl ? nl : end;
-}
-// next position >= pos where a record starts (or size)
-size_t fx_next_record(const u8* d, size_t size, size_t pos, char fmt) {
-    const u8* end = d + size;
-    const u8* p = d + pos;
-    if (pos != 0) {  // move to the start of the next line
-        p = fx_line_end(p - 1, end);
-        if (p < end) ++p;
-    }
-    while (p < end) {
-        if (*p == (u8)fmt) {
-            if (fmt == '>') return (size_t)(p - d);
-            // FASTQ: a header is a '@' line whose second next line starts with '+' (a quality line starting with '@' is
-            // followed by a header and then a sequence line, which never starts with '+')
-            const u8* l1 = fx_line_end(p, end);
-            const u8* l2 = l1 < end ? fx_line_end(l1 + 1, end) : end;
-            if (l2 < end && l2 + 1 < end && l2[1] == '+') return (size_t)(p - d);
-        }
-        p = fx_line_end(p, end);
-        if (p < end) ++p;
-    }
-    return size;
-}
-// one walk over a region; Sink: seq(ptr, n) for every piece of sequence, rec_end() after every record
-template <typename Sink> bool fx_walk(const u8* d, const FastxRegion& r, char fmt, u32 K, Sink&& sink) {
-    const u8* p = d + r.beg;
-    const u8* end = d + r.end;
-    auto line = [&](const u8*& b, size_t& n) -> bool {
-        if (p >= end) return false;
-        const u8* e = fx_line_end(p, end);
-        b = p;
-        n = (size_t)(e - p);
-        if (n && b[n - 1] == '\r') --n;
-        p = e < end ? e + 1 : end;
-        return true;
-    };
-    const u8* b;
-    size_t n;
-    if (fmt == '>') {
-        bool open_rec = false;
-        u64 len = 0;
-        while (line(b, n)) {
-            if (n && b[0] == '>') {
-                if (open_rec) { if (len < K) return false; sink.rec_end(); }
-                open_rec = true;
-                len = 0;
-            } else if (n) {
-                if (!open_rec) return false;  // sequence before the first header
-                sink.seq(b, n);
-                len += n;
-            }
-        }
-        if (open_rec) { if (len < K) return false; sink.rec_end(); }
-        return true;
-    }
-    while (line(b, n)) {
-        if (n == 0) continue;  // blank line between records
-        if (b[0] != '@') return false;
-        const u8 *sq, *pl, *ql;
-        size_t ns, npl, nq;
-        if (!line(sq, ns) || !line(pl, npl) || !line(ql, nq)) return false;
-        if (npl == 0 || pl[0] != '+' || ns < K) return false;
-        sink.seq(sq, ns);
-        sink.rec_end();
-    }
-    return true;
-}
-// a plain FASTA / FASTQ file mapped for the parallel readers
-struct FastxMap {
-    const u8* d = nullptr;
-    size_t size = 0, first = 0;
-    char fmt = 0;
-    ~FastxMap() {
-        // tearing down the page tables of a multi-GB mapping takes tens of milliseconds (30 ms for 1.7 GB): a helper thread
-        // does it while the caller goes on
-        if (!d) return;
-        const u8* dd = d; const size_t nn = size;
-        try { std::thread([dd, nn] { ::munmap((void*)dd, nn); }).detach(); } catch (...) { ::munmap((void*)dd, nn); }
-    }
-    // false: not a file these readers take (small, gzip, unreadable, no record at the start) — the sequential reader's case
-    bool open(const char* path, size_t min_bytes) {
-        const int fd = ::open(path, O_RDONLY);
-        if (fd < 0) return false;
-        struct stat st;
-        if (::fstat(fd, &st) != 0 || (size_t)st.st_size < std::max<size_t>(min_bytes, 2)) { ::close(fd); return false; }
-        size = (size_t)st.st_size;
-        const u8* m = (const u8*)::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-        ::close(fd);
-        if (m == (const u8*)MAP_FAILED) return false;
-        d = m;
-        (void)::madvise((void*)d, size, MADV_SEQUENTIAL);
-        if (d[0] == 0x1f && d[1] == 0x8b) return false;  // gzip
-        while (first < size && (d[first] == '\n' || d[first] == '\r')) ++first;
-        if (first == size || (d[first] != '>' && d[first] != '@')) return false;
-        fmt = (char)d[first];
-        return true;
-    }
-};
-inline size_t fastx_env_bytes(const char* name, size_t dflt) {  // test hooks: small files through the parallel paths
-    const char* e = std::getenv(name);
-    const unsigned long long v = e ? std::strtoull(e, nullptr, 10) : 0;
-    return v ? (size_t)v : dflt;
-}
-// [beg, end) (beg at a record start) cut into regions of about `region` bytes at record starts
-inline void fx_make_regions(const FastxMap& m, size_t beg, size_t end, size_t region, std::vector<FastxRegion>& regs) {
-    for (size_t pos = beg; pos < end;) {
-        size_t nxt = pos + region < end ? fx_next_record(m.d, m.size, pos + region, m.fmt) : end;
-        if (nxt > end) nxt = end;
-        FastxRegion r;
-        r.beg = pos;
-        r.end = nxt;
-        regs.push_back(std::move(r));
-        pos = nxt;
-    }
-}
-// pass 1: records and bases of every region (threads; counting needs no transfer lanes). false: something irregular
-inline bool fx_count_regions(const FastxMap& m, std::vector<FastxRegion>& regs, u32 K, unsigned threads = 0) {
-    if (regs.empty()) return true;
+// threads of the counting pass when the caller has no better figure
+inline unsigned fx_count_threads() {
     const unsigned hc = std::thread::hardware_concurrency();
-    const int TC = (int)std::min<size_t>(threads ? threads : std::max(1u, std::min(2u * (unsigned)Xfer::max_parallel(), hc ? hc / 2 : 2u)), regs.size());
-    std::atomic<size_t> next{0};
-    std::vector<std::thread> th;
-    struct Count { u64 nrec = 0, nbases = 0; void seq(const u8*, size_t n) { nbases += n; } void rec_end() { ++nrec; } };
-    auto body = [&] {
-        for (size_t i; (i = next.fetch_add(1)) < regs.size();) {
-            Count cnt;
-            regs[i].bad = !fx_walk(m.d, regs[i], m.fmt, K, cnt);
-            regs[i].nrec = cnt.nrec;
-            regs[i].nbases = cnt.nbases;
-        }
-    };
-    for (int t = 1; t < TC; ++t) th.emplace_back(body);
-    body();
-    for (auto& x : th) x.join();
-    for (auto& r : regs) if (r.bad) return false;
-    return true;
+    return std::max(1u, std::min(2u * (unsigned)Xfer::max_parallel(), hc ? hc / 2 : 2u));
 }
 // pass 2 over counted regions, in windows of about `window` bytes of bases: the sequence lines go through one transfer lane per
 // thread straight to their place in the pending queue. flush_windows: insert every full window (the build from a file);
@@ -546,7 +407,7 @@ bool fastx_parallel(cblx_ctx* c, const char* path, u64* nrec_out) {
     if (!m.open(path, MIN_BYTES)) return false;
     std::vector<FastxRegion> regs;
     fx_make_regions(m, m.first, m.size, REGION, regs);
-    if (!fx_count_regions(m, regs, c->P.K)) return false;
+    if (!fx_count_regions(m, regs, c->P.K, fx_count_threads())) return false;
     // pass 2, in windows of about 1 GiB of bases (the sequential reader's flush cadence)
     const u64 total = fx_copy_regions(c, m, regs, std::min<u64>(1ull << 30, ingest_flush_bytes()), true);
     if (nrec_out) *nrec_out = total;
@@ -582,7 +443,7 @@ bool fastx_stage_distributed(cblx_ctx* c, const char* path, u64& block, u32 targ
         cut0 = cut(rank);
         cut1 = cut(rank + 1);
         fx_make_regions(m, cut0, cut1, REGION, regs);
-        if (!fx_count_regions(m, regs, K)) flag = 1;
+        if (!fx_count_regions(m, regs, K, fx_count_threads())) flag = 1;
     }
     std::vector<u64> v(world + 1, 0);
     u64 mine = 0;
@@ -622,7 +483,7 @@ bool fastx_stage_distributed(cblx_ctx* c, const char* path, u64& block, u32 targ
         fx_make_regions(m, (size_t)boff[j], (size_t)boff[j + 1], REGION, mine_regs);
         expect += std::min<u64>(block, n_file - j * block);
     }
-    if (!fx_count_regions(m, mine_regs, K)) throw Error(CBLX_EDEVICE, "fastx: the file changed while it was being read");
+    if (!fx_count_regions(m, mine_regs, K, fx_count_threads())) throw Error(CBLX_EDEVICE, "fastx: the file changed while it was being read");
     lap("count my blocks");
     const u64 got = fx_copy_regions(c, m, mine_regs, ~0ull >> 1, false);
     lap("copy my blocks to HBM");

@@ -103,6 +103,15 @@ def test_pack_planes_host_unit(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_fastx_planes_host_unit(tmp_path):
+    """The parser threads' side of the FASTA / FASTQ file insert (cbl_amd/csrc/fastx_parse.hpp: regions, counting pass, PlaneSink)
+    against a byte-by-byte definition, under AddressSanitizer + UBSan (the sanitizers run on the CPU build only)."""
+    exe = tmp_path / "fastx_planes_unit"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", str(exe),
+                    str(ROOT / "tests" / "host" / "fastx_planes_unit.cpp")], check=True, capture_output=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
 @pytest.mark.parametrize("k,pb,nreads,L", [(31, 24, 3000, 150), (9, 4, 1500, 100), (59, 28, 400, 250), (15, 6, 1500, 150), (11, 8, 40, 3000)])
 def test_index_shard_cuts_speculative_equals_sequential(k, pb, nreads, L, tmp_path):
     """Host-only half of cblx_load_shard_from_file: the speculative search for the entry starts of `world` prefix ranges
