@@ -172,12 +172,20 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
     auto sub_buckets = [&](auto em, u8* outp) {  // the sub-ranges of split Tries: sizes (em = false) or bytes at body + voff
         constexpr bool EM = decltype(em)::value;
         const u64 nv = (u64)nsplit * 256;
-        if (vln[0])
-            hipLaunchKernelGGL((k_serde_bucket<64, 16, WS, EM, true>), dim3(vln[0]), dim3(64), 0, c->stream, vlists.get(), vlist_n.get(), (const u32*)nullptr, vstart.get(), vcnt.get(),
-                               (const u8*)nullptr, a_lo, a_hi, P.SB, P.BYTES, vsize.get(), voff.get(), outp);
-        if (vln[1])
-            hipLaunchKernelGGL((k_serde_bucket<256, 16, WS, EM, true>), dim3(vln[1]), dim3(256), 0, c->stream, vlists.get() + nv, vlist_n.get() + 1, (const u32*)nullptr, vstart.get(),
+        auto go = [&](auto th, auto it, u32 cls) {
+            constexpr int TH = decltype(th)::value, IT = decltype(it)::value;
+            hipLaunchKernelGGL((k_serde_bucket<TH, IT, WS, EM, true>), dim3(vln[cls]), dim3(TH), 0, c->stream, vlists.get() + cls * nv, vlist_n.get() + cls, (const u32*)nullptr, vstart.get(),
                                vcnt.get(), (const u8*)nullptr, a_lo, a_hi, P.SB, P.BYTES, vsize.get(), voff.get(), outp);
+        };
+        using std::integral_constant;
+        if (vln[0]) {  // (4 elements per thread when emitting: see `buckets` below)
+            if constexpr (EM) go(integral_constant<int, 256>(), integral_constant<int, 4>(), 0u);
+            else go(integral_constant<int, 64>(), integral_constant<int, 16>(), 0u);
+        }
+        if (vln[1]) {
+            if constexpr (EM) go(integral_constant<int, 1024>(), integral_constant<int, 4>(), 1u);
+            else go(integral_constant<int, 256>(), integral_constant<int, 16>(), 1u);
+        }
         if (vln[2])
             hipLaunchKernelGGL((k_serde_bucket<1024, 8, WS, EM, true>), dim3(vln[2]), dim3(1024), 0, c->stream, vlists.get() + 2 * nv, vlist_n.get() + 2, (const u32*)nullptr, vstart.get(),
                                vcnt.get(), (const u8*)nullptr, a_lo, a_hi, P.SB, P.BYTES, vsize.get(), voff.get(), outp);
@@ -185,12 +193,22 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
     };
     auto buckets = [&](auto em, u8* body) {
         constexpr bool EM = decltype(em)::value;
-        if (ln[SER_C64])
-            hipLaunchKernelGGL((k_serde_bucket<64, 16, WS, EM>), dim3(ln[SER_C64]), dim3(64), 0, c->stream, lists.get() + (size_t)SER_C64 * nb, list_n.get() + SER_C64,
+        // The emitter runs as 4 elements per thread (the sizing pass as 16): its second walk keeps the first walk's offsets next to
+        // the ranks, and at 16 elements per thread that is 240 VGPRs — one wave per SIMD (cfg 2's 9.4 GB: 92 ms; 47 ms like this).
+        auto go = [&](auto th, auto it, u32 cls) {
+            constexpr int TH = decltype(th)::value, IT = decltype(it)::value;
+            hipLaunchKernelGGL((k_serde_bucket<TH, IT, WS, EM>), dim3(ln[cls]), dim3(TH), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls,
                                r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body);
-        if (ln[SER_C256])
-            hipLaunchKernelGGL((k_serde_bucket<256, 16, WS, EM>), dim3(ln[SER_C256]), dim3(256), 0, c->stream, lists.get() + (size_t)SER_C256 * nb, list_n.get() + SER_C256,
-                               r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body);
+        };
+        using std::integral_constant;
+        if (ln[SER_C64]) {
+            if constexpr (EM) go(integral_constant<int, 256>(), integral_constant<int, 4>(), SER_C64);
+            else go(integral_constant<int, 64>(), integral_constant<int, 16>(), SER_C64);
+        }
+        if (ln[SER_C256]) {
+            if constexpr (EM) go(integral_constant<int, 1024>(), integral_constant<int, 4>(), SER_C256);
+            else go(integral_constant<int, 256>(), integral_constant<int, 16>(), SER_C256);
+        }
         if (ln[SER_C1024])
             hipLaunchKernelGGL((k_serde_bucket<1024, 8, WS, EM>), dim3(ln[SER_C1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)SER_C1024 * nb, list_n.get() + SER_C1024,
                                r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body);

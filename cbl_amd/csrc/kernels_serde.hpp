@@ -112,28 +112,65 @@ __global__ __launch_bounds__(THREADS) void k_serde_bucket(const u32* __restrict_
                                                           u32* __restrict__ size, const u64* __restrict__ off, u8* __restrict__ out) {
     constexpr int NW = THREADS / 64, EPW = 64 * ITEMS, CAP = THREADS * ITEMS;
     constexpr u32 D0 = SUB ? 1u : 0u;            // first level this workgroup emits
+    // EMIT: the entry is assembled in LDS and leaves in aligned 16-byte stores (the bytes of an entry are written one by one, a
+    // node header here, a child byte there: as global stores that is one memory transaction per byte — 86 ms for the 9.4 GB of
+    // cfg 2's index). 13 bytes per element cover a Trie of random suffixes (12.4: three bytes per node on the sparse levels); a longer entry is written
+    // to its place directly, as before.
+    constexpr u32 STAGE = EMIT ? (u32)CAP * 13u + 64u : 0u;
     __shared__ u32 s_wtot[NW + 1];
     __shared__ u16 s_ns[CAP + 2];                // X_d at the start of node k (+ sentinel)
     __shared__ u32 s_np[EMIT ? CAP : 1];         // where node k's child bytes start (relative to the entry)
+    __shared__ __attribute__((aligned(16))) u8 s_stage[EMIT ? STAGE + 16 : 16];
     if (blockIdx.x >= *list_n) return;
     const u32 r = list[blockIdx.x];
     const u32 n = cnt[r], pfx = SUB ? 0u : prefix[r];
     const u64 s0 = start[r];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const u32 hdr = SUB ? 0u : vlen(pfx) + 1;
-    u8* o = EMIT ? out + off[r] : nullptr;
+    u8* const gdst = EMIT ? out + off[r] : nullptr;
+    const u32 esz = EMIT ? size[r] : 0u;                                   // the sizing pass's figure for this entry
+    const u32 mis = EMIT ? (u32)(reinterpret_cast<uintptr_t>(gdst) & 15u) : 0u;  // staged at the same misalignment as its place
+    const bool staged = EMIT && esz + mis <= STAGE;
+    // one byte of the entry (position relative to its start): into the staging buffer (an LDS store: a flat pointer that may or
+    // may not point into LDS makes every later LDS read wait for the stores before it), or to its place
+    auto st = [&](u32 pos, u32 v) {
+        if constexpr (EMIT) { if (staged) s_stage[mis + pos] = (u8)v; else gdst[pos] = (u8)v; }
+    };
+    auto st_varint = [&](u32 pos, u32 v) {  // bincode varint of a value below 2^32
+        if (v <= 250u) { st(pos, v); return; }
+        if (v < 65536u) { st(pos, 0xFBu); st(pos + 1, v & 255u); st(pos + 2, v >> 8); return; }
+        st(pos, 0xFCu);
+        for (u32 i = 0; i < 4; ++i) st(pos + 1 + i, (v >> (8 * i)) & 255u);
+    };
+    auto flush_stage = [&]() {  // (every thread of the workgroup)
+        if constexpr (EMIT) {
+            if (!staged) return;
+            __syncthreads();
+            u8* const gbase = gdst - mis;
+            const u32 span = mis + esz, nch = (span + 15u) >> 4;
+            for (u32 k = tid; k < nch; k += THREADS) {
+                const u32 b0 = k << 4;
+                if (b0 >= mis && b0 + 16u <= span) {
+                    *reinterpret_cast<uint4*>(gbase + b0) = *reinterpret_cast<const uint4*>(s_stage + b0);
+                } else {  // the first / last chunk: only the entry's own bytes (the neighbours' are theirs)
+                    for (u32 b = b0 < mis ? mis : b0; b < b0 + 16u && b < span; ++b) gbase[b] = s_stage[b];
+                }
+            }
+        }
+    };
     if (!SUB && kind[r] == KIND_VEC) {           // varint(n) then n x (varint(BYTES) | BYTES little-endian bytes), stored order
         if constexpr (!EMIT) {
             if (tid == 0) size[r] = hdr + vlen(n) + n * (1 + BYTES);
         } else {
-            if (tid == 0) { put_varint(o, pfx); o[hdr - 1] = 0; put_varint(o + hdr, n); }
-            u8* body = o + hdr + vlen(n);
+            if (tid == 0) { st_varint(0, pfx); st(hdr - 1, 0); st_varint(hdr, n); }
+            const u32 body = hdr + vlen(n);
             for (u32 j = tid; j < n; j += THREADS) {
                 const Sfx<WS> s = arena_sfx<WS>(a_lo, a_hi, s0 + j, SB);
-                u8* p = body + (u64)j * (1 + BYTES);
-                p[0] = (u8)BYTES;
-                for (u32 k = 0; k < BYTES; ++k) p[1 + k] = (u8)sfx_byte_le<WS>(s, k);
+                const u32 p = body + j * (1 + BYTES);
+                st(p, BYTES);
+                for (u32 k = 0; k < BYTES; ++k) st(p + 1 + k, sfx_byte_le<WS>(s, k));
             }
+            flush_stage();
         }
         return;
     }
@@ -199,10 +236,10 @@ __global__ __launch_bounds__(THREADS) void k_serde_bucket(const u32* __restrict_
                     const u32 c = (u32)s_ns[xprev[i] + 1] - (u32)s_ns[xprev[i]];
                     const u32 hs = vlen(c) + c + (leaf ? 1u : vlen(c));
                     if constexpr (EM) {
-                        u8* p = o + base[i] + acc[i];
-                        put_varint(p, c);
-                        put_varint(p + vlen(c) + c, leaf ? 0u : c);
-                        s_np[xprev[i]] = base[i] + acc[i] + vlen(c);
+                        const u32 p = base[i] + acc[i];
+                        st_varint(p, c);
+                        st_varint(p + vlen(c) + c, leaf ? 0u : c);
+                        s_np[xprev[i]] = p + vlen(c);
                     }
                     acc[i] += hs;
                 }
@@ -213,7 +250,7 @@ __global__ __launch_bounds__(THREADS) void k_serde_bucket(const u32* __restrict_
                 for (int i = 0; i < ITEMS; ++i) {
                     if (tcur[i]) {
                         const u32 kp = xprev[i] + (tprev[i] ? 1u : 0u) - 1u;  // the node this child belongs to
-                        o[s_np[kp] + (xcur[i] - (u32)s_ns[kp])] = (u8)sfx_byte_le<WS>(x[i], BYTES - 1 - d);
+                        st(s_np[kp] + (xcur[i] - (u32)s_ns[kp]), sfx_byte_le<WS>(x[i], BYTES - 1 - d));
                     }
                 }
             }
@@ -247,8 +284,9 @@ __global__ __launch_bounds__(THREADS) void k_serde_bucket(const u32* __restrict_
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) { base[i] += wbase + hdr; E[i] = 0; }
-        if constexpr (!SUB) if (tid == 0) { put_varint(o, pfx); o[hdr - 1] = 1; put_varint(o + hdr + total, n); }  // TrieOrVec::Trie(.., len)
+        if constexpr (!SUB) if (tid == 0) { st_varint(0, pfx); st(hdr - 1, 1); st_varint(hdr + total, n); }  // TrieOrVec::Trie(.., len)
         levels(std::true_type(), E, base);
+        flush_stage();
     }
 }
 
