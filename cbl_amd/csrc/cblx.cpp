@@ -564,11 +564,10 @@ int cblx_serialize(cblx_ctx* c, uint8_t* buf, uint64_t cap, uint64_t* written) {
     return guard(c, [&] {
         flush(c);
         DevBlob blob;
-        if (serialize_device(c, false, blob)) {
+        // (one sizing pass; the download of a chunk of buckets runs while the next chunk is being emitted)
+        if (serialize_device(c, true, blob, cap, [&](u64 lo, u64 hi) { xfer(c).d2h_copy(buf + lo, blob.bytes.get() + lo, hi - lo); })) {
             if (written) *written = blob.n;
-            if (blob.n > cap) throw Error(CBLX_ERANGE, "buffer too small: need " + std::to_string(blob.n) + " bytes");
-            serialize_device(c, true, blob);
-            xfer(c).d2h_copy(buf, blob.bytes.get(), blob.n);
+            if (blob.over_cap) throw Error(CBLX_ERANGE, "buffer too small: need " + std::to_string(blob.n) + " bytes");
             return;
         }
         HostIndex h;
@@ -582,33 +581,43 @@ int cblx_serialize(cblx_ctx* c, uint8_t* buf, uint64_t cap, uint64_t* written) {
 int cblx_save_to_file(cblx_ctx* c, const char* path) {
     return guard(c, [&] {
         flush(c);
+        // The device emitter's bytes go to the file chunk by chunk (the download of a chunk of buckets runs while the next chunk is
+        // being emitted); the lanes write straight from their pinned slots. The file is opened by the first chunk: when the
+        // device emitter does not take the index (an entry of 4 GiB or more) nothing has been created yet.
         DevBlob blob;
-        if (serialize_device(c, true, blob)) {  // the lanes write their chunks straight from pinned memory
-            const int fd = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
-            if (fd < 0) throw Error(CBLX_EINVAL, std::string("Failed to create ") + path);
-            std::atomic<bool> bad{false};
-            // The lanes fill a shared mapping of the file when the file system gives one: concurrent pwrite()s to ONE file
-            // serialise on its inode lock (3 GB/s on tmpfs with eight lanes), page faults of a mapping do not.
-            void* map = MAP_FAILED;
-            if (blob.n >= (64u << 20) && ::ftruncate(fd, (off_t)blob.n) == 0) map = ::mmap(nullptr, blob.n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        int fd = -1;
+        void* map = MAP_FAILED;
+        std::atomic<bool> bad{false};
+        struct Closer {
+            int& fd; void*& map; DevBlob& blob;
+            ~Closer() { if (map != MAP_FAILED) ::munmap(map, blob.n); if (fd >= 0) ::close(fd); }
+        } closer{fd, map, blob};
+        auto sink = [&](u64 lo, u64 hi) {
+            if (fd < 0) {
+                fd = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+                if (fd < 0) throw Error(CBLX_EINVAL, std::string("Failed to create ") + path);
+                // The lanes fill a shared mapping of the file when the file system gives one: concurrent pwrite()s to ONE file
+                // serialise on its inode lock (3 GB/s on tmpfs with eight lanes), page faults of a mapping do not.
+                if (blob.n >= (64u << 20) && ::ftruncate(fd, (off_t)blob.n) == 0) map = ::mmap(nullptr, blob.n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            }
             if (map != MAP_FAILED) {
-                try {
-                    xfer(c).d2h(blob.bytes.get(), blob.n, [&](const u8* src, size_t off, size_t n) { std::memcpy((u8*)map + off, src, n); });
-                } catch (...) { ::munmap(map, blob.n); ::close(fd); throw; }
-                const bool ok = ::munmap(map, blob.n) == 0;
-                if (::close(fd) != 0 || !ok) throw Error(CBLX_EINVAL, std::string("Failed to write index to ") + path);
+                xfer(c).d2h(blob.bytes.get() + lo, hi - lo, [&](const u8* src, size_t off, size_t n) { std::memcpy((u8*)map + lo + off, src, n); });
                 return;
             }
-            try {
-                xfer(c).d2h(blob.bytes.get(), blob.n, [&](const u8* src, size_t off, size_t n) {
-                    while (n) {
-                        const ssize_t w = ::pwrite(fd, src, n, (off_t)off);
-                        if (w <= 0) { bad = true; return; }
-                        src += w; off += (size_t)w; n -= (size_t)w;
-                    }
-                });
-            } catch (...) { ::close(fd); throw; }
-            if (::close(fd) != 0 || bad) throw Error(CBLX_EINVAL, std::string("Failed to write index to ") + path);
+            xfer(c).d2h(blob.bytes.get() + lo, hi - lo, [&](const u8* src, size_t off, size_t n) {
+                off += lo;
+                while (n) {
+                    const ssize_t w = ::pwrite(fd, src, n, (off_t)off);
+                    if (w <= 0) { bad = true; return; }
+                    src += w; off += (size_t)w; n -= (size_t)w;
+                }
+            });
+        };
+        if (serialize_device(c, true, blob, ~0ull, sink)) {
+            bool ok = !bad;
+            if (map != MAP_FAILED) { ok = ::munmap(map, blob.n) == 0 && ok; map = MAP_FAILED; }
+            if (fd >= 0) { ok = ::close(fd) == 0 && ok; fd = -1; }
+            if (!ok) throw Error(CBLX_EINVAL, std::string("Failed to write index to ") + path);
             return;
         }
         HostIndex h;

@@ -1,6 +1,7 @@
 // host_index.hpp — the index as bytes: host-side copy of the resident index (export), the bincode emitter on the host and
 // its device counterpart's driver (kernels_serde.hpp), the streaming / parallel loader. Included by cblx.cpp only.
 #pragma once
+#include <functional>
 #include <sys/mman.h>
 #include <sys/stat.h>
 
@@ -148,9 +149,14 @@ void serialize_host(const Consts& P, const HostIndex& h, Sink& s) {
     s.pos = base + part[nt];
 }
 // ---- the same bytes, produced in HBM (kernels_serde.hpp): size pass -> exclusive scan -> emit pass ---------------
-struct DevBlob { Buf<u8> bytes; u64 n = 0; };
-// false: only when an entry would not fit the 32-bit size table (>= 4 GiB) -> the caller takes the all-host path
-template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blob) {
+struct DevBlob { Buf<u8> bytes; u64 n = 0; bool over_cap = false; };
+// consumer of the emitted bytes, chunk by chunk: called with [lo, hi) once those bytes of blob.bytes are final, while the emitter
+// goes on with the buckets behind them (the download of a chunk hides the emission of the next)
+typedef std::function<void(u64, u64)> BlobChunkFn;
+static const u32 SER_EMIT_CHUNKS = 4;
+// false: only when an entry would not fit the 32-bit size table (>= 4 GiB) -> the caller takes the all-host path.
+// emit with blob.n > cap: nothing is emitted, blob.over_cap is set.
+template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blob, u64 cap, const BlobChunkFn& on_chunk) {
     constexpr bool WS = C::WS;
     const Resident& r = c->res;
     const Consts& P = c->P;
@@ -191,14 +197,14 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
                                vcnt.get(), (const u8*)nullptr, a_lo, a_hi, P.SB, P.BYTES, vsize.get(), voff.get(), outp);
         CBLX_HIP(hipGetLastError());
     };
-    auto buckets = [&](auto em, u8* body) {
+    auto buckets = [&](auto em, u8* body, u32 r_lo = 0u, u32 r_hi = 0xFFFFFFFFu) {
         constexpr bool EM = decltype(em)::value;
         // The emitter runs as 4 elements per thread (the sizing pass as 16): its second walk keeps the first walk's offsets next to
         // the ranks, and at 16 elements per thread that is 240 VGPRs — one wave per SIMD (cfg 2's 9.4 GB: 92 ms; 47 ms like this).
         auto go = [&](auto th, auto it, u32 cls) {
             constexpr int TH = decltype(th)::value, IT = decltype(it)::value;
             hipLaunchKernelGGL((k_serde_bucket<TH, IT, WS, EM>), dim3(ln[cls]), dim3(TH), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls,
-                               r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body);
+                               r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body, r_lo, r_hi);
         };
         using std::integral_constant;
         if (ln[SER_C64]) {
@@ -211,7 +217,7 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
         }
         if (ln[SER_C1024])
             hipLaunchKernelGGL((k_serde_bucket<1024, 8, WS, EM>), dim3(ln[SER_C1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)SER_C1024 * nb, list_n.get() + SER_C1024,
-                               r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body);
+                               r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body, r_lo, r_hi);
         CBLX_HIP(hipGetLastError());
     };
     if (nb) {
@@ -326,13 +332,18 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
     }
     blob.n = hs.pos + total;
     if (!emit) return true;
+    if (blob.n > cap) { blob.over_cap = true; return true; }
+    bool handed = false;  // the chunks went to on_chunk one by one
     blob.bytes = Buf<u8>(c->pool, blob.n + 16);
     CBLX_HIP(hipMemcpyAsync(blob.bytes.get(), hdr, hs.pos, hipMemcpyHostToDevice, c->stream));
     if (nb) {
         u8* body = blob.bytes.get() + hs.pos;
         hipLaunchKernelGGL((k_serde_tiny<WS, true>), grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
                            P.SB, P.BYTES, size.get(), off.get(), body, (u32*)nullptr, (u32*)nullptr);
-        buckets(std::true_type(), body);
+        // (CBLX_SERDE_CHUNK_MIN: test hook — small indexes through the chunked hand-over)
+        static const u64 chunk_min = [] { const char* e = std::getenv("CBLX_SERDE_CHUNK_MIN"); const unsigned long long v = e ? std::strtoull(e, nullptr, 10) : 0; return v ? (u64)v : (u64)(256u << 20); }();
+        const bool chunked = (bool)on_chunk && nb >= 4 * SER_EMIT_CHUNKS && blob.n >= chunk_min;
+        if (!chunked) buckets(std::true_type(), body);
         if (nsplit) {  // split Tries: header / root / length by one kernel, then every sub-trie at its absolute offset (voff is relative to the blob)
             hipLaunchKernelGGL(k_serde_split_emit, dim3(nsplit), dim3(256), 0, c->stream, lists.get() + (size_t)SER_SPLIT * nb, list_n.get() + SER_SPLIT, r.prefix.get(), r.cnt.get(),
                                vcnt.get(), vsize.get(), split_bad.get(), off.get(), voff.get(), body);
@@ -346,14 +357,40 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
             xfer(c).h2d_copy(body + o, host_bytes[i].data(), host_bytes[i].size());
         }
         if (!host_r.empty()) xfer(c).sync();
+        if (chunked) {
+            // the workgroup entries in chunks of consecutive buckets (everything else of the body is in place by now): chunk k's
+            // bytes [cut[k], cut[k + 1]) are final when its launches are, and are handed over while chunk k + 1 is being emitted
+            const u32 NCH = SER_EMIT_CHUNKS;
+            std::vector<u64> cut(NCH + 1, 0);
+            std::vector<u32> rcut(NCH + 1, 0);
+            for (u32 k = 1; k < NCH; ++k) { rcut[k] = (u32)(nb * k / NCH); cut[k] = hs.pos + d2h<u64>(c, off.get() + rcut[k]); }
+            rcut[NCH] = (u32)nb;
+            cut[NCH] = blob.n;
+            struct Events {
+                std::vector<hipEvent_t> e;
+                ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+            } ev;
+            ev.e.assign(NCH, nullptr);
+            for (u32 k = 0; k < NCH; ++k) {
+                buckets(std::true_type(), body, rcut[k], rcut[k + 1]);
+                CBLX_HIP(hipEventCreateWithFlags(&ev.e[k], hipEventDisableTiming));
+                CBLX_HIP(hipEventRecord(ev.e[k], c->stream));
+            }
+            for (u32 k = 0; k < NCH; ++k) {
+                CBLX_HIP(hipEventSynchronize(ev.e[k]));
+                if (cut[k + 1] > cut[k]) on_chunk(cut[k], cut[k + 1]);
+            }
+            handed = true;
+        }
     }
     CBLX_HIP(hipStreamSynchronize(c->stream));
+    if (on_chunk && !handed && blob.n) on_chunk(0, blob.n);
     return true;
 }
-bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blob) {
+bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blob, u64 cap = ~0ull, const BlobChunkFn& on_chunk = BlobChunkFn()) {
     if (const char* e = std::getenv("CBLX_HOST_SERDE")) if (e[0] == '1') return false;  // test hook: force the host emitter
     bool ok = false;
-    dispatch(c->P, [&](auto cfg) { ok = serialize_device<decltype(cfg)>(c, emit, blob); });
+    dispatch(c->P, [&](auto cfg) { ok = serialize_device<decltype(cfg)>(c, emit, blob, cap, on_chunk); });
     return ok;
 }
 

@@ -109,7 +109,8 @@ template <int THREADS, int ITEMS, bool WS, bool EMIT, bool SUB = false>
 __global__ __launch_bounds__(THREADS) void k_serde_bucket(const u32* __restrict__ list, const u32* __restrict__ list_n, const u32* __restrict__ prefix,
                                                           const u64* __restrict__ start, const u32* __restrict__ cnt, const u8* __restrict__ kind,
                                                           const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u32 SB, u32 BYTES,
-                                                          u32* __restrict__ size, const u64* __restrict__ off, u8* __restrict__ out) {
+                                                          u32* __restrict__ size, const u64* __restrict__ off, u8* __restrict__ out, u32 r_lo = 0u,
+                                                          u32 r_hi = 0xFFFFFFFFu /* only the listed ids in [r_lo, r_hi): the emitter runs in chunks of buckets */) {
     constexpr int NW = THREADS / 64, EPW = 64 * ITEMS, CAP = THREADS * ITEMS;
     constexpr u32 D0 = SUB ? 1u : 0u;            // first level this workgroup emits
     // EMIT: the entry is assembled in LDS and leaves in aligned 16-byte stores (the bytes of an entry are written one by one, a
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(THREADS) void k_serde_bucket(const u32* __restrict_
     __shared__ __attribute__((aligned(16))) u8 s_stage[EMIT ? STAGE + 16 : 16];
     if (blockIdx.x >= *list_n) return;
     const u32 r = list[blockIdx.x];
+    if (r < r_lo || r >= r_hi) return;
     const u32 n = cnt[r], pfx = SUB ? 0u : prefix[r];
     const u64 s0 = start[r];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;

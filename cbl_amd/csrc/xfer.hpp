@@ -217,6 +217,19 @@ public:
         fan_out(L, work);
     }
     void d2h_copy(void* h_dst, const void* d_src, size_t bytes) {
+        if (bytes >= PARALLEL_MIN && is_pinned(h_dst) && is_pinned((const u8*)h_dst + bytes - 1)) {
+            // the caller's buffer is pinned: DMA straight into it, split over a few of the lanes' streams (complete on return)
+            const int L = std::min(4, lanes_for(bytes));
+            ensure(L);
+            const size_t per = ((bytes + (size_t)L - 1) / (size_t)L + 4095) & ~(size_t)4095;
+            for (int i = 0; i < L; ++i) {
+                const size_t off = (size_t)i * per;
+                if (off >= bytes) break;
+                CBLX_HIP(hipMemcpyAsync((u8*)h_dst + off, (const u8*)d_src + off, std::min(per, bytes - off), hipMemcpyDeviceToHost, lanes_[(size_t)i].s));
+            }
+            for (int i = 0; i < L; ++i) CBLX_HIP(hipStreamSynchronize(lanes_[(size_t)i].s));
+            return;
+        }
         d2h(d_src, bytes, [&](const u8* src, size_t off, size_t n) { std::memcpy((u8*)h_dst + off, src, n); });
     }
     // Lanes lent to producers that generate bytes at their own pace (file parsers): with_lanes(T, work) runs work(t) on T

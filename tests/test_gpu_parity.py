@@ -1179,6 +1179,45 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_index_bytes_leave_in_chunks(tmp_path):
+    """cblx_serialize / cblx_save_to_file hand the emitted bytes over in chunks of consecutive buckets (the download of one runs
+    while the next is emitted; indexes of 256 MB and more). With the threshold lowered (child process) small indexes take that
+    path: the bytes equal the oracle's, into a buffer and into a file, for Vec-only, Trie-heavy, wide-suffix and split-Trie shapes."""
+    _need_gpu()
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import cbl_amd
+from cbl_amd import synth
+from oracle import Oracle
+tmp = %r
+for k, pb, nr, L, canonical in ((31, 24, 3000, 150, False), (31, 8, 6000, 150, False), (59, 12, 1500, 250, True), (21, 6, 9000, 150, False), (31, 24, 0, 150, False)):
+    bases, offsets = synth.reads(5 + k, nr, L)
+    o = Oracle(k, pb, canonical); g = cbl_amd.CBL(k, pb, canonical=canonical)
+    if nr:
+        o.insert_seqs(bases, offsets); g.insert_seqs(bases, offsets)
+    want = o.serialize()
+    assert g.serialize() == want, (k, pb)
+    path = tmp + "/i_%%d_%%d.cbl" %% (k, pb)
+    g.save_to_file(path)
+    assert open(path, "rb").read() == want, (k, pb, "file")
+    small = np.empty(max(len(want) - 1, 1), dtype=np.uint8)  # a buffer one byte short: refused, nothing written past it
+    try:
+        import ctypes as C
+        w = C.c_uint64(0)
+        rc = g._L.cblx_serialize(g._h, small.ctypes.data_as(C.POINTER(C.c_uint8)), len(want) - 1, C.byref(w))
+        assert rc == cbl_amd.ERANGE and w.value == len(want), (rc, w.value)
+    finally:
+        pass
+print("ok")
+""" % (ROOT, str(tmp_path))
+    env = dict(os.environ, CBLX_SERDE_CHUNK_MIN="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
 # ---- packed k-mers: CBL::insert / contains / iter and the bucket statistics (/root/reference/src/cbl.rs:219-228,358-386;
 # the reference's own shape: src/cbl.rs:591-662 insert/contains of random k-mers, :700-724 iter) ------------------------
 @pytest.mark.parametrize("k,pb,canonical", [(31, 24, False), (31, 24, True), (25, 12, False), (11, 8, True), (59, 28, False), (45, 20, True), (33, 16, False), (31, 2, True), (31, 3, False)])
