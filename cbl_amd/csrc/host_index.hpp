@@ -153,7 +153,6 @@ struct DevBlob { Buf<u8> bytes; u64 n = 0; bool over_cap = false; };
 // consumer of the emitted bytes, chunk by chunk: called with [lo, hi) once those bytes of blob.bytes are final, while the emitter
 // goes on with the buckets behind them (the download of a chunk hides the emission of the next)
 typedef std::function<void(u64, u64)> BlobChunkFn;
-static const u32 SER_EMIT_CHUNKS = 4;
 // false: only when an entry would not fit the 32-bit size table (>= 4 GiB) -> the caller takes the all-host path.
 // emit with blob.n > cap: nothing is emitted, blob.over_cap is set.
 template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blob, u64 cap, const BlobChunkFn& on_chunk) {
@@ -168,7 +167,7 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
     u64 total = 0;
     Buf<u32> size, lists, list_n;
     Buf<u64> off;
-    std::vector<u32> ln(SER_NCLS, 0), host_r;
+    std::vector<u32> ln(SER_NCLS * SER_CHUNKS, 0), host_r;  // [class][chunk]
     std::vector<std::vector<u8>> host_bytes;
     const u64 *a_lo = r.a_lo.get(), *a_hi = WS ? r.a_hi.get() : (const u64*)nullptr;
     u32 nsplit = 0;
@@ -197,42 +196,45 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
                                vcnt.get(), (const u8*)nullptr, a_lo, a_hi, P.SB, P.BYTES, vsize.get(), voff.get(), outp);
         CBLX_HIP(hipGetLastError());
     };
-    auto buckets = [&](auto em, u8* body, u32 r_lo = 0u, u32 r_hi = 0xFFFFFFFFu) {
+    const u64 per = std::max<u64>(1, ceil_div(nb, (u64)SER_CHUNKS));  // buckets per chunk of the class lists
+    auto LN = [&](u32 cls, u32 k = 0) -> u32& { return ln[cls * SER_CHUNKS + k]; };
+    // the workgroup entries of chunks [k0, k1): sizes (em = false) or bytes
+    auto buckets = [&](auto em, u8* body, u32 k0 = 0u, u32 k1 = SER_CHUNKS) {
         constexpr bool EM = decltype(em)::value;
         // The emitter runs as 4 elements per thread (the sizing pass as 16): its second walk keeps the first walk's offsets next to
         // the ranks, and at 16 elements per thread that is 240 VGPRs — one wave per SIMD (cfg 2's 9.4 GB: 92 ms; 47 ms like this).
-        auto go = [&](auto th, auto it, u32 cls) {
-            constexpr int TH = decltype(th)::value, IT = decltype(it)::value;
-            hipLaunchKernelGGL((k_serde_bucket<TH, IT, WS, EM>), dim3(ln[cls]), dim3(TH), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls,
-                               r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body, r_lo, r_hi);
-        };
         using std::integral_constant;
-        if (ln[SER_C64]) {
-            if constexpr (EM) go(integral_constant<int, 256>(), integral_constant<int, 4>(), SER_C64);
-            else go(integral_constant<int, 64>(), integral_constant<int, 16>(), SER_C64);
+        for (u32 k = k0; k < k1; ++k) {
+            auto go = [&](auto th, auto it, u32 cls) {
+                constexpr int TH = decltype(th)::value, IT = decltype(it)::value;
+                hipLaunchKernelGGL((k_serde_bucket<TH, IT, WS, EM>), dim3(LN(cls, k)), dim3(TH), 0, c->stream, lists.get() + (size_t)cls * nb + (size_t)k * per,
+                                   list_n.get() + cls * SER_CHUNKS + k, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body);
+            };
+            if (LN(SER_C64, k)) {
+                if constexpr (EM) go(integral_constant<int, 256>(), integral_constant<int, 4>(), SER_C64);
+                else go(integral_constant<int, 64>(), integral_constant<int, 16>(), SER_C64);
+            }
+            if (LN(SER_C256, k)) {
+                if constexpr (EM) go(integral_constant<int, 1024>(), integral_constant<int, 4>(), SER_C256);
+                else go(integral_constant<int, 256>(), integral_constant<int, 16>(), SER_C256);
+            }
+            if (LN(SER_C1024, k)) go(integral_constant<int, 1024>(), integral_constant<int, 8>(), SER_C1024);
         }
-        if (ln[SER_C256]) {
-            if constexpr (EM) go(integral_constant<int, 1024>(), integral_constant<int, 4>(), SER_C256);
-            else go(integral_constant<int, 256>(), integral_constant<int, 16>(), SER_C256);
-        }
-        if (ln[SER_C1024])
-            hipLaunchKernelGGL((k_serde_bucket<1024, 8, WS, EM>), dim3(ln[SER_C1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)SER_C1024 * nb, list_n.get() + SER_C1024,
-                               r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi, P.SB, P.BYTES, size.get(), off.get(), body, r_lo, r_hi);
         CBLX_HIP(hipGetLastError());
     };
     if (nb) {
         size = Buf<u32>(c->pool, nb);
         lists = Buf<u32>(c->pool, (size_t)SER_NCLS * nb);
-        list_n = Buf<u32>(c->pool, SER_NCLS);
+        list_n = Buf<u32>(c->pool, SER_NCLS * SER_CHUNKS);
         off = Buf<u64>(c->pool, nb + 1);
-        CBLX_HIP(hipMemsetAsync(list_n.get(), 0, SER_NCLS * 4, c->stream));
+        CBLX_HIP(hipMemsetAsync(list_n.get(), 0, SER_NCLS * SER_CHUNKS * 4, c->stream));
         hipLaunchKernelGGL((k_serde_tiny<WS, false>), grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
-                           P.SB, P.BYTES, size.get(), (const u64*)nullptr, (u8*)nullptr, lists.get(), list_n.get());
+                           P.SB, P.BYTES, size.get(), (const u64*)nullptr, (u8*)nullptr, lists.get(), list_n.get(), per);
         CBLX_HIP(hipGetLastError());
-        ln = d2h_vec<u32>(c, list_n.get(), SER_NCLS);
-        if (ln[SER_SPLIT]) {
+        ln = d2h_vec<u32>(c, list_n.get(), SER_NCLS * SER_CHUNKS);
+        if (LN(SER_SPLIT)) {
             // long Tries, cut at the root: sub-ranges by top byte ("virtual buckets"), sized here by the workgroup kernels
-            nsplit = ln[SER_SPLIT];
+            nsplit = LN(SER_SPLIT);
             const u64 nv = (u64)nsplit * 256;
             vstart = Buf<u64>(c->pool, nv);
             voff = Buf<u64>(c->pool, nv);
@@ -242,22 +244,22 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
             vlist_n = Buf<u32>(c->pool, 3);
             split_bad = Buf<u32>(c->pool, nsplit);
             CBLX_HIP(hipMemsetAsync(vlist_n.get(), 0, 12, c->stream));
-            hipLaunchKernelGGL((k_serde_split_plan<WS>), dim3(nsplit), dim3(256), 0, c->stream, lists.get() + (size_t)SER_SPLIT * nb, list_n.get() + SER_SPLIT, r.start.get(),
+            hipLaunchKernelGGL((k_serde_split_plan<WS>), dim3(nsplit), dim3(256), 0, c->stream, lists.get() + (size_t)SER_SPLIT * nb, list_n.get() + SER_SPLIT * SER_CHUNKS, r.start.get(),
                                r.cnt.get(), a_lo, a_hi, P.SB, P.BYTES, nb, vstart.get(), vcnt.get(), vsize.get(), vlists.get(), nv, vlist_n.get(), split_bad.get(),
-                               lists.get() + (size_t)SER_HOST * nb, list_n.get() + SER_HOST);
+                               lists.get() + (size_t)SER_HOST * nb, list_n.get() + SER_HOST * SER_CHUNKS);
             CBLX_HIP(hipGetLastError());
-            ln = d2h_vec<u32>(c, list_n.get(), SER_NCLS);  // the plan may have handed buckets to the host emitter
+            ln = d2h_vec<u32>(c, list_n.get(), SER_NCLS * SER_CHUNKS);  // the plan may have handed buckets to the host emitter
             vln = d2h_vec<u32>(c, vlist_n.get(), 3);
             sub_buckets(std::false_type(), nullptr);
-            hipLaunchKernelGGL(k_serde_split_size, dim3(nsplit), dim3(256), 0, c->stream, lists.get() + (size_t)SER_SPLIT * nb, list_n.get() + SER_SPLIT, r.prefix.get(), r.cnt.get(),
+            hipLaunchKernelGGL(k_serde_split_size, dim3(nsplit), dim3(256), 0, c->stream, lists.get() + (size_t)SER_SPLIT * nb, list_n.get() + SER_SPLIT * SER_CHUNKS, r.prefix.get(), r.cnt.get(),
                                vcnt.get(), vsize.get(), split_bad.get(), size.get());
             CBLX_HIP(hipGetLastError());
         }
-        if (ln[SER_HOST]) {
+        if (LN(SER_HOST)) {
             // Buckets longer than one workgroup's emitter takes (low-complexity k-mers, tiny PREFIX_BITS): their entries
             // are emitted by host threads from a download of just those buckets and patched into the device-emitted
             // body at their offsets; every other bucket stays on the device path.
-            host_r = d2h_vec<u32>(c, lists.get() + (size_t)SER_HOST * nb, ln[SER_HOST]);
+            host_r = d2h_vec<u32>(c, lists.get() + (size_t)SER_HOST * nb, LN(SER_HOST));
             const size_t nh = host_r.size();
             host_bytes.assign(nh, std::vector<u8>());
             std::vector<HostIndex> hb(nh);
@@ -339,13 +341,13 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
     if (nb) {
         u8* body = blob.bytes.get() + hs.pos;
         hipLaunchKernelGGL((k_serde_tiny<WS, true>), grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, r.prefix.get(), r.start.get(), r.cnt.get(), r.kind.get(), a_lo, a_hi,
-                           P.SB, P.BYTES, size.get(), off.get(), body, (u32*)nullptr, (u32*)nullptr);
+                           P.SB, P.BYTES, size.get(), off.get(), body, (u32*)nullptr, (u32*)nullptr, per);
         // (CBLX_SERDE_CHUNK_MIN: test hook — small indexes through the chunked hand-over)
         static const u64 chunk_min = [] { const char* e = std::getenv("CBLX_SERDE_CHUNK_MIN"); const unsigned long long v = e ? std::strtoull(e, nullptr, 10) : 0; return v ? (u64)v : (u64)(256u << 20); }();
-        const bool chunked = (bool)on_chunk && nb >= 4 * SER_EMIT_CHUNKS && blob.n >= chunk_min;
+        const bool chunked = (bool)on_chunk && nb >= 4 * SER_CHUNKS && blob.n >= chunk_min;
         if (!chunked) buckets(std::true_type(), body);
         if (nsplit) {  // split Tries: header / root / length by one kernel, then every sub-trie at its absolute offset (voff is relative to the blob)
-            hipLaunchKernelGGL(k_serde_split_emit, dim3(nsplit), dim3(256), 0, c->stream, lists.get() + (size_t)SER_SPLIT * nb, list_n.get() + SER_SPLIT, r.prefix.get(), r.cnt.get(),
+            hipLaunchKernelGGL(k_serde_split_emit, dim3(nsplit), dim3(256), 0, c->stream, lists.get() + (size_t)SER_SPLIT * nb, list_n.get() + SER_SPLIT * SER_CHUNKS, r.prefix.get(), r.cnt.get(),
                                vcnt.get(), vsize.get(), split_bad.get(), off.get(), voff.get(), body);
             CBLX_HIP(hipGetLastError());
             sub_buckets(std::true_type(), body);
@@ -360,25 +362,37 @@ template <typename C> bool serialize_device(cblx_ctx* c, bool emit, DevBlob& blo
         if (chunked) {
             // the workgroup entries in chunks of consecutive buckets (everything else of the body is in place by now): chunk k's
             // bytes [cut[k], cut[k + 1]) are final when its launches are, and are handed over while chunk k + 1 is being emitted
-            const u32 NCH = SER_EMIT_CHUNKS;
+            const u32 NCH = SER_CHUNKS;
             std::vector<u64> cut(NCH + 1, 0);
-            std::vector<u32> rcut(NCH + 1, 0);
-            for (u32 k = 1; k < NCH; ++k) { rcut[k] = (u32)(nb * k / NCH); cut[k] = hs.pos + d2h<u64>(c, off.get() + rcut[k]); }
-            rcut[NCH] = (u32)nb;
+            for (u32 k = 1; k < NCH; ++k) cut[k] = (u64)k * per < nb ? hs.pos + d2h<u64>(c, off.get() + (u64)k * per) : blob.n;
             cut[NCH] = blob.n;
+            // groups of chunks by bytes: 1/16 of the blob first (the download starts early), the rest in three parts (the low
+            // prefixes hold the long buckets: chunks of equal bucket counts are far from equal bytes)
+            std::vector<u32> grp(1, 0);
+            {
+                const double share[4] = {1.0 / 16, 6.0 / 16, 11.0 / 16, 1.0};
+                for (int g = 0; g < 4; ++g) {
+                    u32 k = grp.back();
+                    while (k < NCH && (double)cut[k + 1] <= share[g] * (double)blob.n) ++k;
+                    if (g == 3) k = NCH;
+                    if (k == grp.back() && k < NCH) ++k;  // at least one chunk per group
+                    if (k > grp.back()) grp.push_back(k);
+                }
+            }
+            const u32 NG = (u32)grp.size() - 1;
             struct Events {
                 std::vector<hipEvent_t> e;
                 ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
             } ev;
-            ev.e.assign(NCH, nullptr);
-            for (u32 k = 0; k < NCH; ++k) {
-                buckets(std::true_type(), body, rcut[k], rcut[k + 1]);
-                CBLX_HIP(hipEventCreateWithFlags(&ev.e[k], hipEventDisableTiming));
-                CBLX_HIP(hipEventRecord(ev.e[k], c->stream));
+            ev.e.assign(NG, nullptr);
+            for (u32 g = 0; g < NG; ++g) {
+                buckets(std::true_type(), body, grp[g], grp[g + 1]);
+                CBLX_HIP(hipEventCreateWithFlags(&ev.e[g], hipEventDisableTiming));
+                CBLX_HIP(hipEventRecord(ev.e[g], c->stream));
             }
-            for (u32 k = 0; k < NCH; ++k) {
-                CBLX_HIP(hipEventSynchronize(ev.e[k]));
-                if (cut[k + 1] > cut[k]) on_chunk(cut[k], cut[k + 1]);
+            for (u32 g = 0; g < NG; ++g) {
+                CBLX_HIP(hipEventSynchronize(ev.e[g]));
+                if (cut[grp[g + 1]] > cut[grp[g]]) on_chunk(cut[grp[g]], cut[grp[g + 1]]);
             }
             handed = true;
         }

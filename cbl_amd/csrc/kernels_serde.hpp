@@ -54,6 +54,12 @@ template <bool WS> __device__ __forceinline__ u32 top_diff_byte(const Sfx<WS>& a
 }
 
 enum { SER_C64 = 0, SER_C256 = 1, SER_C1024 = 2, SER_HOST = 3, SER_SPLIT = 4, SER_NCLS = 5 };
+// The lists of the three workgroup classes are kept per CHUNK of consecutive buckets (bucket r belongs to chunk r / per): the
+// emitter runs group of chunks by group of chunks (groups of about equal bytes, a small one first) so that the download of a
+// group's bytes hides the emission of the next. Sub-list (class, chunk k)
+// starts at lists[class * nb + k * per] (a chunk holds at most `per` buckets), its length is list_n[class * SER_CHUNKS + k]; the
+// host and split classes use chunk 0 only.
+static const u32 SER_CHUNKS = 32;
 // A Trie longer than one workgroup takes (SER_CAP1024) is cut at its ROOT: the children of the root are the distinct top bytes,
 // the sub-trie under each is the trie of the (contiguous, sorted) sub-range that shares the byte, and pre-order puts the
 // sub-tries one after the other behind the root's header — so every sub-range of <= SER_CAP1024 words is emitted by the same
@@ -68,7 +74,7 @@ template <bool WS, bool EMIT>
 __global__ __launch_bounds__(CLASSIFY_THREADS) void k_serde_tiny(u64 nb, const u32* __restrict__ prefix, const u64* __restrict__ start, const u32* __restrict__ cnt,
                              const u8* __restrict__ kind, const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u32 SB, u32 BYTES,
                              u32* __restrict__ size, const u64* __restrict__ off, u8* __restrict__ out, u32* __restrict__ lists,
-                             u32* __restrict__ list_n) {
+                             u32* __restrict__ list_n, u64 per /* buckets per chunk */) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < nb;
     const u32 n = live ? cnt[r] : 0;
@@ -97,8 +103,9 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_serde_tiny(u64 nb, const u
         int cls = -1;
         if (live && !tiny)
             cls = n <= SER_CAP64 ? SER_C64 : n <= SER_CAP256 ? SER_C256 : n <= SER_CAP1024 ? SER_C1024 : (kind[r] == KIND_TRIE && n <= SER_SPLIT_MAX && BYTES > 1) ? SER_SPLIT : SER_HOST;
-        const u32 slot = block_append<CLASSIFY_THREADS, SER_NCLS>(cls, list_n);
-        if (cls >= 0) lists[(u64)cls * nb + slot] = (u32)r;
+        const u32 ch = (cls == SER_C64 || cls == SER_C256 || cls == SER_C1024) ? (u32)(r / per) : 0u;
+        const u32 slot = block_append<CLASSIFY_THREADS, SER_NCLS * SER_CHUNKS>(cls >= 0 ? cls * (int)SER_CHUNKS + (int)ch : -1, list_n);
+        if (cls >= 0) lists[(u64)cls * nb + (u64)ch * per + slot] = (u32)r;
     }
 }
 
@@ -109,8 +116,7 @@ template <int THREADS, int ITEMS, bool WS, bool EMIT, bool SUB = false>
 __global__ __launch_bounds__(THREADS) void k_serde_bucket(const u32* __restrict__ list, const u32* __restrict__ list_n, const u32* __restrict__ prefix,
                                                           const u64* __restrict__ start, const u32* __restrict__ cnt, const u8* __restrict__ kind,
                                                           const u64* __restrict__ a_lo, const u64* __restrict__ a_hi, u32 SB, u32 BYTES,
-                                                          u32* __restrict__ size, const u64* __restrict__ off, u8* __restrict__ out, u32 r_lo = 0u,
-                                                          u32 r_hi = 0xFFFFFFFFu /* only the listed ids in [r_lo, r_hi): the emitter runs in chunks of buckets */) {
+                                                          u32* __restrict__ size, const u64* __restrict__ off, u8* __restrict__ out) {
     constexpr int NW = THREADS / 64, EPW = 64 * ITEMS, CAP = THREADS * ITEMS;
     constexpr u32 D0 = SUB ? 1u : 0u;            // first level this workgroup emits
     // EMIT: the entry is assembled in LDS and leaves in aligned 16-byte stores (the bytes of an entry are written one by one, a
@@ -124,7 +130,6 @@ __global__ __launch_bounds__(THREADS) void k_serde_bucket(const u32* __restrict_
     __shared__ __attribute__((aligned(16))) u8 s_stage[EMIT ? STAGE + 16 : 16];
     if (blockIdx.x >= *list_n) return;
     const u32 r = list[blockIdx.x];
-    if (r < r_lo || r >= r_hi) return;
     const u32 n = cnt[r], pfx = SUB ? 0u : prefix[r];
     const u64 s0 = start[r];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
