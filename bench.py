@@ -619,14 +619,17 @@ def main():
         del pb_, po_
         best, w = min(ts[1:]), min(wire)
         packed = os.environ.get("CBLX_H2D_PACK", "") != "0" and (os.cpu_count() or 1) >= 16
+        plane_bytes = 4  # per 16 bases: a dword of code planes; the synthetic reads hold no invalid base, so no validity word is sent
         res_ms = dt / args.steps * 1e3
         h2d = {"value": round(kmers_per_rank / best, 1), "unit": "k-mers/s", "ms_per_step": round(best * 1e3, 3),
                "ms_per_step_pageable": round(min(tp) * 1e3, 3),
                "kernels_ms_resident": round(res_ms, 3), "exposed_transfer_ms": round(best * 1e3 - res_ms, 3),
-               "wire_ms": round((-(-hb.numel() // 16) * 6 + ho.numel() * 8 if packed else hb.numel() + ho.numel() * 8) / ((hb.numel() + ho.numel() * 8) / w) * 1e3, 3),
+               "wire_ms": round((-(-hb.numel() // 16) * plane_bytes + ho.numel() * 8 if packed else hb.numel() + ho.numel() * 8) / ((hb.numel() + ho.numel() * 8) / w) * 1e3, 3),
                "ascii_copy_ms": round(w * 1e3, 3), "ascii_copy_gbps": round((hb.numel() + ho.numel() * 8) / w / 1e9, 2),
-               "bytes_on_the_wire": int(-(-hb.numel() // 16) * 6 + ho.numel() * 8) if packed else int(hb.numel() + ho.numel() * 8),
-               "mode": ("bit planes: host threads pack 3 bits per base, units are copied as they are packed, the sliced insert runs right behind them"
+               "bytes_on_the_wire": int(-(-hb.numel() // 16) * plane_bytes + ho.numel() * 8) if packed else int(hb.numel() + ho.numel() * 8),
+               "mode": ("bit planes: host threads pack 2 code bits + 1 validity bit per base; the validity plane of a transfer unit without invalid bases "
+                        "(all of them here) is filled in on the device instead of sent; units (1, 3, 4, 4, 3, 1 sixteenths) are copied as they are packed, "
+                        "the sliced insert runs right behind them"
                         if packed else "ASCII bytes in slices that land front to back, KRN-1 + the first pass of a slice under the wire"),
                "source": "pinned host memory (torch pin_memory) -> cblx_insert_seqs + cblx_flush, best of 2 after 1 warm-up; ascii_copy_ms = one plain copy of the "
                          "same pinned ASCII bytes (what the wire alone would cost if the bases crossed it as they are); wire_ms = bytes_on_the_wire at that rate; "

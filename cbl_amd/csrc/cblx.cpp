@@ -188,16 +188,17 @@ int cblx_insert_seqs(cblx_ctx* c, const uint8_t* bases, const uint64_t* offsets,
     return guard(c, [&] {
         if (n == 0) return;
         if (!bases || !offsets) throw Error(CBLX_EINVAL, "null argument");
-        auto validate = [&] {
-            // branch-free scan (on several threads when there are millions of offsets); the offender is looked up only on failure
+        // branch-free scan of sequences [i0, i1) (on several threads when there are millions of them): monotone? shortest length
+        auto scan = [&](u64 i0, u64 i1, u32 max_threads, bool& mono_out, u64& minlen_out) {
             const unsigned hc = std::thread::hardware_concurrency();
-            const u64 T = n >= (1u << 20) ? std::max(1u, std::min(16u, hc / 2)) : 1;
+            const u64 cnt = i1 - i0;
+            const u64 T = cnt >= (1u << 20) ? std::max(1u, std::min(max_threads, hc / 2)) : 1;
             std::vector<u8> mono(T, 1);
             std::vector<u64> minlen(T, ~0ull);
             auto part = [&](u64 t) {
                 bool m = true;
                 u64 ml = ~0ull;
-                for (u64 i = n * t / T, e = n * (t + 1) / T; i < e; ++i) {
+                for (u64 i = i0 + cnt * t / T, e = i0 + cnt * (t + 1) / T; i < e; ++i) {
                     m &= offsets[i + 1] >= offsets[i];
                     ml = std::min(ml, offsets[i + 1] - offsets[i]);
                 }
@@ -208,12 +209,27 @@ int cblx_insert_seqs(cblx_ctx* c, const uint8_t* bases, const uint64_t* offsets,
             for (u64 t = 1; t < T; ++t) th.emplace_back(part, t);
             part(0);
             for (auto& x : th) x.join();
-            for (u64 t = 0; t < T; ++t) if (!mono[t]) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
-            const u64 ml = *std::min_element(minlen.begin(), minlen.end());
+            mono_out = true;
+            for (u64 t = 0; t < T; ++t) mono_out = mono_out && mono[t];
+            minlen_out = *std::min_element(minlen.begin(), minlen.end());
+        };
+        auto validate = [&] {  // the whole batch; the offender is looked up only on failure
+            bool mono;
+            u64 ml;
+            scan(0, n, 16u, mono, ml);
+            if (!mono) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
             if (ml < c->P.K) throw Error(CBLX_ESHORT, "Sequence size (" + std::to_string(ml) + ") is smaller than K (" + std::to_string(c->P.K) + ")");
         };
+        // a slice of a streamed batch, checked while the slices in front of it run on the device: anything wrong sends the whole
+        // batch through `validate`, which then fails the way a check in front of everything would have
+        auto check_slice = [&](u64 i0, u64 i1) {
+            bool mono;
+            u64 ml;
+            scan(i0, i1, 4u, mono, ml);
+            if (!mono || ml < c->P.K) { validate(); throw Error(CBLX_EINVAL, "offsets must be non-decreasing"); }
+        };
         // a big batch into an empty queue crosses PCIe as bit planes and is inserted right behind the transfer (comm.hpp)
-        if (ingest_seqs_planes(c, bases, offsets, n, validate)) return;
+        if (ingest_seqs_planes(c, bases, offsets, n, check_slice)) return;
         ingest_seqs(c, bases, offsets, n, validate);
     });
 }

@@ -619,23 +619,44 @@ void insert_device_streamed(cblx_ctx* c, const u8* d_bases, const u64* d_offsets
 // finished unit to the device on two streams, and THIS thread runs the sliced insert right behind them: slice s = the sequences
 // that end inside the units landed so far. The index is built when the call returns (the caller's buffers are borrowed for the call
 // only). Pageable or pinned source alike. Returns false when the batch does not qualify (the caller takes the other paths).
-template <typename V> bool ingest_seqs_planes(cblx_ctx* c, const u8* bases, const u64* offsets, u64 n, V&& validate) {
+// check_slice(i0, i1): throws unless sequences [i0, i1) of the batch are well-formed (offsets non-decreasing, every length >= K)
+template <typename V> bool ingest_seqs_planes(cblx_ctx* c, const u8* bases, const u64* offsets, u64 n, V&& check_slice) {
     Ingest& g = c->ing;
+    const bool trace = std::getenv("CBLX_TRACE_H2D") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     const u64 o0 = offsets[0], len = offsets[n] >= o0 ? offsets[n] - o0 : 0;
     const char* pk = std::getenv("CBLX_H2D_PACK");  // 0 off, 1 on, default: by core count (read per call: tests switch it)
     const int mode = pk ? std::atoi(pk) : -1;
     const unsigned hc = std::thread::hardware_concurrency();
     if (mode == 0 || (mode < 0 && hc < 16)) return false;
     if (g.nseq || g.nbytes || g.query || g.staged || c->P.PB < 9 || len < (64u << 20) || n < 1024 || len >= ingest_flush_bytes()) return false;
-    validate();  // (a scan of the offsets: nothing has been touched yet)
-    // transfer units = slices of the insert. Few: the planes are on the device within a dozen milliseconds, so the kernels are the
-    // bound from the first unit on, and every slice costs fixed work (chunk plan, column scans, piece). Measured at cfg 2:
-    // 4 / 6 / 8 / 12 / 16 / 32 units 38.8 / 37.6 / 37.8 / 39.2 / 40.5 / 46.5 ms
+    // transfer units = slices of the insert. Few: every slice costs fixed work (chunk plan, column scans, piece: ~0.5 ms). Measured at
+    // cfg 2 with equal units: 4 / 6 / 8 / 12 / 16 / 32 units 38.8 / 37.6 / 37.8 / 39.2 / 40.5 / 46.5 ms. The kernel time line of that
+    // (tools/dev_h2d_timeline.py): the wire is the bound while the units arrive (0.64 GB = 11.7 ms; KRN-1 + pass A of all of them
+    // take 10.2), in front of it the packing of the first unit, behind it the kernels of the last — so the six default units
+    // are 1, 3, 4, 4, 3, 1 sixteenths of the batch: a short first one (the wire starts early) and a short last one.
     const char* eu = std::getenv("CBLX_H2D_UNITS");
     const u32 NU = eu && std::atoi(eu) > 0 ? (u32)std::min(std::atoi(eu), 64) : 6u;
-    const u64 U = ((len + NU - 1) / NU + 1023) & ~(u64)1023;             // bases per unit (a multiple of 16)
+    std::vector<u64> ub(1, 0);  // unit k = bases [ub[k], ub[k + 1]), multiples of 1024
+    {
+        std::vector<u32> w;  // relative sizes (CBLX_H2D_TAPER="1,3,4,4,3,1" overrides; CBLX_H2D_UNITS = that many equal units)
+        if (const char* et = std::getenv("CBLX_H2D_TAPER")) {
+            for (const char* p = et; *p;) { char* q; const unsigned long v = std::strtoul(p, &q, 10); if (q == p) break; if (v) w.push_back((u32)v); p = *q ? q + 1 : q; }
+        }
+        if (w.empty()) { if (eu) w.assign(NU, 1u); else w = {1, 3, 4, 4, 3, 1}; }
+        u64 tot = 0, acc = 0;
+        for (u32 v : w) tot += v;
+        for (size_t k = 0; k < w.size(); ++k) {
+            acc += w[k];
+            const u64 b = k + 1 == w.size() ? len : std::min<u64>(len, ((u64)((double)len * (double)acc / (double)tot) + 1023) & ~(u64)1023);
+            if (b > ub.back()) ub.push_back(b);
+        }
+        if (ub.back() < len) ub.push_back(len);
+    }
+    const u32 nu = (u32)ub.size() - 1;
+    auto unit_at = [&](u64 base) -> u32 { return (u32)(std::upper_bound(ub.begin(), ub.end(), base) - ub.begin()) - 1u; };
     const u64 ng = (len + 15) / 16;                                      // groups of 16 bases
-    const u32 nu = (u32)((len + U - 1) / U);
     // device planes, offsets, pinned staging (kept between calls)
     if (g.d_codes.n < ng + 8) g.d_codes = Buf<u32>(c->pool, ng + 8);
     if (g.d_valid.n < ng + 8) g.d_valid = Buf<u16>(c->pool, ng + 8);
@@ -652,7 +673,10 @@ template <typename V> bool ingest_seqs_planes(cblx_ctx* c, const u8* bases, cons
     hipStream_t cs[2] = {x.lane_stream(0), x.lane_stream(1)};
     // offsets (relative to the batch's first base): straight from the caller's array when pinned and zero-based, else transformed
     hipEvent_t off_ev = nullptr;
-    if (o0 == 0 && Xfer::is_pinned(offsets) && Xfer::is_pinned(offsets + n)) x.h2d_pinned_lane0(g.d_off.get() + 1, offsets + 1, n * 8, off_ev);
+    // pinned and zero-based: the offsets of a slice travel in front of its unit (all of them up front are 80 MB at cfg 2 — 1.4 ms of
+    // wire before the first base); only the last one, which sizes the arena, goes ahead
+    const bool off_by_slice = o0 == 0 && Xfer::is_pinned(offsets) && Xfer::is_pinned(offsets + n);
+    if (off_by_slice) x.h2d_pinned_lane0(g.d_off.get() + n, offsets + n, 8, off_ev);
     else {
         x.h2d(g.d_off.get() + 1, n * 8, [&](u8* dst, size_t off, size_t nb) {
             u64* d = (u64*)dst;
@@ -665,7 +689,7 @@ template <typename V> bool ingest_seqs_planes(cblx_ctx* c, const u8* bases, cons
     std::vector<u64> cuts(1, 0);
     std::vector<u32> unit_of;  // the last unit a slice needs
     for (u32 k = 0; k < nu; ++k) {
-        const u64 lim = k + 1 == nu ? len : (u64)(k + 1) * U;
+        const u64 lim = ub[k + 1];
         const u64 i = k + 1 == nu ? n : (u64)(std::upper_bound(offsets + 1, offsets + n + 1, o0 + lim) - (offsets + 1));
         if (i > cuts.back()) { cuts.push_back(i); unit_of.push_back(k); }
     }
@@ -674,11 +698,12 @@ template <typename V> bool ingest_seqs_planes(cblx_ctx* c, const u8* bases, cons
     const u64 nsb = (len + SB - 1) / SB;
     std::vector<std::atomic<u32>> left(nu);
     for (u32 k = 0; k < nu; ++k) {
-        const u64 a = (u64)k * U, b = std::min<u64>(len, a + U);
+        const u64 a = ub[k], b = ub[k + 1];
         left[k].store((u32)((b + SB - 1) / SB - a / SB) , std::memory_order_relaxed);
     }
-    static_assert(true, "");
-    // (U is a multiple of SB only by accident: a sub-block may straddle two units — it then counts for both)
+    // (a unit boundary is a multiple of SB only by accident: a sub-block may straddle units — it then counts for each of them)
+    std::vector<std::atomic<u8>> dirty(nu);  // a base outside ACGTacgt in the unit: only then its validity plane is sent
+    for (u32 k = 0; k < nu; ++k) dirty[k].store(0, std::memory_order_relaxed);
     std::atomic<u64> next_sb{0};
     std::atomic<u32> issued{0};
     std::atomic<bool> failed{false};
@@ -689,9 +714,11 @@ template <typename V> bool ingest_seqs_planes(cblx_ctx* c, const u8* bases, cons
     auto pack_worker = [&] {
         for (u64 sb; (sb = next_sb.fetch_add(1)) < nsb;) {
             const u64 a = sb * SB, b = std::min<u64>(len, a + SB);
-            pack_planes(bases + o0 + a, b - a, h_codes + a / 16, h_valid + a / 16);
-            for (u64 k = a / U; k <= (b - 1) / U; ++k)
+            const bool clean = pack_planes(bases + o0 + a, b - a, h_codes + a / 16, h_valid + a / 16);
+            for (u32 k = unit_at(a), k1 = unit_at(b - 1); k <= k1; ++k) {
+                if (!clean) dirty[k].store(1, std::memory_order_relaxed);
                 if (left[k].fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> l(mu); cv.notify_all(); }
+            }
         }
     };
     auto issuer = [&] {
@@ -699,9 +726,20 @@ template <typename V> bool ingest_seqs_planes(cblx_ctx* c, const u8* bases, cons
             CBLX_HIP(hipSetDevice(c->device));
             for (u32 k = 0; k < nu; ++k) {
                 { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return left[k].load(std::memory_order_acquire) == 0; }); }
-                const u64 g0 = (u64)k * U / 16, g1 = std::min<u64>(ng, (u64)(k + 1) * U / 16);
+                const u64 g0 = ub[k] / 16, g1 = k + 1 == nu ? ng : ub[k + 1] / 16;
+                if (off_by_slice)
+                    for (size_t sl = 0; sl < unit_of.size(); ++sl)
+                        if (unit_of[sl] == k && cuts[sl + 1] > cuts[sl])
+                            CBLX_HIP(hipMemcpyAsync(g.d_off.get() + 1 + cuts[sl], offsets + 1 + cuts[sl], (cuts[sl + 1] - cuts[sl]) * 8, hipMemcpyHostToDevice, cs[k & 1]));
                 CBLX_HIP(hipMemcpyAsync(g.d_codes.get() + g0, h_codes + g0, (g1 - g0) * 4, hipMemcpyHostToDevice, cs[k & 1]));
-                CBLX_HIP(hipMemcpyAsync(g.d_valid.get() + g0, h_valid + g0, (g1 - g0) * 2, hipMemcpyHostToDevice, cs[k & 1]));
+                if (dirty[k].load(std::memory_order_relaxed)) {
+                    CBLX_HIP(hipMemcpyAsync(g.d_valid.get() + g0, h_valid + g0, (g1 - g0) * 2, hipMemcpyHostToDevice, cs[k & 1]));
+                } else {
+                    // every base of the unit is valid: its validity plane is all ones and is filled in on the device (a third of
+                    // the unit's bytes stays off the link); the batch's last, partly filled word comes from the host
+                    CBLX_HIP(hipMemsetAsync(g.d_valid.get() + g0, 0xFF, (g1 - g0) * 2, cs[k & 1]));
+                    if (k + 1 == nu && (len & 15)) CBLX_HIP(hipMemcpyAsync(g.d_valid.get() + ng - 1, h_valid + ng - 1, 2, hipMemcpyHostToDevice, cs[k & 1]));
+                }
                 hipEvent_t e;
                 CBLX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 CBLX_HIP(hipEventRecord(e, cs[k & 1]));
@@ -726,12 +764,13 @@ template <typename V> bool ingest_seqs_planes(cblx_ctx* c, const u8* bases, cons
             if (off_ev) (void)hipEventDestroy(off_ev);
         }
     } join{th, ev, off_ev, x};
-    const bool trace = std::getenv("CBLX_TRACE_H2D") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    if (trace) fprintf(stderr, "[cblx h2d planes] threads started %.2f ms\n", ms());
     const BaseView view{nullptr, g.d_codes.get(), g.d_valid.get()};
     insert_device_sliced(c, view, g.d_off.get(), n, cuts, [&](u32 s) {
         if (s == ~0u) { if (off_ev) CBLX_HIP(hipStreamWaitEvent(c->stream, off_ev, 0)); return; }
+        // The slice's offsets are checked before a kernel reads them (the resident index is not touched before the last slice is
+        // in: a failure here leaves it as it was), while its unit is on its way and the slices in front of it run.
+        check_slice(cuts[s], cuts[s + 1]);
         const u32 k = unit_of[s];
         const double a = trace ? ms() : 0;
         { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return issued.load(std::memory_order_acquire) > k; }); }

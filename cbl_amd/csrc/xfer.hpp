@@ -37,7 +37,7 @@ namespace cblx {
 // 16-bit validity word (bit i = base i is one of ACGTacgt). 3 bits cross PCIe per base instead of 8; bits past n stay clear.
 #if CBLX_HAVE_SSE2
 // 32 bases per step where the host has AVX2 (checked once at run time: the library is built on another machine than it runs on)
-__attribute__((target("avx2"))) inline size_t pack_planes_avx2(const u8* src, size_t ng /* groups of 16 */, u32* codes, u16* valid) {
+__attribute__((target("avx2"))) inline size_t pack_planes_avx2(const u8* src, size_t ng /* groups of 16 */, u32* codes, u16* valid, u32& all /* AND of the validity masks */) {
     const __m256i up = _mm256_set1_epi8((char)0xDF), cA = _mm256_set1_epi8('A'), cC = _mm256_set1_epi8('C'), cG = _mm256_set1_epi8('G'), cT = _mm256_set1_epi8('T');
     size_t g = 0;
     for (; g + 2 <= ng; g += 2) {
@@ -51,16 +51,21 @@ __attribute__((target("avx2"))) inline size_t pack_planes_avx2(const u8* src, si
         codes[g + 1] = (p0 >> 16) | (p1 & 0xFFFF0000u);
         valid[g] = (u16)vm;
         valid[g + 1] = (u16)(vm >> 16);
+        all &= vm;
     }
     return g;
 }
 #endif
-inline void pack_planes(const u8* src, size_t n, u32* codes, u16* valid) {
+// Returns true when every one of the n bases is valid (the validity plane of such a stretch need not cross the link at all).
+inline bool pack_planes(const u8* src, size_t n, u32* codes, u16* valid) {
     size_t g = 0;
     const size_t ng = n / 16;
+    u32 all = 0xFFFFFFFFu;
 #if CBLX_HAVE_SSE2
     static const bool avx2 = __builtin_cpu_supports("avx2");
-    if (avx2) g = pack_planes_avx2(src, ng, codes, valid);
+    if (avx2) g = pack_planes_avx2(src, ng, codes, valid, all);
+    all &= all >> 16;  // (both halves of the 32-base masks)
+    all |= 0xFFFF0000u;
     const __m128i up = _mm_set1_epi8((char)0xDF), cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
     for (; g < ng; ++g) {
         const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + 16 * g));
@@ -68,8 +73,10 @@ inline void pack_planes(const u8* src, size_t n, u32* codes, u16* valid) {
         const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(u, cA), _mm_cmpeq_epi8(u, cC)), _mm_or_si128(_mm_cmpeq_epi8(u, cG), _mm_cmpeq_epi8(u, cT)));
         const u32 p0 = (u32)_mm_movemask_epi8(_mm_slli_epi16(v, 6));  // ASCII bit 1 of every byte -> its bit 7
         const u32 p1 = (u32)_mm_movemask_epi8(_mm_slli_epi16(v, 5));  // ASCII bit 2
+        const u32 vm = (u32)_mm_movemask_epi8(ok);
         codes[g] = p0 | (p1 << 16);
-        valid[g] = (u16)_mm_movemask_epi8(ok);
+        valid[g] = (u16)vm;
+        all &= vm | 0xFFFF0000u;
     }
 #endif
     for (; g * 16 < n; ++g) {
@@ -81,7 +88,10 @@ inline void pack_planes(const u8* src, size_t n, u32* codes, u16* valid) {
         }
         codes[g] = c;
         valid[g] = (u16)ok;
+        const size_t cnt = std::min<size_t>(16, n - g * 16);
+        if (ok != (cnt == 16 ? 0xFFFFu : (1u << cnt) - 1u)) all = 0;
     }
+    return (all & 0xFFFFu) == 0xFFFFu;
 }
 
 class Xfer {

@@ -18,7 +18,10 @@ int main() {
         const size_t off = rnd() % 4000, n = 1 + rnd() % 5000;
         std::vector<u32> codes((n + 15) / 16 + 2, 0xDEADBEEFu);
         std::vector<u16> valid((n + 15) / 16 + 2, 0xBEEF);
-        pack_planes(src.data() + off, n, codes.data(), valid.data());
+        const bool clean = pack_planes(src.data() + off, n, codes.data(), valid.data());
+        bool want_clean = true;
+        for (size_t i = 0; i < n; ++i) { const u8 uc = src[off + i] & 0xDF; want_clean = want_clean && (uc == 'A' || uc == 'C' || uc == 'G' || uc == 'T'); }
+        if (clean != want_clean) ++bad;  // the return value: every base valid
         for (size_t i = 0; i < ((n + 15) / 16) * 16; ++i) {
             const u32 w = codes[i >> 4] >> (i & 15);
             const u32 got = (w & 1u) | ((w >> 15) & 2u);
@@ -29,6 +32,17 @@ int main() {
             if (gok != ok || (ok && got != ((c >> 1) & 3u))) ++bad;
         }
         if (codes[(n + 15) / 16] != 0xDEADBEEFu || valid[(n + 15) / 16] != 0xBEEF) ++bad;  // nothing written past the last group
+    }
+    // the return value on clean text with at most one dirty byte somewhere (also in the last, partly filled group)
+    for (int rep = 0; rep < 400; ++rep) {
+        const size_t n = 1 + rnd() % 3000;
+        std::vector<u8> t(n + 64);
+        for (auto& b : t) b = (u8)"ACGTacgt"[rnd() & 7];
+        const bool inject = rep % 2 == 1;
+        if (inject) t[rep % 8 == 1 ? n - 1 : rnd() % n] = (u8)"N-x\n"[rnd() & 3];
+        std::vector<u32> codes((n + 15) / 16 + 1);
+        std::vector<u16> valid((n + 15) / 16 + 1);
+        if (pack_planes(t.data(), n, codes.data(), valid.data()) != !inject) ++bad;
     }
     printf("bad=%ld\n", bad);
     return bad ? 1 : 0;

@@ -356,6 +356,41 @@ def test_incremental_flushes_equal_one_shot():
         assert inc.serialize() == one.serialize() == o.serialize()
 
 
+@pytest.mark.parametrize("pack", ["1", "0"])
+def test_streamed_insert_rejects_bad_offsets_and_leaves_the_index_alone(pack, monkeypatch):
+    """A big host batch is inserted slice by slice behind its transfer, and the offsets of a slice are checked just before a kernel
+    reads them (the first slices are already through KRN-1 by then). A sequence shorter than K in a late slice, or offsets that
+    decrease in the middle, fail as a check in front of everything would (same code, same message: /root/reference/src/cbl.rs:329-334
+    for the short sequence) and leave the resident index exactly as it was."""
+    _need_gpu()
+    monkeypatch.setenv("CBLX_H2D_PACK", pack)
+    k, pb, n, L = 31, 24, 470_000, 150  # 70.5 MB of bases: the streamed paths take batches of 64 MiB and more
+    bases, offsets = synth.reads(7, n, L)
+    g = cbl_amd.CBL(k, pb)
+    g.insert_seqs(bases[: 2000 * L], offsets[:2001])
+    g.flush()
+    before = g.serialize()
+    short = offsets.copy()
+    short[400_001:] -= np.uint64(130)  # sequence 400 000 has 20 bases now
+    with pytest.raises(cbl_amd.CblxError) as e:
+        g.insert_seqs(bases, short)
+        g.flush()
+    assert e.value.code == cbl_amd.ESHORT and "Sequence size (20) is smaller than K (31)" in str(e.value)
+    assert g.serialize() == before
+    down = offsets.copy()
+    down[200_000] = down[200_001] + np.uint64(5)
+    with pytest.raises(cbl_amd.CblxError) as e:
+        g.insert_seqs(bases, down)
+        g.flush()
+    assert e.value.code == cbl_amd.EINVAL and "non-decreasing" in str(e.value)
+    assert g.serialize() == before
+    g.insert_seqs(bases, offsets)  # and the context still works
+    g.flush()
+    o = Oracle(k, pb)
+    o.insert_seqs(bases[: 2000 * L], offsets[:2001])
+    o.insert_seqs(bases, offsets)
+    assert g.serialize() == o.serialize()
+
 @pytest.mark.parametrize("k,pb,canonical,nreads,L,dirty", [(31, 24, False, 600_000, 150, False), (59, 28, True, 300_000, 250, True), (25, 12, False, 700_000, 120, True),
                                                           (31, 8, False, 500_000, 150, False), (27, 20, True, 600_000, 130, "mixed")])
 def test_streamed_insert_from_pinned_host_memory_equals_one_shot(k, pb, canonical, nreads, L, dirty, monkeypatch):
