@@ -139,6 +139,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-serialize", action="store_true", help="skip the serialize leg (index bytes into a host buffer)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (value_h2d_inclusive)")
     ap.add_argument("--no-fasta", action="store_true", help="skip the file-inclusive measurement (fasta_inclusive: the same reads as a FASTA file on tmpfs)")
+    ap.add_argument("--no-per-record", action="store_true", help="skip the per-record measurement (per_record: one cblx_insert_seq call per read from a C++ host program)")
     ap.add_argument("--force-sharded", action="store_true", help="dev: run the N-GPU code path on a 1-rank RCCL group")
     ap.add_argument("--shared-gpu", action="store_true", help="dry run: all ranks on GPU 0, exchange staged through gloo")
     args = ap.parse_args(argv)
@@ -235,6 +236,32 @@ def launch_ranks(args) -> int:
     sys.stdout.write(out.decode())
     sys.stdout.flush()
     return rc
+
+
+def per_record_leg(NR, K, PB, L):
+    """The reference's own call pattern (/root/reference/examples/cbl.rs:160-163: one insert_seq per record), from a plain C++ host
+    program built here against include/cblx.h — Python's per-call cost would be what is measured otherwise. Own process, own context."""
+    import subprocess
+    import tempfile
+
+    root = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(root, "tools", "dev_insert_seq_rate.cpp")
+    if (K, PB, L) != (31, 24, 150):
+        return {"value": None, "error": "the probe is written for cfg 2 (K=31, PREFIX_BITS=24, 150 bp)"}
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            exe = os.path.join(d, "per_record")
+            lib = os.path.join(root, "cbl_amd")
+            subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "include"), "-o", exe, src, "-L", lib, "-lcblx", "-Wl,-rpath," + lib],
+                           check=True, capture_output=True, timeout=120)
+            r = subprocess.run([exe, str(NR), "json"], check=True, capture_output=True, text=True, timeout=300)
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        out["unit"] = "k-mers/s"
+        out["source"] = ("tools/dev_insert_seq_rate.cpp: the step's read shape (iid ACGT, own generator), one cblx_insert_seq call per read from pageable host memory "
+                         "+ cblx_flush, best of 2 after 1 warm-up; ms_calls = the call loop (the queue's pinned blocks are DMA'd while it runs), ms_flush = what is left")
+        return out
+    except Exception as e:
+        return {"value": None, "error": f"{type(e).__name__}: {e}"}
 
 
 def fasta_leg(cbl, h_bases, NR, L, kmers):
@@ -637,6 +664,9 @@ def main():
         # the same reads as a single-line FASTA file (tmpfs) -> cblx_insert_fastx_file + flush: never `value`
         if not args.no_fasta:
             extra["fasta_inclusive"] = fasta_leg(cbl, nb_, NR, L, kmers_per_rank)
+        # the reference's call granularity — one insert_seq per record: never `value`
+        if not args.no_per_record and not args.genome:
+            extra["per_record"] = per_record_leg(NR, K, PB, L)
         del hb, ho
 
     cpu = cpu_early

@@ -356,6 +356,34 @@ def test_incremental_flushes_equal_one_shot():
         assert inc.serialize() == one.serialize() == o.serialize()
 
 
+def test_per_record_inserts_across_queue_blocks():
+    """The reference's call pattern: one insert_seq per record (/root/reference/examples/cbl.rs:160-163). cblx_insert_seq has a
+    short path for the common call (two copies into the current pinned blocks of the queue) and the full path for everything else:
+    70 000 records of ragged lengths cross several 4 MiB base blocks and the 64 Ki-record offsets block; a too short record in the
+    middle is refused (/root/reference/src/cbl.rs:329-334) and leaves the queue as it was; a batch call and a flush in between."""
+    _need_gpu()
+    k, pb = 31, 24
+    rng = np.random.default_rng(11)
+    lens = rng.integers(k, 240, size=70_000)
+    offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    bases = rng.choice(np.frombuffer(b"ACGTacgtN", dtype=np.uint8), size=int(offs[-1]), p=[0.24, 0.24, 0.24, 0.24, 0.01, 0.01, 0.01, 0.005, 0.005])
+    raw = bases.tobytes()
+    g, o = cbl_amd.CBL(k, pb), Oracle(k, pb)
+    for i in range(len(lens)):
+        a, b = int(offs[i]), int(offs[i + 1])
+        g.insert_seq(raw[a:b])
+        if i == 40_000:
+            with pytest.raises(cbl_amd.CblxError) as e:
+                g.insert_seq(b"ACGTACGT")
+            assert e.value.code == cbl_amd.ESHORT
+        if i == 50_000:
+            g.insert_seqs(bases[: int(offs[300])], offs[:301])  # a batch call in between (records 0..299 again)
+        if i == 66_000:
+            g.flush()
+    o.insert_seqs(bases, offs)
+    assert g.serialize() == o.serialize()
+
 @pytest.mark.parametrize("pack", ["1", "0"])
 def test_streamed_insert_rejects_bad_offsets_and_leaves_the_index_alone(pack, monkeypatch):
     """A big host batch is inserted slice by slice behind its transfer, and the offsets of a slice are checked just before a kernel
