@@ -24,4 +24,10 @@ pn = pin.numpy()
 for _ in range(2):
     t0 = time.perf_counter(); g.serialize_np(out=pn); t1 = time.perf_counter()
     print("pinned buffer: %.1f ms (%.1f GB/s)" % ((t1 - t0) * 1e3, n / (t1 - t0) / 1e9))
+for _ in range(2):
+    path = "/dev/shm/cblx_dev_save.cbl"
+    t0 = time.perf_counter(); g.save_to_file(path); t1 = time.perf_counter()
+    print("save_to_file (tmpfs): %.1f ms (%.1f GB/s)" % ((t1 - t0) * 1e3, n / (t1 - t0) / 1e9))
+    assert os.path.getsize(path) == n
+    os.remove(path)
 assert bytes(pn[:64]) == bytes(blob[:64]) and int(pn[:n:4097].astype(np.uint64).sum()) == int(blob[:n:4097].astype(np.uint64).sum())
