@@ -1,0 +1,23 @@
+#!/bin/bash
+# gpurun_out/<tag>/ (tools/final_round.sh on the GPU box) -> the committed profiles/<round>_* files. Usage: tools/refresh_profiles.sh <tag> <round>
+T=$1; R=${2:-r03}
+python tools/write_profiles.py $T $R | tail -1
+python tools/write_sq_profile.py ${T}_sq $R 1200000000 | tail -1
+python tools/write_sharded_profile.py $T $R > /dev/null
+for c in cfg3 cfg4 merge dup; do tail -1 gpurun_out/$T/bench_$c.json > profiles/${R}_bench_$c.json; done
+tail -1 gpurun_out/$T/bench_line.json > profiles/${R}_bench_cfg2.json
+python - "$T" "$R" <<'PY'
+import json, sys
+T, R = sys.argv[1], sys.argv[2]
+m = {'cfg 2 weak scaling: 8 x 10 M x 150 bp, K=31, PB=24': 'emul_reads10000000.json', 'cfg 5 operand: 8 x 6.25 M x 150 bp, K=31, PB=24': 'emul_cfg5.json',
+     'cfg 3: 8 x 12.5 M x 150 bp, K=31, PB=28': 'emul_reads12500000prefixbits2.json', 'cfg 4: 8 x 6.25 M x 250 bp, K=59, PB=28': 'emul_k59prefixbits28reads6250.json'}
+out = {}
+for k, f in m.items():
+    out[k] = json.loads(open(f'gpurun_out/{T}/' + f).read().strip().splitlines()[-1])
+    b = out[k]['build']
+    print(k[:6], round(b['receiver_ms'], 1), {a: round(x, 1) for a, x in b['receiver_stage_ms'].items() if a.startswith('bucket')}, (out[k].get('merge') or {}).get('ms'))
+json.dump(out, open(f'profiles/{R}_emulated_rank.json', 'w'))
+d = json.loads(open(f'profiles/{R}_bench_cfg2.json').read())
+print('cfg2', d['ms_per_step'], d['value'], 'h2d', d['h2d_inclusive']['ms_per_step'], 'fasta', d['fasta_inclusive']['ms_per_step'], 'per record', d['per_record']['ms_total'],
+      'serialize', d['serialize']['to_host_ms'], 'frac', d['roofline']['frac'])
+PY
