@@ -833,6 +833,9 @@ bool fastx_parallel_planes(cblx_ctx* c, const char* path, u64* nrec_out) {
         u32* h_codes = (u32*)g.pin;
         u16* h_valid = (u16*)(g.pin + (size_t)(ng + 8) * 4);
         u64* h_ends = (u64*)(g.pin + (((size_t)(ng + 8) * 6 + 63) & ~(size_t)63));
+        // the last offset (= the window's bases, known from the count) goes ahead of everything: the sliced insert sizes its arena
+        // from it before the first slice (the offsets themselves travel with their slices)
+        CBLX_HIP(hipMemcpy(g.d_off.get() + nrec, &nbases, 8, hipMemcpyHostToDevice));
         std::vector<u64> base(nr + 1, 0), rec0(nr + 1, 0);
         for (size_t i = 0; i < nr; ++i) { base[i + 1] = base[i] + regs[w0 + i].nbases; rec0[i + 1] = rec0[i] + regs[w0 + i].nrec; }
         fx_planes_prezero(base, ng + 8, h_codes, h_valid);
