@@ -9,7 +9,7 @@ g = cbl_amd.CBL(K, PB, device=0)
 g.insert_seqs_device(d_b, d_o, NR)
 blob = g.serialize_np()
 g.close()
-for th in (16, 24, 32, 48, 64):
+for th in (16, 24, 32):
     os.environ["CBLX_LOAD_THREADS"] = str(th)
     ts = []
     for rep in range(2):
