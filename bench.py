@@ -582,7 +582,21 @@ def main():
                               "gbps_to_host_again": round(nbytes / max(t4 - t3, 1e-9) / 1e9, 2),
                               "note": "rank 0's share: device emitter (kernels_serde.hpp; chunks of buckets are downloaded while the next chunk is emitted) + pinned "
                                       "download lanes into a pageable host buffer; to_host_ms writes a FRESH buffer (first touch of every page), to_host_again_ms the "
-                                      "same buffer once more; not part of `value`"}
+                                      "same buffer once more; load_ms = cblx_load of those bytes into a fresh context, the FIRST load of the process (host threads parse, the suffixes go up as they are decoded; pinned blocks and device arrays are allocated on the way: a second load takes 0.8-1.3 s); not part of `value`"}
+        # the same bytes back into a fresh context (`cbl insert` / `merge` / `query` start with this)
+        try:
+            import cbl_amd as _ca
+
+            h = _ca.CBL(K, PB, canonical=bool(args.canonical), device=local_rank)
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            h.load(blob)
+            n_loaded = h.count()
+            t6 = time.perf_counter()
+            h.close()
+            extra["serialize"].update({"load_ms": round((t6 - t5) * 1e3, 3), "gbps_load": round(nbytes / max(t6 - t5, 1e-9) / 1e9, 2), "loaded_kmers": int(n_loaded)})
+        except Exception as e:
+            extra["serialize"]["load_error"] = f"{type(e).__name__}: {e}"
         del blob
 
     exchange = None
