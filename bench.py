@@ -582,7 +582,7 @@ def main():
                               "gbps_to_host_again": round(nbytes / max(t4 - t3, 1e-9) / 1e9, 2),
                               "note": "rank 0's share: device emitter (kernels_serde.hpp; chunks of buckets are downloaded while the next chunk is emitted) + pinned "
                                       "download lanes into a pageable host buffer; to_host_ms writes a FRESH buffer (first touch of every page), to_host_again_ms the "
-                                      "same buffer once more; load_ms = cblx_load of those bytes into a fresh context, the FIRST load of the process (host threads parse, the suffixes go up as they are decoded; pinned blocks and device arrays are allocated on the way: a second load takes 0.8-1.3 s); not part of `value`"}
+                                      "same buffer once more; load_ms = cblx_load of those bytes into a fresh context, the first load of the process (host threads parse, the suffixes go up as they are decoded, the arena is allocated by a helper thread meanwhile); not part of `value`"}
         # the same bytes back into a fresh context (`cbl insert` / `merge` / `query` start with this)
         try:
             import cbl_amd as _ca

@@ -776,6 +776,21 @@ template <bool WS> bool load_parallel(cblx_ctx* c, const Consts& P, const u8* bo
         part[t].lo.reset(new StreamUp(c, guess));
         if (WS) part[t].hi.reset(new StreamUp(c, guess));
     }
+    // The arena the parts are concatenated into, allocated by a helper thread WHILE the regions are parsed: a fresh multi-GB
+    // hipMalloc costs 0.25 - 0.8 s in a process that has not held that memory before (tools/dev_alloc_cost.cpp) — every CLI command
+    // is such a process. Sized by a Vec's 7 bytes per word (a Trie takes more per word; a dense one less: then the exact size is
+    // allocated afterwards, as before).
+    Buf<u64> pre_lo, pre_hi;
+    std::thread pre_alloc([&] {
+        try {
+            CBLX_HIP(hipSetDevice(c->device));
+            std::lock_guard<std::mutex> lk(StreamUp::pool_mu());
+            pre_lo = Buf<u64>(c->pool, len / 7 + len / 64 + 4096);
+            if (WS) pre_hi = Buf<u64>(c->pool, len / 7 + len / 64 + 4096);
+        } catch (...) {
+        }
+    });
+    struct JoinPre { std::thread& t; ~JoinPre() { if (t.joinable()) t.join(); } } join_pre{pre_alloc};
     {
         std::vector<std::thread> th;
         for (unsigned t = 0; t < T; ++t)
@@ -819,8 +834,14 @@ template <bool WS> bool load_parallel(cblx_ctx* c, const Consts& P, const u8* bo
     std::vector<u32> prefix, cnt;
     std::vector<u8> kind;
     prefix.reserve(entries); cnt.reserve(entries); kind.reserve(entries);
-    Buf<u64> a_lo(c->pool, total + 2), a_hi;
-    if (WS) a_hi = Buf<u64>(c->pool, total + 2);
+    if (pre_alloc.joinable()) pre_alloc.join();
+    Buf<u64> a_lo, a_hi;
+    if (pre_lo.n >= total + 2 && (!WS || pre_hi.n >= total + 2)) { a_lo = std::move(pre_lo); a_hi = std::move(pre_hi); }
+    else {
+        pre_lo.reset(); pre_hi.reset();
+        a_lo = Buf<u64>(c->pool, total + 2);
+        if (WS) a_hi = Buf<u64>(c->pool, total + 2);
+    }
     u64 at = 0;
     for (unsigned t = 0; t < T; ++t) {
         Part& pt = part[t];
