@@ -134,6 +134,8 @@ def parse_args(argv=None):
                     help="N > 1: exchange driven from Python over torch.distributed, or the whole sharded insert inside libcblx on RCCL directly")
     ap.add_argument("--cpu-sample-reads", type=int, default=None,
                     help="reads of the CPU leg (default: about 20-30 s of CPU work: 1 M at PREFIX_BITS <= 24, 125 k at 28, 60 k at K = 59)")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0,
+                    help="launcher mode (--gpus N without WORLD_SIZE): seconds after which the rank processes are stopped and the run fails")
     ap.add_argument("--cpu-full", action="store_true", help="time the CPU oracle on the whole workload (cfg 2: about 4 minutes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serialize", action="store_true", help="skip the serialize leg (index bytes into a host buffer)")
@@ -183,7 +185,7 @@ def build_in_child():
             fcntl.flock(lk, fcntl.LOCK_UN)
 
 
-def cpu_baseline_leg(args, genome_reads=None):
+def cpu_baseline_leg(args, genome_reads=None, keep=None):
     """The CPU oracle (C++ port of the reference algorithm, oracle/) on a bounded sample of the same reads, 1 thread: one
     insert_seq call per read. Needs no GPU and no process group: at N > 1 rank 0 runs it BEFORE the group is formed (the other
     ranks wait in the rendezvous), so every line of a scaling run carries it."""
@@ -208,11 +210,43 @@ def cpu_baseline_leg(args, genome_reads=None):
         secs += s1
         done += m
         curve.append(round(m * (L - K + 1) / s1 / 1e6, 2))
+    if keep is not None and ns == NR:  # --cpu-full: the finished oracle index is what the GPU's bytes are compared with (parity_full_size)
+        keep.append(orc)
     return {"value": round(ns * (L - K + 1) / secs, 1), "unit": "k-mers/s", "cores": 1, "kind": "port",
             "sample": (f"all {ns} reads" if ns == NR else f"first {ns} of rank 0's reads") + f" (seed 42), one insert_seq call per read, {secs:.1f} s"
                       + ("" if ns == NR else "; throughput falls as the index grows, so the full-size CPU figure is lower (profiles/ holds a full run)"),
             "mkmers_per_s_by_1M_read_block": curve if len(curve) > 1 else None,
             "host_cores_available": os.cpu_count()}
+
+
+def parity_full_size(cbl, orc, kmers):
+    """Index bytes of the GPU build against the oracle's, whole workload. Both sides are hashed in 256 MiB chunks."""
+    import hashlib
+
+    import numpy as np
+
+    t0 = time.perf_counter()
+    g = cbl.serialize_np()
+    t1 = time.perf_counter()
+    o = orc.serialize_np()
+    t2 = time.perf_counter()
+    hg, ho = hashlib.sha256(), hashlib.sha256()
+    first_diff = None
+    step = 256 << 20
+    for a in range(0, max(g.size, o.size), step):
+        cg, co = g[a:a + step], o[a:a + step]
+        hg.update(memoryview(cg))
+        ho.update(memoryview(co))
+        if first_diff is None and not (cg.size == co.size and np.array_equal(cg, co)):
+            m = min(cg.size, co.size)
+            d = np.flatnonzero(cg[:m] != co[:m])
+            first_diff = int(a + (d[0] if d.size else m))
+    equal = first_diff is None and g.size == o.size
+    return {"equal": bool(equal), "bytes": int(g.size), "bytes_oracle": int(o.size), "sha256": hg.hexdigest(), "sha256_oracle": ho.hexdigest(),
+            "first_difference_at": first_diff, "kmers_inserted": int(kmers), "distinct_kmers": int(cbl.count()), "distinct_kmers_oracle": int(orc.count()),
+            "gpu_serialize_s": round(t1 - t0, 2), "oracle_serialize_s": round(t2 - t1, 2), "compare_s": round(time.perf_counter() - t2, 2),
+            "what": "cblx_serialize of the timed build's index (all of the workload's reads) vs the CPU oracle's serialize after one insert_seq per read: "
+                    "same length, same SHA-256, no differing byte"}
 
 
 # ---- launcher: `python bench.py --gpus N` without torchrun -------------------------------------------------------------
@@ -229,11 +263,47 @@ def launch_ranks(args) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", CBLX_BENCH_CHILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, abs(p.wait()))
-    sys.stdout.write(out.decode())
+    return supervise_ranks(procs, args.launch_timeout)
+
+
+def supervise_ranks(procs, deadline_s: float) -> int:
+    """Wait for the rank processes (fresh children of a launcher that never touched a GPU). Rank 0's stdout is drained by a thread
+    so that it can never block on a full pipe; the children are POLLED: when one exits non-zero, or the deadline passes, the others
+    — which would otherwise wait for it in a collective for ever — are terminated (SIGTERM, then SIGKILL after 10 s) and the result
+    is non-zero. Returns 0 only if every rank returned 0."""
+    import threading
+
+    chunks = []
+    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    t_end = time.monotonic() + deadline_s
+    rc, why = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc, why = max(abs(c) for _, c in bad) or 1, f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > t_end:
+            rc, why = 124, f"no result after {deadline_s:.0f} s"
+            break
+        time.sleep(0.05)
+    if why is not None:
+        print(f"bench.py launcher: {why}; stopping the other ranks", file=sys.stderr)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(t_kill - time.monotonic(), 0.1))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    rd.join(timeout=5)
+    sys.stdout.write(b"".join(chunks).decode(errors="replace"))
     sys.stdout.flush()
     return rc
 
@@ -330,8 +400,9 @@ def main():
 
     # the CPU leg first: no GPU, no process group (rank 0 only; at N > 1 the other ranks wait for it in the rendezvous)
     cpu_early = None
+    oracle_full = []  # --cpu-full: the oracle's finished index of ALL of rank 0's reads, the checker of parity_full_size
     if rank == 0 and not args.no_cpu_baseline and args.kind == "build" and not args.genome:
-        cpu_early = cpu_baseline_leg(args)
+        cpu_early = cpu_baseline_leg(args, keep=oracle_full)
 
     import torch
 
@@ -543,6 +614,12 @@ def main():
                 "b_alg_per_output_word": 3 * by,
                 "achieved": round(count / max(world, 1) * args.steps / dt * 3 * by / 1e9, 1),
                 "frac": round(count / max(world, 1) * args.steps / dt * 3 * by / 1e9 / HBM_PEAK_GBPS, 4)}
+
+    # BASELINE.md §3's gate at FULL size (`--cpu-full`, one GPU): the bytes `cbl build` would write (/root/reference/examples/cbl.rs:147-167,
+    # 132-142) from the timed build's index against the CPU oracle's bytes for the same reads — length, SHA-256 of both, and a
+    # chunk-by-chunk comparison. The oracle is the checker here, never the thing measured.
+    if args.kind == "build" and oracle_full and world == 1 and engine is None:
+        extra["parity_full_size"] = parity_full_size(cbl, oracle_full.pop(), kmers_per_rank)
 
     # what the N-GPU code path costs a rank over the direct build of the same reads (no exchange, no slices): the direct steps
     # run AFTER the timed region, each rank on its own reads

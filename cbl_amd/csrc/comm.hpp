@@ -865,8 +865,8 @@ bool fastx_parallel_planes(cblx_ctx* c, const char* path, u64* nrec_out) {
         auto worker = [&] {
             for (size_t i; (i = next.fetch_add(1)) < nr;) {
                 const FastxRegion& r = regs[w0 + i];
-                PlaneSink sink(h_codes, h_valid, base[i], h_ends + rec0[i], r.nrec);
-                if (!fx_walk(d, r, fmt, K, sink) || sink.pos != base[i + 1] || sink.nrec != r.nrec) failed = true;
+                PlaneSink sink(h_codes, h_valid, base[i], h_ends + rec0[i], r.nrec, base[i + 1]);
+                if (!fx_walk(d, r, fmt, K, sink) || sink.overflow || sink.pos != base[i + 1] || sink.nrec != r.nrec) failed = true;
                 sink.finish();
                 if (left[slice_of[i]].fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> l(mu); cv.notify_all(); }
             }
@@ -876,12 +876,21 @@ bool fastx_parallel_planes(cblx_ctx* c, const char* path, u64* nrec_out) {
                 CBLX_HIP(hipSetDevice(c->device));
                 for (u32 k = 0; k < ns; ++k) {
                     { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return left[k].load(std::memory_order_acquire) == 0; }); }
-                    // the slice's groups (its last, possibly shared word included: the next slice copies it again, complete) and record ends
-                    const u64 g0 = base[sl[k]] >> 4, g1 = std::min<u64>(ng, (base[sl[k + 1]] + 15) >> 4);
+                    // the slice's groups, its last, possibly shared word included. A slice that STARTS inside a group shares that
+                    // word with its predecessor, whose copy of it (taken before this slice's bits were all there) runs on the other
+                    // stream: two DMA writes of one word with nothing between them — whichever lands last stays. So the word this
+                    // slice shares with its predecessor is copied separately, BEHIND the predecessor's event; the bulk does not wait.
+                    const bool shared_front = k > 0 && (base[sl[k]] & 15) != 0;
+                    const u64 g0 = base[sl[k]] >> 4, g1 = std::min<u64>(ng, (base[sl[k + 1]] + 15) >> 4), gb = std::min(g1, g0 + (shared_front ? 1 : 0));
                     hipStream_t st = cs[k & 1];
-                    if (g1 > g0) {
-                        CBLX_HIP(hipMemcpyAsync(g.d_codes.get() + g0, h_codes + g0, (g1 - g0) * 4, hipMemcpyHostToDevice, st));
-                        CBLX_HIP(hipMemcpyAsync(g.d_valid.get() + g0, h_valid + g0, (g1 - g0) * 2, hipMemcpyHostToDevice, st));
+                    if (g1 > gb) {
+                        CBLX_HIP(hipMemcpyAsync(g.d_codes.get() + gb, h_codes + gb, (g1 - gb) * 4, hipMemcpyHostToDevice, st));
+                        CBLX_HIP(hipMemcpyAsync(g.d_valid.get() + gb, h_valid + gb, (g1 - gb) * 2, hipMemcpyHostToDevice, st));
+                    }
+                    if (gb > g0) {
+                        CBLX_HIP(hipStreamWaitEvent(st, ev[k - 1], 0));
+                        CBLX_HIP(hipMemcpyAsync(g.d_codes.get() + g0, h_codes + g0, 4, hipMemcpyHostToDevice, st));
+                        CBLX_HIP(hipMemcpyAsync(g.d_valid.get() + g0, h_valid + g0, 2, hipMemcpyHostToDevice, st));
                     }
                     if (cuts[k + 1] > cuts[k]) CBLX_HIP(hipMemcpyAsync(g.d_off.get() + 1 + cuts[k], h_ends + cuts[k], (cuts[k + 1] - cuts[k]) * 8, hipMemcpyHostToDevice, st));
                     hipEvent_t e;

@@ -47,7 +47,7 @@ struct Pool {
             if (best >= 0) { blks[best].used = true; return blks[best].p; }
         }
         void* p = nullptr;
-        if (sz > (64ull << 30) && std::getenv("CBLX_TRACE_SHARDED")) { fprintf(stderr, "[cblx pool] suspicious allocation of %zu bytes\n", sz); std::abort(); }
+        if (sz > (64ull << 30) && std::getenv("CBLX_TRACE_SHARDED")) fprintf(stderr, "[cblx pool] allocation of %zu bytes\n", sz);  // trace only: legitimate on a 288 GB part
         hipError_t e = hipMalloc(&p, sz);
         if (e != hipSuccess) {
             (void)hipGetLastError();  // the failed call must not surface at the next hipGetLastError() after a launch

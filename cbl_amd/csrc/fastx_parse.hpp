@@ -187,7 +187,11 @@ struct PlaneSink {
     u64 gcur;                 // group the accumulators' low bits belong to
     bool shared = true;       // the next word to leave is the region's first: shared with the previous region
     u64* ends; u64 nrec = 0, cap;
-    PlaneSink(u32* c, u16* v, u64 first_base, u64* e, u64 ecap) : codes(c), valid(v), pos(first_base), nb((u32)(first_base & 15)), gcur(first_base >> 4), ends(e), cap(ecap) {}
+    u64 end;                  // first base of the NEXT region: nothing is written at or past it (the counting pass fixed the layout;
+                              // a file that changed between the two walks must not run into its neighbours' words or past the staging buffer)
+    bool overflow = false;
+    PlaneSink(u32* c, u16* v, u64 first_base, u64* e, u64 ecap, u64 end_base = ~0ull)
+        : codes(c), valid(v), pos(first_base), nb((u32)(first_base & 15)), gcur(first_base >> 4), ends(e), cap(ecap), end(end_base) {}
     void word_out(bool last) {
         const u32 w = (u32)(a0 & 0xFFFFu) | ((u32)(a1 & 0xFFFFu) << 16);
         const u16 vw = (u16)(av & 0xFFFFu);
@@ -208,6 +212,7 @@ struct PlaneSink {
         if (nb >= 16) { word_out(false); nb -= 16; }
     }
     void seq(const u8* p, size_t n) {
+        if (overflow || n > end - pos) { overflow = true; pos += n; return; }  // counted, never written: the caller sees pos != its region's end
         size_t i = 0;
 #if CBLX_FX_SSE2
         const __m128i up = _mm_set1_epi8((char)0xDF), cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'), cT = _mm_set1_epi8('T');
@@ -239,7 +244,7 @@ struct PlaneSink {
 #endif
         pos += n;
     }
-    void rec_end() { if (nrec < cap) ends[nrec] = pos; ++nrec; }
+    void rec_end() { if (nrec < cap && !overflow) ends[nrec] = pos; ++nrec; }
     void finish() { if (nb) { word_out(true); nb = 0; } }
 };
 

@@ -784,7 +784,8 @@ template <bool WS> bool load_parallel(cblx_ctx* c, const Consts& P, const u8* bo
     std::thread pre_alloc([&] {
         try {
             CBLX_HIP(hipSetDevice(c->device));
-            std::lock_guard<std::mutex> lk(StreamUp::pool_mu());
+            // (no StreamUp::pool_mu here: Pool::alloc locks its own bookkeeping and calls hipMalloc outside that lock, so the parser
+            // threads that grow their buffers meanwhile do not wait 0.25 - 0.8 s behind this allocation)
             pre_lo = Buf<u64>(c->pool, len / 7 + len / 64 + 4096);
             if (WS) pre_hi = Buf<u64>(c->pool, len / 7 + len / 64 + 4096);
         } catch (...) {
@@ -836,7 +837,10 @@ template <bool WS> bool load_parallel(cblx_ctx* c, const Consts& P, const u8* bo
     prefix.reserve(entries); cnt.reserve(entries); kind.reserve(entries);
     if (pre_alloc.joinable()) pre_alloc.join();
     Buf<u64> a_lo, a_hi;
-    if (pre_lo.n >= total + 2 && (!WS || pre_hi.n >= total + 2)) { a_lo = std::move(pre_lo); a_hi = std::move(pre_hi); }
+    // adopted only when it is close to the exact size: a Trie-heavy file (12 bytes per word) would otherwise keep an arena of up to
+    // 1.8x the words resident for the life of the index
+    const u64 fit = total + 2 + (total + 2) / 8;
+    if (pre_lo.n >= total + 2 && pre_lo.n <= fit && (!WS || (pre_hi.n >= total + 2 && pre_hi.n <= fit))) { a_lo = std::move(pre_lo); a_hi = std::move(pre_hi); }
     else {
         pre_lo.reset(); pre_hi.reset();
         a_lo = Buf<u64>(c->pool, total + 2);

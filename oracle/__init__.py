@@ -185,6 +185,18 @@ class Oracle:
         finally:
             self._L.oracle_free(buf)
 
+    def serialize_np(self):
+        """serialize() as a numpy uint8 view of the library's own buffer (no second copy: a full-size index is gigabytes)."""
+        import numpy as np
+        import weakref
+
+        buf = C.POINTER(C.c_uint8)()
+        n = C.c_uint64(0)
+        self._chk(self._L.oracle_serialize(self._h, C.byref(buf), C.byref(n)))
+        arr = np.ctypeslib.as_array(buf, shape=(max(n.value, 1),))[: n.value]
+        weakref.finalize(arr.base if arr.base is not None else arr, self._L.oracle_free, buf)
+        return arr
+
     def load(self, data: bytes):
         self._chk(self._L.oracle_load(self._h, data, len(data)))
 

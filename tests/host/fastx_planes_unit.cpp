@@ -76,8 +76,8 @@ int main() {
         std::atomic<long> fails{0};
         auto worker = [&] {
             for (size_t i; (i = next.fetch_add(1)) < nr;) {
-                PlaneSink sink(codes.data(), valid.data(), base[i], ends.data() + rec0[i], regs[i].nrec);
-                if (!fx_walk(m.d, regs[i], m.fmt, K, sink) || sink.pos != base[i + 1] || sink.nrec != regs[i].nrec) ++fails;
+                PlaneSink sink(codes.data(), valid.data(), base[i], ends.data() + rec0[i], regs[i].nrec, base[i + 1]);
+                if (!fx_walk(m.d, regs[i], m.fmt, K, sink) || sink.overflow || sink.pos != base[i + 1] || sink.nrec != regs[i].nrec) ++fails;
                 sink.finish();
             }
         };
@@ -100,6 +100,26 @@ int main() {
         // an irregular file: a record shorter than K in the middle is found by the counting pass
         m.d = nullptr;  // (not a mapping: nothing to unmap)
         std::free(file);
+    }
+    {   // a file that GREW between the counting pass and the second walk: the sink stops at its region's end, flags it, and touches
+        // neither its neighbour's words nor anything past an exactly sized staging buffer (the sanitizer watches the heap blocks)
+        std::string t = ">a\n" + std::string(70, 'C') + "\n>b\n" + std::string(45, 'G') + "\n";
+        FastxMap m;
+        m.d = (const u8*)t.data(); m.size = t.size(); m.first = 0; m.fmt = '>';
+        std::vector<FastxRegion> regs;
+        fx_make_regions(m, 0, m.size, 1 << 20, regs);
+        const u64 counted = 64;  // what an earlier counting pass saw: fewer bases than the walk now meets
+        u32* codes = (u32*)std::malloc((counted / 16) * 4);
+        u16* valid = (u16*)std::malloc((counted / 16) * 2);
+        u64* ends = (u64*)std::malloc(8);
+        std::memset(codes, 0, (counted / 16) * 4);
+        std::memset(valid, 0, (counted / 16) * 2);
+        PlaneSink sink(codes, valid, 0, ends, 1, counted);
+        const bool ok = fx_walk(m.d, regs[0], m.fmt, K, sink);
+        sink.finish();
+        if (!ok || !sink.overflow || sink.pos == counted) { ++bad; printf("a sink past its region's end was not flagged\n"); }
+        m.d = nullptr;
+        std::free(codes); std::free(valid); std::free(ends);
     }
     {   // record shorter than K: the counting pass says no
         std::string t = ">a\n" + std::string(40, 'C') + "\n>b\nACGT\n>c\n" + std::string(50, 'G') + "\n";

@@ -1,0 +1,54 @@
+"""bench.py run the way the driver runs it — a child process, the launcher's own rank children — on one GPU: `--gpus 2 --shared-gpu`
+is the dry run of the N-rank line (ranks share GPU 0, exchange staged through gloo), `--cpu-full` the full-size parity leg at a size
+the oracle finishes in seconds. First contact of `python bench.py --gpus N` must not be the 8-GPU box."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("config", ["cfg3", "cfg2", "merge"])
+def test_two_rank_line_through_the_launcher(config):
+    out = _run("--gpus", "2", "--shared-gpu", "--config", config, "--reads", "20000", "--steps", "1", "--warmup", "0",
+               "--cpu-sample-reads", "2000", "--launch-timeout", "600")
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["roofline"] and out["roofline"]["bound"] == "hbm" and out["roofline"]["kernels"]
+    assert out["exchange"] and out["exchange"]["world_size"] == 2
+    if config == "merge":
+        assert out["merge"]["words_union"] <= out["merge"]["words_self"] + out["merge"]["words_other"]
+    else:
+        assert out["cpu_baseline"] and out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["value"] > 0
+        k = 31
+        assert out["distinct_kmers_in_index"] <= 2 * 20000 * (150 - k + 1)
+        assert all(s > 0 for s in out["exchange"]["sent_bytes_per_rank_step"])
+
+
+def test_launcher_reports_a_failing_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    # K = 32 is not a supported word layout: every rank fails after the rendezvous; the launcher must come back non-zero, promptly
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu", "--reads", "2000", "--k", "32", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline", "--launch-timeout", "300"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_full_size_parity_leg_at_a_small_size():
+    out = _run("--config", "cfg2", "--reads", "30000", "--steps", "1", "--warmup", "0", "--cpu-full", "--no-h2d")
+    p = out["parity_full_size"]
+    assert p["equal"] is True and p["sha256"] == p["sha256_oracle"] and p["bytes"] == p["bytes_oracle"] > 0
+    assert p["distinct_kmers"] == p["distinct_kmers_oracle"] == out["distinct_kmers_in_index"]
+    assert p["first_difference_at"] is None

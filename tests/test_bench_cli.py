@@ -57,3 +57,36 @@ def test_multi_gpu_defaults_take_the_native_bins_path():
 def test_source_hash_is_stable_and_covers_csrc():
     h = bench.source_hash()
     assert len(h) == 16 and h == bench.source_hash()
+
+
+def _child(code: str, stdout=None):
+    import subprocess
+
+    return subprocess.Popen([sys.executable, "-c", code], stdout=stdout)
+
+
+def test_launcher_stops_the_other_ranks_when_one_fails(capsys):
+    import subprocess
+    import time
+
+    t0 = time.monotonic()
+    procs = [_child("import time,sys; print('partial'); sys.stdout.flush(); time.sleep(120)", stdout=subprocess.PIPE),
+             _child("import sys; sys.exit(3)"), _child("import time; time.sleep(120)")]
+    rc = bench.supervise_ranks(procs, 600.0)
+    assert rc == 3 and time.monotonic() - t0 < 30
+    assert all(p.poll() is not None for p in procs)  # nobody is left waiting in a collective
+    assert "partial" in capsys.readouterr().out  # what rank 0 had printed is still relayed
+
+
+def test_launcher_deadline_and_clean_exit(capsys):
+    import subprocess
+    import time
+
+    t0 = time.monotonic()
+    procs = [_child("import time; time.sleep(120)", stdout=subprocess.PIPE), _child("import time; time.sleep(120)")]
+    assert bench.supervise_ranks(procs, 1.0) == 124 and time.monotonic() - t0 < 30
+    assert all(p.poll() is not None for p in procs)
+    # a big line from rank 0 (more than a pipe buffer) while another rank is still running must not deadlock
+    procs = [_child("import sys; sys.stdout.write('x' * 300000 + '\\n{\"ok\": 1}\\n')", stdout=subprocess.PIPE), _child("import time; time.sleep(1)")]
+    assert bench.supervise_ranks(procs, 60.0) == 0
+    assert capsys.readouterr().out.rstrip().endswith('{"ok": 1}')
