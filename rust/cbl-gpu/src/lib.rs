@@ -4,16 +4,19 @@
 //!
 //! NOT compiled in the image this repository was built in (no Rust toolchain there): shipped as source for the maintainer
 //! who wires the MI355X path into the reference. Differences from the reference type that a caller can see:
-//!   * `T` only selects the integer type k-mers are packed in (`u64` for K <= 32, `u128` above — what `build.rs:34-41`
-//!     picks); the word layout behind the ABI follows from K alone.
+//!   * `T` is the reference's `T` (`build.rs:34-41`: the narrowest integer that holds 2K + POS_BITS bits — `u64` up to K = 29,
+//!     `u128` from K = 31 on) and is checked by the reference's own assert (`src/cbl.rs:87-91`); k-mers are packed in it, the
+//!     word layout behind the ABI follows from K alone.
 //!   * `insert_seq` may only enqueue; every observer (`count`, `contains*`, `save_to_file`, `|=`, `iter`) flushes first, so
 //!     results are those of the reference after the same calls.
 //!   * out of scope, as in SURVEY.md §8f: `remove`, `remove_seq`, `&=`, `-=`, `^=`, `merge` / `intersect` on vectors of sets,
 //!     and the Trie node statistics (`buckets_nodes`, `buckets_node_count`).
 //!
-//! Drop-in use in `examples/cbl.rs`: replace `use cbl::CBL;` by `use cbl_gpu::CBL;` and `write_index(&cbl, path)` /
-//! `read_index(path)` by `cbl.save_to_file(path)` / `CBL::load_from_file(path)` (same bytes: bincode DefaultOptions +
-//! varint, `src/cbl.rs:127-160`). `Build`, `Insert`, `Merge`, `Count`, `Query` then run unchanged.
+//! Drop-in use in `examples/cbl.rs`: replace `use cbl::CBL;` by `use cbl_gpu::CBL;` — nothing else. `write_index(&cbl, path)` /
+//! `read_index(path)` (`examples/cbl.rs:117-142`) go through this type's `Serialize` / `Deserialize`, which speak the reference's
+//! serde data model (`serde_model.rs`), so bincode `DefaultOptions` + varint writes and reads the reference's bytes.
+//! `cbl.save_to_file(path)` / `CBL::load_from_file(path)` (`src/cbl.rs:127-160`) do the same inside the library, on the device
+//! (9.4 GB in 0.2 s instead of a host walk). `Build`, `Insert`, `Merge`, `Count`, `Query` run unchanged.
 use std::collections::BTreeMap;
 use std::ffi::{CStr, CString};
 use std::marker::PhantomData;
@@ -22,6 +25,8 @@ use std::os::raw::c_int;
 use std::path::Path;
 
 use cblx_sys as sys;
+
+mod serde_model;
 
 /// The integer types a k-mer is packed in (`IntKmer::to_int`, `src/kmer.rs:200-202`: 2K bits, first base most significant).
 pub trait PackedInt: Copy {
@@ -97,6 +102,8 @@ pub struct CBL<const K: usize, T: PackedInt, const PREFIX_BITS: usize = 24> {
 impl<const K: usize, T: PackedInt, const PREFIX_BITS: usize> CBL<K, T, PREFIX_BITS> {
     /// Number of bits of a k-mer (`src/cbl.rs:16-18`).
     pub const KMER_BITS: usize = 2 * K;
+    /// Number of bits of a position inside a k-mer (`src/cbl.rs:20-22`: ilog2 of 2K rounded up to a power of two).
+    pub const POS_BITS: usize = (2 * K).next_power_of_two().trailing_zeros() as usize;
 
     fn last_error(&self) -> String {
         unsafe { CStr::from_ptr(sys::cblx_last_error(self.ctx)) }.to_string_lossy().into_owned()
@@ -112,16 +119,12 @@ impl<const K: usize, T: PackedInt, const PREFIX_BITS: usize> CBL<K, T, PREFIX_BI
     }
 
     fn with(canonical: bool) -> Self {
-        // `src/cbl.rs:87-91`: the word (2K bits + position) must fit the integer type
-        let pos_bits = (2 * K).next_power_of_two().trailing_zeros() as usize;
+        // the reference's assert, same condition and text (`src/cbl.rs:87-91`): the word — 2K bits + position — must fit `T`,
+        // so `CBL::<31, u64>` (68 bits) panics here exactly as it does there
         assert!(
-            Self::KMER_BITS <= T::BITS as usize,
-            "Cannot fit a {K}-mer in a {}-bit integer",
+            Self::KMER_BITS + Self::POS_BITS <= T::BITS as usize,
+            "Cannot fit a {K}-mer and its length in a {}-bit integer",
             T::BITS
-        );
-        assert!(
-            Self::KMER_BITS + pos_bits <= 128,
-            "Cannot fit a {K}-mer and its length in a 128-bit integer"
         );
         let p = sys::cblx_params {
             k: K as u32,
@@ -188,12 +191,17 @@ impl<const K: usize, T: PackedInt, const PREFIX_BITS: usize> CBL<K, T, PREFIX_BI
 
     /// Inverse of `to_bytes` (`Deserialize`, `src/wordset/mod.rs:398-437`).
     pub fn from_bytes(data: &[u8]) -> Self {
+        Self::try_from_bytes(data).unwrap_or_else(|e| panic!("{}", e))
+    }
+
+    /// `from_bytes` that reports malformed bytes instead of panicking (what `Deserialize` needs).
+    pub fn try_from_bytes(data: &[u8]) -> Result<Self, String> {
         let s = Self::new();
         let rc = unsafe { sys::cblx_load(s.ctx, data.as_ptr(), data.len() as u64) };
         if rc != sys::CBLX_OK {
-            panic!("{}", s.last_error());
+            return Err(s.last_error());
         }
-        s
+        Ok(s)
     }
 
     /// Returns `true` if the set stores canonical k-mers (`src/cbl.rs:164-166`).
@@ -373,15 +381,6 @@ impl<const K: usize, T: PackedInt, const PREFIX_BITS: usize> BitOrAssign<&mut Se
     }
 }
 
-#[cfg(feature = "serde-bytes")]
-impl<const K: usize, T: PackedInt, const PREFIX_BITS: usize> serde::Serialize for CBL<K, T, PREFIX_BITS> {
-    /// With bincode `DefaultOptions` + varint this does NOT reproduce the reference's file (a byte string gets a length
-    /// prefix): files are written with `save_to_file` / `to_bytes`. For other serde formats: the index bytes as one blob.
-    fn serialize<S: serde::Serializer>(&self, serializer: S) -> Result<S::Ok, S::Error> {
-        serializer.serialize_bytes(&self.to_bytes())
-    }
-}
-
 impl<const K: usize, T: PackedInt, const PREFIX_BITS: usize> Drop for CBL<K, T, PREFIX_BITS> {
     fn drop(&mut self) {
         unsafe { sys::cblx_destroy(self.ctx) }
@@ -394,7 +393,7 @@ mod tests {
     use super::*;
 
     const K: usize = 31;
-    type T = u64;
+    type T = u128; // 2K + POS_BITS = 68 bits (`build.rs:34-41`)
 
     fn seq(n: usize, seed: u64) -> Vec<u8> {
         let mut x = seed;
@@ -430,6 +429,29 @@ mod tests {
         let z = CBL::<K, T>::from_bytes(&x.to_bytes());
         assert_eq!(z.count(), x.count());
         assert_eq!(z.to_bytes(), x.to_bytes());
+    }
+
+    /// `write_index` / `read_index` of `examples/cbl.rs:117-142` through this type's serde impls: the bytes bincode writes are the
+    /// bytes `save_to_file` writes, and they read back to the same index (needs the dev-dependency `bincode = "1.3"`).
+    #[test]
+    fn serde_model_is_the_file_format() {
+        use bincode::{DefaultOptions, Options};
+        let mut cbl = CBL::<K, T>::new();
+        for seed in 0..40 {
+            cbl.insert_seq(&seq(3_000, seed)); // enough words under one prefix for both kinds of bucket
+        }
+        let opts = || DefaultOptions::new().with_varint_encoding().reject_trailing_bytes();
+        let via_serde = opts().serialize(&cbl).unwrap();
+        assert_eq!(via_serde, cbl.to_bytes());
+        let back: CBL<K, T> = opts().deserialize(&via_serde).unwrap();
+        assert_eq!(back.count(), cbl.count());
+        assert_eq!(back.to_bytes(), via_serde);
+    }
+
+    #[test]
+    #[should_panic(expected = "Cannot fit a 31-mer and its length in a 64-bit integer")]
+    fn word_must_fit_the_integer_type() {
+        let _ = CBL::<31, u64>::new(); // `src/cbl.rs:87-91`
     }
 
     #[test]

@@ -68,6 +68,21 @@ def test_rust_sys_crate_declares_every_symbol():
                  "insert_seq", "iter", "prefix_load", "buckets_sizes", "buckets_size_count", "buckets_load_repartition"):
         assert re.search(r"pub fn %s\b" % meth, facade), meth
     assert "BitOrAssign<&mut Self>" in facade and "impl<const K: usize, T: PackedInt, const PREFIX_BITS: usize> Drop" in facade
+    # the reference's assert, not a weaker one (/root/reference/src/cbl.rs:87-91): CBL::<31, u64> must panic as it does there
+    assert re.search(r"assert!\(\s*Self::KMER_BITS \+ Self::POS_BITS <= T::BITS as usize,\s*\"Cannot fit a \{K\}-mer and its length in a \{\}-bit integer\"", facade)
+    assert "Self::KMER_BITS <= T::BITS" not in facade
+    # Serialize / Deserialize in the reference's serde data model (src/cbl.rs:40-54, src/wordset/mod.rs:382-437, src/trievec/mod.rs:8-15,
+    # src/trie.rs:8-9,53-57, src/sliced_int.rs:110-114, src/bitvector/tiny/mod.rs:97-105): the calls that fix the bytes under bincode
+    model = (ROOT / "rust" / "cbl-gpu" / "src" / "serde_model.rs").read_text()
+    assert "mod serde_model;" in facade and "serialize_bytes(&self.to_bytes())" not in facade
+    for call in ('serialize_struct("CBL", 2)', 'serialize_field("canonical"', 'serialize_field("wordset"', "serialize_map(Some(nb as usize))",
+                 'serialize_newtype_struct("TrieVec"', 'serialize_newtype_variant("TrieOrVec", 0, "Vec"', 'serialize_tuple_variant("TrieOrVec", 1, "Trie", 2)',
+                 'serialize_newtype_struct("Trie"', 'serialize_struct("TrieNode", 2)', 'serialize_field("bv"', 'serialize_field("children"', "serialize_bytes(&self.le[..self.bytes])",
+                 "impl<const K: usize, T: PackedInt, const PREFIX_BITS: usize> Serialize for CBL<K, T, PREFIX_BITS>",
+                 "impl<'de, const K: usize, T: PackedInt, const PREFIX_BITS: usize> de::Deserialize<'de> for CBL<K, T, PREFIX_BITS>",
+                 'deserialize_enum("TrieOrVec", &["Vec", "Trie"]', "try_from_bytes(&file)"):
+        assert call in model, call
+    assert set(re.findall(r"sys::(cblx_[a-z0-9_]+)\(", model)) <= set(rust_fns)
 
 
 def test_no_cpu_fallback_without_gpu():
