@@ -107,6 +107,10 @@ SIGNATURES = {
     "cblx_comm_last_error": (C.c_char_p, [C.c_void_p]),
     "cblx_comm_stats": (C.c_int, [C.c_void_p, C.POINTER(ExchangeStats), C.c_int]),
     "cblx_comm_set_protocol": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "cblx_comm_init_sim": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64, C.c_double]),
+    "cblx_sim_store_free": (C.c_int, [C.c_uint64]),
+    "cblx_comm_set_recv_groups": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "cblx_comm_groups_used": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "cblx_sharded_insert_seqs_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
                                                   C.POINTER(C.c_int)]),
     "cblx_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -287,6 +291,21 @@ class Comm:
             raise CblxError(rc, L.cblx_last_global_error().decode())
         return cls(h, keep=cbs)
 
+    @classmethod
+    def sim(cls, rank: int, world: int, store_id: int, link_gbps: float = 0.0, device: int = -1) -> "Comm":
+        """Rehearsal of one rank of a `world`-GPU job on one GPU (include/cblx.h: cblx_comm_init_sim): ranks 1 .. world-1 record what they
+        would send rank 0, rank 0 replays it paced at `link_gbps` GB/s per source rank."""
+        L = lib()
+        h = C.c_void_p()
+        rc = L.cblx_comm_init_sim(C.byref(h), rank, world, device, store_id, link_gbps)
+        if rc != OK:
+            raise CblxError(rc, L.cblx_last_global_error().decode())
+        return cls(h)
+
+    @staticmethod
+    def sim_store_free(store_id: int):
+        lib().cblx_sim_store_free(store_id)
+
     PROTOCOLS = {"sorted": 0, "bins": 1}  # CBLX_PROTO_SORTED / CBLX_PROTO_BINS (include/cblx.h)
 
     def set_protocol(self, name: str):
@@ -295,6 +314,19 @@ class Comm:
         rc = self._L.cblx_comm_set_protocol(self._h, self.PROTOCOLS[name])
         if rc != OK:
             raise CblxError(rc, "cblx_comm_set_protocol")
+
+    def set_recv_groups(self, groups: int):
+        """Groups per rank of the "bins" receiver (0 = default: CBLX_RECV_GROUPS or 8; 1 = ungrouped): the data crosses the links
+        group-major and the receiver works on group g while g + 1 .. are still on the wire. The same on every rank."""
+        rc = self._L.cblx_comm_set_recv_groups(self._h, groups)
+        if rc != OK:
+            raise CblxError(rc, "cblx_comm_set_recv_groups")
+
+    def groups_used(self) -> int:
+        """Groups the last sharded insert of this rank worked through (0: the ungrouped path)."""
+        g = C.c_uint32(0)
+        self._L.cblx_comm_groups_used(self._h, C.byref(g))
+        return g.value
 
     def stats(self, reset: bool = False) -> dict:
         st = ExchangeStats()

@@ -520,6 +520,26 @@ int cblx_comm_init_transport(cblx_comm** out, const cblx_transport* t, uint32_t 
         *out = cm.release();
     });
 }
+int cblx_comm_init_sim(cblx_comm** out, uint32_t rank, uint32_t world, int32_t device, uint64_t store_id, double link_gbps) {
+    return guard(nullptr, [&] {
+        if (!out) throw Error(CBLX_EINVAL, "null argument");
+        *out = nullptr;
+        if (world < 2 || rank >= world || world > MAX_DEST || link_gbps < 0) throw Error(CBLX_EINVAL, "rehearsal: 2 <= world <= " + std::to_string(MAX_DEST) + ", rank below world");
+        int dev = device;
+        if (dev < 0) CBLX_HIP(hipGetDevice(&dev));
+        CBLX_HIP(hipSetDevice(dev));
+        std::unique_ptr<cblx_comm> cm(new cblx_comm());
+        cm->device = dev;
+        cm->t.reset(new SimTransport(SimStore::get(store_id, world), rank, world, link_gbps));
+        *out = cm.release();
+    });
+}
+int cblx_sim_store_free(uint64_t store_id) {
+    return guard(nullptr, [&] {
+        std::lock_guard<std::mutex> g(SimStore::mu());
+        SimStore::all().erase(store_id);
+    });
+}
 void cblx_comm_destroy(cblx_comm* cm) { delete cm; }
 const char* cblx_comm_last_error(const cblx_comm* cm) { return cm ? cm->err.c_str() : g_global_err.c_str(); }
 int cblx_comm_stats(cblx_comm* cm, cblx_exchange_stats* out, int reset) {
@@ -531,6 +551,18 @@ int cblx_comm_stats(cblx_comm* cm, cblx_exchange_stats* out, int reset) {
 int cblx_comm_set_protocol(cblx_comm* cm, uint32_t protocol) {
     if (!cm || (protocol != CBLX_PROTO_SORTED && protocol != CBLX_PROTO_BINS)) return CBLX_EINVAL;
     cm->protocol = protocol;
+    return CBLX_OK;
+}
+int cblx_comm_set_recv_groups(cblx_comm* cm, uint32_t groups) {
+    if (!cm || groups > 14) return CBLX_EINVAL;
+    cm->recv_groups = groups;
+    cm->g_bounds.clear();  // the cuts are chosen again, for this number of groups
+    cm->g_cuts.clear();
+    return CBLX_OK;
+}
+int cblx_comm_groups_used(const cblx_comm* cm, uint32_t* out) {
+    if (!cm || !out) return CBLX_EINVAL;
+    *out = cm->groups_used;
     return CBLX_OK;
 }
 int cblx_stage_fastx_blocks_comm(cblx_ctx* c, cblx_comm* cm, const char* path, uint64_t* block, uint32_t slices, const uint8_t** d_bases, const uint64_t** d_offsets,
@@ -574,9 +606,12 @@ int cblx_sharded_insert_seqs_device(cblx_ctx* c, cblx_comm* cm, const uint8_t* d
         if (n) check_aligned16(d_bases, "d_bases");
         flush(c);  // keep stream order with anything enqueued earlier
         u32 dummy = 0;
+        SimTransport* sim = dynamic_cast<SimTransport*>(cm->t.get());  // rehearsal: every rank uses the cuts the first one chose
+        if (sim && sim->st->have_cuts) { cm->g_bounds = sim->st->g_bounds; cm->g_cuts = sim->st->g_cuts; }
         try {
             dispatch(c->P, [&](auto cfg) { sharded_insert<decltype(cfg)>(c, cm, d_bases, d_offsets, n, slice_cuts, n_slices, bounds ? bounds : &dummy, bounds_valid); });
         } catch (const Error& e) { cm->err = e.what(); throw; }
+        if (sim && !sim->st->have_cuts) { sim->st->g_bounds = cm->g_bounds; sim->st->g_cuts = cm->g_cuts; sim->st->have_cuts = true; }
         collect_events(c);
     });
 }

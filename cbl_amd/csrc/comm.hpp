@@ -13,6 +13,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <atomic>
+#include <map>
 
 #include "shard.hpp"
 
@@ -30,6 +31,14 @@ struct Transport {
     // Returns once the exchange is ISSUED; wait() returns when everything issued so far has landed.
     virtual void exchange(const u8* d_src, const u64* send_off, u8* d_dst, const u64* recv_off, hipStream_t after) = 0;
     virtual void wait() = 0;
+    // Several personalised exchanges issued as ONE (grouped receiver: a group's share of every slice and of every record array). The
+    // runs of an item lie anywhere in its arrays: bytes [s_off[d], s_off[d] + s_len[d]) of src go to rank d, the bytes from rank r
+    // land at [r_off[r], r_off[r] + r_len[r]) of dst; the own rank's entries are ignored (its records never leave the device).
+    struct Item { const u8* src; u8* dst; std::vector<u64> s_off, s_len, r_off, r_len; };
+    virtual void exchange_items(const std::vector<Item>& items, hipStream_t after) = 0;
+    // `e` fires once everything issued so far has landed (`after`: the stream of a transport that completes on return)
+    virtual void record(hipEvent_t e, hipStream_t after) { CBLX_HIP(hipEventRecord(e, after)); }
+    virtual void begin_job() {}  // a sharded insert starts (the rehearsal transports count their calls from here)
 };
 
 // ---- RCCL, resolved at run time (librccl.so.1; a process that already loaded one — torch's — gets that one) ------------
@@ -154,6 +163,23 @@ struct RcclTransport : Transport {
         recv_bytes += ro[world] - (ro[me + 1] - ro[me]);
     }
     void wait() override { CBLX_HIP(hipStreamSynchronize(cs)); }
+    void exchange_items(const std::vector<Item>& items, hipStream_t after) override {
+        CBLX_HIP(hipEventRecord(ev, after));
+        CBLX_HIP(hipStreamWaitEvent(cs, ev, 0));
+        const u32 me = rank;
+        CBLX_RCCL(rccl().GroupStart());
+        for (u32 d = 1; d < world; ++d) {  // ring order, items in the same order on both ends: the k-th send to a peer meets its k-th receive
+            const u32 to = (me + d) % world, from = (me + world - d) % world;
+            for (const Item& it : items) {
+                for (u64 o = 0; o < it.s_len[to]; o += MAX_MSG) { CBLX_RCCL(rccl().Send(it.src + it.s_off[to] + o, (size_t)std::min<u64>(MAX_MSG, it.s_len[to] - o), RCCL_UINT8, (int)to, comm, cs)); ++messages; }
+                for (u64 o = 0; o < it.r_len[from]; o += MAX_MSG) { CBLX_RCCL(rccl().Recv(it.dst + it.r_off[from] + o, (size_t)std::min<u64>(MAX_MSG, it.r_len[from] - o), RCCL_UINT8, (int)from, comm, cs)); ++messages; }
+            }
+        }
+        CBLX_RCCL(rccl().GroupEnd());
+        for (const Item& it : items)
+            for (u32 r = 0; r < world; ++r) if (r != me) { sent_bytes += it.s_len[r]; recv_bytes += it.r_len[r]; }
+    }
+    void record(hipEvent_t e, hipStream_t) override { CBLX_HIP(hipEventRecord(e, cs)); }
 };
 
 // ---- host callbacks (include/cblx.h: cblx_transport): the embedding program moves the bytes -----------------------------
@@ -171,8 +197,149 @@ struct CallbackTransport : Transport {
         messages += 2 * (world - 1);
     }
     void wait() override {}
+    // the callback moves back-to-back runs: an item's runs are packed into a staging buffer, exchanged, and unpacked (tests only)
+    void exchange_items(const std::vector<Item>& items, hipStream_t after) override {
+        CBLX_HIP(hipStreamSynchronize(after));
+        for (const Item& it : items) {
+            std::vector<u64> so(world + 1, 0), ro(world + 1, 0);
+            for (u32 r = 0; r < world; ++r) { so[r + 1] = so[r] + (r == rank ? 0 : it.s_len[r]); ro[r + 1] = ro[r] + (r == rank ? 0 : it.r_len[r]); }
+            u8 *ts = nullptr, *tr = nullptr;
+            CBLX_HIP(hipMalloc((void**)&ts, so[world] + 16));
+            if (hipMalloc((void**)&tr, ro[world] + 16) != hipSuccess) { (void)hipFree(ts); throw Error(CBLX_ENOMEM, "staging buffer of the callback transport"); }
+            struct Free { u8 *a, *b; ~Free() { (void)hipFree(a); (void)hipFree(b); } } fr{ts, tr};
+            for (u32 r = 0; r < world; ++r) if (r != rank && it.s_len[r]) CBLX_HIP(hipMemcpy(ts + so[r], it.src + it.s_off[r], it.s_len[r], hipMemcpyDeviceToDevice));
+            CBLX_HIP(hipDeviceSynchronize());
+            chk(t.exchange(t.user, ts, so.data(), tr, ro.data()), "exchange");
+            for (u32 r = 0; r < world; ++r) if (r != rank && it.r_len[r]) CBLX_HIP(hipMemcpy(it.dst + it.r_off[r], tr + ro[r], it.r_len[r], hipMemcpyDeviceToDevice));
+            CBLX_HIP(hipDeviceSynchronize());
+            sent_bytes += so[world];
+            recv_bytes += ro[world];
+            messages += 2 * (world - 1);
+        }
+    }
 };
 
+
+// ---- rehearsal of ONE rank of a W-GPU job on one GPU (dev / bench: tools/emulate_wire.py; cblx_comm_init_sim) ----------------------
+// No multi-GPU node was available while this was built, so the schedule of the sharded insert — what the receiver's kernels hide of
+// the wire — is measured on one GPU: ranks 1 .. W-1 run one after the other on a RECORDING transport that keeps what each of them
+// would send to rank 0 (headers and device bytes, per call); then rank 0 runs for real on a REPLAYING transport: its collectives are
+// answered from the records, and the bytes of every exchange are copied into its receive arena on a side stream that a host function
+// holds back until a wire of `link_gbps` per source rank (W-1 links working in parallel, one per peer, as on an xGMI mesh) would
+// have delivered them. The copies read and write what RCCL's sends and receives would read and write (HBM traffic of both
+// directions); what is not emulated: the CUs RCCL's kernels occupy, and link contention. Sums over ranks are answered as W times the
+// own value (the ranks of the rehearsal hold equally many reads); the group cuts travel through the store so that every rank of the
+// rehearsal uses rank 1's.
+struct SimStore {
+    struct Buf8 { u8* p = nullptr; u64 n = 0; };
+    u32 world = 0;
+    std::vector<std::vector<std::vector<u64>>> a2a;             // [rank][call] -> what the rank sends rank 0
+    std::vector<std::vector<std::vector<Buf8>>> xch;            // [rank][call][item] -> bytes for rank 0
+    std::vector<u32> g_bounds, g_cuts;
+    bool have_cuts = false;
+    ~SimStore() { for (auto& r : xch) for (auto& cl : r) for (auto& b : cl) if (b.p) (void)hipFree(b.p); }
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static std::map<u64, std::unique_ptr<SimStore>>& all() { static std::map<u64, std::unique_ptr<SimStore>> m; return m; }
+    static SimStore* get(u64 id, u32 world) {
+        std::lock_guard<std::mutex> g(mu());
+        auto& p = all()[id];
+        if (!p) { p.reset(new SimStore()); p->world = world; p->a2a.resize(world); p->xch.resize(world); }
+        if (p->world != world) throw Error(CBLX_EINVAL, "rehearsal store: created for another world size");
+        return p.get();
+    }
+};
+struct SimTransport : Transport {
+    SimStore* st;
+    double link_gbps;
+    size_t n_a2a = 0, n_x = 0;
+    hipStream_t ps = nullptr;  // replay: the "wire"
+    hipEvent_t ev = nullptr;
+    struct Pace { std::chrono::steady_clock::time_point start, done; bool any = false; } pace;
+    struct Gate { SimTransport* t; double seconds; bool opens; };
+    std::vector<std::unique_ptr<Gate>> gates;
+    SimTransport(SimStore* s, u32 r, u32 w, double gbps) : st(s), link_gbps(gbps) {
+        rank = r; world = w;
+        if (r == 0) {
+            CBLX_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+            CBLX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+    }
+    ~SimTransport() override {
+        if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
+        if (ev) (void)hipEventDestroy(ev);
+    }
+    void begin_job() override {
+        n_a2a = n_x = 0;
+        if (rank) { st->a2a[rank].clear(); for (auto& cl : st->xch[rank]) for (auto& b : cl) if (b.p) (void)hipFree(b.p); st->xch[rank].clear(); }
+        else { if (ps) CBLX_HIP(hipStreamSynchronize(ps)); gates.clear(); pace.any = false; }
+    }
+    void all_reduce_sum_u64(u64* v, size_t n) override { for (size_t i = 0; i < n; ++i) v[i] *= world; }
+    void all_to_all_u64(const u64* send, u64* recv, size_t per) override {
+        std::memset(recv, 0, per * world * 8);
+        std::memcpy(recv + rank * per, send + rank * per, per * 8);
+        if (rank) { st->a2a[rank].push_back(std::vector<u64>(send, send + per)); return; }  // (what goes to rank 0)
+        for (u32 r = 1; r < world; ++r) {
+            if (st->a2a[r].size() <= n_a2a || st->a2a[r][n_a2a].size() != per) throw Error(CBLX_EINVAL, "rehearsal: rank " + std::to_string(r) + " was not recorded with this schedule");
+            std::memcpy(recv + r * per, st->a2a[r][n_a2a].data(), per * 8);
+        }
+        ++n_a2a;
+    }
+    static void gate_fn(void* p) {
+        Gate* g = (Gate*)p;
+        Pace& pc = g->t->pace;
+        const auto now = std::chrono::steady_clock::now();
+        if (g->opens) { pc.start = pc.any && pc.done > now ? pc.done : now; return; }  // the wire takes the call when it is free
+        pc.done = pc.start + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(g->seconds));
+        pc.any = true;
+        std::this_thread::sleep_until(pc.done);
+    }
+    void items_common(const std::vector<Item>& items, hipStream_t after) {
+        if (rank) {  // record what goes to rank 0
+            CBLX_HIP(hipStreamSynchronize(after));
+            std::vector<SimStore::Buf8> call;
+            for (const Item& it : items) {
+                SimStore::Buf8 b;
+                b.n = it.s_len[0];
+                if (b.n) { CBLX_HIP(hipMalloc((void**)&b.p, b.n)); CBLX_HIP(hipMemcpy(b.p, it.src + it.s_off[0], b.n, hipMemcpyDeviceToDevice)); }
+                call.push_back(b);
+                sent_bytes += b.n;
+            }
+            st->xch[rank].push_back(std::move(call));
+            return;
+        }
+        CBLX_HIP(hipEventRecord(ev, after));
+        CBLX_HIP(hipStreamWaitEvent(ps, ev, 0));
+        gates.emplace_back(new Gate{this, 0.0, true});
+        CBLX_HIP(hipLaunchHostFunc(ps, gate_fn, gates.back().get()));
+        u64 worst = 0;
+        for (u32 r = 1; r < world; ++r) {
+            if (st->xch[r].size() <= n_x || st->xch[r][n_x].size() != items.size()) throw Error(CBLX_EINVAL, "rehearsal: rank " + std::to_string(r) + " was not recorded with this schedule");
+            u64 from_r = 0;
+            for (size_t i = 0; i < items.size(); ++i) {
+                const SimStore::Buf8& b = st->xch[r][n_x][i];
+                if (b.n != items[i].r_len[r]) throw Error(CBLX_EDEVICE, "rehearsal: rank " + std::to_string(r) + " recorded " + std::to_string(b.n) + " bytes, rank 0 expects " + std::to_string(items[i].r_len[r]));
+                if (b.n) CBLX_HIP(hipMemcpyAsync(items[i].dst + items[i].r_off[r], b.p, b.n, hipMemcpyDeviceToDevice, ps));
+                from_r += b.n;
+            }
+            recv_bytes += from_r;
+            worst = std::max(worst, from_r);
+        }
+        for (const Item& it : items) for (u32 r = 1; r < world; ++r) sent_bytes += it.s_len[r];
+        messages += 2 * (world - 1) * items.size();
+        gates.emplace_back(new Gate{this, link_gbps > 0 ? (double)worst / (link_gbps * 1e9) : 0.0, false});
+        CBLX_HIP(hipLaunchHostFunc(ps, gate_fn, gates.back().get()));
+        ++n_x;
+    }
+    void exchange_items(const std::vector<Item>& items, hipStream_t after) override { items_common(items, after); }
+    void exchange(const u8* src, const u64* so, u8* dst, const u64* ro, hipStream_t after) override {
+        Item it{src, dst, {}, {}, {}, {}};
+        for (u32 r = 0; r < world; ++r) { it.s_off.push_back(so[r]); it.s_len.push_back(so[r + 1] - so[r]); it.r_off.push_back(ro[r]); it.r_len.push_back(ro[r + 1] - ro[r]); }
+        if (so[rank + 1] > so[rank]) CBLX_HIP(hipMemcpyAsync(dst + ro[rank], src + so[rank], so[rank + 1] - so[rank], hipMemcpyDeviceToDevice, after));
+        items_common(std::vector<Item>{it}, after);
+    }
+    void wait() override { if (ps) CBLX_HIP(hipStreamSynchronize(ps)); }
+    void record(hipEvent_t e, hipStream_t after) override { CBLX_HIP(hipEventRecord(e, ps ? ps : after)); }
+};
 }  // namespace
 
 struct cblx_comm {
@@ -180,6 +347,10 @@ struct cblx_comm {
     int device = 0;
     u32 protocol = CBLX_PROTO_BINS;
     std::string err;
+    // grouped receiver (sharded_insert_grouped): groups per rank asked for (0: CBLX_RECV_GROUPS or the default), the group cuts chosen
+    // together with the bounds they refine, and how many groups the last call worked through (0: it took the ungrouped path)
+    u32 recv_groups = 0, groups_used = 0;
+    std::vector<u32> g_bounds, g_cuts;
 };
 
 namespace {
@@ -213,9 +384,9 @@ std::vector<u32> choose_bounds(const std::vector<u64>& hist, u32 world, u32 PB, 
     return b;
 }
 
-// first batch only: quantile ranges from the all-reduced, sampled prefix histogram of one slice's words
+// the all-reduced, sampled prefix histogram (2^min(16, PB) bins) of one slice's words
 template <typename C>
-void choose_bounds_from_slice(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 nseq, u32* bounds) {
+std::vector<u64> sampled_prefix_hist(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 nseq) {
     typedef typename C::HiT HiT;
     const Consts& P = c->P;
     const u32 hb = std::min(SPLIT_HIST_BITS, P.PB);
@@ -238,8 +409,51 @@ void choose_bounds_from_slice(cblx_ctx* c, Transport& T, const u8* d_bases, cons
         }
     }
     T.all_reduce_sum_u64(hist.data(), hist.size());
+    return hist;
+}
+// The cuts of the grouped receiver: inside every rank's range [bounds[d-1], bounds[d]) up to G - 1 more prefix values that split
+// the range's sampled mass evenly — multiples of 64 (two groups of one rank never share a bitvector word), strictly inside the
+// range, ascending. Fewer than G - 1 where the histogram has no room for them (a cell of it is 2^(PB-16) prefixes wide).
+std::vector<u32> choose_group_cuts(const std::vector<u64>& hist, const u32* bounds, u32 W, u32 G, u32 PB) {
+    std::vector<u32> cuts;
+    const size_t nh = hist.size();
+    const u32 hb = (u32)ilog2_npo2((u32)nh);
+    const int shift = (int)PB - (int)hb;
+    if (shift < 0 || G < 2) return cuts;
+    std::vector<double> cum(nh + 1, 0.0);
+    for (size_t i = 0; i < nh; ++i) cum[i + 1] = cum[i] + (double)hist[i];
+    auto mass_below = [&](u64 prefix) {  // sampled words with a smaller prefix (linear inside a cell)
+        const u64 cell = prefix >> shift;
+        if (cell >= nh) return cum[nh];
+        return cum[cell] + (double)hist[cell] * (double)(prefix - (cell << shift)) / (double)(1ull << shift);
+    };
+    for (u32 d = 0; d < W; ++d) {
+        const u64 lo = d ? bounds[d - 1] : 0, hi = d + 1 < W ? bounds[d] : 1ull << PB;
+        if (hi <= lo) continue;
+        const double m0 = mass_below(lo), m1 = mass_below(hi);
+        u64 last = lo;
+        for (u32 j = 1; j < G; ++j) {
+            const double want = m0 + (m1 - m0) * j / G;
+            u64 cell = (u64)(std::upper_bound(cum.begin(), cum.end(), want) - cum.begin());  // first cell boundary with more mass below it
+            cell = std::min<u64>(std::max<u64>(cell, 1), nh);
+            u64 v = ((cell << shift) + 63) & ~63ull;
+            if (v <= last || v >= hi || v <= lo) continue;
+            cuts.push_back((u32)v);
+            last = v;
+        }
+    }
+    return cuts;
+}
+
+// first batch only: quantile ranges from the all-reduced, sampled prefix histogram of one slice's words
+template <typename C>
+void choose_bounds_from_slice(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 nseq, u32* bounds, std::vector<u64>* hist_out = nullptr) {
+    const Consts& P = c->P;
+    const u32 hb = std::min(SPLIT_HIST_BITS, P.PB);
+    std::vector<u64> hist = sampled_prefix_hist<C>(c, T, d_bases, d_offsets, nseq);
     const std::vector<u32> bb = choose_bounds(hist, T.world, P.PB, hb);
     for (u32 d = 0; d + 1 < T.world; ++d) bounds[d] = bb[d];
+    if (hist_out) *hist_out = std::move(hist);
 }
 
 // ---- protocol "sorted": the sender partitions completely; prefixes, counts and packed suffixes on the wire; the receiver
@@ -551,16 +765,430 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const BaseView& d_bases, con
     CBLX_HIP(hipStreamSynchronize(c->stream));
 }
 
+// ---- protocol "bins" with a GROUPED receiver: the wire hidden behind the receiver's own kernels ---------------------------------
+// In sharded_insert_bins the remaining passes and the bucket kernels start when the LAST record has landed: at 8 GPUs the wire
+// (25 - 30 ms) lies bare in front of 27 - 36 ms of receiver kernels. Here every rank's prefix range is cut into G groups of about
+// equal sampled mass (choose_group_cuts) and the senders' first pass runs on bins that refine the pass-A segment by ALL cuts
+// (DigitCut) — so a sender's output is contiguous per (destination, group), and inside that per segment, as before. The senders
+// finish KRN-1 + pass A of all their slices first (10 - 12 ms during which the wire idles, but the GPU does not); then the data
+// crosses GROUP-MAJOR: one grouped send / receive per group, carrying that group's share of every slice. The receive log is laid
+// out exactly as before (slice-major, source-minor pieces, each sorted by bin), only the order of arrival changes: when group g
+// has landed (an event on the transport's stream) its records — pieces of the log — go through the LSD passes, their window of the
+// directory and the bucket kernels into the group's slot of the final arena (pipeline_group) while groups g + 1 .. are still on the
+// wire. Per group the receiver's kernels take about as long as the group's bytes need on 7 links, so from the first group on the
+// GPU is the bound. Inside a group a segment value occurs in one bin only (every cut is a group or rank boundary), so the group's
+// piece table is the old one with other counts. Declines (returns false, identically on every rank: the decision rests on
+// replicated values only) when the index is not empty anywhere, the cuts do not fit the table, or a rank's share needs two rounds.
+struct CutPlan {
+    bool ok = false;
+    std::vector<u32> cuts;              // ascending, distinct, non-zero: rank bounds and group cuts
+    std::vector<u32> dest_of, grp_of;   // per interval [cuts[i-1], cuts[i]): owner rank, group inside the owner's range
+    std::vector<CutCell> tab;           // DigitCut's table
+    u32 v_of[256], iv_of[256];          // bin -> pass-A segment, interval (0xFFFFFFFF: no such bin)
+    u32 bin_lo[MAX_DEST + 1];           // first bin of every rank (bins of one rank are consecutive)
+    u32 ngroups[MAX_DEST];              // groups of every rank
+};
+inline CutPlan make_cut_plan(const Consts& P, const u32* bounds, u32 W, const std::vector<u32>& gcuts) {
+    CutPlan M;
+    const u32 RB = P.PB - 8;
+    for (u32 i = 0; i < 256; ++i) M.v_of[i] = M.iv_of[i] = 0xFFFFFFFFu;
+    for (u32 i = 0; i + 1 < W; ++i) {
+        if (bounds[i] == 0 || (i && bounds[i] <= bounds[i - 1]) || (u64)bounds[i] > (255ull << RB)) return M;  // an empty range, or the all-ones segment cut
+        M.cuts.push_back(bounds[i]);
+    }
+    for (u32 g : gcuts) M.cuts.push_back(g);
+    std::sort(M.cuts.begin(), M.cuts.end());
+    for (size_t i = 1; i < M.cuts.size(); ++i) if (M.cuts[i] == M.cuts[i - 1]) return M;
+    if (M.cuts.size() > 120 || M.cuts.empty() || (u64)M.cuts.back() > (255ull << RB)) return M;
+    const u32 nc = (u32)M.cuts.size();
+    // the table: per key the cuts at or below the key's first prefix, and the one cut inside the key's range
+    M.tab.assign(CUT_KEYS, CutCell{0xFFFFFFFFu, 0u});
+    for (u32 k = 0; k < CUT_KEYS; ++k) {
+        const u32 first = cut_key_first(k);
+        M.tab[k].base = (u32)(std::upper_bound(M.cuts.begin(), M.cuts.end(), first) - M.cuts.begin());
+    }
+    for (u32 cv : M.cuts) {
+        const u32 k = cut_key(cv);
+        if (cv == cut_key_first(k)) continue;  // counted in the key's base
+        if (M.tab[k].cut != 0xFFFFFFFFu) return M;  // two cuts inside one cell of the table
+        M.tab[k].cut = cv;
+    }
+    auto cnt = [&](u64 p) { return (u32)(std::upper_bound(M.cuts.begin(), M.cuts.end(), (u32)p) - M.cuts.begin()); };
+    M.dest_of.resize(nc + 1);
+    M.grp_of.resize(nc + 1);
+    for (u32 i = 0; i <= nc; ++i) {
+        const u32 first = i ? M.cuts[i - 1] : 0u;
+        u32 d = 0;
+        for (u32 j = 0; j + 1 < W; ++j) d += bounds[j] <= first ? 1u : 0u;
+        M.dest_of[i] = d;
+        M.grp_of[i] = i && M.dest_of[i - 1] == d ? M.grp_of[i - 1] + 1 : 0u;
+    }
+    for (u32 d = 0; d < W; ++d) M.ngroups[d] = 0;
+    for (u32 i = 0; i <= nc; ++i) M.ngroups[M.dest_of[i]] = std::max(M.ngroups[M.dest_of[i]], M.grp_of[i] + 1);
+    for (u32 v = 0; v < 128; ++v)
+        for (u32 k = cnt((u64)v << RB); k <= cnt((((u64)v + 1) << RB) - 1); ++k) {
+            if (v + k >= 254) return M;
+            M.v_of[v + k] = v;
+            M.iv_of[v + k] = k;
+        }
+    M.v_of[255] = 255; M.iv_of[255] = nc;
+    // bins of one rank are consecutive: first bin per rank (a rank without any bin gets an empty range)
+    for (u32 d = 0; d <= W; ++d) M.bin_lo[d] = 256;
+    for (int b = 255; b >= 0; --b) if (M.iv_of[b] != 0xFFFFFFFFu) M.bin_lo[M.dest_of[M.iv_of[b]]] = (u32)b;
+    M.bin_lo[W] = 256;
+    for (int d = (int)W - 1; d >= 0; --d) if (M.bin_lo[d] == 256) M.bin_lo[d] = M.bin_lo[d + 1];
+    M.ok = true;
+    return M;
+}
+__global__ void k_add_u64(u64* __restrict__ v, u64 n, u64 add) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] += add;
+}
+inline u32 recv_groups_wanted(const cblx_comm* cm) {
+    if (cm->recv_groups) return cm->recv_groups;
+    const char* e = std::getenv("CBLX_RECV_GROUPS");
+    const u32 v = e ? (u32)std::strtoul(e, nullptr, 10) : 0;
+    return v ? std::min(v, 14u) : 8u;
+}
+template <typename C>
+bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, const u32* bounds) {
+    typedef typename C::HiT HiT;
+    constexpr bool WS = C::WS;
+    constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
+    typedef typename std::conditional<DROP_HI, NoHi, HiT>::type OutH;
+    constexpr size_t OHS = HiTraits<OutH>::has ? sizeof(u64) : 0;
+    Transport& T = *cm->t;
+    const Consts& P = c->P;
+    const u32 W = T.world, me = T.rank, RB = P.PB - 8;
+    const u32 G = recv_groups_wanted(cm);
+    cm->groups_used = 0;
+    if (W < 2 || W > MAX_DEST || G < 2 || P.PB < 9 || nslices == 0) return false;
+    for (u32 s = 0; s < nslices; ++s) if (cuts[s + 1] < cuts[s] || cuts[s + 1] > n) throw Error(CBLX_EINVAL, "slice cuts must be ascending and at most n");
+    // -- the group cuts that go with these bounds (chosen once per set of bounds: a sampled histogram of the first slice, all-reduced)
+    const std::vector<u32> bvec(bounds, bounds + (W - 1));
+    if (cm->g_bounds != bvec) {
+        const std::vector<u64> hist = sampled_prefix_hist<C>(c, T, d_bases, d_offsets + cuts[0], cuts[1] - cuts[0]);
+        cm->g_cuts = choose_group_cuts(hist, bounds, W, G, P.PB);
+        cm->g_bounds = bvec;
+    }
+    const CutPlan M = make_cut_plan(P, bounds, W, cm->g_cuts);
+    // -- the job: k-mers per rank (upper bound), whether any rank holds an index already
+    const u64 n0 = cuts[0], n1 = cuts[nslices];
+    u64 mine = 0;
+    if (n1 > n0) {
+        const u64 first = d2h<u64>(c, d_offsets + n0), last = d2h<u64>(c, d_offsets + n1);
+        if (last < first) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
+        const u64 sub = (n1 - n0) * (u64)(P.K - 1);
+        mine = last - first > sub ? last - first - sub : 0;
+    }
+    u64 agree[2] = {mine, c->res.count != 0 ? 1ull : 0ull};
+    T.all_reduce_sum_u64(agree, 2);
+    const u64 job = agree[0];
+    const u64 LIMIT = 0xFFFFFFF0ull - 2 * RDX_TILE;
+    if (!M.ok || agree[1] != 0 || job / W + job / (2 * W) + (1u << 20) >= LIMIT || mine >= LIMIT) return false;
+    const bool trace = std::getenv("CBLX_TRACE_SHARDED") != nullptr;
+    const LsdPlan LP = lsd_plan(P);
+    const DigitBits nextd{P.SB + LP.sh[0], LP.wid[0]};
+    Buf<CutCell> d_tab(c->pool, CUT_KEYS);
+    h2d(c, d_tab.get(), M.tab.data(), CUT_KEYS);
+    const DigitCut fn{P.SB, P.PB, RB, d_tab.get()};
+    EncHist eh0{};
+    eh0.nd = W; eh0.SB = P.SB; eh0.PB = P.PB; eh0.binRB = RB; eh0.cut_tab = d_tab.get();
+    const u32 my_lo = M.bin_lo[me], my_cells = M.bin_lo[me + 1] - M.bin_lo[me], NG = M.ngroups[me];
+    // cells (= my bins) of every one of my groups
+    std::vector<u32> gc0(NG + 1, my_cells);
+    for (u32 cl = my_cells; cl-- > 0;) gc0[M.grp_of[M.iv_of[my_lo + cl]]] = cl;
+    for (int g = (int)NG - 1; g >= 0; --g) if (gc0[g] > gc0[g + 1]) gc0[g] = gc0[g + 1];
+    u32 Gmax = 0;
+    for (u32 d = 0; d < W; ++d) Gmax = std::max(Gmax, M.ngroups[d]);
+
+    // -- senders: KRN-1 + pass A of every slice; the own records go straight into the log, the rest waits in the slice's send buffer
+    u64 cap = std::min<u64>(std::max<u64>(std::min<u64>(job, job / W + job / (4 * W) + (1u << 20)), 1024), LIMIT);
+    Buf<u64> a_lo;
+    Buf<u8> a_hi, a_dig;
+    auto alloc_log = [&](u64 ncap, Buf<u64>& lo, Buf<u8>& hi, Buf<u8>& dg) {
+        lo = Buf<u64>(c->pool, ncap + 2);
+        hi = Buf<u8>(c->pool, OHS ? (ncap + 2) * OHS : 8);
+        dg = Buf<u8>(c->pool, ncap + 64);
+    };
+    struct Sent { Buf<u64> lo; Buf<u8> hi, dig; std::vector<u32> tot; u64 own_a = 0, own = 0; };
+    std::vector<Sent> sent(nslices);
+    std::vector<u32> pcnt, pbase;  // [piece][256] records per CELL of mine, log position of every piece; piece = slice * W + source
+    const size_t HDR = 257;
+    std::vector<std::vector<u64>> recvh(nslices);  // headers: what every source sends me, per slice
+    u64 filled = 0;
+    struct Drain { Transport& t; ~Drain() { try { t.wait(); } catch (...) {} } } drain{T};
+    auto grow = [&](u64 need) {  // (nothing is on the wire yet: only own pieces are in the log)
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+        const u64 ncap = std::min<u64>(LIMIT, need + need / 4 + 4096);
+        Buf<u64> lo;
+        Buf<u8> hi, dg;
+        alloc_log(ncap, lo, hi, dg);
+        if (filled) {
+            CBLX_HIP(hipMemcpyAsync(lo.get(), a_lo.get(), filled * 8, hipMemcpyDeviceToDevice, c->stream));
+            if (OHS) CBLX_HIP(hipMemcpyAsync(hi.get(), a_hi.get(), filled * OHS, hipMemcpyDeviceToDevice, c->stream));
+            CBLX_HIP(hipMemcpyAsync(dg.get(), a_dig.get(), filled, hipMemcpyDeviceToDevice, c->stream));
+            CBLX_HIP(hipStreamSynchronize(c->stream));
+        }
+        a_lo = std::move(lo); a_hi = std::move(hi); a_dig = std::move(dg);
+        cap = ncap;
+    };
+    struct Work { ChunkPlan pl; Buf<u64> t_lo; Buf<u8> t_hi; Buf<u32> counts, colpre, scratch, adj, coltot; };
+    Work prev_work;
+    for (u32 s = 0; s < nslices; ++s) {
+        const u64 a = cuts[s], b = cuts[s + 1];
+        ChunkPlan pl;
+        BaseView pb = ascii_view(d_bases);
+        u64 N = 0;
+        if (b > a) { plan_chunks(c, pb, d_offsets + a, b - a, pl); N = pl.n_kmers; }
+        else CBLX_HIP(hipStreamSynchronize(c->stream));
+        prev_work = Work();
+        if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "one slice takes fewer than 2^32-16 words (use more slices)");
+        const u32 ntiles = (u32)ceil_div(N, RDX_TILE);
+        Work wk;
+        wk.coltot = Buf<u32>(c->pool, 256);
+        wk.adj = Buf<u32>(c->pool, 256);
+        wk.pl = std::move(pl);
+        Sent& S = sent[s];
+        S.tot.assign(256, 0u);
+        if (N) {
+            const size_t hs = hi_elem_size(P);
+            wk.t_lo = Buf<u64>(c->pool, N + 2);
+            wk.t_hi = Buf<u8>(c->pool, hs ? (N + 2) * hs : 8);
+            wk.counts = Buf<u32>(c->pool, (size_t)256 * (ntiles + 2));
+            wk.colpre = Buf<u32>(c->pool, (size_t)256 * ntiles);
+            CBLX_HIP(hipMemsetAsync(wk.counts.get(), 0, (size_t)256 * (ntiles + 2) * 4, c->stream));
+            EncHist eh = eh0;
+            eh.counts = wk.counts.get();
+            encode<C>(c, pb, wk.pl, wk.t_lo.get(), (HiT*)wk.t_hi.get(), 0, eh);
+            { StageTimer t(c, ST_SCAN);
+              colscan(c, wk.counts.get(), nullptr, ntiles, wk.colpre.get(), wk.coltot.get(), wk.scratch);
+              hipLaunchKernelGGL(k_seg_adjust, dim3(1), dim3(256), 0, c->stream, wk.colpre.get(), wk.coltot.get(), (const u32*)nullptr, (const u32*)nullptr,
+                                 (const u32*)nullptr, ntiles, 1u, wk.adj.get()); }
+            CBLX_HIP(hipGetLastError());
+            S.tot = d2h_vec<u32>(c, wk.coltot.get(), 256);
+        }
+        // header per destination: words, then words per cell of the destination's range
+        std::vector<u64> send((size_t)W * HDR, 0);
+        recvh[s].assign((size_t)W * HDR, 0);
+        u64 sum = 0;
+        for (u32 bin = 0; bin < 256; ++bin) {
+            if (!S.tot[bin]) continue;
+            if (M.iv_of[bin] == 0xFFFFFFFFu) throw Error(CBLX_EDEVICE, "sharded build: a word fell into a bin no prefix maps to (internal error)");
+            const u32 d = M.dest_of[M.iv_of[bin]];
+            send[(size_t)d * HDR] += S.tot[bin];
+            send[(size_t)d * HDR + 1 + (bin - M.bin_lo[d])] += S.tot[bin];
+            sum += S.tot[bin];
+        }
+        if (sum != N) throw Error(CBLX_EDEVICE, "sharded build: the bin histogram counts " + std::to_string(sum) + " words, the slice has " + std::to_string(N) + " (internal error)");
+        T.all_to_all_u64(send.data(), recvh[s].data(), HDR);
+        const std::vector<u64>& recv = recvh[s];
+        u64 incoming = 0;
+        for (u32 d = 0; d < me; ++d) S.own_a += send[(size_t)d * HDR];
+        S.own = send[(size_t)me * HDR];
+        if (recv[(size_t)me * HDR] != S.own) throw Error(CBLX_EDEVICE, "sharded build: the count exchange returned another own count (transport error)");
+        for (u32 r = 0; r < W; ++r) incoming += recv[(size_t)r * HDR];
+        if (filled + incoming >= LIMIT) throw Error(CBLX_ERANGE, "this rank's share of the job takes more than one round: set CBLX_RECV_GROUPS=1 (ungrouped receiver) or use more ranks");
+        if (!a_lo.get()) alloc_log(cap, a_lo, a_hi, a_dig);
+        if (filled + incoming > cap) grow(filled + incoming);
+        // log layout of the slice as in sharded_insert_bins: the own piece first, then the other sources in rank order
+        u64 ro = 0;
+        for (u32 r = 0; r < W; ++r) {
+            pbase.push_back((u32)(r == me ? filled : filled + S.own + ro));
+            if (r != me) ro += recv[(size_t)r * HDR];
+            for (u32 cl = 0; cl < 256; ++cl) pcnt.push_back((u32)recv[(size_t)r * HDR + 1 + cl]);
+        }
+        const u64 nsend = N - S.own;
+        S.lo = Buf<u64>(c->pool, nsend + 2);
+        S.hi = Buf<u8>(c->pool, OHS ? (nsend + 2) * OHS : 8);
+        S.dig = Buf<u8>(c->pool, nsend + 64);
+        if (N) {
+            const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
+            const OwnWindow ow{S.own_a, S.own_a + S.own, a_lo.get() + filled, OHS ? (void*)(a_hi.get() + filled * OHS) : nullptr, a_dig.get() + filled};
+            StageTimer t(c, ST_SCATTER);
+            hipLaunchKernelGGL((k_radix_scatter<HiT, OutH, DigitCut, true>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, (const u64*)wk.t_lo.get(), (const HiT*)wk.t_hi.get(), tv, fn,
+                               (const u32*)wk.colpre.get(), (const u32*)wk.adj.get(), S.lo.get(), (OutH*)S.hi.get(), nextd, S.dig.get(), (u32*)nullptr, 0u, 0u, 0u, (u32*)nullptr, 0u, ow);
+            CBLX_HIP(hipGetLastError());
+        }
+        if (trace) fprintf(stderr, "[cblx grouped] rank %u slice %u: N=%llu own=%llu incoming=%llu filled=%llu\n", me, s, (unsigned long long)N, (unsigned long long)S.own,
+                           (unsigned long long)incoming, (unsigned long long)filled);
+        filled += incoming;
+        prev_work = std::move(wk);
+    }
+    // -- the wire, group-major: exchange k carries group k of EVERY rank (ranks with fewer groups send nothing in the later ones)
+    std::vector<hipEvent_t> gev(Gmax, nullptr);
+    struct Events { std::vector<hipEvent_t>& v; ~Events() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } events{gev};
+    // record range [first, first + len) of bins [b0, b1) in a slice's send buffer (the own window is not in it)
+    auto send_range = [&](const Sent& S, u32 b0, u32 b1, u64& first, u64& len) {
+        u64 before = 0, inside = 0;
+        for (u32 bin = 0; bin < b1; ++bin) (bin < b0 ? before : inside) += S.tot[bin];
+        first = before >= S.own_a + S.own ? before - S.own : before;  // ranges of other ranks lie wholly before or behind the own window
+        len = inside;
+    };
+    for (u32 k = 0; k < Gmax; ++k) {
+        std::vector<Transport::Item> items;
+        for (u32 s = 0; s < nslices; ++s) {
+            Sent& S = sent[s];
+            std::vector<u64> so(W, 0), sl(W, 0), rof(W, 0), rl(W, 0);
+            for (u32 d = 0; d < W; ++d) {
+                if (d == me || k >= M.ngroups[d]) continue;
+                // bins of (rank d, group k)
+                u32 b0 = 256, b1 = 0;
+                for (u32 bin = M.bin_lo[d]; bin < M.bin_lo[d + 1]; ++bin)
+                    if (M.iv_of[bin] != 0xFFFFFFFFu && M.grp_of[M.iv_of[bin]] == k) { b0 = std::min(b0, bin); b1 = std::max(b1, bin + 1); }
+                if (b0 >= b1) continue;
+                send_range(S, b0, b1, so[d], sl[d]);
+            }
+            if (k < NG)
+                for (u32 r = 0; r < W; ++r) {
+                    if (r == me) continue;
+                    const u32* pc = pcnt.data() + ((size_t)s * W + r) * 256;
+                    u64 before = 0, inside = 0;
+                    for (u32 cl = 0; cl < gc0[k + 1]; ++cl) (cl < gc0[k] ? before : inside) += pc[cl];
+                    rof[r] = (u64)pbase[(size_t)s * W + r] + before;
+                    rl[r] = inside;
+                }
+            // (every rank issues the same items in the same order, empty ones included: a callback transport's exchange is a collective)
+            auto item = [&](const u8* src, u8* dst, size_t es) {
+                Transport::Item it{src, dst, so, sl, rof, rl};
+                for (u32 r = 0; r < W; ++r) { it.s_off[r] *= es; it.s_len[r] *= es; it.r_off[r] *= es; it.r_len[r] *= es; }
+                items.push_back(std::move(it));
+            };
+            item((const u8*)S.lo.get(), (u8*)a_lo.get(), 8);
+            if (OHS) item(S.hi.get(), a_hi.get(), OHS);
+            item(S.dig.get(), a_dig.get(), 1);
+        }
+        T.exchange_items(items, c->stream);
+        CBLX_HIP(hipEventCreateWithFlags(&gev[k], hipEventDisableTiming));
+        T.record(gev[k], c->stream);
+    }
+    prev_work = Work();  // (the stream is past the last slice's pass A once the first group is waited for; the workspace is only returned to the pool)
+    // -- the receiver, group by group behind the wire
+    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    Resident fin;
+    fin.bv = Buf<u64>(c->pool, nwords);
+    CBLX_HIP(hipMemsetAsync(fin.bv.get(), 0, nwords * 8, c->stream));
+    fin.a_lo = Buf<u64>(c->pool, filled + 2);
+    Buf<u64> fin_hi_keep;  // 16-byte records through the passes: a target for the hi parts even when the arena keeps none
+    if (WS) fin.a_hi = Buf<u64>(c->pool, filled + 2);
+    else if (OHS) fin_hi_keep = Buf<u64>(c->pool, filled + 2);
+    u64* fin_hi = WS ? fin.a_hi.get() : fin_hi_keep.get();
+    // words of every group of mine
+    std::vector<u64> gN(NG, 0);
+    const size_t np = (size_t)nslices * W;
+    for (size_t p = 0; p < np; ++p)
+        for (u32 g = 0; g < NG; ++g)
+            for (u32 cl = gc0[g]; cl < gc0[g + 1]; ++cl) gN[g] += pcnt[p * 256 + cl];
+    u64 gmax = 0;
+    for (u64 x : gN) gmax = std::max(gmax, x);
+    Buf<u64> scr_lo(c->pool, gmax + 2), scr_hi(c->pool, OHS ? gmax + 2 : 1);
+    Buf<u8> dig2(c->pool, gmax + 64);
+    std::vector<Resident> parts(NG);
+    std::vector<u64> gbase(NG + 1, 0);
+    // prefix window of every group: its cuts (multiples of 64), the range's ends rounded outwards
+    auto group_first_prefix = [&](u32 g) -> u64 {
+        if (g >= NG) return me + 1 < W ? ((u64)bounds[me] + 63) & ~63ull : nprefix;
+        if (g == 0) return me ? (u64)bounds[me - 1] & ~63ull : 0ull;
+        const u32 iv = M.iv_of[my_lo + gc0[g]];
+        return iv ? (u64)M.cuts[iv - 1] : 0ull;
+    };
+    for (u32 g = 0; g < NG; ++g) {
+        gbase[g + 1] = gbase[g] + gN[g];
+        if (g < Gmax && gev[g]) CBLX_HIP(hipStreamWaitEvent(c->stream, gev[g], 0));
+        if (gN[g] == 0) continue;
+        // the group's share of every piece: counts per SEGMENT (inside a group a segment occurs in one cell only), first record
+        std::vector<u32> cnt_g(np * 256, 0u), pb_g(np);
+        for (size_t p = 0; p < np; ++p) {
+            u64 before = 0;
+            for (u32 cl = 0; cl < gc0[g]; ++cl) before += pcnt[p * 256 + cl];
+            pb_g[p] = (u32)(pbase[p] + before);
+            for (u32 cl = gc0[g]; cl < gc0[g + 1]; ++cl) {
+                const u32 v = M.v_of[my_lo + cl];
+                if (cnt_g[p * 256 + v] && pcnt[p * 256 + cl]) throw Error(CBLX_EDEVICE, "grouped receiver: a segment occurs in two cells of one group (internal error)");
+                cnt_g[p * 256 + v] += pcnt[p * 256 + cl];
+            }
+        }
+        PieceInput pin;
+        pin.np = (u32)np;
+        pin.cnt = cnt_g.data();
+        pin.pbase = pb_g.data();
+        pin.dig_in = a_dig.get();
+        pin.dig_out = dig2.get();
+        DirWindow win;
+        win.w_lo = (u32)group_first_prefix(g);
+        const u64 whi = group_first_prefix(g + 1);
+        win.w_hi = (u32)std::min<u64>(whi, 0xFFFFFFC0ull);
+        win.bv = fin.bv.get();
+        GroupRegions R;
+        R.log_lo = a_lo.get();
+        R.log_hi = OHS ? (const void*)a_hi.get() : nullptr;
+        R.fin_lo = fin.a_lo.get() + gbase[g];
+        R.fin_hi = fin_hi ? fin_hi + gbase[g] : nullptr;
+        R.scr_lo = scr_lo.get();
+        R.scr_hi = OHS ? scr_hi.get() : nullptr;
+        if (trace) fprintf(stderr, "[cblx grouped] rank %u group %u: %llu words, prefixes [%u, %u)\n", me, g, (unsigned long long)gN[g], win.w_lo, win.w_hi);
+        pipeline_group<C>(c, R, pin, gN[g], win, parts[g]);
+        ++cm->groups_used;
+    }
+    T.wait();
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    for (Sent& S : sent) { S.lo.reset(); S.hi.reset(); S.dig.reset(); }
+    a_lo.reset(); a_hi.reset(); a_dig.reset();
+    // -- one index out of the groups: tables concatenated (starts made absolute), rank directory over the whole bitvector
+    if (filled) {
+        u64 nb = 0;
+        for (const Resident& r : parts) { nb += r.nb; fin.count += r.count; }
+        fin.nb = nb;
+        fin.prefix = Buf<u32>(c->pool, nb + 1);
+        fin.start = Buf<u64>(c->pool, nb + 1);
+        fin.cnt = Buf<u32>(c->pool, nb + 1);
+        fin.kind = Buf<u8>(c->pool, nb + 1);
+        u64 at = 0;
+        for (u32 g = 0; g < NG; ++g) {
+            const Resident& r = parts[g];
+            if (!r.nb) continue;
+            CBLX_HIP(hipMemcpyAsync(fin.prefix.get() + at, r.prefix.get(), r.nb * 4, hipMemcpyDeviceToDevice, c->stream));
+            CBLX_HIP(hipMemcpyAsync(fin.start.get() + at, r.start.get(), r.nb * 8, hipMemcpyDeviceToDevice, c->stream));
+            CBLX_HIP(hipMemcpyAsync(fin.cnt.get() + at, r.cnt.get(), r.nb * 4, hipMemcpyDeviceToDevice, c->stream));
+            CBLX_HIP(hipMemcpyAsync(fin.kind.get() + at, r.kind.get(), r.nb, hipMemcpyDeviceToDevice, c->stream));
+            if (gbase[g]) hipLaunchKernelGGL(k_add_u64, grid1(r.nb, 256), dim3(256), 0, c->stream, fin.start.get() + at, r.nb, gbase[g]);
+            at += r.nb;
+        }
+        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, fin.start.get() + nb, filled);
+        Buf<u32> popc(c->pool, nwords);
+        fin.rank_dir = Buf<u64>(c->pool, nwords + 1);
+        hipLaunchKernelGGL(k_bv_or, grid1(nwords, 256), dim3(256), 0, c->stream, nwords, (const u64*)fin.bv.get(), (const u64*)fin.bv.get(), fin.bv.get(), popc.get());
+        const u64 nb2 = exclusive_scan<u64>(c, popc.get(), nwords, fin.rank_dir.get());
+        CBLX_HIP(hipGetLastError());
+        if (nb2 != nb) throw Error(CBLX_EDEVICE, "grouped receiver: the groups hold " + std::to_string(nb) + " buckets, the bitvector " + std::to_string(nb2) + " (internal error)");
+        CBLX_HIP(hipStreamSynchronize(c->stream));
+        parts.clear();
+        c->res = std::move(fin);
+        c->kmers_inserted += filled;
+    }
+    CBLX_HIP(hipStreamSynchronize(c->stream));
+    return true;
+}
+
 template <typename C>
 void sharded_insert(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, u32* bounds, int* bounds_valid) {
     Transport& T = *cm->t;
+    T.begin_job();
     if (nslices && !*bounds_valid) {
         if (cuts[1] < cuts[0] || cuts[1] > n) throw Error(CBLX_EINVAL, "slice cuts must be ascending and at most n");
-        choose_bounds_from_slice<C>(c, T, d_bases, d_offsets + cuts[0], cuts[1] - cuts[0], bounds);
+        std::vector<u64> hist;
+        choose_bounds_from_slice<C>(c, T, d_bases, d_offsets + cuts[0], cuts[1] - cuts[0], bounds, &hist);
         *bounds_valid = 1;
+        if (T.world > 1) {  // the group cuts of the grouped receiver come from the same histogram
+            cm->g_cuts = choose_group_cuts(hist, bounds, T.world, recv_groups_wanted(cm), c->P.PB);
+            cm->g_bounds.assign(bounds, bounds + (T.world - 1));
+        }
     }
-    if (cm->protocol == CBLX_PROTO_BINS && bins_protocol_fits(c->P, bounds, T.world))
+    cm->groups_used = 0;
+    if (cm->protocol == CBLX_PROTO_BINS && bins_protocol_fits(c->P, bounds, T.world)) {
+        if (sharded_insert_grouped<C>(c, cm, d_bases, d_offsets, n, cuts, nslices, bounds)) return;
         sharded_insert_bins<C>(c, T, ascii_view(d_bases), d_offsets, n, cuts, nslices, bounds, [](u32) {});
+    }
     else
         sharded_insert_sorted<C>(c, T, d_bases, d_offsets, n, cuts, nslices, bounds, bounds_valid);
 }
@@ -572,6 +1200,7 @@ struct LocalTransport : Transport {
     void all_to_all_u64(const u64* send, u64* recv, size_t per) override { std::memcpy(recv, send, per * 8); }
     void exchange(const u8*, const u64*, u8*, const u64*, hipStream_t) override {}
     void wait() override {}
+    void exchange_items(const std::vector<Item>&, hipStream_t) override {}
 };
 }  // namespace (reopened below: insert_device_streamed is declared in ingest.hpp)
 

@@ -90,14 +90,15 @@ __global__ void k_bitvector(const u32* __restrict__ start_dense, u64 nprefix, u6
     }
 }
 __global__ void k_bucket_table(const u32* __restrict__ start_dense, u64 nprefix, const u64* __restrict__ bv,
-                               const u64* __restrict__ rank_dir, u32* __restrict__ bucket_prefix, u64* __restrict__ raw_start) {
+                               const u64* __restrict__ rank_dir, u32* __restrict__ bucket_prefix, u64* __restrict__ raw_start,
+                               u32 prefix_base = 0 /* the arrays describe prefixes [prefix_base, prefix_base + nprefix), a multiple of 64 */) {
     u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nprefix) return;
     u32 s = start_dense[p];
     if (s == EMPTY32) return;
     u64 w = bv[p >> 6];
     u64 r = rank_dir[p >> 6] + (u64)__builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
-    bucket_prefix[r] = (u32)p;
+    bucket_prefix[r] = (u32)p + prefix_base;
     raw_start[r] = s;
 }
 

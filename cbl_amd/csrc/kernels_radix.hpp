@@ -241,6 +241,34 @@ struct DigitBin {
         return v >= 255u ? 255u : (b < 254u ? b : 254u);
     }
 };
+// ... or (grouped receiver, comm.hpp) the bin under an arbitrary ascending list of CUTS of the prefix space — the destination
+// bounds plus, inside every destination's range, the bounds of the GROUPS the receiver works through while later groups are
+// still on the wire: bin = (prefix >> RB) + #{cuts <= prefix}. Up to 126 cuts: counting them by compares would cost two
+// VALU instructions each, so the count comes from a table over a floating-point-like key of the prefix (the 6 leading bits:
+// 32 cells per octave, exact below 64): entry = {cuts <= the cell's first prefix, the one cut inside the cell or ~0}. The host
+// refuses a cut list with two cuts inside one cell (make_cut_table); 768 entries of 8 bytes, read through the vector L1.
+struct CutCell { u32 cut, base; };
+static const u32 CUT_KEYS = 64 + 26 * 32;
+__host__ __device__ __forceinline__ u32 cut_key(u32 p) {
+    if (p < 64u) return p;
+    const u32 e = 31u - (u32)__builtin_clz(p);
+    return 64u + ((e - 6u) << 5) + ((p >> (e - 5u)) & 31u);
+}
+__host__ __device__ __forceinline__ u32 cut_key_first(u32 k) {  // smallest prefix with that key
+    if (k < 64u) return k;
+    const u32 e = 6u + ((k - 64u) >> 5), m = (k - 64u) & 31u;
+    return (32u + m) << (e - 5u);
+}
+struct DigitCut {
+    u32 SB, PB, RB;
+    const CutCell* tab;
+    __device__ __forceinline__ u32 operator()(u64 lo, u64 hi) const {
+        const u32 p = get_bits(lo, hi, SB, PB);
+        const CutCell c = tab[cut_key(p)];
+        const u32 v = p >> RB, b = v + c.base + (p >= c.cut ? 1u : 0u);
+        return v >= 255u ? 255u : (b < 254u ? b : 254u);
+    }
+};
 // Where the records of the sender's OWN destination go: positions [a, b) of the pass's output order leave for other arrays
 // (position - a); what lies behind them moves down by b - a, so the send buffer holds the other ranks' records only.
 struct OwnWindow {
@@ -670,18 +698,21 @@ __global__ void k_tile_table_grp(u32 G, u32 low_bits, const u32* __restrict__ gr
 // tiles count for d. One workgroup per group, one thread per digit value.
 __global__ __launch_bounds__(256) void k_dir_gather(u32 low_bits, u32 last_bits, const u32* __restrict__ grp_first, const u32* __restrict__ seg_start,
                                                     const u32* __restrict__ ntiles_dev, const u32* __restrict__ colpre, const u32* __restrict__ coltot,
-                                                    const u32* __restrict__ adj, u32* __restrict__ start_dense) {
+                                                    const u32* __restrict__ adj, u32* __restrict__ start_dense, u32 w_lo = 0, u32 w_hi = 0xFFFFFFFFu) {
+    // [w_lo, w_hi): the prefixes this launch owns (a receiver's group works on its window of the prefix space: start_dense is that
+    // window's array, passed as `array - w_lo`; prefixes outside it belong to other groups and are not touched)
     const u32 g = blockIdx.x, d = threadIdx.x;
     if (d >= (1u << last_bits)) return;
     const u32 nt = *ntiles_dev, s = g >> low_bits, low = g & ((1u << low_bits) - 1u);
+    const u32 prefix = (s << (low_bits + last_bits)) | (d << low_bits) | low;
+    if (prefix < w_lo || prefix >= w_hi) return;
     if (low_bits && seg_cold(seg_start, s)) {  // its tiles were not cut at the groups: k_boundaries_cold fills these in
-        start_dense[(s << (low_bits + last_bits)) | (d << low_bits) | low] = 0xFFFFFFFFu;
+        start_dense[prefix] = 0xFFFFFFFFu;
         return;
     }
     const u32 f0 = grp_first[g], f1 = grp_first[g + 1];
     const u32 p0 = f0 < nt ? colpre[(u64)f0 * 256 + d] : coltot[d];
     const u32 p1 = f1 < nt ? colpre[(u64)f1 * 256 + d] : coltot[d];
-    const u32 prefix = (s << (low_bits + last_bits)) | (d << low_bits) | low;
     start_dense[prefix] = p1 > p0 ? adj[s * 256 + d] + p0 : 0xFFFFFFFFu;
 }
 

@@ -26,6 +26,20 @@ struct PieceInput {
     const u32* cnt = nullptr;    // host [np][256]
     const u32* pbase = nullptr;  // host [np]
     Buf<u8>* dig = nullptr;      // the first LSD pass's digit of every record (same positions), owned by the caller; reused as the side channel
+    // ... or, for ONE GROUP of a receive log that other groups still need (comm.hpp, grouped receiver): the digits are read where they
+    // are and the later passes' side channel goes to a buffer of the group's own (at least N + 64 bytes)
+    const u8* dig_in = nullptr;
+    u8* dig_out = nullptr;
+};
+
+// A group of the grouped receiver works on its WINDOW [w_lo, w_hi) of the prefix space (both multiples of 64; its records hold no
+// other prefix): start_dense, the popcounts and the bucket table cover the window only, the bitvector words are written straight
+// into the final bitvector `bv` (2^PB bits, zeroed by the caller; windows of different groups share no word), and the directory
+// that comes back is the window's: nr.nb buckets, nr.prefix (absolute values), nr.start (positions relative to the group's records),
+// nr.rank_dir relative to the window. nr.bv stays empty.
+struct DirWindow {
+    u32 w_lo = 0, w_hi = 0;
+    u64* bv = nullptr;
 };
 
 // the LSD passes behind pass A: digit widths and shifts (relative to SUFFIX_BITS) of the RB = PB - min(8, PB) remaining prefix bits
@@ -48,7 +62,7 @@ inline LsdPlan lsd_plan(const Consts& P) {
 // KRN-2 + KRN-4 over N records: stable partition by prefix, then the directory (bitvector, rank directory, bucket table
 // with the RAW run of every prefix; nr.cnt / nr.kind are allocated, not filled). The sorted records end up in rec.lo/hi.
 // `countsA`: histogram of the first pass already accumulated by KRN-1 (empty Buf = compute it here)
-template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA, Resident& nr, const PieceInput* pin = nullptr) {
+template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u64 N, Buf<u32> countsA, Resident& nr, const PieceInput* pin = nullptr, const DirWindow* win = nullptr) {
     typedef typename C::HiT HiT;
     const Consts& P = c->P;
     if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "a single batch takes fewer than 2^32-16 words (callers cut larger inserts into sub-batches)");
@@ -69,8 +83,11 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
     constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
     Buf<u32> seg_start(c->pool, 257);
     const u32 nA = std::min(8u, P.PB), RB = P.PB - nA;  // bits of pass A, bits left for the LSD passes
-    const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
-    Buf<u32> start_dense(c->pool, nprefix);
+    const u32 w_lo = win ? win->w_lo : 0u;
+    const u64 nprefix = win ? (u64)win->w_hi - win->w_lo : 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
+    if (win && ((win->w_lo | win->w_hi) & 63u)) throw Error(CBLX_EINVAL, "a directory window must be cut at multiples of 64 (internal error)");
+    Buf<u32> start_dense(c->pool, std::max<u64>(nprefix, 1));
+    u32* const sd = start_dense.get() - w_lo;  // indexed by the absolute prefix
     bool have_dense = false;
     {
         // pieces: every (segment, piece) may end in a partly filled tile
@@ -105,14 +122,17 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
         // digit side channel: a scatter also writes the NEXT pass's digit of every record (1 byte, same order). (When the
         // hi byte is dropped by pass A the remaining digits all lie in the lo word: the word has <= 72 bits.)
         Buf<u8> dig;
+        const u8* dig_rd = nullptr;  // what this pass's histogram reads ...
+        u8* dig_wr = nullptr;        // ... and where its scatter leaves the next pass's digits (the same array unless the caller split them)
         Buf<u32> seg_tot;  // pieces: records per pass-A segment
         bool have_dig = false;
         auto next_digit = [&](u32 next_pass) -> DigitBits {
             if (next_pass >= npassL) return DigitBits{0, 0};
             return DigitBits{P.SB + sh[next_pass], wid[next_pass]};
         };
-        if (pin && pin->dig) { dig = std::move(*pin->dig); have_dig = dig.get() != nullptr; }
-        else if (next_digit(0).nbits) dig = Buf<u8>(c->pool, N + 64);
+        if (pin && pin->dig_in) { dig_rd = pin->dig_in; dig_wr = pin->dig_out; have_dig = true; }
+        else if (pin && pin->dig) { dig = std::move(*pin->dig); have_dig = dig.get() != nullptr; dig_rd = dig_wr = dig.get(); }
+        else if (next_digit(0).nbits) { dig = Buf<u8>(c->pool, N + 64); dig_rd = dig_wr = dig.get(); }
         if (pin) {
             // pass A ran on the senders: segment and tile tables of the first LSD pass from the piece table
             StageTimer t(c, ST_SCAN);
@@ -131,7 +151,7 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
             const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
             const DigitBits dfn{P.SB + RB, nA};
             const DigitBits nd = next_digit(0);
-            u8* ndp = nd.nbits ? dig.get() : nullptr;
+            u8* ndp = nd.nbits ? dig_wr : nullptr;
             if (!haveA) { StageTimer t(c, ST_HIST);
               hipLaunchKernelGGL((k_radix_hist<HiT, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, tv, dfn, counts.get()); }
             { StageTimer t(c, ST_SCAN);
@@ -166,10 +186,10 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
                 const H* hin = (const H*)hi;
                 H* hout = (H*)hi2;
                 const DigitBits nd = next_digit(pass + 1);
-                u8* ndp = nd.nbits && dig.get() ? dig.get() : nullptr;
+                u8* ndp = nd.nbits && dig_wr ? dig_wr : nullptr;
                 { StageTimer t(c, ST_HIST);
                   if (have_dig)
-                      hipLaunchKernelGGL(k_radix_hist_bytes, dim3((xcd_grid(ntm) + HISTB_WAVES - 1) / HISTB_WAVES + 8), dim3(64 * HISTB_WAVES), 0, c->stream, (const u8*)dig.get(), tv, counts.get());
+                      hipLaunchKernelGGL(k_radix_hist_bytes, dim3((xcd_grid(ntm) + HISTB_WAVES - 1) / HISTB_WAVES + 8), dim3(64 * HISTB_WAVES), 0, c->stream, dig_rd, tv, counts.get());
                   else
                       hipLaunchKernelGGL((k_radix_hist<H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, counts.get()); }
                 { StageTimer t(c, ST_SCAN);
@@ -192,15 +212,16 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
                 }
                 { StageTimer t(c, ST_SCATTER);
                   hipLaunchKernelGGL((k_radix_scatter<H, H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, colpre.get(),
-                                     adj.get(), lo2, hout, nd, ndp, fused_dir ? start_dense.get() : (u32*)nullptr, P.SB, RB, low_bits, amb.get(), amb_stride); }
+                                     adj.get(), lo2, hout, nd, ndp, fused_dir ? sd : (u32*)nullptr, P.SB, RB, low_bits, amb.get(), amb_stride); }
                 if (fused_dir) {
                     StageTimer t(c, ST_DIR);
                     hipLaunchKernelGGL(k_dir_resolve<H>, grid1((u64)ntm * amb_stride, 256), dim3(256), 0, c->stream, ntd, amb_stride, (const u32*)amb.get(), tv.seg,
-                                       (const u32*)seg_start.get(), (const u64*)lo2, (const H*)hout, P.SB, RB, start_dense.get());
+                                       (const u32*)seg_start.get(), (const u64*)lo2, (const H*)hout, P.SB, RB, sd);
                     CBLX_HIP(hipStreamSynchronize(c->stream));  // amb is released at the end of this scope
                     have_dense = true;
                 }
                 have_dig = ndp != nullptr;
+                if (have_dig) dig_rd = dig_wr;  // the next pass reads what this one wrote
                 if (pin && pass == 0 && !last) {
                     // the piece tiles described the arena; from here on the segments are contiguous: the plain tile table
                     // (the column totals of the pass that made the segments were kept aside: this pass's scan overwrote coltot)
@@ -211,9 +232,9 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
                 if (last && tbl_dir) {
                     StageTimer t(c, ST_DIR);
                     hipLaunchKernelGGL(k_dir_gather, dim3(G), dim3(256), 0, c->stream, low_bits, last_bits, grp_tiles ? grp_first.get() : seg_first.get(), seg_start.get(), ntd,
-                                       colpre.get(), coltot.get(), adj.get(), start_dense.get());
+                                       colpre.get(), coltot.get(), adj.get(), sd, w_lo, win ? win->w_hi : 0xFFFFFFFFu);
                     if (grp_tiles)  // cold segments kept plain tiles: their boundaries come from their (few) records, now in lo2
-                        hipLaunchKernelGGL(k_boundaries_cold<H>, dim3(nseg, 32), dim3(256), 0, c->stream, (const u64*)lo2, (const H*)hout, P.SB, RB, seg_start.get(), start_dense.get());
+                        hipLaunchKernelGGL(k_boundaries_cold<H>, dim3(nseg, 32), dim3(256), 0, c->stream, (const u64*)lo2, (const H*)hout, P.SB, RB, seg_start.get(), sd);
                     have_dense = true;
                 }
             };
@@ -226,28 +247,30 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
     }
     rec.lo2.reset();
     rec.hi2.reset();
-    // -- KRN-4: bitvector, rank directory, bucket table
+    // -- KRN-4: bitvector, rank directory, bucket table (of the whole prefix space, or of the caller's window of it)
     {
         StageTimer t(c, ST_DIR);
         Buf<u32> popc(c->pool, nwords);
-        nr.bv = Buf<u64>(c->pool, nwords);
+        u64* bvp;
+        if (win) bvp = win->bv + (w_lo >> 6);
+        else { nr.bv = Buf<u64>(c->pool, nwords); bvp = nr.bv.get(); CBLX_HIP(hipMemsetAsync(bvp, 0, nwords * 8, c->stream)); }
         nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
-        CBLX_HIP(hipMemsetAsync(nr.bv.get(), 0, nwords * 8, c->stream));
         CBLX_HIP(hipMemsetAsync(popc.get(), 0, nwords * 4, c->stream));
         if (!have_dense) {  // boundaries from a scan of the sorted records (more groups than the table method takes)
+            if (win) throw Error(CBLX_EINVAL, "a directory window needs PREFIX_BITS >= 9 (internal error)");
             CBLX_HIP(hipMemsetAsync(start_dense.get(), 0xFF, nprefix * 4, c->stream));
             if constexpr (DROP_HI)
                 hipLaunchKernelGGL(k_boundaries_seg, grid1(ceil_div(N, 4), 256), dim3(256), 0, c->stream, lo, N, P.SB, RB, seg_start.get(), start_dense.get());
             else
                 hipLaunchKernelGGL(k_boundaries<HiT>, grid1(ceil_div(N, 4), 256), dim3(256), 0, c->stream, lo, hi, N, P.SB, P.PB, start_dense.get());
         }
-        hipLaunchKernelGGL(k_bitvector, grid1(std::max<u64>(nprefix, 64), 256), dim3(256), 0, c->stream, start_dense.get(), nprefix, nr.bv.get(), popc.get());
-        nr.nb = exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get());
+        if (nprefix) hipLaunchKernelGGL(k_bitvector, grid1(std::max<u64>(nprefix, 64), 256), dim3(256), 0, c->stream, start_dense.get(), nprefix, bvp, popc.get());
+        nr.nb = nprefix ? exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get()) : 0;
         nr.prefix = Buf<u32>(c->pool, nr.nb + 1);
         nr.start = Buf<u64>(c->pool, nr.nb + 1);
         nr.cnt = Buf<u32>(c->pool, nr.nb + 1);
         nr.kind = Buf<u8>(c->pool, nr.nb + 1);
-        hipLaunchKernelGGL(k_bucket_table, grid1(nprefix, 256), dim3(256), 0, c->stream, start_dense.get(), nprefix, nr.bv.get(), nr.rank_dir.get(), nr.prefix.get(), nr.start.get());
+        if (nprefix) hipLaunchKernelGGL(k_bucket_table, grid1(nprefix, 256), dim3(256), 0, c->stream, start_dense.get(), nprefix, bvp, nr.rank_dir.get(), nr.prefix.get(), nr.start.get(), w_lo);
         hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, nr.start.get() + nr.nb, N);
         CBLX_HIP(hipGetLastError());
     }
@@ -393,12 +416,15 @@ template <typename C> void big_stage(cblx_ctx* c, const BDesc* d_list, const u32
 }
 // After every bucket kernel of the stage: the finished long runs sit in the twin, everything else in the arena. The buffer that
 // holds more words becomes the arena; the other side's buckets are copied over (count[r] words at the same positions).
-template <typename C> void finish_twin(cblx_ctx* c, Resident& nr, Twin& tw) {
+// `force`: -1 = the rule above; 0 / 1 = the result must end up in the arena / in the twin (a group of the grouped receiver, whose
+// two buffers are a slot of the final arena and a scratch area: pipeline_group)
+template <typename C> void finish_twin(cblx_ctx* c, Resident& nr, Twin& tw, int force = -1) {
     constexpr bool WS = C::WS;
     if (!tw.used()) return;
+    if (force == 0 && tw.runs == 0) { tw = Twin(); return; }  // a preset twin nothing went through
     StageTimer t(c, ST_BBIG);
     const u64 T = d2h<u64>(c, nr.start.get() + nr.nb);
-    const bool to_twin = tw.arrivals * 2 > T;
+    const bool to_twin = force < 0 ? tw.arrivals * 2 > T : force == 1;
     const u64* src_lo = to_twin ? nr.a_lo.get() : tw.lo.get();
     const u64* src_hi = to_twin ? nr.a_hi.get() : tw.hi.get();
     u64* dst_lo = to_twin ? tw.lo.get() : nr.a_lo.get();
@@ -427,12 +453,19 @@ bool repeat_prepass() {
     const char* e = std::getenv("CBLX_REPEAT_PREPASS");
     return !(e && e[0] == '0');
 }
-template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView& old) {
+// `preset` (optional): the twin buffer of the long-run path, supplied by the caller (lo / hi set, same positions as the arena) instead of
+// allocated here; `force`: see finish_twin
+template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView& old, Twin* preset = nullptr, int force = -1) {
     typedef typename C::HiT HiT;
     const Consts& P = c->P;
     u64* a_lo = nr.a_lo.get();  // the arena (the long runs may move it to a twin buffer at the end: finish_twin)
     HiT* a_hi = C::WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr;
     Twin tw;
+    if (preset) {
+        tw = std::move(*preset);
+        tw.in_twin = Buf<u8>(c->pool, nr.nb + 1);
+        CBLX_HIP(hipMemsetAsync(tw.in_twin.get(), 0, nr.nb + 1, c->stream));
+    }
     {
     const u64 nb = nr.nb;
     Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
@@ -609,7 +642,7 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
     }
     }
     CBLX_HIP(hipGetLastError());
-    finish_twin<C>(c, nr, tw);
+    finish_twin<C>(c, nr, tw, force);
     {
         Buf<u64> total(c->pool, 1);
         CBLX_HIP(hipMemsetAsync(total.get(), 0, 8, c->stream));
@@ -700,6 +733,56 @@ template <typename C> void pipeline(cblx_ctx* c, Records& rec, u64 N, Buf<u32> c
     bucket_stage<C>(c, nr, s.view());
     CBLX_HIP(hipStreamSynchronize(c->stream));  // the batch and the table buffers are released at scope exit
     c->res = std::move(nr);
+}
+
+// ---- one GROUP of the grouped receiver (comm.hpp: sharded_insert_grouped) ----------------------------------------------------------
+// The records of the group's prefix window lie in pieces of the receive log (pass A done by the senders; `pin` describes the group's
+// share of every piece). They go through the LSD passes, the window's directory and the bucket kernels while later groups are still
+// on the wire, and end up in the group's SLOT of the final arena (`fin`, the slot's first element); `scr` is a scratch area of at
+// least N + 2 elements that plays the other ping-pong buffer (and the twin of the long-run path). Positions in `out.start` are
+// relative to the slot. A non-owning Buf (pool = nullptr) stands for a region of somebody else's allocation.
+template <typename T> Buf<T> alias_buf(T* p, size_t n) { Buf<T> b; b.pool = nullptr; b.p = p; b.n = n; return b; }
+struct GroupRegions {
+    const u64* log_lo = nullptr; const void* log_hi = nullptr;   // receive log (hi: words that keep their hi part behind pass A)
+    u64* fin_lo = nullptr; u64* fin_hi = nullptr;                // the group's slot in the final arena (hi: 8-byte elements)
+    u64* scr_lo = nullptr; u64* scr_hi = nullptr;                // scratch, >= N + 2 elements
+};
+template <typename C> void pipeline_group(cblx_ctx* c, const GroupRegions& R, const PieceInput& pin, u64 N, const DirWindow& win, Resident& out) {
+    typedef typename C::HiT HiT;
+    constexpr bool WS = C::WS;
+    constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
+    constexpr bool KEEP_HI = HiTraits<HiT>::has && !DROP_HI;  // 16-byte records through the LSD passes
+    const Consts& P = c->P;
+    const u32 npass = lsd_plan(P).npass;
+    // DEEP group (thousands of words per possible prefix: the dense low ranges of a many-GPU job at PREFIX_BITS <= 24): nearly every run
+    // takes the long-run path, whose output is the twin — so the LSD passes end in the scratch area and the twin IS the slot.
+    const bool deep = msd_takes<WS>(P.SB) && N / std::max<u64>(1, (u64)win.w_hi - win.w_lo) >= 2048;
+    u64* last_lo = deep ? R.scr_lo : R.fin_lo;   // where the last LSD pass writes
+    u64* last_hi = deep ? R.scr_hi : R.fin_hi;
+    u64* oth_lo = deep ? R.fin_lo : R.scr_lo;
+    u64* oth_hi = deep ? R.fin_hi : R.scr_hi;
+    Records rec;
+    rec.ext_lo = R.log_lo;
+    rec.ext_hi = R.log_hi;
+    // with an external source the passes write rec.lo, rec.lo2, rec.lo, ...: the last of `npass` lands in rec.lo iff npass is odd
+    const bool last_is_first = (npass & 1u) != 0;
+    rec.lo = alias_buf<u64>(last_is_first ? last_lo : oth_lo, N + 2);
+    rec.lo2 = alias_buf<u64>(last_is_first ? oth_lo : last_lo, N + 2);
+    if (KEEP_HI) {
+        rec.hi = alias_buf<u8>((u8*)(last_is_first ? last_hi : oth_hi), (N + 2) * 8);
+        rec.hi2 = alias_buf<u8>((u8*)(last_is_first ? oth_hi : last_hi), (N + 2) * 8);
+    }
+    partition_and_directory<C>(c, rec, N, Buf<u32>(), out, &pin, &win);
+    if (rec.lo.get() != last_lo) throw Error(CBLX_EDEVICE, "grouped receiver: the last pass landed in the wrong buffer (internal error)");
+    out.a_lo = alias_buf<u64>(last_lo, N + 2);
+    if (WS) out.a_hi = alias_buf<u64>(last_hi, N + 2);
+    Twin tw;
+    tw.lo = alias_buf<u64>(oth_lo, N + 2);
+    if (WS) tw.hi = alias_buf<u64>(oth_hi, N + 2);
+    bucket_stage<C>(c, out, DirView{nullptr, nullptr, nullptr, nullptr, nullptr, 0}, &tw, deep ? 1 : 0);
+    if (out.a_lo.get() != R.fin_lo) throw Error(CBLX_EDEVICE, "grouped receiver: a group did not end in its slot (internal error)");
+    out.a_lo = Buf<u64>();  // the slot belongs to the final arena
+    out.a_hi = Buf<u64>();
 }
 
 // record buffers (ping-pong) for a batch of n_new words

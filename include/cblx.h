@@ -233,6 +233,22 @@ int cblx_comm_stats(cblx_comm* comm, cblx_exchange_stats* out, int reset);
 #define CBLX_PROTO_SORTED 0u
 #define CBLX_PROTO_BINS 1u
 int cblx_comm_set_protocol(cblx_comm* comm, uint32_t protocol);
+/* The receiver of CBLX_PROTO_BINS in GROUPS (no reference counterpart; same result, another schedule): every rank's prefix range is
+ * cut into `groups` parts of about equal sampled mass, the senders' first pass also separates the groups, the data crosses the links
+ * group-major, and the receiver runs the remaining passes + bucket kernels of group g while groups g+1.. are still on the wire.
+ * 0 = default (CBLX_RECV_GROUPS in the environment, else 8), 1 = off (everything waits for the last record), at most 14. Every rank
+ * of a job sets the same. cblx_comm_groups_used: groups the last cblx_sharded_insert_seqs_device of this rank worked through
+ * (0: it took the ungrouped path — index not empty, ranges too narrow for the cuts, one rank). */
+/* Rehearsal of ONE rank of a `world`-GPU job on one GPU (dev / bench tooling, no reference counterpart: tools/emulate_wire.py). Ranks
+ * 1 .. world-1 are run one after the other on communicators that RECORD, in the process-wide store `store_id`, what each would send
+ * to rank 0; a rank-0 communicator then REPLAYS them: its collectives are answered from the records and the bytes of every exchange
+ * are copied into its receive arena on a side stream held back until a wire of `link_gbps` GB/s per source rank would have delivered
+ * them (0 = as fast as the copies go). All ranks of a rehearsal hold equally many reads and make the same calls with the same bounds
+ * and group setting. */
+int cblx_comm_init_sim(cblx_comm** out, uint32_t rank, uint32_t world, int32_t device, uint64_t store_id, double link_gbps);
+int cblx_sim_store_free(uint64_t store_id);
+int cblx_comm_set_recv_groups(cblx_comm* comm, uint32_t groups);
+int cblx_comm_groups_used(const cblx_comm* comm, uint32_t* out);
 /* CBL::insert_seq for every sequence of THIS rank's shard, into an index sharded by prefix range over the ranks of `comm`
  * (every rank makes the same call with its own shard). The shard is consumed in n_slices slices, reads
  * [slice_cuts[s], slice_cuts[s+1]) (n_slices + 1 ascending values, the same NUMBER of slices on every rank): the exchange of

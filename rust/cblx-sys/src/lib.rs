@@ -232,6 +232,10 @@ extern "C" {
     pub fn cblx_comm_last_error(comm: *const cblx_comm) -> *const c_char;
     pub fn cblx_comm_stats(comm: *mut cblx_comm, out: *mut cblx_exchange_stats, reset: c_int) -> c_int;
     pub fn cblx_comm_set_protocol(comm: *mut cblx_comm, protocol: u32) -> c_int;
+    pub fn cblx_comm_init_sim(out: *mut *mut cblx_comm, rank: u32, world: u32, device: i32, store_id: u64, link_gbps: f64) -> c_int;
+    pub fn cblx_sim_store_free(store_id: u64) -> c_int;
+    pub fn cblx_comm_set_recv_groups(comm: *mut cblx_comm, groups: u32) -> c_int;
+    pub fn cblx_comm_groups_used(comm: *const cblx_comm, out: *mut u32) -> c_int;
     pub fn cblx_sharded_insert_seqs_device(
         ctx: *mut cblx_ctx,
         comm: *mut cblx_comm,

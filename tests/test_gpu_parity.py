@@ -1947,7 +1947,7 @@ def test_native_sharded_insert_single_rank_rccl():
     comm.close()
 
 
-def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q, protocol="bins"):
+def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q, protocol="bins", groups=0):
     import torch.distributed as dist
 
     from cbl_amd import sharded
@@ -1957,12 +1957,15 @@ def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q, protoco
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         comm = cbl_amd.Comm.over_group(dist, rank, world, 0)  # host callbacks: the ranks share this GPU
+        comm.set_recv_groups(groups)  # 0: the default (8 groups per rank), 1: the ungrouped receiver
         g = cbl_amd.CBL(k, pb, canonical=canonical, device=0)
         sb = sharded.ShardedBuilder(g, dist, slices=3, comm=comm, protocol=protocol)
-        for batch, n in enumerate(per[rank]):  # two batches; the second reuses the first one's splitters
+        used = []
+        for batch, n in enumerate(per[rank]):  # two batches; the second reuses the first one's splitters (and meets a non-empty index)
             first = sum(per[r][bb] for r in range(world) for bb in range(batch)) + sum(per[r][batch] for r in range(rank))
             d_b, d_o = synth.reads_torch(23, n, L, first_read=first, device="cuda:0")
             sb.insert_seqs_device(d_b, d_o, n)
+            used.append(comm.groups_used())
         blob = sharded.gather_serialized(g.serialize(), dist)
         fblob = None
         if path:
@@ -1980,16 +1983,19 @@ def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q, protoco
                     fblob.append(("error", e.code))
                     break
         if rank == 0:
-            q.put((blob, [int(x) for x in sb.bounds], g.count(), fblob, sb.stats["sent_bytes"]))
+            q.put((blob, [int(x) for x in sb.bounds], g.count(), fblob, sb.stats["sent_bytes"], used))
         comm.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k,pb,canonical,protocol", [(2, 31, 24, False, "bins"), (3, 59, 28, True, "bins"), (4, 25, 12, False, "bins"), (8, 31, 24, False, "bins"),
-                                                           (3, 31, 28, True, "bins"), (2, 21, 16, False, "bins"), (5, 59, 28, False, "bins"),
-                                                           (2, 31, 24, False, "sorted"), (3, 59, 28, True, "sorted"), (8, 31, 24, False, "sorted")])
-def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canonical, protocol, tmp_path):
+@pytest.mark.parametrize("world,k,pb,canonical,protocol,groups", [
+    (2, 31, 24, False, "bins", 0), (3, 59, 28, True, "bins", 0), (4, 25, 12, False, "bins", 0), (8, 31, 24, False, "bins", 0),
+    (3, 31, 28, True, "bins", 0), (2, 21, 16, False, "bins", 0), (5, 59, 28, False, "bins", 0),
+    (2, 31, 24, False, "bins", 1), (3, 59, 28, True, "bins", 1), (8, 31, 24, False, "bins", 1), (3, 31, 28, True, "bins", 1),  # the ungrouped receiver
+    (2, 31, 24, False, "bins", 3), (4, 31, 28, False, "bins", 14), (3, 45, 20, True, "bins", 5), (2, 27, 9, False, "bins", 4),
+    (2, 31, 24, False, "sorted", 0), (3, 59, 28, True, "sorted", 0), (8, 31, 24, False, "sorted", 0)])
+def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canonical, protocol, groups, tmp_path):
     """The C++ orchestration of the multi-GPU build (slices, splitter choice, count exchange, grouped exchange, batch merge)
     with `world` ranks sharing this GPU and the bytes moved by host callbacks over gloo: byte-identical to the one-process
     oracle in the job's stream order (slice-major, rank-minor), and to the file's order for a file dealt block-cyclically."""
@@ -2014,10 +2020,17 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_native_worker, args=(r, world, port, k, pb, canonical, per, L, path, q, protocol)) for r in range(world)]
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, k, pb, canonical, per, L, path, q, protocol, groups)) for r in range(world)]
     for p in procs:
         p.start()
-    blob, bounds, count0, fblob, sent = q.get(timeout=900)
+    blob, bounds, count0, fblob, sent, used = q.get(timeout=900)
+    # the grouped receiver (bins protocol, empty index): rank 0 worked its range off in groups; a second batch meets a non-empty index
+    # and takes the ungrouped path; groups = 1 switches it off
+    assert used[1] == 0
+    if protocol == "sorted" or groups == 1:
+        assert used[0] == 0
+    elif pb >= 12:
+        assert 2 <= used[0] <= (groups or 8), used
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -2041,3 +2054,45 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
         oq.insert_seq(r)
     assert fblob[0] == (len(recs), of.serialize()) and fblob[1] == (len(recs), of.serialize())
     assert fblob[2] == (len(qrecs), oq.serialize())
+
+
+@pytest.mark.parametrize("world,k,pb,canonical,groups,slices,gbps", [(4, 31, 24, False, 0, 2, 0.0), (4, 31, 24, False, 1, 3, 0.0), (8, 31, 28, True, 6, 1, 2.0), (3, 59, 28, False, 4, 2, 0.0),
+                                                                     (2, 25, 16, False, 0, 1, 1.0), (8, 31, 24, False, 1, 4, 2.0)])
+def test_rehearsal_of_rank_0_on_recorded_senders(world, k, pb, canonical, groups, slices, gbps):
+    """cblx_comm_init_sim (the paced one-GPU rehearsal tools/emulate_wire.py times): ranks 1 .. W-1 record what they would send rank 0,
+    rank 0 replays it — grouped receiver or not, paced or not — and ends up with exactly its range of the job's index: the entries of
+    the one-process oracle's file (stream order slice-major, rank-minor) start with rank 0's entries."""
+    _need_gpu()
+    from cbl_amd.sharded import ShardedBuilder, _read_varint
+
+    L, nr, store = (150 if k < 59 else 250), 2500, 77 + world * 16 + groups
+    bounds = np.zeros(world - 1, dtype=np.uint32)
+    valid = False
+    cuts = [nr * s // slices for s in range(slices + 1)]
+    for r in list(range(1, world)) + [0, 0]:  # rank 0 twice: a replay can be repeated
+        d_b, d_o = synth.reads_torch(5, nr, L, first_read=r * nr, device="cuda")
+        cm = cbl_amd.Comm.sim(r, world, store, gbps if r == 0 else 0.0)
+        cm.set_recv_groups(groups)
+        g = cbl_amd.CBL(k, pb, canonical=canonical)
+        valid = g.sharded_insert_seqs_device(cm, d_b, d_o, nr, cuts, bounds, valid)
+        if r == 0:
+            used, blob0, st = cm.groups_used(), g.serialize(), cm.stats()
+        g.close()
+        cm.close()
+    cbl_amd.Comm.sim_store_free(store)
+    assert used == 0 if groups == 1 else 2 <= used <= (groups or 8)
+    assert st["recv_bytes"] > 0 and st["sent_bytes"] > 0
+    one = Oracle(k, pb, canonical)
+    for c in range(slices):
+        for r in range(world):
+            if cuts[c + 1] > cuts[c]:
+                hb, ho = synth.reads(5, cuts[c + 1] - cuts[c], L, first_read=r * nr + cuts[c])
+                one.insert_seqs(hb, ho)
+    full = one.serialize()
+    n0, p0 = _read_varint(blob0, 1)
+    nf, pf = _read_varint(full, 1)
+    assert 0 < n0 < nf and blob0[0] == full[0]
+    assert full[pf:pf + len(blob0) - p0] == blob0[p0:]
+    # ... and the next entry of the job's file belongs to rank 1: its prefix is at or above the bound
+    nxt, _ = _read_varint(full, pf + len(blob0) - p0)
+    assert nxt >= int(bounds[0])

@@ -29,7 +29,7 @@ def _port():
     return p
 
 
-def _worker(rank, world, port, k, pb, canonical, protocol, native, per, L, q):
+def _worker(rank, world, port, k, pb, canonical, protocol, native, per, L, q, groups=0):
     import torch.distributed as dist
 
     from cbl_amd import sharded
@@ -44,6 +44,7 @@ def _worker(rank, world, port, k, pb, canonical, protocol, native, per, L, q):
             box = [cbl_amd.Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             comm = cbl_amd.Comm.rccl(box[0], rank, world, rank)
+            comm.set_recv_groups(groups)  # 0: the default (grouped receiver, 8 groups per rank), 1: everything waits for the last record
         g = cbl_amd.CBL(k, pb, canonical=canonical, device=rank)
         sb = sharded.ShardedBuilder(g, dist, slices=3, protocol=protocol, comm=comm)
         for batch, n in enumerate(per[rank]):
@@ -70,10 +71,12 @@ def _worker(rank, world, port, k, pb, canonical, protocol, native, per, L, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k,pb,canonical,protocol,native", [(2, 31, 24, False, "sorted", False), (2, 31, 24, True, "words", False), (2, 59, 28, False, "sorted", True),
-                                                                  (4, 31, 24, False, "sorted", True), (8, 31, 28, False, "sorted", False),
-                                                                  (2, 31, 24, False, "bins", True), (4, 59, 28, True, "bins", True), (8, 31, 28, False, "bins", True)])
-def test_sharded_build_and_merge_on_real_rccl(world, k, pb, canonical, protocol, native):
+@pytest.mark.parametrize("world,k,pb,canonical,protocol,native,groups", [
+    (2, 31, 24, False, "sorted", False, 0), (2, 31, 24, True, "words", False, 0), (2, 59, 28, False, "sorted", True, 0),
+    (4, 31, 24, False, "sorted", True, 0), (8, 31, 28, False, "sorted", False, 0),
+    (2, 31, 24, False, "bins", True, 0), (4, 59, 28, True, "bins", True, 0), (8, 31, 28, False, "bins", True, 0),
+    (2, 31, 24, False, "bins", True, 1), (8, 31, 28, False, "bins", True, 1), (4, 31, 24, True, "bins", True, 3)])
+def test_sharded_build_and_merge_on_real_rccl(world, k, pb, canonical, protocol, native, groups):
     if _ngpu() < world:
         pytest.skip(f"needs {world} GPUs in one box, {_ngpu()} visible (RCCL refuses two ranks on one GPU)")
     import torch.multiprocessing as mp
@@ -85,7 +88,7 @@ def test_sharded_build_and_merge_on_real_rccl(world, k, pb, canonical, protocol,
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, k, pb, canonical, protocol, native, per, L, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, k, pb, canonical, protocol, native, per, L, q, groups)) for r in range(world)]
     for p in procs:
         p.start()
     blob, mblob, sent = q.get(timeout=900)
