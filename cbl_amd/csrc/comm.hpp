@@ -896,8 +896,9 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     eh0.nd = W; eh0.SB = P.SB; eh0.PB = P.PB; eh0.binRB = RB; eh0.cut_tab = d_tab.get();
     const u32 my_lo = M.bin_lo[me], my_cells = M.bin_lo[me + 1] - M.bin_lo[me], NG = M.ngroups[me];
     // cells (= my bins) of every one of my groups
+    // (a cut that falls exactly on a segment boundary leaves one bin number unused: such a cell holds nothing and belongs nowhere)
     std::vector<u32> gc0(NG + 1, my_cells);
-    for (u32 cl = my_cells; cl-- > 0;) gc0[M.grp_of[M.iv_of[my_lo + cl]]] = cl;
+    for (u32 cl = my_cells; cl-- > 0;) if (M.iv_of[my_lo + cl] != 0xFFFFFFFFu) gc0[M.grp_of[M.iv_of[my_lo + cl]]] = cl;
     for (int g = (int)NG - 1; g >= 0; --g) if (gc0[g] > gc0[g + 1]) gc0[g] = gc0[g + 1];
     u32 Gmax = 0;
     for (u32 d = 0; d < W; ++d) Gmax = std::max(Gmax, M.ngroups[d]);
@@ -1089,8 +1090,10 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     auto group_first_prefix = [&](u32 g) -> u64 {
         if (g >= NG) return me + 1 < W ? ((u64)bounds[me] + 63) & ~63ull : nprefix;
         if (g == 0) return me ? (u64)bounds[me - 1] & ~63ull : 0ull;
-        const u32 iv = M.iv_of[my_lo + gc0[g]];
-        return iv ? (u64)M.cuts[iv - 1] : 0ull;
+        u32 cl = gc0[g];
+        while (cl + 1 < my_cells && M.iv_of[my_lo + cl] == 0xFFFFFFFFu) ++cl;  // (an unused bin number in front of the group's first cell)
+        const u32 iv = M.iv_of[my_lo + cl];
+        return iv && iv != 0xFFFFFFFFu ? (u64)M.cuts[iv - 1] : 0ull;
     };
     for (u32 g = 0; g < NG; ++g) {
         gbase[g + 1] = gbase[g] + gN[g];
@@ -1104,6 +1107,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
             pb_g[p] = (u32)(pbase[p] + before);
             for (u32 cl = gc0[g]; cl < gc0[g + 1]; ++cl) {
                 const u32 v = M.v_of[my_lo + cl];
+                if (v == 0xFFFFFFFFu) { if (pcnt[p * 256 + cl]) throw Error(CBLX_EDEVICE, "grouped receiver: words in a bin no prefix maps to (internal error)"); continue; }
                 if (cnt_g[p * 256 + v] && pcnt[p * 256 + cl]) throw Error(CBLX_EDEVICE, "grouped receiver: a segment occurs in two cells of one group (internal error)");
                 cnt_g[p * 256 + v] += pcnt[p * 256 + cl];
             }

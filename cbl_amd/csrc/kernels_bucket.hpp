@@ -250,12 +250,14 @@ template <bool WS, int LPB>
 __global__ __launch_bounds__(256) void k_merge_gather(u64 nb, const u64* __restrict__ start, const u32* __restrict__ m_cs, const u64* __restrict__ m_sstart,
                                                       const u64* __restrict__ m_ostart, const u64* __restrict__ s_lo, const u64* __restrict__ s_hi,
                                                       const u64* __restrict__ o_lo, const u64* __restrict__ o_hi, u64* __restrict__ out_lo,
-                                                      u64* __restrict__ out_hi) {
+                                                      u64* __restrict__ out_hi, const u8* __restrict__ skip_skind = nullptr, const u8* __restrict__ skip_okind = nullptr) {
     const u64 r = ((u64)blockIdx.x * 256 + threadIdx.x) / LPB;
     if (r >= nb) return;
     const u32 lane = threadIdx.x & (LPB - 1);
     const u64 d0 = start[r];
     const u32 c = (u32)(start[r + 1] - d0), cs = m_cs[r];
+    // Trie |= Trie: k_bucket_union merges the two stored lists straight into the run — nothing to copy here
+    if (skip_skind && cs != 0 && cs != c && skip_skind[r] == KIND_TRIE && skip_okind[r] == KIND_TRIE) return;
     const u64 ss = m_sstart[r], os = m_ostart[r];
     for (u32 j = lane; j < c; j += LPB) {
         const bool from_self = j < cs;
@@ -266,9 +268,10 @@ __global__ __launch_bounds__(256) void k_merge_gather(u64 nb, const u64* __restr
 }
 // one-sided buckets are final after the gather (self-only: untouched; other-only: cloned as stored); both-sided ones
 // go to the merge epilogue of the bucket kernel of their length class
+static const int CLS_UNION = CLS_S16;  // `self |= other` only (its classification has no small classes): Trie |= Trie by merge path (k_bucket_union)
 __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify_merge(u64 nb, u32 med_max_threads, const u64* __restrict__ raw_start, const u32* __restrict__ m_cs,
                                  const u8* __restrict__ m_skind, const u8* __restrict__ m_okind, u32* __restrict__ out_count,
-                                 u8* __restrict__ out_kind, BDesc* __restrict__ lists, u32* __restrict__ list_n) {
+                                 u8* __restrict__ out_kind, BDesc* __restrict__ lists, u32* __restrict__ list_n, bool union_path = false) {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     int cls = -1;
     u64 c = 0;
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify_merge(u64 nb, u32
         ks = m_skind[r];
         if (co == 0) { out_count[r] = cs; out_kind[r] = ks; }
         else if (cs == 0) { out_count[r] = co; out_kind[r] = m_okind[r]; }
+        else if (union_path && ks == KIND_TRIE && m_okind[r] == KIND_TRIE) cls = CLS_UNION;  // two ascending lists, any length: merged, not sorted again
         else if (c <= 16 * MED_ITEMS) cls = CLS_M16;   // workgroup size follows the run length, as in k_classify
         else if (c <= 64 * MED_ITEMS) cls = CLS_M64;
         else if (c <= 128 * MED_ITEMS) cls = CLS_M128;
@@ -290,6 +294,116 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify_merge(u64 nb, u32
     }
     const u32 slot = block_append<CLASSIFY_THREADS, CLS_N>(cls, list_n);
     if (cls >= 0) lists[(u64)cls * nb + slot] = BDesc{raw_start[r], (u32)c | (ks == KIND_TRIE ? BDESC_TRIE : 0u), (u32)r};
+}
+
+// ---- Trie |= Trie: the union of two ASCENDING lists is a merge, not a sort (/root/reference/src/trievec/set_ops.rs:43-71 merges two
+// sorted iterators with two pointers; src/trievec/mod.rs:118-136 inserts what self lacks) ------------------------------------------------
+// One workgroup per bucket, any length. Rounds of UNI_TILE outputs: the next <= UNI_TILE words of either list are staged in LDS
+// (coalesced loads from the two indexes' own arenas — the merged run is written, never read), every thread finds the co-rank of the
+// END of its 8 consecutive outputs by a binary search on the round's diagonal (merge path; ties take self's copy first) and gets its
+// start from its neighbour, loads 8 + 8 candidates into registers and merges them with a fixed network — min(a[k], b[7-k]) leaves the
+// 8 smallest as a bitonic sequence, three compare-exchange stages sort it — so no lane follows data-dependent control flow. The
+// outputs go back to LDS (one padding word per 8: a lane's 64-byte row would otherwise hit the banks of its neighbours'), are
+// compared with their predecessor there (equal = other's copy of a word self holds: dropped) and leave compacted in order. The
+// co-rank of the round's last output says how far either list was consumed. HBM traffic: every word read once (twice in a long
+// bucket: a round loads UNI_TILE words of both lists and consumes UNI_TILE in all; the L2 holds the rest), the union written once.
+static const int UNI_THREADS = 256, UNI_ITEMS = 8, UNI_TILE = UNI_THREADS * UNI_ITEMS;
+__device__ __forceinline__ u32 uni_pad(u32 i) { return i + (i >> 3); }
+__device__ __forceinline__ void uni_cmpx(u64& a, u64& b) { const u64 lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; }
+__global__ __launch_bounds__(UNI_THREADS) void k_bucket_union(const BDesc* __restrict__ list, const u32* __restrict__ list_n, const u32* __restrict__ m_cs,
+                                                              const u64* __restrict__ m_sstart, const u64* __restrict__ m_ostart, const u64* __restrict__ s_lo,
+                                                              const u64* __restrict__ o_lo, u64* __restrict__ out_lo, u32 SB, u32* __restrict__ out_count,
+                                                              u8* __restrict__ out_kind) {
+    constexpr int NW = UNI_THREADS / 64;
+    constexpr u32 T = UNI_TILE;
+    __shared__ u64 s_in[T * 2 + (T * 2) / 8 + 8];  // A's chunk at logical [0, T), B's at [T, 2T); later the round's outputs at [0, T)
+    __shared__ u32 s_split[NW + 1];
+    __shared__ u32 s_wtot[NW + 1];
+    if (blockIdx.x >= *list_n) return;
+    const BDesc dsc = list[blockIdx.x];
+    const u32 r = dsc.r, c = dsc.c & BDESC_LEN_MASK, cs = m_cs[r], co = c - cs;
+    const u64* __restrict__ A = s_lo + m_sstart[r];
+    const u64* __restrict__ B = o_lo + m_ostart[r];
+    u64* __restrict__ dst = out_lo + dsc.start;
+    const u64 mask = SB >= 64 ? ~0ull : ((1ull << SB) - 1ull);
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    u32 ia = 0, ib = 0, written = 0;
+    u64 carry = 0;
+    bool have_carry = false;
+    while (ia < cs || ib < co) {
+        const u32 na = cs - ia < T ? cs - ia : T, nb = co - ib < T ? co - ib : T, nout = na + nb < T ? na + nb : T;
+        for (u32 i = tid; i < na; i += UNI_THREADS) s_in[uni_pad(i)] = A[ia + i] & mask;
+        for (u32 i = tid; i < nb; i += UNI_THREADS) s_in[uni_pad(T + i)] = B[ib + i] & mask;
+        __syncthreads();
+        // co-rank of the end of this thread's outputs: how many of the first d1 outputs come from A
+        const u32 d0 = tid * UNI_ITEMS < nout ? tid * UNI_ITEMS : nout, d1 = (tid + 1) * UNI_ITEMS < nout ? (tid + 1) * UNI_ITEMS : nout;
+        u32 lo = d1 > nb ? d1 - nb : 0u, hi = d1 < na ? d1 : na;
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (s_in[uni_pad(mid)] <= s_in[uni_pad(T + d1 - 1 - mid)]) lo = mid + 1; else hi = mid;
+        }
+        const u32 i1 = lo;
+        if (lane == 63) s_split[w + 1] = i1;
+        if (tid == 0) s_split[0] = 0;
+        __syncthreads();
+        u32 i0 = __shfl_up(i1, 1, 64);
+        if (lane == 0) i0 = s_split[w];
+        const u32 iend = s_split[NW];  // co-rank of nout (the last thread's end)
+        const u32 j0 = d0 - i0;
+        u64 a[UNI_ITEMS], b[UNI_ITEMS];
+#pragma unroll
+        for (int k = 0; k < UNI_ITEMS; ++k) {
+            const u32 x = i0 + k, y = j0 + k;
+            a[k] = s_in[uni_pad(x < na ? x : 0u)];
+            b[k] = s_in[uni_pad(T + (y < nb ? y : 0u))];
+            if (x >= na) a[k] = ~0ull;
+            if (y >= nb) b[k] = ~0ull;
+        }
+        u64 o[UNI_ITEMS];
+#pragma unroll
+        for (int k = 0; k < UNI_ITEMS; ++k) o[k] = a[k] < b[UNI_ITEMS - 1 - k] ? a[k] : b[UNI_ITEMS - 1 - k];
+#pragma unroll
+        for (int st = UNI_ITEMS / 2; st >= 1; st >>= 1)
+#pragma unroll
+            for (int k = 0; k < UNI_ITEMS; ++k)
+                if ((k & st) == 0) uni_cmpx(o[k], o[k + st]);
+        __syncthreads();  // every read of the chunks is done: the outputs take their place
+#pragma unroll
+        for (int k = 0; k < UNI_ITEMS; ++k) s_in[uni_pad(tid * UNI_ITEMS + k)] = o[k];
+        __syncthreads();
+        // ordered compaction of the outputs that differ from their predecessor (wave-contiguous slices keep the order)
+        u64 v[UNI_ITEMS];
+        bool head[UNI_ITEMS];
+        u32 wh = 0;
+#pragma unroll
+        for (int j = 0; j < UNI_ITEMS; ++j) {
+            const u32 p = w * (64 * UNI_ITEMS) + j * 64 + lane;
+            const bool live = p < nout;
+            v[j] = s_in[uni_pad(live ? p : 0u)];
+            const u64 u = s_in[uni_pad((live && p) ? p - 1 : 0u)];
+            head[j] = live && (p ? v[j] != u : (!have_carry || v[j] != carry));
+            wh += (u32)__builtin_popcountll(__ballot(head[j]));
+        }
+        const u64 last = s_in[uni_pad(nout - 1)];
+        if (lane == 0) s_wtot[w] = wh;
+        __syncthreads();
+        u32 run = 0, tot = 0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) { const u32 t = s_wtot[ww]; if ((u32)ww < w) run += t; tot += t; }
+#pragma unroll
+        for (int j = 0; j < UNI_ITEMS; ++j) {
+            const u64 bal = __ballot(head[j]);
+            if (head[j]) dst[written + run + mbcnt(bal)] = v[j];
+            run += (u32)__builtin_popcountll(bal);
+        }
+        carry = last;
+        have_carry = true;
+        written += tot;
+        ia += iend;
+        ib += nout - iend;
+        __syncthreads();  // the next round overwrites the staging area and the split table
+    }
+    if (tid == 0) { out_count[r] = written; out_kind[r] = KIND_TRIE; }
 }
 
 // ---- suffix access --------------------------------------------------------------------------------------

@@ -729,6 +729,129 @@ __global__ __launch_bounds__(256) void k_boundaries_cold(const u64* __restrict__
     }
 }
 
+// ---- PREFIX_BITS > 24: the last 1 .. 4 prefix bits without a fourth pass over HBM through the scatter kernel ----------------------
+// The partition passes sort 24 prefix bits (A + two LSD passes, bucket starts from the last pass's tables); a run of equal 24-bit
+// prefix — a few hundred to a few thousand records, up to 2^xb real buckets interleaved in stream order — is then split by its last
+// xb prefix bits by ONE workgroup that stages the run (tile by tile of SPLIT_TILE records) in LDS in its final order and writes it
+// out front to back: whole cache lines, where the scatter kernel's 16-record runs leave partial ones (that is what a
+// scatter pass costs over a copy). Stable (ballot ranking, as tile_rank): the order inside a bucket stays the stream order. A run of
+// several tiles is counted first (its records are read twice; the second read comes from the L2). The kernel also writes the bucket
+// starts of the run's 2^xb prefixes (EMPTY32 for the absent ones) — the fused directory of the old last pass, without candidates to
+// settle. Reads `in`, writes `out` (the ping-pong partner) at the same run positions.
+static const int SPLIT_THREADS = 256, SPLIT_ITEMS = 8, SPLIT_TILE = SPLIT_THREADS * SPLIT_ITEMS, SPLIT_NW = SPLIT_THREADS / 64;
+template <typename H>
+__global__ __launch_bounds__(SPLIT_THREADS) void k_prefix_split(u64 nruns, const u32* __restrict__ run_prefix, const u64* __restrict__ run_start, const u64* __restrict__ in_lo,
+                                                                const H* __restrict__ in_hi, u64* __restrict__ out_lo, H* __restrict__ out_hi, u32 SB, u32 xb,
+                                                                u32* __restrict__ start_dense /* indexed by the absolute prefix */) {
+    constexpr bool HAS = HiTraits<H>::has;
+    __shared__ u64 s_lo[SPLIT_TILE];
+    __shared__ u64 s_hi[HAS ? SPLIT_TILE : 1];
+    __shared__ u32 s_wcnt[SPLIT_NW * 16];  // per wave and digit: records seen so far in the tile
+    __shared__ u32 s_tbase[16];            // tile-local first slot of every digit
+    __shared__ u32 s_rbase[16];            // run: records of smaller digits
+    __shared__ u32 s_roff[16];             // run: records of the digit in earlier tiles
+    const u64 run = blockIdx.x;
+    if (run >= nruns) return;
+    const u64 s0 = run_start[run];
+    const u32 c = (u32)(run_start[run + 1] - s0), NB = 1u << xb;
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const u32 ntiles = (c + SPLIT_TILE - 1) / SPLIT_TILE;
+    const u64* __restrict__ lo_r = in_lo + s0;
+    const H* __restrict__ hi_r = HAS ? in_hi + s0 : in_hi;
+    if (tid < 16) { s_rbase[tid] = 0; s_roff[tid] = 0; }
+    __syncthreads();
+    // one tile: load, rank by digit (stable); `place`: stage in LDS in final order and write out
+    auto tile_pass = [&](u32 t, bool place) {
+        const u32 t0 = t * SPLIT_TILE, n_tile = c - t0 < (u32)SPLIT_TILE ? c - t0 : (u32)SPLIT_TILE;
+        const u32 R = (n_tile + SPLIT_THREADS - 1) / SPLIT_THREADS, EPW = 64 * R;  // wave-contiguous slices
+        if (tid < SPLIT_NW * 16) s_wcnt[tid] = 0;
+        __syncthreads();
+        u64 klo[SPLIT_ITEMS];
+        u64 khi[HAS ? SPLIT_ITEMS : 1];
+        u32 dp[SPLIT_ITEMS];
+        u32* my = s_wcnt + w * 16;
+#pragma unroll
+        for (int j = 0; j < SPLIT_ITEMS; ++j) {
+            const u32 e = w * EPW + j * 64 + lane;
+            const bool valid = (u32)j < R && e < n_tile;
+            klo[j] = lo_r[t0 + (valid ? e : 0u)];
+            if constexpr (HAS) khi[j] = (u64)hi_r[t0 + (valid ? e : 0u)];
+            dp[j] = valid ? (u32)(get_bits(klo[j], HAS ? khi[j] : 0ull, SB, xb)) : 0xFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < SPLIT_ITEMS; ++j) {
+            if ((u32)j < R) {
+                const u32 d = dp[j];
+                const bool valid = d != 0xFFu;
+                u64 m = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const u64 bal = __ballot(valid && ((d >> b) & 1u));
+                    m &= ((d >> b) & 1u) ? bal : ~bal;
+                }
+                const u32 lower = mbcnt(m), tot = (u32)__builtin_popcountll(m);
+                const u32 old = valid ? my[d] : 0u;
+                __builtin_amdgcn_wave_barrier();
+                if (valid && lower == 0) my[d] = old + tot;
+                __builtin_amdgcn_wave_barrier();
+                dp[j] = valid ? (d << 16) | (old + lower) : 0xFFFFFFFFu;
+            }
+        }
+        __syncthreads();
+        if (tid < 16) {  // per digit: exclusive scan across the waves, tile totals
+            u32 runc = 0;
+#pragma unroll
+            for (int ww = 0; ww < SPLIT_NW; ++ww) { const u32 x = s_wcnt[ww * 16 + tid]; s_wcnt[ww * 16 + tid] = runc; runc += x; }
+            s_tbase[tid] = runc;  // (the tile's count of the digit, turned into its first slot below)
+        }
+        __syncthreads();
+        if (!place) {  // counting pass of a long run
+            if (tid < 16) s_rbase[tid] += s_tbase[tid];
+            __syncthreads();
+            return;
+        }
+        u32 tcnt = 0;
+        if (tid < 16) tcnt = s_tbase[tid];
+        __syncthreads();
+        if (tid == 0) { u32 acc = 0; for (u32 k = 0; k < 16; ++k) { const u32 x = s_tbase[k]; s_tbase[k] = acc; acc += x; } }
+        __syncthreads();
+        if (ntiles == 1 && tid < 16) s_rbase[tid] = s_tbase[tid];  // a one-tile run: the run's digit starts are the tile's
+#pragma unroll
+        for (int j = 0; j < SPLIT_ITEMS; ++j) {
+            if ((u32)j < R && dp[j] != 0xFFFFFFFFu) {
+                const u32 d = dp[j] >> 16, pos = s_tbase[d] + my[d] + (dp[j] & 0xFFFFu);
+                s_lo[pos] = klo[j];
+                if constexpr (HAS) s_hi[pos] = khi[j];
+            }
+        }
+        __syncthreads();
+        // slot i of the staged tile holds digit d = the one whose [tbase[d], tbase[d+1]) contains i; it leaves for
+        // s0 + rbase[d] + roff[d] + (i - tbase[d]). A one-tile run is written front to back (rbase = tbase, roff = 0).
+        for (u32 i = tid; i < n_tile; i += SPLIT_THREADS) {
+            const u64 v = s_lo[i];
+            u64 h = 0;
+            if constexpr (HAS) h = s_hi[i];
+            const u32 d = (u32)get_bits(v, h, SB, xb);
+            const u64 dst = s0 + s_rbase[d] + s_roff[d] + (i - s_tbase[d]);
+            out_lo[dst] = v;
+            if constexpr (HAS) out_hi[dst] = (H)h;
+        }
+        __syncthreads();
+        if (tid < 16) s_roff[tid] += tcnt;
+        __syncthreads();
+    };
+    if (ntiles > 1) {
+        for (u32 t = 0; t < ntiles; ++t) tile_pass(t, false);
+        if (tid == 0) { u32 acc = 0; for (u32 k = 0; k < 16; ++k) { const u32 x = s_rbase[k]; s_rbase[k] = acc; acc += x; } }
+        __syncthreads();
+        for (u32 t = 0; t < ntiles; ++t) tile_pass(t, true);
+    } else {
+        tile_pass(0, true);
+    }
+    // bucket starts of the run's prefixes: digit d starts at s0 + rbase[d] and holds roff[d] records
+    if (tid < NB) start_dense[((u64)run_prefix[run] << xb) | tid] = s_roff[tid] ? (u32)(s0 + s_rbase[tid]) : 0xFFFFFFFFu;
+}
+
 // ---- tiles of the first LSD pass over records that ARRIVE in pieces (receiver of the multi-GPU build) ------------------
 // A piece = what one (slice, source rank) sent: its records for this rank, already sorted by the pass-A segment (segment
 // = top prefix bits), cnt[piece][256] records per segment, first record at arena position pbase[piece]. Stream order

@@ -42,15 +42,29 @@ struct DirWindow {
     u64* bv = nullptr;
 };
 
-// the LSD passes behind pass A: digit widths and shifts (relative to SUFFIX_BITS) of the RB = PB - min(8, PB) remaining prefix bits
-struct LsdPlan { u32 npass = 0, wid[4] = {0, 0, 0, 0}, sh[5] = {0, 0, 0, 0, 0}; };
+// the LSD passes behind pass A: digit widths and shifts (relative to SUFFIX_BITS) of the remaining prefix bits
+#ifndef CBLX_PREFIX_SPLIT
+#define CBLX_PREFIX_SPLIT 1  // PREFIX_BITS > 24: the last PB - 24 bits by k_prefix_split instead of a third LSD pass (0: three LSD passes of 7 + 7 + 6 bits)
+#endif
+struct LsdPlan {
+    u32 npass = 0, wid[4] = {0, 0, 0, 0}, sh[5] = {0, 0, 0, 0, 0};
+    u32 xb = 0;  // lowest prefix bits left to k_prefix_split (the passes sort the PB - xb bits above them)
+    u32 total() const { return npass + (xb ? 1u : 0u); }  // times the records change buffers behind pass A
+};
 inline LsdPlan lsd_plan(const Consts& P) {
-    // Up to two passes: 8 bits, then the rest (the group-cut tiles of the last pass are built for that shape). Three passes
-    // (PREFIX_BITS > 24): the bits are spread evenly — 20 bits go as 7 + 7 + 6 instead of 8 + 8 + 4: a pass costs nearly the
-    // same whatever its width (4.0 ms at 4 bits, 4.4 at 8 on 1.2 G records), but one that also writes the digit side channel
-    // costs 5.15 ms at 8 bits and 4.45 at 7 (narrower digits).
+    // Up to two passes: 8 bits, then the rest (the group-cut tiles of the last pass are built for that shape). PREFIX_BITS > 24:
+    // 8 + 8 bits by two passes with the directory of 2^24 "super-prefixes" from the second one's tables, and the last 1 .. 4 bits
+    // by k_prefix_split (a run of equal 24-bit prefix staged in LDS, written back in order: copy speed). Three passes
+    // of 7 + 7 + 6 bits before that (CBLX_PREFIX_SPLIT=0): a pass costs nearly the same whatever its width.
     LsdPlan L;
     const u32 RB = P.PB - std::min(8u, P.PB);
+    if (CBLX_PREFIX_SPLIT && P.PB > 24) {
+        L.xb = P.PB - 24;
+        L.npass = 2;
+        L.wid[0] = L.wid[1] = 8;
+        L.sh[0] = L.xb; L.sh[1] = L.xb + 8; L.sh[2] = L.xb + 16;
+        return L;
+    }
     L.npass = (RB + 7) / 8;
     for (u32 i = 0; i < L.npass; ++i) {
         L.wid[i] = L.npass <= 2 ? std::min(8u, RB - 8 * i) : RB / L.npass + (i < RB % L.npass ? 1u : 0u);
@@ -82,24 +96,30 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
     //    Per pass: tile histogram, column scan, per-segment adjust, LDS-staged scatter.
     constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
     Buf<u32> seg_start(c->pool, 257);
-    const u32 nA = std::min(8u, P.PB), RB = P.PB - nA;  // bits of pass A, bits left for the LSD passes
+    // PREFIX_BITS > 24: the passes sort the top PBs = 24 prefix bits ("super-prefixes": the xb bits below them count as suffix here,
+    // SBs), their directory comes from the last pass's tables, and k_prefix_split finishes the job run by run (below)
+    const LsdPlan LP = lsd_plan(P);
+    const u32 xb = LP.xb, PBs = P.PB - xb, SBs = P.SB + xb;
+    const u32 nA = std::min(8u, PBs), RB = PBs - nA;  // bits of pass A, bits left for the LSD passes
     const u32 w_lo = win ? win->w_lo : 0u;
     const u64 nprefix = win ? (u64)win->w_hi - win->w_lo : 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
     if (win && ((win->w_lo | win->w_hi) & 63u)) throw Error(CBLX_EINVAL, "a directory window must be cut at multiples of 64 (internal error)");
-    Buf<u32> start_dense(c->pool, std::max<u64>(nprefix, 1));
-    u32* const sd = start_dense.get() - w_lo;  // indexed by the absolute prefix
+    // the directory the PASSES produce: of the prefixes (xb = 0), or of the super-prefixes of the window
+    const u32 sw_lo = w_lo >> xb;
+    const u64 sw_hi = win ? ((u64)win->w_hi + ((1u << xb) - 1u)) >> xb : 1ull << PBs, nsuper = sw_hi - sw_lo;
+    Buf<u32> start_dense(c->pool, std::max<u64>(nsuper, 1));
+    u32* sd = start_dense.get() - sw_lo;  // indexed by the absolute (super-)prefix
     bool have_dense = false;
     {
         // pieces: every (segment, piece) may end in a partly filled tile
         const u32 ntiles = (u32)ceil_div(N, RDX_TILE), nt_max = ntiles + 256 * (pin ? std::max(1u, pin->np) : 1u);
-        const LsdPlan LP = lsd_plan(P);
         const u32 npassL = LP.npass, nseg = 1u << nA;
         const u32 (&wid)[4] = LP.wid;
         const u32 (&sh)[5] = LP.sh;
         if (pin && (npassL == 0 || nA != 8)) throw Error(CBLX_EINVAL, "records in pieces need PREFIX_BITS >= 9 (internal error)");
         // The last LSD pass cuts its tiles at (segment x lower digits) groups when there are few enough of them; the
         // bucket directory then comes from that pass's tables (k_dir_gather) instead of a scan of the sorted records.
-        const u32 low_bits = npassL ? sh[npassL - 1] : 0, last_bits = RB - low_bits;
+        const u32 low_bits = npassL ? sh[npassL - 1] - xb : 0, last_bits = RB - low_bits;
         const bool tbl_dir = npassL >= 1 && nA + low_bits <= 16;
         const bool grp_tiles = tbl_dir && low_bits > 0;  // low_bits = 0: the groups are the segments (existing tile table)
         const u32 G = nseg << low_bits, nt_maxC = grp_tiles ? ntiles + G + 256 : nt_max;
@@ -149,7 +169,7 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
             CBLX_HIP(hipStreamSynchronize(c->stream));  // the piece tables are released here
         } else {   // pass A
             const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
-            const DigitBits dfn{P.SB + RB, nA};
+            const DigitBits dfn{SBs + RB, nA};
             const DigitBits nd = next_digit(0);
             u8* ndp = nd.nbits ? dig_wr : nullptr;
             if (!haveA) { StageTimer t(c, ST_HIST);
@@ -208,15 +228,15 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
                 Buf<u32> amb;
                 if (fused_dir) {
                     amb = Buf<u32>(c->pool, (size_t)ntm * amb_stride);
-                    CBLX_HIP(hipMemsetAsync(start_dense.get(), 0xFF, nprefix * 4, c->stream));
+                    CBLX_HIP(hipMemsetAsync(start_dense.get(), 0xFF, nsuper * 4, c->stream));
                 }
                 { StageTimer t(c, ST_SCATTER);
                   hipLaunchKernelGGL((k_radix_scatter<H, H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, colpre.get(),
-                                     adj.get(), lo2, hout, nd, ndp, fused_dir ? sd : (u32*)nullptr, P.SB, RB, low_bits, amb.get(), amb_stride); }
+                                     adj.get(), lo2, hout, nd, ndp, fused_dir ? sd : (u32*)nullptr, SBs, RB, low_bits, amb.get(), amb_stride); }
                 if (fused_dir) {
                     StageTimer t(c, ST_DIR);
                     hipLaunchKernelGGL(k_dir_resolve<H>, grid1((u64)ntm * amb_stride, 256), dim3(256), 0, c->stream, ntd, amb_stride, (const u32*)amb.get(), tv.seg,
-                                       (const u32*)seg_start.get(), (const u64*)lo2, (const H*)hout, P.SB, RB, sd);
+                                       (const u32*)seg_start.get(), (const u64*)lo2, (const H*)hout, SBs, RB, sd);
                     CBLX_HIP(hipStreamSynchronize(c->stream));  // amb is released at the end of this scope
                     have_dense = true;
                 }
@@ -232,9 +252,9 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
                 if (last && tbl_dir) {
                     StageTimer t(c, ST_DIR);
                     hipLaunchKernelGGL(k_dir_gather, dim3(G), dim3(256), 0, c->stream, low_bits, last_bits, grp_tiles ? grp_first.get() : seg_first.get(), seg_start.get(), ntd,
-                                       colpre.get(), coltot.get(), adj.get(), sd, w_lo, win ? win->w_hi : 0xFFFFFFFFu);
+                                       colpre.get(), coltot.get(), adj.get(), sd, sw_lo, win ? (u32)std::min<u64>(sw_hi, 0xFFFFFFFFull) : 0xFFFFFFFFu);
                     if (grp_tiles)  // cold segments kept plain tiles: their boundaries come from their (few) records, now in lo2
-                        hipLaunchKernelGGL(k_boundaries_cold<H>, dim3(nseg, 32), dim3(256), 0, c->stream, (const u64*)lo2, (const H*)hout, P.SB, RB, seg_start.get(), sd);
+                        hipLaunchKernelGGL(k_boundaries_cold<H>, dim3(nseg, 32), dim3(256), 0, c->stream, (const u64*)lo2, (const H*)hout, SBs, RB, seg_start.get(), sd);
                     have_dense = true;
                 }
             };
@@ -242,9 +262,45 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
             advance();
         }
         CBLX_HIP(hipGetLastError());
-        if (lo == rec.lo2.get()) { std::swap(rec.lo, rec.lo2); std::swap(rec.hi, rec.hi2); }  // final data -> rec.lo/hi
         CBLX_HIP(hipStreamSynchronize(c->stream));  // the pass tables are released here
     }
+    if (xb) {
+        // -- the last xb prefix bits: every run of equal super-prefix split in LDS, written to the other buffer in final order, the
+        //    bucket starts of its 2^xb prefixes with it (k_prefix_split)
+        if (!have_dense) throw Error(CBLX_EDEVICE, "prefix split without a super-prefix directory (internal error)");
+        const u64 swords = std::max<u64>(1, (nsuper + 63) / 64);
+        Buf<u32> spopc(c->pool, swords), sprefix, real_dense(c->pool, std::max<u64>(nprefix, 1));
+        Buf<u64> sbv(c->pool, swords), srank(c->pool, swords + 1), sstart;
+        u64 nruns = 0;
+        { StageTimer t(c, ST_DIR);
+          CBLX_HIP(hipMemsetAsync(spopc.get(), 0, swords * 4, c->stream));
+          CBLX_HIP(hipMemsetAsync(sbv.get(), 0, swords * 8, c->stream));
+          CBLX_HIP(hipMemsetAsync(real_dense.get(), 0xFF, std::max<u64>(nprefix, 1) * 4, c->stream));
+          hipLaunchKernelGGL(k_bitvector, grid1(std::max<u64>(nsuper, 64), 256), dim3(256), 0, c->stream, start_dense.get(), nsuper, sbv.get(), spopc.get());
+          nruns = exclusive_scan<u64>(c, spopc.get(), swords, srank.get());
+          sprefix = Buf<u32>(c->pool, nruns + 1);
+          sstart = Buf<u64>(c->pool, nruns + 1);
+          hipLaunchKernelGGL(k_bucket_table, grid1(std::max<u64>(nsuper, 1), 256), dim3(256), 0, c->stream, start_dense.get(), nsuper, sbv.get(), srank.get(), sprefix.get(), sstart.get(), sw_lo);
+          hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, sstart.get() + nruns, N); }
+        if (nruns) {
+            StageTimer t(c, ST_SCATTER);
+            u32* const rd = real_dense.get() - w_lo;
+            for (u64 a = 0; a < nruns; a += 1u << 30) {  // (one grid holds fewer than 2^32 work items)
+                const u64 m = std::min<u64>(1u << 30, nruns - a);
+                if constexpr (DROP_HI || !HiTraits<HiT>::has)
+                    hipLaunchKernelGGL(k_prefix_split<NoHi>, dim3((unsigned)m), dim3(SPLIT_THREADS), 0, c->stream, m, sprefix.get() + a, sstart.get() + a, lo, (const NoHi*)nullptr, lo2, (NoHi*)nullptr,
+                                       P.SB, xb, rd);
+                else
+                    hipLaunchKernelGGL(k_prefix_split<HiT>, dim3((unsigned)m), dim3(SPLIT_THREADS), 0, c->stream, m, sprefix.get() + a, sstart.get() + a, lo, hi, lo2, hi2, P.SB, xb, rd);
+            }
+            CBLX_HIP(hipGetLastError());
+            advance();
+        }
+        CBLX_HIP(hipStreamSynchronize(c->stream));  // the run table is released here
+        start_dense = std::move(real_dense);
+        sd = start_dense.get() - w_lo;
+    }
+    if (lo == rec.lo2.get()) { std::swap(rec.lo, rec.lo2); std::swap(rec.hi, rec.hi2); }  // final data -> rec.lo/hi
     rec.lo2.reset();
     rec.hi2.reset();
     // -- KRN-4: bitvector, rank directory, bucket table (of the whole prefix space, or of the caller's window of it)
@@ -753,7 +809,7 @@ template <typename C> void pipeline_group(cblx_ctx* c, const GroupRegions& R, co
     constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
     constexpr bool KEEP_HI = HiTraits<HiT>::has && !DROP_HI;  // 16-byte records through the LSD passes
     const Consts& P = c->P;
-    const u32 npass = lsd_plan(P).npass;
+    const u32 npass = lsd_plan(P).total();  // buffer changes behind pass A: the LSD passes (+ the prefix split at PREFIX_BITS > 24)
     // DEEP group (thousands of words per possible prefix: the dense low ranges of a many-GPU job at PREFIX_BITS <= 24): nearly every run
     // takes the long-run path, whose output is the twin — so the LSD passes end in the scratch area and the twin IS the slot.
     const bool deep = msd_takes<WS>(P.SB) && N / std::max<u64>(1, (u64)win.w_hi - win.w_lo) >= 2048;
@@ -1258,24 +1314,35 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
     const u64 nb = nr.nb;
     nr.a_lo = Buf<u64>(c->pool, N + 2);
     if (WS) nr.a_hi = Buf<u64>(c->pool, N + 2);
+    // Trie |= Trie (both lists ascending): merged by k_bucket_union straight from the two arenas — not gathered, not sorted again.
+    // Narrow suffixes; CBLX_MERGE_UNION=0 keeps the counting-sort route (tests compare the two)
+    const char* union_env = std::getenv("CBLX_MERGE_UNION");  // (read per call: tests switch it)
+    const bool union_path = !WS && !(union_env && union_env[0] == '0');
     {
         StageTimer t(c, ST_EXPAND);
         with_lpb(N, nb, [&](auto lpb) {
             constexpr int LPB = decltype(lpb)::value;
             hipLaunchKernelGGL((k_merge_gather<WS, LPB>), lpb_grid(nb, LPB), dim3(256), 0, c->stream, nb, nr.start.get(), m_cs.get(), m_sstart.get(), m_ostart.get(),
-                               s.a_lo.get(), s.a_hi.get(), o.a_lo.get(), o.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
+                               s.a_lo.get(), s.a_hi.get(), o.a_lo.get(), o.a_hi.get(), nr.a_lo.get(), nr.a_hi.get(), union_path ? m_skind.get() : (const u8*)nullptr,
+                               union_path ? m_okind.get() : (const u8*)nullptr);
         });
     }
     Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
     Buf<u32> list_n(c->pool, CLS_N);
     CBLX_HIP(hipMemsetAsync(list_n.get(), 0, CLS_N * 4, c->stream));
     hipLaunchKernelGGL(k_classify_merge, grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, WS ? 512u : 1024u, nr.start.get(), m_cs.get(), m_skind.get(), m_okind.get(),
-                       nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get());
+                       nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get(), union_path);
     CBLX_HIP(hipGetLastError());
     std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
     const MergeArgs ma{m_cs.get(), m_ostart.get(), m_okind.get(), o.a_lo.get(), o.a_hi.get()};
     u64* a_lo = nr.a_lo.get();
     HiT* a_hi = WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr;
+    if (ln[CLS_UNION]) {
+        StageTimer t(c, ST_BBIG);
+        hipLaunchKernelGGL(k_bucket_union, dim3(ln[CLS_UNION]), dim3(UNI_THREADS), 0, c->stream, lists.get() + (size_t)CLS_UNION * nb, list_n.get() + CLS_UNION, m_cs.get(), m_sstart.get(),
+                           m_ostart.get(), (const u64*)s.a_lo.get(), (const u64*)o.a_lo.get(), a_lo, P.SB, nr.cnt.get(), nr.kind.get());
+        CBLX_HIP(hipGetLastError());
+    }
     {
         StageTimer t(c, ST_BMED);
         // both-sided buckets: counting sort on the top suffix bits + ranking inside the sub-buckets (k_bucket_msd in its

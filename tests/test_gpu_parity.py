@@ -2023,7 +2023,7 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
     procs = [ctx.Process(target=_native_worker, args=(r, world, port, k, pb, canonical, per, L, path, q, protocol, groups)) for r in range(world)]
     for p in procs:
         p.start()
-    blob, bounds, count0, fblob, sent, used = q.get(timeout=900)
+    blob, bounds, count0, fblob, sent, used = q.get(timeout=420)
     # the grouped receiver (bins protocol, empty index): rank 0 worked its range off in groups; a second batch meets a non-empty index
     # and takes the ungrouped path; groups = 1 switches it off
     assert used[1] == 0
@@ -2096,3 +2096,30 @@ def test_rehearsal_of_rank_0_on_recorded_senders(world, k, pb, canonical, groups
     # ... and the next entry of the job's file belongs to rank 1: its prefix is at or above the bound
     nxt, _ = _read_varint(full, pf + len(blob0) - p0)
     assert nxt >= int(bounds[0])
+
+
+@pytest.mark.parametrize("k,pb,n,canonical", [(31, 6, 300000, False), (21, 8, 600000, True), (15, 4, 200000, False), (31, 10, 1500000, False), (27, 9, 40000, False)])
+def test_trie_union_by_merge_path_equals_the_sorting_route(k, pb, n, canonical, monkeypatch):
+    """Trie |= Trie: two ascending lists are MERGED (k_bucket_union: merge-path rounds of 2048 outputs straight from the two arenas) instead
+    of gathered and sorted again (CBLX_MERGE_UNION=0). Buckets of thousands to tens of thousands of words (several rounds per bucket),
+    a shared stretch (words both sides hold: other's copy is dropped), one side much longer than the other, and self == other."""
+    _need_gpu()
+    rng = random.Random(1000 + k + pb)
+    s1 = _rand_seq(rng, n)
+    s2 = _rand_seq(rng, n // 5) + s1[n // 4: n // 4 + n // 3] + _rand_seq(rng, 100)
+    o1, o2 = Oracle(k, pb, canonical), Oracle(k, pb, canonical)
+    o1.insert_seq(s1), o2.insert_seq(s2)
+    o1.merge(o2)
+    want1, want2 = o1.serialize(), o2.serialize()
+    o1.merge(o2)  # once more: the set stays, but a Vec that met other's bucket is sorted again as a whole (iter_sorted, src/trievec/mod.rs:209-220)
+    want1b = o1.serialize()
+    for route in ("1", "0"):
+        monkeypatch.setenv("CBLX_MERGE_UNION", route)
+        g1, g2 = cbl_amd.CBL(k, pb, canonical=canonical), cbl_amd.CBL(k, pb, canonical=canonical)
+        g1.insert_seq(s1), g2.insert_seq(s2)
+        g1 |= g2
+        assert g1.serialize() == want1 and g2.serialize() == want2, route
+        assert g1.validate(strict=False) == 0
+        g1 |= g2  # again: nothing new arrives, every word of other is a duplicate
+        assert g1.serialize() == want1b and g2.serialize() == want2, route
+        g1.close(), g2.close()
