@@ -142,6 +142,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (value_h2d_inclusive)")
     ap.add_argument("--no-fasta", action="store_true", help="skip the file-inclusive measurement (fasta_inclusive: the same reads as a FASTA file on tmpfs)")
     ap.add_argument("--no-per-record", action="store_true", help="skip the per-record measurement (per_record: one cblx_insert_seq call per read from a C++ host program)")
+    ap.add_argument("--recv-groups", type=int, default=0, help="N > 1, native bins protocol: groups per rank of the receiver (0 = default 8, 1 = ungrouped)")
     ap.add_argument("--force-sharded", action="store_true", help="dev: run the N-GPU code path on a 1-rank RCCL group")
     ap.add_argument("--shared-gpu", action="store_true", help="dry run: all ranks on GPU 0, exchange staged through gloo")
     args = ap.parse_args(argv)
@@ -482,6 +483,8 @@ def main():
                 tdist.broadcast_object_list(box, src=0)
                 comm = cbl_amd.Comm.rccl(box[0], rank, world, local_rank)
                 transport = "libcblx sharded insert on RCCL (ncclSend / ncclRecv groups on a side stream)"
+        if comm is not None and args.recv_groups:
+            comm.set_recv_groups(args.recv_groups)
         engine = sharded.ShardedBuilder(cbl, dist, slices=args.slices, protocol=args.protocol, comm=comm) if dist is not None else None
 
         def step(_i):
@@ -688,6 +691,9 @@ def main():
         recv = [p[1] // args.steps for p in parts]
         peers = max(world - 1, 1)
         exchange = {"world_size": dist.get_world_size(), "transport": transport, "protocol": args.protocol,
+                    # groups rank 0's receiver worked its range off in while the later ones were still on the wire (0: the ungrouped
+                    # receiver — everything waits for the last record)
+                    "recv_groups_used": (comm.groups_used() if (args.kind == "build" and comm is not None) else None),
                     "sent_bytes_per_rank_step": sent, "recv_bytes_per_rank_step": recv,
                     "outstanding_ms_per_step": round(out_s / args.steps * 1e3, 3), "wait_ms_per_step": round(allreduce_max(st["wait_s"]) / args.steps * 1e3, 3),
                     # bytes one rank pushes to ONE peer / the time its exchanges were in flight (they overlap the kernels of the next slice)

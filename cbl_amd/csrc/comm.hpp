@@ -411,40 +411,6 @@ std::vector<u64> sampled_prefix_hist(cblx_ctx* c, Transport& T, const u8* d_base
     T.all_reduce_sum_u64(hist.data(), hist.size());
     return hist;
 }
-// The cuts of the grouped receiver: inside every rank's range [bounds[d-1], bounds[d]) up to G - 1 more prefix values that split
-// the range's sampled mass evenly — multiples of 64 (two groups of one rank never share a bitvector word), strictly inside the
-// range, ascending. Fewer than G - 1 where the histogram has no room for them (a cell of it is 2^(PB-16) prefixes wide).
-std::vector<u32> choose_group_cuts(const std::vector<u64>& hist, const u32* bounds, u32 W, u32 G, u32 PB) {
-    std::vector<u32> cuts;
-    const size_t nh = hist.size();
-    const u32 hb = (u32)ilog2_npo2((u32)nh);
-    const int shift = (int)PB - (int)hb;
-    if (shift < 0 || G < 2) return cuts;
-    std::vector<double> cum(nh + 1, 0.0);
-    for (size_t i = 0; i < nh; ++i) cum[i + 1] = cum[i] + (double)hist[i];
-    auto mass_below = [&](u64 prefix) {  // sampled words with a smaller prefix (linear inside a cell)
-        const u64 cell = prefix >> shift;
-        if (cell >= nh) return cum[nh];
-        return cum[cell] + (double)hist[cell] * (double)(prefix - (cell << shift)) / (double)(1ull << shift);
-    };
-    for (u32 d = 0; d < W; ++d) {
-        const u64 lo = d ? bounds[d - 1] : 0, hi = d + 1 < W ? bounds[d] : 1ull << PB;
-        if (hi <= lo) continue;
-        const double m0 = mass_below(lo), m1 = mass_below(hi);
-        u64 last = lo;
-        for (u32 j = 1; j < G; ++j) {
-            const double want = m0 + (m1 - m0) * j / G;
-            u64 cell = (u64)(std::upper_bound(cum.begin(), cum.end(), want) - cum.begin());  // first cell boundary with more mass below it
-            cell = std::min<u64>(std::max<u64>(cell, 1), nh);
-            u64 v = ((cell << shift) + 63) & ~63ull;
-            if (v <= last || v >= hi || v <= lo) continue;
-            cuts.push_back((u32)v);
-            last = v;
-        }
-    }
-    return cuts;
-}
-
 // first batch only: quantile ranges from the all-reduced, sampled prefix histogram of one slice's words
 template <typename C>
 void choose_bounds_from_slice(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 nseq, u32* bounds, std::vector<u64>* hist_out = nullptr) {
@@ -555,7 +521,7 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const BaseView& d_bases, con
     const Consts& P = c->P;
     const u32 W = T.world, me = T.rank, RB = P.PB - 8;
     const BinMap M = make_bin_map(P, bounds, W);
-    const LsdPlan LP = lsd_plan(P);
+    const LsdPlan LP = lsd_plan(P, false);  // (the receiver runs LSD passes only: pipeline.hpp)
     const DigitBits nextd{P.SB + LP.sh[0], LP.wid[0]};
     DigitBin fn;
     fn.SB = P.SB; fn.PB = P.PB; fn.RB = RB; fn.nd = W;
@@ -779,67 +745,6 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const BaseView& d_bases, con
 // GPU is the bound. Inside a group a segment value occurs in one bin only (every cut is a group or rank boundary), so the group's
 // piece table is the old one with other counts. Declines (returns false, identically on every rank: the decision rests on
 // replicated values only) when the index is not empty anywhere, the cuts do not fit the table, or a rank's share needs two rounds.
-struct CutPlan {
-    bool ok = false;
-    std::vector<u32> cuts;              // ascending, distinct, non-zero: rank bounds and group cuts
-    std::vector<u32> dest_of, grp_of;   // per interval [cuts[i-1], cuts[i]): owner rank, group inside the owner's range
-    std::vector<CutCell> tab;           // DigitCut's table
-    u32 v_of[256], iv_of[256];          // bin -> pass-A segment, interval (0xFFFFFFFF: no such bin)
-    u32 bin_lo[MAX_DEST + 1];           // first bin of every rank (bins of one rank are consecutive)
-    u32 ngroups[MAX_DEST];              // groups of every rank
-};
-inline CutPlan make_cut_plan(const Consts& P, const u32* bounds, u32 W, const std::vector<u32>& gcuts) {
-    CutPlan M;
-    const u32 RB = P.PB - 8;
-    for (u32 i = 0; i < 256; ++i) M.v_of[i] = M.iv_of[i] = 0xFFFFFFFFu;
-    for (u32 i = 0; i + 1 < W; ++i) {
-        if (bounds[i] == 0 || (i && bounds[i] <= bounds[i - 1]) || (u64)bounds[i] > (255ull << RB)) return M;  // an empty range, or the all-ones segment cut
-        M.cuts.push_back(bounds[i]);
-    }
-    for (u32 g : gcuts) M.cuts.push_back(g);
-    std::sort(M.cuts.begin(), M.cuts.end());
-    for (size_t i = 1; i < M.cuts.size(); ++i) if (M.cuts[i] == M.cuts[i - 1]) return M;
-    if (M.cuts.size() > 120 || M.cuts.empty() || (u64)M.cuts.back() > (255ull << RB)) return M;
-    const u32 nc = (u32)M.cuts.size();
-    // the table: per key the cuts at or below the key's first prefix, and the one cut inside the key's range
-    M.tab.assign(CUT_KEYS, CutCell{0xFFFFFFFFu, 0u});
-    for (u32 k = 0; k < CUT_KEYS; ++k) {
-        const u32 first = cut_key_first(k);
-        M.tab[k].base = (u32)(std::upper_bound(M.cuts.begin(), M.cuts.end(), first) - M.cuts.begin());
-    }
-    for (u32 cv : M.cuts) {
-        const u32 k = cut_key(cv);
-        if (cv == cut_key_first(k)) continue;  // counted in the key's base
-        if (M.tab[k].cut != 0xFFFFFFFFu) return M;  // two cuts inside one cell of the table
-        M.tab[k].cut = cv;
-    }
-    auto cnt = [&](u64 p) { return (u32)(std::upper_bound(M.cuts.begin(), M.cuts.end(), (u32)p) - M.cuts.begin()); };
-    M.dest_of.resize(nc + 1);
-    M.grp_of.resize(nc + 1);
-    for (u32 i = 0; i <= nc; ++i) {
-        const u32 first = i ? M.cuts[i - 1] : 0u;
-        u32 d = 0;
-        for (u32 j = 0; j + 1 < W; ++j) d += bounds[j] <= first ? 1u : 0u;
-        M.dest_of[i] = d;
-        M.grp_of[i] = i && M.dest_of[i - 1] == d ? M.grp_of[i - 1] + 1 : 0u;
-    }
-    for (u32 d = 0; d < W; ++d) M.ngroups[d] = 0;
-    for (u32 i = 0; i <= nc; ++i) M.ngroups[M.dest_of[i]] = std::max(M.ngroups[M.dest_of[i]], M.grp_of[i] + 1);
-    for (u32 v = 0; v < 128; ++v)
-        for (u32 k = cnt((u64)v << RB); k <= cnt((((u64)v + 1) << RB) - 1); ++k) {
-            if (v + k >= 254) return M;
-            M.v_of[v + k] = v;
-            M.iv_of[v + k] = k;
-        }
-    M.v_of[255] = 255; M.iv_of[255] = nc;
-    // bins of one rank are consecutive: first bin per rank (a rank without any bin gets an empty range)
-    for (u32 d = 0; d <= W; ++d) M.bin_lo[d] = 256;
-    for (int b = 255; b >= 0; --b) if (M.iv_of[b] != 0xFFFFFFFFu) M.bin_lo[M.dest_of[M.iv_of[b]]] = (u32)b;
-    M.bin_lo[W] = 256;
-    for (int d = (int)W - 1; d >= 0; --d) if (M.bin_lo[d] == 256) M.bin_lo[d] = M.bin_lo[d + 1];
-    M.ok = true;
-    return M;
-}
 __global__ void k_add_u64(u64* __restrict__ v, u64 n, u64 add) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] += add;
@@ -871,7 +776,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         cm->g_cuts = choose_group_cuts(hist, bounds, W, G, P.PB);
         cm->g_bounds = bvec;
     }
-    const CutPlan M = make_cut_plan(P, bounds, W, cm->g_cuts);
+    const CutPlan M = make_cut_plan(P.PB, bounds, W, cm->g_cuts);
     // -- the job: k-mers per rank (upper bound), whether any rank holds an index already
     const u64 n0 = cuts[0], n1 = cuts[nslices];
     u64 mine = 0;
@@ -887,7 +792,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     const u64 LIMIT = 0xFFFFFFF0ull - 2 * RDX_TILE;
     if (!M.ok || agree[1] != 0 || job / W + job / (2 * W) + (1u << 20) >= LIMIT || mine >= LIMIT) return false;
     const bool trace = std::getenv("CBLX_TRACE_SHARDED") != nullptr;
-    const LsdPlan LP = lsd_plan(P);
+    const LsdPlan LP = lsd_plan(P, false);  // (the receiver runs LSD passes only: pipeline.hpp)
     const DigitBits nextd{P.SB + LP.sh[0], LP.wid[0]};
     Buf<CutCell> d_tab(c->pool, CUT_KEYS);
     h2d(c, d_tab.get(), M.tab.data(), CUT_KEYS);

@@ -13,6 +13,7 @@
 #pragma once
 #include <type_traits>
 
+#include "cuts.hpp"
 #include "kernels_encode.hpp"
 
 namespace cblx {
@@ -247,18 +248,6 @@ struct DigitBin {
 // VALU instructions each, so the count comes from a table over a floating-point-like key of the prefix (the 6 leading bits:
 // 32 cells per octave, exact below 64): entry = {cuts <= the cell's first prefix, the one cut inside the cell or ~0}. The host
 // refuses a cut list with two cuts inside one cell (make_cut_table); 768 entries of 8 bytes, read through the vector L1.
-struct CutCell { u32 cut, base; };
-static const u32 CUT_KEYS = 64 + 26 * 32;
-__host__ __device__ __forceinline__ u32 cut_key(u32 p) {
-    if (p < 64u) return p;
-    const u32 e = 31u - (u32)__builtin_clz(p);
-    return 64u + ((e - 6u) << 5) + ((p >> (e - 5u)) & 31u);
-}
-__host__ __device__ __forceinline__ u32 cut_key_first(u32 k) {  // smallest prefix with that key
-    if (k < 64u) return k;
-    const u32 e = 6u + ((k - 64u) >> 5), m = (k - 64u) & 31u;
-    return (32u + m) << (e - 5u);
-}
 struct DigitCut {
     u32 SB, PB, RB;
     const CutCell* tab;
@@ -738,33 +727,74 @@ __global__ __launch_bounds__(256) void k_boundaries_cold(const u64* __restrict__
 // several tiles is counted first (its records are read twice; the second read comes from the L2). The kernel also writes the bucket
 // starts of the run's 2^xb prefixes (EMPTY32 for the absent ones) — the fused directory of the old last pass, without candidates to
 // settle. Reads `in`, writes `out` (the ping-pong partner) at the same run positions.
-static const int SPLIT_THREADS = 256, SPLIT_ITEMS = 8, SPLIT_TILE = SPLIT_THREADS * SPLIT_ITEMS, SPLIT_NW = SPLIT_THREADS / 64;
-template <typename H>
-__global__ __launch_bounds__(SPLIT_THREADS) void k_prefix_split(u64 nruns, const u32* __restrict__ run_prefix, const u64* __restrict__ run_start, const u64* __restrict__ in_lo,
-                                                                const H* __restrict__ in_hi, u64* __restrict__ out_lo, H* __restrict__ out_hi, u32 SB, u32 xb,
-                                                                u32* __restrict__ start_dense /* indexed by the absolute prefix */) {
+// Three workgroup sizes by run length — one wave (up to 512 records), four (up to 2048), eight (longer: tiles of 4096; only a run
+// of more than one tile is read twice) — every launch walks the whole run list and a workgroup leaves at once when the run is not of
+// its class.
+// Per tile: the lanes' records (wave-contiguous slices) are ranked by digit with xb ballots (stable), the per-wave counts are scanned
+// across the waves, and every record goes straight from its register to its place — the run's pieces are written by one workgroup
+// within microseconds of each other, so their partial lines meet in the L2.
+static const int SPLIT_ITEMS = 8;
+static const u32 SPLIT_SMALL = 64 * SPLIT_ITEMS, SPLIT_MID = 256 * SPLIT_ITEMS;  // one tile of the one-wave / four-wave kernel: a run of one tile is read once
+template <typename H, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_prefix_split(u64 nruns, const u32* __restrict__ run_prefix, const u64* __restrict__ run_start, const u64* __restrict__ in_lo,
+                                                          const H* __restrict__ in_hi, u64* __restrict__ out_lo, H* __restrict__ out_hi, u32 SB, u32 xb,
+                                                          u32* __restrict__ start_dense /* indexed by the absolute prefix */, u32 len_above, u32 len_upto) {
     constexpr bool HAS = HiTraits<H>::has;
-    __shared__ u64 s_lo[SPLIT_TILE];
-    __shared__ u64 s_hi[HAS ? SPLIT_TILE : 1];
-    __shared__ u32 s_wcnt[SPLIT_NW * 16];  // per wave and digit: records seen so far in the tile
-    __shared__ u32 s_tbase[16];            // tile-local first slot of every digit
-    __shared__ u32 s_rbase[16];            // run: records of smaller digits
-    __shared__ u32 s_roff[16];             // run: records of the digit in earlier tiles
+    constexpr int NW = THREADS / 64, TILE = THREADS * SPLIT_ITEMS;
+    __shared__ u32 s_wcnt[NW * 16];  // per wave and digit: records of the tile seen so far, then the wave's offset inside the digit
+    __shared__ u32 s_rbase[16];      // run: first position of the digit
+    __shared__ u32 s_roff[16];       // run: records of the digit in earlier tiles
     const u64 run = blockIdx.x;
     if (run >= nruns) return;
     const u64 s0 = run_start[run];
-    const u32 c = (u32)(run_start[run + 1] - s0), NB = 1u << xb;
-    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const u32 ntiles = (c + SPLIT_TILE - 1) / SPLIT_TILE;
+    const u32 c = (u32)(run_start[run + 1] - s0);
+    if (c <= len_above || c > len_upto) return;
+    const u32 NB = 1u << xb, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const u32 ntiles = (c + TILE - 1) / TILE;
     const u64* __restrict__ lo_r = in_lo + s0;
     const H* __restrict__ hi_r = HAS ? in_hi + s0 : in_hi;
     if (tid < 16) { s_rbase[tid] = 0; s_roff[tid] = 0; }
     __syncthreads();
-    // one tile: load, rank by digit (stable); `place`: stage in LDS in final order and write out
-    auto tile_pass = [&](u32 t, bool place) {
-        const u32 t0 = t * SPLIT_TILE, n_tile = c - t0 < (u32)SPLIT_TILE ? c - t0 : (u32)SPLIT_TILE;
-        const u32 R = (n_tile + SPLIT_THREADS - 1) / SPLIT_THREADS, EPW = 64 * R;  // wave-contiguous slices
-        if (tid < SPLIT_NW * 16) s_wcnt[tid] = 0;
+    if (ntiles > 1) {  // a run of several tiles is counted first (the second read of its records comes from the L2)
+        u32 cnt[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cnt[k] = 0;
+        for (u32 t = 0; t < ntiles; ++t) {
+            const u32 t0 = t * TILE, n_tile = c - t0 < (u32)TILE ? c - t0 : (u32)TILE;
+            u32 dg[SPLIT_ITEMS];
+#pragma unroll
+            for (int j = 0; j < SPLIT_ITEMS; ++j) {
+                const u32 e = j * THREADS + tid;  // (order does not matter for counting: coalesced rows)
+                const bool valid = e < n_tile;
+                const u64 v = lo_r[t0 + (valid ? e : 0u)];
+                u64 h = 0;
+                if constexpr (HAS) h = (u64)hi_r[t0 + (valid ? e : 0u)];
+                dg[j] = valid ? (u32)get_bits(v, h, SB, xb) : 0xFFu;
+            }
+#pragma unroll
+            for (int j = 0; j < SPLIT_ITEMS; ++j)
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if ((u32)k < NB) cnt[k] += (u32)__builtin_popcountll(__ballot(dg[j] == (u32)k));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if ((u32)k < NB && cnt[k]) atomicAdd(&s_rbase[k], cnt[k]);
+        }
+        __syncthreads();
+        if (w == 0) {
+            const u32 x = lane < 16 ? s_rbase[lane] : 0u;
+            u32 inc = x;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { const u32 t = __shfl_up(inc, o, 64); if (lane >= (u32)o) inc += t; }
+            if (lane < 16) s_rbase[lane] = inc - x;
+        }
+        __syncthreads();
+    }
+    for (u32 t = 0; t < ntiles; ++t) {
+        const u32 t0 = t * TILE, n_tile = c - t0 < (u32)TILE ? c - t0 : (u32)TILE;
+        const u32 R = (n_tile + THREADS - 1) / THREADS, EPW = 64 * R;  // wave-contiguous slices: (wave, round, lane) is the stream order
+        if (tid < NW * 16) s_wcnt[tid] = 0;
         __syncthreads();
         u64 klo[SPLIT_ITEMS];
         u64 khi[HAS ? SPLIT_ITEMS : 1];
@@ -776,7 +806,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_prefix_split(u64 nruns, const
             const bool valid = (u32)j < R && e < n_tile;
             klo[j] = lo_r[t0 + (valid ? e : 0u)];
             if constexpr (HAS) khi[j] = (u64)hi_r[t0 + (valid ? e : 0u)];
-            dp[j] = valid ? (u32)(get_bits(klo[j], HAS ? khi[j] : 0ull, SB, xb)) : 0xFFu;
+            dp[j] = valid ? (u32)get_bits(klo[j], HAS ? khi[j] : 0ull, SB, xb) : 0xFFu;
         }
 #pragma unroll
         for (int j = 0; j < SPLIT_ITEMS; ++j) {
@@ -798,56 +828,35 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_prefix_split(u64 nruns, const
             }
         }
         __syncthreads();
-        if (tid < 16) {  // per digit: exclusive scan across the waves, tile totals
-            u32 runc = 0;
-#pragma unroll
-            for (int ww = 0; ww < SPLIT_NW; ++ww) { const u32 x = s_wcnt[ww * 16 + tid]; s_wcnt[ww * 16 + tid] = runc; runc += x; }
-            s_tbase[tid] = runc;  // (the tile's count of the digit, turned into its first slot below)
-        }
-        __syncthreads();
-        if (!place) {  // counting pass of a long run
-            if (tid < 16) s_rbase[tid] += s_tbase[tid];
-            __syncthreads();
-            return;
-        }
         u32 tcnt = 0;
-        if (tid < 16) tcnt = s_tbase[tid];
-        __syncthreads();
-        if (tid == 0) { u32 acc = 0; for (u32 k = 0; k < 16; ++k) { const u32 x = s_tbase[k]; s_tbase[k] = acc; acc += x; } }
-        __syncthreads();
-        if (ntiles == 1 && tid < 16) s_rbase[tid] = s_tbase[tid];  // a one-tile run: the run's digit starts are the tile's
+        if (w == 0) {  // per digit: exclusive scan across the waves; a one-tile run also gets its digit starts here
+            if (lane < 16) {
+                u32 runc = 0;
 #pragma unroll
-        for (int j = 0; j < SPLIT_ITEMS; ++j) {
-            if ((u32)j < R && dp[j] != 0xFFFFFFFFu) {
-                const u32 d = dp[j] >> 16, pos = s_tbase[d] + my[d] + (dp[j] & 0xFFFFu);
-                s_lo[pos] = klo[j];
-                if constexpr (HAS) s_hi[pos] = khi[j];
+                for (int ww = 0; ww < NW; ++ww) { const u32 x = s_wcnt[ww * 16 + lane]; s_wcnt[ww * 16 + lane] = runc; runc += x; }
+                tcnt = runc;
+            }
+            if (ntiles == 1) {
+                u32 inc = tcnt;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { const u32 x = __shfl_up(inc, o, 64); if (lane >= (u32)o) inc += x; }
+                if (lane < 16) s_rbase[lane] = inc - tcnt;
             }
         }
         __syncthreads();
-        // slot i of the staged tile holds digit d = the one whose [tbase[d], tbase[d+1]) contains i; it leaves for
-        // s0 + rbase[d] + roff[d] + (i - tbase[d]). A one-tile run is written front to back (rbase = tbase, roff = 0).
-        for (u32 i = tid; i < n_tile; i += SPLIT_THREADS) {
-            const u64 v = s_lo[i];
-            u64 h = 0;
-            if constexpr (HAS) h = s_hi[i];
-            const u32 d = (u32)get_bits(v, h, SB, xb);
-            const u64 dst = s0 + s_rbase[d] + s_roff[d] + (i - s_tbase[d]);
-            out_lo[dst] = v;
-            if constexpr (HAS) out_hi[dst] = (H)h;
+#pragma unroll
+        for (int j = 0; j < SPLIT_ITEMS; ++j) {
+            if ((u32)j < R && dp[j] != 0xFFFFFFFFu) {
+                const u32 d = dp[j] >> 16;
+                const u64 dst = s0 + s_rbase[d] + s_roff[d] + my[d] + (dp[j] & 0xFFFFu);
+                out_lo[dst] = klo[j];
+                if constexpr (HAS) out_hi[dst] = (H)khi[j];
+            }
         }
         __syncthreads();
-        if (tid < 16) s_roff[tid] += tcnt;
-        __syncthreads();
-    };
-    if (ntiles > 1) {
-        for (u32 t = 0; t < ntiles; ++t) tile_pass(t, false);
-        if (tid == 0) { u32 acc = 0; for (u32 k = 0; k < 16; ++k) { const u32 x = s_rbase[k]; s_rbase[k] = acc; acc += x; } }
-        __syncthreads();
-        for (u32 t = 0; t < ntiles; ++t) tile_pass(t, true);
-    } else {
-        tile_pass(0, true);
+        if (w == 0 && lane < 16) s_roff[lane] += tcnt;
     }
+    __syncthreads();
     // bucket starts of the run's prefixes: digit d starts at s0 + rbase[d] and holds roff[d] records
     if (tid < NB) start_dense[((u64)run_prefix[run] << xb) | tid] = s_roff[tid] ? (u32)(s0 + s_rbase[tid]) : 0xFFFFFFFFu;
 }

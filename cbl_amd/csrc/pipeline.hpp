@@ -51,14 +51,17 @@ struct LsdPlan {
     u32 xb = 0;  // lowest prefix bits left to k_prefix_split (the passes sort the PB - xb bits above them)
     u32 total() const { return npass + (xb ? 1u : 0u); }  // times the records change buffers behind pass A
 };
-inline LsdPlan lsd_plan(const Consts& P) {
+// `split_ok` = false: records that arrive in pieces (the receiver of the multi-GPU build, and its senders, whose side channel carries
+// the first pass's digit): at the bucket depth of a many-GPU job a run of equal 24-bit prefix holds tens of thousands of records, which
+// k_prefix_split has to read twice (12 ms per 1.5 G records against 6.2 for a scatter pass, profiles/r04_wire_emulated.md): three passes.
+inline LsdPlan lsd_plan(const Consts& P, bool split_ok = true) {
     // Up to two passes: 8 bits, then the rest (the group-cut tiles of the last pass are built for that shape). PREFIX_BITS > 24:
     // 8 + 8 bits by two passes with the directory of 2^24 "super-prefixes" from the second one's tables, and the last 1 .. 4 bits
     // by k_prefix_split (a run of equal 24-bit prefix staged in LDS, written back in order: copy speed). Three passes
     // of 7 + 7 + 6 bits before that (CBLX_PREFIX_SPLIT=0): a pass costs nearly the same whatever its width.
     LsdPlan L;
     const u32 RB = P.PB - std::min(8u, P.PB);
-    if (CBLX_PREFIX_SPLIT && P.PB > 24) {
+    if (CBLX_PREFIX_SPLIT && split_ok && P.PB > 24) {
         L.xb = P.PB - 24;
         L.npass = 2;
         L.wid[0] = L.wid[1] = 8;
@@ -98,7 +101,7 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
     Buf<u32> seg_start(c->pool, 257);
     // PREFIX_BITS > 24: the passes sort the top PBs = 24 prefix bits ("super-prefixes": the xb bits below them count as suffix here,
     // SBs), their directory comes from the last pass's tables, and k_prefix_split finishes the job run by run (below)
-    const LsdPlan LP = lsd_plan(P);
+    const LsdPlan LP = lsd_plan(P, pin == nullptr);
     const u32 xb = LP.xb, PBs = P.PB - xb, SBs = P.SB + xb;
     const u32 nA = std::min(8u, PBs), RB = PBs - nA;  // bits of pass A, bits left for the LSD passes
     const u32 w_lo = win ? win->w_lo : 0u;
@@ -285,13 +288,18 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
         if (nruns) {
             StageTimer t(c, ST_SCATTER);
             u32* const rd = real_dense.get() - w_lo;
-            for (u64 a = 0; a < nruns; a += 1u << 30) {  // (one grid holds fewer than 2^32 work items)
-                const u64 m = std::min<u64>(1u << 30, nruns - a);
-                if constexpr (DROP_HI || !HiTraits<HiT>::has)
-                    hipLaunchKernelGGL(k_prefix_split<NoHi>, dim3((unsigned)m), dim3(SPLIT_THREADS), 0, c->stream, m, sprefix.get() + a, sstart.get() + a, lo, (const NoHi*)nullptr, lo2, (NoHi*)nullptr,
-                                       P.SB, xb, rd);
-                else
-                    hipLaunchKernelGGL(k_prefix_split<HiT>, dim3((unsigned)m), dim3(SPLIT_THREADS), 0, c->stream, m, sprefix.get() + a, sstart.get() + a, lo, hi, lo2, hi2, P.SB, xb, rd);
+            for (u64 a = 0; a < nruns; a += 1u << 24) {  // (one grid holds fewer than 2^32 work items)
+                const u64 m = std::min<u64>(1u << 24, nruns - a);
+                auto launch = [&](auto h_tag, const auto* hin, auto* hout) {
+                    typedef decltype(h_tag) H;
+                    hipLaunchKernelGGL((k_prefix_split<H, 64>), dim3((unsigned)m), dim3(64), 0, c->stream, m, sprefix.get() + a, sstart.get() + a, lo, hin, lo2, hout, P.SB, xb, rd, 0u, SPLIT_SMALL);
+                    hipLaunchKernelGGL((k_prefix_split<H, 256>), dim3((unsigned)m), dim3(256), 0, c->stream, m, sprefix.get() + a, sstart.get() + a, lo, hin, lo2, hout, P.SB, xb, rd, SPLIT_SMALL,
+                                       SPLIT_MID);
+                    hipLaunchKernelGGL((k_prefix_split<H, 512>), dim3((unsigned)m), dim3(512), 0, c->stream, m, sprefix.get() + a, sstart.get() + a, lo, hin, lo2, hout, P.SB, xb, rd, SPLIT_MID,
+                                       0xFFFFFFFFu);
+                };
+                if constexpr (DROP_HI || !HiTraits<HiT>::has) launch(NoHi(), (const NoHi*)nullptr, (NoHi*)nullptr);
+                else launch(HiT(), hi, hi2);
             }
             CBLX_HIP(hipGetLastError());
             advance();
@@ -809,7 +817,7 @@ template <typename C> void pipeline_group(cblx_ctx* c, const GroupRegions& R, co
     constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
     constexpr bool KEEP_HI = HiTraits<HiT>::has && !DROP_HI;  // 16-byte records through the LSD passes
     const Consts& P = c->P;
-    const u32 npass = lsd_plan(P).total();  // buffer changes behind pass A: the LSD passes (+ the prefix split at PREFIX_BITS > 24)
+    const u32 npass = lsd_plan(P, false).total();  // buffer changes behind pass A (records in pieces: LSD passes only, no prefix split)
     // DEEP group (thousands of words per possible prefix: the dense low ranges of a many-GPU job at PREFIX_BITS <= 24): nearly every run
     // takes the long-run path, whose output is the twin — so the LSD passes end in the scratch area and the twin IS the slot.
     const bool deep = msd_takes<WS>(P.SB) && N / std::max<u64>(1, (u64)win.w_hi - win.w_lo) >= 2048;

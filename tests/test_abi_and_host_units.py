@@ -127,6 +127,17 @@ def test_fastx_planes_host_unit(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
 
+def test_cut_plan_host_unit(tmp_path):
+    """Host logic of the grouped receiver (cbl_amd/csrc/cuts.hpp: the key of the cut table, group cuts from the sampled histogram, the bin
+    map) against the definitions, under AddressSanitizer + UBSan: table lookup == counting the cuts, bins of a rank consecutive, a
+    segment value at most once per group, cuts multiples of 64 inside their range."""
+    exe = tmp_path / "cut_plan_unit"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", str(exe),
+                    str(ROOT / "tests" / "host" / "cut_plan_unit.cpp")], check=True, capture_output=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("k,pb,nreads,L", [(31, 24, 3000, 150), (9, 4, 1500, 100), (59, 28, 400, 250), (15, 6, 1500, 150), (11, 8, 40, 3000)])
 def test_index_shard_cuts_speculative_equals_sequential(k, pb, nreads, L, tmp_path):
     """Host-only half of cblx_load_shard_from_file: the speculative search for the entry starts of `world` prefix ranges

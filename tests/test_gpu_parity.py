@@ -2113,13 +2113,28 @@ def test_trie_union_by_merge_path_equals_the_sorting_route(k, pb, n, canonical, 
     want1, want2 = o1.serialize(), o2.serialize()
     o1.merge(o2)  # once more: the set stays, but a Vec that met other's bucket is sorted again as a whole (iter_sorted, src/trievec/mod.rs:209-220)
     want1b = o1.serialize()
+    def same(g, want, what):
+        got = g.serialize()
+        if got == want:
+            return
+        w = cbl_amd.CBL(k, pb, canonical=canonical)
+        w.load(want)
+        for (p1, k1, x1), (p2, k2, x2) in zip(g.buckets(), w.buckets()):
+            assert (p1, k1, len(x1)) == (p2, k2, len(x2)), f"{what}: bucket header differs: gpu {(p1, k1, len(x1))} oracle {(p2, k2, len(x2))}"
+            if x1 != x2:
+                bad = [i for i in range(len(x1)) if x1[i] != x2[i]]
+                raise AssertionError(f"{what}: bucket {p1:#x} kind {k1} len {len(x1)}: {len(bad)} positions differ, first {bad[:5]}: gpu {[hex(x1[i]) for i in bad[:3]]} oracle {[hex(x2[i]) for i in bad[:3]]}")
+        raise AssertionError(f"{what}: bytes differ, buckets equal")
+
     for route in ("1", "0"):
         monkeypatch.setenv("CBLX_MERGE_UNION", route)
         g1, g2 = cbl_amd.CBL(k, pb, canonical=canonical), cbl_amd.CBL(k, pb, canonical=canonical)
         g1.insert_seq(s1), g2.insert_seq(s2)
         g1 |= g2
-        assert g1.serialize() == want1 and g2.serialize() == want2, route
+        same(g1, want1, f"route {route}, self after the first merge")
+        same(g2, want2, f"route {route}, other after the first merge")
         assert g1.validate(strict=False) == 0
         g1 |= g2  # again: nothing new arrives, every word of other is a duplicate
-        assert g1.serialize() == want1b and g2.serialize() == want2, route
+        same(g1, want1b, f"route {route}, self after the second merge")
+        same(g2, want2b, f"route {route}, other after the second merge")
         g1.close(), g2.close()

@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CFG), default="cfg3")
     ap.add_argument("--reads", type=int, default=None, help="reads per rank")
     ap.add_argument("--wire-gbps", default="40,55,75,0")
-    ap.add_argument("--groups", type=int, default=8)
+    ap.add_argument("--groups", default="8", help="groups per rank of the grouped receiver; several values separated by commas")
     ap.add_argument("--slices", type=int, default=4, help="slices of the UNGROUPED run (the grouped one sends nothing before its last slice is through pass A: 1 slice)")
     ap.add_argument("--steps", type=int, default=3)
     a = ap.parse_args()
@@ -54,7 +54,8 @@ def main():
 
     bounds = np.zeros(W - 1, dtype=np.uint32)
     have_bounds = False
-    for mode, groups, slices in (("grouped", a.groups, 1), ("ungrouped", 1, a.slices)):
+    modes = [("grouped", int(x), 1) for x in a.groups.split(",")] + [("ungrouped", 1, a.slices)]
+    for mode, groups, slices in modes:
         store = 1000 + groups
         for r in range(1, W):  # the senders: what each would send rank 0
             rb, ro = synth.reads_torch(42, nr, L, first_read=r * nr, device="cuda")
@@ -77,7 +78,7 @@ def main():
                 if it:
                     ts.append(time.perf_counter() - t0)
             st = cm.stats()
-            run = {"mode": mode, "groups_used": cm.groups_used(), "slices": slices, "link_gbps": gbps, "ms": [round(t * 1e3, 3) for t in ts], "ms_best": round(min(ts) * 1e3, 3),
+            run = {"mode": mode, "groups": groups, "groups_used": cm.groups_used(), "slices": slices, "link_gbps": gbps, "ms": [round(t * 1e3, 3) for t in ts], "ms_best": round(min(ts) * 1e3, 3),
                    "words_in_index": w.count(), "recv_bytes_per_step": st["recv_bytes"] // (a.steps + 1), "sent_bytes_per_step": st["sent_bytes"] // (a.steps + 1),
                    "wire_ms_at_rate": round(st["recv_bytes"] / (a.steps + 1) / (W - 1) / (gbps * 1e9) * 1e3, 3) if gbps else None,
                    "stage_ms_last_step": {n: round(ms, 3) for n, (ms, _) in w.stage_times().items() if ms > 0}}
