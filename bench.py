@@ -129,7 +129,9 @@ def parse_args(argv=None):
     ap.add_argument("--canonical", action="store_true")
     ap.add_argument("--protocol", choices=["bins", "sorted", "words"], default=None,
                     help="N > 1: what crosses the links. native transport: bins (default) or sorted; torch transport: sorted (default) or words")
-    ap.add_argument("--slices", type=int, default=4)
+    ap.add_argument("--slices", type=int, default=None,
+                    help="N > 1: slices per rank and step. Default 1 for the native bins protocol (its grouped receiver sends group-major after the rank's "
+                         "whole first pass: slices only add fixed costs), 4 otherwise (the exchange of a slice overlaps the next slice's kernels)")
     ap.add_argument("--transport", choices=["torch", "native"], default="native",
                     help="N > 1: exchange driven from Python over torch.distributed, or the whole sharded insert inside libcblx on RCCL directly")
     ap.add_argument("--cpu-sample-reads", type=int, default=None,
@@ -154,6 +156,8 @@ def parse_args(argv=None):
     for name in ("k", "prefix_bits", "reads", "read_len"):
         if getattr(args, name) is None:
             setattr(args, name, cfg[name])
+    if args.slices is None:
+        args.slices = 1 if (args.transport == "native" and args.protocol == "bins" and not args.force_sharded) else 4
     args.kind = cfg["kind"]
     args.genome = cfg.get("genome", 0)
     if args.cpu_sample_reads is None:  # the oracle slows down with PREFIX_BITS (2^28-bit Fenwick bitvector) and word width

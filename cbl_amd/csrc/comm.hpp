@@ -2,11 +2,19 @@
 // supplied by the embedding program) and the sharded insert that runs on it. Included by cblx.cpp only.
 //
 // No reference counterpart (the reference is one process); the path is BASELINE.json's north_star: buckets are
-// independent by prefix, so the 2^PREFIX_BITS space is cut into `world` contiguous ranges and what the k-mers turn into
-// crosses the links once. Same protocol as cbl_amd/sharded.py's "sorted" one (which drives the same device steps through
-// torch.distributed): per slice of the rank's reads KRN-1 + the full stable partition, per destination a slice of the
-// prefix-sorted batch (prefixes, counts, packed suffixes), one grouped personalised exchange, and at the end one
-// bucket-by-bucket merge of the received batches in (slice, source rank) order = stream order.
+// independent by prefix, so the 2^PREFIX_BITS space is cut into `world` contiguous ranges (quantiles of a sampled, all-reduced
+// prefix histogram) and what the k-mers turn into crosses the links once. Three protocols, same result (byte-identical to the
+// one-process build in the job's stream order, slice-major / rank-minor):
+//   "bins", grouped receiver (default on an empty index; sharded_insert_grouped): the senders run KRN-1 + the FIRST partition pass on
+//     bins that refine that pass's digit by the destination rank and by G groups per rank; 8-byte records + a digit byte cross the
+//     links group-major, and the receiver runs the remaining passes, its window of the directory and the bucket kernels of group g
+//     while groups g+1.. are still on the wire;
+//   "bins", plain receiver (sharded_insert_bins: non-empty index, degenerate bounds, one rank, the sliced one-GPU host input): the
+//     same records slice-major, everything behind the first pass once the last record has landed;
+//   "sorted" (sharded_insert_sorted): the sender partitions completely and ships prefixes, counts and packed suffixes; the receiver
+//     merges the batches run by run — a third fewer bytes on the wire, one more pass over the words (2 - 4 GPUs, PREFIX_BITS <= 8).
+// Transports: RCCL (grouped ncclSend / ncclRecv on a side stream), host callbacks (tests: ranks sharing one GPU), the one-rank
+// local transport (a batch arriving over PCIe), and the recording / replaying pair of the one-GPU rehearsal (SimTransport).
 #pragma once
 #include <dlfcn.h>
 
@@ -554,8 +562,22 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const BaseView& d_bases, con
         hi = Buf<u8>(c->pool, OHS ? (ncap + 2) * OHS : 8);
         dg = Buf<u8>(c->pool, ncap + 64);
     };
-    struct Sent { Buf<u64> lo; Buf<u8> hi, dig; };
-    std::vector<Sent> sent;            // send buffers of the round's exchanges (alive until they have completed)
+    // send buffers of the exchanges in flight. A slice's buffers go back to the pool as soon as its exchange has completed (an event
+    // behind it on the transport's stream, polled at the start of every later slice): what stays allocated is bounded by the slices the
+    // wire is behind, not by the job (a whole call's send buffers — (W-1)/W of the rank's words, 9 bytes each — next to the receive
+    // arena and the pipeline's twin could run one rank out of memory while the others wait in a collective)
+    struct Sent { Buf<u64> lo; Buf<u8> hi, dig; hipEvent_t done = nullptr; };
+    std::vector<Sent> sent;
+    struct SentEvents { std::vector<Sent>& v; ~SentEvents() { for (Sent& x : v) if (x.done) (void)hipEventDestroy(x.done); } } sent_events{sent};
+    auto reap_sent = [&]() {
+        for (size_t i = 0; i < sent.size();) {
+            if (sent[i].done && hipEventQuery(sent[i].done) == hipSuccess) {
+                (void)hipEventDestroy(sent[i].done);
+                sent[i] = std::move(sent.back());
+                sent.pop_back();
+            } else { (void)hipGetLastError(); ++i; }
+        }
+    };
     std::vector<u32> pcnt, pbase;      // piece table of the round: [piece][256] counts, arena position of every piece
     // one rank (a batch arriving over PCIe, insert_device_sliced): everything is the rank's own, nothing has to be agreed per slice —
     // the bin counts of a slice stay on the device until the round ends, and the slices run without a host round trip between
@@ -586,6 +608,7 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const BaseView& d_bases, con
     auto finish_round = [&]() {
         T.wait();
         CBLX_HIP(hipStreamSynchronize(c->stream));
+        for (Sent& x : sent) if (x.done) { (void)hipEventDestroy(x.done); x.done = nullptr; }
         sent.clear();
         if (trace) fprintf(stderr, "[cblx bins] rank %u round ends: filled=%llu pieces=%zu\n", me, (unsigned long long)filled, pbase.size());
         for (Deferred& d : deferred) {
@@ -621,6 +644,7 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const BaseView& d_bases, con
     for (u32 s = 0; s < nslices; ++s) {
         const u64 a = cuts[s], b = cuts[s + 1];
         before_slice(s);
+        reap_sent();
         // -- KRN-1 with the bin histogram fused in, column prefixes of pass A
         ChunkPlan pl;
         BaseView pb = d_bases;
@@ -722,6 +746,10 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const BaseView& d_bases, con
             xchg(S.dig.get(), a_dig.get() + filled + own, 1);
         }
         filled += incoming;
+        if (W > 1) {
+            CBLX_HIP(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+            T.record(S.done, c->stream);
+        }
         sent.push_back(std::move(S));
         // the slice's workspace (chunk plan, words, count matrix) stays until the next slice's chunk plan has synchronised the
         // stream: the host queues the next slice's first kernels while this slice's pass A is still running

@@ -728,27 +728,53 @@ __global__ __launch_bounds__(256) void k_boundaries_cold(const u64* __restrict__
 // starts of the run's 2^xb prefixes (EMPTY32 for the absent ones) — the fused directory of the old last pass, without candidates to
 // settle. Reads `in`, writes `out` (the ping-pong partner) at the same run positions.
 // Three workgroup sizes by run length — one wave (up to 512 records), four (up to 2048), eight (longer: tiles of 4096; only a run
-// of more than one tile is read twice) — every launch walks the whole run list and a workgroup leaves at once when the run is not of
-// its class.
+// of more than one tile is read twice) — each launched over the list of its own runs (k_split_classify).
 // Per tile: the lanes' records (wave-contiguous slices) are ranked by digit with xb ballots (stable), the per-wave counts are scanned
 // across the waves, and every record goes straight from its register to its place — the run's pieces are written by one workgroup
 // within microseconds of each other, so their partial lines meet in the L2.
 static const int SPLIT_ITEMS = 8;
-static const u32 SPLIT_SMALL = 64 * SPLIT_ITEMS, SPLIT_MID = 256 * SPLIT_ITEMS;  // one tile of the one-wave / four-wave kernel: a run of one tile is read once
+// runs by length class (one list per workgroup size): a launch over ALL runs whose workgroups leave when the run is not theirs costs
+// more than the split itself — 1.7 M workgroups of 512 threads that only read two offsets still hold their wave slots for 2 us each
+// (3 of 8 ms at cfg 3, profiles/r04_kernel_stats_cfg3.md)
+__global__ __launch_bounds__(1024) void k_split_classify(u64 nruns, const u64* __restrict__ run_start, u32* __restrict__ lists /* [3][nruns] */, u32* __restrict__ list_n /* 3 */) {
+    __shared__ u32 s_cnt[3 * 16];
+    __shared__ u32 s_base[3];
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int cls = -1;
+    if (i < nruns) {
+        const u64 c = run_start[i + 1] - run_start[i];
+        cls = c <= 64 * 8 ? 0 : (c <= 256 * 8 ? 1 : 2);
+    }
+    u32 my_rank = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const u64 bal = __ballot(cls == k);
+        if (cls == k) my_rank = mbcnt(bal);
+        if (lane == 0) s_cnt[k * 16 + w] = (u32)__builtin_popcountll(bal);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const u32 k = threadIdx.x;
+        u32 run = 0;
+        for (int ww = 0; ww < 16; ++ww) { const u32 t = s_cnt[k * 16 + ww]; s_cnt[k * 16 + ww] = run; run += t; }
+        s_base[k] = run ? atomicAdd(&list_n[k], run) : 0u;
+    }
+    __syncthreads();
+    if (cls >= 0) lists[(u64)cls * nruns + s_base[cls] + s_cnt[cls * 16 + w] + my_rank] = (u32)i;
+}
 template <typename H, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_prefix_split(u64 nruns, const u32* __restrict__ run_prefix, const u64* __restrict__ run_start, const u64* __restrict__ in_lo,
+__global__ __launch_bounds__(THREADS) void k_prefix_split(const u32* __restrict__ run_list, const u32* __restrict__ run_prefix, const u64* __restrict__ run_start, const u64* __restrict__ in_lo,
                                                           const H* __restrict__ in_hi, u64* __restrict__ out_lo, H* __restrict__ out_hi, u32 SB, u32 xb,
-                                                          u32* __restrict__ start_dense /* indexed by the absolute prefix */, u32 len_above, u32 len_upto) {
+                                                          u32* __restrict__ start_dense /* indexed by the absolute prefix */) {
     constexpr bool HAS = HiTraits<H>::has;
     constexpr int NW = THREADS / 64, TILE = THREADS * SPLIT_ITEMS;
     __shared__ u32 s_wcnt[NW * 16];  // per wave and digit: records of the tile seen so far, then the wave's offset inside the digit
     __shared__ u32 s_rbase[16];      // run: first position of the digit
     __shared__ u32 s_roff[16];       // run: records of the digit in earlier tiles
-    const u64 run = blockIdx.x;
-    if (run >= nruns) return;
+    const u64 run = run_list[blockIdx.x];
     const u64 s0 = run_start[run];
     const u32 c = (u32)(run_start[run + 1] - s0);
-    if (c <= len_above || c > len_upto) return;
     const u32 NB = 1u << xb, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const u32 ntiles = (c + TILE - 1) / TILE;
     const u64* __restrict__ lo_r = in_lo + s0;

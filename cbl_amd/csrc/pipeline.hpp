@@ -288,19 +288,19 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
         if (nruns) {
             StageTimer t(c, ST_SCATTER);
             u32* const rd = real_dense.get() - w_lo;
-            for (u64 a = 0; a < nruns; a += 1u << 24) {  // (one grid holds fewer than 2^32 work items)
-                const u64 m = std::min<u64>(1u << 24, nruns - a);
-                auto launch = [&](auto h_tag, const auto* hin, auto* hout) {
-                    typedef decltype(h_tag) H;
-                    hipLaunchKernelGGL((k_prefix_split<H, 64>), dim3((unsigned)m), dim3(64), 0, c->stream, m, sprefix.get() + a, sstart.get() + a, lo, hin, lo2, hout, P.SB, xb, rd, 0u, SPLIT_SMALL);
-                    hipLaunchKernelGGL((k_prefix_split<H, 256>), dim3((unsigned)m), dim3(256), 0, c->stream, m, sprefix.get() + a, sstart.get() + a, lo, hin, lo2, hout, P.SB, xb, rd, SPLIT_SMALL,
-                                       SPLIT_MID);
-                    hipLaunchKernelGGL((k_prefix_split<H, 512>), dim3((unsigned)m), dim3(512), 0, c->stream, m, sprefix.get() + a, sstart.get() + a, lo, hin, lo2, hout, P.SB, xb, rd, SPLIT_MID,
-                                       0xFFFFFFFFu);
-                };
-                if constexpr (DROP_HI || !HiTraits<HiT>::has) launch(NoHi(), (const NoHi*)nullptr, (NoHi*)nullptr);
-                else launch(HiT(), hi, hi2);
-            }
+            if (nruns >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "too many runs for the prefix split");
+            Buf<u32> lists(c->pool, 3 * nruns), list_n(c->pool, 3);
+            CBLX_HIP(hipMemsetAsync(list_n.get(), 0, 12, c->stream));
+            hipLaunchKernelGGL(k_split_classify, grid1(nruns, 1024), dim3(1024), 0, c->stream, nruns, sstart.get(), lists.get(), list_n.get());
+            const std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), 3);
+            auto launch = [&](auto h_tag, const auto* hin, auto* hout) {
+                typedef decltype(h_tag) H;
+                if (ln[0]) hipLaunchKernelGGL((k_prefix_split<H, 64>), dim3(ln[0]), dim3(64), 0, c->stream, lists.get(), sprefix.get(), sstart.get(), lo, hin, lo2, hout, P.SB, xb, rd);
+                if (ln[1]) hipLaunchKernelGGL((k_prefix_split<H, 256>), dim3(ln[1]), dim3(256), 0, c->stream, lists.get() + nruns, sprefix.get(), sstart.get(), lo, hin, lo2, hout, P.SB, xb, rd);
+                if (ln[2]) hipLaunchKernelGGL((k_prefix_split<H, 512>), dim3(ln[2]), dim3(512), 0, c->stream, lists.get() + 2 * nruns, sprefix.get(), sstart.get(), lo, hin, lo2, hout, P.SB, xb, rd);
+            };
+            if constexpr (DROP_HI || !HiTraits<HiT>::has) launch(NoHi(), (const NoHi*)nullptr, (NoHi*)nullptr);
+            else launch(HiT(), hi, hi2);
             CBLX_HIP(hipGetLastError());
             advance();
         }
@@ -820,7 +820,9 @@ template <typename C> void pipeline_group(cblx_ctx* c, const GroupRegions& R, co
     const u32 npass = lsd_plan(P, false).total();  // buffer changes behind pass A (records in pieces: LSD passes only, no prefix split)
     // DEEP group (thousands of words per possible prefix: the dense low ranges of a many-GPU job at PREFIX_BITS <= 24): nearly every run
     // takes the long-run path, whose output is the twin — so the LSD passes end in the scratch area and the twin IS the slot.
-    const bool deep = msd_takes<WS>(P.SB) && N / std::max<u64>(1, (u64)win.w_hi - win.w_lo) >= 2048;
+    // (CBLX_GROUP_DEEP = 0 / 1 forces the choice: tests run small groups through both layouts)
+    const char* deep_env = std::getenv("CBLX_GROUP_DEEP");
+    const bool deep = msd_takes<WS>(P.SB) && (deep_env ? deep_env[0] == '1' : N / std::max<u64>(1, (u64)win.w_hi - win.w_lo) >= 2048);
     u64* last_lo = deep ? R.scr_lo : R.fin_lo;   // where the last LSD pass writes
     u64* last_hi = deep ? R.scr_hi : R.fin_hi;
     u64* oth_lo = deep ? R.fin_lo : R.scr_lo;

@@ -2029,8 +2029,8 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
     assert used[1] == 0
     if protocol == "sorted" or groups == 1:
         assert used[0] == 0
-    elif pb >= 12:
-        assert 2 <= used[0] <= (groups or 8), used
+    elif pb >= 12:  # (a rank whose range is narrower than a few histogram cells gets fewer groups than asked for, down to one)
+        assert 1 <= used[0] <= (groups or 8), used
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -2056,16 +2056,22 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
     assert fblob[2] == (len(qrecs), oq.serialize())
 
 
-@pytest.mark.parametrize("world,k,pb,canonical,groups,slices,gbps", [(4, 31, 24, False, 0, 2, 0.0), (4, 31, 24, False, 1, 3, 0.0), (8, 31, 28, True, 6, 1, 2.0), (3, 59, 28, False, 4, 2, 0.0),
-                                                                     (2, 25, 16, False, 0, 1, 1.0), (8, 31, 24, False, 1, 4, 2.0)])
-def test_rehearsal_of_rank_0_on_recorded_senders(world, k, pb, canonical, groups, slices, gbps):
+@pytest.mark.parametrize("world,k,pb,canonical,groups,slices,gbps,deep", [
+    (4, 31, 24, False, 0, 2, 0.0, None), (4, 31, 24, False, 1, 3, 0.0, None), (8, 31, 28, True, 6, 1, 2.0, None), (3, 59, 28, False, 4, 2, 0.0, None),
+    (2, 25, 16, False, 0, 1, 1.0, None), (8, 31, 24, False, 1, 4, 2.0, None),
+    # the two layouts of a group (last pass into the slot / into the scratch with the long-run path's twin as the slot), forced; short buckets and
+    # PREFIX_BITS = 6 buckets of thousands of words (the long-run path proper)
+    (4, 31, 24, False, 5, 2, 0.0, "1"), (4, 31, 24, False, 5, 2, 0.0, "0"), (2, 31, 9, False, 3, 1, 0.0, "1"), (2, 31, 9, True, 3, 2, 0.0, "0"), (3, 59, 12, False, 4, 1, 0.0, "1")])
+def test_rehearsal_of_rank_0_on_recorded_senders(world, k, pb, canonical, groups, slices, gbps, deep, monkeypatch):
     """cblx_comm_init_sim (the paced one-GPU rehearsal tools/emulate_wire.py times): ranks 1 .. W-1 record what they would send rank 0,
     rank 0 replays it — grouped receiver or not, paced or not — and ends up with exactly its range of the job's index: the entries of
     the one-process oracle's file (stream order slice-major, rank-minor) start with rank 0's entries."""
     _need_gpu()
     from cbl_amd.sharded import ShardedBuilder, _read_varint
 
-    L, nr, store = (150 if k < 59 else 250), 2500, 77 + world * 16 + groups
+    if deep is not None:
+        monkeypatch.setenv("CBLX_GROUP_DEEP", deep)
+    L, nr, store = (150 if k < 59 else 250), (2500 if pb > 12 else 12000), 77 + world * 16 + groups + (100 if deep else 0)
     bounds = np.zeros(world - 1, dtype=np.uint32)
     valid = False
     cuts = [nr * s // slices for s in range(slices + 1)]
@@ -2080,7 +2086,7 @@ def test_rehearsal_of_rank_0_on_recorded_senders(world, k, pb, canonical, groups
         g.close()
         cm.close()
     cbl_amd.Comm.sim_store_free(store)
-    assert used == 0 if groups == 1 else 2 <= used <= (groups or 8)
+    assert used == 0 if groups == 1 else 1 <= used <= (groups or 8)
     assert st["recv_bytes"] > 0 and st["sent_bytes"] > 0
     one = Oracle(k, pb, canonical)
     for c in range(slices):
@@ -2112,7 +2118,7 @@ def test_trie_union_by_merge_path_equals_the_sorting_route(k, pb, n, canonical, 
     o1.merge(o2)
     want1, want2 = o1.serialize(), o2.serialize()
     o1.merge(o2)  # once more: the set stays, but a Vec that met other's bucket is sorted again as a whole (iter_sorted, src/trievec/mod.rs:209-220)
-    want1b = o1.serialize()
+    want1b, want2b = o1.serialize(), o2.serialize()  # (other's Vecs that now meet a bucket cloned by the first merge get sorted too)
     def same(g, want, what):
         got = g.serialize()
         if got == want:

@@ -21,3 +21,5 @@ d = json.loads(open(f'profiles/{R}_bench_cfg2.json').read())
 print('cfg2', d['ms_per_step'], d['value'], 'h2d', d['h2d_inclusive']['ms_per_step'], 'fasta', d['fasta_inclusive']['ms_per_step'], 'per record', d['per_record']['ms_total'],
       'serialize', d['serialize']['to_host_ms'], 'frac', d['roofline']['frac'])
 PY
+python tools/write_wire_profile.py profiles/${R}_wire_emulated.md gpurun_out/$T/wire_cfg3.json gpurun_out/$T/wire_cfg2.json gpurun_out/$T/wire_cfg4.json
+[ -s gpurun_out/$T/bench_cpufull.json ] && tail -1 gpurun_out/$T/bench_cpufull.json | python -c "import json,sys; json.dump(json.loads(sys.stdin.read()), open('profiles/${R}_bench_cpufull.json','w'), indent=1)"
