@@ -130,8 +130,9 @@ def parse_args(argv=None):
     ap.add_argument("--protocol", choices=["bins", "sorted", "words"], default=None,
                     help="N > 1: what crosses the links. native transport: bins (default) or sorted; torch transport: sorted (default) or words")
     ap.add_argument("--slices", type=int, default=None,
-                    help="N > 1: slices per rank and step. Default 1 for the native bins protocol (its grouped receiver sends group-major after the rank's "
-                         "whole first pass: slices only add fixed costs), 4 otherwise (the exchange of a slice overlaps the next slice's kernels)")
+                    help="N > 1: slices per rank and step. Default 2 for the native bins protocol (its grouped receiver sends group-major after the rank's "
+                         "whole first pass; only the first group's share of slice 0 crosses under slice 1's kernels — more slices only add fixed costs), "
+                         "4 otherwise (the exchange of a slice overlaps the next slice's kernels)")
     ap.add_argument("--transport", choices=["torch", "native"], default="native",
                     help="N > 1: exchange driven from Python over torch.distributed, or the whole sharded insert inside libcblx on RCCL directly")
     ap.add_argument("--cpu-sample-reads", type=int, default=None,
@@ -144,7 +145,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (value_h2d_inclusive)")
     ap.add_argument("--no-fasta", action="store_true", help="skip the file-inclusive measurement (fasta_inclusive: the same reads as a FASTA file on tmpfs)")
     ap.add_argument("--no-per-record", action="store_true", help="skip the per-record measurement (per_record: one cblx_insert_seq call per read from a C++ host program)")
-    ap.add_argument("--recv-groups", type=int, default=0, help="N > 1, native bins protocol: groups per rank of the receiver (0 = default 8, 1 = ungrouped)")
+    ap.add_argument("--recv-groups", type=int, default=0, help="N > 1, native bins protocol: groups per rank of the receiver (0 = default 4, 1 = ungrouped)")
     ap.add_argument("--force-sharded", action="store_true", help="dev: run the N-GPU code path on a 1-rank RCCL group")
     ap.add_argument("--shared-gpu", action="store_true", help="dry run: all ranks on GPU 0, exchange staged through gloo")
     args = ap.parse_args(argv)
@@ -157,7 +158,7 @@ def parse_args(argv=None):
         if getattr(args, name) is None:
             setattr(args, name, cfg[name])
     if args.slices is None:
-        args.slices = 1 if (args.transport == "native" and args.protocol == "bins" and not args.force_sharded) else 4
+        args.slices = 2 if (args.transport == "native" and args.protocol == "bins" and not args.force_sharded) else 4
     args.kind = cfg["kind"]
     args.genome = cfg.get("genome", 0)
     if args.cpu_sample_reads is None:  # the oracle slows down with PREFIX_BITS (2^28-bit Fenwick bitvector) and word width

@@ -781,7 +781,7 @@ inline u32 recv_groups_wanted(const cblx_comm* cm) {
     if (cm->recv_groups) return cm->recv_groups;
     const char* e = std::getenv("CBLX_RECV_GROUPS");
     const u32 v = e ? (u32)std::strtoul(e, nullptr, 10) : 0;
-    return v ? std::min(v, 14u) : 8u;
+    return v ? std::min(v, 14u) : 4u;  // measured against a paced wire (profiles/r04_wire_emulated.md): 4 groups are best at 55 GB/s per link for every configuration; more pay on slower links
 }
 template <typename C>
 bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, const u32* bounds) {
@@ -852,7 +852,8 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     std::vector<std::vector<u64>> recvh(nslices);  // headers: what every source sends me, per slice
     u64 filled = 0;
     struct Drain { Transport& t; ~Drain() { try { t.wait(); } catch (...) {} } } drain{T};
-    auto grow = [&](u64 need) {  // (nothing is on the wire yet: only own pieces are in the log)
+    auto grow = [&](u64 need) {  // (only own pieces and the first group's early shares are in the log)
+        T.wait();
         CBLX_HIP(hipStreamSynchronize(c->stream));
         const u64 ncap = std::min<u64>(LIMIT, need + need / 4 + 4096);
         Buf<u64> lo;
@@ -866,6 +867,47 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         }
         a_lo = std::move(lo); a_hi = std::move(hi); a_dig = std::move(dg);
         cap = ncap;
+    };
+    std::vector<hipEvent_t> gev(Gmax, nullptr);
+    struct Events { std::vector<hipEvent_t>& v; ~Events() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } events{gev};
+    // record range [first, first + len) of bins [b0, b1) in a slice's send buffer (the own window is not in it)
+    auto send_range = [&](const Sent& S, u32 b0, u32 b1, u64& first, u64& len) {
+        u64 before = 0, inside = 0;
+        for (u32 bin = 0; bin < b1; ++bin) (bin < b0 ? before : inside) += S.tot[bin];
+        first = before >= S.own_a + S.own ? before - S.own : before;  // ranges of other ranks lie wholly before or behind the own window
+        len = inside;
+    };
+    // the items of (group k, slice s): this rank's records for every other rank's group k, and where the other ranks' records for
+    // this rank's group k land in the log (every rank issues the same items in the same order, empty ones included: a callback
+    // transport's exchange is a collective)
+    auto add_items = [&](u32 k, u32 s, std::vector<Transport::Item>& items) {
+        Sent& S = sent[s];
+        std::vector<u64> so(W, 0), sl(W, 0), rof(W, 0), rl(W, 0);
+        for (u32 d = 0; d < W; ++d) {
+            if (d == me || k >= M.ngroups[d]) continue;
+            u32 b0 = 256, b1 = 0;  // bins of (rank d, group k)
+            for (u32 bin = M.bin_lo[d]; bin < M.bin_lo[d + 1]; ++bin)
+                if (M.iv_of[bin] != 0xFFFFFFFFu && M.grp_of[M.iv_of[bin]] == k) { b0 = std::min(b0, bin); b1 = std::max(b1, bin + 1); }
+            if (b0 >= b1) continue;
+            send_range(S, b0, b1, so[d], sl[d]);
+        }
+        if (k < NG)
+            for (u32 r = 0; r < W; ++r) {
+                if (r == me) continue;
+                const u32* pc = pcnt.data() + ((size_t)s * W + r) * 256;
+                u64 before = 0, inside = 0;
+                for (u32 cl = 0; cl < gc0[k + 1]; ++cl) (cl < gc0[k] ? before : inside) += pc[cl];
+                rof[r] = (u64)pbase[(size_t)s * W + r] + before;
+                rl[r] = inside;
+            }
+        auto item = [&](const u8* src, u8* dst, size_t es) {
+            Transport::Item it{src, dst, so, sl, rof, rl};
+            for (u32 r = 0; r < W; ++r) { it.s_off[r] *= es; it.s_len[r] *= es; it.r_off[r] *= es; it.r_len[r] *= es; }
+            items.push_back(std::move(it));
+        };
+        item((const u8*)S.lo.get(), (u8*)a_lo.get(), 8);
+        if (OHS) item(S.hi.get(), a_hi.get(), OHS);
+        item(S.dig.get(), a_dig.get(), 1);
     };
     struct Work { ChunkPlan pl; Buf<u64> t_lo; Buf<u8> t_hi; Buf<u32> counts, colpre, scratch, adj, coltot; };
     Work prev_work;
@@ -947,51 +989,18 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         if (trace) fprintf(stderr, "[cblx grouped] rank %u slice %u: N=%llu own=%llu incoming=%llu filled=%llu\n", me, s, (unsigned long long)N, (unsigned long long)S.own,
                            (unsigned long long)incoming, (unsigned long long)filled);
         filled += incoming;
+        if (s + 1 < nslices) {  // the first group's share of this slice crosses the links under the next slice's kernels
+            std::vector<Transport::Item> items;
+            add_items(0, s, items);
+            T.exchange_items(items, c->stream);
+        }
         prev_work = std::move(wk);
     }
     // -- the wire, group-major: exchange k carries group k of EVERY rank (ranks with fewer groups send nothing in the later ones)
-    std::vector<hipEvent_t> gev(Gmax, nullptr);
-    struct Events { std::vector<hipEvent_t>& v; ~Events() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } events{gev};
-    // record range [first, first + len) of bins [b0, b1) in a slice's send buffer (the own window is not in it)
-    auto send_range = [&](const Sent& S, u32 b0, u32 b1, u64& first, u64& len) {
-        u64 before = 0, inside = 0;
-        for (u32 bin = 0; bin < b1; ++bin) (bin < b0 ? before : inside) += S.tot[bin];
-        first = before >= S.own_a + S.own ? before - S.own : before;  // ranges of other ranks lie wholly before or behind the own window
-        len = inside;
-    };
     for (u32 k = 0; k < Gmax; ++k) {
         std::vector<Transport::Item> items;
-        for (u32 s = 0; s < nslices; ++s) {
-            Sent& S = sent[s];
-            std::vector<u64> so(W, 0), sl(W, 0), rof(W, 0), rl(W, 0);
-            for (u32 d = 0; d < W; ++d) {
-                if (d == me || k >= M.ngroups[d]) continue;
-                // bins of (rank d, group k)
-                u32 b0 = 256, b1 = 0;
-                for (u32 bin = M.bin_lo[d]; bin < M.bin_lo[d + 1]; ++bin)
-                    if (M.iv_of[bin] != 0xFFFFFFFFu && M.grp_of[M.iv_of[bin]] == k) { b0 = std::min(b0, bin); b1 = std::max(b1, bin + 1); }
-                if (b0 >= b1) continue;
-                send_range(S, b0, b1, so[d], sl[d]);
-            }
-            if (k < NG)
-                for (u32 r = 0; r < W; ++r) {
-                    if (r == me) continue;
-                    const u32* pc = pcnt.data() + ((size_t)s * W + r) * 256;
-                    u64 before = 0, inside = 0;
-                    for (u32 cl = 0; cl < gc0[k + 1]; ++cl) (cl < gc0[k] ? before : inside) += pc[cl];
-                    rof[r] = (u64)pbase[(size_t)s * W + r] + before;
-                    rl[r] = inside;
-                }
-            // (every rank issues the same items in the same order, empty ones included: a callback transport's exchange is a collective)
-            auto item = [&](const u8* src, u8* dst, size_t es) {
-                Transport::Item it{src, dst, so, sl, rof, rl};
-                for (u32 r = 0; r < W; ++r) { it.s_off[r] *= es; it.s_len[r] *= es; it.r_off[r] *= es; it.r_len[r] *= es; }
-                items.push_back(std::move(it));
-            };
-            item((const u8*)S.lo.get(), (u8*)a_lo.get(), 8);
-            if (OHS) item(S.hi.get(), a_hi.get(), OHS);
-            item(S.dig.get(), a_dig.get(), 1);
-        }
+        // (group 0 of every slice but the last left right behind that slice's pass A, under the next slice's kernels)
+        for (u32 s = (k == 0 ? nslices - 1 : 0u); s < nslices; ++s) add_items(k, s, items);
         T.exchange_items(items, c->stream);
         CBLX_HIP(hipEventCreateWithFlags(&gev[k], hipEventDisableTiming));
         T.record(gev[k], c->stream);

@@ -730,8 +730,7 @@ __global__ __launch_bounds__(256) void k_boundaries_cold(const u64* __restrict__
 // Three workgroup sizes by run length — one wave (up to 512 records), four (up to 2048), eight (longer: tiles of 4096; only a run
 // of more than one tile is read twice) — each launched over the list of its own runs (k_split_classify).
 // Per tile: the lanes' records (wave-contiguous slices) are ranked by digit with xb ballots (stable), the per-wave counts are scanned
-// across the waves, and every record goes straight from its register to its place — the run's pieces are written by one workgroup
-// within microseconds of each other, so their partial lines meet in the L2.
+// across the waves, the tile is staged in LDS in its final order and leaves as one contiguous piece per digit.
 static const int SPLIT_ITEMS = 8;
 // runs by length class (one list per workgroup size): a launch over ALL runs whose workgroups leave when the run is not theirs costs
 // more than the split itself — 1.7 M workgroups of 512 threads that only read two offsets still hold their wave slots for 2 us each
@@ -772,6 +771,14 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split(const u32* __restrict_
     __shared__ u32 s_wcnt[NW * 16];  // per wave and digit: records of the tile seen so far, then the wave's offset inside the digit
     __shared__ u32 s_rbase[16];      // run: first position of the digit
     __shared__ u32 s_roff[16];       // run: records of the digit in earlier tiles
+    __shared__ u32 s_tbase[16];      // tile: first staged slot of the digit
+    // the tile in its final order: what leaves is one contiguous piece per digit (the whole tile front to back for a one-tile run).
+    // (Straight from the registers every store instruction touched ~16 lines with 32 bytes each — the partial-line pieces that make the
+    // scatter kernel slow, DESIGN.md §3.4 — and the split took as long as the pass it replaced.)
+    // 16-byte records (K = 59) go straight from the registers instead: staged they take 64 KB per eight-wave workgroup, two per CU,
+    // and the split loses more to occupancy than the pieces cost (cfg 4: 61.7 ms staged, 60.1 not)
+    constexpr bool STAGE = !HAS;
+    __shared__ u64 s_lo[STAGE ? TILE : 1];
     const u64 run = run_list[blockIdx.x];
     const u64 s0 = run_start[run];
     const u32 c = (u32)(run_start[run + 1] - s0);
@@ -855,28 +862,42 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split(const u32* __restrict_
         }
         __syncthreads();
         u32 tcnt = 0;
-        if (w == 0) {  // per digit: exclusive scan across the waves; a one-tile run also gets its digit starts here
+        if (w == 0) {  // per digit: exclusive scan across the waves, the tile's digit starts; a one-tile run's are the run's
             if (lane < 16) {
                 u32 runc = 0;
 #pragma unroll
                 for (int ww = 0; ww < NW; ++ww) { const u32 x = s_wcnt[ww * 16 + lane]; s_wcnt[ww * 16 + lane] = runc; runc += x; }
                 tcnt = runc;
             }
-            if (ntiles == 1) {
-                u32 inc = tcnt;
+            u32 inc = tcnt;
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { const u32 x = __shfl_up(inc, o, 64); if (lane >= (u32)o) inc += x; }
-                if (lane < 16) s_rbase[lane] = inc - tcnt;
-            }
+            for (int o = 1; o < 16; o <<= 1) { const u32 x = __shfl_up(inc, o, 64); if (lane >= (u32)o) inc += x; }
+            if (lane < 16) { s_tbase[lane] = inc - tcnt; if (ntiles == 1) s_rbase[lane] = inc - tcnt; }
         }
         __syncthreads();
+        if constexpr (STAGE) {
 #pragma unroll
-        for (int j = 0; j < SPLIT_ITEMS; ++j) {
-            if ((u32)j < R && dp[j] != 0xFFFFFFFFu) {
-                const u32 d = dp[j] >> 16;
-                const u64 dst = s0 + s_rbase[d] + s_roff[d] + my[d] + (dp[j] & 0xFFFFu);
-                out_lo[dst] = klo[j];
-                if constexpr (HAS) out_hi[dst] = (H)khi[j];
+            for (int j = 0; j < SPLIT_ITEMS; ++j) {
+                if ((u32)j < R && dp[j] != 0xFFFFFFFFu) {
+                    const u32 d = dp[j] >> 16;
+                    s_lo[s_tbase[d] + my[d] + (dp[j] & 0xFFFFu)] = klo[j];
+                }
+            }
+            __syncthreads();
+            for (u32 i = tid; i < n_tile; i += THREADS) {
+                const u64 v = s_lo[i];
+                const u32 d = (u32)get_bits(v, 0ull, SB, xb);
+                out_lo[s0 + s_rbase[d] + s_roff[d] + (i - s_tbase[d])] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SPLIT_ITEMS; ++j) {
+                if ((u32)j < R && dp[j] != 0xFFFFFFFFu) {
+                    const u32 d = dp[j] >> 16;
+                    const u64 dst = s0 + s_rbase[d] + s_roff[d] + my[d] + (dp[j] & 0xFFFFu);
+                    out_lo[dst] = klo[j];
+                    if constexpr (HAS) out_hi[dst] = (H)khi[j];
+                }
             }
         }
         __syncthreads();

@@ -169,7 +169,9 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
             hipLaunchKernelGGL(k_piece_tile_table, grid1(nt_max, 256), dim3(256), 0, c->stream, d_cnt.get(), np, seg_first.get(), nt_dev.get(), pfirst.get(), ppos.get(), t_start.get(),
                                t_count.get(), t_seg.get());
             CBLX_HIP(hipGetLastError());
-            CBLX_HIP(hipStreamSynchronize(c->stream));  // the piece tables are released here
+            // the piece tables are released here. (A group of the grouped receiver skips the host wait: everything that could reuse the
+            // blocks is queued on this stream behind the kernels that read them, and eight groups pay every idle gap eight times)
+            if (!win) CBLX_HIP(hipStreamSynchronize(c->stream));
         } else {   // pass A
             const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
             const DigitBits dfn{SBs + RB, nA};
@@ -265,7 +267,7 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
             advance();
         }
         CBLX_HIP(hipGetLastError());
-        CBLX_HIP(hipStreamSynchronize(c->stream));  // the pass tables are released here
+        if (!win) CBLX_HIP(hipStreamSynchronize(c->stream));  // the pass tables are released here (a group: see above)
     }
     if (xb) {
         // -- the last xb prefix bits: every run of equal super-prefix split in LDS, written to the other buffer in final order, the

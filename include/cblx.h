@@ -236,7 +236,7 @@ int cblx_comm_set_protocol(cblx_comm* comm, uint32_t protocol);
 /* The receiver of CBLX_PROTO_BINS in GROUPS (no reference counterpart; same result, another schedule): every rank's prefix range is
  * cut into `groups` parts of about equal sampled mass, the senders' first pass also separates the groups, the data crosses the links
  * group-major, and the receiver runs the remaining passes + bucket kernels of group g while groups g+1.. are still on the wire.
- * 0 = default (CBLX_RECV_GROUPS in the environment, else 8), 1 = off (everything waits for the last record), at most 14. Every rank
+ * 0 = default (CBLX_RECV_GROUPS in the environment, else 4), 1 = off (everything waits for the last record), at most 14. Every rank
  * of a job sets the same. cblx_comm_groups_used: groups the last cblx_sharded_insert_seqs_device of this rank worked through
  * (0: it took the ungrouped path — index not empty, ranges too narrow for the cuts, one rank). */
 /* Rehearsal of ONE rank of a `world`-GPU job on one GPU (dev / bench tooling, no reference counterpart: tools/emulate_wire.py). Ranks

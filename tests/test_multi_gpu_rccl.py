@@ -44,7 +44,7 @@ def _worker(rank, world, port, k, pb, canonical, protocol, native, per, L, q, gr
             box = [cbl_amd.Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             comm = cbl_amd.Comm.rccl(box[0], rank, world, rank)
-            comm.set_recv_groups(groups)  # 0: the default (grouped receiver, 8 groups per rank), 1: everything waits for the last record
+            comm.set_recv_groups(groups)  # 0: the default (grouped receiver, 4 groups per rank), 1: everything waits for the last record
         g = cbl_amd.CBL(k, pb, canonical=canonical, device=rank)
         sb = sharded.ShardedBuilder(g, dist, slices=3, protocol=protocol, comm=comm)
         for batch, n in enumerate(per[rank]):

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--wire-gbps", default="40,55,75,0")
     ap.add_argument("--groups", default="8", help="groups per rank of the grouped receiver; several values separated by commas")
     ap.add_argument("--slices", type=int, default=4, help="slices of the UNGROUPED run (the grouped one sends nothing before its last slice is through pass A: 1 slice)")
+    ap.add_argument("--grouped-slices", default="2", help="slices of the grouped runs (group 0 of every slice but the last crosses under the next slice's kernels); several values separated by commas")
     ap.add_argument("--steps", type=int, default=3)
     a = ap.parse_args()
     k, pb, nr, L = CFG[a.config]
@@ -54,9 +55,9 @@ def main():
 
     bounds = np.zeros(W - 1, dtype=np.uint32)
     have_bounds = False
-    modes = [("grouped", int(x), 1) for x in a.groups.split(",")] + [("ungrouped", 1, a.slices)]
+    modes = [("grouped", int(x), int(y)) for x in a.groups.split(",") for y in a.grouped_slices.split(",")] + [("ungrouped", 1, a.slices)]
     for mode, groups, slices in modes:
-        store = 1000 + groups
+        store = 1000 + groups * 16 + slices
         for r in range(1, W):  # the senders: what each would send rank 0
             rb, ro = synth.reads_torch(42, nr, L, first_read=r * nr, device="cuda")
             cm = cbl_amd.Comm.sim(r, W, store)

@@ -15,6 +15,7 @@ v = json.loads(open("$OUT/bench_line.json").read().strip().splitlines()[-1])["va
 print("REGRESSION GUARD cfg 2:", "ok" if v >= 41e9 else "BELOW 41 G k-mers/s", v)
 PY
 bash tools/collect_counters.sh ${TAG}_sq cfg2
+bash tools/collect_counters.sh ${TAG}_sq4 cfg4   # K = 59: VALU per k-mer of the 128-bit k_encode
 bash tools/r3_lines.sh $TAG configs sharded
 for w in "--reads 10000000" "" "--reads 12500000 --prefix-bits 28" "--k 59 --prefix-bits 28 --reads 6250000 --read-len 250"; do
   n=$(echo "$w" | tr -d ' -' | cut -c1-24); [ -z "$n" ] && n=cfg5

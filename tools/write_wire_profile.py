@@ -29,7 +29,7 @@ def main():
         for m in modes:
             row = {r["link_gbps"]: r for r in o["runs"] if (r["mode"], r.get("groups", 0), r["slices"]) == m}
             any_r = next(iter(row.values()))
-            name = (f"grouped, {any_r['groups_used']} groups, 1 slice" if m[0] == "grouped" else f"ungrouped (round 3), {m[2]} slices")
+            name = (f"grouped, {any_r['groups_used']} groups, {m[2]} slice{'s' if m[2] > 1 else ''}" if m[0] == "grouped" else f"ungrouped (round 3), {m[2]} slices")
             L.append(f"| {name} | " + " | ".join(f"**{row[x]['ms_best']:.1f}**" if x in row else "—" for x in rates) +
                      f" | {any_r['recv_bytes_per_step'] / 1e9:.2f} GB | {any_r['recv_bytes_per_step'] / (W - 1) / 55e9 * 1e3:.1f} ms |")
         L.append("")
@@ -38,7 +38,7 @@ def main():
             row = {r["link_gbps"]: r for r in o["runs"] if (r["mode"], r.get("groups", 0), r["slices"]) == m}
             if 55.0 in row:
                 ms = row[55.0]["ms_best"]
-                L.append(f"* {m[0]}{' ' + str(m[1]) if m[0] == 'grouped' else ''} at 55 GB/s: {W} x {km / 1e9:.2f} G / {ms:.1f} ms = {W * km / ms / 1e6:.0f} G k-mers/s if every rank kept rank 0's pace "
+                L.append(f"* {m[0]}{' ' + str(m[1]) + ' groups, ' + str(m[2]) + ' slice(s)' if m[0] == 'grouped' else ''} at 55 GB/s: {W} x {km / 1e9:.2f} G / {ms:.1f} ms = {W * km / ms / 1e6:.0f} G k-mers/s if every rank kept rank 0's pace "
                          f"= {W * km / ms / (km / o['direct_one_gpu_ms']):.2f} x the one-GPU rate of the same configuration.")
         g = [r for r in o["runs"] if r["mode"] == "grouped" and r["link_gbps"] == 0]
         u = [r for r in o["runs"] if r["mode"] == "ungrouped" and r["link_gbps"] == 0]
