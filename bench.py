@@ -67,14 +67,17 @@ def stage_alg_bytes(k: int, pb: int, read_len: int):
     r_out = 8 if hi == 1 else r_in
     n_a = min(8, pb)
     lsd = (pb - n_a + 7) // 8
-    # digit side channel: a scatter also writes the next pass's digit (1 B); that pass's histogram then reads 1 B per
+    split = 0
+    if pb > 24:  # two LSD passes on 16 bits, the last pb - 24 bits by k_prefix_split: one more read + write of every record, no histogram
+        lsd, split = 2, 1
+    # digit side channel: a scatter also writes the next LSD pass's digit (1 B); that pass's histogram then reads 1 B per
     # record instead of the record
     side = lsd
     return {
         "chunks": read_len / (read_len - k + 1),             # validity scan reads every base once
         "encode": read_len / (read_len - k + 1) + r_in,        # read bases, write one record (+ fused first-pass histogram)
         "radix_hist": float(side),                             # pass A's histogram is fused in KRN-1; the others read the side channel
-        "radix_scatter": (r_in + r_out) + lsd * 2 * r_out + side,  # every pass reads + writes every record once
+        "radix_scatter": (r_in + r_out) + (lsd + split) * 2 * r_out + side,  # every pass (and the prefix split) reads + writes every record once
         # bucket starts: from the last pass's tables (k_dir_gather) or stored by the last scatter itself (PREFIX_BITS > 24,
         # k_dir_resolve); the sorted records are re-read for them only when there is no LSD pass at all (PREFIX_BITS <= 8)
         "directory": 0.0 if lsd >= 1 else r_out,
@@ -93,7 +96,7 @@ def merge_alg_bytes(k: int, pb: int):
 
 
 KERNEL_OF = {"radix_scatter": "k_radix_scatter", "radix_hist": "k_radix_hist_bytes", "radix_scan": "k_colscan_*+k_seg_*", "encode": "k_encode",
-             "bucket_medium": "k_bucket_msd (+ k_bucket_claim for runs full of repeats)", "bucket_small": "k_bucket_small", "bucket_huge": "k_bucket_huge", "bucket_big": "k_big_split+k_bucket_msd+k_big_collect",
+             "bucket_medium": "k_bucket_msd (+ k_bucket_claim for runs full of repeats)", "bucket_small": "k_bucket_small", "bucket_huge": "k_bucket_huge", "bucket_big": "long runs: k_radix_scatter on the runs + k_bucket_msd (build); k_bucket_union (Trie |= Trie)",
              "directory": "k_dir_gather/k_dir_resolve+k_bitvector+k_bucket_table", "chunks": "k_scan_invalid+chunk table",
              "merge_gather": "k_merge_gather"}
 

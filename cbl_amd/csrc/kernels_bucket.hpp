@@ -214,7 +214,12 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify(u64 nb, u32 lds_m
 // ---- `self |= other` without re-partitioning: both indexes are already grouped by prefix ----------------------------
 // (src/wordset/set_ops.rs:123-157 walks the union of the two prefix bitvectors; here: OR of the bitvector words, rank
 // by popcount scan, one merged run of cs + co slots per prefix, then the per-bucket |= rules of src/trievec/set_ops.rs)
-struct MergeArgs { const u32* cs; const u64* ostart; const u8* okind; u64* o_lo; u64* o_hi; };
+struct MergeArgs {
+    const u32* cs; const u64* ostart; const u8* okind; u64* o_lo; u64* o_hi;
+    // DIRECT mode (k_bucket_msd's merge instantiation; null = the run was gathered): the bucket's two halves are read where they are
+    // stored — self's arena from sstart[r], other's from ostart[r] — and only the result is written to the run
+    const u64* s_lo = nullptr; const u64* s_hi = nullptr; const u64* sstart = nullptr;
+};
 
 __global__ void k_bv_or(u64 nwords, const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ out, u32* __restrict__ popc) {
     const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,7 +255,8 @@ template <bool WS, int LPB>
 __global__ __launch_bounds__(256) void k_merge_gather(u64 nb, const u64* __restrict__ start, const u32* __restrict__ m_cs, const u64* __restrict__ m_sstart,
                                                       const u64* __restrict__ m_ostart, const u64* __restrict__ s_lo, const u64* __restrict__ s_hi,
                                                       const u64* __restrict__ o_lo, const u64* __restrict__ o_hi, u64* __restrict__ out_lo,
-                                                      u64* __restrict__ out_hi, const u8* __restrict__ skip_skind = nullptr, const u8* __restrict__ skip_okind = nullptr) {
+                                                      u64* __restrict__ out_hi, const u8* __restrict__ skip_skind = nullptr, const u8* __restrict__ skip_okind = nullptr,
+                                                      u32 skip_upto = 0 /* both-sided buckets of up to this many words are read in place by their kernel */) {
     const u64 r = ((u64)blockIdx.x * 256 + threadIdx.x) / LPB;
     if (r >= nb) return;
     const u32 lane = threadIdx.x & (LPB - 1);
@@ -258,12 +264,29 @@ __global__ __launch_bounds__(256) void k_merge_gather(u64 nb, const u64* __restr
     const u32 c = (u32)(start[r + 1] - d0), cs = m_cs[r];
     // Trie |= Trie: k_bucket_union merges the two stored lists straight into the run — nothing to copy here
     if (skip_skind && cs != 0 && cs != c && skip_skind[r] == KIND_TRIE && skip_okind[r] == KIND_TRIE) return;
+    if (cs != 0 && cs != c && c <= skip_upto) return;
     const u64 ss = m_sstart[r], os = m_ostart[r];
     for (u32 j = lane; j < c; j += LPB) {
         const bool from_self = j < cs;
         const u64 src = from_self ? ss + j : os + (j - cs);
         out_lo[d0 + j] = from_self ? s_lo[src] : o_lo[src];
         if constexpr (WS) out_hi[d0 + j] = from_self ? s_hi[src] : o_hi[src];
+    }
+}
+// the same for the buckets of a list (a both-sided bucket that was read in place gave up in its kernel and goes to the radix kernel, which works on the run)
+template <bool WS>
+__global__ __launch_bounds__(256) void k_merge_gather_list(const BDesc* __restrict__ list, const u32* __restrict__ list_n, const u32* __restrict__ m_cs, const u64* __restrict__ m_sstart,
+                                                           const u64* __restrict__ m_ostart, const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, const u64* __restrict__ o_lo,
+                                                           const u64* __restrict__ o_hi, u64* __restrict__ out_lo, u64* __restrict__ out_hi) {
+    if (blockIdx.x >= *list_n) return;
+    const BDesc d = list[blockIdx.x];
+    const u32 c = d.c & BDESC_LEN_MASK, cs = m_cs[d.r];
+    const u64 ss = m_sstart[d.r], os = m_ostart[d.r];
+    for (u32 j = threadIdx.x; j < c; j += 256) {
+        const bool from_self = j < cs;
+        const u64 src = from_self ? ss + j : os + (j - cs);
+        out_lo[d.start + j] = from_self ? s_lo[src] : o_lo[src];
+        if constexpr (WS) out_hi[d.start + j] = from_self ? s_hi[src] : o_hi[src];
     }
 }
 // one-sided buckets are final after the gather (self-only: untouched; other-only: cloned as stored); both-sided ones
@@ -955,11 +978,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MS
     bool valid[ITEMS];
     // all loads first, unconditionally (slots past the run re-read its first element): eight independent global loads in
     // flight per lane instead of eight load -> wait -> use round trips inside per-slot branches
+    u32 cs_dir = 0;   // direct merge: self's length, and where the two halves are stored
+    u64 a_self = 0, a_oth = 0;
+    bool direct = false;
+    if constexpr (MERGE) if (merging && mg.s_lo) { direct = true; cs_dir = mg.cs[r]; a_self = mg.sstart[r]; a_oth = mg.ostart[r]; }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const u32 e = w * EPW + j * 64 + lane;
         valid[j] = (u32)j < R && e < c;
-        key[j] = load_sfx<WS, HiT>(lo, hi, s0 + (valid[j] ? e : 0u), SB);
+        const u32 ee = valid[j] ? e : 0u;
+        if (MERGE && direct) key[j] = ee < cs_dir ? load_sfx<WS, u64>(mg.s_lo, mg.s_hi, a_self + ee, SB) : load_sfx<WS, u64>(mg.o_lo, mg.o_hi, a_oth + (ee - cs_dir), SB);
+        else key[j] = load_sfx<WS, HiT>(lo, hi, s0 + ee, SB);
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {

@@ -1330,13 +1330,19 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
     // Narrow suffixes; CBLX_MERGE_UNION=0 keeps the counting-sort route (tests compare the two)
     const char* union_env = std::getenv("CBLX_MERGE_UNION");  // (read per call: tests switch it)
     const bool union_path = !WS && !(union_env && union_env[0] == '0');
+    // both-sided buckets of up to 4096 words (the counting-sort classes) are read where they are stored: their kernel loads self's part from
+    // self's arena and other's from other's, and only the result is written — the gather moved 16 bytes per word for nothing.
+    // CBLX_MERGE_DIRECT=0 gathers them as before
+    const char* direct_env = std::getenv("CBLX_MERGE_DIRECT");
+    const bool direct = msd_takes<WS>(P.SB) && !(direct_env && direct_env[0] == '0');
+    const u32 direct_upto = direct ? 512u * MED_ITEMS : 0u;
     {
         StageTimer t(c, ST_EXPAND);
         with_lpb(N, nb, [&](auto lpb) {
             constexpr int LPB = decltype(lpb)::value;
             hipLaunchKernelGGL((k_merge_gather<WS, LPB>), lpb_grid(nb, LPB), dim3(256), 0, c->stream, nb, nr.start.get(), m_cs.get(), m_sstart.get(), m_ostart.get(),
                                s.a_lo.get(), s.a_hi.get(), o.a_lo.get(), o.a_hi.get(), nr.a_lo.get(), nr.a_hi.get(), union_path ? m_skind.get() : (const u8*)nullptr,
-                               union_path ? m_okind.get() : (const u8*)nullptr);
+                               union_path ? m_okind.get() : (const u8*)nullptr, direct_upto);
         });
     }
     Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
@@ -1346,7 +1352,9 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
                        nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get(), union_path);
     CBLX_HIP(hipGetLastError());
     std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
-    const MergeArgs ma{m_cs.get(), m_ostart.get(), m_okind.get(), o.a_lo.get(), o.a_hi.get()};
+    const MergeArgs ma{m_cs.get(), m_ostart.get(), m_okind.get(), o.a_lo.get(), o.a_hi.get()};  // (kernels that work on the gathered run)
+    MergeArgs ma_msd = ma;                                                                       // (the counting-sort classes: in place)
+    if (direct) { ma_msd.s_lo = s.a_lo.get(); ma_msd.s_hi = s.a_hi.get(); ma_msd.sstart = m_sstart.get(); }
     u64* a_lo = nr.a_lo.get();
     HiT* a_hi = WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr;
     if (ln[CLS_UNION]) {
@@ -1366,19 +1374,19 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
             constexpr bool PK = decltype(packed_tag)::value;
             if (ln[CLS_M16])
                 hipLaunchKernelGGL((k_bucket_msd<64, 128, PK, WS, HiT, true>), dim3(ln[CLS_M16]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M16 * nb, list_n.get() + CLS_M16,
-                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
+                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma_msd);
             if (ln[CLS_M64])
                 hipLaunchKernelGGL((k_bucket_msd<64, 512, PK, WS, HiT, true>), dim3(ln[CLS_M64]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M64 * nb, list_n.get() + CLS_M64,
-                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
+                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma_msd);
             if (ln[CLS_M128])
                 hipLaunchKernelGGL((k_bucket_msd<128, 1024, PK, WS, HiT, true>), dim3(ln[CLS_M128]), dim3(128), 0, c->stream, lists.get() + (size_t)CLS_M128 * nb, list_n.get() + CLS_M128,
-                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
+                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma_msd);
             if (ln[CLS_M256])
                 hipLaunchKernelGGL((k_bucket_msd<256, 2048, PK, WS, HiT, true>), dim3(ln[CLS_M256]), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_M256 * nb, list_n.get() + CLS_M256,
-                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
+                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma_msd);
             if (ln[CLS_M512])
                 hipLaunchKernelGGL((k_bucket_msd<512, 4096, PK, WS, HiT, true>), dim3(ln[CLS_M512]), dim3(512), 0, c->stream, lists.get() + (size_t)CLS_M512 * nb, list_n.get() + CLS_M512,
-                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma);
+                                   a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma_msd);
         };
         if constexpr (!WS) {
             if (P.SB + PK_BITS <= 64) msd(std::true_type()); else msd(std::false_type());
@@ -1391,8 +1399,12 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
                                            nr.cnt.get(), nr.kind.get(), ma);
         }
         const u32 nretry = (ln[CLS_M16] || ln[CLS_M64] || ln[CLS_M128] || ln[CLS_M256] || ln[CLS_M512]) ? d2h<u32>(c, retry_n.get()) : 0u;
-        if (nretry)
+        if (nretry) {
+            if (direct)  // (these buckets were not gathered: the radix kernel works on the run)
+                hipLaunchKernelGGL((k_merge_gather_list<WS>), dim3(nretry), dim3(256), 0, c->stream, retry.get(), retry_n.get(), m_cs.get(), m_sstart.get(), m_ostart.get(), s.a_lo.get(),
+                                   s.a_hi.get(), (const u64*)o.a_lo.get(), (const u64*)o.a_hi.get(), nr.a_lo.get(), nr.a_hi.get());
             hipLaunchKernelGGL((k_bucket_medium<512, WS, HiT>), dim3(nretry), dim3(512), 0, c->stream, retry.get(), retry_n.get(), a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);
+        }
         if constexpr (!WS) if (ln[CLS_M1024])
             hipLaunchKernelGGL((k_bucket_medium<1024, WS, HiT>), dim3(ln[CLS_M1024]), dim3(1024), 0, c->stream, lists.get() + (size_t)CLS_M1024 * nb,
                                list_n.get() + CLS_M1024, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), ma);

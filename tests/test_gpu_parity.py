@@ -2104,7 +2104,8 @@ def test_rehearsal_of_rank_0_on_recorded_senders(world, k, pb, canonical, groups
     assert nxt >= int(bounds[0])
 
 
-@pytest.mark.parametrize("k,pb,n,canonical", [(31, 6, 300000, False), (21, 8, 600000, True), (15, 4, 200000, False), (31, 10, 1500000, False), (27, 9, 40000, False)])
+@pytest.mark.parametrize("k,pb,n,canonical", [(31, 6, 300000, False), (21, 8, 600000, True), (15, 4, 200000, False), (31, 10, 1500000, False), (27, 9, 40000, False),
+                                              (31, 16, 900000, False), (59, 12, 200000, True), (35, 14, 500000, False)])
 def test_trie_union_by_merge_path_equals_the_sorting_route(k, pb, n, canonical, monkeypatch):
     """Trie |= Trie: two ascending lists are MERGED (k_bucket_union: merge-path rounds of 2048 outputs straight from the two arenas) instead
     of gathered and sorted again (CBLX_MERGE_UNION=0). Buckets of thousands to tens of thousands of words (several rounds per bucket),
@@ -2132,8 +2133,11 @@ def test_trie_union_by_merge_path_equals_the_sorting_route(k, pb, n, canonical, 
                 raise AssertionError(f"{what}: bucket {p1:#x} kind {k1} len {len(x1)}: {len(bad)} positions differ, first {bad[:5]}: gpu {[hex(x1[i]) for i in bad[:3]]} oracle {[hex(x2[i]) for i in bad[:3]]}")
         raise AssertionError(f"{what}: bytes differ, buckets equal")
 
-    for route in ("1", "0"):
+    # routes: Trie |= Trie merged or sorted again (CBLX_MERGE_UNION), the counting-sort classes read in place or gathered first (CBLX_MERGE_DIRECT)
+    for route, direct in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("CBLX_MERGE_UNION", route)
+        monkeypatch.setenv("CBLX_MERGE_DIRECT", direct)
+        route = f"union={route} direct={direct}"
         g1, g2 = cbl_amd.CBL(k, pb, canonical=canonical), cbl_amd.CBL(k, pb, canonical=canonical)
         g1.insert_seq(s1), g2.insert_seq(s2)
         g1 |= g2
