@@ -735,14 +735,18 @@ static const int SPLIT_ITEMS = 8;
 // runs by length class (one list per workgroup size): a launch over ALL runs whose workgroups leave when the run is not theirs costs
 // more than the split itself — 1.7 M workgroups of 512 threads that only read two offsets still hold their wave slots for 2 us each
 // (3 of 8 ms at cfg 3, profiles/r04_kernel_stats_cfg3.md)
-__global__ __launch_bounds__(1024) void k_split_classify(u64 nruns, const u64* __restrict__ run_start, u32* __restrict__ lists /* [3][nruns] */, u32* __restrict__ list_n /* 3 */) {
+struct SplitRun { u64 start; u32 len, prefix; };  // one 16-byte descriptor per run: a split workgroup starts from a single load
+__global__ __launch_bounds__(1024) void k_split_classify(u64 nruns, const u32* __restrict__ run_prefix, const u64* __restrict__ run_start, SplitRun* __restrict__ lists /* [3][nruns] */,
+                                                         u32* __restrict__ list_n /* 3 */) {
     __shared__ u32 s_cnt[3 * 16];
     __shared__ u32 s_base[3];
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int cls = -1;
+    u64 st = 0, c = 0;
     if (i < nruns) {
-        const u64 c = run_start[i + 1] - run_start[i];
+        st = run_start[i];
+        c = run_start[i + 1] - st;
         cls = c <= 64 * 8 ? 0 : (c <= 256 * 8 ? 1 : 2);
     }
     u32 my_rank = 0;
@@ -760,10 +764,10 @@ __global__ __launch_bounds__(1024) void k_split_classify(u64 nruns, const u64* _
         s_base[k] = run ? atomicAdd(&list_n[k], run) : 0u;
     }
     __syncthreads();
-    if (cls >= 0) lists[(u64)cls * nruns + s_base[cls] + s_cnt[cls * 16 + w] + my_rank] = (u32)i;
+    if (cls >= 0) lists[(u64)cls * nruns + s_base[cls] + s_cnt[cls * 16 + w] + my_rank] = SplitRun{st, (u32)c, run_prefix[i]};
 }
 template <typename H, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_prefix_split(const u32* __restrict__ run_list, const u32* __restrict__ run_prefix, const u64* __restrict__ run_start, const u64* __restrict__ in_lo,
+__global__ __launch_bounds__(THREADS) void k_prefix_split(const SplitRun* __restrict__ run_list, const u64* __restrict__ in_lo,
                                                           const H* __restrict__ in_hi, u64* __restrict__ out_lo, H* __restrict__ out_hi, u32 SB, u32 xb,
                                                           u32* __restrict__ start_dense /* indexed by the absolute prefix */) {
     constexpr bool HAS = HiTraits<H>::has;
@@ -779,9 +783,9 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split(const u32* __restrict_
     // and the split loses more to occupancy than the pieces cost (cfg 4: 61.7 ms staged, 60.1 not)
     constexpr bool STAGE = !HAS;
     __shared__ u64 s_lo[STAGE ? TILE : 1];
-    const u64 run = run_list[blockIdx.x];
-    const u64 s0 = run_start[run];
-    const u32 c = (u32)(run_start[run + 1] - s0);
+    const SplitRun rd = run_list[blockIdx.x];
+    const u64 s0 = rd.start;
+    const u32 c = rd.len;
     const u32 NB = 1u << xb, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const u32 ntiles = (c + TILE - 1) / TILE;
     const u64* __restrict__ lo_r = in_lo + s0;
@@ -905,7 +909,7 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split(const u32* __restrict_
     }
     __syncthreads();
     // bucket starts of the run's prefixes: digit d starts at s0 + rbase[d] and holds roff[d] records
-    if (tid < NB) start_dense[((u64)run_prefix[run] << xb) | tid] = s_roff[tid] ? (u32)(s0 + s_rbase[tid]) : 0xFFFFFFFFu;
+    if (tid < NB) start_dense[((u64)rd.prefix << xb) | tid] = s_roff[tid] ? (u32)(s0 + s_rbase[tid]) : 0xFFFFFFFFu;
 }
 
 // ---- tiles of the first LSD pass over records that ARRIVE in pieces (receiver of the multi-GPU build) ------------------
