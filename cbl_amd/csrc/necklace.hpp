@@ -33,8 +33,91 @@ template <> struct NkBits<nk_u128> {
     }
 };
 
+// The same method for a ring of 2H bits (a k-mer of K = H bases wider than 64 bits) kept as TWO 64-bit halves of H bits each: a
+// rotation by s < H is hi' = (hi << s | lo >> (H - s)) & M, lo' = (lo << s | hi >> (H - s)) & M — four 64-bit shifts and four
+// logic operations — and one by s >= H swaps the halves first; on a 128-bit integer the compiler needs six shifts and more glue per
+// rotation (every shift costs 1.7 logic operations on this part, tools/dev_valu_rate.cpp). Steps and tie rule are those of
+// necklace_pos_fast below, which hands wide words with an even number of bits over to this function.
+__host__ __device__ inline void necklace_pos_halves(nk_u128 x, unsigned BITS, nk_u128& necklace, unsigned& pos) {
+    const unsigned H = BITS >> 1;  // < 64
+    const uint64_t M = (1ull << H) - 1;
+    const uint64_t xh = (uint64_t)(x >> H) & M, xl = (uint64_t)x & M;
+    if ((xh | xl) == 0 || (xh & xl) == M) {  // single-symbol words: every rotation equal, smallest p = 0
+        necklace = x;
+        pos = 0;
+        return;
+    }
+    // rotl by s on the ring, 0 <= s <= BITS (0 and BITS are the identity: b >> H and a << H vanish under the mask)
+    auto rot = [&](uint64_t h, uint64_t l, unsigned s, uint64_t& oh, uint64_t& ol) {
+        const bool sw = s >= H;
+        const unsigned t = sw ? s - H : s;
+        const uint64_t a = sw ? l : h, b = sw ? h : l;
+        oh = ((a << t) | (b >> (H - t))) & M;
+        ol = ((b << t) | (a >> (H - t))) & M;
+    };
+    uint64_t rh = ~xh & M, rl = ~xl & M, th, tl;
+    unsigned L = 1;
+    {
+        rot(rh, rl, 1, th, tl);
+        const uint64_t r2h = rh & th, r2l = rl & tl;      // runs >= 2
+        rot(r2h, r2l, 2, th, tl);
+        const uint64_t r4h = r2h & th, r4l = r2l & tl;    // runs >= 4
+        if (r4h | r4l) {
+            rh = r4h; rl = r4l; L = 4;
+            rot(rh, rl, 4, th, tl); th &= rh; tl &= rl; if (th | tl) { rh = th; rl = tl; L += 4; }
+            rot(rh, rl, 2, th, tl); th &= rh; tl &= rl; if (th | tl) { rh = th; rl = tl; L += 2; }
+        } else if (r2h | r2l) {
+            rh = r2h; rl = r2l; L = 2;
+        }
+    }
+    {
+        rot(rh, rl, 1, th, tl); th &= rh; tl &= rl;
+        if (th | tl) { rh = th; rl = tl; ++L; }
+        if (L == 11) {
+            for (;;) {
+                rot(rh, rl, 1, th, tl); th &= rh; tl &= rl;
+                if ((th | tl) == 0) break;
+                rh = th; rl = tl;
+                ++L;
+            }
+        }
+    }
+    {
+        rot(~xh & M, ~xl & M, L + 1, th, tl); th &= rh; tl &= rl;
+        if (th | tl) { rh = th; rl = tl; }
+    }
+    uint64_t bh = M, bl = M;
+    unsigned bestp = 0;
+    bool first = true;
+    while (rh | rl) {
+        unsigned s;  // highest remaining candidate
+        if (rh) { const unsigned b = 63u - (unsigned)__builtin_clzll(rh); rh &= ~(1ull << b); s = H + b; }
+        else { const unsigned b = 63u - (unsigned)__builtin_clzll(rl); rl &= ~(1ull << b); s = b; }
+        const unsigned p = BITS - 1 - s;
+        rot(xh, xl, p, th, tl);
+        if (first || th < bh || (th == bh && tl < bl)) {
+            bh = th; bl = tl;
+            bestp = p;
+            first = false;
+        }
+    }
+    necklace = ((nk_u128)bh << H) | bl;
+    pos = bestp;
+}
+
 // x must already be masked to BITS bits, BITS < 8 * sizeof(T). T = uint64_t (BITS <= 62) or nk_u128 (BITS <= 118).
 template <typename T> __host__ __device__ inline void necklace_pos_fast(T x, unsigned BITS, T& necklace, unsigned& pos) {
+#ifndef CBLX_NK_HALVES
+#define CBLX_NK_HALVES 1
+#endif
+    if constexpr (CBLX_NK_HALVES && sizeof(T) == 16) {
+        if ((BITS & 1u) == 0 && BITS < 128) {
+            nk_u128 nk;
+            necklace_pos_halves((nk_u128)x, BITS, nk, pos);
+            necklace = (T)nk;
+            return;
+        }
+    }
     const T MASK = (BITS >= sizeof(T) * 8) ? ~(T)0 : ((((T)1) << BITS) - 1);
     if (x == 0 || x == MASK) {  // single-symbol words: every rotation equal, smallest p = 0
         necklace = x;

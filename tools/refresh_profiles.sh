@@ -24,3 +24,4 @@ print('cfg2', d['ms_per_step'], d['value'], 'h2d', d['h2d_inclusive']['ms_per_st
 PY
 python tools/write_wire_profile.py profiles/${R}_wire_emulated.md gpurun_out/$T/wire_cfg3.json gpurun_out/$T/wire_cfg2.json gpurun_out/$T/wire_cfg4.json
 [ -s gpurun_out/$T/bench_cpufull.json ] && tail -1 gpurun_out/$T/bench_cpufull.json | python -c "import json,sys; json.dump(json.loads(sys.stdin.read()), open('profiles/${R}_bench_cpufull.json','w'), indent=1)"
+python tools/write_emulated_rank_md.py $R r03
