@@ -3,7 +3,7 @@
 T=$1; R=${2:-r03}
 python tools/write_profiles.py $T $R | tail -1
 python tools/write_sq_profile.py ${T}_sq $R 1200000000 | tail -1
-[ -d gpurun_out/${T}_sq4 ] && python tools/write_sq_profile.py ${T}_sq4 ${R}_cfg4 960000000 | tail -1
+[ -d gpurun_out/${T}_sq4 ] && python tools/write_sq_profile.py ${T}_sq4 ${R}_cfg4 1200000000 | tail -1
 python tools/write_sharded_profile.py $T $R > /dev/null
 for c in cfg3 cfg4 merge dup; do tail -1 gpurun_out/$T/bench_$c.json > profiles/${R}_bench_$c.json; done
 tail -1 gpurun_out/$T/bench_line.json > profiles/${R}_bench_cfg2.json
