@@ -133,9 +133,9 @@ def parse_args(argv=None):
     ap.add_argument("--protocol", choices=["bins", "sorted", "words"], default=None,
                     help="N > 1: what crosses the links. native transport: bins (default) or sorted; torch transport: sorted (default) or words")
     ap.add_argument("--slices", type=int, default=None,
-                    help="N > 1: slices per rank and step. Default 2 for the native bins protocol (its grouped receiver sends group-major after the rank's "
-                         "whole first pass; only the first group's share of slice 0 crosses under slice 1's kernels — more slices only add fixed costs), "
-                         "4 otherwise (the exchange of a slice overlaps the next slice's kernels)")
+                    help="N > 1: slices per rank and step. Default 3 for the native bins protocol, 50 / 30 / 20 % of the reads (its grouped receiver sends "
+                         "group-major after the rank's whole first pass; the first group's share of slices 0 and 1 crosses under the next slice's kernels, only "
+                         "the short last slice's share of it is exposed), 4 otherwise (the exchange of a slice overlaps the next slice's kernels)")
     ap.add_argument("--transport", choices=["torch", "native"], default="native",
                     help="N > 1: exchange driven from Python over torch.distributed, or the whole sharded insert inside libcblx on RCCL directly")
     ap.add_argument("--cpu-sample-reads", type=int, default=None,
@@ -161,7 +161,7 @@ def parse_args(argv=None):
         if getattr(args, name) is None:
             setattr(args, name, cfg[name])
     if args.slices is None:
-        args.slices = 2 if (args.transport == "native" and args.protocol == "bins" and not args.force_sharded) else 4
+        args.slices = 3 if (args.transport == "native" and args.protocol == "bins" and not args.force_sharded) else 4
     args.kind = cfg["kind"]
     args.genome = cfg.get("genome", 0)
     if args.cpu_sample_reads is None:  # the oracle slows down with PREFIX_BITS (2^28-bit Fenwick bitvector) and word width
@@ -493,7 +493,9 @@ def main():
                 transport = "libcblx sharded insert on RCCL (ncclSend / ncclRecv groups on a side stream)"
         if comm is not None and args.recv_groups:
             comm.set_recv_groups(args.recv_groups)
-        engine = sharded.ShardedBuilder(cbl, dist, slices=args.slices, protocol=args.protocol, comm=comm) if dist is not None else None
+        grouped = comm is not None and args.protocol == "bins" and args.slices == len(sharded.ShardedBuilder.GROUPED_WEIGHTS) and not args.force_sharded
+        engine = sharded.ShardedBuilder(cbl, dist, slices=args.slices, protocol=args.protocol, comm=comm,
+                                        slice_weights=sharded.ShardedBuilder.GROUPED_WEIGHTS if grouped else None) if dist is not None else None
 
         def step(_i):
             cbl.clear()

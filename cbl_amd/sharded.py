@@ -256,7 +256,7 @@ class ShardedBuilder(_Wire):
     i.e. file order when the file is dealt to the ranks block-cyclically; with slices=1 it is plain rank order.
     """
 
-    def __init__(self, cbl, dist, engine=None, slices: int = 4, slack: float = 1.3, protocol: str | None = None, comm=None):
+    def __init__(self, cbl, dist, engine=None, slices: int = 4, slack: float = 1.3, protocol: str | None = None, comm=None, slice_weights=None):
         """comm: a cbl_amd.Comm — the whole insert then runs inside libcblx (cblx_sharded_insert_seqs_device, exchange on
         RCCL directly; protocol "bins" (default there: the exchange sits between the first and the second partition pass,
         nothing is partitioned twice or copied) or "sorted"); `dist` is still used for the few host-side agreements (slice
@@ -273,19 +273,29 @@ class ShardedBuilder(_Wire):
             comm.set_protocol(self.protocol)
         self._wire_init(dist)
         self.slices, self.slack = max(1, slices), slack
+        self.slice_weights = tuple(slice_weights) if slice_weights else None  # relative slice lengths (len == slices), else the default cut
         self.bounds = None  # fixed by the first batch so later batches land on the same owners
         self.last_counts = None
 
+    # Slices of the GROUPED receiver's schedule (native "bins" protocol on an empty index): the senders run all their
+    # slices before the data crosses group-major, and only the first group's share of the LAST slice is exposed (the earlier slices'
+    # shares of it cross under the next slice's kernels) — so the last slice is the short one. Measured against a paced wire
+    # (cfg 3, 55 GB/s per link, 4 groups): 2 equal slices 56.6 ms, these three 54.9, four (45 / 30 / 17 / 8 %) 55.3.
+    GROUPED_WEIGHTS = (5, 3, 2)
+
     @staticmethod
-    def slice_bounds(n: int, slices: int):
-        """Read ranges [a, b) of the slices of an n-read shard (same formula on every rank). With three or more slices the
-        first and the last are half as long as the others: the first slice's encode + partition is the only work no
-        exchange hides (it bounds the job when the links do), the last slice's exchange the only exchange no kernel hides
-        (it bounds the job when the kernels do)."""
+    def slice_bounds(n: int, slices: int, weights=None):
+        """Read ranges [a, b) of the slices of an n-read shard (same formula on every rank). `weights`: relative lengths (one per
+        slice). Default: with three or more slices the first and the last are half as long as the others: the first slice's
+        encode + partition is the only work no exchange hides (it bounds the job when the links do), the last slice's exchange
+        the only exchange no kernel hides (it bounds the job when the kernels do)."""
         slices = max(1, slices)  # every rank walks the same number of slices whatever its n (an empty slice still takes part in the exchange)
-        if slices < 3:
+        if weights is not None and len(weights) == slices:
+            w = list(weights)
+        elif slices < 3:
             return [(n * c // slices, n * (c + 1) // slices) for c in range(slices)]
-        w = [1] + [2] * (slices - 2) + [1]
+        else:
+            w = [1] + [2] * (slices - 2) + [1]
         tot, acc, cuts = sum(w), 0, [0]
         for x in w:
             acc += x
@@ -300,7 +310,7 @@ class ShardedBuilder(_Wire):
             # big shard (the same number on every rank: a slice is also a round of the exchange)
             nbases = int(d_offsets[n] - d_offsets[0]) if n else 0
             need = -(-nbases // SLICE_MAX_BASES)
-            slice_list = self.slice_bounds(n, max(self.slices, self._all_reduce_ints([need], "max")[0]))
+            slice_list = self.slice_bounds(n, max(self.slices, self._all_reduce_ints([need], "max")[0]), self.slice_weights)
         self._slice_list = list(slice_list)
         if self.comm is not None:
             return self._insert_native(d_bases, d_offsets, n)

@@ -21,7 +21,12 @@ from cbl_amd import synth
 CFG = {"cfg2": (31, 24, 10_000_000, 150), "cfg3": (31, 28, 12_500_000, 150), "cfg4": (59, 28, 6_250_000, 250)}
 
 
+TAPER = {}
+
+
 def cuts_of(n, slices):
+    if slices in TAPER:  # tapered slices: cumulative fractions
+        return [0] + [int(n * f) for f in TAPER[slices][:-1]] + [n]
     return [n * s // slices for s in range(slices + 1)]
 
 
@@ -33,9 +38,13 @@ def main():
     ap.add_argument("--wire-gbps", default="40,55,75,0")
     ap.add_argument("--groups", default="8", help="groups per rank of the grouped receiver; several values separated by commas")
     ap.add_argument("--slices", type=int, default=4, help="slices of the UNGROUPED run (the grouped one sends nothing before its last slice is through pass A: 1 slice)")
-    ap.add_argument("--grouped-slices", default="2", help="slices of the grouped runs (group 0 of every slice but the last crosses under the next slice's kernels); several values separated by commas")
+    ap.add_argument("--grouped-slices", default="3", help="slices of the grouped runs (group 0 of every slice but the last crosses under the next slice's kernels); several values separated by commas")
+    ap.add_argument("--taper", default="0.5,0.8,1", help="cumulative fractions of the grouped runs' slices instead of equal ones, e.g. 0.5,0.8,1 (the number of values selects the runs with that many slices)")
     ap.add_argument("--steps", type=int, default=3)
     a = ap.parse_args()
+    if a.taper:
+        fr = [float(x) for x in a.taper.split(",")]
+        TAPER[len(fr)] = fr
     k, pb, nr, L = CFG[a.config]
     nr = a.reads or nr
     W = a.world

@@ -24,7 +24,7 @@ for w in "--reads 10000000" "" "--reads 12500000 --prefix-bits 28" "--k 59 --pre
 done
 # round 4: rank 0 of 8 against a paced wire, grouped receiver on / off
 for c in cfg3 cfg2 cfg4; do
-  timeout 1200 python tools/emulate_wire.py --config $c --groups 4,8 --grouped-slices 2 --wire-gbps 40,55,75,0 > $OUT/wire_$c.json 2> $OUT/wire_$c.err; echo "wire $c rc=$?"
+  timeout 1200 python tools/emulate_wire.py --config $c --groups 4,8 --wire-gbps 40,55,75,0 > $OUT/wire_$c.json 2> $OUT/wire_$c.err; echo "wire $c rc=$?"
 done
 timeout 1800 python bench.py --cpu-full --steps 5 --warmup 1 --no-h2d --no-fasta --no-per-record > $OUT/bench_cpufull.json 2> $OUT/bench_cpufull.err; echo "cpu-full rc=$?"
 bash tools/fuzz_campaign.sh ${TAG}_fuzz 1101 1110

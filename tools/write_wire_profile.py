@@ -13,7 +13,8 @@ def main():
          "bucket kernels at the bucket depth of the 8-GPU job — on a replaying communicator whose exchanges are D2D copies on a side stream, held back by a",
          "host function until a wire of `link` GB/s per source rank (7 links in parallel) would have delivered them. ms per step of rank 0 (the densest",
          "prefix range), best of 3; `0` = the copies at their own speed (no wire: what the kernels alone take). Not emulated: the CUs RCCL's kernels",
-         "occupy, link contention, the other ranks being slower than rank 0.", ""]
+         "occupy, link contention, the other ranks being slower than rank 0. Grouped runs with three slices use 50 / 30 / 20 % of the reads",
+         "(`ShardedBuilder.GROUPED_WEIGHTS`: only the first group's share of the LAST slice is exposed).", ""]
     for f in files:
         o = json.loads(open(f).read().strip().splitlines()[-1])
         W = o["world"]
