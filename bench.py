@@ -140,7 +140,7 @@ def parse_args(argv=None):
                     help="N > 1: exchange driven from Python over torch.distributed, or the whole sharded insert inside libcblx on RCCL directly")
     ap.add_argument("--cpu-sample-reads", type=int, default=None,
                     help="reads of the CPU leg (default: about 20-30 s of CPU work: 1 M at PREFIX_BITS <= 24, 125 k at 28, 60 k at K = 59)")
-    ap.add_argument("--launch-timeout", type=float, default=3600.0,
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="launcher mode (--gpus N without WORLD_SIZE): seconds after which the rank processes are stopped and the run fails")
     ap.add_argument("--cpu-full", action="store_true", help="time the CPU oracle on the whole workload (cfg 2: about 4 minutes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
