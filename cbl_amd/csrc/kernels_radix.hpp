@@ -735,9 +735,8 @@ static const int SPLIT_ITEMS = 8;
 // runs by length class (one list per workgroup size): a launch over ALL runs whose workgroups leave when the run is not theirs costs
 // more than the split itself — 1.7 M workgroups of 512 threads that only read two offsets still hold their wave slots for 2 us each
 // (3 of 8 ms at cfg 3, profiles/r04_kernel_stats_cfg3.md)
-struct SplitRun { u64 start; u32 len, prefix; };  // one 16-byte descriptor per run: a split workgroup starts from a single load
-__global__ __launch_bounds__(1024) void k_split_classify(u64 nruns, const u32* __restrict__ run_prefix, const u64* __restrict__ run_start, SplitRun* __restrict__ lists /* [3][nruns] */,
-                                                         u32* __restrict__ list_n /* 3 */) {
+struct SplitRun { u64 start; u32 len, idx; };  // one 16-byte descriptor per run (idx = its rank among the runs): a split workgroup starts from a single load
+__global__ __launch_bounds__(1024) void k_split_classify(u64 nruns, const u64* __restrict__ run_start, SplitRun* __restrict__ lists /* [3][nruns] */, u32* __restrict__ list_n /* 3 */) {
     __shared__ u32 s_cnt[3 * 16];
     __shared__ u32 s_base[3];
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -764,12 +763,13 @@ __global__ __launch_bounds__(1024) void k_split_classify(u64 nruns, const u32* _
         s_base[k] = run ? atomicAdd(&list_n[k], run) : 0u;
     }
     __syncthreads();
-    if (cls >= 0) lists[(u64)cls * nruns + s_base[cls] + s_cnt[cls * 16 + w] + my_rank] = SplitRun{st, (u32)c, run_prefix[i]};
+    if (cls >= 0) lists[(u64)cls * nruns + s_base[cls] + s_cnt[cls * 16 + w] + my_rank] = SplitRun{st, (u32)c, (u32)i};
 }
 template <typename H, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_prefix_split(const SplitRun* __restrict__ run_list, const u64* __restrict__ in_lo,
                                                           const H* __restrict__ in_hi, u64* __restrict__ out_lo, H* __restrict__ out_hi, u32 SB, u32 xb,
-                                                          u32* __restrict__ start_dense /* indexed by the absolute prefix */) {
+                                                          u32* __restrict__ sub_start /* [nruns][16]: first record of the run's every prefix */,
+                                                          u16* __restrict__ sub_mask /* [nruns]: which of them hold records */, u32* __restrict__ sub_nz /* [nruns]: how many */) {
     constexpr bool HAS = HiTraits<H>::has;
     constexpr int NW = THREADS / 64, TILE = THREADS * SPLIT_ITEMS;
     __shared__ u32 s_wcnt[NW * 16];  // per wave and digit: records of the tile seen so far, then the wave's offset inside the digit
@@ -908,8 +908,32 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split(const SplitRun* __rest
         if (w == 0 && lane < 16) s_roff[lane] += tcnt;
     }
     __syncthreads();
-    // bucket starts of the run's prefixes: digit d starts at s0 + rbase[d] and holds roff[d] records
-    if (tid < NB) start_dense[((u64)rd.prefix << xb) | tid] = s_roff[tid] ? (u32)(s0 + s_rbase[tid]) : 0xFFFFFFFFu;
+    // the run's buckets: digit d starts at s0 + rbase[d] and holds roff[d] records. Three small per-run tables instead of 2^xb entries of
+    // a dense array over all 2^PREFIX_BITS prefixes: the bitvector, rank directory and bucket table then cost O(runs), not three passes
+    // over a gigabyte (k_split_table)
+    if (w == 0) {
+        const u64 m = __ballot(lane < NB && s_roff[lane < 16 ? lane : 0] != 0);
+        if (lane < 16) sub_start[(u64)rd.idx * 16 + lane] = lane < NB ? (u32)(s0 + s_rbase[lane]) : 0u;
+        if (lane == 0) { sub_mask[rd.idx] = (u16)m; sub_nz[rd.idx] = (u32)__builtin_popcountll(m); }
+    }
+}
+
+// bucket table and bitvector from the per-run tables of k_prefix_split: thread (run, d) of a non-empty sub-bucket writes its row at
+// rank_base[run] + (non-empty sub-buckets of the run below d); one thread per run ORs the run's 2^xb bits into the bitvector (they lie
+// inside one 64-bit word: 2^xb divides 64 and the run's first prefix is a multiple of 2^xb)
+__global__ void k_split_table(u64 nruns, const u32* __restrict__ run_prefix, const u32* __restrict__ sub_start, const u16* __restrict__ sub_mask, const u64* __restrict__ rank_base,
+                              u32 xb, u32* __restrict__ bucket_prefix, u64* __restrict__ raw_start, u64* __restrict__ bv) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 run = i >> 4;
+    const u32 d = (u32)i & 15u;
+    if (run >= nruns) return;
+    const u32 m = sub_mask[run];
+    const u64 p0 = (u64)run_prefix[run] << xb;
+    if (d == 0 && m) atomicOr((unsigned long long*)&bv[p0 >> 6], (unsigned long long)m << (p0 & 63u));
+    if (!((m >> d) & 1u)) return;
+    const u64 r = rank_base[run] + (u64)__builtin_popcount(m & ((1u << d) - 1u));
+    bucket_prefix[r] = (u32)(p0 | d);
+    raw_start[r] = sub_start[run * 16 + d];
 }
 
 // ---- tiles of the first LSD pass over records that ARRIVE in pieces (receiver of the multi-GPU build) ------------------

@@ -269,53 +269,75 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
         CBLX_HIP(hipGetLastError());
         if (!win) CBLX_HIP(hipStreamSynchronize(c->stream));  // the pass tables are released here (a group: see above)
     }
+    bool dir_done = false;
     if (xb) {
-        // -- the last xb prefix bits: every run of equal super-prefix split in LDS, written to the other buffer in final order, the
-        //    bucket starts of its 2^xb prefixes with it (k_prefix_split)
+        // -- the last xb prefix bits: every run of equal super-prefix split in LDS, written to the other buffer in final order; the
+        //    directory comes from the runs' own small tables (k_prefix_split, k_split_table) — nothing walks the 2^PREFIX_BITS prefixes
         if (!have_dense) throw Error(CBLX_EDEVICE, "prefix split without a super-prefix directory (internal error)");
+        if (win) throw Error(CBLX_EINVAL, "prefix split inside a directory window (internal error)");
         const u64 swords = std::max<u64>(1, (nsuper + 63) / 64);
-        Buf<u32> spopc(c->pool, swords), sprefix, real_dense(c->pool, std::max<u64>(nprefix, 1));
+        Buf<u32> spopc(c->pool, swords), sprefix;
         Buf<u64> sbv(c->pool, swords), srank(c->pool, swords + 1), sstart;
         u64 nruns = 0;
         { StageTimer t(c, ST_DIR);
           CBLX_HIP(hipMemsetAsync(spopc.get(), 0, swords * 4, c->stream));
           CBLX_HIP(hipMemsetAsync(sbv.get(), 0, swords * 8, c->stream));
-          CBLX_HIP(hipMemsetAsync(real_dense.get(), 0xFF, std::max<u64>(nprefix, 1) * 4, c->stream));
           hipLaunchKernelGGL(k_bitvector, grid1(std::max<u64>(nsuper, 64), 256), dim3(256), 0, c->stream, start_dense.get(), nsuper, sbv.get(), spopc.get());
           nruns = exclusive_scan<u64>(c, spopc.get(), swords, srank.get());
           sprefix = Buf<u32>(c->pool, nruns + 1);
           sstart = Buf<u64>(c->pool, nruns + 1);
           hipLaunchKernelGGL(k_bucket_table, grid1(std::max<u64>(nsuper, 1), 256), dim3(256), 0, c->stream, start_dense.get(), nsuper, sbv.get(), srank.get(), sprefix.get(), sstart.get(), sw_lo);
           hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, sstart.get() + nruns, N); }
+        if (nruns >= 0xFFFFFFF0ull / 16) throw Error(CBLX_ERANGE, "too many runs for the prefix split");
+        Buf<u32> sub_start(c->pool, 16 * nruns + 16), sub_nz(c->pool, nruns + 1);
+        Buf<u16> sub_mask(c->pool, nruns + 1);
+        Buf<u64> rank_base(c->pool, nruns + 1);
         if (nruns) {
             StageTimer t(c, ST_SCATTER);
-            u32* const rd = real_dense.get() - w_lo;
-            if (nruns >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "too many runs for the prefix split");
             Buf<SplitRun> lists(c->pool, 3 * nruns);
             Buf<u32> list_n(c->pool, 3);
             CBLX_HIP(hipMemsetAsync(list_n.get(), 0, 12, c->stream));
-            hipLaunchKernelGGL(k_split_classify, grid1(nruns, 1024), dim3(1024), 0, c->stream, nruns, sprefix.get(), sstart.get(), lists.get(), list_n.get());
+            hipLaunchKernelGGL(k_split_classify, grid1(nruns, 1024), dim3(1024), 0, c->stream, nruns, sstart.get(), lists.get(), list_n.get());
             const std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), 3);
             auto launch = [&](auto h_tag, const auto* hin, auto* hout) {
                 typedef decltype(h_tag) H;
-                if (ln[0]) hipLaunchKernelGGL((k_prefix_split<H, 64>), dim3(ln[0]), dim3(64), 0, c->stream, lists.get(), lo, hin, lo2, hout, P.SB, xb, rd);
-                if (ln[1]) hipLaunchKernelGGL((k_prefix_split<H, 256>), dim3(ln[1]), dim3(256), 0, c->stream, lists.get() + nruns, lo, hin, lo2, hout, P.SB, xb, rd);
-                if (ln[2]) hipLaunchKernelGGL((k_prefix_split<H, 512>), dim3(ln[2]), dim3(512), 0, c->stream, lists.get() + 2 * nruns, lo, hin, lo2, hout, P.SB, xb, rd);
+                if (ln[0]) hipLaunchKernelGGL((k_prefix_split<H, 64>), dim3(ln[0]), dim3(64), 0, c->stream, lists.get(), lo, hin, lo2, hout, P.SB, xb, sub_start.get(), sub_mask.get(), sub_nz.get());
+                if (ln[1]) hipLaunchKernelGGL((k_prefix_split<H, 256>), dim3(ln[1]), dim3(256), 0, c->stream, lists.get() + nruns, lo, hin, lo2, hout, P.SB, xb, sub_start.get(), sub_mask.get(), sub_nz.get());
+                if (ln[2]) hipLaunchKernelGGL((k_prefix_split<H, 512>), dim3(ln[2]), dim3(512), 0, c->stream, lists.get() + 2 * nruns, lo, hin, lo2, hout, P.SB, xb, sub_start.get(), sub_mask.get(), sub_nz.get());
             };
             if constexpr (DROP_HI || !HiTraits<HiT>::has) launch(NoHi(), (const NoHi*)nullptr, (NoHi*)nullptr);
             else launch(HiT(), hi, hi2);
             CBLX_HIP(hipGetLastError());
             advance();
         }
-        CBLX_HIP(hipStreamSynchronize(c->stream));  // the run table is released here
-        start_dense = std::move(real_dense);
-        sd = start_dense.get() - w_lo;
+        {   // KRN-4 from the runs' tables: bucket table rows by rank, bitvector bits run by run, rank directory by one popcount scan
+            StageTimer t(c, ST_DIR);
+            nr.nb = nruns ? exclusive_scan<u64>(c, sub_nz.get(), nruns, rank_base.get()) : 0;
+            nr.bv = Buf<u64>(c->pool, nwords);
+            nr.rank_dir = Buf<u64>(c->pool, nwords + 1);
+            nr.prefix = Buf<u32>(c->pool, nr.nb + 1);
+            nr.start = Buf<u64>(c->pool, nr.nb + 1);
+            nr.cnt = Buf<u32>(c->pool, nr.nb + 1);
+            nr.kind = Buf<u8>(c->pool, nr.nb + 1);
+            Buf<u32> popc(c->pool, nwords);
+            CBLX_HIP(hipMemsetAsync(nr.bv.get(), 0, nwords * 8, c->stream));
+            if (nruns)
+                hipLaunchKernelGGL(k_split_table, grid1(nruns * 16, 256), dim3(256), 0, c->stream, nruns, (const u32*)sprefix.get(), (const u32*)sub_start.get(), (const u16*)sub_mask.get(),
+                                   (const u64*)rank_base.get(), xb, nr.prefix.get(), nr.start.get(), nr.bv.get());
+            hipLaunchKernelGGL(k_popc_words, grid1(nwords, 256), dim3(256), 0, c->stream, nwords, (const u64*)nr.bv.get(), popc.get());
+            const u64 nb2 = exclusive_scan<u64>(c, popc.get(), nwords, nr.rank_dir.get());
+            if (nb2 != nr.nb) throw Error(CBLX_EDEVICE, "prefix split: the runs hold " + std::to_string(nr.nb) + " buckets, the bitvector " + std::to_string(nb2) + " (internal error)");
+            hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, c->stream, nr.start.get() + nr.nb, N);
+            CBLX_HIP(hipGetLastError());
+            CBLX_HIP(hipStreamSynchronize(c->stream));  // the run tables are released here
+        }
+        dir_done = true;
     }
     if (lo == rec.lo2.get()) { std::swap(rec.lo, rec.lo2); std::swap(rec.hi, rec.hi2); }  // final data -> rec.lo/hi
     rec.lo2.reset();
     rec.hi2.reset();
     // -- KRN-4: bitvector, rank directory, bucket table (of the whole prefix space, or of the caller's window of it)
-    {
+    if (!dir_done) {
         StageTimer t(c, ST_DIR);
         Buf<u32> popc(c->pool, nwords);
         u64* bvp;
