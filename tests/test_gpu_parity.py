@@ -275,6 +275,48 @@ def test_deep_buckets_take_the_split_path(k, pb, nreads, L, canonical):
     _check_index(d, od)
 
 
+@pytest.mark.parametrize(
+    "k,pb,canonical,alphabet,glen,cov",
+    [
+        (31, 28, False, b"AC", 60000, 12),    # 2^4 buckets per run; runs of every length class, repeats in all of them
+        (31, 26, False, b"AC", 120000, 8),    # 2^2 buckets per run: buckets over the Vec threshold inside one-tile runs
+        (31, 25, True, b"ACG", 100000, 6),
+        (27, 27, False, b"AC", 40000, 20),    # 8-byte records from the start (no hi part to drop)
+        (31, 28, False, b"ACGT", 30000, 30),  # plain 30x coverage: every run one value, many times
+        (59, 28, False, b"AC", 30000, 10),    # 16-byte records (split straight from the registers)
+    ],
+)
+def test_prefix_split_on_crowded_runs_full_of_repeats(k, pb, canonical, alphabet, glen, cov):
+    """PREFIX_BITS > 24: the runs of equal 24-bit prefix are split by their last bits in LDS (k_prefix_split).
+    Low-complexity reads crowd the runs (two-letter genomes: 4096 possible 24-bit prefixes, runs of one to several tiles, buckets on
+    both sides of the Vec threshold), coverage repeats every word. Build, an incremental batch on top, everything again."""
+    _need_gpu()
+    rng = random.Random(pb * 1000 + k)
+    genome = _rand_seq(rng, glen, alphabet)
+    L = max(100, k + 40)
+
+    def reads(n):
+        out = []
+        for _ in range(n):
+            q = rng.randrange(0, len(genome) - L)
+            out.append(genome[q : q + L])
+        return _concat(out)
+
+    b1, o1 = reads(glen * cov // L)
+    g, o = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
+    g.insert_seqs(b1, o1)
+    o.insert_seqs(b1, o1)
+    _check_index(g, o)
+    assert g.validate() == 0
+    b2, o2 = reads(glen * cov // (3 * L))
+    extra = _concat([_rand_seq(rng, 3000, alphabet) for _ in range(20)])
+    for bb, oo in ((b2, o2), extra, (b1, o1)):
+        g.insert_seqs(bb, oo)
+        o.insert_seqs(bb, oo)
+        _check_index(g, o)
+    assert g.validate() == 0
+
+
 def test_duplicate_heavy_reads_keep_first_occurrence_order():
     """30x coverage of a small genome: every k-mer arrives many times; Vec buckets must keep stream order."""
     _need_gpu()
