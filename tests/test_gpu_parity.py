@@ -2033,7 +2033,7 @@ def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q, protoco
 
 @pytest.mark.parametrize("world,k,pb,canonical,protocol,groups", [
     (2, 31, 24, False, "bins", 0), (3, 59, 28, True, "bins", 0), (4, 25, 12, False, "bins", 0), (8, 31, 24, False, "bins", 0),
-    (3, 31, 28, True, "bins", 0), (2, 21, 16, False, "bins", 0), (5, 59, 28, False, "bins", 0),
+    (3, 31, 28, True, "bins", 0), (2, 21, 16, False, "bins", 0), (5, 59, 26, False, "bins", 0),  # (five ranks at PREFIX_BITS = 28: 157 s of gigabyte-sized first allocations)
     (2, 31, 24, False, "bins", 1), (3, 59, 28, True, "bins", 1), (8, 31, 24, False, "bins", 1), (3, 31, 28, True, "bins", 1),  # the ungrouped receiver
     (2, 31, 24, False, "bins", 3), (4, 31, 28, False, "bins", 14), (3, 45, 20, True, "bins", 5), (2, 27, 9, False, "bins", 4),
     (2, 31, 24, False, "sorted", 0), (3, 59, 28, True, "sorted", 0), (8, 31, 24, False, "sorted", 0)])
