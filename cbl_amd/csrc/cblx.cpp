@@ -864,7 +864,8 @@ int cblx_merge_assign(cblx_ctx* self, cblx_ctx* other) {
                 typedef typename std::remove_reference<decltype(*src.get())>::type T;
                 if (!src.get()) return;
                 dst = Buf<T>(self->pool, src.n);
-                CBLX_HIP(hipMemcpyPeerAsync(dst.get(), self->device, src.get(), other->device, src.n * sizeof(T), self->stream));
+                if (self->device == other->device) device_copy(self->stream, dst.get(), src.get(), src.n * sizeof(T));
+                else CBLX_HIP(hipMemcpyPeerAsync(dst.get(), self->device, src.get(), other->device, src.n * sizeof(T), self->stream));
             };
             dup(copy.bv, o.bv); dup(copy.rank_dir, o.rank_dir); dup(copy.prefix, o.prefix); dup(copy.start, o.start);
             dup(copy.cnt, o.cnt); dup(copy.kind, o.kind); dup(copy.a_lo, o.a_lo); dup(copy.a_hi, o.a_hi);

@@ -246,6 +246,28 @@ template <typename T> void h2d(cblx_ctx* c, T* dptr, const T* h, size_t n) {
     if (n) CBLX_HIP(hipMemcpyAsync(dptr, h, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
 }
 
+// A large copy inside one device (the clone of an index: `|=` into an empty one, src/trievec/set_ops.rs:43-71 clones every bucket as stored):
+// 16 bytes per lane, eight loads in flight per thread before the first store. hipMemcpyAsync's blit moved the 6 GB arena of cfg 5's operand
+// at 4.3 TB/s of read + written bytes; small or odd-sized buffers still take it.
+__global__ __launch_bounds__(512) void k_copy16(const uint4* __restrict__ a, uint4* __restrict__ b, u64 n) {
+    const u64 base = (u64)blockIdx.x * (512 * 8);
+    uint4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const u64 i = base + (u64)j * 512 + threadIdx.x; v[j] = i < n ? a[i] : uint4{0, 0, 0, 0}; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const u64 i = base + (u64)j * 512 + threadIdx.x; if (i < n) b[i] = v[j]; }
+}
+inline void device_copy(hipStream_t st, void* dst, const void* src, size_t bytes) {
+    const size_t n16 = bytes / 16;
+    if (bytes < (1u << 20) || (((uintptr_t)dst | (uintptr_t)src) & 15u) || ceil_div((u64)n16, 512 * 8) >= (1ull << 31)) {
+        if (bytes) CBLX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+        return;
+    }
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)ceil_div((u64)n16, 512 * 8)), dim3(512), 0, st, (const uint4*)src, (uint4*)dst, (u64)n16);
+    CBLX_HIP(hipGetLastError());
+    if (bytes & 15u) CBLX_HIP(hipMemcpyAsync((char*)dst + n16 * 16, (const char*)src + n16 * 16, bytes & 15u, hipMemcpyDeviceToDevice, st));
+}
+
 // device-wide exclusive scan of u32 -> OutT; returns the total
 template <typename OutT> u64 exclusive_scan(cblx_ctx* c, const u32* in, u64 n, OutT* out) {
     if (n == 0) return 0;

@@ -323,14 +323,17 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify_merge(u64 nb, u32
 // sorted iterators with two pointers; src/trievec/mod.rs:118-136 inserts what self lacks) ------------------------------------------------
 // One workgroup per bucket, any length. Rounds of UNI_TILE outputs: the next <= UNI_TILE words of either list are staged in LDS
 // (coalesced loads from the two indexes' own arenas — the merged run is written, never read), every thread finds the co-rank of the
-// END of its 8 consecutive outputs by a binary search on the round's diagonal (merge path; ties take self's copy first) and gets its
-// start from its neighbour, loads 8 + 8 candidates into registers and merges them with a fixed network — min(a[k], b[7-k]) leaves the
-// 8 smallest as a bitonic sequence, three compare-exchange stages sort it — so no lane follows data-dependent control flow. The
+// END of its UNI_ITEMS consecutive outputs by a binary search on the round's diagonal (merge path; ties take self's copy first) and gets
+// its start from its neighbour, loads n + n candidates into registers and merges them with a fixed network — min(a[k], b[n-1-k]) leaves
+// the n smallest as a bitonic sequence, log2 n compare-exchange stages sort it — so no lane follows data-dependent control flow. The
 // outputs go back to LDS (one padding word per 8: a lane's 64-byte row would otherwise hit the banks of its neighbours'), are
 // compared with their predecessor there (equal = other's copy of a word self holds: dropped) and leave compacted in order. The
 // co-rank of the round's last output says how far either list was consumed. HBM traffic: every word read once (twice in a long
 // bucket: a round loads UNI_TILE words of both lists and consumes UNI_TILE in all; the L2 holds the rest), the union written once.
-static const int UNI_THREADS = 256, UNI_ITEMS = 8, UNI_TILE = UNI_THREADS * UNI_ITEMS;
+// Workgroup shape, measured on cfg 5's share (`bench.py --config merge`, stage bucket_big) / at the 8-GPU depth of cfg 5 (`tools/emulate_rank.py --merge`:
+// 752 M + 752 M words in buckets of 10 635 each): 256 threads x 8 outputs 3.18 / 9.4 ms, 128 x 8 3.09, 256 x 4 2.14 / 6.3, **128 x 4 2.07 / 6.2**, 256 x 2 2.53 — half the registers
+// (a[], b[], o[]), half the merge network and a shorter search per round buy more than the extra rounds cost; padding one word per 4 instead of 8: 2.33 / 6.7.
+static const int UNI_THREADS = 128, UNI_ITEMS = 4, UNI_TILE = UNI_THREADS * UNI_ITEMS;
 __device__ __forceinline__ u32 uni_pad(u32 i) { return i + (i >> 3); }
 __device__ __forceinline__ void uni_cmpx(u64& a, u64& b) { const u64 lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; }
 __global__ __launch_bounds__(UNI_THREADS) void k_bucket_union(const BDesc* __restrict__ list, const u32* __restrict__ list_n, const u32* __restrict__ m_cs,

@@ -26,6 +26,19 @@ def _need_gpu():
         pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
 
 
+def _spawn_context():
+    """Context for the tests that start several ranks on this one GPU. The parent first gives back what earlier tests left cached
+    (contexts not yet collected, torch's caching allocator): with that memory held, five K = 59 ranks at PREFIX_BITS >= 26 spent
+    115-157 s in allocation retries where they take 13 s on a free GPU."""
+    import gc
+
+    import torch.multiprocessing as mp
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    return mp.get_context("spawn")
+
+
 def _rand_seq(rng, n, alphabet=b"ACGT"):
     return bytes(rng.choice(alphabet) for _ in range(n))
 
@@ -1588,7 +1601,6 @@ def test_two_ranks_on_one_gpu_through_a_gloo_shim(world, k, pb, canonical, proto
     _need_gpu()
     import socket
 
-    import torch.multiprocessing as mp
 
     from cbl_amd.sharded import ShardedBuilder
 
@@ -1598,7 +1610,7 @@ def test_two_ranks_on_one_gpu_through_a_gloo_shim(world, k, pb, canonical, proto
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    ctx = mp.get_context("spawn")
+    ctx = _spawn_context()
     q = ctx.Queue()
     procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, k, pb, canonical, protocol, per, L, q)) for r in range(world)]
     for p in procs:
@@ -1814,7 +1826,6 @@ def test_sharded_index_merge_load_save_on_one_gpu(world, k, pb, canonical, per, 
     _need_gpu()
     import socket
 
-    import torch.multiprocessing as mp
 
     from cbl_amd.sharded import ShardedBuilder
 
@@ -1822,7 +1833,7 @@ def test_sharded_index_merge_load_save_on_one_gpu(world, k, pb, canonical, per, 
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    ctx = mp.get_context("spawn")
+    ctx = _spawn_context()
     q = ctx.Queue()
     procs = [ctx.Process(target=_sharded_index_worker, args=(r, world, port, k, pb, canonical, per, L, slices, str(tmp_path), q)) for r in range(world)]
     for p in procs:
@@ -1937,7 +1948,6 @@ def test_sharded_build_of_one_file_has_file_order_on_one_gpu(world, k, pb, canon
     _need_gpu()
     import socket
 
-    import torch.multiprocessing as mp
 
     path = str(tmp_path / "reads.fa")
     recs = _ragged_fasta(path, nrec, nrec)
@@ -1945,7 +1955,7 @@ def test_sharded_build_of_one_file_has_file_order_on_one_gpu(world, k, pb, canon
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    ctx = mp.get_context("spawn")
+    ctx = _spawn_context()
     q = ctx.Queue()
     procs = [ctx.Process(target=_file_order_worker, args=(r, world, port, k, pb, canonical, path, block, protocol, q)) for r in range(world)]
     for p in procs:
@@ -2044,7 +2054,6 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
     _need_gpu()
     import socket
 
-    import torch.multiprocessing as mp
 
     from cbl_amd.sharded import ShardedBuilder
 
@@ -2060,7 +2069,7 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    ctx = mp.get_context("spawn")
+    ctx = _spawn_context()
     q = ctx.Queue()
     procs = [ctx.Process(target=_native_worker, args=(r, world, port, k, pb, canonical, per, L, path, q, protocol, groups)) for r in range(world)]
     for p in procs:
