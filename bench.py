@@ -142,7 +142,8 @@ def parse_args(argv=None):
                     help="reads of the CPU leg (default: about 20-30 s of CPU work: 1 M at PREFIX_BITS <= 24, 125 k at 28, 60 k at K = 59)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="launcher mode (--gpus N without WORLD_SIZE): seconds after which the rank processes are stopped and the run fails")
-    ap.add_argument("--cpu-full", action="store_true", help="time the CPU oracle on the whole workload (cfg 2: about 4 minutes)")
+    ap.add_argument("--cpu-full", action="store_true", help="time the CPU oracle on the whole workload (cfg 2: about 10 minutes) and compare the index bytes of both sides (parity_full_size); "
+                    "--config merge: the oracle builds both operands, merges them, and both resulting indexes are compared")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serialize", action="store_true", help="skip the serialize leg (index bytes into a host buffer)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (value_h2d_inclusive)")
@@ -256,6 +257,44 @@ def parity_full_size(cbl, orc, kmers):
             "gpu_serialize_s": round(t1 - t0, 2), "oracle_serialize_s": round(t2 - t1, 2), "compare_s": round(time.perf_counter() - t2, 2),
             "what": "cblx_serialize of the timed build's index (all of the workload's reads) vs the CPU oracle's serialize after one insert_seq per read: "
                     "same length, same SHA-256, no differing byte"}
+
+
+def merge_parity_full_size(args, work, other, kmers_b):
+    """cfg 5 at its per-GPU size through the checker (`--config merge --cpu-full`, one GPU): the oracle builds A (seed 42) and B (seed 43)
+    with one insert_seq per read, merges them (`A |= B`, /root/reference/src/cbl.rs:433-449), and its bytes are compared with the merged
+    index of the last timed step — and B's with the GPU's B, whose both-sided Vec buckets the merge left sorted
+    (/root/reference/src/trievec/mod.rs:209-220). Returns (parity record, cpu_baseline of the merge)."""
+    from cbl_amd import synth
+    from oracle import Oracle
+
+    K, PB, L, NR = args.k, args.prefix_bits, args.read_len, args.reads
+
+    def build(seed):
+        o = Oracle(K, PB, args.canonical)
+        secs = 0.0
+        for done in range(0, NR, 1_000_000):
+            m = min(1_000_000, NR - done)
+            b, off = synth.reads(seed, m, L, first_read=done)
+            secs += o.insert_seqs(b, off)
+        return o, secs
+
+    oa, sa = build(42)
+    ob, sb = build(43)
+    t0 = time.perf_counter()
+    oa.merge(ob)
+    tm = time.perf_counter() - t0
+    rec = parity_full_size(work, oa, kmers_b)
+    rec["what"] = ("cblx_serialize of the merged index (A |= B, the last timed step's) vs the CPU oracle's bytes after the same merge of the same two "
+                   "indexes: same length, same SHA-256, no differing byte; `other_after_merge`: B itself, whose Vec buckets the merge sorted")
+    ro = parity_full_size(other, ob, kmers_b)
+    rec["other_after_merge"] = {k: ro[k] for k in ("equal", "bytes", "bytes_oracle", "sha256", "sha256_oracle", "first_difference_at")}
+    rec["equal"] = bool(rec["equal"] and ro["equal"])
+    rec["oracle_build_s"] = [round(sa, 1), round(sb, 1)]
+    rec["oracle_merge_s"] = round(tm, 2)
+    cpu = {"value": round(kmers_b / tm, 1), "unit": "k-mers/s", "cores": 1, "kind": "port",
+           "sample": f"the oracle's merge of the two full indexes ({NR} reads each, seeds 42 / 43): {tm:.1f} s (their builds, one insert_seq per read: {sa:.0f} + {sb:.0f} s)",
+           "mkmers_per_s_by_1M_read_block": None, "host_cores_available": os.cpu_count()}
+    return rec, cpu
 
 
 # ---- launcher: `python bench.py --gpus N` without torchrun -------------------------------------------------------------
@@ -777,6 +816,8 @@ def main():
         del hb, ho
 
     cpu = cpu_early
+    if args.kind == "merge" and args.cpu_full and world == 1 and dist is None and not args.no_cpu_baseline:
+        extra["parity_full_size"], cpu = merge_parity_full_size(args, work, B, count_b)
     if cpu is None and rank == 0 and not args.no_cpu_baseline and args.kind == "build" and args.genome:
         cpu = cpu_baseline_leg(args, lambda done, m: (d_bases[done * L:(done + m) * L].cpu().numpy(), None))  # the same reads the GPU got
 
