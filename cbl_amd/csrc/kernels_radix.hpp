@@ -727,8 +727,9 @@ __global__ __launch_bounds__(256) void k_boundaries_cold(const u64* __restrict__
 // several tiles is counted first (its records are read twice; the second read comes from the L2). The kernel also writes the bucket
 // starts of the run's 2^xb prefixes (EMPTY32 for the absent ones) — the fused directory of the old last pass, without candidates to
 // settle. Reads `in`, writes `out` (the ping-pong partner) at the same run positions.
-// Three workgroup sizes by run length — one wave (up to 512 records), four (up to 2048), eight (longer: tiles of 4096; only a run
-// of more than one tile is read twice) — each launched over the list of its own runs (k_split_classify).
+// Four workgroup sizes by run length — one wave (up to 512 records), two (up to 1024), four (up to 2048), eight (longer: tiles of 4096;
+// only a run of more than one tile is read twice) — each launched over the list of its own runs (k_split_classify). (The two-wave class
+// came last: a 900-record run in a four-wave workgroup keeps four loads per lane in flight where eight fit; cfg 3 -0.3 ms, same box.)
 // Per tile: the lanes' records (wave-contiguous slices) are ranked by digit with xb ballots (stable), the per-wave counts are scanned
 // across the waves, the tile is staged in LDS in its final order and leaves as one contiguous piece per digit.
 static const int SPLIT_ITEMS = 8;
@@ -736,9 +737,11 @@ static const int SPLIT_ITEMS = 8;
 // more than the split itself — 1.7 M workgroups of 512 threads that only read two offsets still hold their wave slots for 2 us each
 // (3 of 8 ms at cfg 3, profiles/r04_kernel_stats_cfg3.md)
 struct SplitRun { u64 start; u32 len, idx; };  // one 16-byte descriptor per run (idx = its rank among the runs): a split workgroup starts from a single load
-__global__ __launch_bounds__(1024) void k_split_classify(u64 nruns, const u64* __restrict__ run_start, SplitRun* __restrict__ lists /* [3][nruns] */, u32* __restrict__ list_n /* 3 */) {
-    __shared__ u32 s_cnt[3 * 16];
-    __shared__ u32 s_base[3];
+static const int SPLIT_CLASSES = 4;  // workgroups of 64 / 128 / 256 / 512 threads: runs of up to 512 / 1024 / 2048 records in one tile, longer ones in tiles of 4096
+__global__ __launch_bounds__(1024) void k_split_classify(u64 nruns, const u64* __restrict__ run_start, SplitRun* __restrict__ lists /* [SPLIT_CLASSES][nruns] */,
+                                                         u32* __restrict__ list_n /* SPLIT_CLASSES */) {
+    __shared__ u32 s_cnt[SPLIT_CLASSES * 16];
+    __shared__ u32 s_base[SPLIT_CLASSES];
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int cls = -1;
@@ -746,17 +749,17 @@ __global__ __launch_bounds__(1024) void k_split_classify(u64 nruns, const u64* _
     if (i < nruns) {
         st = run_start[i];
         c = run_start[i + 1] - st;
-        cls = c <= 64 * 8 ? 0 : (c <= 256 * 8 ? 1 : 2);
+        cls = c <= 64 * SPLIT_ITEMS ? 0 : (c <= 128 * SPLIT_ITEMS ? 1 : (c <= 256 * SPLIT_ITEMS ? 2 : 3));
     }
     u32 my_rank = 0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < SPLIT_CLASSES; ++k) {
         const u64 bal = __ballot(cls == k);
         if (cls == k) my_rank = mbcnt(bal);
         if (lane == 0) s_cnt[k * 16 + w] = (u32)__builtin_popcountll(bal);
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < SPLIT_CLASSES) {
         const u32 k = threadIdx.x;
         u32 run = 0;
         for (int ww = 0; ww < 16; ++ww) { const u32 t = s_cnt[k * 16 + ww]; s_cnt[k * 16 + ww] = run; run += t; }
@@ -841,7 +844,7 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split(const SplitRun* __rest
         for (int j = 0; j < SPLIT_ITEMS; ++j) {
             const u32 e = w * EPW + j * 64 + lane;
             const bool valid = (u32)j < R && e < n_tile;
-            klo[j] = lo_r[t0 + (valid ? e : 0u)];
+            klo[j] = lo_r[t0 + (valid ? e : 0u)];  // (non-temporal loads here: +0.5 ms at cfg 3, measured)
             if constexpr (HAS) khi[j] = (u64)hi_r[t0 + (valid ? e : 0u)];
             dp[j] = valid ? (u32)get_bits(klo[j], HAS ? khi[j] : 0ull, SB, xb) : 0xFFu;
         }

@@ -294,16 +294,17 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
         Buf<u64> rank_base(c->pool, nruns + 1);
         if (nruns) {
             StageTimer t(c, ST_SCATTER);
-            Buf<SplitRun> lists(c->pool, 3 * nruns);
-            Buf<u32> list_n(c->pool, 3);
-            CBLX_HIP(hipMemsetAsync(list_n.get(), 0, 12, c->stream));
+            Buf<SplitRun> lists(c->pool, SPLIT_CLASSES * nruns);
+            Buf<u32> list_n(c->pool, SPLIT_CLASSES);
+            CBLX_HIP(hipMemsetAsync(list_n.get(), 0, SPLIT_CLASSES * 4, c->stream));
             hipLaunchKernelGGL(k_split_classify, grid1(nruns, 1024), dim3(1024), 0, c->stream, nruns, sstart.get(), lists.get(), list_n.get());
-            const std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), 3);
+            const std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), SPLIT_CLASSES);
             auto launch = [&](auto h_tag, const auto* hin, auto* hout) {
                 typedef decltype(h_tag) H;
                 if (ln[0]) hipLaunchKernelGGL((k_prefix_split<H, 64>), dim3(ln[0]), dim3(64), 0, c->stream, lists.get(), lo, hin, lo2, hout, P.SB, xb, sub_start.get(), sub_mask.get(), sub_nz.get());
-                if (ln[1]) hipLaunchKernelGGL((k_prefix_split<H, 256>), dim3(ln[1]), dim3(256), 0, c->stream, lists.get() + nruns, lo, hin, lo2, hout, P.SB, xb, sub_start.get(), sub_mask.get(), sub_nz.get());
-                if (ln[2]) hipLaunchKernelGGL((k_prefix_split<H, 512>), dim3(ln[2]), dim3(512), 0, c->stream, lists.get() + 2 * nruns, lo, hin, lo2, hout, P.SB, xb, sub_start.get(), sub_mask.get(), sub_nz.get());
+                if (ln[1]) hipLaunchKernelGGL((k_prefix_split<H, 128>), dim3(ln[1]), dim3(128), 0, c->stream, lists.get() + nruns, lo, hin, lo2, hout, P.SB, xb, sub_start.get(), sub_mask.get(), sub_nz.get());
+                if (ln[2]) hipLaunchKernelGGL((k_prefix_split<H, 256>), dim3(ln[2]), dim3(256), 0, c->stream, lists.get() + 2 * nruns, lo, hin, lo2, hout, P.SB, xb, sub_start.get(), sub_mask.get(), sub_nz.get());
+                if (ln[3]) hipLaunchKernelGGL((k_prefix_split<H, 512>), dim3(ln[3]), dim3(512), 0, c->stream, lists.get() + 3 * nruns, lo, hin, lo2, hout, P.SB, xb, sub_start.get(), sub_mask.get(), sub_nz.get());
             };
             if constexpr (DROP_HI || !HiTraits<HiT>::has) launch(NoHi(), (const NoHi*)nullptr, (NoHi*)nullptr);
             else launch(HiT(), hi, hi2);
