@@ -1665,26 +1665,49 @@ __global__ void k_big_tile_table(const BDesc* __restrict__ list, u32 nruns, cons
 // run i = the digits [v << (DB - B), (v + 1) << (DB - B)) of the pass, contiguous in the twin from rel[i][v << (DB - B)]
 // (k_seg_adjust's grp_start, relative to the run), listed by length class for the sort kernel. A sub-range that outgrows the
 // sort kernel marks itself BIG_SENT - 1 in v_count and is not listed: the whole run then takes the general kernel.
+// (A workgroup takes BIG_VLIST_RUNS runs and reserves its list slots with ONE atomic per class: one workgroup per run meant 70 000 atomics on the same two
+// counters on the receiving side of an 8-GPU job, 0.8 ms of nothing else.)
+static const int BIG_VLIST_RUNS = 8;
 __global__ __launch_bounds__(256) void k_big_vlist(const BDesc* __restrict__ list, u32 nruns, const u64* __restrict__ vb_, const u32* __restrict__ rel /* [nruns][256] */, u32 SB,
                                                    BDesc* __restrict__ vlist, u32* __restrict__ v_count, BDesc* __restrict__ cls_lists /* [2][vtot]: <= 1024 words, <= BIG_VCAP */,
                                                    u32* __restrict__ cls_n, u64 vtot) {
-    const u32 i = blockIdx.x, v = threadIdx.x;
-    const BDesc dsc = list[i];
-    const u32 c = dsc.c & ~BDESC_TRIE, DB = big_digit_bits(SB), B = big_bits(c) < DB ? big_bits(c) : DB, V = 1u << B, sh = DB - B;
-    int cls = -1;
-    BDesc d{0, 0, 0};
-    if (v < V) {
-        const u32 a = rel[(u64)i * 256 + (v << sh)], b = v + 1 < V ? rel[(u64)i * 256 + ((v + 1) << sh)] : c;
-        const u32 hv = b - a;
-        const bool fits = hv <= BIG_VCAP;
-        const u64 vb = vb_[i];
-        d = BDesc{dsc.start + a, hv | BDESC_TRIE | (B << BDESC_SKIP_SHIFT), (u32)(vb + v)};
-        vlist[vb + v] = d;
-        v_count[vb + v] = fits ? (hv ? BIG_SENT : 0u) : BIG_SENT - 1;  // an empty sub-range is finished
-        if (fits && hv) cls = hv <= 1024 ? 0 : 1;  // the sort kernel's workgroup follows the sub-range's length
+    __shared__ u32 s_n[2], s_base[2];
+    const u32 v = threadIdx.x;
+    if (v < 2) s_n[v] = 0;
+    __syncthreads();
+    int cls[BIG_VLIST_RUNS];
+    BDesc d[BIG_VLIST_RUNS];
+    u32 slot[BIG_VLIST_RUNS];
+    const u32 DB = big_digit_bits(SB);
+#pragma unroll
+    for (int rr = 0; rr < BIG_VLIST_RUNS; ++rr) {
+        cls[rr] = -1;
+        d[rr] = BDesc{0, 0, 0};
+        slot[rr] = 0;
+        const u32 i = blockIdx.x * BIG_VLIST_RUNS + rr;
+        if (i >= nruns) continue;
+        const BDesc dsc = list[i];
+        const u32 c = dsc.c & ~BDESC_TRIE, B = big_bits(c) < DB ? big_bits(c) : DB, V = 1u << B, sh = DB - B;
+        if (v < V) {
+            const u32 a = rel[(u64)i * 256 + (v << sh)], b = v + 1 < V ? rel[(u64)i * 256 + ((v + 1) << sh)] : c;
+            const u32 hv = b - a;
+            const bool fits = hv <= BIG_VCAP;
+            const u64 vb = vb_[i];
+            d[rr] = BDesc{dsc.start + a, hv | BDESC_TRIE | (B << BDESC_SKIP_SHIFT), (u32)(vb + v)};
+            vlist[vb + v] = d[rr];
+            v_count[vb + v] = fits ? (hv ? BIG_SENT : 0u) : BIG_SENT - 1;  // an empty sub-range is finished
+            if (fits && hv) {
+                cls[rr] = hv <= 1024 ? 0 : 1;  // the sort kernel's workgroup follows the sub-range's length
+                slot[rr] = atomicAdd(&s_n[cls[rr]], 1u);
+            }
+        }
     }
-    const u32 slot = block_append<256, 2>(cls, cls_n);
-    if (cls >= 0) cls_lists[(u64)cls * vtot + slot] = d;
+    __syncthreads();
+    if (v < 2) s_base[v] = s_n[v] ? atomicAdd(&cls_n[v], s_n[v]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < BIG_VLIST_RUNS; ++rr)
+        if (cls[rr] >= 0) cls_lists[(u64)cls[rr] * vtot + s_base[cls[rr]] + slot[rr]] = d[rr];
 }
 // One workgroup per big run: its distinct count = the sum over its sorted sub-ranges, which move down over the gaps the
 // duplicates left (in the twin). A run that must stay a Vec or whose sort gave up goes to `fb` for the general kernel.

@@ -473,7 +473,7 @@ template <typename C> void big_stage(cblx_ctx* c, const BDesc* d_list, const u32
         CBLX_HIP(hipMemsetAsync(retry_n.get(), 0, 4, c->stream));
         CBLX_HIP(hipMemsetAsync(cls_n.get(), 0, 8, c->stream));
         CBLX_HIP(hipMemsetAsync(fb_n.get(), 0, 4, c->stream));
-        hipLaunchKernelGGL(k_big_vlist, dim3(nbig), dim3(256), 0, c->stream, d_list, nbig, vb.get(), rel.get(), P.SB, vlist.get(), v_count.get(), cls_lists.get(), cls_n.get(), vtot);
+        hipLaunchKernelGGL(k_big_vlist, dim3((nbig + BIG_VLIST_RUNS - 1) / BIG_VLIST_RUNS), dim3(256), 0, c->stream, d_list, nbig, vb.get(), rel.get(), P.SB, vlist.get(), v_count.get(), cls_lists.get(), cls_n.get(), vtot);
         const std::vector<u32> cn = d2h_vec<u32>(c, cls_n.get(), 2);
         HiT* th = WS ? (HiT*)tw.hi.get() : (HiT*)nullptr;
         // sub-ranges of up to 1024 words take the 128-thread workgroup — its `self |= other` instantiation without merge
