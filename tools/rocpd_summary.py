@@ -15,7 +15,7 @@ def main():
     print("| kernel | calls | total ms | avg us | min us | max us | % |")
     print("|---|---|---|---|---|---|---|")
     for n, c, s, a, mn, mx in rows:
-        n = n.split("(")[0][-90:]
+        n = n.replace("(anonymous namespace)::", "").split("(")[0][-90:]
         print(f"| {n} | {c} | {s/1e6:.3f} | {a/1e3:.1f} | {mn/1e3:.1f} | {mx/1e3:.1f} | {100*s/tot:.1f} |")
     try:
         pc = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
@@ -28,7 +28,7 @@ def main():
                 print("\n| kernel | counter | dispatches | sum | per dispatch |")
                 print("|---|---|---|---|---|")
                 for k, c, n, s in res:
-                    print(f"| {k.split('(')[0][-70:]} | {c} | {n} | {s:.6g} | {s/n:.6g} |")
+                    print(f"| {k.replace('(anonymous namespace)::', '').split('(')[0][-70:]} | {c} | {n} | {s:.6g} | {s/n:.6g} |")
     except sqlite3.Error as e:
         print("no counters:", e)
 

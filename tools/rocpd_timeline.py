@@ -17,7 +17,7 @@ def main():
     db = sqlite3.connect(a.db)
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-    ev = [(s, e, n.split("(")[0][-60:]) for s, e, n in db.execute(f"select start, end, {namecol} from kernels")]
+    ev = [(s, e, n.replace("(anonymous namespace)::", "").split("(")[0][-60:]) for s, e, n in db.execute(f"select start, end, {namecol} from kernels")]
     try:
         mc = [r[1] for r in db.execute("pragma table_info(memory_copies)")]
         if mc:
