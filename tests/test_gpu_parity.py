@@ -1533,8 +1533,10 @@ def test_merge_into_an_empty_index_is_a_clone():
     a device-side deep copy; `other` keeps working and the copy is independent of it."""
     _need_gpu()
     rng = random.Random(8)
-    for k, pb, canonical in ((31, 24, False), (13, 6, True), (59, 28, False)):
-        s1, s2 = _rand_seq(rng, 30000), _rand_seq(rng, 4000)
+    # (the arrays of the longer cases pass 1 MB and take the 16-byte copy kernel, k_copy16, with an 8-byte tail when the arena has an odd
+    # number of words; the short ones take hipMemcpyAsync)
+    for k, pb, canonical, n1 in ((31, 24, False, 30000), (13, 6, True, 30000), (59, 28, False, 30000), (31, 24, False, 400003), (59, 28, True, 250002), (27, 20, False, 300000)):
+        s1, s2 = _rand_seq(rng, n1), _rand_seq(rng, 4000)
         g, o = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
         g.insert_seq(s1), o.insert_seq(s1)
         e, oe = cbl_amd.CBL(k, pb, canonical=canonical), Oracle(k, pb, canonical)
