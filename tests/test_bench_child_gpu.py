@@ -52,3 +52,15 @@ def test_full_size_parity_leg_at_a_small_size():
     assert p["equal"] is True and p["sha256"] == p["sha256_oracle"] and p["bytes"] == p["bytes_oracle"] > 0
     assert p["distinct_kmers"] == p["distinct_kmers_oracle"] == out["distinct_kmers_in_index"]
     assert p["first_difference_at"] is None
+
+
+def test_full_size_parity_leg_of_the_merge_at_a_small_size():
+    """`--config merge --cpu-full`: the oracle builds both operands, merges them, and BOTH resulting indexes are byte-compared (the merged one
+    and other, whose Vec buckets the merge sorted); the CPU baseline of that line is the oracle's merge."""
+    out = _run("--config", "merge", "--reads", "30000", "--steps", "2", "--warmup", "1", "--cpu-full", "--no-h2d")
+    p = out["parity_full_size"]
+    assert p["equal"] is True and p["sha256"] == p["sha256_oracle"] and p["bytes"] == p["bytes_oracle"] > 0
+    o = p["other_after_merge"]
+    assert o["equal"] is True and o["sha256"] == o["sha256_oracle"] and 0 < o["bytes"] < p["bytes"]
+    assert p["distinct_kmers"] == p["distinct_kmers_oracle"] == out["merge"]["words_union"]
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0 and "merge" in out["cpu_baseline"]["sample"]
