@@ -111,6 +111,7 @@ SIGNATURES = {
     "cblx_sim_store_free": (C.c_int, [C.c_uint64]),
     "cblx_comm_set_recv_groups": (C.c_int, [C.c_void_p, C.c_uint32]),
     "cblx_comm_groups_used": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "cblx_comm_groups_fine": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "cblx_sharded_insert_seqs_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
                                                   C.POINTER(C.c_int)]),
     "cblx_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -316,7 +317,7 @@ class Comm:
             raise CblxError(rc, "cblx_comm_set_protocol")
 
     def set_recv_groups(self, groups: int):
-        """Groups per rank of the "bins" receiver (0 = default: CBLX_RECV_GROUPS or 8; 1 = ungrouped): the data crosses the links
+        """Groups per rank of the "bins" receiver (0 = default: CBLX_RECV_GROUPS or 4; 1 = ungrouped): the data crosses the links
         group-major and the receiver works on group g while g + 1 .. are still on the wire. The same on every rank."""
         rc = self._L.cblx_comm_set_recv_groups(self._h, groups)
         if rc != OK:
@@ -326,6 +327,12 @@ class Comm:
         """Groups the last sharded insert of this rank worked through (0: the ungrouped path)."""
         g = C.c_uint32(0)
         self._L.cblx_comm_groups_used(self._h, C.byref(g))
+        return g.value
+
+    def groups_fine(self) -> int:
+        """... of which sorted 16 prefix bits behind the senders' first pass (FINE bins, PREFIX_BITS > 24: two passes instead of three)."""
+        g = C.c_uint32(0)
+        self._L.cblx_comm_groups_fine(self._h, C.byref(g))
         return g.value
 
     def stats(self, reset: bool = False) -> dict:

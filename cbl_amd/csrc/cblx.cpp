@@ -565,6 +565,11 @@ int cblx_comm_groups_used(const cblx_comm* cm, uint32_t* out) {
     *out = cm->groups_used;
     return CBLX_OK;
 }
+int cblx_comm_groups_fine(const cblx_comm* cm, uint32_t* out) {
+    if (!cm || !out) return CBLX_EINVAL;
+    *out = cm->groups_fine;
+    return CBLX_OK;
+}
 int cblx_stage_fastx_blocks_comm(cblx_ctx* c, cblx_comm* cm, const char* path, uint64_t* block, uint32_t slices, const uint8_t** d_bases, const uint64_t** d_offsets,
                                  uint64_t* n_staged, uint64_t* n_in_file) {
     return guard(c, [&] {

@@ -358,6 +358,7 @@ struct cblx_comm {
     // grouped receiver (sharded_insert_grouped): groups per rank asked for (0: CBLX_RECV_GROUPS or the default), the group cuts chosen
     // together with the bounds they refine, and how many groups the last call worked through (0: it took the ungrouped path)
     u32 recv_groups = 0, groups_used = 0;
+    u32 groups_fine = 0;  // ... of which sorted 16 prefix bits behind the first pass (FINE bins, PREFIX_BITS > 24)
     std::vector<u32> g_bounds, g_cuts;
 };
 
@@ -795,6 +796,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     const u32 W = T.world, me = T.rank, RB = P.PB - 8;
     const u32 G = recv_groups_wanted(cm);
     cm->groups_used = 0;
+    cm->groups_fine = 0;
     if (W < 2 || W > MAX_DEST || G < 2 || P.PB < 9 || nslices == 0) return false;
     for (u32 s = 0; s < nslices; ++s) if (cuts[s + 1] < cuts[s] || cuts[s + 1] > n) throw Error(CBLX_EINVAL, "slice cuts must be ascending and at most n");
     // -- the group cuts that go with these bounds (chosen once per set of bounds: a sampled histogram of the first slice, all-reduced)
@@ -804,7 +806,18 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         cm->g_cuts = choose_group_cuts(hist, bounds, W, G, P.PB);
         cm->g_bounds = bvec;
     }
-    const CutPlan M = make_cut_plan(P.PB, bounds, W, cm->g_cuts);
+    // PREFIX_BITS > 24: FINE bins (cuts.hpp) — the first pass also cuts the narrow groups into aligned blocks of 2^16 prefixes, so their
+    // receiver sorts 16 bits in two LSD passes instead of 20 in three (CBLX_FINE_BINS=0: the bins of the top 8 prefix bits, as below 25)
+    FinePlan FM;
+    {
+        const char* fe = std::getenv("CBLX_FINE_BINS");
+        // every bin must imply the prefix bits a record does not carry behind the first pass: 65..72-bit words travel as their low 64 bits
+        const u32 lmax = DROP_HI ? std::min(24u, 64u - P.SB) : 24u;
+        if (P.PB > 24 && !(fe && fe[0] == '0')) FM = make_fine_plan(P.PB, lmax, bounds, W, cm->g_cuts);
+    }
+    const bool fine = FM.ok;
+    const CutPlan LM = fine ? CutPlan() : make_cut_plan(P.PB, bounds, W, cm->g_cuts);
+    const CutPlan& M = fine ? static_cast<const CutPlan&>(FM) : LM;
     // -- the job: k-mers per rank (upper bound), whether any rank holds an index already
     const u64 n0 = cuts[0], n1 = cuts[nslices];
     u64 mine = 0;
@@ -814,19 +827,20 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         const u64 sub = (n1 - n0) * (u64)(P.K - 1);
         mine = last - first > sub ? last - first - sub : 0;
     }
-    u64 agree[2] = {mine, c->res.count != 0 ? 1ull : 0ull};
-    T.all_reduce_sum_u64(agree, 2);
-    const u64 job = agree[0];
     const u64 LIMIT = 0xFFFFFFF0ull - 2 * RDX_TILE;
-    if (!M.ok || agree[1] != 0 || job / W + job / (2 * W) + (1u << 20) >= LIMIT || mine >= LIMIT) return false;
+    // (every term of the decision below is replicated: a rank that alone holds 2^32 k-mers says so through the sum)
+    u64 agree[3] = {mine, c->res.count != 0 ? 1ull : 0ull, mine >= LIMIT ? 1ull : 0ull};
+    T.all_reduce_sum_u64(agree, 3);
+    const u64 job = agree[0];
+    if (!M.ok || agree[1] != 0 || agree[2] != 0 || job / W + job / (2 * W) + (1u << 20) >= LIMIT) return false;
     const bool trace = std::getenv("CBLX_TRACE_SHARDED") != nullptr;
-    const LsdPlan LP = lsd_plan(P, false);  // (the receiver runs LSD passes only: pipeline.hpp)
+    const LsdPlan LP = fine ? lsd_plan_bits(FINE_LEVEL) : lsd_plan(P, false);  // (the receiver runs LSD passes only: pipeline.hpp; FINE bins: the first digit is the same for 16 and 24 sorted bits)
     const DigitBits nextd{P.SB + LP.sh[0], LP.wid[0]};
-    Buf<CutCell> d_tab(c->pool, CUT_KEYS);
-    h2d(c, d_tab.get(), M.tab.data(), CUT_KEYS);
-    const DigitCut fn{P.SB, P.PB, RB, d_tab.get()};
+    Buf<CutCell> d_tab(c->pool, M.tab.size());
+    h2d(c, d_tab.get(), M.tab.data(), M.tab.size());
+    const DigitCut fn{P.SB, P.PB, RB, d_tab.get(), fine ? FM.ksh : 0xFFFFFFFFu};
     EncHist eh0{};
-    eh0.nd = W; eh0.SB = P.SB; eh0.PB = P.PB; eh0.binRB = RB; eh0.cut_tab = d_tab.get();
+    eh0.nd = W; eh0.SB = P.SB; eh0.PB = P.PB; eh0.binRB = RB; eh0.cut_tab = d_tab.get(); eh0.cut_ksh = fn.ksh;
     const u32 my_lo = M.bin_lo[me], my_cells = M.bin_lo[me + 1] - M.bin_lo[me], NG = M.ngroups[me];
     // cells (= my bins) of every one of my groups
     // (a cut that falls exactly on a segment boundary leaves one bin number unused: such a cell holds nothing and belongs nowhere)
@@ -964,7 +978,12 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         S.own = send[(size_t)me * HDR];
         if (recv[(size_t)me * HDR] != S.own) throw Error(CBLX_EDEVICE, "sharded build: the count exchange returned another own count (transport error)");
         for (u32 r = 0; r < W; ++r) incoming += recv[(size_t)r * HDR];
-        if (filled + incoming >= LIMIT) throw Error(CBLX_ERANGE, "this rank's share of the job takes more than one round: set CBLX_RECV_GROUPS=1 (ungrouped receiver) or use more ranks");
+        {   // a share that needs two rounds is an error of the JOB: every rank learns of it here and leaves together (a rank that threw on
+            // its own left its peers waiting in the next collective until the launcher's deadline)
+            u64 over = filled + incoming >= LIMIT ? 1ull : 0ull;
+            T.all_reduce_sum_u64(&over, 1);
+            if (over) throw Error(CBLX_ERANGE, "a rank's share of the job takes more than one round: set CBLX_RECV_GROUPS=1 (ungrouped receiver) or use more ranks");
+        }
         if (!a_lo.get()) alloc_log(cap, a_lo, a_hi, a_dig);
         if (filled + incoming > cap) grow(filled + incoming);
         // log layout of the slice as in sharded_insert_bins: the own piece first, then the other sources in rank order
@@ -1042,13 +1061,19 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         if (g < Gmax && gev[g]) CBLX_HIP(hipStreamWaitEvent(c->stream, gev[g], 0));
         if (gN[g] == 0) continue;
         // the group's share of every piece: counts per SEGMENT (inside a group a segment occurs in one cell only), first record
-        std::vector<u32> cnt_g(np * 256, 0u), pb_g(np);
+        std::vector<u32> cnt_g(np * 256, 0u), pb_g(np), segp(256, 0xFFFFFFFFu);
+        if (fine)  // a bin's records share their prefix bits from the bin's level up: the first prefix of its aligned block
+            for (u32 cl = gc0[g]; cl < gc0[g + 1]; ++cl) {
+                const u32 bin = my_lo + cl, iv = M.iv_of[bin];
+                if (iv == 0xFFFFFFFFu) continue;
+                segp[FM.seg_of[bin]] = bin == 255 ? (u32)((1ull << P.PB) - 1) : (FM.first[iv] >> FM.level[iv]) << FM.level[iv];
+            }
         for (size_t p = 0; p < np; ++p) {
             u64 before = 0;
             for (u32 cl = 0; cl < gc0[g]; ++cl) before += pcnt[p * 256 + cl];
             pb_g[p] = (u32)(pbase[p] + before);
             for (u32 cl = gc0[g]; cl < gc0[g + 1]; ++cl) {
-                const u32 v = M.v_of[my_lo + cl];
+                const u32 v = fine ? FM.seg_of[my_lo + cl] : M.v_of[my_lo + cl];
                 if (v == 0xFFFFFFFFu) { if (pcnt[p * 256 + cl]) throw Error(CBLX_EDEVICE, "grouped receiver: words in a bin no prefix maps to (internal error)"); continue; }
                 if (cnt_g[p * 256 + v] && pcnt[p * 256 + cl]) throw Error(CBLX_EDEVICE, "grouped receiver: a segment occurs in two cells of one group (internal error)");
                 cnt_g[p * 256 + v] += pcnt[p * 256 + cl];
@@ -1060,6 +1085,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         pin.pbase = pb_g.data();
         pin.dig_in = a_dig.get();
         pin.dig_out = dig2.get();
+        if (fine) { pin.sort_bits = FM.sort_bits[me][g]; pin.seg_prefix = segp.data(); }
         DirWindow win;
         win.w_lo = (u32)group_first_prefix(g);
         const u64 whi = group_first_prefix(g + 1);
@@ -1075,6 +1101,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         if (trace) fprintf(stderr, "[cblx grouped] rank %u group %u: %llu words, prefixes [%u, %u)\n", me, g, (unsigned long long)gN[g], win.w_lo, win.w_hi);
         pipeline_group<C>(c, R, pin, gN[g], win, parts[g]);
         ++cm->groups_used;
+        if (pin.sort_bits == FINE_LEVEL) ++cm->groups_fine;
     }
     T.wait();
     CBLX_HIP(hipStreamSynchronize(c->stream));
@@ -1131,6 +1158,7 @@ void sharded_insert(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_
         }
     }
     cm->groups_used = 0;
+    cm->groups_fine = 0;
     if (cm->protocol == CBLX_PROTO_BINS && bins_protocol_fits(c->P, bounds, T.world)) {
         if (sharded_insert_grouped<C>(c, cm, d_bases, d_offsets, n, cuts, nslices, bounds)) return;
         sharded_insert_bins<C>(c, T, ascii_view(d_bases), d_offsets, n, cuts, nslices, bounds, [](u32) {});

@@ -132,4 +132,141 @@ inline CutPlan make_cut_plan(u32 PB, const u32* bounds, u32 W, const std::vector
     M.ok = true;
     return M;
 }
+
+// ---- FINE bins (PREFIX_BITS > 24): the senders' first pass does more of the receiver's sorting --------------------------------------
+// With bin = (top 8 prefix bits) + #{cuts <= prefix} a receiver is left with PREFIX_BITS - 8 bits to sort: three LSD passes at
+// PREFIX_BITS = 28. But a rank of a many-GPU job owns a NARROW prefix range (necklace prefixes are dense at the bottom of the prefix space:
+// the lowest eighth of the mass spans 2^20 of the 2^28 prefixes), and the bins below 128 + cuts are mostly unused. Here the bins are the
+// intervals between up to 253 cuts, bin(p) = #{cuts <= p}: the rank bounds and group cuts as before, plus STRUCTURAL cuts at multiples of
+// 2^lmax everywhere (so that every bin lies inside an aligned block of 2^lmax prefixes: the bin implies the prefix bits from lmax up,
+// which is what lets 65..72-bit words travel without their hi byte) and at multiples of 2^16 inside the groups that are narrow enough
+// for the budget — narrowest first: groups hold about equal mass, so those are the cheapest per word. A group all of whose bins lie
+// inside aligned blocks of 2^16 prefixes needs 16 bits sorted behind the first pass — two LSD passes instead of three; the others sort
+// 24 bits in three passes of 8. A bin's LEVEL = the smallest L with (first >> L) == (last >> L); `sort_bits` of a group = 16 or 24.
+// The lookup table is linear: key = prefix >> ksh (8192 cells), entry = {cuts at or below the cell's first prefix, the one cut inside
+// the cell or ~0}; structural cuts are multiples of 2^16 >= the cell width, so only rank bounds and group cuts can fall inside a cell,
+// and a list with two of them in one cell is refused (a cell is 1/8192 of the prefix space, a group 1/(W G) of the MASS).
+static const u32 FINE_LEVEL = 16, FINE_MAX_CUTS = 253;
+struct FinePlan : CutPlan {
+    u32 ksh = 0;                         // key of `tab` = prefix >> ksh
+    std::vector<u32> first;              // per interval (= bin, except the all-ones bin 255): its first prefix
+    std::vector<u32> level;              // per interval
+    u32 sort_bits[CUT_MAX_DEST][16];     // per (rank, group): prefix bits the receiver sorts behind the first pass (16 or 24)
+    u32 seg_of[256];                     // bin -> segment number inside its group (what the receiver's tables are indexed by)
+};
+inline u32 fine_bin(const FinePlan& M, u32 PB, u32 p) {  // (host restatement of DigitCut in its linear-key mode)
+    if ((p >> (PB - 8)) >= 255u) return 255u;
+    const CutCell c = M.tab[p >> M.ksh];
+    const u32 b = c.base + (p >= c.cut ? 1u : 0u);
+    return b < 254u ? b : 254u;
+}
+// `lmax`: every bin must lie inside an aligned block of 2^lmax prefixes (<= 24: three passes of 8 bits sort that much)
+inline FinePlan make_fine_plan(u32 PB, u32 lmax, const u32* bounds, u32 W, const std::vector<u32>& gcuts) {
+    FinePlan M;
+    for (u32 i = 0; i < 256; ++i) M.v_of[i] = M.iv_of[i] = M.seg_of[i] = 0xFFFFFFFFu;
+    for (u32 d = 0; d < CUT_MAX_DEST; ++d) for (u32 g = 0; g < 16; ++g) M.sort_bits[d][g] = 24;
+    if (PB <= 24 || PB > 32 || lmax <= FINE_LEVEL || lmax > 24 || W > CUT_MAX_DEST) return M;
+    const u32 RB8 = PB - 8;
+    const u64 half = 1ull << (PB - 1);  // necklace prefixes lie below it, except the all-ones word (bin 255)
+    // forced cuts: rank bounds (kind 1), group cuts (kind 2)
+    std::vector<std::pair<u32, u32>> cuts;  // (value, kind); kind 0 = structural
+    for (u32 i = 0; i + 1 < W; ++i) {
+        if (bounds[i] == 0 || (i && bounds[i] <= bounds[i - 1]) || (u64)bounds[i] > (255ull << RB8)) return M;
+        cuts.push_back({bounds[i], 1u});
+    }
+    for (u32 g : gcuts) cuts.push_back({g, 2u});
+    std::sort(cuts.begin(), cuts.end());
+    for (size_t i = 1; i < cuts.size(); ++i) if (cuts[i].first == cuts[i - 1].first) return M;
+    if (cuts.empty() || cuts.front().first == 0) return M;
+    const size_t nforced = cuts.size();
+    auto has = [&](u64 v) { return std::binary_search(cuts.begin(), cuts.end(), std::make_pair((u32)v, 0u), [](const std::pair<u32, u32>& a, const std::pair<u32, u32>& b) { return a.first < b.first; }); };
+    // structural cuts at the multiples of 2^lmax up to 2^(PB-1): everything above is one never-used bin in front of the all-ones one
+    {
+        std::vector<std::pair<u32, u32>> add;
+        for (u64 v = 1ull << lmax; v <= half; v += 1ull << lmax) if (!has(v)) add.push_back({(u32)v, 0u});
+        cuts.insert(cuts.end(), add.begin(), add.end());
+        std::sort(cuts.begin(), cuts.end());
+    }
+    if (cuts.size() > FINE_MAX_CUTS) return M;
+    // the groups' windows (between consecutive forced cuts), narrowest first: multiples of 2^16 inside them while the budget lasts
+    {
+        std::vector<u64> edge{0};
+        for (const auto& c : cuts) if (c.second) edge.push_back(c.first);
+        edge.push_back(half);
+        struct Win { u64 need, lo, hi; };
+        std::vector<Win> wins;
+        for (size_t i = 0; i + 1 < edge.size(); ++i) {
+            const u64 lo = edge[i], hi = std::min<u64>(edge[i + 1], half);
+            if (hi <= lo) continue;
+            u64 need = 0;
+            for (u64 v = ((lo >> FINE_LEVEL) + 1) << FINE_LEVEL; v < hi; v += 1ull << FINE_LEVEL) if (!has(v)) ++need;
+            wins.push_back(Win{need, lo, hi});
+        }
+        std::sort(wins.begin(), wins.end(), [](const Win& a, const Win& b) { return a.need != b.need ? a.need < b.need : a.lo < b.lo; });
+        size_t total = cuts.size();
+        std::vector<std::pair<u32, u32>> add;
+        for (const Win& w : wins) {
+            if (total + w.need > FINE_MAX_CUTS) break;
+            for (u64 v = ((w.lo >> FINE_LEVEL) + 1) << FINE_LEVEL; v < w.hi; v += 1ull << FINE_LEVEL) if (!has(v)) add.push_back({(u32)v, 0u});
+            total += w.need;
+        }
+        cuts.insert(cuts.end(), add.begin(), add.end());
+        std::sort(cuts.begin(), cuts.end());
+    }
+    (void)nforced;
+    const u32 nc = (u32)cuts.size();
+    for (const auto& c : cuts) M.cuts.push_back(c.first);
+    // intervals: owner, group, first prefix, level
+    M.dest_of.resize(nc + 1); M.grp_of.resize(nc + 1); M.first.resize(nc + 1); M.level.resize(nc + 1);
+    for (u32 d = 0; d < W; ++d) M.ngroups[d] = 0;
+    for (u32 i = 0; i <= nc; ++i) {
+        const u32 first = i ? M.cuts[i - 1] : 0u;
+        const u64 end = i < nc ? M.cuts[i] : 1ull << PB;
+        u32 d = 0;
+        for (u32 j = 0; j + 1 < W; ++j) d += bounds[j] <= first ? 1u : 0u;
+        M.dest_of[i] = d;
+        M.grp_of[i] = !i || M.dest_of[i - 1] != d ? 0u : M.grp_of[i - 1] + (cuts[i - 1].second == 2u ? 1u : 0u);
+        if (M.grp_of[i] >= 16) return M;
+        M.ngroups[d] = std::max(M.ngroups[d], M.grp_of[i] + 1);
+        M.first[i] = first;
+        u32 L = 0;
+        if (first < half) { const u64 last = std::min<u64>(end, half) - 1; while ((first >> L) != (last >> L)) ++L; }  // (the bin above 2^(PB-1) holds nothing)
+        M.level[i] = L;
+        if (L > lmax) return M;  // (cannot happen: the multiples of 2^lmax are all cuts)
+    }
+    for (u32 d = 0; d < W; ++d) for (u32 g = 0; g < 16; ++g) M.sort_bits[d][g] = FINE_LEVEL;
+    for (u32 i = 0; i <= nc; ++i) if (M.level[i] > FINE_LEVEL) M.sort_bits[M.dest_of[i]][M.grp_of[i]] = 24;
+    // the all-ones word rides in bin 255 of the last interval's (rank, group), whatever that group's other bins look like
+    // bins: interval i is bin i; 255 = the all-ones segment
+    if (nc + 1 > 254) return M;
+    for (u32 i = 0; i <= nc; ++i) { M.v_of[i] = i; M.iv_of[i] = i; }
+    M.v_of[255] = 255; M.iv_of[255] = nc;
+    for (u32 d = 0; d <= W; ++d) M.bin_lo[d] = 256;
+    for (int b = 255; b >= 0; --b) if (M.iv_of[b] != 0xFFFFFFFFu) M.bin_lo[M.dest_of[M.iv_of[b]]] = (u32)b;
+    M.bin_lo[W] = 256;
+    for (int d = (int)W - 1; d >= 0; --d) if (M.bin_lo[d] == 256) M.bin_lo[d] = M.bin_lo[d + 1];
+    // segment numbers inside a group: 0, 1, ... in bin order; the all-ones bin is segment 255 of its group
+    {
+        u32 run = 0;
+        for (u32 i = 0; i <= nc; ++i) {
+            if (i && (M.dest_of[i] != M.dest_of[i - 1] || M.grp_of[i] != M.grp_of[i - 1])) run = 0;
+            M.seg_of[i] = run++;
+            if (run > 254) return M;
+        }
+        M.seg_of[255] = 255;
+    }
+    // the table
+    M.ksh = PB > 13 ? PB - 13 : 0;
+    const u32 ncell = 1u << (PB - M.ksh);
+    M.tab.assign(ncell, CutCell{0xFFFFFFFFu, 0u});
+    for (u32 k = 0; k < ncell; ++k) M.tab[k].base = (u32)(std::upper_bound(M.cuts.begin(), M.cuts.end(), (u32)((u64)k << M.ksh)) - M.cuts.begin());
+    for (u32 cv : M.cuts) {
+        if ((cv & ((1u << M.ksh) - 1u)) == 0) continue;  // on a cell's first prefix: counted in its base
+        CutCell& c = M.tab[cv >> M.ksh];
+        if (c.cut != 0xFFFFFFFFu) return M;  // two cuts inside one cell
+        c.cut = cv;
+    }
+    M.ok = true;
+    return M;
+}
 }  // namespace cblx

@@ -86,14 +86,21 @@ struct EncHist {
     u32 nd, SB, PB, bounds[15];   // ... or, when nd != 0, the destination rank of its prefix: #{i < nd-1 : bounds[i] <= prefix}
     u32 binRB;                    // ... or, when nd != 0 and binRB != 0, the sender's pass-A BIN (DigitBin, kernels_radix.hpp): (prefix >> binRB) + rank
     const void* cut_tab = nullptr;  // ... or, when set, the bin under a list of cuts (DigitCut, kernels_radix.hpp): {u32 cut, base} per cut_key of the prefix
+    u32 cut_ksh = 0xFFFFFFFFu;      // ... or (FINE bins, cuts.hpp) per (prefix >> cut_ksh), and the bin is the count of cuts alone
     __device__ __forceinline__ u32 digit(u64 lo, u64 hi) const {
         if (nd == 0) return get_bits(lo, hi, shift, nbits);
         const u32 p = get_bits(lo, hi, SB, PB);
         if (cut_tab) {
+            const u32 v = p >> binRB;
+            if (cut_ksh != 0xFFFFFFFFu) {
+                const uint2 c = reinterpret_cast<const uint2*>(cut_tab)[p >> cut_ksh];
+                const u32 b = c.y + (p >= c.x ? 1u : 0u);
+                return v >= 255u ? 255u : (b < 254u ? b : 254u);
+            }
             u32 key = p;
             if (p >= 64u) { const u32 e = 31u - (u32)__builtin_clz(p); key = 64u + ((e - 6u) << 5) + ((p >> (e - 5u)) & 31u); }
             const uint2 c = reinterpret_cast<const uint2*>(cut_tab)[key];  // x = the cut inside the cell (or ~0), y = cuts at or below its first prefix
-            const u32 v = p >> binRB, b = v + c.y + (p >= c.x ? 1u : 0u);
+            const u32 b = v + c.y + (p >= c.x ? 1u : 0u);
             return v >= 255u ? 255u : (b < 254u ? b : 254u);
         }
         u32 d = 0;

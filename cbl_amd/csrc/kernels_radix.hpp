@@ -248,13 +248,17 @@ struct DigitBin {
 // VALU instructions each, so the count comes from a table over a floating-point-like key of the prefix (the 6 leading bits:
 // 32 cells per octave, exact below 64): entry = {cuts <= the cell's first prefix, the one cut inside the cell or ~0}. The host
 // refuses a cut list with two cuts inside one cell (make_cut_table); 768 entries of 8 bytes, read through the vector L1.
+// FINE bins (cuts.hpp: make_fine_plan; PREFIX_BITS > 24): bin = #{cuts <= prefix} alone, from a linear table over prefix >> ksh.
 struct DigitCut {
     u32 SB, PB, RB;
     const CutCell* tab;
+    u32 ksh = 0xFFFFFFFFu;  // FINE bins: key shift of the linear table
     __device__ __forceinline__ u32 operator()(u64 lo, u64 hi) const {
         const u32 p = get_bits(lo, hi, SB, PB);
-        const CutCell c = tab[cut_key(p)];
-        const u32 v = p >> RB, b = v + c.base + (p >= c.cut ? 1u : 0u);
+        const u32 v = p >> RB;
+        u32 b;
+        if (ksh != 0xFFFFFFFFu) { const CutCell c = tab[p >> ksh]; b = c.base + (p >= c.cut ? 1u : 0u); }
+        else { const CutCell c = tab[cut_key(p)]; b = v + c.base + (p >= c.cut ? 1u : 0u); }
         return v >= 255u ? 255u : (b < 254u ? b : 254u);
     }
 };
@@ -424,7 +428,8 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
                                                                u8* __restrict__ out_next = nullptr, u32* __restrict__ start_dense = nullptr,
                                                                u32 pfx_shift = 0, u32 pfx_bits = 0, u32 grp_bits = 0, u32* __restrict__ amb = nullptr,
                                                                u32 amb_stride = 0, OwnWindow ow = OwnWindow{0, 0, nullptr, nullptr, nullptr},
-                                                               const u64* __restrict__ seg_base = nullptr /* adj is relative to the segment's own start */) {
+                                                               const u64* __restrict__ seg_base = nullptr /* adj is relative to the segment's own start */,
+                                                               const u32* __restrict__ seg_prefix = nullptr /* fused directory: first prefix of the segment's block (null: seg << pfx_bits) */) {
     constexpr bool STAGE_HI = HiTraits<HiT>::has && HiTraits<OutHiT>::has;
     __shared__ u64 s_lo[RDX_TILE];
     __shared__ typename std::conditional<STAGE_HI, HiT, u8>::type s_hi[STAGE_HI ? RDX_TILE : 1];
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
                 }
                 if (st) {
                     if ((p & ((1u << grp_bits) - 1u)) == g_first) amb[(u64)tile * amb_stride + d] = (u32)dst;
-                    else start_dense[((u64)seg << pfx_bits) | p] = (u32)dst;
+                    else start_dense[(seg_prefix ? (u64)seg_prefix[seg] : (u64)seg << pfx_bits) | p] = (u32)dst;
                 }
             }
         }
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
 template <typename HiT>
 __global__ void k_dir_resolve(const u32* __restrict__ ntiles_dev, u32 amb_stride, const u32* __restrict__ amb, const u16* __restrict__ t_seg,
                               const u32* __restrict__ seg_start, const u64* __restrict__ lo, const HiT* __restrict__ hi, u32 pfx_shift,
-                              u32 pfx_bits, u32* __restrict__ start_dense) {
+                              u32 pfx_bits, u32* __restrict__ start_dense, const u32* __restrict__ seg_prefix = nullptr) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (u64)*ntiles_dev * amb_stride) return;
     const u32 dst = amb[i];
@@ -540,7 +545,7 @@ __global__ void k_dir_resolve(const u32* __restrict__ ntiles_dev, u32 amb_stride
     const u32 seg = t_seg ? t_seg[i / amb_stride] : 0u;
     const u32 p = get_bits(lo[dst], (u64)ld_hi<HiT>(hi, dst), pfx_shift, pfx_bits);
     const bool first = dst == (seg_start ? seg_start[seg] : 0u) || get_bits(lo[dst - 1], (u64)ld_hi<HiT>(hi, dst - 1), pfx_shift, pfx_bits) != p;
-    if (first) start_dense[((u64)seg << pfx_bits) | p] = dst;
+    if (first) start_dense[(seg_prefix ? (u64)seg_prefix[seg] : (u64)seg << pfx_bits) | p] = dst;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -687,13 +692,15 @@ __global__ void k_tile_table_grp(u32 G, u32 low_bits, const u32* __restrict__ gr
 // tiles count for d. One workgroup per group, one thread per digit value.
 __global__ __launch_bounds__(256) void k_dir_gather(u32 low_bits, u32 last_bits, const u32* __restrict__ grp_first, const u32* __restrict__ seg_start,
                                                     const u32* __restrict__ ntiles_dev, const u32* __restrict__ colpre, const u32* __restrict__ coltot,
-                                                    const u32* __restrict__ adj, u32* __restrict__ start_dense, u32 w_lo = 0, u32 w_hi = 0xFFFFFFFFu) {
+                                                    const u32* __restrict__ adj, u32* __restrict__ start_dense, u32 w_lo = 0, u32 w_hi = 0xFFFFFFFFu,
+                                                    const u32* __restrict__ seg_prefix = nullptr /* FINE bins: first prefix of the segment's block */) {
     // [w_lo, w_hi): the prefixes this launch owns (a receiver's group works on its window of the prefix space: start_dense is that
     // window's array, passed as `array - w_lo`; prefixes outside it belong to other groups and are not touched)
     const u32 g = blockIdx.x, d = threadIdx.x;
     if (d >= (1u << last_bits)) return;
     const u32 nt = *ntiles_dev, s = g >> low_bits, low = g & ((1u << low_bits) - 1u);
-    const u32 prefix = (s << (low_bits + last_bits)) | (d << low_bits) | low;
+    if (seg_prefix && seg_prefix[s] == 0xFFFFFFFFu) return;  // no such segment (its rows would land on another segment's prefixes)
+    const u32 prefix = (seg_prefix ? seg_prefix[s] : s << (low_bits + last_bits)) | (d << low_bits) | low;
     if (prefix < w_lo || prefix >= w_hi) return;
     if (low_bits && seg_cold(seg_start, s)) {  // its tiles were not cut at the groups: k_boundaries_cold fills these in
         start_dense[prefix] = 0xFFFFFFFFu;
@@ -708,13 +715,13 @@ __global__ __launch_bounds__(256) void k_dir_gather(u32 low_bits, u32 last_bits,
 // bucket boundaries of the cold segments from their (few) sorted records
 template <typename HiT>
 __global__ __launch_bounds__(256) void k_boundaries_cold(const u64* __restrict__ lo, const HiT* __restrict__ hi, u32 SB, u32 R, const u32* __restrict__ seg_start,
-                                                         u32* __restrict__ start_dense) {
+                                                         u32* __restrict__ start_dense, const u32* __restrict__ seg_prefix = nullptr) {
     const u32 s = blockIdx.x;  // gridDim.y workgroups share a segment
     if (!seg_cold(seg_start, s)) return;
     const u32 a = seg_start[s], b = seg_start[s + 1];
     for (u32 i = a + blockIdx.y * blockDim.x + threadIdx.x; i < b; i += blockDim.x * gridDim.y) {
         const u32 p = get_bits(lo[i], (u64)ld_hi<HiT>(hi, i), SB, R);
-        if (i == a || get_bits(lo[i - 1], (u64)ld_hi<HiT>(hi, i - 1), SB, R) != p) start_dense[(s << R) | p] = i;
+        if (i == a || get_bits(lo[i - 1], (u64)ld_hi<HiT>(hi, i - 1), SB, R) != p) start_dense[(seg_prefix ? seg_prefix[s] : s << R) | p] = i;
     }
 }
 

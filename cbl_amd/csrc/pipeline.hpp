@@ -30,6 +30,11 @@ struct PieceInput {
     // are and the later passes' side channel goes to a buffer of the group's own (at least N + 64 bytes)
     const u8* dig_in = nullptr;
     u8* dig_out = nullptr;
+    // FINE bins (cuts.hpp: make_fine_plan): the "segments" are bins of the senders' first pass that lie inside aligned blocks of
+    // 2^sort_bits prefixes — the passes sort that many prefix bits (16: two passes, 24: three) and a record's prefix is
+    // seg_prefix[segment] | its low sort_bits bits (host array of 256; 0 / null: segment = top 8 prefix bits, PREFIX_BITS - 8 bits sorted)
+    u32 sort_bits = 0;
+    const u32* seg_prefix = nullptr;
 };
 
 // A group of the grouped receiver works on its WINDOW [w_lo, w_hi) of the prefix space (both multiples of 64; its records hold no
@@ -75,6 +80,14 @@ inline LsdPlan lsd_plan(const Consts& P, bool split_ok = true) {
     }
     return L;
 }
+// FINE bins: `bits` (16 or 24) prefix bits in passes of 8 from the bottom — the first digit is the same for every group, so the senders'
+// side channel does not depend on who receives a record
+inline LsdPlan lsd_plan_bits(u32 bits) {
+    LsdPlan L;
+    L.npass = (bits + 7) / 8;
+    for (u32 i = 0; i < L.npass; ++i) { L.wid[i] = std::min(8u, bits - 8 * i); L.sh[i + 1] = L.sh[i] + L.wid[i]; }
+    return L;
+}
 
 // KRN-2 + KRN-4 over N records: stable partition by prefix, then the directory (bitvector, rank directory, bucket table
 // with the RAW run of every prefix; nr.cnt / nr.kind are allocated, not filled). The sorted records end up in rec.lo/hi.
@@ -101,9 +114,13 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
     Buf<u32> seg_start(c->pool, 257);
     // PREFIX_BITS > 24: the passes sort the top PBs = 24 prefix bits ("super-prefixes": the xb bits below them count as suffix here,
     // SBs), their directory comes from the last pass's tables, and k_prefix_split finishes the job run by run (below)
-    const LsdPlan LP = lsd_plan(P, pin == nullptr);
+    const bool fine = pin && pin->sort_bits != 0;
+    const LsdPlan LP = fine ? lsd_plan_bits(pin->sort_bits) : lsd_plan(P, pin == nullptr);
     const u32 xb = LP.xb, PBs = P.PB - xb, SBs = P.SB + xb;
-    const u32 nA = std::min(8u, PBs), RB = PBs - nA;  // bits of pass A, bits left for the LSD passes
+    const u32 nA = std::min(8u, PBs), RB = fine ? pin->sort_bits : PBs - nA;  // bits of pass A, bits left for the LSD passes
+    Buf<u32> d_segp;  // FINE bins: first prefix of every segment's aligned block
+    if (fine) { d_segp = Buf<u32>(c->pool, 256); h2d(c, d_segp.get(), pin->seg_prefix, 256); }
+    const u32* segp = d_segp.get();
     const u32 w_lo = win ? win->w_lo : 0u;
     const u64 nprefix = win ? (u64)win->w_hi - win->w_lo : 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
     if (win && ((win->w_lo | win->w_hi) & 63u)) throw Error(CBLX_EINVAL, "a directory window must be cut at multiples of 64 (internal error)");
@@ -237,11 +254,12 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
                 }
                 { StageTimer t(c, ST_SCATTER);
                   hipLaunchKernelGGL((k_radix_scatter<H, H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, colpre.get(),
-                                     adj.get(), lo2, hout, nd, ndp, fused_dir ? sd : (u32*)nullptr, SBs, RB, low_bits, amb.get(), amb_stride); }
+                                     adj.get(), lo2, hout, nd, ndp, fused_dir ? sd : (u32*)nullptr, SBs, RB, low_bits, amb.get(), amb_stride,
+                                     OwnWindow{0, 0, nullptr, nullptr, nullptr}, (const u64*)nullptr, segp); }
                 if (fused_dir) {
                     StageTimer t(c, ST_DIR);
                     hipLaunchKernelGGL(k_dir_resolve<H>, grid1((u64)ntm * amb_stride, 256), dim3(256), 0, c->stream, ntd, amb_stride, (const u32*)amb.get(), tv.seg,
-                                       (const u32*)seg_start.get(), (const u64*)lo2, (const H*)hout, SBs, RB, sd);
+                                       (const u32*)seg_start.get(), (const u64*)lo2, (const H*)hout, SBs, RB, sd, segp);
                     CBLX_HIP(hipStreamSynchronize(c->stream));  // amb is released at the end of this scope
                     have_dense = true;
                 }
@@ -257,9 +275,9 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
                 if (last && tbl_dir) {
                     StageTimer t(c, ST_DIR);
                     hipLaunchKernelGGL(k_dir_gather, dim3(G), dim3(256), 0, c->stream, low_bits, last_bits, grp_tiles ? grp_first.get() : seg_first.get(), seg_start.get(), ntd,
-                                       colpre.get(), coltot.get(), adj.get(), sd, sw_lo, win ? (u32)std::min<u64>(sw_hi, 0xFFFFFFFFull) : 0xFFFFFFFFu);
+                                       colpre.get(), coltot.get(), adj.get(), sd, sw_lo, win ? (u32)std::min<u64>(sw_hi, 0xFFFFFFFFull) : 0xFFFFFFFFu, segp);
                     if (grp_tiles)  // cold segments kept plain tiles: their boundaries come from their (few) records, now in lo2
-                        hipLaunchKernelGGL(k_boundaries_cold<H>, dim3(nseg, 32), dim3(256), 0, c->stream, (const u64*)lo2, (const H*)hout, SBs, RB, seg_start.get(), sd);
+                        hipLaunchKernelGGL(k_boundaries_cold<H>, dim3(nseg, 32), dim3(256), 0, c->stream, (const u64*)lo2, (const H*)hout, SBs, RB, seg_start.get(), sd, segp);
                     have_dense = true;
                 }
             };
@@ -843,7 +861,7 @@ template <typename C> void pipeline_group(cblx_ctx* c, const GroupRegions& R, co
     constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
     constexpr bool KEEP_HI = HiTraits<HiT>::has && !DROP_HI;  // 16-byte records through the LSD passes
     const Consts& P = c->P;
-    const u32 npass = lsd_plan(P, false).total();  // buffer changes behind pass A (records in pieces: LSD passes only, no prefix split)
+    const u32 npass = pin.sort_bits ? lsd_plan_bits(pin.sort_bits).total() : lsd_plan(P, false).total();  // buffer changes behind pass A (records in pieces: LSD passes only, no prefix split)
     // DEEP group (thousands of words per possible prefix: the dense low ranges of a many-GPU job at PREFIX_BITS <= 24): nearly every run
     // takes the long-run path, whose output is the twin — so the LSD passes end in the scratch area and the twin IS the slot.
     // (CBLX_GROUP_DEEP = 0 / 1 forces the choice: tests run small groups through both layouts)

@@ -249,6 +249,10 @@ int cblx_comm_init_sim(cblx_comm** out, uint32_t rank, uint32_t world, int32_t d
 int cblx_sim_store_free(uint64_t store_id);
 int cblx_comm_set_recv_groups(cblx_comm* comm, uint32_t groups);
 int cblx_comm_groups_used(const cblx_comm* comm, uint32_t* out);
+/* ... and how many of those groups sorted 16 prefix bits behind the senders' first pass instead of PREFIX_BITS - 8 (PREFIX_BITS > 24: the first
+ * pass runs on FINE bins that cut a narrow group's prefix range into aligned blocks of 2^16 prefixes, so its receiver needs two partition
+ * passes instead of three; CBLX_FINE_BINS=0 in the environment switches that off). Same result either way. */
+int cblx_comm_groups_fine(const cblx_comm* comm, uint32_t* out);
 /* CBL::insert_seq for every sequence of THIS rank's shard, into an index sharded by prefix range over the ranks of `comm`
  * (every rank makes the same call with its own shard). The shard is consumed in n_slices slices, reads
  * [slice_cuts[s], slice_cuts[s+1]) (n_slices + 1 ascending values, the same NUMBER of slices on every rank): the exchange of

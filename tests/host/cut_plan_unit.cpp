@@ -4,6 +4,7 @@
 // ranks and groups ascend with the prefix, a segment value occurs in at most one bin of a group; group cuts are multiples of 64,
 // strictly inside their rank's range, and split its sampled mass about evenly.
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <random>
 
@@ -109,6 +110,66 @@ int main() {
             }
         }
     }
-    printf("cut plan unit: %ld plans checked, %ld refused, %ld bad\n", plans, refused, bad);
-    return bad || plans < 100 ? 1 : 0;
+    // ---- FINE bins (PREFIX_BITS > 24): bin(p) = #{cuts <= p} from the linear table; every bin inside an aligned block of 2^level
+    // prefixes with level <= lmax; a group's sort_bits covers the levels of its bins; segments number a group's bins 0, 1, ...; the
+    // narrow groups of a necklace-shaped histogram get 16 bits
+    long fplans = 0, frefused = 0, fine16 = 0, fgroups = 0;
+    for (int trial = 0; trial < 300; ++trial) {
+        const u32 PB = 25 + rnd() % 4, W = 2 + rnd() % 7, G = 2 + rnd() % 5;
+        const u32 lmax = (trial & 1) ? 24u : std::min(24u, PB - 4);  // (K = 31: 65..72-bit words travel as their low 64 bits)
+        const u32 hb = 16;
+        std::vector<u64> hist((size_t)1 << hb, 0);
+        for (int i = 0; i < 200000; ++i) {  // density ~ n (1 - x)^(n - 1), n = 40: the minimum of n uniform rotations
+            const double u = (double)(rnd() >> 11) / 9007199254740992.0;
+            const double x = 1.0 - std::pow(1.0 - u, 1.0 / 40.0);
+            hist[(size_t)(x * 0.5 * hist.size())]++;
+        }
+        std::vector<u32> bounds;
+        {
+            u64 tot = 0, run = 0;
+            for (u64 h : hist) tot += h;
+            size_t cell = 0;
+            for (u32 d = 1; d < W; ++d) {
+                while (cell < hist.size() && run + hist[cell] < tot * d / W) run += hist[cell++];
+                bounds.push_back((u32)std::min<u64>(((u64)cell + 1) << (PB - hb), (1ull << PB) - 1));
+            }
+            for (size_t i = 1; i < bounds.size(); ++i) if (bounds[i] < bounds[i - 1]) bounds[i] = bounds[i - 1];
+        }
+        const std::vector<u32> gc = choose_group_cuts(hist, bounds.data(), W, G, PB);
+        const FinePlan M = make_fine_plan(PB, lmax, bounds.data(), W, gc);
+        if (!M.ok) { ++frefused; continue; }
+        ++fplans;
+        CHECK(M.cuts.size() <= FINE_MAX_CUTS, "fine plan: %zu cuts", M.cuts.size());
+        auto cnt = [&](u32 p) { return (u32)(std::upper_bound(M.cuts.begin(), M.cuts.end(), p) - M.cuts.begin()); };
+        auto dest = [&](u32 p) { u32 d = 0; for (u32 b : bounds) d += b <= p ? 1u : 0u; return d; };
+        auto grp = [&](u32 p) { const u32 d = dest(p); const u32 lo = d ? bounds[d - 1] : 0u; u32 g = 0; for (u32 cv : gc) g += (cv > lo && cv <= p) ? 1u : 0u; return g; };
+        for (int i = 0; i < 30000; ++i) {
+            u32 p;
+            const int kind = i % 4;
+            if (kind == 0) p = (u32)(rnd() % (1ull << (PB - 1)));
+            else if (kind == 1) p = (u32)((rnd() % (1ull << (PB - 1))) >> (rnd() % PB));
+            else { const u32 cv = M.cuts[rnd() % M.cuts.size()]; p = cv - 1 + (u32)(rnd() % 3); if (p >= (1u << (PB - 1))) p = cv - 1; }
+            const u32 bin = fine_bin(M, PB, p);
+            CHECK(bin == cnt(p) && bin < 254, "PB %u: fine bin %u != %u at prefix %u", PB, bin, cnt(p), p);
+            if (bin >= 254) continue;
+            const u32 iv = M.iv_of[bin];
+            CHECK(iv == bin, "fine plan: bin %u is interval %u", bin, iv);
+            CHECK(M.dest_of[iv] == dest(p) && M.grp_of[iv] == grp(p), "fine plan: prefix %u owner %u/%u group %u/%u", p, M.dest_of[iv], dest(p), M.grp_of[iv], grp(p));
+            const u32 L = M.level[iv];
+            CHECK(L <= lmax && (p >> L) == (M.first[iv] >> L), "fine plan: prefix %u not in the level-%u block of its bin (first %u)", p, L, M.first[iv]);
+            CHECK(L <= M.sort_bits[M.dest_of[iv]][M.grp_of[iv]], "fine plan: level %u above the group's %u sorted bits", L, M.sort_bits[M.dest_of[iv]][M.grp_of[iv]]);
+            CHECK(bin >= M.bin_lo[M.dest_of[iv]] && bin < M.bin_lo[M.dest_of[iv] + 1], "fine plan: bin %u outside its rank's bins", bin);
+        }
+        CHECK(fine_bin(M, PB, (u32)((1ull << PB) - 1)) == 255u && M.iv_of[255] == (u32)M.cuts.size(), "fine plan: the all-ones word");
+        // segments: 0, 1, 2, ... inside every (rank, group)
+        for (u32 b = 0; b + 1 <= (u32)M.cuts.size(); ++b) {
+            const bool same = b && M.dest_of[b] == M.dest_of[b - 1] && M.grp_of[b] == M.grp_of[b - 1];
+            CHECK(M.seg_of[b] == (same ? M.seg_of[b - 1] + 1 : 0u), "fine plan: segment numbers at bin %u", b);
+        }
+        for (u32 d = 0; d < W; ++d) for (u32 g = 0; g < M.ngroups[d]; ++g) { ++fgroups; fine16 += M.sort_bits[d][g] == 16; }
+        // the lowest rank's groups are the narrowest: with 8 ranks or more of a necklace-shaped histogram they sort 16 bits
+        if (W >= 6 && G <= 4 && PB == 28) CHECK(M.sort_bits[0][0] == 16, "fine plan: PB %u W %u G %u: the first group sorts %u bits", PB, W, G, M.sort_bits[0][0]);
+    }
+    printf("cut plan unit: %ld plans checked, %ld refused, %ld bad; fine: %ld plans, %ld refused, %ld of %ld groups sort 16 bits\n", plans, refused, bad, fplans, frefused, fine16, fgroups);
+    return bad || plans < 100 || fplans < 100 ? 1 : 0;
 }

@@ -2014,12 +2014,13 @@ def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q, protoco
         comm.set_recv_groups(groups)  # 0: the default (4 groups per rank), 1: the ungrouped receiver
         g = cbl_amd.CBL(k, pb, canonical=canonical, device=0)
         sb = sharded.ShardedBuilder(g, dist, slices=3, comm=comm, protocol=protocol)
-        used = []
+        used, fine = [], []
         for batch, n in enumerate(per[rank]):  # two batches; the second reuses the first one's splitters (and meets a non-empty index)
             first = sum(per[r][bb] for r in range(world) for bb in range(batch)) + sum(per[r][batch] for r in range(rank))
             d_b, d_o = synth.reads_torch(23, n, L, first_read=first, device="cuda:0")
             sb.insert_seqs_device(d_b, d_o, n)
             used.append(comm.groups_used())
+            fine.append(comm.groups_fine())
         blob = sharded.gather_serialized(g.serialize(), dist)
         fblob = None
         if path:
@@ -2037,7 +2038,7 @@ def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q, protoco
                     fblob.append(("error", e.code))
                     break
         if rank == 0:
-            q.put((blob, [int(x) for x in sb.bounds], g.count(), fblob, sb.stats["sent_bytes"], used))
+            q.put((blob, [int(x) for x in sb.bounds], g.count(), fblob, sb.stats["sent_bytes"], used, fine))
         comm.close()
     finally:
         dist.destroy_process_group()
@@ -2048,6 +2049,7 @@ def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q, protoco
     (3, 31, 28, True, "bins", 0), (2, 21, 16, False, "bins", 0), (5, 59, 26, False, "bins", 0),  # (five ranks at PREFIX_BITS = 28: 157 s of gigabyte-sized first allocations)
     (2, 31, 24, False, "bins", 1), (3, 59, 28, True, "bins", 1), (8, 31, 24, False, "bins", 1), (3, 31, 28, True, "bins", 1),  # the ungrouped receiver
     (2, 31, 24, False, "bins", 3), (4, 31, 28, False, "bins", 14), (3, 45, 20, True, "bins", 5), (2, 27, 9, False, "bins", 4),
+    (4, 31, 25, True, "bins", 3), (2, 33, 27, False, "bins", 5),  # FINE bins where a 65..72-bit word's bins must imply 21 prefix bits; 16-byte records
     (2, 31, 24, False, "sorted", 0), (3, 59, 28, True, "sorted", 0), (8, 31, 24, False, "sorted", 0)])
 def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canonical, protocol, groups, tmp_path):
     """The C++ orchestration of the multi-GPU build (slices, splitter choice, count exchange, grouped exchange, batch merge)
@@ -2076,7 +2078,7 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
     procs = [ctx.Process(target=_native_worker, args=(r, world, port, k, pb, canonical, per, L, path, q, protocol, groups)) for r in range(world)]
     for p in procs:
         p.start()
-    blob, bounds, count0, fblob, sent, used = q.get(timeout=420)
+    blob, bounds, count0, fblob, sent, used, fine = q.get(timeout=420)
     # the grouped receiver (bins protocol, empty index): rank 0 worked its range off in groups; a second batch meets a non-empty index
     # and takes the ungrouped path; groups = 1 switches it off
     assert used[1] == 0
@@ -2084,6 +2086,8 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
         assert used[0] == 0
     elif pb >= 12:  # (a rank whose range is narrower than a few histogram cells gets fewer groups than asked for, down to one)
         assert 1 <= used[0] <= (groups or 4), used
+    # PREFIX_BITS > 24: the first pass ran on FINE bins, and rank 0 — the narrowest prefix range — sorted 16 bits in its groups, not 20
+    assert fine[1] == 0 and (fine[0] >= 1 if (pb > 24 and protocol == "bins" and groups != 1) else fine[0] == 0), fine
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -2111,6 +2115,7 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
 
 @pytest.mark.parametrize("world,k,pb,canonical,groups,slices,gbps,deep", [
     (4, 31, 24, False, 0, 2, 0.0, None), (4, 31, 24, False, 1, 3, 0.0, None), (8, 31, 28, True, 6, 1, 2.0, None), (3, 59, 28, False, 4, 2, 0.0, None),
+    (8, 31, 28, False, 4, 3, 0.0, "fine=0"), (2, 31, 26, True, 4, 2, 0.0, None), (8, 31, 28, False, 0, 3, 0.0, None),  # FINE bins off (three passes of 7 + 7 + 6 bits) / on
     (2, 25, 16, False, 0, 1, 1.0, None), (8, 31, 24, False, 1, 4, 2.0, None),
     # the two layouts of a group (last pass into the slot / into the scratch with the long-run path's twin as the slot), forced; short buckets and
     # PREFIX_BITS = 6 buckets of thousands of words (the long-run path proper)
@@ -2122,9 +2127,13 @@ def test_rehearsal_of_rank_0_on_recorded_senders(world, k, pb, canonical, groups
     _need_gpu()
     from cbl_amd.sharded import ShardedBuilder, _read_varint
 
+    fine_on = deep != "fine=0"
+    if not fine_on:
+        monkeypatch.setenv("CBLX_FINE_BINS", "0")
+        deep = None
     if deep is not None:
         monkeypatch.setenv("CBLX_GROUP_DEEP", deep)
-    L, nr, store = (150 if k < 59 else 250), (2500 if pb > 12 else 12000), 77 + world * 16 + groups + (100 if deep else 0)
+    L, nr, store = (150 if k < 59 else 250), (2500 if pb > 12 else 12000), 77 + world * 16 + groups + (100 if deep else 0) + (0 if fine_on else 1000) + pb
     bounds = np.zeros(world - 1, dtype=np.uint32)
     valid = False
     cuts = [nr * s // slices for s in range(slices + 1)]
@@ -2135,11 +2144,13 @@ def test_rehearsal_of_rank_0_on_recorded_senders(world, k, pb, canonical, groups
         g = cbl_amd.CBL(k, pb, canonical=canonical)
         valid = g.sharded_insert_seqs_device(cm, d_b, d_o, nr, cuts, bounds, valid)
         if r == 0:
-            used, blob0, st = cm.groups_used(), g.serialize(), cm.stats()
+            used, blob0, st, fine = cm.groups_used(), g.serialize(), cm.stats(), cm.groups_fine()
         g.close()
         cm.close()
     cbl_amd.Comm.sim_store_free(store)
     assert used == 0 if groups == 1 else 1 <= used <= (groups or 4)
+    # PREFIX_BITS > 24: rank 0's groups (the narrowest of the job) sort 16 prefix bits behind the senders' first pass: FINE bins
+    assert fine == (used if (pb > 24 and fine_on and groups != 1) else 0), (fine, used)
     assert st["recv_bytes"] > 0 and st["sent_bytes"] > 0
     one = Oracle(k, pb, canonical)
     for c in range(slices):

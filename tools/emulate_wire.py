@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--grouped-slices", default="3", help="slices of the grouped runs (group 0 of every slice but the last crosses under the next slice's kernels); several values separated by commas")
     ap.add_argument("--taper", default="0.5,0.8,1", help="cumulative fractions of the grouped runs' slices instead of equal ones, e.g. 0.5,0.8,1 (the number of values selects the runs with that many slices)")
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--no-ungrouped", action="store_true", help="skip the ungrouped receiver's runs")
+    ap.add_argument("--no-direct", action="store_true", help="skip the one-GPU build of the same reads")
     a = ap.parse_args()
     if a.taper:
         fr = [float(x) for x in a.taper.split(",")]
@@ -53,18 +55,19 @@ def main():
 
     # the one-GPU build of the same share of reads, for reference
     d_b, d_o = synth.reads_torch(42, nr, L, first_read=0, device="cuda")
-    g = cbl_amd.CBL(k, pb)
-    g.insert_seqs_device(d_b, d_o, nr)
-    ts = []
-    for _ in range(a.steps):
-        g.clear(); torch.cuda.synchronize(); t0 = time.perf_counter()
-        g.insert_seqs_device(d_b, d_o, nr); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-    out["direct_one_gpu_ms"] = round(min(ts) * 1e3, 3)
-    g.close(); del g
+    if not a.no_direct:
+        g = cbl_amd.CBL(k, pb)
+        g.insert_seqs_device(d_b, d_o, nr)
+        ts = []
+        for _ in range(a.steps):
+            g.clear(); torch.cuda.synchronize(); t0 = time.perf_counter()
+            g.insert_seqs_device(d_b, d_o, nr); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        out["direct_one_gpu_ms"] = round(min(ts) * 1e3, 3)
+        g.close(); del g
 
     bounds = np.zeros(W - 1, dtype=np.uint32)
     have_bounds = False
-    modes = [("grouped", int(x), int(y)) for x in a.groups.split(",") for y in a.grouped_slices.split(",")] + [("ungrouped", 1, a.slices)]
+    modes = [("grouped", int(x), int(y)) for x in a.groups.split(",") for y in a.grouped_slices.split(",")] + ([] if a.no_ungrouped else [("ungrouped", 1, a.slices)])
     for mode, groups, slices in modes:
         store = 1000 + groups * 16 + slices
         for r in range(1, W):  # the senders: what each would send rank 0
@@ -88,7 +91,7 @@ def main():
                 if it:
                     ts.append(time.perf_counter() - t0)
             st = cm.stats()
-            run = {"mode": mode, "groups": groups, "groups_used": cm.groups_used(), "slices": slices, "link_gbps": gbps, "ms": [round(t * 1e3, 3) for t in ts], "ms_best": round(min(ts) * 1e3, 3),
+            run = {"mode": mode, "groups": groups, "groups_used": cm.groups_used(), "groups_fine": cm.groups_fine(), "fine_bins": os.environ.get("CBLX_FINE_BINS", "1") != "0", "slices": slices, "link_gbps": gbps, "ms": [round(t * 1e3, 3) for t in ts], "ms_best": round(min(ts) * 1e3, 3),
                    "words_in_index": w.count(), "recv_bytes_per_step": st["recv_bytes"] // (a.steps + 1), "sent_bytes_per_step": st["sent_bytes"] // (a.steps + 1),
                    "wire_ms_at_rate": round(st["recv_bytes"] / (a.steps + 1) / (W - 1) / (gbps * 1e9) * 1e3, 3) if gbps else None,
                    "stage_ms_last_step": {n: round(ms, 3) for n, (ms, _) in w.stage_times().items() if ms > 0}}
