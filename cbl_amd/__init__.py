@@ -112,6 +112,7 @@ SIGNATURES = {
     "cblx_comm_set_recv_groups": (C.c_int, [C.c_void_p, C.c_uint32]),
     "cblx_comm_groups_used": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "cblx_comm_groups_fine": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "cblx_fine_builds": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_sharded_insert_seqs_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
                                                   C.POINTER(C.c_int)]),
     "cblx_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -798,6 +799,12 @@ class CBL:
     def kmers_inserted(self) -> int:
         v = C.c_uint64(0)
         self._chk(self._L.cblx_kmers_inserted(self._h, C.byref(v)))
+        return v.value
+
+    def fine_builds(self) -> int:
+        """Batches built through the FINE-bins route (PREFIX_BITS > 24, empty index, CBLX_FINE_MIN k-mers or more)."""
+        v = C.c_uint64(0)
+        self._chk(self._L.cblx_fine_builds(self._h, C.byref(v)))
         return v.value
 
     def trim(self):

@@ -1143,6 +1143,7 @@ int cblx_stage_times_reset(cblx_ctx* c) {
     return guard(c, [&] { collect_events(c); for (auto& s : c->stages) { s.ms = 0; s.launches = 0; } });
 }
 int cblx_kmers_inserted(cblx_ctx* c, uint64_t* out) { if (!c || !out) return CBLX_EINVAL; *out = c->kmers_inserted; return CBLX_OK; }
+int cblx_fine_builds(cblx_ctx* c, uint64_t* out) { if (!c || !out) return CBLX_EINVAL; *out = c->fine_builds; return CBLX_OK; }
 int cblx_trim(cblx_ctx* c) {
     return guard(c, [&] {
         if (c->ing.nseq == 0) { ingest_wait(c); c->ing.d_bases.reset(); c->ing.d_off.reset(); }

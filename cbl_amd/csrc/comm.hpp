@@ -778,14 +778,21 @@ __global__ void k_add_u64(u64* __restrict__ v, u64 n, u64 add) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] += add;
 }
+// batches from this many k-mers (an upper bound of them) on take the FINE-bins build on one GPU; CBLX_FINE_MIN overrides (tests: 0)
+u64 fine_min_words() {  // read per call: tests switch it
+    const char* e = std::getenv("CBLX_FINE_MIN");
+    return e ? std::strtoull(e, nullptr, 10) : (u64)(4u << 20);
+}
 inline u32 recv_groups_wanted(const cblx_comm* cm) {
     if (cm->recv_groups) return cm->recv_groups;
     const char* e = std::getenv("CBLX_RECV_GROUPS");
     const u32 v = e ? (u32)std::strtoul(e, nullptr, 10) : 0;
     return v ? std::min(v, 14u) : 4u;  // measured against a paced wire (profiles/r04_wire_emulated.md): 4 groups are best at 55 GB/s per link for every configuration; more pay on slower links
 }
+// `single`: ONE rank whose "groups" are the part of the prefix space the FINE bins cover in blocks of 2^16 prefixes and the rest (insert_device_fine):
+// no wire, the same sender and receiver steps
 template <typename C>
-bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, const u32* bounds) {
+bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, const u32* bounds, bool single = false) {
     typedef typename C::HiT HiT;
     constexpr bool WS = C::WS;
     constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
@@ -797,11 +804,11 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     const u32 G = recv_groups_wanted(cm);
     cm->groups_used = 0;
     cm->groups_fine = 0;
-    if (W < 2 || W > MAX_DEST || G < 2 || P.PB < 9 || nslices == 0) return false;
+    if ((W < 2 && !single) || W > MAX_DEST || G < 2 || P.PB < 9 || nslices == 0) return false;
     for (u32 s = 0; s < nslices; ++s) if (cuts[s + 1] < cuts[s] || cuts[s + 1] > n) throw Error(CBLX_EINVAL, "slice cuts must be ascending and at most n");
     // -- the group cuts that go with these bounds (chosen once per set of bounds: a sampled histogram of the first slice, all-reduced)
     const std::vector<u32> bvec(bounds, bounds + (W - 1));
-    if (cm->g_bounds != bvec) {
+    if (!single && cm->g_bounds != bvec) {
         const std::vector<u64> hist = sampled_prefix_hist<C>(c, T, d_bases, d_offsets + cuts[0], cuts[1] - cuts[0]);
         cm->g_cuts = choose_group_cuts(hist, bounds, W, G, P.PB);
         cm->g_bounds = bvec;
@@ -816,6 +823,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         if (P.PB > 24 && !(fe && fe[0] == '0')) FM = make_fine_plan(P.PB, lmax, bounds, W, cm->g_cuts);
     }
     const bool fine = FM.ok;
+    if (single && !fine) return false;
     const CutPlan LM = fine ? CutPlan() : make_cut_plan(P.PB, bounds, W, cm->g_cuts);
     const CutPlan& M = fine ? static_cast<const CutPlan&>(FM) : LM;
     // -- the job: k-mers per rank (upper bound), whether any rank holds an index already
@@ -833,6 +841,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     T.all_reduce_sum_u64(agree, 3);
     const u64 job = agree[0];
     if (!M.ok || agree[1] != 0 || agree[2] != 0 || job / W + job / (2 * W) + (1u << 20) >= LIMIT) return false;
+    if (single && mine < fine_min_words()) return false;  // (a small batch: the groups' fixed costs outweigh the pass saved)
     const bool trace = std::getenv("CBLX_TRACE_SHARDED") != nullptr;
     const LsdPlan LP = fine ? lsd_plan_bits(FINE_LEVEL) : lsd_plan(P, false);  // (the receiver runs LSD passes only: pipeline.hpp; FINE bins: the first digit is the same for 16 and 24 sorted bits)
     const DigitBits nextd{P.SB + LP.sh[0], LP.wid[0]};
@@ -1176,6 +1185,28 @@ struct LocalTransport : Transport {
     void wait() override {}
     void exchange_items(const std::vector<Item>&, hipStream_t) override {}
 };
+// ---- one GPU, PREFIX_BITS > 24, an empty index: the build on FINE bins --------------------------------------------------------------
+// The plain build sorts 24 prefix bits in three passes and finishes the last PREFIX_BITS - 24 run by run (k_prefix_split): four trips
+// of every record through HBM. Here the first pass runs on the FINE bins of the grouped receiver (cuts.hpp: make_fine_plan) with ONE
+// rank and TWO "groups": the prefixes below 245 * 2^16 — where nearly nine tenths of the necklace prefixes of random reads lie — in
+// aligned blocks of 2^16 prefixes, whose records need 16 more bits sorted (two passes), and the rest in blocks of 2^24 (three passes of
+// 8 bits). No sampling: the cut is fixed, and a batch whose words all lie above it simply takes three passes behind the first, as the
+// plain build does. Same index (tests run every PREFIX_BITS > 24 shape through both routes).
+inline u32 fine_single_cut(u32 PB) { return std::min<u32>(245u << FINE_LEVEL, (1u << (PB - 1)) - (1u << FINE_LEVEL)); }
+bool insert_device_fine(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq) {
+    const char* fe = std::getenv("CBLX_FINE_BINS");
+    if ((fe && fe[0] == '0') || c->P.PB <= 24 || nseq == 0 || c->res.count != 0) return false;
+    check_aligned16(d_bases, "d_bases");
+    cblx_comm cm;
+    cm.t.reset(new LocalTransport());
+    cm.recv_groups = 2;
+    cm.g_cuts.assign(1, fine_single_cut(c->P.PB));
+    const u64 cuts[2] = {0, nseq};
+    bool done = false;
+    dispatch(c->P, [&](auto cfg) { done = sharded_insert_grouped<decltype(cfg)>(c, &cm, d_bases, d_offsets, nseq, cuts, 1, nullptr, true); });
+    if (done) ++c->fine_builds;
+    return done;
+}
 }  // namespace (reopened below: insert_device_streamed is declared in ingest.hpp)
 
 namespace {

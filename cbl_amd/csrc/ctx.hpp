@@ -185,6 +185,7 @@ struct cblx_ctx {
     SortedBatch batch;
     std::string err;
     u64 kmers_inserted = 0;
+    u64 fine_builds = 0;       // batches that took the FINE-bins build (PREFIX_BITS > 24 on an empty index: comm.hpp insert_device_fine)
     Stage stages[ST_N];
     struct Ev { int st; hipEvent_t a, b; };
     std::vector<Ev> evs;

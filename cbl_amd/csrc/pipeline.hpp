@@ -1002,6 +1002,8 @@ u64 batch_max_bases() {
     return x ? x : (1ull << 31);
 }
 void insert_device_one(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq, const u64* ends = nullptr);
+// PREFIX_BITS > 24 on an empty index: the build on FINE bins (comm.hpp; false = not taken, nothing was touched)
+bool insert_device_fine(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq);
 void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq) {
     if (nseq == 0) return;
     check_aligned16(d_bases, "d_bases");
@@ -1029,6 +1031,7 @@ void insert_device(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nse
     }
 }
 void insert_device_one(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq, const u64* ends) {
+    if (c->res.count == 0 && c->P.PB > 24 && insert_device_fine(c, d_bases, d_offsets, nseq)) { collect_events(c); return; }
     dispatch(c->P, [&](auto cfg) {
         typedef decltype(cfg) C;
         ChunkPlan pl;

@@ -345,6 +345,10 @@ int cblx_stage_times(cblx_ctx* ctx, const char** names, double* ms, uint64_t* la
 int cblx_stage_times_reset(cblx_ctx* ctx);
 /* k-mers (words) consumed by insert calls since creation — the numerator of the throughput metric. */
 int cblx_kmers_inserted(cblx_ctx* ctx, uint64_t* out);
+/* Batches this ctx built through the FINE-bins route (PREFIX_BITS > 24, empty index, a batch of CBLX_FINE_MIN k-mers or more — default
+ * 2^22 —, CBLX_FINE_BINS != 0): the first partition pass runs on 253 intervals of the prefix space — aligned blocks of 2^16 prefixes
+ * where the necklace prefixes are dense — so that most words need two more passes instead of three. Same index either way. */
+int cblx_fine_builds(cblx_ctx* ctx, uint64_t* out);
 /* Release cached device workspace (kept between flushes to avoid hipMalloc in the hot path). */
 int cblx_trim(cblx_ctx* ctx);
 /* Back to the state of CBL::new(): drops the resident index and anything enqueued, keeps the cached workspace. */

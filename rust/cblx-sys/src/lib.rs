@@ -237,6 +237,7 @@ extern "C" {
     pub fn cblx_comm_set_recv_groups(comm: *mut cblx_comm, groups: u32) -> c_int;
     pub fn cblx_comm_groups_used(comm: *const cblx_comm, out: *mut u32) -> c_int;
     pub fn cblx_comm_groups_fine(comm: *const cblx_comm, out: *mut u32) -> c_int;
+    pub fn cblx_fine_builds(ctx: *mut cblx_ctx, out: *mut u64) -> c_int;
     pub fn cblx_sharded_insert_seqs_device(
         ctx: *mut cblx_ctx,
         comm: *mut cblx_comm,

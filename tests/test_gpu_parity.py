@@ -220,6 +220,43 @@ def test_index_matches_oracle(k, pb, nreads, L, canonical):
     _check_index(g, o)
 
 
+@pytest.mark.parametrize("k,pb,nreads,L,canonical", [(31, 28, 3000, 150, False), (31, 25, 2500, 150, True), (59, 28, 1500, 250, False), (59, 26, 1200, 250, True),
+                                                    (33, 27, 2000, 150, True), (27, 26, 2500, 150, False), (31, 26, 2500, 150, False), (15, 25, 4000, 100, False)])
+def test_fine_bins_build_on_one_gpu(k, pb, nreads, L, canonical, monkeypatch):
+    """PREFIX_BITS > 24 on an empty index: the first partition pass runs on FINE bins (253 intervals: blocks of 2^16 prefixes where the
+    necklace prefixes are dense, two passes behind them; blocks of 2^24 above, three) instead of the top 8 prefix bits + three passes + a
+    run-by-run split of the last bits. Same bytes either way: reads with N and lower case, a sequence of several chunks, every read
+    twice; the second batch meets a non-empty index (the incremental path); CBLX_FINE_BINS=0 keeps the plain build."""
+    _need_gpu()
+    monkeypatch.setenv("CBLX_FINE_MIN", "0")
+    rng = random.Random(k * 100 + pb)
+    bases, offsets = synth.reads(42, nreads, L)
+    b = bytearray(bases.tobytes())
+    for _ in range(nreads // 40):  # a few dirty chunks
+        b[rng.randrange(len(b))] = ord("N")
+    for i in range(0, len(b), 997):
+        b[i] = ord(chr(b[i]).lower()) if chr(b[i]) in "ACGT" else b[i]
+    bases = np.frombuffer(bytes(b), dtype=np.uint8)
+    long_seq = _rand_seq(rng, 7000)
+    o = Oracle(k, pb, canonical)
+    o.insert_seqs(bases, offsets)
+    o.insert_seqs(bases, offsets)
+    o.insert_seq(long_seq)
+    for fine in ("1", "0"):
+        monkeypatch.setenv("CBLX_FINE_BINS", fine)
+        g = cbl_amd.CBL(k, pb, canonical=canonical)
+        both = np.concatenate([bases, bases])
+        off2 = np.concatenate([offsets, offsets[1:] + offsets[-1]])
+        g.insert_seqs(both, off2)
+        g.flush()
+        assert g.fine_builds() == (1 if fine == "1" else 0)
+        g.insert_seq(long_seq)  # on a non-empty index: the incremental path
+        assert g.fine_builds() == (1 if fine == "1" else 0)
+        _check_index(g, o)
+        assert g.validate() == 0
+        g.close()
+
+
 @pytest.mark.parametrize(
     "k,pb,n,canonical",
     [(9, 4, 40000, False), (9, 4, 40000, True), (11, 8, 60000, False), (11, 10, 200000, False), (13, 12, 300000, False),
