@@ -820,7 +820,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         const char* fe = std::getenv("CBLX_FINE_BINS");
         // every bin must imply the prefix bits a record does not carry behind the first pass: 65..72-bit words travel as their low 64 bits
         const u32 lmax = DROP_HI ? std::min(24u, 64u - P.SB) : 24u;
-        if (P.PB > 24 && !(fe && fe[0] == '0')) FM = make_fine_plan(P.PB, lmax, bounds, W, cm->g_cuts);
+        if (P.PB > 24 && !(fe && fe[0] == '0')) FM = make_fine_plan(P.PB, lmax, bounds, W, cm->g_cuts, single);
     }
     const bool fine = FM.ok;
     if (single && !fine) return false;
@@ -845,8 +845,9 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     const bool trace = std::getenv("CBLX_TRACE_SHARDED") != nullptr;
     const LsdPlan LP = fine ? lsd_plan_bits(FINE_LEVEL) : lsd_plan(P, false);  // (the receiver runs LSD passes only: pipeline.hpp; FINE bins: the first digit is the same for 16 and 24 sorted bits)
     const DigitBits nextd{P.SB + LP.sh[0], LP.wid[0]};
-    Buf<CutCell> d_tab(c->pool, M.tab.size());
-    h2d(c, d_tab.get(), M.tab.data(), M.tab.size());
+    Buf<u32> d_tab(c->pool, DigitCut::LDS_WORDS);  // CutCell[CUT_KEYS], or u32[FINE_CELLS]: staged in LDS by the kernels that look bins up
+    if (fine) h2d(c, d_tab.get(), FM.tab32.data(), FM.tab32.size());
+    else h2d(c, d_tab.get(), reinterpret_cast<const u32*>(M.tab.data()), M.tab.size() * 2);
     const DigitCut fn{P.SB, P.PB, RB, d_tab.get(), fine ? FM.ksh : 0xFFFFFFFFu};
     EncHist eh0{};
     eh0.nd = W; eh0.SB = P.SB; eh0.PB = P.PB; eh0.binRB = RB; eh0.cut_tab = d_tab.get(); eh0.cut_ksh = fn.ksh;
@@ -1010,6 +1011,11 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
             const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
             const OwnWindow ow{S.own_a, S.own_a + S.own, a_lo.get() + filled, OHS ? (void*)(a_hi.get() + filled * OHS) : nullptr, a_dig.get() + filled};
             StageTimer t(c, ST_SCATTER);
+            static const bool plain_single = [] { const char* e = std::getenv("CBLX_FINE_REDIR"); return !(e && e[0] == '1'); }();  // (dev A/B)
+            if (single && plain_single)  // one rank: every record is its own, the pass writes the log directly
+                hipLaunchKernelGGL((k_radix_scatter<HiT, OutH, DigitCut, false>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, (const u64*)wk.t_lo.get(), (const HiT*)wk.t_hi.get(), tv, fn,
+                                   (const u32*)wk.colpre.get(), (const u32*)wk.adj.get(), a_lo.get() + filled, OHS ? (OutH*)(a_hi.get() + filled * OHS) : (OutH*)nullptr, nextd, a_dig.get() + filled);
+            else
             hipLaunchKernelGGL((k_radix_scatter<HiT, OutH, DigitCut, true>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, (const u64*)wk.t_lo.get(), (const HiT*)wk.t_hi.get(), tv, fn,
                                (const u32*)wk.colpre.get(), (const u32*)wk.adj.get(), S.lo.get(), (OutH*)S.hi.get(), nextd, S.dig.get(), (u32*)nullptr, 0u, 0u, 0u, (u32*)nullptr, 0u, ow);
             CBLX_HIP(hipGetLastError());
@@ -1107,7 +1113,8 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         R.fin_hi = fin_hi ? fin_hi + gbase[g] : nullptr;
         R.scr_lo = scr_lo.get();
         R.scr_hi = OHS ? scr_hi.get() : nullptr;
-        if (trace) fprintf(stderr, "[cblx grouped] rank %u group %u: %llu words, prefixes [%u, %u)\n", me, g, (unsigned long long)gN[g], win.w_lo, win.w_hi);
+        if (trace) fprintf(stderr, "[cblx grouped] rank %u group %u: %llu words, prefixes [%u, %u), cells [%u, %u), %u bits sorted behind the first pass\n", me, g, (unsigned long long)gN[g], win.w_lo, win.w_hi,
+                           gc0[g], gc0[g + 1], pin.sort_bits ? pin.sort_bits : RB);
         pipeline_group<C>(c, R, pin, gN[g], win, parts[g]);
         ++cm->groups_used;
         if (pin.sort_bits == FINE_LEVEL) ++cm->groups_fine;

@@ -147,8 +147,12 @@ inline CutPlan make_cut_plan(u32 PB, const u32* bounds, u32 W, const std::vector
 // the cell or ~0}; structural cuts are multiples of 2^16 >= the cell width, so only rank bounds and group cuts can fall inside a cell,
 // and a list with two of them in one cell is refused (a cell is 1/8192 of the prefix space, a group 1/(W G) of the MASS).
 static const u32 FINE_LEVEL = 16, FINE_MAX_CUTS = 253;
+// the table the kernels stage in LDS: one u32 per cell of 2^(PB - 12) prefixes over [0, 2^(PB-1)) — low byte = cuts at or below the
+// cell's first prefix, upper 24 bits = offset of the one cut inside the cell (FINE_NO_CUT: none). 8 KB.
+static const u32 FINE_CELLS = 2048, FINE_NO_CUT = 0xFFFFFFu;
 struct FinePlan : CutPlan {
-    u32 ksh = 0;                         // key of `tab` = prefix >> ksh
+    u32 ksh = 0;                         // key of `tab32` = prefix >> ksh
+    std::vector<u32> tab32;              // FINE_CELLS entries (see above); `tab` stays empty
     std::vector<u32> first;              // per interval (= bin, except the all-ones bin 255): its first prefix
     std::vector<u32> level;              // per interval
     u32 sort_bits[CUT_MAX_DEST][16];     // per (rank, group): prefix bits the receiver sorts behind the first pass (16 or 24)
@@ -156,16 +160,18 @@ struct FinePlan : CutPlan {
 };
 inline u32 fine_bin(const FinePlan& M, u32 PB, u32 p) {  // (host restatement of DigitCut in its linear-key mode)
     if ((p >> (PB - 8)) >= 255u) return 255u;
-    const CutCell c = M.tab[p >> M.ksh];
-    const u32 b = c.base + (p >= c.cut ? 1u : 0u);
+    const u32 k = p >> M.ksh, c = M.tab32[k < FINE_CELLS ? k : FINE_CELLS - 1];
+    const u32 b = (c & 255u) + ((p & ((1u << M.ksh) - 1u)) >= (c >> 8) ? 1u : 0u);
     return b < 254u ? b : 254u;
 }
 // `lmax`: every bin must lie inside an aligned block of 2^lmax prefixes (<= 24: three passes of 8 bits sort that much)
-inline FinePlan make_fine_plan(u32 PB, u32 lmax, const u32* bounds, u32 W, const std::vector<u32>& gcuts) {
+// `bottom_first`: the windows are filled from the lowest prefixes up instead of narrowest first (one rank, whose "groups" are not
+// equal shares of the mass: comm.hpp insert_device_fine)
+inline FinePlan make_fine_plan(u32 PB, u32 lmax, const u32* bounds, u32 W, const std::vector<u32>& gcuts, bool bottom_first = false) {
     FinePlan M;
     for (u32 i = 0; i < 256; ++i) M.v_of[i] = M.iv_of[i] = M.seg_of[i] = 0xFFFFFFFFu;
     for (u32 d = 0; d < CUT_MAX_DEST; ++d) for (u32 g = 0; g < 16; ++g) M.sort_bits[d][g] = 24;
-    if (PB <= 24 || PB > 32 || lmax <= FINE_LEVEL || lmax > 24 || W > CUT_MAX_DEST) return M;
+    if (PB <= 24 || PB > 28 || lmax <= FINE_LEVEL || lmax > 24 || W > CUT_MAX_DEST) return M;  // (PB <= 28: a cell of the table is at most 2^16 prefixes wide)
     const u32 RB8 = PB - 8;
     const u64 half = 1ull << (PB - 1);  // necklace prefixes lie below it, except the all-ones word (bin 255)
     // forced cuts: rank bounds (kind 1), group cuts (kind 2)
@@ -202,11 +208,11 @@ inline FinePlan make_fine_plan(u32 PB, u32 lmax, const u32* bounds, u32 W, const
             for (u64 v = ((lo >> FINE_LEVEL) + 1) << FINE_LEVEL; v < hi; v += 1ull << FINE_LEVEL) if (!has(v)) ++need;
             wins.push_back(Win{need, lo, hi});
         }
-        std::sort(wins.begin(), wins.end(), [](const Win& a, const Win& b) { return a.need != b.need ? a.need < b.need : a.lo < b.lo; });
+        if (!bottom_first) std::sort(wins.begin(), wins.end(), [](const Win& a, const Win& b) { return a.need != b.need ? a.need < b.need : a.lo < b.lo; });
         size_t total = cuts.size();
         std::vector<std::pair<u32, u32>> add;
         for (const Win& w : wins) {
-            if (total + w.need > FINE_MAX_CUTS) break;
+            if (total + w.need > FINE_MAX_CUTS) { if (bottom_first) continue; break; }
             for (u64 v = ((w.lo >> FINE_LEVEL) + 1) << FINE_LEVEL; v < w.hi; v += 1ull << FINE_LEVEL) if (!has(v)) add.push_back({(u32)v, 0u});
             total += w.need;
         }
@@ -256,15 +262,14 @@ inline FinePlan make_fine_plan(u32 PB, u32 lmax, const u32* bounds, u32 W, const
         M.seg_of[255] = 255;
     }
     // the table
-    M.ksh = PB > 13 ? PB - 13 : 0;
-    const u32 ncell = 1u << (PB - M.ksh);
-    M.tab.assign(ncell, CutCell{0xFFFFFFFFu, 0u});
-    for (u32 k = 0; k < ncell; ++k) M.tab[k].base = (u32)(std::upper_bound(M.cuts.begin(), M.cuts.end(), (u32)((u64)k << M.ksh)) - M.cuts.begin());
+    M.ksh = PB - 12;  // FINE_CELLS cells below 2^(PB-1)
+    M.tab32.assign(FINE_CELLS, FINE_NO_CUT << 8);
+    for (u32 k = 0; k < FINE_CELLS; ++k) M.tab32[k] |= (u32)(std::upper_bound(M.cuts.begin(), M.cuts.end(), (u32)((u64)k << M.ksh)) - M.cuts.begin());
     for (u32 cv : M.cuts) {
-        if ((cv & ((1u << M.ksh) - 1u)) == 0) continue;  // on a cell's first prefix: counted in its base
-        CutCell& c = M.tab[cv >> M.ksh];
-        if (c.cut != 0xFFFFFFFFu) return M;  // two cuts inside one cell
-        c.cut = cv;
+        if ((cv & ((1u << M.ksh) - 1u)) == 0 || cv >= half) continue;  // on a cell's first prefix: counted in its base (above 2^(PB-1): no necklace prefix)
+        u32& c = M.tab32[cv >> M.ksh];
+        if ((c >> 8) != FINE_NO_CUT) return M;  // two cuts inside one cell
+        c = (c & 255u) | ((cv & ((1u << M.ksh) - 1u)) << 8);
     }
     M.ok = true;
     return M;

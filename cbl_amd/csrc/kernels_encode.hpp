@@ -87,20 +87,23 @@ struct EncHist {
     u32 binRB;                    // ... or, when nd != 0 and binRB != 0, the sender's pass-A BIN (DigitBin, kernels_radix.hpp): (prefix >> binRB) + rank
     const void* cut_tab = nullptr;  // ... or, when set, the bin under a list of cuts (DigitCut, kernels_radix.hpp): {u32 cut, base} per cut_key of the prefix
     u32 cut_ksh = 0xFFFFFFFFu;      // ... or (FINE bins, cuts.hpp) per (prefix >> cut_ksh), and the bin is the count of cuts alone
-    __device__ __forceinline__ u32 digit(u64 lo, u64 hi) const {
+    // u32 words of the cut table (the main kernel stages them in LDS: as a gather from global memory the lookup cost it 1 ms of 7.5)
+    __device__ __forceinline__ u32 cut_words() const { return cut_ksh != 0xFFFFFFFFu ? 2048u : 2u * (64u + 26u * 32u); }
+    // `t`: the cut table where the caller staged it (null: in global memory)
+    __device__ __forceinline__ u32 digit(u64 lo, u64 hi, const u32* t = nullptr) const {
         if (nd == 0) return get_bits(lo, hi, shift, nbits);
         const u32 p = get_bits(lo, hi, SB, PB);
         if (cut_tab) {
+            if (!t) t = reinterpret_cast<const u32*>(cut_tab);
             const u32 v = p >> binRB;
-            if (cut_ksh != 0xFFFFFFFFu) {
-                const uint2 c = reinterpret_cast<const uint2*>(cut_tab)[p >> cut_ksh];
-                const u32 b = c.y + (p >= c.x ? 1u : 0u);
+            if (cut_ksh != 0xFFFFFFFFu) {  // FINE bins: low byte = cuts at or below the cell's first prefix, upper bits = offset of the one cut inside the cell
+                const u32 k = p >> cut_ksh, c = t[k < 2048u ? k : 2047u];
+                const u32 b = (c & 255u) + ((p & ((1u << cut_ksh) - 1u)) >= (c >> 8) ? 1u : 0u);
                 return v >= 255u ? 255u : (b < 254u ? b : 254u);
             }
             u32 key = p;
             if (p >= 64u) { const u32 e = 31u - (u32)__builtin_clz(p); key = 64u + ((e - 6u) << 5) + ((p >> (e - 5u)) & 31u); }
-            const uint2 c = reinterpret_cast<const uint2*>(cut_tab)[key];  // x = the cut inside the cell (or ~0), y = cuts at or below its first prefix
-            const u32 b = v + c.y + (p >= c.x ? 1u : 0u);
+            const u32 b = v + t[2 * key + 1] + (p >= t[2 * key] ? 1u : 0u);  // {the cut inside the cell (or ~0), cuts at or below its first prefix}
             return v >= 255u ? 255u : (b < 254u ? b : 254u);
         }
         u32 d = 0;
@@ -331,6 +334,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(BaseView B, u64 total_ba
     __shared__ u64 s_par[(ENC_MAX_KMERS + ENC_THREADS) / 64 + 2];
     __shared__ u32 s_parpre[(ENC_MAX_KMERS + ENC_THREADS) / 64 + 2];
     __shared__ u32 s_cfwd[ENC_MAX_CHUNKS + 1];  // canonical: forward-strand k-mers of the tile in front of each chunk
+    extern __shared__ u32 s_cut[];              // the cut table of the fused histogram's bins (launched with its size only when there is one)
 
     const u32 tid = threadIdx.x;
     const u32 c0 = tile_first[blockIdx.x], c1 = tile_first[blockIdx.x + 1];
@@ -348,6 +352,12 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(BaseView B, u64 total_ba
     const u64 win0 = (out_base + kbase) / ENC_HIST_WINDOW;  // first window this tile's outputs fall into
     if (eh.counts)
         for (u32 i = tid; i < ENC_HIST_WINDOWS * 256; i += ENC_THREADS) s_hist[i] = 0;
+    const u32* ctab = nullptr;
+    if (eh.counts && eh.cut_tab) {
+        const u32 nw = eh.cut_words();
+        for (u32 i = tid * 4; i < nw; i += ENC_THREADS * 4) *reinterpret_cast<uint4*>(s_cut + i) = *reinterpret_cast<const uint4*>(reinterpret_cast<const u32*>(eh.cut_tab) + i);
+        ctab = s_cut;  // (the barrier behind the code stream below covers it)
+    }
     const u32 nwords = (u32)((B1 - A0 + 15) >> 4);
     for (u32 i = tid; i < nwords + 6 && i < ENC_CODE_WORDS; i += ENC_THREADS) {
         u64 b = A0 + (u64)i * 16;
@@ -441,14 +451,14 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(BaseView B, u64 total_ba
             }
             u64 lo, hi;
             kmer_word<WIDE>(x, PK, rc, lo, hi);
-#if CBLX_ENC_PROBE  // timing probe only (tools/dev_encode_probe.py): one byte per k-mer instead of the word
+#if CBLX_ENC_PROBE == 1  // timing probe only (tools/dev_encode_probe.py): one byte per k-mer instead of the word
             reinterpret_cast<u8*>(out_lo)[obase + drel] = (u8)lo ^ (u8)hi;
 #else
             out_lo[obase + drel] = lo;
             st_hi<HiT>(out_hi, obase + drel, hi);
 #endif
             if (eh.counts) {
-                const u32 key = ((hbase + drel) / ENC_HIST_WINDOW) * 256 + eh.digit(lo, hi);
+                const u32 key = ((hbase + drel) / ENC_HIST_WINDOW) * 256 + eh.digit(lo, hi, ctab);
 #if CBLX_ENC_HIST_VOTE
                 // The first-pass digit is the skewed one: a wave's 64 keys are a handful of distinct values (2-3 on
                 // average), which per-lane LDS atomics serialise address by address. Instead the wave votes value by
@@ -510,7 +520,11 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(BaseView B, u64 total_ba
         if (P.K == 59) kmer_loop(std::integral_constant<u32, 59>());
         else kmer_loop(std::integral_constant<u32, 0>());
     }
+#if CBLX_ENC_PROBE == 2  // timing probe only (wrong histogram): what the flush of the tile's counts costs
+    if (false) {
+#else
     if (eh.counts) {  // the first-pass digit is the skewed one: only a few dozen bins per window are non-zero
+#endif
         __syncthreads();
         for (u32 i = tid; i < ENC_HIST_WINDOWS * 256; i += ENC_THREADS) {
             const u32 v = s_hist[i];

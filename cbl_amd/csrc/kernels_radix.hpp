@@ -248,20 +248,37 @@ struct DigitBin {
 // VALU instructions each, so the count comes from a table over a floating-point-like key of the prefix (the 6 leading bits:
 // 32 cells per octave, exact below 64): entry = {cuts <= the cell's first prefix, the one cut inside the cell or ~0}. The host
 // refuses a cut list with two cuts inside one cell (make_cut_table); 768 entries of 8 bytes, read through the vector L1.
-// FINE bins (cuts.hpp: make_fine_plan; PREFIX_BITS > 24): bin = #{cuts <= prefix} alone, from a linear table over prefix >> ksh.
+// FINE bins (cuts.hpp: make_fine_plan; PREFIX_BITS > 24): bin = #{cuts <= prefix} alone, from a linear table of FINE_CELLS u32 over
+// prefix >> ksh (low byte = cuts at or below the cell's first prefix, upper bits = offset of the one cut inside the cell).
+// The kernels STAGE the table in LDS (`staged`): as a gather from global memory it cost the first pass 3.7 ms of 9.6 per 1.5 G records and
+// KRN-1 1 ms of 7.5 (a wave's 64 lanes touch about ten cells: ten L1 lines per wave instruction next to the streaming records).
 struct DigitCut {
     u32 SB, PB, RB;
-    const CutCell* tab;
+    const void* tab;        // CutCell[CUT_KEYS] (key = cut_key(prefix)), or u32[FINE_CELLS] for FINE bins
     u32 ksh = 0xFFFFFFFFu;  // FINE bins: key shift of the linear table
-    __device__ __forceinline__ u32 operator()(u64 lo, u64 hi) const {
+    static constexpr u32 LDS_WORDS = 2048;  // u32 words of LDS either table takes (CUT_KEYS * 2 = 1792 <= FINE_CELLS = 2048)
+    __device__ __forceinline__ u32 words() const { return ksh != 0xFFFFFFFFu ? FINE_CELLS : CUT_KEYS * 2; }
+    // bin of a word from the table at `t` (LDS or global)
+    __device__ __forceinline__ u32 at(const u32* t, u64 lo, u64 hi) const {
         const u32 p = get_bits(lo, hi, SB, PB);
         const u32 v = p >> RB;
         u32 b;
-        if (ksh != 0xFFFFFFFFu) { const CutCell c = tab[p >> ksh]; b = c.base + (p >= c.cut ? 1u : 0u); }
-        else { const CutCell c = tab[cut_key(p)]; b = v + c.base + (p >= c.cut ? 1u : 0u); }
+        if (ksh != 0xFFFFFFFFu) {
+            const u32 k = p >> ksh, c = t[k < FINE_CELLS ? k : FINE_CELLS - 1u];
+            b = (c & 255u) + ((p & ((1u << ksh) - 1u)) >= (c >> 8) ? 1u : 0u);
+        } else {
+            const u32 k = cut_key(p);
+            b = v + t[2 * k + 1] + (p >= t[2 * k] ? 1u : 0u);  // CutCell{cut, base}
+        }
         return v >= 255u ? 255u : (b < 254u ? b : 254u);
     }
+    __device__ __forceinline__ u32 operator()(u64 lo, u64 hi) const { return at(reinterpret_cast<const u32*>(tab), lo, hi); }
 };
+template <typename F> struct DigitUsesTable : std::false_type {};
+template <> struct DigitUsesTable<DigitCut> : std::true_type {};
+template <typename F> __device__ __forceinline__ u32 digit_at(const F& f, const u32* t, u64 lo, u64 hi) {
+    if constexpr (DigitUsesTable<F>::value) return f.at(t, lo, hi); else return f(lo, hi);
+}
 // Where the records of the sender's OWN destination go: positions [a, b) of the pass's output order leave for other arrays
 // (position - a); what lies behind them moves down by b - a, so the send buffer holds the other ranks' records only.
 struct OwnWindow {
@@ -431,9 +448,11 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
                                                                const u64* __restrict__ seg_base = nullptr /* adj is relative to the segment's own start */,
                                                                const u32* __restrict__ seg_prefix = nullptr /* fused directory: first prefix of the segment's block (null: seg << pfx_bits) */) {
     constexpr bool STAGE_HI = HiTraits<HiT>::has && HiTraits<OutHiT>::has;
+    constexpr bool TABLE = DigitUsesTable<DigitFn>::value;  // the digit comes from a table staged in LDS (dead once the records are staged)
+    constexpr bool KEEP_DIG = !STAGE_HI || TABLE;
     __shared__ u64 s_lo[RDX_TILE];
     __shared__ typename std::conditional<STAGE_HI, HiT, u8>::type s_hi[STAGE_HI ? RDX_TILE : 1];
-    __shared__ u8 s_dig[STAGE_HI ? 1 : RDX_TILE];  // digit of the staged record when it cannot be recomputed from lo alone
+    __shared__ u8 s_dig[KEEP_DIG ? RDX_TILE : 1];  // digit of the staged record when it cannot be recomputed from lo alone
     // the ranking counters live in the staging area (they are dead before the first record is staged): 39 KB of LDS per
     // workgroup instead of 47 KB = four resident workgroups per CU instead of three
     static_assert((RDX_THREADS / 64) * 256 * 4 <= RDX_TILE * 8, "rank counters must fit the staging area");
@@ -445,6 +464,15 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
     u32 tile, n_tile, seg;
     u64 tbase;
     if (!tile_get(tv, blockIdx.x, tile, tbase, n_tile, seg)) return;
+    const u32* ltab = nullptr;
+    if constexpr (TABLE) {  // behind the rank counters (the first 8 KB of the staging area)
+        static_assert((RDX_THREADS / 64) * 256 * 4 + DigitCut::LDS_WORDS * 4 <= RDX_TILE * 8, "rank counters + digit table must fit the staging area");
+        u32* t = reinterpret_cast<u32*>(s_lo) + (RDX_THREADS / 64) * 256;
+        const u32 nw = dfn.words();
+        for (u32 i = tid * 4; i < nw; i += RDX_THREADS * 4) *reinterpret_cast<uint4*>(t + i) = *reinterpret_cast<const uint4*>(reinterpret_cast<const u32*>(dfn.tab) + i);
+        __syncthreads();
+        ltab = t;
+    }
 
     u64 klo[RDX_ITEMS];
     typename std::conditional<std::is_same<HiT, u64>::value, u64, u32>::type khi[RDX_ITEMS];
@@ -461,7 +489,7 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
         // same hint on the STORES doubles the time: they are what must stay)
         klo[j] = __builtin_nontemporal_load(&lo_t[eo]);
         if constexpr (HiTraits<HiT>::has) khi[j] = __builtin_nontemporal_load(&hi_t[eo]); else khi[j] = 0;
-        digit[j] = valid ? dfn(klo[j], (u64)khi[j]) : 255u;
+        digit[j] = valid ? digit_at(dfn, ltab, klo[j], (u64)khi[j]) : 255u;
     }
     tile_rank_packed<RDX_THREADS, RDX_ITEMS>(digit, s_wcnt, s_dbase, s_scan, RDX_ITEMS);  // digit[j] = digit << 16 | position
     if (tid < 256) {
@@ -481,7 +509,7 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
         const u32 pj = digit[j] & 0xFFFFu;  // < RDX_TILE always; tail slots land in [n_tile, RDX_TILE)
         s_lo[pj] = klo[j];
         if constexpr (STAGE_HI) s_hi[pj] = (HiT)khi[j];
-        else s_dig[pj] = (u8)(digit[j] >> 16);
+        if constexpr (KEEP_DIG) s_dig[pj] = (u8)(digit[j] >> 16);
     }
     __syncthreads();
 #pragma unroll
@@ -491,8 +519,8 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
             const u64 a = s_lo[s];
             u64 b = 0;
             u32 d;
-            if constexpr (STAGE_HI) { b = (u64)s_hi[s]; d = dfn(a, b); }
-            else d = s_dig[s];
+            if constexpr (STAGE_HI) b = (u64)s_hi[s];
+            if constexpr (KEEP_DIG) d = s_dig[s]; else d = dfn(a, b);
             u64 dst = s_gbase[d] + s;
             if constexpr (REDIR) {  // multi-GPU sender: the records of its own prefix range go straight to the receive arena
                 const bool own = dst >= ow.a && dst < ow.b;

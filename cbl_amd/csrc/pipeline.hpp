@@ -274,6 +274,8 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
                 }
                 if (last && tbl_dir) {
                     StageTimer t(c, ST_DIR);
+                    // FINE bins: the segments' blocks need not cover the window (the last group's reaches up to 2^PREFIX_BITS, its bins do not)
+                    if (fine) CBLX_HIP(hipMemsetAsync(start_dense.get(), 0xFF, nsuper * 4, c->stream));
                     hipLaunchKernelGGL(k_dir_gather, dim3(G), dim3(256), 0, c->stream, low_bits, last_bits, grp_tiles ? grp_first.get() : seg_first.get(), seg_start.get(), ntd,
                                        colpre.get(), coltot.get(), adj.get(), sd, sw_lo, win ? (u32)std::min<u64>(sw_hi, 0xFFFFFFFFull) : 0xFFFFFFFFu, segp);
                     if (grp_tiles)  // cold segments kept plain tiles: their boundaries come from their (few) records, now in lo2
@@ -975,8 +977,8 @@ template <typename C> void encode(cblx_ctx* c, const BaseView& d_bases, const Ch
     typedef typename C::HiT HiT;
     StageTimer t(c, ST_ENCODE);
     const u64 ntiles = ceil_div(pl.total_bases, ENC_TILE_BYTES);
-    if (ntiles)
-        hipLaunchKernelGGL((k_encode<C::WIDE, HiT>), dim3((unsigned)ntiles), dim3(ENC_THREADS), 0, c->stream, d_bases, pl.total_bases, pl.chunk_start.get(),
+    if (ntiles)  // (dynamic LDS: the cut table of the fused histogram's bins, when there is one)
+        hipLaunchKernelGGL((k_encode<C::WIDE, HiT>), dim3((unsigned)ntiles), dim3(ENC_THREADS), (eh.counts && eh.cut_tab) ? 8192 : 0, c->stream, d_bases, pl.total_bases, pl.chunk_start.get(),
                            pl.chunk_len.get(), pl.kmer_off.get(), pl.ndirty ? pl.dirty.get() : (const u8*)nullptr, pl.tile_first.get(), c->P, out_lo, out_hi, out_base, eh);
     if (pl.ndirty)
         hipLaunchKernelGGL((k_encode_dirty_wave<C::WIDE, HiT>), dim3((pl.ndirty + 3) / 4), dim3(256), 0, c->stream, d_bases, pl.chunk_start.get(), pl.chunk_len.get(),

@@ -170,6 +170,20 @@ int main() {
         // the lowest rank's groups are the narrowest: with 8 ranks or more of a necklace-shaped histogram they sort 16 bits
         if (W >= 6 && G <= 4 && PB == 28) CHECK(M.sort_bits[0][0] == 16, "fine plan: PB %u W %u G %u: the first group sorts %u bits", PB, W, G, M.sort_bits[0][0]);
     }
+    // one rank (insert_device_fine): one cut at 245 * 2^16, filled from the bottom — the low group sorts 16 bits at every PREFIX_BITS > 24
+    for (u32 PB = 25; PB <= 28; ++PB)
+        for (u32 lmax : {24u, PB - 4 < 24u ? PB - 4 : 24u}) {
+            const std::vector<u32> gc{std::min<u32>(245u << 16, (1u << (PB - 1)) - (1u << 16))};
+            const FinePlan M = make_fine_plan(PB, lmax, nullptr, 1, gc, true);
+            CHECK(M.ok && M.ngroups[0] == 2 && M.sort_bits[0][0] == 16, "one-rank fine plan at PB %u lmax %u: ok %d groups %u bits %u", PB, lmax, (int)M.ok, M.ngroups[0], M.sort_bits[0][0]);
+            if (!M.ok) continue;
+            for (u32 p = 0; p < (1u << (PB - 1)); p += 4099) {
+                const u32 bin = fine_bin(M, PB, p);
+                CHECK(bin == (u32)(std::upper_bound(M.cuts.begin(), M.cuts.end(), p) - M.cuts.begin()) && (p >> M.level[bin]) == (M.first[bin] >> M.level[bin]) && M.level[bin] <= lmax,
+                      "one-rank fine plan at PB %u: prefix %u bin %u", PB, p, bin);
+                CHECK(M.grp_of[bin] == (p >= gc[0] ? 1u : 0u), "one-rank fine plan at PB %u: group of prefix %u", PB, p);
+            }
+        }
     printf("cut plan unit: %ld plans checked, %ld refused, %ld bad; fine: %ld plans, %ld refused, %ld of %ld groups sort 16 bits\n", plans, refused, bad, fplans, frefused, fine16, fgroups);
     return bad || plans < 100 || fplans < 100 ? 1 : 0;
 }
