@@ -848,9 +848,20 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     Buf<u32> d_tab(c->pool, DigitCut::LDS_WORDS);  // CutCell[CUT_KEYS], or u32[FINE_CELLS]: staged in LDS by the kernels that look bins up
     if (fine) h2d(c, d_tab.get(), FM.tab32.data(), FM.tab32.size());
     else h2d(c, d_tab.get(), reinterpret_cast<const u32*>(M.tab.data()), M.tab.size() * 2);
-    const DigitCut fn{P.SB, P.PB, RB, d_tab.get(), fine ? FM.ksh : 0xFFFFFFFFu};
+    DigitCut fn{P.SB, P.PB, RB, d_tab.get(), fine ? FM.ksh : 0xFFFFFFFFu};
     EncHist eh0{};
     eh0.nd = W; eh0.SB = P.SB; eh0.PB = P.PB; eh0.binRB = RB; eh0.cut_tab = d_tab.get(); eh0.cut_ksh = fn.ksh;
+    if (single && fine) {
+        // one rank: the plan is regular — multiples of 2^16 up to the one group cut, multiples of 2^lmax above — and the bin is arithmetic
+        // (checked against the plan's table, cell by cell; the table route stays for anything else)
+        const u32 x = cm->g_cuts[0], lm = DROP_HI ? std::min(24u, 64u - P.SB) : 24u;
+        bool regular = (x & 0xFFFFu) == 0;
+        for (u32 k = 0; regular && k < FINE_CELLS; ++k) {
+            const u32 p = k << FM.ksh, b = ((p < x ? p : x) >> 16) + (p >= x ? (p >> lm) - (x >> lm) : 0u);
+            regular = (FM.tab32[k] >> 8) == FINE_NO_CUT && (FM.tab32[k] & 255u) == b;
+        }
+        if (regular) { fn.reg_x = x; fn.reg_lmax = lm; fn.tab = nullptr; eh0.reg_x = x; eh0.reg_lmax = lm; eh0.cut_tab = nullptr; }
+    }
     const u32 my_lo = M.bin_lo[me], my_cells = M.bin_lo[me + 1] - M.bin_lo[me], NG = M.ngroups[me];
     // cells (= my bins) of every one of my groups
     // (a cut that falls exactly on a segment boundary leaves one bin number unused: such a cell holds nothing and belongs nowhere)
@@ -1103,7 +1114,14 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         if (fine) { pin.sort_bits = FM.sort_bits[me][g]; pin.seg_prefix = segp.data(); }
         DirWindow win;
         win.w_lo = (u32)group_first_prefix(g);
-        const u64 whi = group_first_prefix(g + 1);
+        u64 whi = group_first_prefix(g + 1);
+        if (fine && whi > (nprefix >> 1) && win.w_lo < (nprefix >> 1)) {
+            // FINE bins: no necklace prefix lies in the upper half of the prefix space except the all-ones word's (bin 255): a group that
+            // reaches up there and holds no such word ends its directory window at the half (the dense directory costs a pass over the window)
+            u64 ones = 0;
+            if (my_lo + my_cells == 256) for (size_t p = 0; p < np; ++p) ones += pcnt[p * 256 + (255 - my_lo)];
+            if (!ones) whi = nprefix >> 1;
+        }
         win.w_hi = (u32)std::min<u64>(whi, 0xFFFFFFC0ull);
         win.bv = fin.bv.get();
         GroupRegions R;

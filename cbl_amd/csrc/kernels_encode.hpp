@@ -87,12 +87,17 @@ struct EncHist {
     u32 binRB;                    // ... or, when nd != 0 and binRB != 0, the sender's pass-A BIN (DigitBin, kernels_radix.hpp): (prefix >> binRB) + rank
     const void* cut_tab = nullptr;  // ... or, when set, the bin under a list of cuts (DigitCut, kernels_radix.hpp): {u32 cut, base} per cut_key of the prefix
     u32 cut_ksh = 0xFFFFFFFFu;      // ... or (FINE bins, cuts.hpp) per (prefix >> cut_ksh), and the bin is the count of cuts alone
+    u32 reg_x = 0, reg_lmax = 0;    // ... or (FINE bins of one rank) cuts at the multiples of 2^16 up to reg_x and of 2^reg_lmax above: arithmetic, no table
     // u32 words of the cut table (the main kernel stages them in LDS: as a gather from global memory the lookup cost it 1 ms of 7.5)
     __device__ __forceinline__ u32 cut_words() const { return cut_ksh != 0xFFFFFFFFu ? 2048u : 2u * (64u + 26u * 32u); }
     // `t`: the cut table where the caller staged it (null: in global memory)
     __device__ __forceinline__ u32 digit(u64 lo, u64 hi, const u32* t = nullptr) const {
         if (nd == 0) return get_bits(lo, hi, shift, nbits);
         const u32 p = get_bits(lo, hi, SB, PB);
+        if (reg_x) {
+            const u32 v = p >> binRB, b = ((p < reg_x ? p : reg_x) >> 16) + (p >= reg_x ? (p >> reg_lmax) - (reg_x >> reg_lmax) : 0u);
+            return v >= 255u ? 255u : (b < 254u ? b : 254u);
+        }
         if (cut_tab) {
             if (!t) t = reinterpret_cast<const u32*>(cut_tab);
             const u32 v = p >> binRB;

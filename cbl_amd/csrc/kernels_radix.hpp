@@ -256,14 +256,19 @@ struct DigitCut {
     u32 SB, PB, RB;
     const void* tab;        // CutCell[CUT_KEYS] (key = cut_key(prefix)), or u32[FINE_CELLS] for FINE bins
     u32 ksh = 0xFFFFFFFFu;  // FINE bins: key shift of the linear table
+    // FINE bins of ONE rank (comm.hpp insert_device_fine): the cuts are the multiples of 2^16 up to reg_x and the multiples of 2^reg_lmax
+    // above it — the count is arithmetic, no table (reg_x = 0: not this case)
+    u32 reg_x = 0, reg_lmax = 0;
     static constexpr u32 LDS_WORDS = 2048;  // u32 words of LDS either table takes (CUT_KEYS * 2 = 1792 <= FINE_CELLS = 2048)
-    __device__ __forceinline__ u32 words() const { return ksh != 0xFFFFFFFFu ? FINE_CELLS : CUT_KEYS * 2; }
+    __device__ __forceinline__ u32 words() const { return reg_x ? 0u : (ksh != 0xFFFFFFFFu ? FINE_CELLS : CUT_KEYS * 2); }
     // bin of a word from the table at `t` (LDS or global)
     __device__ __forceinline__ u32 at(const u32* t, u64 lo, u64 hi) const {
         const u32 p = get_bits(lo, hi, SB, PB);
         const u32 v = p >> RB;
         u32 b;
-        if (ksh != 0xFFFFFFFFu) {
+        if (reg_x) {
+            b = ((p < reg_x ? p : reg_x) >> 16) + (p >= reg_x ? (p >> reg_lmax) - (reg_x >> reg_lmax) : 0u);
+        } else if (ksh != 0xFFFFFFFFu) {
             const u32 k = p >> ksh, c = t[k < FINE_CELLS ? k : FINE_CELLS - 1u];
             b = (c & 255u) + ((p & ((1u << ksh) - 1u)) >= (c >> 8) ? 1u : 0u);
         } else {
@@ -464,15 +469,6 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
     u32 tile, n_tile, seg;
     u64 tbase;
     if (!tile_get(tv, blockIdx.x, tile, tbase, n_tile, seg)) return;
-    const u32* ltab = nullptr;
-    if constexpr (TABLE) {  // behind the rank counters (the first 8 KB of the staging area)
-        static_assert((RDX_THREADS / 64) * 256 * 4 + DigitCut::LDS_WORDS * 4 <= RDX_TILE * 8, "rank counters + digit table must fit the staging area");
-        u32* t = reinterpret_cast<u32*>(s_lo) + (RDX_THREADS / 64) * 256;
-        const u32 nw = dfn.words();
-        for (u32 i = tid * 4; i < nw; i += RDX_THREADS * 4) *reinterpret_cast<uint4*>(t + i) = *reinterpret_cast<const uint4*>(reinterpret_cast<const u32*>(dfn.tab) + i);
-        __syncthreads();
-        ltab = t;
-    }
 
     u64 klo[RDX_ITEMS];
     typename std::conditional<std::is_same<HiT, u64>::value, u64, u32>::type khi[RDX_ITEMS];
@@ -489,7 +485,23 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
         // same hint on the STORES doubles the time: they are what must stay)
         klo[j] = __builtin_nontemporal_load(&lo_t[eo]);
         if constexpr (HiTraits<HiT>::has) khi[j] = __builtin_nontemporal_load(&hi_t[eo]); else khi[j] = 0;
-        digit[j] = valid ? digit_at(dfn, ltab, klo[j], (u64)khi[j]) : 255u;
+        if constexpr (!TABLE) digit[j] = valid ? dfn(klo[j], (u64)khi[j]) : 255u;
+    }
+    if constexpr (TABLE) {
+        // the bin table goes into LDS behind the rank counters (the first 8 KB of the staging area) — its loads are issued behind the
+        // records' so that the tile waits for memory once, not twice
+        static_assert((RDX_THREADS / 64) * 256 * 4 + DigitCut::LDS_WORDS * 4 <= RDX_TILE * 8, "rank counters + digit table must fit the staging area");
+        u32* t = reinterpret_cast<u32*>(s_lo) + (RDX_THREADS / 64) * 256;
+        const u32 nw = dfn.words();
+        if (nw) {
+            for (u32 i = tid * 4; i < nw; i += RDX_THREADS * 4) *reinterpret_cast<uint4*>(t + i) = *reinterpret_cast<const uint4*>(reinterpret_cast<const u32*>(dfn.tab) + i);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < RDX_ITEMS; ++j) {
+            const u32 e = w * (64 * RDX_ITEMS) + j * 64 + lane;
+            digit[j] = e < n_tile ? dfn.at(t, klo[j], (u64)khi[j]) : 255u;
+        }
     }
     tile_rank_packed<RDX_THREADS, RDX_ITEMS>(digit, s_wcnt, s_dbase, s_scan, RDX_ITEMS);  // digit[j] = digit << 16 | position
     if (tid < 256) {
