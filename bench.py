@@ -89,10 +89,12 @@ def stage_alg_bytes(k: int, pb: int, read_len: int):
     }
 
 
-# `A |= B`: bytes per word of the merged runs (|A| + |B| words)
+# `A |= B`: bytes per word a stage's kernels were GIVEN (cblx_stage_units: the bucket classes split the words between the stages) —
+# the gather copies the one-sided buckets (read + write), the sorting classes read both halves and write the result, the Trie |= Trie
+# unions are priced on their OUTPUT words by SURVEY.md §8d's figure (2 BYTES read + BYTES written)
 def merge_alg_bytes(k: int, pb: int):
-    _, _, _, sfx, _ = word_layout(k, pb)
-    return {"merge_gather": 2 * sfx, "bucket_medium": 2 * sfx, "bucket_huge": 2 * sfx, "bucket_big": 2 * sfx, "directory": 0.0}
+    _, _, _, sfx, by = word_layout(k, pb)
+    return {"merge_gather": 2 * sfx, "bucket_medium": 2 * sfx, "bucket_huge": 2 * sfx, "bucket_big": 3 * by, "directory": 0.0}
 
 
 KERNEL_OF = {"radix_scatter": "k_radix_scatter", "radix_hist": "k_radix_hist_bytes", "radix_scan": "k_colscan_*+k_seg_*", "encode": "k_encode",
@@ -146,6 +148,7 @@ def parse_args(argv=None):
                     "--config merge: the oracle builds both operands, merges them, and both resulting indexes are compared")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serialize", action="store_true", help="skip the serialize leg (index bytes into a host buffer)")
+    ap.add_argument("--merge-clone", action="store_true", help="--config merge on one GPU: a step = clone A into the work index, then `|=` (the round-4 step) instead of cblx_merge_from")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (value_h2d_inclusive)")
     ap.add_argument("--no-fasta", action="store_true", help="skip the file-inclusive measurement (fasta_inclusive: the same reads as a FASTA file on tmpfs)")
     ap.add_argument("--no-per-record", action="store_true", help="skip the per-record measurement (per_record: one cblx_insert_seq call per read from a C++ host program)")
@@ -562,10 +565,16 @@ def main():
             work = cbl_amd.CBL(K, PB, canonical=args.canonical, device=local_rank, profile=True)
             count_a, count_b = A.count(), B.count()
 
-            def step(_i):
-                work.clear()
-                work.__ior__(A)
-                work.__ior__(B)
+            # `work = A; work |= B` without the copy (cblx_merge_from: the device merge writes a new arena anyway; A stays as it is, B
+            # as `|=` leaves it). --merge-clone restores the round-4 step (clear, clone A into the work index, `|=`): 2.2 ms more
+            if args.merge_clone:
+                def step(_i):
+                    work.clear()
+                    work.__ior__(A)
+                    work.__ior__(B)
+            else:
+                def step(_i):
+                    work.merge_from(A, B)
 
             last = lambda: work  # noqa: E731
         else:
@@ -608,6 +617,7 @@ def main():
     else:
         count = allreduce_sum(last().count())
         stages = last().stage_times()
+        stage_units = last().stage_units()  # words per stage over the timed steps (the bucket classes split them)
         units_alg = (count_a + count_b) * args.steps  # words of the merged runs
         extra["merge"]["words_union"] = count
     total_units = allreduce_sum(units_per_rank_step) * args.steps
@@ -616,7 +626,9 @@ def main():
     # every kernel group of the step against the HBM roofline: ALGORITHMIC bytes per launch / average launch time (HIP
     # events recorded on the ctx's own stream around every launch of the group, timed steps only); `dom` = the slowest
     kernels = []
-    # the bucket kernels split the words between them by run length and the split is not reported: the whole word count is
+    if args.kind == "build":
+        stage_units = {}
+    # the bucket kernels split the words between them by run length and (builds) the split is not reported: the whole word count is
     # priced against the slowest of them (at these workloads it holds > 99 % of the words), the others carry no fraction
     bucket_stages = [n for n in ("bucket_medium", "bucket_small", "bucket_big", "bucket_huge") if stages.get(n, (0, 0))[0] > 0]
     bucket_main = max(bucket_stages, key=lambda n: stages[n][0]) if bucket_stages else None
@@ -626,7 +638,11 @@ def main():
         launches = max(int(launches), 1)
         row = {"name": KERNEL_OF.get(n, n), "stage": n, "ms_per_step": round(ms / args.steps, 3), "launches_per_step": launches / args.steps,
                "launch_ms_avg": round(ms / launches, 3)}
-        if n in bucket_stages and n != bucket_main:
+        if stage_units.get(n, 0) > 0:  # the library counted the words this stage was given
+            bpl = alg[n] * stage_units[n] / launches
+            ach = bpl / (ms / launches * 1e-3) / 1e9
+            row.update({"alg_bytes_per_launch": int(bpl), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4), "words_per_step": int(stage_units[n] / args.steps)})
+        elif args.kind != "build" or (n in bucket_stages and n != bucket_main):
             row.update({"alg_bytes_per_launch": None, "achieved": None, "frac": None})
         else:
             bpl = alg[n] * units_alg / launches
@@ -634,6 +650,8 @@ def main():
             row.update({"alg_bytes_per_launch": int(bpl), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4)})
         kernels.append(row)
     kernels.sort(key=lambda x: -x["ms_per_step"])
+    for row in kernels:  # an algorithmic rate above the peak is a bookkeeping error, never a result
+        assert row["frac"] is None or row["frac"] <= 1.0, f"stage {row['stage']}: algorithmic rate {row['achieved']} GB/s above the HBM peak"
     roofline = None
     if kernels:
         dom = kernels[0]
@@ -831,7 +849,7 @@ def main():
             par = "1 GPU" if world == 1 else f"{world} GPUs: read-sharded encode + partition, prefix-range exchange ({args.protocol} protocol), per-range bucket insert"
         else:
             workload = (f"merge (cfg 5 per-GPU share): K={K} ({wb}-bit word) PREFIX_BITS={PB}, A |= B with A, B = indexes of {NR}x{L}bp reads per GPU each "
-                        f"(seeds 42 / 43); a step = device copy of A into a work index + the merge; value = k-mers of B merged per second")
+                        f"(seeds 42 / 43); a step = " + ("device copy of A into a work index + the merge" if args.merge_clone or world > 1 else "cblx_merge_from(work, A, B): work = A | B as `A |= B` would leave A, A untouched (no copy)") + "; value = k-mers of B merged per second")
             par = "1 GPU" if world == 1 else f"{world} GPUs: both operands prefix-range sharded, B re-sharded to A's bounds, per-rank merge"
         out = {
             "metric": "k-mers inserted/sec (build index)" if args.kind == "build" else "k-mers inserted/sec (merge: self |= other)",

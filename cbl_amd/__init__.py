@@ -125,6 +125,8 @@ SIGNATURES = {
     "cblx_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "cblx_load_from_file": (C.c_int, [C.c_void_p, C.c_char_p]),
     "cblx_merge_assign": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cblx_merge_from": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cblx_stage_units": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32)]),
     "cblx_export_buckets": (C.c_int, [C.c_void_p, BUCKET_CB, C.c_void_p]),
     "cblx_contains_seq": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "cblx_contains_seqs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
@@ -747,6 +749,11 @@ class CBL:
         self._chk(self._L.cblx_merge_assign(self._h, other._h))
         return self
 
+    def merge_from(self, a: "CBL", b: "CBL") -> "CBL":
+        """self = what `a |= b` would leave in a, with a untouched (b as `|=` leaves it): `self = a.clone(); self |= b` without the copy."""
+        self._chk(self._L.cblx_merge_from(self._h, a._h, b._h))
+        return self
+
     # ---- inspection -------------------------------------------------------------------------------------------
     def consts(self) -> dict:
         c = Consts()
@@ -792,6 +799,15 @@ class CBL:
         n = C.c_uint32(0)
         self._chk(self._L.cblx_stage_times(self._h, names, ms, ln, 16, C.byref(n)))
         return {names[i].decode(): (ms[i], ln[i]) for i in range(n.value)}
+
+    def stage_units(self) -> dict:
+        """{stage: words} the stage's kernels were given since the last reset, where the pipeline counts them (`|=`); 0 = not counted."""
+        names = (C.c_char_p * 16)()
+        n = C.c_uint32(0)
+        self._chk(self._L.cblx_stage_times(self._h, names, None, None, 16, C.byref(n)))
+        un = (C.c_uint64 * 16)()
+        self._chk(self._L.cblx_stage_units(self._h, un, 16, C.byref(n)))
+        return {names[i].decode(): un[i] for i in range(n.value)}
 
     def stage_times_reset(self):
         self._chk(self._L.cblx_stage_times_reset(self._h))

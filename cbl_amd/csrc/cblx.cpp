@@ -140,6 +140,27 @@ void read_fastx_into_queue(cblx_ctx* c, const char* path, uint64_t* n_records, c
 }  // namespace
 
 // ================================================================================================ C ABI
+namespace {
+// a deep copy of `src`'s resident index into dst's pool (same device: a copy kernel; another device: over the fabric)
+Resident clone_resident(cblx_ctx* dst, const cblx_ctx* src) {
+    const Resident& o = src->res;
+    Resident copy;
+    copy.nb = o.nb;
+    copy.count = o.count;
+    auto dup = [&](auto& d, const auto& s) {
+        typedef typename std::remove_reference<decltype(*s.get())>::type T;
+        if (!s.get()) return;
+        d = Buf<T>(dst->pool, s.n);
+        if (dst->device == src->device) device_copy(dst->stream, d.get(), s.get(), s.n * sizeof(T));
+        else CBLX_HIP(hipMemcpyPeerAsync(d.get(), dst->device, s.get(), src->device, s.n * sizeof(T), dst->stream));
+    };
+    dup(copy.bv, o.bv); dup(copy.rank_dir, o.rank_dir); dup(copy.prefix, o.prefix); dup(copy.start, o.start);
+    dup(copy.cnt, o.cnt); dup(copy.kind, o.kind); dup(copy.a_lo, o.a_lo); dup(copy.a_hi, o.a_hi);
+    CBLX_HIP(hipStreamSynchronize(dst->stream));
+    return copy;
+}
+}  // namespace
+
 extern "C" {
 
 uint32_t cblx_abi_version(void) { return CBLX_ABI_VERSION; }
@@ -844,6 +865,43 @@ int cblx_write_body_at(cblx_ctx* c, const char* path, uint64_t file_off) {
         write_body_at(c, path, file_off);
     });
 }
+int cblx_merge_from(cblx_ctx* dst, cblx_ctx* self, cblx_ctx* other) {
+    return guard(dst, [&] {
+        if (!self || !other) throw Error(CBLX_EINVAL, "null argument");
+        if (dst == self || dst == other || self == other) throw Error(CBLX_EINVAL, "merge_from: dst, self and other must be three different contexts");
+        for (cblx_ctx* x : {self, other}) {
+            if (dst->P.K != x->P.K || dst->P.PB != x->P.PB) throw Error(CBLX_EINVAL, "merge: K / PREFIX_BITS mismatch");
+            if (dst->P.canonical != x->P.canonical) throw Error(CBLX_EINVAL, "One of the index is canonical while the other isn't");
+        }
+        if (dst->device != self->device) throw Error(CBLX_EINVAL, "merge_from: dst and self must live on the same device");
+        CBLX_HIP(hipStreamSynchronize(dst->stream));
+        dst->res = Resident();
+        dst->batch = SortedBatch();
+        ingest_drop(dst);
+        for (cblx_ctx* x : {self, other}) {
+            CBLX_HIP(hipSetDevice(x->device));
+            flush(x);
+            CBLX_HIP(hipStreamSynchronize(x->stream));
+        }
+        CBLX_HIP(hipSetDevice(dst->device));
+        if (self->res.count == 0 && other->res.count == 0) return;
+        if (other->res.count == 0) { dst->res = clone_resident(dst, self); return; }
+        if (self->res.count == 0) { dst->res = clone_resident(dst, other); return; }  // every bucket other-only: cloned as stored
+        const char* fp = std::getenv("CBLX_FORCE_PEER_COPY");
+        const bool peer = dst->device != other->device || (fp && fp[0] == '1');
+        Resident copy;
+        if (peer) copy = clone_resident(dst, other);
+        dispatch(dst->P, [&](auto cfg) { merge_direct<decltype(cfg)>(dst, self->res, peer ? copy : other->res); });
+        collect_events(dst);
+        CBLX_HIP(hipStreamSynchronize(dst->stream));
+        if (peer) {  // (as in cblx_merge_assign: the merge sorted other's Vec buckets in the copy)
+            Resident& o = other->res;
+            CBLX_HIP(hipMemcpyPeerAsync(o.a_lo.get(), other->device, copy.a_lo.get(), dst->device, o.a_lo.n * sizeof(u64), dst->stream));
+            if (o.a_hi.get()) CBLX_HIP(hipMemcpyPeerAsync(o.a_hi.get(), other->device, copy.a_hi.get(), dst->device, o.a_hi.n * sizeof(u64), dst->stream));
+            CBLX_HIP(hipStreamSynchronize(dst->stream));
+        }
+    });
+}
 int cblx_merge_assign(cblx_ctx* self, cblx_ctx* other) {
     return guard(self, [&] {
         if (!other) throw Error(CBLX_EINVAL, "null argument");
@@ -881,7 +939,7 @@ int cblx_merge_assign(cblx_ctx* self, cblx_ctx* other) {
             self->res = std::move(copy);
             return;
         }
-        dispatch(self->P, [&](auto cfg) { merge_direct<decltype(cfg)>(self, peer ? copy : other->res); });
+        dispatch(self->P, [&](auto cfg) { merge_direct<decltype(cfg)>(self, self->res, peer ? copy : other->res); });
         collect_events(self);
         CBLX_HIP(hipStreamSynchronize(self->stream));
         if (peer) {
@@ -1140,7 +1198,14 @@ int cblx_stage_times(cblx_ctx* c, const char** names, double* ms, uint64_t* laun
     });
 }
 int cblx_stage_times_reset(cblx_ctx* c) {
-    return guard(c, [&] { collect_events(c); for (auto& s : c->stages) { s.ms = 0; s.launches = 0; } });
+    return guard(c, [&] { collect_events(c); for (auto& s : c->stages) { s.ms = 0; s.launches = 0; s.units = 0; } });
+}
+int cblx_stage_units(cblx_ctx* c, uint64_t* units, uint32_t cap, uint32_t* n) {
+    return guard(c, [&] {
+        u32 k = 0;
+        for (; k < ST_N && k < cap; ++k) if (units) units[k] = c->stages[k].units;
+        if (n) *n = k;
+    });
 }
 int cblx_kmers_inserted(cblx_ctx* c, uint64_t* out) { if (!c || !out) return CBLX_EINVAL; *out = c->kmers_inserted; return CBLX_OK; }
 int cblx_fine_builds(cblx_ctx* c, uint64_t* out) { if (!c || !out) return CBLX_EINVAL; *out = c->fine_builds; return CBLX_OK; }

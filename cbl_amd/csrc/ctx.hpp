@@ -113,7 +113,7 @@ struct Resident {
     DirView view() const { return DirView{bv.get(), rank_dir.get(), cnt.get(), kind.get(), start.get(), nb}; }
 };
 
-struct Stage { const char* name; double ms = 0; u64 launches = 0; };
+struct Stage { const char* name; double ms = 0; u64 launches = 0; u64 units = 0; /* words the stage's kernels were given, where the pipeline counts them (`|=`: per bucket class) */ };
 enum { ST_CHUNKS, ST_ENCODE, ST_HIST, ST_SCAN, ST_SCATTER, ST_DIR, ST_BSMALL, ST_BMED, ST_BHUGE, ST_EXPAND, ST_BBIG, ST_N };
 const char* kStageNames[ST_N] = {"chunks", "encode", "radix_hist", "radix_scan", "radix_scatter", "directory",
                                  "bucket_small", "bucket_medium", "bucket_huge", "merge_gather", "bucket_big"};

@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void k_merge_gather_list(const BDesc* __restri
 static const int CLS_UNION = CLS_S16;  // `self |= other` only (its classification has no small classes): Trie |= Trie by merge path (k_bucket_union)
 __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify_merge(u64 nb, u32 med_max_threads, const u64* __restrict__ raw_start, const u32* __restrict__ m_cs,
                                  const u8* __restrict__ m_skind, const u8* __restrict__ m_okind, u32* __restrict__ out_count,
-                                 u8* __restrict__ out_kind, BDesc* __restrict__ lists, u32* __restrict__ list_n, bool union_path = false) {
+                                 u8* __restrict__ out_kind, BDesc* __restrict__ lists, u32* __restrict__ list_n, bool union_path = false,
+                                 unsigned long long* __restrict__ cls_words = nullptr /* profiling: [CLS_N + 1] words per class, [CLS_N] = one-sided */) {
     u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     int cls = -1;
     u64 c = 0;
@@ -317,6 +318,13 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify_merge(u64 nb, u32
     }
     const u32 slot = block_append<CLASSIFY_THREADS, CLS_N>(cls, list_n);
     if (cls >= 0) lists[(u64)cls * nb + slot] = BDesc{raw_start[r], (u32)c | (ks == KIND_TRIE ? BDESC_TRIE : 0u), (u32)r};
+    if (cls_words) {  // (profiling only: one wave reduction and one atomic per class and wave)
+#pragma unroll
+        for (int k = -1; k < CLS_N; ++k) {
+            const u64 s = wave_reduce_sum(cls == k && r < nb ? c : 0ull);
+            if ((threadIdx.x & 63) == 0 && s) atomicAdd(&cls_words[k < 0 ? CLS_N : k], (unsigned long long)s);
+        }
+    }
 }
 
 // ---- Trie |= Trie: the union of two ASCENDING lists is a merge, not a sort (/root/reference/src/trievec/set_ops.rs:43-71 merges two

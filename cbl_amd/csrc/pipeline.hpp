@@ -418,6 +418,13 @@ __global__ void k_sum_bdesc_len(const BDesc* __restrict__ list, u32 n, u64* __re
     s = wave_reduce_sum(s);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd((unsigned long long*)out, (unsigned long long)s);
 }
+// (profiling) sum of the final counts of the buckets of a list
+__global__ void k_sum_list_counts(const BDesc* __restrict__ list, u32 n, const u32* __restrict__ cnt, u64* __restrict__ out) {
+    u64 s = 0;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += cnt[list[i].r];
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd((unsigned long long*)out, (unsigned long long)s);
+}
 // runs of 4097 .. BIG_MAX words (kernels_bucket.hpp: k_big_*): one more partition pass on the top suffix bits with the runs as
 // segments, out of the arena into a twin buffer at the same positions; sub-ranges sorted + deduplicated in place there by
 // k_bucket_msd; what cannot be finished that way takes the general kernel on the (untouched) arena run. The finished runs stay
@@ -1334,11 +1341,11 @@ template <typename C> void insert_sorted_batches(cblx_ctx* c, const cblx_batch_v
 }
 
 // ---- `self |= other`, both resident on this device (src/cbl.rs:433-449 -> src/wordset/set_ops.rs:123-157) ---------
-template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
+// `s`: self's index (c->res for `c |= o`; another context's for cblx_merge_from, which leaves it untouched); the result becomes c->res
+template <typename C> void merge_direct(cblx_ctx* c, const Resident& s, const Resident& o) {
     typedef typename C::HiT HiT;
     constexpr bool WS = C::WS;
     const Consts& P = c->P;
-    const Resident& s = c->res;
     const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
     Resident nr;
     Buf<u32> raw, m_cs;
@@ -1395,10 +1402,15 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
     Buf<BDesc> lists(c->pool, (size_t)CLS_N * std::max<u64>(nb, 1));
     Buf<u32> list_n(c->pool, CLS_N);
     CBLX_HIP(hipMemsetAsync(list_n.get(), 0, CLS_N * 4, c->stream));
+    const bool prof = (c->flags & CBLX_FLAG_PROFILE) != 0;
+    Buf<unsigned long long> cls_words;
+    if (prof) { cls_words = Buf<unsigned long long>(c->pool, CLS_N + 2); CBLX_HIP(hipMemsetAsync(cls_words.get(), 0, (CLS_N + 2) * 8, c->stream)); }
     hipLaunchKernelGGL(k_classify_merge, grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, WS ? 512u : 1024u, nr.start.get(), m_cs.get(), m_skind.get(), m_okind.get(),
-                       nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get(), union_path);
+                       nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get(), union_path, cls_words.get());
     CBLX_HIP(hipGetLastError());
     std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
+    std::vector<unsigned long long> cw;
+    if (prof) cw = d2h_vec<unsigned long long>(c, cls_words.get(), CLS_N + 1);
     const MergeArgs ma{m_cs.get(), m_ostart.get(), m_okind.get(), o.a_lo.get(), o.a_hi.get()};  // (kernels that work on the gathered run)
     MergeArgs ma_msd = ma;                                                                       // (the counting-sort classes: in place)
     if (direct) { ma_msd.s_lo = s.a_lo.get(); ma_msd.s_hi = s.a_hi.get(); ma_msd.sstart = m_sstart.get(); }
@@ -1470,6 +1482,26 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& o) {
         CBLX_HIP(hipMemsetAsync(total.get(), 0, 8, c->stream));
         hipLaunchKernelGGL(k_sum_u32, dim3((unsigned)std::min<u64>(2048, std::max<u64>(1, ceil_div(nb, 256)))), dim3(256), 0, c->stream, nr.cnt.get(), nb, total.get());
         nr.count = d2h<u64>(c, total.get());
+    }
+    if (prof) {
+        // words every stage's kernels were given (cblx_stage_units): the gather copies the one-sided buckets and the both-sided ones their
+        // kernel does not read in place; the unions are priced on what they WRITE (2 BYTES read + BYTES written per output)
+        u64 msd = 0, gathered = cw[CLS_N];
+        for (int cls : {CLS_M16, CLS_M64, CLS_M128, CLS_M256, CLS_M512}) msd += cw[cls];
+        if (!direct) gathered += msd;
+        gathered += cw[CLS_M1024] + cw[CLS_HUGE] + cw[CLS_BIG];
+        c->stages[ST_EXPAND].units += gathered;
+        c->stages[ST_BMED].units += msd + cw[CLS_M1024];
+        c->stages[ST_BHUGE].units += cw[CLS_HUGE];
+        u64 uni_out = 0;
+        if (ln[CLS_UNION]) {
+            Buf<u64> tot(c->pool, 1);
+            CBLX_HIP(hipMemsetAsync(tot.get(), 0, 8, c->stream));
+            hipLaunchKernelGGL(k_sum_list_counts, dim3((unsigned)std::min<u64>(1024, ceil_div(ln[CLS_UNION], 256))), dim3(256), 0, c->stream, lists.get() + (size_t)CLS_UNION * nb, ln[CLS_UNION],
+                               (const u32*)nr.cnt.get(), tot.get());
+            uni_out = d2h<u64>(c, tot.get());
+        }
+        c->stages[ST_BBIG].units += uni_out + cw[CLS_BIG];
     }
     c->res = std::move(nr);
 }

@@ -282,6 +282,11 @@ int cblx_load_from_file(cblx_ctx* ctx, const char* path);
 
 /* `self |= other` (src/cbl.rs:433-449 -> src/wordset/set_ops.rs:123-157). */
 int cblx_merge_assign(cblx_ctx* self, cblx_ctx* other);
+/* dst = what `self |= other` would leave in self, with self itself untouched (and other exactly as `|=` leaves it: its Vec buckets that
+ * meet a bucket of self sorted). No reference counterpart as a call — it is `dst = self.clone(); dst |= other`
+ * (/root/reference/src/cbl.rs:433-449) without the copy: the device merge writes a new arena anyway. dst's previous content is dropped;
+ * dst, self and other are three different contexts of equal K / PREFIX_BITS / canonical, dst and self on the same device. */
+int cblx_merge_from(cblx_ctx* dst, cblx_ctx* self, cblx_ctx* other);
 
 /* Walk the resident buckets in ascending prefix order (lets a Rust shim rebuild a WordSet, and tests
  * compare bucket contents): kind 0 = Vec (stored = first-occurrence order), 1 = Trie (ascending).
@@ -343,6 +348,11 @@ int cblx_get_consts(const cblx_ctx* ctx, cblx_consts* out);
  * CBLX_FLAG_PROFILE. names[i] points to static storage. Returns the number of stages in *n (<= cap). */
 int cblx_stage_times(cblx_ctx* ctx, const char** names, double* ms, uint64_t* launches, uint32_t cap, uint32_t* n);
 int cblx_stage_times_reset(cblx_ctx* ctx);
+/* Words the kernels of every stage were given since the last reset, in the order of cblx_stage_times, where the pipeline counts them
+ * (CBLX_FLAG_PROFILE; today: `self |= other`, whose bucket classes split the words between the stages — merge_gather: the words of the
+ * one-sided buckets it copies, bucket_medium: the words of both-sided buckets with a Vec side, bucket_big: the OUTPUT words of the
+ * Trie |= Trie unions, bucket_huge: the rest). 0 = not counted: the caller prices the stage on the whole batch. */
+int cblx_stage_units(cblx_ctx* ctx, uint64_t* units, uint32_t cap, uint32_t* n);
 /* k-mers (words) consumed by insert calls since creation — the numerator of the throughput metric. */
 int cblx_kmers_inserted(cblx_ctx* ctx, uint64_t* out);
 /* Batches this ctx built through the FINE-bins route (PREFIX_BITS > 24, empty index, a batch of CBLX_FINE_MIN k-mers or more — default

@@ -262,6 +262,8 @@ extern "C" {
     pub fn cblx_load_from_file(ctx: *mut cblx_ctx, path: *const c_char) -> c_int;
 
     pub fn cblx_merge_assign(this: *mut cblx_ctx, other: *mut cblx_ctx) -> c_int;
+    pub fn cblx_merge_from(dst: *mut cblx_ctx, this: *mut cblx_ctx, other: *mut cblx_ctx) -> c_int;
+    pub fn cblx_stage_units(ctx: *mut cblx_ctx, units: *mut u64, cap: u32, n: *mut u32) -> c_int;
 
     pub fn cblx_export_buckets(ctx: *mut cblx_ctx, cb: cblx_bucket_cb, user: *mut c_void) -> c_int;
 

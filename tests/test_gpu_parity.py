@@ -617,6 +617,47 @@ def test_merge_matches_oracle():
         _check_index(g1, o1)
 
 
+@pytest.mark.parametrize("peer", ["0", "1"])
+def test_merge_from_is_clone_then_ior_without_the_copy(peer, monkeypatch):
+    """cblx_merge_from(dst, a, b): dst = what `a |= b` leaves in a, a untouched, b as `|=` leaves it (its Vecs that met a bucket of a sorted) —
+    the bench's merge step. Also with an empty side, on top of a dst that held something else, through the peer-copy path, and the words
+    the stages were given add up (cblx_stage_units: what the bench prices the merge kernels on)."""
+    _need_gpu()
+    monkeypatch.setenv("CBLX_FORCE_PEER_COPY", peer)
+    rng = random.Random(23)
+    for k, pb, n, canonical in ((31, 24, 20000, False), (11, 8, 60000, False), (13, 10, 150000, True), (59, 28, 30000, True), (31, 10, 1200000, False)):
+        s1, s2 = _rand_seq(rng, n), _rand_seq(rng, n // 2) + _rand_seq(rng, 64)
+        if n >= 100000:
+            s2 = s2 + s1[n // 3: n // 3 + n // 4]
+        a, b = cbl_amd.CBL(k, pb, canonical=canonical), cbl_amd.CBL(k, pb, canonical=canonical)
+        oa, ob = Oracle(k, pb, canonical), Oracle(k, pb, canonical)
+        a.insert_seq(s1), oa.insert_seq(s1)
+        b.insert_seq(s2), ob.insert_seq(s2)
+        a_before = a.serialize()
+        w = cbl_amd.CBL(k, pb, canonical=canonical, profile=True)
+        w.insert_seq(_rand_seq(rng, 500))  # dropped by merge_from
+        w.stage_times_reset()
+        w.merge_from(a, b)
+        oa.merge(ob)
+        _check_index(w, oa)
+        _check_index(b, ob)
+        assert a.serialize() == a_before
+        assert w.validate(strict=False) == 0
+        un = w.stage_units()
+        assert sum(un.values()) > 0 and un["merge_gather"] + un["bucket_medium"] + un["bucket_huge"] <= a.count() + b.count()
+        w.merge_from(a, b)  # again: b's Vecs are sorted now, the result is the same
+        _check_index(w, oa)
+        e = cbl_amd.CBL(k, pb, canonical=canonical)
+        w.merge_from(e, b)  # an empty self: every bucket of b cloned as stored
+        assert w.serialize() == b.serialize()
+        w.merge_from(a, e)
+        assert w.serialize() == a_before
+        with pytest.raises(cbl_amd.CblxError):
+            w.merge_from(w, b)
+        for x in (a, b, w, e):
+            x.close()
+
+
 def test_merge_through_the_peer_copy_path(monkeypatch):
     """`|=` of indexes on different GPUs copies other's resident index over the fabric (hipMemcpyPeer) and merges on the
     device; CBLX_FORCE_PEER_COPY=1 takes that path on one GPU. Same bytes as the oracle for self and other, quirks included,

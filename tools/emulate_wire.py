@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--taper", default="0.5,0.8,1", help="cumulative fractions of the grouped runs' slices instead of equal ones, e.g. 0.5,0.8,1 (the number of values selects the runs with that many slices)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-ungrouped", action="store_true", help="skip the ungrouped receiver's runs")
+    ap.add_argument("--protocol", choices=["bins", "sorted"], default="bins", help="what crosses the links (sorted: full partition on the sender, packed suffixes; always ungrouped)")
     ap.add_argument("--no-direct", action="store_true", help="skip the one-GPU build of the same reads")
     a = ap.parse_args()
     if a.taper:
@@ -68,11 +69,15 @@ def main():
     bounds = np.zeros(W - 1, dtype=np.uint32)
     have_bounds = False
     modes = [("grouped", int(x), int(y)) for x in a.groups.split(",") for y in a.grouped_slices.split(",")] + ([] if a.no_ungrouped else [("ungrouped", 1, a.slices)])
+    if a.protocol == "sorted":
+        modes = [("sorted", 1, a.slices)]
+    out["protocol"] = a.protocol
     for mode, groups, slices in modes:
         store = 1000 + groups * 16 + slices
         for r in range(1, W):  # the senders: what each would send rank 0
             rb, ro = synth.reads_torch(42, nr, L, first_read=r * nr, device="cuda")
             cm = cbl_amd.Comm.sim(r, W, store)
+            cm.set_protocol(a.protocol)
             cm.set_recv_groups(groups)
             w = cbl_amd.CBL(k, pb)
             have_bounds = w.sharded_insert_seqs_device(cm, rb, ro, nr, cuts_of(nr, slices), bounds, have_bounds)
@@ -81,6 +86,7 @@ def main():
             torch.cuda.empty_cache()
         for gbps in rates:
             cm = cbl_amd.Comm.sim(0, W, store, gbps)
+            cm.set_protocol(a.protocol)
             cm.set_recv_groups(groups)
             w = cbl_amd.CBL(k, pb, profile=True)
             ts = []
