@@ -132,8 +132,9 @@ def parse_args(argv=None):
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--canonical", action="store_true")
-    ap.add_argument("--protocol", choices=["bins", "sorted", "words"], default=None,
-                    help="N > 1: what crosses the links. native transport: bins (default) or sorted; torch transport: sorted (default) or words")
+    ap.add_argument("--protocol", choices=["auto", "bins", "sorted", "words"], default=None,
+                    help="N > 1: what crosses the links. native transport: auto (default: the library's choice — sorted on 2 - 4 ranks, where one link per pair "
+                         "of GPUs bounds the job, bins otherwise), bins or sorted; torch transport: sorted (default) or words")
     ap.add_argument("--slices", type=int, default=None,
                     help="N > 1: slices per rank and step. Default 3 for the native bins protocol, 50 / 30 / 20 % of the reads (its grouped receiver sends "
                          "group-major after the rank's whole first pass; the first group's share of slices 0 and 1 crosses under the next slice's kernels, only "
@@ -159,13 +160,15 @@ def parse_args(argv=None):
     if args.config is None:
         args.config = "cfg2" if args.gpus == 1 else "cfg3"
     if args.protocol is None:
-        args.protocol = "bins" if args.transport == "native" else "sorted"
+        args.protocol = "auto" if args.transport == "native" else "sorted"
+    # what "auto" resolves to inside the library (cblx.h: CBLX_PROTO_AUTO; restated here because the slice schedule follows it)
+    args.protocol_resolved = ("sorted" if 2 <= args.gpus <= 4 else "bins") if args.protocol == "auto" else args.protocol
     cfg = CONFIGS[args.config]
     for name in ("k", "prefix_bits", "reads", "read_len"):
         if getattr(args, name) is None:
             setattr(args, name, cfg[name])
     if args.slices is None:
-        args.slices = 3 if (args.transport == "native" and args.protocol == "bins" and not args.force_sharded) else 4
+        args.slices = 3 if (args.transport == "native" and args.protocol_resolved == "bins" and not args.force_sharded) else 4
     args.kind = cfg["kind"]
     args.genome = cfg.get("genome", 0)
     if args.cpu_sample_reads is None:  # the oracle slows down with PREFIX_BITS (2^28-bit Fenwick bitvector) and word width
@@ -535,7 +538,9 @@ def main():
                 transport = "libcblx sharded insert on RCCL (ncclSend / ncclRecv groups on a side stream)"
         if comm is not None and args.recv_groups:
             comm.set_recv_groups(args.recv_groups)
-        grouped = comm is not None and args.protocol == "bins" and args.slices == len(sharded.ShardedBuilder.GROUPED_WEIGHTS) and not args.force_sharded
+        # the tapered slices belong to the GROUPED receiver's schedule: not to the ungrouped one (--recv-groups 1), not to "sorted"
+        grouped = (comm is not None and args.protocol_resolved == "bins" and args.recv_groups != 1 and args.slices == len(sharded.ShardedBuilder.GROUPED_WEIGHTS)
+                   and not args.force_sharded)
         engine = sharded.ShardedBuilder(cbl, dist, slices=args.slices, protocol=args.protocol, comm=comm,
                                         slice_weights=sharded.ShardedBuilder.GROUPED_WEIGHTS if grouped else None) if dist is not None else None
 
@@ -706,6 +711,13 @@ def main():
         d_dt = time.perf_counter() - t1
         d_stages = cbl.stage_times()
         sh_ms, di_ms = dt / args.steps * 1e3, d_dt / args.steps * 1e3
+        if world > 1:
+            # the denominator of a scaling figure: THIS configuration on one GPU (rank 0 building its own share directly, on the same box,
+            # right after the timed steps) — the driver's N = 1 line is another configuration (cfg 2)
+            one = kmers_per_rank / (d_dt / args.steps)
+            extra["one_gpu_same_config"] = {"ms_per_step": round(di_ms, 3), "value": round(one, 1), "unit": "k-mers/s",
+                                            "what": f"rank 0's {NR} reads through cblx_insert_seqs_device on its own GPU, no exchange, {args.steps} steps after the timed region"}
+            extra["scaling_vs_one_gpu_same_config"] = round(value / one, 3)
         extra["sharded_overhead"] = {
             "direct_ms": round(di_ms, 3), "sharded_ms": round(sh_ms, 3), "ratio": round(sh_ms / di_ms, 4),
             "direct_stage_ms": {n: round(ms / args.steps, 3) for n, (ms, _) in d_stages.items() if ms > 0},
@@ -757,7 +769,10 @@ def main():
         sent = [p[0] // args.steps for p in parts]
         recv = [p[1] // args.steps for p in parts]
         peers = max(world - 1, 1)
-        exchange = {"world_size": dist.get_world_size(), "transport": transport, "protocol": args.protocol,
+        exchange = {"world_size": dist.get_world_size(), "transport": transport,
+                    # what crossed the links: the library's own report where it chose ("auto": sorted on 2 - 4 ranks, bins otherwise)
+                    "protocol": (comm.protocol_used() if (args.kind == "build" and comm is not None) else args.protocol_resolved), "protocol_asked": args.protocol,
+                    "slice_weights": (list(sharded.ShardedBuilder.GROUPED_WEIGHTS) if (args.kind == "build" and grouped) else None),
                     # groups rank 0's receiver worked its range off in while the later ones were still on the wire (0: the ungrouped
                     # receiver — everything waits for the last record)
                     "recv_groups_used": (comm.groups_used() if (args.kind == "build" and comm is not None) else None),
@@ -846,7 +861,7 @@ def main():
             workload = (f"{args.config}: K={K} ({wb}-bit word) PREFIX_BITS={PB} {NR}x{L}bp reads per GPU, "
                         + (f"{NR * L // args.genome}x coverage of a {args.genome} bp genome, " if args.genome else "")
                         + f"{'canonical' if args.canonical else 'non-canonical'}, build from empty index")
-            par = "1 GPU" if world == 1 else f"{world} GPUs: read-sharded encode + partition, prefix-range exchange ({args.protocol} protocol), per-range bucket insert"
+            par = "1 GPU" if world == 1 else f"{world} GPUs: read-sharded encode + partition, prefix-range exchange ({args.protocol_resolved} protocol), per-range bucket insert"
         else:
             workload = (f"merge (cfg 5 per-GPU share): K={K} ({wb}-bit word) PREFIX_BITS={PB}, A |= B with A, B = indexes of {NR}x{L}bp reads per GPU each "
                         f"(seeds 42 / 43); a step = " + ("device copy of A into a work index + the merge" if args.merge_clone or world > 1 else "cblx_merge_from(work, A, B): work = A | B as `A |= B` would leave A, A untouched (no copy)") + "; value = k-mers of B merged per second")

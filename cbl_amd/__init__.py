@@ -112,6 +112,7 @@ SIGNATURES = {
     "cblx_comm_set_recv_groups": (C.c_int, [C.c_void_p, C.c_uint32]),
     "cblx_comm_groups_used": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "cblx_comm_groups_fine": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "cblx_comm_protocol_used": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "cblx_fine_builds": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "cblx_sharded_insert_seqs_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
                                                   C.POINTER(C.c_int)]),
@@ -310,11 +311,24 @@ class Comm:
     def sim_store_free(store_id: int):
         lib().cblx_sim_store_free(store_id)
 
-    PROTOCOLS = {"sorted": 0, "bins": 1}  # CBLX_PROTO_SORTED / CBLX_PROTO_BINS (include/cblx.h)
+    PROTOCOLS = {"sorted": 0, "bins": 1, "auto": 2}  # CBLX_PROTO_SORTED / CBLX_PROTO_BINS / CBLX_PROTO_AUTO (include/cblx.h)
+
+    @staticmethod
+    def auto_protocol(world: int) -> str:
+        """What "auto" resolves to (the library's rule, restated for callers that shape their slices by it): "sorted" on 2 - 4 ranks
+        (one link per pair of GPUs bounds the job), "bins" otherwise."""
+        return "sorted" if 2 <= world <= 4 else "bins"
+
+    def protocol_used(self) -> str:
+        """What the last sharded insert of this rank ran on ("auto" resolved; "bins" falls back to "sorted" at PREFIX_BITS <= 8)."""
+        v = C.c_uint32(0)
+        self._L.cblx_comm_protocol_used(self._h, C.byref(v))
+        return {0: "sorted", 1: "bins"}[v.value]
 
     def set_protocol(self, name: str):
-        """What crosses the links in sharded_insert_seqs_device: "bins" (default; exchange between the first and the second
-        partition pass) or "sorted" (full partition on the sender, packed suffixes on the wire). The same on every rank."""
+        """What crosses the links in sharded_insert_seqs_device: "bins" (exchange between the first and the second partition pass),
+        "sorted" (full partition on the sender, packed suffixes on the wire) or "auto" (default: sorted on 2 - 4 ranks, bins
+        otherwise). The same on every rank."""
         rc = self._L.cblx_comm_set_protocol(self._h, self.PROTOCOLS[name])
         if rc != OK:
             raise CblxError(rc, "cblx_comm_set_protocol")

@@ -570,8 +570,13 @@ int cblx_comm_stats(cblx_comm* cm, cblx_exchange_stats* out, int reset) {
     return CBLX_OK;
 }
 int cblx_comm_set_protocol(cblx_comm* cm, uint32_t protocol) {
-    if (!cm || (protocol != CBLX_PROTO_SORTED && protocol != CBLX_PROTO_BINS)) return CBLX_EINVAL;
+    if (!cm || (protocol != CBLX_PROTO_SORTED && protocol != CBLX_PROTO_BINS && protocol != CBLX_PROTO_AUTO)) return CBLX_EINVAL;
     cm->protocol = protocol;
+    return CBLX_OK;
+}
+int cblx_comm_protocol_used(const cblx_comm* cm, uint32_t* out) {
+    if (!cm || !out) return CBLX_EINVAL;
+    *out = cm->protocol_used;
     return CBLX_OK;
 }
 int cblx_comm_set_recv_groups(cblx_comm* cm, uint32_t groups) {

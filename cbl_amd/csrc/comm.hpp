@@ -353,7 +353,8 @@ struct SimTransport : Transport {
 struct cblx_comm {
     std::unique_ptr<Transport> t;
     int device = 0;
-    u32 protocol = CBLX_PROTO_BINS;
+    u32 protocol = CBLX_PROTO_AUTO;
+    u32 protocol_used = CBLX_PROTO_BINS;  // what the last sharded insert resolved AUTO to
     std::string err;
     // grouped receiver (sharded_insert_grouped): groups per rank asked for (0: CBLX_RECV_GROUPS or the default), the group cuts chosen
     // together with the bounds they refine, and how many groups the last call worked through (0: it took the ungrouped path)
@@ -1193,7 +1194,12 @@ void sharded_insert(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_
     }
     cm->groups_used = 0;
     cm->groups_fine = 0;
-    if (cm->protocol == CBLX_PROTO_BINS && bins_protocol_fits(c->P, bounds, T.world)) {
+    // AUTO: between 2 and 4 ranks every pair of GPUs shares one link and its bytes bound the job — "sorted" moves a third fewer
+    // (rehearsed: profiles/r05_wire_emulated.md); from 5 ranks on the receiver's kernels are the bound and "bins" adds no pass
+    u32 proto = cm->protocol == CBLX_PROTO_AUTO ? ((T.world >= 2 && T.world <= 4) ? CBLX_PROTO_SORTED : CBLX_PROTO_BINS) : cm->protocol;
+    if (proto == CBLX_PROTO_BINS && !bins_protocol_fits(c->P, bounds, T.world)) proto = CBLX_PROTO_SORTED;
+    cm->protocol_used = proto;
+    if (proto == CBLX_PROTO_BINS) {
         if (sharded_insert_grouped<C>(c, cm, d_bases, d_offsets, n, cuts, nslices, bounds)) return;
         sharded_insert_bins<C>(c, T, ascii_view(d_bases), d_offsets, n, cuts, nslices, bounds, [](u32) {});
     }

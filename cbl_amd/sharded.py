@@ -264,9 +264,9 @@ class ShardedBuilder(_Wire):
         self.cbl = cbl
         self.engine = engine or GpuEngine(cbl)
         if protocol is None:
-            protocol = "bins" if comm is not None else "sorted"
-        if protocol not in (("sorted", "bins") if comm is not None else ("sorted", "words")):
-            raise ValueError("protocol must be 'sorted' or 'bins' with a native communicator, 'sorted' or 'words' without")
+            protocol = "auto" if comm is not None else "sorted"
+        if protocol not in (("sorted", "bins", "auto") if comm is not None else ("sorted", "words")):
+            raise ValueError("protocol must be 'sorted', 'bins' or 'auto' with a native communicator, 'sorted' or 'words' without")
         self.protocol = protocol if (comm is not None or hasattr(self.engine, "sorted_batch_begin")) else "words"
         self.comm = comm
         if comm is not None:

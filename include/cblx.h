@@ -222,17 +222,22 @@ const char* cblx_comm_last_error(const cblx_comm* comm);
 typedef struct cblx_exchange_stats { uint64_t sent_bytes, recv_bytes, messages; } cblx_exchange_stats; /* own runs excluded */
 int cblx_comm_stats(cblx_comm* comm, cblx_exchange_stats* out, int reset);
 /* What crosses the links in cblx_sharded_insert_seqs_device (every rank of a job sets the same):
- *   CBLX_PROTO_BINS (default): the exchange sits between the first and the second partition pass. The sender runs KRN-1 and
+ *   CBLX_PROTO_BINS: the exchange sits between the first and the second partition pass. The sender runs KRN-1 and
  *     the first pass on bins that refine that pass's digit by the destination rank; 8-byte records (16 for words that keep
  *     a 64-bit hi part) + 1 digit byte per word cross the links, the receiver runs the remaining passes and the bucket
  *     kernels on what arrived. No pass is added to the one-GPU pipeline and nothing is copied: the choice when the kernels
  *     are the bound (8 GPUs). Needs PREFIX_BITS >= 9, else SORTED is used.
  *   CBLX_PROTO_SORTED: the sender partitions completely; non-empty prefixes, counts and the suffixes packed to
  *     cblx_consts.bytes cross the links (6.1 B per word at K = 31 / PREFIX_BITS = 24), the receiver merges the batches run
- *     by run (one more pass over the words): the choice when the links are the bound (2-4 GPUs). */
+ *     by run (one more pass over the words): the choice when the links are the bound (2-4 GPUs).
+ *   CBLX_PROTO_AUTO (what a new communicator is set to): SORTED on 2 - 4 ranks, BINS otherwise. Between 2 - 4 GPUs every pair shares ONE link
+ *     and the bytes on it bound the job; rehearsed against a paced wire (profiles/r05_wire_emulated.md, cfg 3, 55 GB/s per link): 2 ranks
+ *     99 ms SORTED / 138 ms BINS, 4 ranks 69 / 76 ms, 8 ranks BINS 48 ms. cblx_comm_protocol_used: what the last sharded insert ran on. */
 #define CBLX_PROTO_SORTED 0u
 #define CBLX_PROTO_BINS 1u
+#define CBLX_PROTO_AUTO 2u
 int cblx_comm_set_protocol(cblx_comm* comm, uint32_t protocol);
+int cblx_comm_protocol_used(const cblx_comm* comm, uint32_t* out);
 /* The receiver of CBLX_PROTO_BINS in GROUPS (no reference counterpart; same result, another schedule): every rank's prefix range is
  * cut into `groups` parts of about equal sampled mass, the senders' first pass also separates the groups, the data crosses the links
  * group-major, and the receiver runs the remaining passes + bucket kernels of group g while groups g+1.. are still on the wire.

@@ -22,6 +22,7 @@ pub const CBLX_FLAG_PROFILE: u32 = 1;
 pub const CBLX_COMM_ID_BYTES: usize = 128;
 pub const CBLX_PROTO_SORTED: u32 = 0;
 pub const CBLX_PROTO_BINS: u32 = 1;
+pub const CBLX_PROTO_AUTO: u32 = 2;
 
 #[repr(C)]
 pub struct cblx_ctx {
@@ -237,6 +238,7 @@ extern "C" {
     pub fn cblx_comm_set_recv_groups(comm: *mut cblx_comm, groups: u32) -> c_int;
     pub fn cblx_comm_groups_used(comm: *const cblx_comm, out: *mut u32) -> c_int;
     pub fn cblx_comm_groups_fine(comm: *const cblx_comm, out: *mut u32) -> c_int;
+    pub fn cblx_comm_protocol_used(comm: *const cblx_comm, out: *mut u32) -> c_int;
     pub fn cblx_fine_builds(ctx: *mut cblx_ctx, out: *mut u64) -> c_int;
     pub fn cblx_sharded_insert_seqs_device(
         ctx: *mut cblx_ctx,

@@ -35,6 +35,13 @@ def test_two_rank_line_through_the_launcher(config):
         k = 31
         assert out["distinct_kmers_in_index"] <= 2 * 20000 * (150 - k + 1)
         assert all(s > 0 for s in out["exchange"]["sent_bytes_per_rank_step"])
+        # the line carries its own denominator: the same configuration on one GPU (rank 0's share, built directly after the timed steps) ...
+        one = out["one_gpu_same_config"]
+        assert one["value"] > 0 and one["ms_per_step"] > 0 and abs(out["scaling_vs_one_gpu_same_config"] - out["value"] / one["value"]) < 0.01
+        # ... and says what crossed the links: the library's choice at two ranks is "sorted" (one link per pair of GPUs bounds the job)
+        assert out["exchange"]["protocol_asked"] == "auto" and out["exchange"]["protocol"] == "sorted"
+    # an algorithmic rate above the HBM peak is a bookkeeping error (bench.py asserts it too)
+    assert all(r["frac"] is None or r["frac"] <= 1.0 for r in out["roofline"]["kernels"])
 
 
 def test_launcher_reports_a_failing_rank():

@@ -2128,7 +2128,8 @@ def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q, protoco
     (2, 31, 24, False, "bins", 1), (3, 59, 28, True, "bins", 1), (8, 31, 24, False, "bins", 1), (3, 31, 28, True, "bins", 1),  # the ungrouped receiver
     (2, 31, 24, False, "bins", 3), (4, 31, 28, False, "bins", 14), (3, 45, 20, True, "bins", 5), (2, 27, 9, False, "bins", 4),
     (4, 31, 25, True, "bins", 3), (2, 33, 27, False, "bins", 5),  # FINE bins where a 65..72-bit word's bins must imply 21 prefix bits; 16-byte records
-    (2, 31, 24, False, "sorted", 0), (3, 59, 28, True, "sorted", 0), (8, 31, 24, False, "sorted", 0)])
+    (2, 31, 24, False, "sorted", 0), (3, 59, 28, True, "sorted", 0), (8, 31, 24, False, "sorted", 0),
+    (2, 31, 28, False, "auto", 0), (5, 31, 24, True, "auto", 0)])  # the library's choice: "sorted" on 2 - 4 ranks, "bins" from 5 on
 def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canonical, protocol, groups, tmp_path):
     """The C++ orchestration of the multi-GPU build (slices, splitter choice, count exchange, grouped exchange, batch merge)
     with `world` ranks sharing this GPU and the bytes moved by host callbacks over gloo: byte-identical to the one-process
@@ -2160,6 +2161,8 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
     # the grouped receiver (bins protocol, empty index): rank 0 worked its range off in groups; a second batch meets a non-empty index
     # and takes the ungrouped path; groups = 1 switches it off
     assert used[1] == 0
+    if protocol == "auto":
+        protocol = cbl_amd.Comm.auto_protocol(world)
     if protocol == "sorted" or groups == 1:
         assert used[0] == 0
     elif pb >= 12:  # (a rank whose range is narrower than a few histogram cells gets fewer groups than asked for, down to one)
@@ -2218,6 +2221,7 @@ def test_rehearsal_of_rank_0_on_recorded_senders(world, k, pb, canonical, groups
     for r in list(range(1, world)) + [0, 0]:  # rank 0 twice: a replay can be repeated
         d_b, d_o = synth.reads_torch(5, nr, L, first_read=r * nr, device="cuda")
         cm = cbl_amd.Comm.sim(r, world, store, gbps if r == 0 else 0.0)
+        cm.set_protocol("bins")  # (the default, "auto", is "sorted" up to four ranks)
         cm.set_recv_groups(groups)
         g = cbl_amd.CBL(k, pb, canonical=canonical)
         valid = g.sharded_insert_seqs_device(cm, d_b, d_o, nr, cuts, bounds, valid)
