@@ -931,8 +931,18 @@ __device__ __forceinline__ bool w128_less(const W128& a, const W128& b) { return
 __device__ __forceinline__ bool w128_same_sfx(const W128& a, const W128& b) { return a.hi == b.hi && ((a.lo ^ b.lo) >> 12u) == 0; }
 template <bool WS> __host__ __device__ inline bool msd_takes(u32 SB) { return !WS || SB + 12u <= 128; }  // else: the LDS radix kernel
 
+// The occupancy every instantiation is compiled FOR = what the register allocator can meet (round 5: all of them asked for 7 and 26 of
+// them got 4 - 6 with a warning each, so a register regression in one of them would have gone unnoticed): 16-byte elements (WS) take 4
+// waves per SIMD (5 in the shortest build class that has them), the unpacked 2048- and 4096-slot classes and the packed 4096-slot one
+// 5 - 6, everything else CBLX_MSD_WAVES.
+template <int CAP, bool PACKED, bool WS, bool MERGE> constexpr int msd_waves() {
+    if (WS) return CAP <= 128 ? CBLX_MSD_WAVES : ((CAP <= 512 && !MERGE) ? 5 : 4);
+    if (CAP >= 4096) return (PACKED && !MERGE) ? 6 : 5;
+    if (CAP >= 2048 && !PACKED) return MERGE ? 5 : 6;
+    return CBLX_MSD_WAVES;
+}
 template <int THREADS, int CAP, bool PACKED, bool WS, typename HiT, bool MERGE = false>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CBLX_MSD_WAVES, 8))) void k_bucket_msd(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_waves<CAP, PACKED, WS, MERGE>(), 8))) void k_bucket_msd(const BDesc* __restrict__ list, const u32* __restrict__ list_n,
                                                         u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB,
                                                         u32* __restrict__ out_count, u8* __restrict__ out_kind,
                                                         BDesc* __restrict__ retry, u32* __restrict__ retry_n, MergeArgs mg = MergeArgs{},
