@@ -618,6 +618,7 @@ def main():
     if args.kind == "build":
         count = allreduce_sum(cbl.count())
         stages = cbl.stage_times()  # rank 0's stream, HIP events around every launch group, timed steps only
+        scatter_record_passes = cbl.stage_units().get("radix_scatter", 0)  # records x partition passes over the timed steps (the passes a record takes vary with the route)
         units_alg = kmers_per_rank * args.steps  # k-mers through the kernels of this rank in the timed region
     else:
         count = allreduce_sum(last().count())
@@ -633,6 +634,15 @@ def main():
     kernels = []
     if args.kind == "build":
         stage_units = {}
+        if scatter_record_passes and engine is None:
+            # every record-pass reads and writes a record behind the first pass's layout; the first pass reads KRN-1's wider records; every
+            # pass but a record's last also writes the next pass's digit byte
+            _, _, hi_b, _, _ = word_layout(K, PB)
+            r_in = 8 + hi_b
+            r_out = 8 if hi_b == 1 else r_in
+            alg = dict(alg)
+            alg["radix_scatter"] = (scatter_record_passes * 2 * r_out + units_alg * (r_in - r_out) + max(scatter_record_passes - units_alg, 0)) / units_alg
+            extra["partition_passes_per_record"] = round(scatter_record_passes / units_alg, 3)
     # the bucket kernels split the words between them by run length and (builds) the split is not reported: the whole word count is
     # priced against the slowest of them (at these workloads it holds > 99 % of the words), the others carry no fraction
     bucket_stages = [n for n in ("bucket_medium", "bucket_small", "bucket_big", "bucket_huge") if stages.get(n, (0, 0))[0] > 0]

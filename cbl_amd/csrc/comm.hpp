@@ -731,6 +731,7 @@ void sharded_insert_bins(cblx_ctx* c, Transport& T, const BaseView& d_bases, con
             const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
             const OwnWindow ow{own_a, own_b, a_lo.get() + filled, OHS ? (void*)(a_hi.get() + filled * OHS) : nullptr, a_dig.get() + filled};
             StageTimer t(c, ST_SCATTER);
+            c->stages[ST_SCATTER].units += N;
             hipLaunchKernelGGL((k_radix_scatter<HiT, OutH, DigitBin, true>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, (const u64*)t_lo.get(), (const HiT*)t_hi.get(), tv, fn,
                                (const u32*)colpre.get(), (const u32*)adj.get(), S.lo.get(), (OutH*)S.hi.get(), nextd, S.dig.get(), (u32*)nullptr, 0u, 0u, 0u, (u32*)nullptr, 0u, ow);
             CBLX_HIP(hipGetLastError());
@@ -1023,6 +1024,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
             const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
             const OwnWindow ow{S.own_a, S.own_a + S.own, a_lo.get() + filled, OHS ? (void*)(a_hi.get() + filled * OHS) : nullptr, a_dig.get() + filled};
             StageTimer t(c, ST_SCATTER);
+            c->stages[ST_SCATTER].units += N;
             static const bool plain_single = [] { const char* e = std::getenv("CBLX_FINE_REDIR"); return !(e && e[0] == '1'); }();  // (dev A/B)
             if (single && plain_single)  // one rank: every record is its own, the pass writes the log directly
                 hipLaunchKernelGGL((k_radix_scatter<HiT, OutH, DigitCut, false>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, (const u64*)wk.t_lo.get(), (const HiT*)wk.t_hi.get(), tv, fn,

@@ -204,6 +204,7 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
               hipLaunchKernelGGL(k_tile_table, grid1(nt_max, 256), dim3(256), 0, c->stream, seg_start.get(), seg_first.get(), nt_dev.get(), t_start.get(),
                                  t_count.get(), t_seg.get()); }
             { StageTimer t(c, ST_SCATTER);
+              c->stages[ST_SCATTER].units += N;  // (records through a partition pass: cblx_stage_units — the passes a record takes vary with the route)
               if constexpr (DROP_HI)
                   hipLaunchKernelGGL((k_radix_scatter<HiT, NoHi, DigitBits>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, lo, hi, tv, dfn, colpre.get(),
                                      adj.get(), lo2, (NoHi*)nullptr, nd, ndp);
@@ -253,6 +254,7 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
                     CBLX_HIP(hipMemsetAsync(start_dense.get(), 0xFF, nsuper * 4, c->stream));
                 }
                 { StageTimer t(c, ST_SCATTER);
+                  c->stages[ST_SCATTER].units += N;
                   hipLaunchKernelGGL((k_radix_scatter<H, H, DigitBits>), dim3(xcd_grid(ntm)), dim3(RDX_THREADS), 0, c->stream, lo, hin, tv, dfn, colpre.get(),
                                      adj.get(), lo2, hout, nd, ndp, fused_dir ? sd : (u32*)nullptr, SBs, RB, low_bits, amb.get(), amb_stride,
                                      OwnWindow{0, 0, nullptr, nullptr, nullptr}, (const u64*)nullptr, segp); }
@@ -314,6 +316,7 @@ template <typename C> void partition_and_directory(cblx_ctx* c, Records& rec, u6
         Buf<u64> rank_base(c->pool, nruns + 1);
         if (nruns) {
             StageTimer t(c, ST_SCATTER);
+            c->stages[ST_SCATTER].units += N;
             Buf<SplitRun> lists(c->pool, SPLIT_CLASSES * nruns);
             Buf<u32> list_n(c->pool, SPLIT_CLASSES);
             CBLX_HIP(hipMemsetAsync(list_n.get(), 0, SPLIT_CLASSES * 4, c->stream));

@@ -354,9 +354,11 @@ int cblx_get_consts(const cblx_ctx* ctx, cblx_consts* out);
 int cblx_stage_times(cblx_ctx* ctx, const char** names, double* ms, uint64_t* launches, uint32_t cap, uint32_t* n);
 int cblx_stage_times_reset(cblx_ctx* ctx);
 /* Words the kernels of every stage were given since the last reset, in the order of cblx_stage_times, where the pipeline counts them
- * (CBLX_FLAG_PROFILE; today: `self |= other`, whose bucket classes split the words between the stages — merge_gather: the words of the
- * one-sided buckets it copies, bucket_medium: the words of both-sided buckets with a Vec side, bucket_big: the OUTPUT words of the
- * Trie |= Trie unions, bucket_huge: the rest). 0 = not counted: the caller prices the stage on the whole batch. */
+ * (today: radix_scatter — records through a partition pass, summed over the passes: how many a record takes depends on the route
+ * (PREFIX_BITS > 24: the FINE-bins build sorts most of them in three passes, the rest in four); and, with CBLX_FLAG_PROFILE, `self |= other`,
+ * whose bucket classes split the words between the stages — merge_gather: the words of the one-sided buckets it copies, bucket_medium:
+ * the words of both-sided buckets with a Vec side, bucket_big: the OUTPUT words of the Trie |= Trie unions, bucket_huge: the rest).
+ * 0 = not counted: the caller prices the stage on the whole batch. */
 int cblx_stage_units(cblx_ctx* ctx, uint64_t* units, uint32_t cap, uint32_t* n);
 /* k-mers (words) consumed by insert calls since creation — the numerator of the throughput metric. */
 int cblx_kmers_inserted(cblx_ctx* ctx, uint64_t* out);
