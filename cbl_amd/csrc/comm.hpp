@@ -241,23 +241,34 @@ struct CallbackTransport : Transport {
 struct SimStore {
     struct Buf8 { u8* p = nullptr; u64 n = 0; };
     u32 world = 0;
-    std::vector<std::vector<std::vector<u64>>> a2a;             // [rank][call] -> what the rank sends rank 0
+    u32 target = 0;  // the rank that replays (CBLX_SIM_TARGET when the store is created; 0 = the densest prefix range, W - 1 = the sparse tail)
+    std::vector<std::vector<std::vector<u64>>> a2a;             // [rank][call] -> what the rank sends the target
     std::vector<std::vector<std::vector<Buf8>>> xch;            // [rank][call][item] -> bytes for rank 0
     std::vector<u32> g_bounds, g_cuts;
     bool have_cuts = false;
     ~SimStore() { for (auto& r : xch) for (auto& cl : r) for (auto& b : cl) if (b.p) (void)hipFree(b.p); }
     static std::mutex& mu() { static std::mutex m; return m; }
-    static std::map<u64, std::unique_ptr<SimStore>>& all() { static std::map<u64, std::unique_ptr<SimStore>> m; return m; }
-    static SimStore* get(u64 id, u32 world) {
+    // (shared ownership: a communicator keeps its store alive after cblx_sim_store_free has dropped the name)
+    static std::map<u64, std::shared_ptr<SimStore>>& all() { static std::map<u64, std::shared_ptr<SimStore>> m; return m; }
+    static std::shared_ptr<SimStore> get(u64 id, u32 world) {
         std::lock_guard<std::mutex> g(mu());
-        auto& p = all()[id];
-        if (!p) { p.reset(new SimStore()); p->world = world; p->a2a.resize(world); p->xch.resize(world); }
-        if (p->world != world) throw Error(CBLX_EINVAL, "rehearsal store: created for another world size");
-        return p.get();
+        auto it = all().find(id);
+        if (it != all().end()) {
+            if (it->second->world != world) throw Error(CBLX_EINVAL, "rehearsal store: created for another world size");
+            return it->second;
+        }
+        if (world == 0 || world > CUT_MAX_DEST) throw Error(CBLX_EINVAL, "rehearsal store: world size out of range");
+        std::shared_ptr<SimStore> p(new SimStore());
+        p->world = world; p->a2a.resize(world); p->xch.resize(world);
+        const char* e = std::getenv("CBLX_SIM_TARGET");
+        const u32 t = e ? (u32)std::strtoul(e, nullptr, 10) : 0u;
+        p->target = t < world ? t : 0u;
+        all()[id] = p;
+        return p;
     }
 };
 struct SimTransport : Transport {
-    SimStore* st;
+    std::shared_ptr<SimStore> st;
     double link_gbps;
     size_t n_a2a = 0, n_x = 0;
     hipStream_t ps = nullptr;  // replay: the "wire"
@@ -265,9 +276,9 @@ struct SimTransport : Transport {
     struct Pace { std::chrono::steady_clock::time_point start, done; bool any = false; } pace;
     struct Gate { SimTransport* t; double seconds; bool opens; };
     std::vector<std::unique_ptr<Gate>> gates;
-    SimTransport(SimStore* s, u32 r, u32 w, double gbps) : st(s), link_gbps(gbps) {
+    SimTransport(std::shared_ptr<SimStore> s, u32 r, u32 w, double gbps) : st(std::move(s)), link_gbps(gbps) {
         rank = r; world = w;
-        if (r == 0) {
+        if (r == st->target) {
             CBLX_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
             CBLX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         }
@@ -278,15 +289,17 @@ struct SimTransport : Transport {
     }
     void begin_job() override {
         n_a2a = n_x = 0;
-        if (rank) { st->a2a[rank].clear(); for (auto& cl : st->xch[rank]) for (auto& b : cl) if (b.p) (void)hipFree(b.p); st->xch[rank].clear(); }
+        if (rank != st->target) { st->a2a[rank].clear(); for (auto& cl : st->xch[rank]) for (auto& b : cl) if (b.p) (void)hipFree(b.p); st->xch[rank].clear(); }
         else { if (ps) CBLX_HIP(hipStreamSynchronize(ps)); gates.clear(); pace.any = false; }
     }
     void all_reduce_sum_u64(u64* v, size_t n) override { for (size_t i = 0; i < n; ++i) v[i] *= world; }
     void all_to_all_u64(const u64* send, u64* recv, size_t per) override {
         std::memset(recv, 0, per * world * 8);
         std::memcpy(recv + rank * per, send + rank * per, per * 8);
-        if (rank) { st->a2a[rank].push_back(std::vector<u64>(send, send + per)); return; }  // (what goes to rank 0)
-        for (u32 r = 1; r < world; ++r) {
+        const u32 tg = st->target;
+        if (rank != tg) { st->a2a[rank].push_back(std::vector<u64>(send + (size_t)tg * per, send + (size_t)(tg + 1) * per)); return; }  // (what goes to the target)
+        for (u32 r = 0; r < world; ++r) {
+            if (r == tg) continue;
             if (st->a2a[r].size() <= n_a2a || st->a2a[r][n_a2a].size() != per) throw Error(CBLX_EINVAL, "rehearsal: rank " + std::to_string(r) + " was not recorded with this schedule");
             std::memcpy(recv + r * per, st->a2a[r][n_a2a].data(), per * 8);
         }
@@ -302,13 +315,14 @@ struct SimTransport : Transport {
         std::this_thread::sleep_until(pc.done);
     }
     void items_common(const std::vector<Item>& items, hipStream_t after) {
-        if (rank) {  // record what goes to rank 0
+        const u32 tg = st->target;
+        if (rank != tg) {  // record what goes to the target
             CBLX_HIP(hipStreamSynchronize(after));
             std::vector<SimStore::Buf8> call;
             for (const Item& it : items) {
                 SimStore::Buf8 b;
-                b.n = it.s_len[0];
-                if (b.n) { CBLX_HIP(hipMalloc((void**)&b.p, b.n)); CBLX_HIP(hipMemcpy(b.p, it.src + it.s_off[0], b.n, hipMemcpyDeviceToDevice)); }
+                b.n = it.s_len[tg];
+                if (b.n) { CBLX_HIP(hipMalloc((void**)&b.p, b.n)); CBLX_HIP(hipMemcpy(b.p, it.src + it.s_off[tg], b.n, hipMemcpyDeviceToDevice)); }
                 call.push_back(b);
                 sent_bytes += b.n;
             }
@@ -320,7 +334,8 @@ struct SimTransport : Transport {
         gates.emplace_back(new Gate{this, 0.0, true});
         CBLX_HIP(hipLaunchHostFunc(ps, gate_fn, gates.back().get()));
         u64 worst = 0;
-        for (u32 r = 1; r < world; ++r) {
+        for (u32 r = 0; r < world; ++r) {
+            if (r == tg) continue;
             if (st->xch[r].size() <= n_x || st->xch[r][n_x].size() != items.size()) throw Error(CBLX_EINVAL, "rehearsal: rank " + std::to_string(r) + " was not recorded with this schedule");
             u64 from_r = 0;
             for (size_t i = 0; i < items.size(); ++i) {
@@ -332,7 +347,7 @@ struct SimTransport : Transport {
             recv_bytes += from_r;
             worst = std::max(worst, from_r);
         }
-        for (const Item& it : items) for (u32 r = 1; r < world; ++r) sent_bytes += it.s_len[r];
+        for (const Item& it : items) for (u32 r = 0; r < world; ++r) if (r != tg) sent_bytes += it.s_len[r];
         messages += 2 * (world - 1) * items.size();
         gates.emplace_back(new Gate{this, link_gbps > 0 ? (double)worst / (link_gbps * 1e9) : 0.0, false});
         CBLX_HIP(hipLaunchHostFunc(ps, gate_fn, gates.back().get()));

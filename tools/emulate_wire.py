@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--no-ungrouped", action="store_true", help="skip the ungrouped receiver's runs")
     ap.add_argument("--protocol", choices=["bins", "sorted"], default="bins", help="what crosses the links (sorted: full partition on the sender, packed suffixes; always ungrouped)")
     ap.add_argument("--no-direct", action="store_true", help="skip the one-GPU build of the same reads")
+    ap.add_argument("--rank", type=int, default=0, help="the rank that is rehearsed (CBLX_SIM_TARGET): 0 = the densest prefix range, W - 1 = the sparse tail")
     a = ap.parse_args()
     if a.taper:
         fr = [float(x) for x in a.taper.split(",")]
@@ -51,11 +52,14 @@ def main():
     k, pb, nr, L = CFG[a.config]
     nr = a.reads or nr
     W = a.world
+    tgt = a.rank
+    assert 0 <= tgt < W
+    os.environ["CBLX_SIM_TARGET"] = str(tgt)  # read when a rehearsal store is created
     rates = [float(x) for x in a.wire_gbps.split(",")]
-    out = {"config": a.config, "k": k, "prefix_bits": pb, "reads_per_rank": nr, "read_len": L, "world": W, "kmers_per_rank": nr * (L - k + 1), "runs": []}
+    out = {"config": a.config, "k": k, "prefix_bits": pb, "reads_per_rank": nr, "read_len": L, "world": W, "rank": tgt, "kmers_per_rank": nr * (L - k + 1), "runs": []}
 
     # the one-GPU build of the same share of reads, for reference
-    d_b, d_o = synth.reads_torch(42, nr, L, first_read=0, device="cuda")
+    d_b, d_o = synth.reads_torch(42, nr, L, first_read=tgt * nr, device="cuda")
     if not a.no_direct:
         g = cbl_amd.CBL(k, pb)
         g.insert_seqs_device(d_b, d_o, nr)
@@ -73,8 +77,8 @@ def main():
         modes = [("sorted", 1, a.slices)]
     out["protocol"] = a.protocol
     for mode, groups, slices in modes:
-        store = 1000 + groups * 16 + slices
-        for r in range(1, W):  # the senders: what each would send rank 0
+        store = 1000 + groups * 16 + slices + 100000 * tgt
+        for r in [x for x in range(W) if x != tgt]:  # the senders: what each would send the rehearsed rank
             rb, ro = synth.reads_torch(42, nr, L, first_read=r * nr, device="cuda")
             cm = cbl_amd.Comm.sim(r, W, store)
             cm.set_protocol(a.protocol)
@@ -85,7 +89,7 @@ def main():
             del rb, ro
             torch.cuda.empty_cache()
         for gbps in rates:
-            cm = cbl_amd.Comm.sim(0, W, store, gbps)
+            cm = cbl_amd.Comm.sim(tgt, W, store, gbps)
             cm.set_protocol(a.protocol)
             cm.set_recv_groups(groups)
             w = cbl_amd.CBL(k, pb, profile=True)
