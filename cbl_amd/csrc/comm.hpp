@@ -436,12 +436,32 @@ std::vector<u64> sampled_prefix_hist(cblx_ctx* c, Transport& T, const u8* d_base
     T.all_reduce_sum_u64(hist.data(), hist.size());
     return hist;
 }
+// PREFIX_BITS > 24 (FINE bins, cuts.hpp): the budget of 253 cuts covers about the lowest 214 blocks of 2^16 prefixes at 8 ranks x 4 groups — the
+// ranges below sort 16 bits behind the first pass (two passes), the sparse tail above 24 (three passes, and a directory over a wide window).
+// Rehearsed at cfg 3 (profiles/r05_wire_emulated.md): with equal words per rank, ranks 0 - 6 take 43 - 44 ms without a wire (47 - 50 at 55 GB/s
+// per link) and rank 7 — the tail — 51 (52.5). The quantiles (rank bounds and group cuts) are therefore taken over the histogram with the
+// tail's cells weighted, so that the ranks take equal TIME rather than equal words: at 55 GB/s per link a weight of 1.12 levels rank 0
+// (wire-bound by then) and rank 7 at 48.8 - 48.9 ms (1.20: 48.9 / 47.4, 1.28: 49.4 / 47.4). (A heuristic: the factor is cfg 3's; any
+// bounds are correct, only the balance depends on it. CBLX_FINE_TAIL_WEIGHT overrides it in percent, 100 = off.)
+inline void weigh_tail_for_fine_bins(std::vector<u64>& hist, u32 PB, u32 W, u32 G, u32 hb) {
+    const char* fe = std::getenv("CBLX_FINE_BINS");
+    if (PB <= 24 || PB > 28 || W < 2 || (fe && fe[0] == '0') || hb + FINE_LEVEL < PB) return;  // (cells must not be wider than 2^16 prefixes)
+    const char* we = std::getenv("CBLX_FINE_TAIL_WEIGHT");
+    const u64 pct = we ? std::strtoull(we, nullptr, 10) : 112;
+    if (pct == 100 || pct == 0) return;
+    const u64 forced = (u64)W * G - 1, fixed = 8;  // rank bounds + group cuts, the multiples of 2^lmax
+    if (forced + fixed + 16 >= FINE_MAX_CUTS) return;
+    const u64 x = (FINE_MAX_CUTS - forced - fixed) << FINE_LEVEL;   // where the blocks of 2^16 prefixes end, about
+    const size_t first = (size_t)(x >> (PB - hb));
+    for (size_t i = 0; i < hist.size(); ++i) hist[i] = hist[i] * (i >= first ? pct : 100);
+}
 // first batch only: quantile ranges from the all-reduced, sampled prefix histogram of one slice's words
 template <typename C>
-void choose_bounds_from_slice(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 nseq, u32* bounds, std::vector<u64>* hist_out = nullptr) {
+void choose_bounds_from_slice(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 nseq, u32* bounds, std::vector<u64>* hist_out = nullptr, u32 fine_groups = 0) {
     const Consts& P = c->P;
     const u32 hb = std::min(SPLIT_HIST_BITS, P.PB);
     std::vector<u64> hist = sampled_prefix_hist<C>(c, T, d_bases, d_offsets, nseq);
+    if (fine_groups) weigh_tail_for_fine_bins(hist, P.PB, T.world, fine_groups, hb);  // (the "bins" protocol with its grouped receiver: FINE bins at PREFIX_BITS > 24)
     const std::vector<u32> bb = choose_bounds(hist, T.world, P.PB, hb);
     for (u32 d = 0; d + 1 < T.world; ++d) bounds[d] = bb[d];
     if (hist_out) *hist_out = std::move(hist);
@@ -826,7 +846,8 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     // -- the group cuts that go with these bounds (chosen once per set of bounds: a sampled histogram of the first slice, all-reduced)
     const std::vector<u32> bvec(bounds, bounds + (W - 1));
     if (!single && cm->g_bounds != bvec) {
-        const std::vector<u64> hist = sampled_prefix_hist<C>(c, T, d_bases, d_offsets + cuts[0], cuts[1] - cuts[0]);
+        std::vector<u64> hist = sampled_prefix_hist<C>(c, T, d_bases, d_offsets + cuts[0], cuts[1] - cuts[0]);
+        weigh_tail_for_fine_bins(hist, P.PB, W, G, std::min(SPLIT_HIST_BITS, P.PB));
         cm->g_cuts = choose_group_cuts(hist, bounds, W, G, P.PB);
         cm->g_bounds = bvec;
     }
@@ -1202,7 +1223,9 @@ void sharded_insert(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_
     if (nslices && !*bounds_valid) {
         if (cuts[1] < cuts[0] || cuts[1] > n) throw Error(CBLX_EINVAL, "slice cuts must be ascending and at most n");
         std::vector<u64> hist;
-        choose_bounds_from_slice<C>(c, T, d_bases, d_offsets + cuts[0], cuts[1] - cuts[0], bounds, &hist);
+        const bool want_bins = cm->protocol == CBLX_PROTO_AUTO ? !(T.world >= 2 && T.world <= 4) : cm->protocol == CBLX_PROTO_BINS;
+        const u32 G = recv_groups_wanted(cm);
+        choose_bounds_from_slice<C>(c, T, d_bases, d_offsets + cuts[0], cuts[1] - cuts[0], bounds, &hist, (want_bins && G >= 2) ? G : 0u);
         *bounds_valid = 1;
         if (T.world > 1) {  // the group cuts of the grouped receiver come from the same histogram
             cm->g_cuts = choose_group_cuts(hist, bounds, T.world, recv_groups_wanted(cm), c->P.PB);
