@@ -90,8 +90,9 @@ struct EncHist {
     u32 reg_x = 0, reg_lmax = 0;    // ... or (FINE bins of one rank) cuts at the multiples of 2^16 up to reg_x and of 2^reg_lmax above: arithmetic, no table
     // u32 words of the cut table (the main kernel stages them in LDS: as a gather from global memory the lookup cost it 1 ms of 7.5)
     __device__ __forceinline__ u32 cut_words() const { return cut_ksh != 0xFFFFFFFFu ? 2048u : 2u * (64u + 26u * 32u); }
-    // `t`: the cut table where the caller staged it (null: in global memory)
-    __device__ __forceinline__ u32 digit(u64 lo, u64 hi, const u32* t = nullptr) const {
+    // `lds`: the cut table where the caller staged it in LDS (null: read from global memory). The two sources are read under a uniform
+    // branch each — ONE pointer that may hold either becomes a generic pointer, and its loads FLAT loads: the lookup cost KRN-1 1.4 ms of 7.9
+    __device__ __forceinline__ u32 digit(u64 lo, u64 hi, const u32* lds = nullptr, bool staged = false) const {
         if (nd == 0) return get_bits(lo, hi, shift, nbits);
         const u32 p = get_bits(lo, hi, SB, PB);
         if (reg_x) {
@@ -99,16 +100,25 @@ struct EncHist {
             return v >= 255u ? 255u : (b < 254u ? b : 254u);
         }
         if (cut_tab) {
-            if (!t) t = reinterpret_cast<const u32*>(cut_tab);
             const u32 v = p >> binRB;
-            if (cut_ksh != 0xFFFFFFFFu) {  // FINE bins: low byte = cuts at or below the cell's first prefix, upper bits = offset of the one cut inside the cell
-                const u32 k = p >> cut_ksh, c = t[k < 2048u ? k : 2047u];
-                const u32 b = (c & 255u) + ((p & ((1u << cut_ksh) - 1u)) >= (c >> 8) ? 1u : 0u);
-                return v >= 255u ? 255u : (b < 254u ? b : 254u);
+            const bool fine = cut_ksh != 0xFFFFFFFFu;
+            u32 i0, i1;
+            if (fine) {  // FINE bins: low byte = cuts at or below the cell's first prefix, upper bits = offset of the one cut inside the cell
+                const u32 k = p >> cut_ksh;
+                i0 = i1 = k < 2048u ? k : 2047u;
+            } else {
+                u32 key = p;
+                if (p >= 64u) { const u32 e = 31u - (u32)__builtin_clz(p); key = 64u + ((e - 6u) << 5) + ((p >> (e - 5u)) & 31u); }
+                i0 = 2 * key; i1 = 2 * key + 1;  // {the cut inside the cell (or ~0), cuts at or below its first prefix}
             }
-            u32 key = p;
-            if (p >= 64u) { const u32 e = 31u - (u32)__builtin_clz(p); key = 64u + ((e - 6u) << 5) + ((p >> (e - 5u)) & 31u); }
-            const u32 b = v + t[2 * key + 1] + (p >= t[2 * key] ? 1u : 0u);  // {the cut inside the cell (or ~0), cuts at or below its first prefix}
+            u32 c0, c1;
+            // (explicit address spaces: left to itself the compiler folds the two sources into one generic pointer and reads the table with
+            // FLAT loads inside the k-mer loop, each of them behind the loop's own global stores)
+            typedef const __attribute__((address_space(3))) u32* lds_cptr;
+            typedef const __attribute__((address_space(1))) u32* glb_cptr;
+            if (staged) { lds_cptr L = (lds_cptr)lds; c0 = L[i0]; c1 = L[i1]; }
+            else { glb_cptr g = (glb_cptr)cut_tab; c0 = g[i0]; c1 = g[i1]; }
+            const u32 b = fine ? (c0 & 255u) + ((p & ((1u << cut_ksh) - 1u)) >= (c0 >> 8) ? 1u : 0u) : v + c1 + (p >= c0 ? 1u : 0u);
             return v >= 255u ? 255u : (b < 254u ? b : 254u);
         }
         u32 d = 0;
@@ -357,11 +367,10 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(BaseView B, u64 total_ba
     const u64 win0 = (out_base + kbase) / ENC_HIST_WINDOW;  // first window this tile's outputs fall into
     if (eh.counts)
         for (u32 i = tid; i < ENC_HIST_WINDOWS * 256; i += ENC_THREADS) s_hist[i] = 0;
-    const u32* ctab = nullptr;
-    if (eh.counts && eh.cut_tab) {
+    const bool cut_staged = eh.counts && eh.cut_tab;
+    if (cut_staged) {  // (the barrier behind the code stream below covers it)
         const u32 nw = eh.cut_words();
         for (u32 i = tid * 4; i < nw; i += ENC_THREADS * 4) *reinterpret_cast<uint4*>(s_cut + i) = *reinterpret_cast<const uint4*>(reinterpret_cast<const u32*>(eh.cut_tab) + i);
-        ctab = s_cut;  // (the barrier behind the code stream below covers it)
     }
     const u32 nwords = (u32)((B1 - A0 + 15) >> 4);
     for (u32 i = tid; i < nwords + 6 && i < ENC_CODE_WORDS; i += ENC_THREADS) {
@@ -463,7 +472,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(BaseView B, u64 total_ba
             st_hi<HiT>(out_hi, obase + drel, hi);
 #endif
             if (eh.counts) {
-                const u32 key = ((hbase + drel) / ENC_HIST_WINDOW) * 256 + eh.digit(lo, hi, ctab);
+                const u32 key = ((hbase + drel) / ENC_HIST_WINDOW) * 256 + eh.digit(lo, hi, s_cut, cut_staged);
 #if CBLX_ENC_HIST_VOTE
                 // The first-pass digit is the skewed one: a wave's 64 keys are a handful of distinct values (2-3 on
                 // average), which per-lane LDS atomics serialise address by address. Instead the wave votes value by
