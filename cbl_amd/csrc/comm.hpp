@@ -1061,8 +1061,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
             const OwnWindow ow{S.own_a, S.own_a + S.own, a_lo.get() + filled, OHS ? (void*)(a_hi.get() + filled * OHS) : nullptr, a_dig.get() + filled};
             StageTimer t(c, ST_SCATTER);
             c->stages[ST_SCATTER].units += N;
-            static const bool plain_single = [] { const char* e = std::getenv("CBLX_FINE_REDIR"); return !(e && e[0] == '1'); }();  // (dev A/B)
-            if (single && plain_single)  // one rank: every record is its own, the pass writes the log directly
+            if (single)  // one rank: every record is its own, the pass writes the log directly (measured: the redirecting instantiation costs the same)
                 hipLaunchKernelGGL((k_radix_scatter<HiT, OutH, DigitCut, false>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, (const u64*)wk.t_lo.get(), (const HiT*)wk.t_hi.get(), tv, fn,
                                    (const u32*)wk.colpre.get(), (const u32*)wk.adj.get(), a_lo.get() + filled, OHS ? (OutH*)(a_hi.get() + filled * OHS) : (OutH*)nullptr, nextd, a_dig.get() + filled);
             else

@@ -987,9 +987,8 @@ template <typename C> void encode(cblx_ctx* c, const BaseView& d_bases, const Ch
     typedef typename C::HiT HiT;
     StageTimer t(c, ST_ENCODE);
     const u64 ntiles = ceil_div(pl.total_bases, ENC_TILE_BYTES);
-    static const size_t dev_extra_lds = [] { const char* e = std::getenv("CBLX_DEV_ENC_LDS"); return e ? (size_t)std::strtoul(e, nullptr, 10) : (size_t)0; }();  // (dev: occupancy probe)
-    if (ntiles)  // (dynamic LDS: the cut table of the fused histogram's bins, when there is one)
-        hipLaunchKernelGGL((k_encode<C::WIDE, HiT>), dim3((unsigned)ntiles), dim3(ENC_THREADS), ((eh.counts && eh.cut_tab) ? 8192 : 0) + dev_extra_lds, c->stream, d_bases, pl.total_bases, pl.chunk_start.get(),
+    if (ntiles)  // (dynamic LDS: the cut table of the fused histogram's bins, when there is one — 8 KB more per workgroup cost the kernel nothing, measured)
+        hipLaunchKernelGGL((k_encode<C::WIDE, HiT>), dim3((unsigned)ntiles), dim3(ENC_THREADS), (eh.counts && eh.cut_tab) ? 8192 : 0, c->stream, d_bases, pl.total_bases, pl.chunk_start.get(),
                            pl.chunk_len.get(), pl.kmer_off.get(), pl.ndirty ? pl.dirty.get() : (const u8*)nullptr, pl.tile_first.get(), c->P, out_lo, out_hi, out_base, eh);
     if (pl.ndirty)
         hipLaunchKernelGGL((k_encode_dirty_wave<C::WIDE, HiT>), dim3((pl.ndirty + 3) / 4), dim3(256), 0, c->stream, d_bases, pl.chunk_start.get(), pl.chunk_len.get(),

@@ -20,6 +20,7 @@ def rand_seq(rng, n, alphabet):
 
 def main():
     os.environ["CBLX_QUERY_JOIN_MIN"] = "1"  # tallies-only queries take the join path whatever their size
+    os.environ.setdefault("CBLX_FINE_MIN", "0")  # PREFIX_BITS > 24: the first batch into an empty index takes the FINE-bins build whatever its size
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)

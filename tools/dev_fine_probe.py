@@ -21,5 +21,5 @@ for i in range(4):
         res["error"] = str(e)[:80]
     torch.cuda.synchronize()
 st = g.stage_times()
-print(cfg, os.environ.get("CBLX_LIB_PATH", "default"), "fine_bins", os.environ.get("CBLX_FINE_BINS", "1"), "redir", os.environ.get("CBLX_FINE_REDIR", "0"),
+print(cfg, os.environ.get("CBLX_LIB_PATH", "default"), "fine_bins", os.environ.get("CBLX_FINE_BINS", "1"),
       {k_: round(v[0] / 3, 3) for k_, v in st.items() if v[0] > 0}, res)
