@@ -22,6 +22,11 @@ d = json.loads(open(f'profiles/{R}_bench_cfg2.json').read())
 print('cfg2', d['ms_per_step'], d['value'], 'h2d', d['h2d_inclusive']['ms_per_step'], 'fasta', d['fasta_inclusive']['ms_per_step'], 'per record', d['per_record']['ms_total'],
       'serialize', d['serialize']['to_host_ms'], 'frac', d['roofline']['frac'])
 PY
-python tools/write_wire_profile.py profiles/${R}_wire_emulated.md gpurun_out/$T/wire_cfg3.json gpurun_out/$T/wire_cfg2.json gpurun_out/$T/wire_cfg4.json
+W=""; for f in wire_cfg3 wire_cfg3_rank3 wire_cfg3_rank6 wire_cfg3_rank7 wire_cfg2 wire_cfg4 wire_cfg4_rank7 wire_w2_sorted wire_w2_bins wire_w4_sorted wire_w4_bins; do [ -s gpurun_out/$T/$f.json ] && W="$W gpurun_out/$T/$f.json"; done
+python tools/write_wire_profile.py profiles/${R}_wire_emulated.md $R $W
 [ -s gpurun_out/$T/bench_cpufull.json ] && tail -1 gpurun_out/$T/bench_cpufull.json | python -c "import json,sys; json.dump(json.loads(sys.stdin.read()), open('profiles/${R}_bench_cpufull.json','w'), indent=1)"
-python tools/write_emulated_rank_md.py $R r03
+for c in cfg3 cfg4 merge; do
+  [ -s gpurun_out/$T/bench_cpufull_$c.json ] && tail -1 gpurun_out/$T/bench_cpufull_$c.json | python -c "import json,sys; json.dump(json.loads(sys.stdin.read()), open('profiles/${R}_bench_cpufull_$c.json','w'), indent=1)"
+  [ -s gpurun_out/$T/kernel_stats_$c.md ] && { echo "# ${R} — rocprofv3 --kernel-trace --stats, \`bench.py --config $c --steps 3 --warmup 1\` (1 x MI355X; tools/r5_final.sh kstats, summarised by tools/rocpd_summary.py; the table also holds the input generation and, for the merge, the two index builds in front of the timed steps)"; echo; cat gpurun_out/$T/kernel_stats_$c.md; } > profiles/${R}_kernel_stats_$c.md
+done
+python tools/write_emulated_rank_md.py $R r04
