@@ -440,14 +440,15 @@ std::vector<u64> sampled_prefix_hist(cblx_ctx* c, Transport& T, const u8* d_base
 // ranges below sort 16 bits behind the first pass (two passes), the sparse tail above 24 (three passes, and a directory over a wide window).
 // Rehearsed at cfg 3 (profiles/r05_wire_emulated.md): with equal words per rank, ranks 0 - 6 take 43 - 44 ms without a wire (47 - 50 at 55 GB/s
 // per link) and rank 7 — the tail — 51 (52.5). The quantiles (rank bounds and group cuts) are therefore taken over the histogram with the
-// tail's cells weighted, so that the ranks take equal TIME rather than equal words: at 55 GB/s per link a weight of 1.12 levels rank 0
-// (wire-bound by then) and rank 7 at 48.8 - 48.9 ms (1.20: 48.9 / 47.4, 1.28: 49.4 / 47.4). (A heuristic: the factor is cfg 3's; any
-// bounds are correct, only the balance depends on it. CBLX_FINE_TAIL_WEIGHT overrides it in percent, 100 = off.)
+// tail's cells weighted, so that the ranks take equal TIME rather than equal words: 1.20 levels rank 0 and rank 7 within a millisecond of
+// each other at 55 GB/s per link and without a wire (47.6 / 46.5 and 45.4 / 46.2 ms with 8-byte records on the wire; 1.12: 46.4 / 48.3,
+// 1.28: 47.6 / 45.6 — box-to-box noise is a millisecond). (A heuristic: the factor is cfg 3's; any bounds are correct, only the balance
+// depends on it. CBLX_FINE_TAIL_WEIGHT overrides it in percent, 100 = off.)
 inline void weigh_tail_for_fine_bins(std::vector<u64>& hist, u32 PB, u32 W, u32 G, u32 hb) {
     const char* fe = std::getenv("CBLX_FINE_BINS");
     if (PB <= 24 || PB > 28 || W < 2 || (fe && fe[0] == '0') || hb + FINE_LEVEL < PB) return;  // (cells must not be wider than 2^16 prefixes)
     const char* we = std::getenv("CBLX_FINE_TAIL_WEIGHT");
-    const u64 pct = we ? std::strtoull(we, nullptr, 10) : 112;
+    const u64 pct = we ? std::strtoull(we, nullptr, 10) : 120;
     if (pct == 100 || pct == 0) return;
     const u64 forced = (u64)W * G - 1, fixed = 8;  // rank bounds + group cuts, the multiples of 2^lmax
     if (forced + fixed + 16 >= FINE_MAX_CUTS) return;
@@ -882,7 +883,13 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     if (single && mine < fine_min_words()) return false;  // (a small batch: the groups' fixed costs outweigh the pass saved)
     const bool trace = std::getenv("CBLX_TRACE_SHARDED") != nullptr;
     const LsdPlan LP = fine ? lsd_plan_bits(FINE_LEVEL) : lsd_plan(P, false);  // (the receiver runs LSD passes only: pipeline.hpp; FINE bins: the first digit is the same for 16 and 24 sorted bits)
-    const DigitBits nextd{P.SB + LP.sh[0], LP.wid[0]};
+    // The digit side channel of the receiver's first LSD pass (1 byte per word) stays OFF the wire by default (round 5): at 8 GPUs and 55 GB/s per
+    // link the step is bound by the wire from the first group on, the byte is a ninth of it, and the receiver's first histogram
+    // reads the records instead (8 bytes per word where it read 1: about the millisecond the senders' byte stores cost). CBLX_WIRE_DIGITS=1 sends
+    // it as rounds 3 - 4 did; one rank (no wire) always keeps it.
+    const char* wd_env = std::getenv("CBLX_WIRE_DIGITS");
+    const bool wire_dig = single || (wd_env && wd_env[0] == '1');
+    const DigitBits nextd = wire_dig ? DigitBits{P.SB + LP.sh[0], LP.wid[0]} : DigitBits{0, 0};
     Buf<u32> d_tab(c->pool, DigitCut::LDS_WORDS);  // CutCell[CUT_KEYS], or u32[FINE_CELLS]: staged in LDS by the kernels that look bins up
     if (fine) h2d(c, d_tab.get(), FM.tab32.data(), FM.tab32.size());
     else h2d(c, d_tab.get(), reinterpret_cast<const u32*>(M.tab.data()), M.tab.size() * 2);
@@ -916,7 +923,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     auto alloc_log = [&](u64 ncap, Buf<u64>& lo, Buf<u8>& hi, Buf<u8>& dg) {
         lo = Buf<u64>(c->pool, ncap + 2);
         hi = Buf<u8>(c->pool, OHS ? (ncap + 2) * OHS : 8);
-        dg = Buf<u8>(c->pool, ncap + 64);
+        dg = Buf<u8>(c->pool, wire_dig ? ncap + 64 : 64);
     };
     struct Sent { Buf<u64> lo; Buf<u8> hi, dig; std::vector<u32> tot; u64 own_a = 0, own = 0; };
     std::vector<Sent> sent(nslices);
@@ -935,7 +942,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         if (filled) {
             CBLX_HIP(hipMemcpyAsync(lo.get(), a_lo.get(), filled * 8, hipMemcpyDeviceToDevice, c->stream));
             if (OHS) CBLX_HIP(hipMemcpyAsync(hi.get(), a_hi.get(), filled * OHS, hipMemcpyDeviceToDevice, c->stream));
-            CBLX_HIP(hipMemcpyAsync(dg.get(), a_dig.get(), filled, hipMemcpyDeviceToDevice, c->stream));
+            if (wire_dig) CBLX_HIP(hipMemcpyAsync(dg.get(), a_dig.get(), filled, hipMemcpyDeviceToDevice, c->stream));
             CBLX_HIP(hipStreamSynchronize(c->stream));
         }
         a_lo = std::move(lo); a_hi = std::move(hi); a_dig = std::move(dg);
@@ -980,24 +987,27 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         };
         item((const u8*)S.lo.get(), (u8*)a_lo.get(), 8);
         if (OHS) item(S.hi.get(), a_hi.get(), OHS);
-        item(S.dig.get(), a_dig.get(), 1);
+        if (wire_dig) item(S.dig.get(), a_dig.get(), 1);
     };
-    struct Work { ChunkPlan pl; Buf<u64> t_lo; Buf<u8> t_hi; Buf<u32> counts, colpre, scratch, adj, coltot; };
+    struct Work { Buf<u64> t_lo; Buf<u8> t_hi; Buf<u32> counts, colpre, scratch, adj, coltot; };
     Work prev_work;
+    // ONE chunk plan for the call, the slices are ranges of it (a plan per slice cost the send phase 0.4 ms of host round trips each)
+    ChunkPlan PL;
+    BaseView pb = ascii_view(d_bases);
+    std::vector<PlanSlice> psl(nslices);
+    if (n1 > n0) {
+        std::vector<u64> marks(nslices + 1);
+        for (u32 s = 0; s <= nslices; ++s) marks[s] = cuts[s] - n0;
+        plan_chunks(c, pb, d_offsets + n0, n1 - n0, PL, nullptr, &marks, &psl);
+    }
     for (u32 s = 0; s < nslices; ++s) {
-        const u64 a = cuts[s], b = cuts[s + 1];
-        ChunkPlan pl;
-        BaseView pb = ascii_view(d_bases);
-        u64 N = 0;
-        if (b > a) { plan_chunks(c, pb, d_offsets + a, b - a, pl); N = pl.n_kmers; }
-        else CBLX_HIP(hipStreamSynchronize(c->stream));
-        prev_work = Work();
+        const u64 N = psl[s].k_hi - psl[s].k_lo;
+        prev_work = Work();  // (its kernels are queued on this stream in front of whatever takes the blocks next)
         if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "one slice takes fewer than 2^32-16 words (use more slices)");
         const u32 ntiles = (u32)ceil_div(N, RDX_TILE);
         Work wk;
         wk.coltot = Buf<u32>(c->pool, 256);
         wk.adj = Buf<u32>(c->pool, 256);
-        wk.pl = std::move(pl);
         Sent& S = sent[s];
         S.tot.assign(256, 0u);
         if (N) {
@@ -1009,7 +1019,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
             CBLX_HIP(hipMemsetAsync(wk.counts.get(), 0, (size_t)256 * (ntiles + 2) * 4, c->stream));
             EncHist eh = eh0;
             eh.counts = wk.counts.get();
-            encode<C>(c, pb, wk.pl, wk.t_lo.get(), (HiT*)wk.t_hi.get(), 0, eh);
+            encode<C>(c, pb, PL, wk.t_lo.get(), (HiT*)wk.t_hi.get(), 0, eh, &psl[s]);
             { StageTimer t(c, ST_SCAN);
               colscan(c, wk.counts.get(), nullptr, ntiles, wk.colpre.get(), wk.coltot.get(), wk.scratch);
               hipLaunchKernelGGL(k_seg_adjust, dim3(1), dim3(256), 0, c->stream, wk.colpre.get(), wk.coltot.get(), (const u32*)nullptr, (const u32*)nullptr,
@@ -1055,10 +1065,10 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         const u64 nsend = N - S.own;
         S.lo = Buf<u64>(c->pool, nsend + 2);
         S.hi = Buf<u8>(c->pool, OHS ? (nsend + 2) * OHS : 8);
-        S.dig = Buf<u8>(c->pool, nsend + 64);
+        S.dig = Buf<u8>(c->pool, wire_dig ? nsend + 64 : 64);
         if (N) {
             const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
-            const OwnWindow ow{S.own_a, S.own_a + S.own, a_lo.get() + filled, OHS ? (void*)(a_hi.get() + filled * OHS) : nullptr, a_dig.get() + filled};
+            const OwnWindow ow{S.own_a, S.own_a + S.own, a_lo.get() + filled, OHS ? (void*)(a_hi.get() + filled * OHS) : nullptr, wire_dig ? a_dig.get() + filled : (u8*)nullptr};
             StageTimer t(c, ST_SCATTER);
             c->stages[ST_SCATTER].units += N;
             if (single)  // one rank: every record is its own, the pass writes the log directly (measured: the redirecting instantiation costs the same)
@@ -1066,7 +1076,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
                                    (const u32*)wk.colpre.get(), (const u32*)wk.adj.get(), a_lo.get() + filled, OHS ? (OutH*)(a_hi.get() + filled * OHS) : (OutH*)nullptr, nextd, a_dig.get() + filled);
             else
             hipLaunchKernelGGL((k_radix_scatter<HiT, OutH, DigitCut, true>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, (const u64*)wk.t_lo.get(), (const HiT*)wk.t_hi.get(), tv, fn,
-                               (const u32*)wk.colpre.get(), (const u32*)wk.adj.get(), S.lo.get(), (OutH*)S.hi.get(), nextd, S.dig.get(), (u32*)nullptr, 0u, 0u, 0u, (u32*)nullptr, 0u, ow);
+                               (const u32*)wk.colpre.get(), (const u32*)wk.adj.get(), S.lo.get(), (OutH*)S.hi.get(), nextd, wire_dig ? S.dig.get() : (u8*)nullptr, (u32*)nullptr, 0u, 0u, 0u, (u32*)nullptr, 0u, ow);
             CBLX_HIP(hipGetLastError());
         }
         if (trace) fprintf(stderr, "[cblx grouped] rank %u slice %u: N=%llu own=%llu incoming=%llu filled=%llu\n", me, s, (unsigned long long)N, (unsigned long long)S.own,
@@ -1147,8 +1157,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         pin.np = (u32)np;
         pin.cnt = cnt_g.data();
         pin.pbase = pb_g.data();
-        pin.dig_in = a_dig.get();
-        pin.dig_out = dig2.get();
+        if (wire_dig) { pin.dig_in = a_dig.get(); pin.dig_out = dig2.get(); }  // (else: the first histogram reads the records, the later passes' digits go to a buffer of the pass's own)
         if (fine) { pin.sort_bits = FM.sort_bits[me][g]; pin.seg_prefix = segp.data(); }
         DirWindow win;
         win.w_lo = (u32)group_first_prefix(g);

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(BaseView B, u64 total_ba
                                                         const u8* __restrict__ dirty /* may be null */,
                                                         const u32* __restrict__ tile_first, Consts P,
                                                         u64* __restrict__ out_lo, HiT* __restrict__ out_hi, u64 out_base,
-                                                        EncHist eh) {
+                                                        EncHist eh, u32 c_lo = 0, u32 c_hi = 0xFFFFFFFFu /* only the chunks in [c_lo, c_hi): a slice of a plan */) {
     typedef typename KmerT<WIDE>::type T;
     __shared__ u32 s_hist[ENC_HIST_WINDOWS * 256];
     __shared__ u32 s_codes[ENC_CODE_WORDS];
@@ -352,7 +352,9 @@ __global__ __launch_bounds__(ENC_THREADS) void k_encode(BaseView B, u64 total_ba
     extern __shared__ u32 s_cut[];              // the cut table of the fused histogram's bins (launched with its size only when there is one)
 
     const u32 tid = threadIdx.x;
-    const u32 c0 = tile_first[blockIdx.x], c1 = tile_first[blockIdx.x + 1];
+    u32 c0 = tile_first[blockIdx.x], c1 = tile_first[blockIdx.x + 1];
+    c0 = c0 > c_lo ? c0 : c_lo;  // (a tile on the edge of the slice holds chunks of its neighbour: theirs to encode)
+    c1 = c1 < c_hi ? c1 : c_hi;
     if (c0 >= c1) return;
     const u32 nc = c1 - c0;  // <= ENC_MAX_CHUNKS by construction (chunk length >= K >= 5)
     const u64 B0 = chunk_start[c0];
@@ -559,7 +561,7 @@ static const u32 DIRTY_MAX_BASES = CHUNK_KMERS + 64 + 64;  // a chunk spans at m
 template <bool WIDE, typename HiT>
 __global__ __launch_bounds__(256) void k_encode_dirty_wave(BaseView B, const u64* __restrict__ chunk_start, const u32* __restrict__ chunk_len,
                                                            const u64* __restrict__ kmer_off, const u32* __restrict__ list, u32 nlist, Consts P,
-                                                           u64* __restrict__ out_lo, HiT* __restrict__ out_hi, u64 out_base, EncHist eh) {
+                                                           u64* __restrict__ out_lo, HiT* __restrict__ out_hi, u64 out_base, EncHist eh, u32 c_lo = 0, u32 c_hi = 0xFFFFFFFFu) {
     typedef typename KmerT<WIDE>::type T;
     constexpr u32 NWV = 4, CW = DIRTY_MAX_BASES / 16 + 8, PW = DIRTY_MAX_BASES / 64 + 2;
     __shared__ u8 s_cb_all[NWV][DIRTY_MAX_BASES + 16];
@@ -576,6 +578,7 @@ __global__ __launch_bounds__(256) void k_encode_dirty_wave(BaseView B, const u64
     if (eh.counts)
         for (u32 i = lane; i < 2 * 256; i += 64) s_hist[i] = 0;
     const u32 c = list[li];
+    if (c < c_lo || c >= c_hi) return;  // (another slice's chunk)
     const u64 s0 = chunk_start[c];
     const u32 len = chunk_len[c], K = P.K;
     const u64 o0 = out_base + kmer_off[c];

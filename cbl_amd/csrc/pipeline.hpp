@@ -926,9 +926,23 @@ struct ChunkPlan {
     Buf<u8> dirty;
     Buf<u32> dirty_list;  // the dirty chunks, any order (ndirty of them)
 };
+// what a SLICE of a plan needs (sequences [seq_a, seq_b) of the planned ones): its chunks, k-mers and tiles
+struct PlanSlice { u64 c_lo = 0, c_hi = 0, k_lo = 0, k_hi = 0, t_lo = 0, t_hi = 0; };
+__global__ void k_plan_marks(const u64* __restrict__ chunk_base, const u64* __restrict__ marks, u32 n, u64 nchunks, const u64* __restrict__ chunk_start, const u64* __restrict__ kmer_off,
+                             u64* __restrict__ out /* [n][3]: chunk, its first k-mer, its first base */) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 ch = chunk_base[marks[i]];
+    out[3 * i] = ch;
+    out[3 * i + 1] = kmer_off[ch];                     // (kmer_off[nchunks] = all k-mers)
+    out[3 * i + 2] = ch < nchunks ? chunk_start[ch] : ~0ull;
+}
 // `ends`: offsets[0] and offsets[nseq] when the caller has read them already (each read is a host round trip)
 // `B`: where the bases live (ASCII bytes, or the bit planes a big host batch crossed PCIe as); advanced to the slice's aligned start
-void plan_chunks(cblx_ctx* c, BaseView& d_bases, const u64* d_offsets, u64 nseq, ChunkPlan& pl, const u64* ends = nullptr) {
+// `seq_marks` / `slices`: sequence indices m[0] <= m[1] <= ... (relative to d_offsets) -> the slices [m[i], m[i+1]) of the plan, so that a caller
+// that works slice by slice plans ONCE (a plan costs half a dozen host round trips)
+void plan_chunks(cblx_ctx* c, BaseView& d_bases, const u64* d_offsets, u64 nseq, ChunkPlan& pl, const u64* ends = nullptr, const std::vector<u64>* seq_marks = nullptr,
+                 std::vector<PlanSlice>* slices = nullptr) {
     StageTimer t(c, ST_CHUNKS);
     const Consts& P = c->P;
     // offsets may start anywhere in the buffer (a slice of a larger batch): work relative to the 16-byte aligned
@@ -975,6 +989,24 @@ void plan_chunks(cblx_ctx* c, BaseView& d_bases, const u64* d_offsets, u64 nseq,
     pl.tile_first = Buf<u32>(c->pool, ntiles + 2);
     hipLaunchKernelGGL(k_tile_first_chunk, grid1(ntiles + 1, 256), dim3(256), 0, c->stream, pl.chunk_start.get(), pl.nchunks, ntiles, pl.tile_first.get());
     CBLX_HIP(hipGetLastError());
+    if (seq_marks && slices) {
+        const u32 nm = (u32)seq_marks->size();
+        Buf<u64> d_marks(c->pool, nm), d_out(c->pool, 3 * (size_t)nm);
+        h2d(c, d_marks.get(), seq_marks->data(), nm);
+        hipLaunchKernelGGL(k_plan_marks, grid1(nm, 64), dim3(64), 0, c->stream, (const u64*)chunk_base.get(), (const u64*)d_marks.get(), nm, pl.nchunks, (const u64*)pl.chunk_start.get(),
+                           (const u64*)pl.kmer_off.get(), d_out.get());
+        const std::vector<u64> o = d2h_vec<u64>(c, d_out.get(), 3 * (size_t)nm);
+        slices->assign(nm ? nm - 1 : 0, PlanSlice());
+        for (u32 i = 0; i + 1 < nm; ++i) {
+            PlanSlice& S = (*slices)[i];
+            S.c_lo = o[3 * i]; S.c_hi = o[3 * (i + 1)]; S.k_lo = o[3 * i + 1]; S.k_hi = o[3 * (i + 1) + 1];
+            if (S.c_hi > S.c_lo) {  // tiles of the base stream (4 KiB each) that hold the slice's chunk starts
+                const std::vector<u64> last = d2h_vec<u64>(c, pl.chunk_start.get() + (S.c_hi - 1), 1);
+                S.t_lo = o[3 * i + 2] / ENC_TILE_BYTES;
+                S.t_hi = last[0] / ENC_TILE_BYTES + 1;
+            }
+        }
+    }
     CBLX_HIP(hipStreamSynchronize(c->stream));  // temporaries (nch, err, chunk_base, chunk_nk, ndirty) die here
 }
 void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq, ChunkPlan& pl, const u64* ends = nullptr) {
@@ -982,10 +1014,23 @@ void plan_chunks(cblx_ctx* c, const u8*& d_bases, const u64* d_offsets, u64 nseq
     plan_chunks(c, B, d_offsets, nseq, pl, ends);
     d_bases = B.ascii;
 }
+// `sl`: only that slice of the plan (its outputs start at out_base: k-mer k of the plan goes to out_base + k - sl->k_lo)
 template <typename C> void encode(cblx_ctx* c, const BaseView& d_bases, const ChunkPlan& pl, u64* out_lo, typename C::HiT* out_hi, u64 out_base,
-                                  EncHist eh = EncHist{}) {
+                                  EncHist eh = EncHist{}, const PlanSlice* sl = nullptr) {
     typedef typename C::HiT HiT;
     StageTimer t(c, ST_ENCODE);
+    if (sl) {
+        if (sl->c_hi <= sl->c_lo) return;
+        const u64 nt = sl->t_hi - sl->t_lo, ob = out_base - sl->k_lo;  // (modulo 2^64: the kernels add a chunk's k-mer offset back)
+        hipLaunchKernelGGL((k_encode<C::WIDE, HiT>), dim3((unsigned)nt), dim3(ENC_THREADS), (eh.counts && eh.cut_tab) ? 8192 : 0, c->stream, d_bases, pl.total_bases, pl.chunk_start.get(),
+                           pl.chunk_len.get(), pl.kmer_off.get(), pl.ndirty ? pl.dirty.get() : (const u8*)nullptr, pl.tile_first.get() + sl->t_lo, c->P, out_lo, out_hi, ob, eh, (u32)sl->c_lo,
+                           (u32)sl->c_hi);
+        if (pl.ndirty)
+            hipLaunchKernelGGL((k_encode_dirty_wave<C::WIDE, HiT>), dim3((pl.ndirty + 3) / 4), dim3(256), 0, c->stream, d_bases, pl.chunk_start.get(), pl.chunk_len.get(),
+                               pl.kmer_off.get(), pl.dirty_list.get(), pl.ndirty, c->P, out_lo, out_hi, ob, eh, (u32)sl->c_lo, (u32)sl->c_hi);
+        CBLX_HIP(hipGetLastError());
+        return;
+    }
     const u64 ntiles = ceil_div(pl.total_bases, ENC_TILE_BYTES);
     if (ntiles)  // (dynamic LDS: the cut table of the fused histogram's bins, when there is one — 8 KB more per workgroup cost the kernel nothing, measured)
         hipLaunchKernelGGL((k_encode<C::WIDE, HiT>), dim3((unsigned)ntiles), dim3(ENC_THREADS), (eh.counts && eh.cut_tab) ? 8192 : 0, c->stream, d_bases, pl.total_bases, pl.chunk_start.get(),
