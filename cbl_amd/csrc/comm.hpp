@@ -1224,6 +1224,8 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     return true;
 }
 
+// one rank's FINE plan: the one "group cut" below which the bins are blocks of 2^16 prefixes (insert_device_fine; a one-rank communicator)
+inline u32 fine_single_cut(u32 PB) { return std::min<u32>(245u << FINE_LEVEL, (1u << (PB - 1)) - (1u << FINE_LEVEL)); }
 template <typename C>
 void sharded_insert(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, u32* bounds, int* bounds_valid) {
     Transport& T = *cm->t;
@@ -1248,6 +1250,15 @@ void sharded_insert(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_
     if (proto == CBLX_PROTO_BINS && !bins_protocol_fits(c->P, bounds, T.world)) proto = CBLX_PROTO_SORTED;
     cm->protocol_used = proto;
     if (proto == CBLX_PROTO_BINS) {
+        if (T.world == 1 && c->P.PB > 24 && c->res.count == 0) {
+            // a one-rank group at PREFIX_BITS > 24: the FINE-bins build of insert_device_fine on this communicator (its slices as given)
+            std::vector<u32> keep = std::move(cm->g_cuts);
+            cm->g_cuts.assign(1, fine_single_cut(c->P.PB));
+            bool done = false;
+            try { done = sharded_insert_grouped<C>(c, cm, d_bases, d_offsets, n, cuts, nslices, bounds, true); } catch (...) { cm->g_cuts = std::move(keep); throw; }
+            cm->g_cuts = std::move(keep);
+            if (done) { ++c->fine_builds; return; }
+        }
         if (sharded_insert_grouped<C>(c, cm, d_bases, d_offsets, n, cuts, nslices, bounds)) return;
         sharded_insert_bins<C>(c, T, ascii_view(d_bases), d_offsets, n, cuts, nslices, bounds, [](u32) {});
     }
@@ -1271,7 +1282,6 @@ struct LocalTransport : Transport {
 // aligned blocks of 2^16 prefixes, whose records need 16 more bits sorted (two passes), and the rest in blocks of 2^24 (three passes of
 // 8 bits). No sampling: the cut is fixed, and a batch whose words all lie above it simply takes three passes behind the first, as the
 // plain build does. Same index (tests run every PREFIX_BITS > 24 shape through both routes).
-inline u32 fine_single_cut(u32 PB) { return std::min<u32>(245u << FINE_LEVEL, (1u << (PB - 1)) - (1u << FINE_LEVEL)); }
 bool insert_device_fine(cblx_ctx* c, const u8* d_bases, const u64* d_offsets, u64 nseq) {
     const char* fe = std::getenv("CBLX_FINE_BINS");
     if ((fe && fe[0] == '0') || c->P.PB <= 24 || nseq == 0 || c->res.count != 0) return false;
