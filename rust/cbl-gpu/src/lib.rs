@@ -381,6 +381,17 @@ impl<const K: usize, T: PackedInt, const PREFIX_BITS: usize> BitOrAssign<&mut Se
     }
 }
 
+impl<const K: usize, T: PackedInt, const PREFIX_BITS: usize> CBL<K, T, PREFIX_BITS> {
+    /// `let mut c = self.clone(); c |= other; c` without the clone's copy (no reference counterpart as a method: the device merge writes a new
+    /// arena anyway, `cblx_merge_from`). `self` is untouched; `other` is left as `|=` leaves it (its Vec buckets that meet a bucket of `self` sorted).
+    pub fn merged_with(&self, other: &mut Self) -> Self {
+        assert_eq!(self.is_canonical(), other.is_canonical(), "One of the index is canonical while the other isn't");
+        let s = Self::with(self.is_canonical());
+        s.check(unsafe { sys::cblx_merge_from(s.ctx, self.ctx, other.ctx) });
+        s
+    }
+}
+
 impl<const K: usize, T: PackedInt, const PREFIX_BITS: usize> Drop for CBL<K, T, PREFIX_BITS> {
     fn drop(&mut self) {
         unsafe { sys::cblx_destroy(self.ctx) }

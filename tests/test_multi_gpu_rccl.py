@@ -75,7 +75,8 @@ def _worker(rank, world, port, k, pb, canonical, protocol, native, per, L, q, gr
     (2, 31, 24, False, "sorted", False, 0), (2, 31, 24, True, "words", False, 0), (2, 59, 28, False, "sorted", True, 0),
     (4, 31, 24, False, "sorted", True, 0), (8, 31, 28, False, "sorted", False, 0),
     (2, 31, 24, False, "bins", True, 0), (4, 59, 28, True, "bins", True, 0), (8, 31, 28, False, "bins", True, 0),
-    (2, 31, 24, False, "bins", True, 1), (8, 31, 28, False, "bins", True, 1), (4, 31, 24, True, "bins", True, 3)])
+    (2, 31, 24, False, "bins", True, 1), (8, 31, 28, False, "bins", True, 1), (4, 31, 24, True, "bins", True, 3),
+    (2, 31, 28, False, "auto", True, 0), (8, 31, 26, True, "auto", True, 0)])  # the library's choice ("sorted" on 2 - 4 ranks); FINE bins at PREFIX_BITS > 24 on 8
 def test_sharded_build_and_merge_on_real_rccl(world, k, pb, canonical, protocol, native, groups):
     if _ngpu() < world:
         pytest.skip(f"needs {world} GPUs in one box, {_ngpu()} visible (RCCL refuses two ranks on one GPU)")
