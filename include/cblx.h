@@ -232,7 +232,7 @@ int cblx_comm_stats(cblx_comm* comm, cblx_exchange_stats* out, int reset);
  *     by run (one more pass over the words): the choice when the links are the bound (2-4 GPUs).
  *   CBLX_PROTO_AUTO (what a new communicator is set to): SORTED on 2 - 4 ranks, BINS otherwise. Between 2 - 4 GPUs every pair shares ONE link
  *     and the bytes on it bound the job; rehearsed against a paced wire (profiles/r05_wire_emulated.md, cfg 3, 55 GB/s per link): 2 ranks
- *     99 ms SORTED / 138 ms BINS, 4 ranks 69 / 76 ms, 8 ranks BINS 48 ms. cblx_comm_protocol_used: what the last sharded insert ran on. */
+ *     101 ms SORTED / 127 ms BINS, 4 ranks 69 / 71 ms (the two meet near 60 GB/s per link), 8 ranks BINS 47 ms. cblx_comm_protocol_used: what the last sharded insert ran on. */
 #define CBLX_PROTO_SORTED 0u
 #define CBLX_PROTO_BINS 1u
 #define CBLX_PROTO_AUTO 2u

@@ -15,7 +15,7 @@ def main():
          "copies at their own speed (what the kernels alone take). Not emulated: the CUs RCCL's kernels occupy, link contention, the peers' own pace. Grouped runs",
          "with three slices use 50 / 30 / 20 % of the reads (`ShardedBuilder.GROUPED_WEIGHTS`). Round 5: PREFIX_BITS > 24 runs on FINE bins (DESIGN.md §3.12, §5.8:",
          "`fine groups` = groups of the rehearsed rank that sort 16 prefix bits behind the first pass, in two LSD passes), any rank can be rehearsed (rank 0 = the",
-         "densest prefix range, rank W - 1 = the sparse tail), and the rank bounds are cost-weighted quantiles (the tail's histogram cells count 1.12 x).", ""]
+         "densest prefix range, rank W - 1 = the sparse tail), and the rank bounds are cost-weighted quantiles (the tail's histogram cells count 1.20 x); 8 bytes per word on the wire (the digit byte stays home).", ""]
     for f in files:
         o = json.loads(open(f).read().strip().splitlines()[-1])
         W, rk, proto = o["world"], o.get("rank", 0), o.get("protocol", "bins")
