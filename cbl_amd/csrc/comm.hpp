@@ -436,26 +436,6 @@ std::vector<u64> sampled_prefix_hist(cblx_ctx* c, Transport& T, const u8* d_base
     T.all_reduce_sum_u64(hist.data(), hist.size());
     return hist;
 }
-// PREFIX_BITS > 24 (FINE bins, cuts.hpp): the budget of 253 cuts covers about the lowest 214 blocks of 2^16 prefixes at 8 ranks x 4 groups — the
-// ranges below sort 16 bits behind the first pass (two passes), the sparse tail above 24 (three passes, and a directory over a wide window).
-// Rehearsed at cfg 3 (profiles/r05_wire_emulated.md): with equal words per rank, ranks 0 - 6 take 43 - 44 ms without a wire (47 - 50 at 55 GB/s
-// per link) and rank 7 — the tail — 51 (52.5). The quantiles (rank bounds and group cuts) are therefore taken over the histogram with the
-// tail's cells weighted, so that the ranks take equal TIME rather than equal words: 1.20 levels rank 0 and rank 7 within a millisecond of
-// each other at 55 GB/s per link and without a wire (47.6 / 46.5 and 45.4 / 46.2 ms with 8-byte records on the wire; 1.12: 46.4 / 48.3,
-// 1.28: 47.6 / 45.6 — box-to-box noise is a millisecond). (A heuristic: the factor is cfg 3's; any bounds are correct, only the balance
-// depends on it. CBLX_FINE_TAIL_WEIGHT overrides it in percent, 100 = off.)
-inline void weigh_tail_for_fine_bins(std::vector<u64>& hist, u32 PB, u32 W, u32 G, u32 hb) {
-    const char* fe = std::getenv("CBLX_FINE_BINS");
-    if (PB <= 24 || PB > 28 || W < 2 || (fe && fe[0] == '0') || hb + FINE_LEVEL < PB) return;  // (cells must not be wider than 2^16 prefixes)
-    const char* we = std::getenv("CBLX_FINE_TAIL_WEIGHT");
-    const u64 pct = we ? std::strtoull(we, nullptr, 10) : 120;
-    if (pct == 100 || pct == 0) return;
-    const u64 forced = (u64)W * G - 1, fixed = 8;  // rank bounds + group cuts, the multiples of 2^lmax
-    if (forced + fixed + 16 >= FINE_MAX_CUTS) return;
-    const u64 x = (FINE_MAX_CUTS - forced - fixed) << FINE_LEVEL;   // where the blocks of 2^16 prefixes end, about
-    const size_t first = (size_t)(x >> (PB - hb));
-    for (size_t i = 0; i < hist.size(); ++i) hist[i] = hist[i] * (i >= first ? pct : 100);
-}
 // first batch only: quantile ranges from the all-reduced, sampled prefix histogram of one slice's words
 template <typename C>
 void choose_bounds_from_slice(cblx_ctx* c, Transport& T, const u8* d_bases, const u64* d_offsets, u64 nseq, u32* bounds, std::vector<u64>* hist_out = nullptr, u32 fine_groups = 0) {

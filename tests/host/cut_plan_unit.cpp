@@ -184,6 +184,35 @@ int main() {
                 CHECK(M.grp_of[bin] == (p >= gc[0] ? 1u : 0u), "one-rank fine plan at PB %u: group of prefix %u", PB, p);
             }
         }
+    // the tail weight (cost-weighted quantiles): only cells at or above the end of the fine region are scaled, by the same factor; PREFIX_BITS <= 24,
+    // one rank or a weight of 100 leave the histogram alone; with the weighted histogram the tail rank of 8 gets FEWER sampled words than an eighth
+    {
+        std::vector<u64> h((size_t)1 << 16, 0);
+        for (int i = 0; i < 400000; ++i) {
+            const double u = (double)(rnd() >> 11) / 9007199254740992.0;
+            h[(size_t)((1.0 - std::pow(1.0 - u, 1.0 / 40.0)) * 0.5 * h.size())]++;
+        }
+        std::vector<u64> w = h;
+        weigh_tail_for_fine_bins(w, 28, 8, 4, 16);
+        const size_t first = (size_t)(((u64)(FINE_MAX_CUTS - 31 - 8) << FINE_LEVEL) >> 12);
+        bool ok = true;
+        for (size_t i = 0; i < h.size(); ++i) ok = ok && w[i] == h[i] * (i >= first ? 120u : 100u);
+        CHECK(ok, "tail weight: cells below %zu x 100, from there on x 120", first);
+        std::vector<u64> same = h;
+        weigh_tail_for_fine_bins(same, 24, 8, 4, 16);
+        CHECK(same == h, "tail weight touches PREFIX_BITS = 24");
+        weigh_tail_for_fine_bins(same, 28, 1, 4, 16);
+        CHECK(same == h, "tail weight touches a one-rank job");
+        auto tail_share = [&](const std::vector<u64>& hist) {  // sampled words (unweighted) of the last of 8 quantile ranges of `hist`
+            u64 tot = 0, run = 0, words = 0, all = 0;
+            for (u64 x : hist) tot += x;
+            size_t cell = 0;
+            while (cell < hist.size() && run + hist[cell] < tot * 7 / 8) run += hist[cell++];
+            for (size_t i = 0; i < h.size(); ++i) { all += h[i]; if (i > cell) words += h[i]; }
+            return (double)words / (double)all;
+        };
+        CHECK(tail_share(w) < tail_share(h) && tail_share(w) > 0.08 && tail_share(h) < 0.13, "tail weight: the tail rank's share %.4f -> %.4f", tail_share(h), tail_share(w));
+    }
     printf("cut plan unit: %ld plans checked, %ld refused, %ld bad; fine: %ld plans, %ld refused, %ld of %ld groups sort 16 bits\n", plans, refused, bad, fplans, frefused, fine16, fgroups);
     return bad || plans < 100 || fplans < 100 ? 1 : 0;
 }

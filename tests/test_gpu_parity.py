@@ -2250,6 +2250,53 @@ def test_rehearsal_of_rank_0_on_recorded_senders(world, k, pb, canonical, groups
     assert nxt >= int(bounds[0])
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_rehearsal_of_any_rank_on_random_fine_plans(seed, monkeypatch):
+    """FINE bins (PREFIX_BITS > 24) under random plans: world size, groups, slices, K, the REHEARSED RANK (CBLX_SIM_TARGET: any rank, not only the
+    densest range) and the tail weight drawn at random; the rehearsed rank must end up with exactly the buckets of its prefix range of the
+    one-process oracle's index (kinds, stored order), whichever of its groups sort 16 bits and whichever 24."""
+    _need_gpu()
+    rng = random.Random(9000 + seed)
+    world = rng.choice([2, 3, 4, 5, 8])
+    k = rng.choice([27, 31, 31, 33, 59])
+    pb = rng.randint(25, 28)
+    canonical = rng.random() < 0.3
+    groups, slices, tgt = rng.choice([0, 2, 3, 5, 6]), rng.randint(1, 3), rng.randrange(world)
+    monkeypatch.setenv("CBLX_SIM_TARGET", str(tgt))
+    monkeypatch.setenv("CBLX_FINE_TAIL_WEIGHT", str(rng.choice([100, 120, 180])))
+    monkeypatch.setenv("CBLX_WIRE_DIGITS", rng.choice(["0", "1"]))
+    L, nr, store = (150 if k < 59 else 250), rng.choice([900, 2500, 6000]), 50000 + seed
+    bounds = np.zeros(world - 1, dtype=np.uint32)
+    valid = False
+    cuts = [nr * s // slices for s in range(slices + 1)]
+    for r in [x for x in range(world) if x != tgt] + [tgt]:
+        d_b, d_o = synth.reads_torch(77 + seed, nr, L, first_read=r * nr, device="cuda")
+        cm = cbl_amd.Comm.sim(r, world, store, 0.0)
+        cm.set_protocol("bins")
+        cm.set_recv_groups(groups)
+        g = cbl_amd.CBL(k, pb, canonical=canonical)
+        valid = g.sharded_insert_seqs_device(cm, d_b, d_o, nr, cuts, bounds, valid)
+        if r == tgt:
+            mine, used, fine = g.buckets(), cm.groups_used(), cm.groups_fine()
+        g.close()
+        cm.close()
+    cbl_amd.Comm.sim_store_free(store)
+    one = Oracle(k, pb, canonical)
+    for c in range(slices):
+        for r in range(world):
+            if cuts[c + 1] > cuts[c]:
+                hb, ho = synth.reads(77 + seed, cuts[c + 1] - cuts[c], L, first_read=r * nr + cuts[c])
+                one.insert_seqs(hb, ho)
+    full = cbl_amd.CBL(k, pb, canonical=canonical)
+    full.load(one.serialize())
+    lo, hi = (int(bounds[tgt - 1]) if tgt else 0), (int(bounds[tgt]) if tgt + 1 < world else 1 << pb)
+    want = [b for b in full.buckets() if lo <= b[0] < hi]
+    full.close()
+    desc = f"world {world} k {k} pb {pb} canonical {canonical} groups {groups} slices {slices} rank {tgt}: {used} groups, {fine} fine"
+    assert fine <= used, desc  # (used = 0: the plan was refused — coinciding bounds on a tiny job — and the ungrouped receiver ran)
+    assert len(mine) == len(want) and mine == want, desc
+
+
 @pytest.mark.parametrize("k,pb,n,canonical", [(31, 6, 300000, False), (21, 8, 600000, True), (15, 4, 200000, False), (31, 10, 1500000, False), (27, 9, 40000, False),
                                               (31, 16, 900000, False), (59, 12, 200000, True), (35, 14, 500000, False)])
 def test_trie_union_by_merge_path_equals_the_sorting_route(k, pb, n, canonical, monkeypatch):
