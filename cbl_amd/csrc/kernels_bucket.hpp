@@ -318,12 +318,18 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify_merge(u64 nb, u32
     }
     const u32 slot = block_append<CLASSIFY_THREADS, CLS_N>(cls, list_n);
     if (cls >= 0) lists[(u64)cls * nb + slot] = BDesc{raw_start[r], (u32)c | (ks == KIND_TRIE ? BDESC_TRIE : 0u), (u32)r};
-    if (cls_words) {  // (profiling only: one wave reduction and one atomic per class and wave)
+    if (cls_words) {  // (profiling only: a wave reduction per class, summed per workgroup in LDS, ONE global atomic per class and workgroup —
+                      //  one per class and WAVE, as first written, serialised half a million atomics on eleven addresses: 22 -> 737 us at cfg 5's share)
+        __shared__ unsigned long long s_cw[CLS_N + 1];
+        if (threadIdx.x <= CLS_N) s_cw[threadIdx.x] = 0ull;
+        __syncthreads();
 #pragma unroll
         for (int k = -1; k < CLS_N; ++k) {
             const u64 s = wave_reduce_sum(cls == k && r < nb ? c : 0ull);
-            if ((threadIdx.x & 63) == 0 && s) atomicAdd(&cls_words[k < 0 ? CLS_N : k], (unsigned long long)s);
+            if ((threadIdx.x & 63) == 0 && s) atomicAdd(&s_cw[k < 0 ? CLS_N : k], (unsigned long long)s);
         }
+        __syncthreads();
+        if (threadIdx.x <= CLS_N && s_cw[threadIdx.x]) atomicAdd(&cls_words[threadIdx.x], s_cw[threadIdx.x]);
     }
 }
 
@@ -912,8 +918,17 @@ static const int MSD_TRIP = CBLX_MSD_TRIP;  // sub-bucket entries read per trip 
 #ifndef CBLX_MSD_PROBE
 #define CBLX_MSD_PROBE 0  // > 0: timing probes that leave phases out (tools/variants.sh); never in the product build
 #endif
+#ifndef CBLX_MSD_PROBE_MERGE
+#define CBLX_MSD_PROBE_MERGE 0  // 1: probes 1 - 3 only touch `self |= other` launches (the two indexes in front of a merge bench stay right); 4 / 5 are merge-only anyway
+#endif
 #if (CBLX_MSD_PROBE || CBLX_ENC_PROBE) && !defined(CBLX_TIMING_PROBES)
 #error "CBLX_MSD_PROBE / CBLX_ENC_PROBE leave phases out and produce wrong results: timing builds only (-DCBLX_TIMING_PROBES)"
+#endif
+#ifndef CBLX_MSD_MERGE_REUSE
+#define CBLX_MSD_MERGE_REUSE 0
+#endif
+#ifndef CBLX_MSD_MERGE_WAVES
+#define CBLX_MSD_MERGE_WAVES 7
 #endif
 #ifndef CBLX_MSD_WAVES
 #define CBLX_MSD_WAVES 7  // waves per SIMD the register allocation aims at (LDS allows 7 workgroups of the 256-thread class; 76 -> 72 VGPRs: 7.28 -> 7.10 ms)
@@ -939,6 +954,7 @@ template <int CAP, bool PACKED, bool WS, bool MERGE> constexpr int msd_waves() {
     if (WS) return CAP <= 128 ? CBLX_MSD_WAVES : ((CAP <= 512 && !MERGE) ? 5 : 4);
     if (CAP >= 4096) return (PACKED && !MERGE) ? 6 : 5;
     if (CAP >= 2048 && !PACKED) return MERGE ? 5 : 6;
+    if (MERGE && CAP > 128) return CBLX_MSD_MERGE_WAVES;
     return CBLX_MSD_WAVES;
 }
 template <int THREADS, int CAP, bool PACKED, bool WS, typename HiT, bool MERGE = false>
@@ -961,6 +977,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
     __shared__ u32 s_scan[NW + 1];
     __shared__ u32 s_wtot[NW + 1];
     __shared__ u32 s_max;
+    __shared__ u32 s_sel[MERGE ? NW : 1];  // merge epilogue: per-wave counts of its three selections (10-bit fields)
 
     if (blockIdx.x >= *list_n) return;
     const BDesc dsc = list[blockIdx.x];
@@ -982,7 +999,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
     // `self |= other` (mg.cs set): the run is [self's suffixes][other's], both parts distinct; every outcome needs the sorted
     // order, so the sub-buckets are always by the top bits
     const bool merging = MERGE && mg.cs != nullptr;
-    const bool vec_only = c <= VEC_THRESHOLD && !res_trie && !merging;  // no sorted output needed: sub-buckets by hash
+    // no sorted output needed: sub-buckets by hash. Never in the MERGE instantiation: its other caller (the sub-ranges of a long run,
+    // k_big_vlist) always asks for the sorted list — as a run-time value there, the hashed variants of the sub-bucket index and of the
+    // ranking loop sat behind a branch per slot in the kernel `self |= other` spends its time in
+    const bool vec_only = !MERGE && c <= VEC_THRESHOLD && !res_trie;
     // Largest sub-bucket the ranking loop is worth running on. Hashed sub-buckets of distinct suffixes stay below 10
     // entries, so more than MSD_LIMIT_HASHED means repeats (every copy of a value lands in its sub-bucket): such runs are
     // deduplicated far cheaper by the claim table. Top-bit sub-buckets reach 45 entries without a single repeat (necklace
@@ -999,17 +1019,45 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
     bool valid[ITEMS];
     // all loads first, unconditionally (slots past the run re-read its first element): eight independent global loads in
     // flight per lane instead of eight load -> wait -> use round trips inside per-slot branches
-    u32 cs_dir = 0;   // direct merge: self's length, and where the two halves are stored
-    u64 a_self = 0, a_oth = 0;
-    bool direct = false;
-    if constexpr (MERGE) if (merging && mg.s_lo) { direct = true; cs_dir = mg.cs[r]; a_self = mg.sstart[r]; a_oth = mg.ostart[r]; }
+    u32 cs_m = 0;     // merge: self's length (index < cs_m = the element came from self)
+    if constexpr (MERGE) if (merging) cs_m = mg.cs[r];
+    if constexpr (MERGE) {
+        // One address form for the three cases: element e is word e of `pa` (e < split) or of `pb`. Gathered run / no merge: both are the
+        // run. Direct merge: self's part where self stores it, other's where other does, the latter's pointer moved back by cs so that
+        // the element index needs no subtraction (two selects and one 64-bit multiply-add per slot; the case distinction per slot that
+        // stood here cost twice that). (HiT is u64 whenever the suffix is wide.)
+        static_assert(!WS || sizeof(HiT) == 8, "wide suffixes keep their high part in 64-bit words");
+        const u64* pa = lo + s0;
+        const u64* pb = pa;
+        const u64* ha = WS ? reinterpret_cast<const u64*>(hi) + s0 : nullptr;
+        const u64* hb = ha;
+        u32 split = 0;
+        if (merging && mg.s_lo) {
+            split = cs_m;
+            const u64 a_self = mg.sstart[r], a_oth = mg.ostart[r];
+            pa = mg.s_lo + a_self;
+            pb = reinterpret_cast<const u64*>(reinterpret_cast<uintptr_t>(mg.o_lo + a_oth) - 8ull * split);
+            if constexpr (WS) {
+                ha = mg.s_hi + a_self;
+                hb = reinterpret_cast<const u64*>(reinterpret_cast<uintptr_t>(mg.o_hi + a_oth) - 8ull * split);
+            }
+        }
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const u32 e = w * EPW + j * 64 + lane;
-        valid[j] = (u32)j < R && e < c;
-        const u32 ee = valid[j] ? e : 0u;
-        if (MERGE && direct) key[j] = ee < cs_dir ? load_sfx<WS, u64>(mg.s_lo, mg.s_hi, a_self + ee, SB) : load_sfx<WS, u64>(mg.o_lo, mg.o_hi, a_oth + (ee - cs_dir), SB);
-        else key[j] = load_sfx<WS, HiT>(lo, hi, s0 + ee, SB);
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 e = w * EPW + j * 64 + lane;
+            valid[j] = (u32)j < R && e < c;
+            const u32 ee = valid[j] ? e : 0u;
+            const bool in_a = ee < split;
+            key[j] = load_sfx<WS, u64>(in_a ? pa : pb, in_a ? ha : hb, ee, SB);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 e = w * EPW + j * 64 + lane;
+            valid[j] = (u32)j < R && e < c;
+            const u32 ee = valid[j] ? e : 0u;
+            key[j] = load_sfx<WS, HiT>(lo, hi, s0 + ee, SB);
+        }
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -1050,9 +1098,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
         }
     }
     __syncthreads();
-#if CBLX_MSD_PROBE >= 3  // timing probe only: loads, counting atomics and scan alone
-    if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_VEC; }
-    if (key[0].lo != 0x1234567ull) return;
+#if CBLX_MSD_PROBE == 3  // timing probe only: loads, counting atomics and scan alone
+    if (!CBLX_MSD_PROBE_MERGE || merging) {
+        if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_VEC; }
+        if (key[0].lo != 0x1234567ull) return;
+    }
 #endif
     if (tid == 0) s_off[NB] = (u16)c;
     if constexpr (PACKED) { if (tid < 4) s_klo[c + tid] = ~0ull; }  // the slack the ranking loop may read compares greater than every element
@@ -1092,11 +1142,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
     u32 sa[ITEMS], sb[ITEMS];  // sub-bucket bounds of every item, fetched in one batch of independent LDS reads
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-#if CBLX_MSD_REUSE_BASE
-        sa[j] = sbase[j];  // the offsets did not change since the scatter read them: one LDS read per item less
-#else
-        sa[j] = s_off[sub[j]];
-#endif
+        if constexpr (CBLX_MSD_REUSE_BASE || (MERGE && CBLX_MSD_MERGE_REUSE)) sa[j] = sbase[j];  // the offsets did not change since the scatter read them: one LDS read per item less
+        else sa[j] = s_off[sub[j]];
         sb[j] = s_off[sub[j] + 1];
     }
 #pragma unroll
@@ -1105,8 +1152,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
         fin[j] = 0;
         if (valid[j]) {
             const u32 e = w * EPW + j * 64 + lane;
-#if CBLX_MSD_PROBE >= 1  // timing probe only (wrong order): no ranking reads
-            const u32 b = sb[j], a = b;
+#if CBLX_MSD_PROBE >= 1 && CBLX_MSD_PROBE <= 2  // timing probe only (wrong order): no ranking reads
+            const u32 b = sb[j], a = (!CBLX_MSD_PROBE_MERGE || merging) ? b : ((b - sa[j] > 1u) ? sa[j] : b);
             const u32 a0 = sa[j];
 #elif CBLX_MSD_SKIP_SINGLE
             const u32 b = sb[j], a = (b - sa[j] > 1u) ? sa[j] : b;  // alone: rank 0, no duplicate, nothing to read
@@ -1217,99 +1264,102 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
         wave_heads += (u32)__builtin_popcountll(__ballot(head[j]));
     }
     if constexpr (MERGE) if (merging) {
-        // Every element goes to its rank by (suffix, index) with its index: the slots then hold the run sorted, self's copy
-        // of a suffix in front of other's (index < cs = came from self), and the rules of src/trievec/set_ops.rs:43-71 are
-        // ordered compactions of slot subsets, as in k_bucket_medium's merge epilogue.
+        // Every element goes to its rank by (suffix, index): the slots then hold the run sorted, self's copy of a suffix in front of
+        // other's (index < cs = came from self), and the rules of src/trievec/set_ops.rs:43-71 are ordered compactions of slot subsets,
+        // as in k_bucket_medium's merge epilogue. What a slot has to say about its element is two bits, both known here: which side it
+        // came from, and whether it is the first of its suffix (the ranking loop's `dup`: an equal suffix with a smaller index — the
+        // other side's copy of a word self holds). Round 5: the slots carried the 12-bit index instead, every thread read its slot AND
+        // the one in front of it to find the heads again, and the (up to) three compactions each had their own pair of barriers.
+#if CBLX_MSD_PROBE == 4  // timing probe only: no merge epilogue at all
+        if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_VEC; }
+        if (fin[0] != 0x12345u) return;
+#endif
         __syncthreads();  // every read of the sub-bucket order is done
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             if (valid[j]) {
                 const u32 e = w * EPW + j * 64 + lane;
+                const u32 fl = (e < cs_m ? 2u : 0u) | (head[j] ? 1u : 0u);
                 if constexpr (PACKED) {
-                    s_klo[fin[j]] = (key[j].lo << PK_BITS) | e;
+                    s_klo[fin[j]] = (key[j].lo << PK_BITS) | fl;
                 } else if constexpr (WP) {
-                    s_kw[fin[j]] = w128_pack(key[j], e);
+                    s_kw[fin[j]] = w128_pack(key[j], fl);
                 } else {
                     s_klo[fin[j]] = key[j].lo;
-                    s_idx[fin[j]] = (u16)e;
+                    s_idx[fin[j]] = (u16)fl;
                 }
             }
         }
         __syncthreads();
-        const u32 cs = mg.cs[r];
-        u32 idx[ITEMS];
-        u32 wh = 0;
+        const bool o_vec = mg.okind[r] == KIND_VEC;  // the reference's iter_sorted leaves other's Vec sorted
+        // three ordered selections of the slots, counted and written together:
+        //   O = other's elements (back to other's arena, sorted)            A = Trie |= x: the heads (sorted union); Vec |= x: self's elements
+        //   B = Vec |= x only: other's heads = other \ self, behind self's   (every self element is a head)
+        u32 fl[ITEMS];
+        u32 nO = 0;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const u32 p = w * EPW + j * 64 + lane;
             const bool live = (u32)j < R && p < c;
-            const u32 pc = live ? p : 0u, pp = (live && p) ? p - 1 : 0u;
-            Sfx<WS> prev;
+            const u32 pc = live ? p : 0u;
+            u32 f;
             if constexpr (PACKED) {
-                const u64 v = s_klo[pc], u = s_klo[pp];
+                const u64 v = s_klo[pc];
                 key[j].lo = v >> PK_BITS;
-                idx[j] = (u32)v & ((1u << PK_BITS) - 1u);
-                prev.lo = u >> PK_BITS;
+                f = (u32)v & 3u;
             } else if constexpr (WP) {
-                const W128 v = s_kw[pc], u = s_kw[pp];
+                const W128 v = s_kw[pc];
                 key[j] = w128_sfx(v);
-                idx[j] = (u32)v.lo & ((1u << PK_BITS) - 1u);
-                prev = w128_sfx(u);
+                f = (u32)v.lo & 3u;
             } else {
                 key[j].lo = s_klo[pc];
-                prev.lo = s_klo[pp];
-                idx[j] = s_idx[pc];
+                f = s_idx[pc];
             }
-            valid[j] = live;
-            head[j] = live && (p == 0 || prev != key[j]);
-            wh += (u32)__builtin_popcountll(__ballot(head[j]));
+            // bit 0: in O; bit 10: in A; bit 20: in B — a lane's eight slots, and then the wave's 512, are counted by plain additions of
+            // these words (three 10-bit fields) and ONE wave reduction; a ballot per selection and slot here kept 24 lane masks alive for
+            // the write loop below (the compiler re-used them) and spilled half the scalar registers
+            const bool self_el = (f & 2u) != 0, hd = (f & 1u) != 0;
+            const bool inO = live && !self_el && o_vec, inA = live && (res_trie ? hd : self_el), inB = live && !res_trie && !self_el && hd;
+            fl[j] = (inO ? 1u : 0u) | (inA ? (1u << 10) : 0u) | (inB ? (1u << 20) : 0u);
+            nO += fl[j];
         }
-        if (lane == 0) s_wtot[w] = wh;
+        nO = wave_reduce_sum(nO);  // (every lane gets the sum) <= 512 per field
+        if (lane == 0) s_sel[w] = nO;
         __syncthreads();
-        u32 d = 0;
-        for (int ww = 0; ww < NW; ++ww) d += s_wtot[ww];
-        // ordered compaction of the slots selected by `sel` to dst[base + rank]
-        auto compact = [&](const bool (&sel)[ITEMS], u64* dlo, u64* dhi, u64 base) {
-            u32 wk = 0;
+        u32 runO = 0, runA = 0, runB = 0, totA = 0, totB = 0;
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) wk += (u32)__builtin_popcountll(__ballot(sel[j]));
-            __syncthreads();
-            if (lane == 0) s_wtot[w] = wk;
-            __syncthreads();
-            u32 run = 0;
-            for (u32 ww = 0; ww < w; ++ww) run += s_wtot[ww];
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                const u64 bal = __ballot(sel[j]);
-                if (sel[j]) {
-                    dlo[base + run + mbcnt(bal)] = key[j].lo;
-                    if constexpr (WS) dhi[base + run + mbcnt(bal)] = key[j].hi;
-                }
-                run += (u32)__builtin_popcountll(bal);
-            }
-        };
-        bool sel[ITEMS];
-        if (mg.okind[r] == KIND_VEC) {  // the reference's iter_sorted leaves other's Vec sorted
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) sel[j] = valid[j] && idx[j] >= cs;
-            compact(sel, mg.o_lo, mg.o_hi, mg.ostart[r]);
+        for (int ww = 0; ww < NW; ++ww) {
+            const u32 t = s_sel[ww], tO = t & 1023u, tA = (t >> 10) & 1023u, tB = t >> 20;
+            if ((u32)ww < w) { runO += tO; runA += tA; runB += tB; }
+            totA += tA;
+            totB += tB;
         }
         u64* slo = lo;
         u64* shi = reinterpret_cast<u64*>(hi);
-        if (res_trie) {  // Trie |= anything: sorted union
+        const u64 obase = mg.ostart[r];
+        runB += cs_m;  // B follows self's cs elements
+#if CBLX_MSD_PROBE == 5  // timing probe only: the merge epilogue without its global stores
+        if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_VEC; }
+        if (runO + runA + runB + fl[0] != 0x12345u) return;
+#endif
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) sel[j] = head[j];
-            compact(sel, slo, shi, s0);
-        } else {         // Vec |= anything: sorted(self) ++ sorted(other \ self); every self element is a head
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) sel[j] = head[j] && idx[j] < cs;
-            compact(sel, slo, shi, s0);
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) sel[j] = head[j] && idx[j] >= cs;
-            compact(sel, slo, shi, s0 + cs);
+        for (int j = 0; j < ITEMS; ++j) {
+            const u64 balO = __ballot((fl[j] & 1u) != 0), balA = __ballot((fl[j] & (1u << 10)) != 0), balB = __ballot((fl[j] & (1u << 20)) != 0);
+            if (fl[j] & 1u) {
+                mg.o_lo[obase + runO + mbcnt(balO)] = key[j].lo;
+                if constexpr (WS) mg.o_hi[obase + runO + mbcnt(balO)] = key[j].hi;
+            }
+            if (fl[j] & ((1u << 10) | (1u << 20))) {  // A and B are disjoint
+                const u32 q = (fl[j] & (1u << 10)) ? runA + mbcnt(balA) : runB + mbcnt(balB);
+                slo[s0 + q] = key[j].lo;
+                if constexpr (WS) shi[s0 + q] = key[j].hi;
+            }
+            runO += (u32)__builtin_popcountll(balO);
+            runA += (u32)__builtin_popcountll(balA);
+            runB += (u32)__builtin_popcountll(balB);
         }
         if (tid == 0) {
-            out_count[r] = d;
+            out_count[r] = res_trie ? totA : cs_m + totB;
             out_kind[r] = res_trie ? KIND_TRIE : KIND_VEC;
         }
         return;
@@ -1323,7 +1373,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
     }
     __syncthreads();
     const u32 d = s_wtot[NW];
-#if CBLX_MSD_PROBE >= 2  // timing probe only: no sorted write-back
+#if CBLX_MSD_PROBE == 2  // timing probe only: no sorted write-back (and no ranking reads)
     const bool trie = false;
 #else
     const bool trie = d > VEC_THRESHOLD || res_trie;

@@ -25,6 +25,11 @@ PY
         rocprofv3 --kernel-trace --stats -d $OUT/ks_$c -o r -- python3 $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-h2d --no-serialize --no-fasta --no-per-record > /dev/null 2> $OUT/ks_$c.err
         python3 $R/tools/rocpd_summary.py $OUT/ks_$c/r_results.db > $OUT/kernel_stats_$c.md; rm -rf $OUT/ks_$c; echo "kstats $c: $(wc -l < $OUT/kernel_stats_$c.md) rows"
       done; cd $R ;;
+    merge) timeout 600 python bench.py --config merge --steps 10 --warmup 3 > $OUT/bench_merge.json 2> $OUT/bench_merge.err; echo "bench merge rc=$?"
+      cd /tmp && export TMPDIR=/tmp
+      rocprofv3 --kernel-trace --stats -d $OUT/ks_merge -o r -- python3 $R/bench.py --config merge --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/ks_merge.err
+      python3 $R/tools/rocpd_summary.py $OUT/ks_merge/r_results.db > $OUT/kernel_stats_merge.md; rm -rf $OUT/ks_merge; cd $R
+      bash tools/r5_merge_traffic.sh ${TAG}_mt > /dev/null 2>&1; bash tools/collect_counters.sh ${TAG}_msq merge > /dev/null 2>&1 ;;
     emul) for w in "--reads 10000000" "" "--reads 12500000 --prefix-bits 28" "--k 59 --prefix-bits 28 --reads 6250000 --read-len 250"; do
         n=$(echo "$w" | tr -d ' -' | cut -c1-24); [ -z "$n" ] && n=cfg5
         m=""; case "$n" in reads10000000|cfg5) m="--merge";; esac
