@@ -342,8 +342,8 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify_merge(u64 nb, u32
 // the n smallest as a bitonic sequence, log2 n compare-exchange stages sort it — so no lane follows data-dependent control flow. The
 // outputs go back to LDS (one padding word per 8: a lane's 64-byte row would otherwise hit the banks of its neighbours'), are
 // compared with their predecessor there (equal = other's copy of a word self holds: dropped) and leave compacted in order. The
-// co-rank of the round's last output says how far either list was consumed. HBM traffic: every word read once (twice in a long
-// bucket: a round loads UNI_TILE words of both lists and consumes UNI_TILE in all; the L2 holds the rest), the union written once.
+// co-rank of the round's last output says how far either list was consumed. HBM traffic: every word read once (the staging areas are
+// rings since round 5: a round refills only the slots it consumed — see the kernel), the union written once.
 // Workgroup shape, measured on cfg 5's share (`bench.py --config merge`, stage bucket_big) / at the 8-GPU depth of cfg 5 (`tools/emulate_rank.py --merge`:
 // 752 M + 752 M words in buckets of 10 635 each): 256 threads x 8 outputs 3.18 / 9.4 ms, 128 x 8 3.09, 256 x 4 2.14 / 6.3, **128 x 4 2.07 / 6.2**, 256 x 2 2.53 — half the registers
 // (a[], b[], o[]), half the merge network and a shorter search per round buy more than the extra rounds cost; padding one word per 4 instead of 8: 2.33 / 6.7.
@@ -356,7 +356,8 @@ __global__ __launch_bounds__(UNI_THREADS) void k_bucket_union(const BDesc* __res
                                                               u8* __restrict__ out_kind) {
     constexpr int NW = UNI_THREADS / 64;
     constexpr u32 T = UNI_TILE;
-    __shared__ u64 s_in[T * 2 + (T * 2) / 8 + 8];  // A's chunk at logical [0, T), B's at [T, 2T); later the round's outputs at [0, T)
+    static_assert((T & (T - 1)) == 0, "the staging rings index by g mod T");
+    __shared__ u64 s_in[T * 2 + (T * 2) / 8 + 8];  // A's ring at logical [0, T), B's at [T, 2T); the round's outputs in the slots it consumed
     __shared__ u32 s_split[NW + 1];
     __shared__ u32 s_wtot[NW + 1];
     if (blockIdx.x >= *list_n) return;
@@ -367,20 +368,28 @@ __global__ __launch_bounds__(UNI_THREADS) void k_bucket_union(const BDesc* __res
     u64* __restrict__ dst = out_lo + dsc.start;
     const u64 mask = SB >= 64 ? ~0ull : ((1ull << SB) - 1ull);
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    // The two staging areas are RINGS of T slots (round 5): word g of a list lives in slot g mod T of its ring, a round consumes nout
+    // words — iend from A, the rest from B — and only those nout slots are refilled in front of the next round; the round's outputs pass
+    // through exactly the slots it freed. As first written every round staged the next T words of BOTH lists again and consumed T in
+    // all: every word crossed the L2 twice, and with 16 workgroups per CU holding 8 KB each the second read missed — 6.3 GB fetched for
+    // 4.0 GB of lists by the TCC counters (profiles/r05_merge_hbm_traffic.md).
     u32 ia = 0, ib = 0, written = 0;
+    u32 ha = 0, hb = 0;  // words of A from ia / of B from ib already in the rings
     u64 carry = 0;
     bool have_carry = false;
+    auto ra = [&](u32 g) { return uni_pad(g & (T - 1)); };
+    auto rb = [&](u32 g) { return uni_pad(T + (g & (T - 1))); };
     while (ia < cs || ib < co) {
         const u32 na = cs - ia < T ? cs - ia : T, nb = co - ib < T ? co - ib : T, nout = na + nb < T ? na + nb : T;
-        for (u32 i = tid; i < na; i += UNI_THREADS) s_in[uni_pad(i)] = A[ia + i] & mask;
-        for (u32 i = tid; i < nb; i += UNI_THREADS) s_in[uni_pad(T + i)] = B[ib + i] & mask;
+        for (u32 g = ia + ha + tid; g < ia + na; g += UNI_THREADS) s_in[ra(g)] = A[g] & mask;
+        for (u32 g = ib + hb + tid; g < ib + nb; g += UNI_THREADS) s_in[rb(g)] = B[g] & mask;
         __syncthreads();
         // co-rank of the end of this thread's outputs: how many of the first d1 outputs come from A
         const u32 d0 = tid * UNI_ITEMS < nout ? tid * UNI_ITEMS : nout, d1 = (tid + 1) * UNI_ITEMS < nout ? (tid + 1) * UNI_ITEMS : nout;
         u32 lo = d1 > nb ? d1 - nb : 0u, hi = d1 < na ? d1 : na;
         while (lo < hi) {
             const u32 mid = (lo + hi) >> 1;
-            if (s_in[uni_pad(mid)] <= s_in[uni_pad(T + d1 - 1 - mid)]) lo = mid + 1; else hi = mid;
+            if (s_in[ra(ia + mid)] <= s_in[rb(ib + d1 - 1 - mid)]) lo = mid + 1; else hi = mid;
         }
         const u32 i1 = lo;
         if (lane == 63) s_split[w + 1] = i1;
@@ -394,8 +403,8 @@ __global__ __launch_bounds__(UNI_THREADS) void k_bucket_union(const BDesc* __res
 #pragma unroll
         for (int k = 0; k < UNI_ITEMS; ++k) {
             const u32 x = i0 + k, y = j0 + k;
-            a[k] = s_in[uni_pad(x < na ? x : 0u)];
-            b[k] = s_in[uni_pad(T + (y < nb ? y : 0u))];
+            a[k] = s_in[ra(ia + (x < na ? x : 0u))];
+            b[k] = s_in[rb(ib + (y < nb ? y : 0u))];
             if (x >= na) a[k] = ~0ull;
             if (y >= nb) b[k] = ~0ull;
         }
@@ -407,9 +416,14 @@ __global__ __launch_bounds__(UNI_THREADS) void k_bucket_union(const BDesc* __res
 #pragma unroll
             for (int k = 0; k < UNI_ITEMS; ++k)
                 if ((k & st) == 0) uni_cmpx(o[k], o[k + st]);
-        __syncthreads();  // every read of the chunks is done: the outputs take their place
+        __syncthreads();  // every read of the chunks is done: the outputs take the place of what the round consumed
+        // output q of the round sits in the q-th freed slot: A's ring first (iend of them), then B's
+        auto oslot = [&](u32 q) { return q < iend ? ra(ia + q) : rb(ib + (q - iend)); };
 #pragma unroll
-        for (int k = 0; k < UNI_ITEMS; ++k) s_in[uni_pad(tid * UNI_ITEMS + k)] = o[k];
+        for (int k = 0; k < UNI_ITEMS; ++k) {
+            const u32 q = tid * UNI_ITEMS + k;
+            if (q < nout) s_in[oslot(q)] = o[k];  // (nothing past nout: those slots hold words of the next round)
+        }
         __syncthreads();
         // ordered compaction of the outputs that differ from their predecessor (wave-contiguous slices keep the order)
         u64 v[UNI_ITEMS];
@@ -419,12 +433,12 @@ __global__ __launch_bounds__(UNI_THREADS) void k_bucket_union(const BDesc* __res
         for (int j = 0; j < UNI_ITEMS; ++j) {
             const u32 p = w * (64 * UNI_ITEMS) + j * 64 + lane;
             const bool live = p < nout;
-            v[j] = s_in[uni_pad(live ? p : 0u)];
-            const u64 u = s_in[uni_pad((live && p) ? p - 1 : 0u)];
+            v[j] = s_in[oslot(live ? p : 0u)];
+            const u64 u = s_in[oslot((live && p) ? p - 1 : 0u)];
             head[j] = live && (p ? v[j] != u : (!have_carry || v[j] != carry));
             wh += (u32)__builtin_popcountll(__ballot(head[j]));
         }
-        const u64 last = s_in[uni_pad(nout - 1)];
+        const u64 last = s_in[oslot(nout - 1)];
         if (lane == 0) s_wtot[w] = wh;
         __syncthreads();
         u32 run = 0, tot = 0;
@@ -439,9 +453,11 @@ __global__ __launch_bounds__(UNI_THREADS) void k_bucket_union(const BDesc* __res
         carry = last;
         have_carry = true;
         written += tot;
+        ha = na - iend;
+        hb = nb - (nout - iend);
         ia += iend;
         ib += nout - iend;
-        __syncthreads();  // the next round overwrites the staging area and the split table
+        __syncthreads();  // the next round refills the freed slots and rewrites the split table
     }
     if (tid == 0) { out_count[r] = written; out_kind[r] = KIND_TRIE; }
 }
@@ -952,7 +968,7 @@ template <bool WS> __host__ __device__ inline bool msd_takes(u32 SB) { return !W
 // 5 - 6, everything else CBLX_MSD_WAVES.
 template <int CAP, bool PACKED, bool WS, bool MERGE> constexpr int msd_waves() {
     if (WS) return CAP <= 128 ? CBLX_MSD_WAVES : ((CAP <= 512 && !MERGE) ? 5 : 4);
-    if (CAP >= 4096) return (PACKED && !MERGE) ? 6 : 5;
+    if (CAP >= 4096) return PACKED ? 6 : 5;
     if (CAP >= 2048 && !PACKED) return MERGE ? 5 : 6;
     if (MERGE && CAP > 128) return CBLX_MSD_MERGE_WAVES;
     return CBLX_MSD_WAVES;
@@ -993,6 +1009,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
     }
     const u32 R = (c + THREADS - 1) / THREADS;
     const u32 EPW = 64 * R;  // wave-contiguous slices: ballots then compact in stream order
+    // The lane's first slot; slot j is + 64 j. In the MERGE instantiation every phase takes it through an empty asm, so that the compiler
+    // adds 64 j again where it needs a slot index instead of keeping the eight sums alive from the loads to the epilogue — with the
+    // merge epilogue on top they were what spilled (8 registers, 36 bytes of scratch per lane, 3.7 GB of scratch writes per merge by the
+    // TCC counters). The build's instantiations keep their code.
+    const u32 slot_first = w * EPW + lane;
+    auto slot0 = [&]() { u32 v = slot_first; if constexpr (MERGE) asm volatile("" : "+v"(v)); return v; };
     u32 nbits = 32 - __builtin_clz(c - 1 > 0 ? c - 1 : 1);  // ceil(log2 c)
     if (nbits > SB - skip) nbits = SB - skip;
     const u32 NB = 1u << nbits;  // <= CAP because c <= CAP
@@ -1042,18 +1064,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
                 hb = reinterpret_cast<const u64*>(reinterpret_cast<uintptr_t>(mg.o_hi + a_oth) - 8ull * split);
             }
         }
+        const u32 sl1 = slot0();
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const u32 e = w * EPW + j * 64 + lane;
+            const u32 e = sl1 + j * 64;
             valid[j] = (u32)j < R && e < c;
             const u32 ee = valid[j] ? e : 0u;
             const bool in_a = ee < split;
             key[j] = load_sfx<WS, u64>(in_a ? pa : pb, in_a ? ha : hb, ee, SB);
         }
     } else {
+        const u32 sl2 = slot0();
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const u32 e = w * EPW + j * 64 + lane;
+            const u32 e = sl2 + j * 64;
             valid[j] = (u32)j < R && e < c;
             const u32 ee = valid[j] ? e : 0u;
             key[j] = load_sfx<WS, HiT>(lo, hi, s0 + ee, SB);
@@ -1112,13 +1136,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
     u32 sbase[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) sbase[j] = s_off[sub[j]];
+    const u32 sl3 = slot0();
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
 #if CBLX_MSD_SKIP_SELF
         arr[j] += sbase[j];  // the element's own slot, kept for the ranking loop (same register as the arrival order)
 #endif
         if (valid[j]) {
-            const u32 e = w * EPW + j * 64 + lane;
+            const u32 e = sl3 + j * 64;
 #if CBLX_MSD_SKIP_SELF
             const u32 p = arr[j];
 #else
@@ -1146,12 +1171,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
         else sa[j] = s_off[sub[j]];
         sb[j] = s_off[sub[j] + 1];
     }
+    const u32 sl4 = slot0();
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         head[j] = false;
         fin[j] = 0;
         if (valid[j]) {
-            const u32 e = w * EPW + j * 64 + lane;
+            const u32 e = sl4 + j * 64;
 #if CBLX_MSD_PROBE >= 1 && CBLX_MSD_PROBE <= 2  // timing probe only (wrong order): no ranking reads
             const u32 b = sb[j], a = (!CBLX_MSD_PROBE_MERGE || merging) ? b : ((b - sa[j] > 1u) ? sa[j] : b);
             const u32 a0 = sa[j];
@@ -1275,10 +1301,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
         if (fin[0] != 0x12345u) return;
 #endif
         __syncthreads();  // every read of the sub-bucket order is done
+        const u32 sl5 = slot0();
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             if (valid[j]) {
-                const u32 e = w * EPW + j * 64 + lane;
+                const u32 e = sl5 + j * 64;
                 const u32 fl = (e < cs_m ? 2u : 0u) | (head[j] ? 1u : 0u);
                 if constexpr (PACKED) {
                     s_klo[fin[j]] = (key[j].lo << PK_BITS) | fl;
@@ -1297,9 +1324,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
         //   B = Vec |= x only: other's heads = other \ self, behind self's   (every self element is a head)
         u32 fl[ITEMS];
         u32 nO = 0;
+        const u32 sl6 = slot0();
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const u32 p = w * EPW + j * 64 + lane;
+            const u32 p = sl6 + j * 64;
             const bool live = (u32)j < R && p < c;
             const u32 pc = live ? p : 0u;
             u32 f;

@@ -1465,8 +1465,7 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& s, const Re
     u64* a_lo = nr.a_lo.get();
     HiT* a_hi = WS ? (HiT*)nr.a_hi.get() : (HiT*)nullptr;
     // (Round 5 measured the unions on a second stream beside the counting-sort classes — launched first they take every wave slot and the two run one
-    //  after the other, launched second they share the chip and the pair takes exactly the sum of the two: 10.10 against 10.06 ms. Both sit on the
-    //  memory system — the sort classes move 27 GB through HBM in 7.4 ms by the TCC counters, the unions 9 GB in 2.0 — so one stream it stays.)
+    //  after the other, launched second they share the chip and the pair takes exactly the sum of the two: 10.10 against 10.06 ms. One stream it stays.)
     if (ln[CLS_UNION]) {
         StageTimer t(c, ST_BBIG);
         hipLaunchKernelGGL(k_bucket_union, dim3(ln[CLS_UNION]), dim3(UNI_THREADS), 0, c->stream, lists.get() + (size_t)CLS_UNION * nb, list_n.get() + CLS_UNION, m_cs.get(), m_sstart.get(),
