@@ -49,6 +49,7 @@ PY
       for c in cfg3 cfg4 merge; do
         timeout 2400 python bench.py --config $c --cpu-full --steps 5 --warmup 1 --no-h2d --no-fasta --no-per-record > $OUT/bench_cpufull_$c.json 2> $OUT/bench_cpufull_$c.err; echo "cpu-full $c rc=$?"
       done ;;
-    fuzz) bash tools/fuzz_campaign.sh ${TAG}_fuzz 1211 1220 ;;
+    cpumerge) timeout 2400 python bench.py --config merge --cpu-full --steps 5 --warmup 1 --no-h2d --no-fasta --no-per-record > $OUT/bench_cpufull_merge.json 2> $OUT/bench_cpufull_merge.err; echo "cpu-full merge rc=$?" ;;
+    fuzz) bash tools/fuzz_campaign.sh ${TAG}_fuzz ${FUZZ_FROM:-1211} ${FUZZ_TO:-1220} ;;
   esac
 done
