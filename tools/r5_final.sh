@@ -49,6 +49,8 @@ PY
       for c in cfg3 cfg4 merge; do
         timeout 2400 python bench.py --config $c --cpu-full --steps 5 --warmup 1 --no-h2d --no-fasta --no-per-record > $OUT/bench_cpufull_$c.json 2> $OUT/bench_cpufull_$c.err; echo "cpu-full $c rc=$?"
       done ;;
+    cpu23) timeout 1800 python bench.py --cpu-full --steps 5 --warmup 1 --no-h2d --no-fasta --no-per-record > $OUT/bench_cpufull.json 2> $OUT/bench_cpufull.err; echo "cpu-full cfg2 rc=$?"
+      timeout 2400 python bench.py --config cfg3 --cpu-full --steps 5 --warmup 1 --no-h2d --no-fasta --no-per-record > $OUT/bench_cpufull_cfg3.json 2> $OUT/bench_cpufull_cfg3.err; echo "cpu-full cfg3 rc=$?" ;;
     cpumerge) timeout 2400 python bench.py --config merge --cpu-full --steps 5 --warmup 1 --no-h2d --no-fasta --no-per-record > $OUT/bench_cpufull_merge.json 2> $OUT/bench_cpufull_merge.err; echo "cpu-full merge rc=$?" ;;
     fuzz) bash tools/fuzz_campaign.sh ${TAG}_fuzz ${FUZZ_FROM:-1211} ${FUZZ_TO:-1220} ;;
   esac
