@@ -349,25 +349,69 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify_merge(u64 nb, u32
 // (a[], b[], o[]), half the merge network and a shorter search per round buy more than the extra rounds cost; padding one word per 4 instead of 8: 2.33 / 6.7.
 static const int UNI_THREADS = 128, UNI_ITEMS = 4, UNI_TILE = UNI_THREADS * UNI_ITEMS;
 __device__ __forceinline__ u32 uni_pad(u32 i) { return i + (i >> 3); }
-__device__ __forceinline__ void uni_cmpx(u64& a, u64& b) { const u64 lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; }
+// An element of a union: the suffix alone — one u64, or (hi, lo) for suffixes wider than 64 bits (round 5: those took the sorting
+// classes whatever their kinds; the rings hold their two halves in two arrays of the same shape).
+template <bool WS> struct UniE;
+template <> struct UniE<false> { u64 lo; };
+template <> struct UniE<true> { u64 lo, hi; };
+template <bool WS> __device__ __forceinline__ bool uni_lt(const UniE<WS>& a, const UniE<WS>& b) {
+    if constexpr (WS) return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo);
+    else return a.lo < b.lo;
+}
+template <bool WS> __device__ __forceinline__ bool uni_eq(const UniE<WS>& a, const UniE<WS>& b) {
+    if constexpr (WS) return a.lo == b.lo && a.hi == b.hi;
+    else return a.lo == b.lo;
+}
+template <bool WS> __device__ __forceinline__ UniE<WS> uni_inf() {
+    UniE<WS> e;
+    e.lo = ~0ull;
+    if constexpr (WS) e.hi = ~0ull;
+    return e;
+}
+// (selects word by word: a select between two structs sends the arrays they sit in to scratch memory — 224 bytes per lane and 1.4 TB/s
+//  as first written)
+template <bool WS> __device__ __forceinline__ UniE<WS> uni_sel(bool take_a, const UniE<WS>& a, const UniE<WS>& b) {
+    UniE<WS> e;
+    e.lo = take_a ? a.lo : b.lo;
+    if constexpr (WS) e.hi = take_a ? a.hi : b.hi;
+    return e;
+}
+template <bool WS> __device__ __forceinline__ void uni_cmpx(UniE<WS>& a, UniE<WS>& b) {
+    const bool sw = uni_lt<WS>(b, a);
+    const UniE<WS> lo = uni_sel<WS>(sw, b, a), hi = uni_sel<WS>(sw, a, b);
+    a = lo;
+    b = hi;
+}
+template <bool WS>
 __global__ __launch_bounds__(UNI_THREADS) void k_bucket_union(const BDesc* __restrict__ list, const u32* __restrict__ list_n, const u32* __restrict__ m_cs,
                                                               const u64* __restrict__ m_sstart, const u64* __restrict__ m_ostart, const u64* __restrict__ s_lo,
-                                                              const u64* __restrict__ o_lo, u64* __restrict__ out_lo, u32 SB, u32* __restrict__ out_count,
+                                                              const u64* __restrict__ s_hi, const u64* __restrict__ o_lo, const u64* __restrict__ o_hi,
+                                                              u64* __restrict__ out_lo, u64* __restrict__ out_hi, u32 SB, u32* __restrict__ out_count,
                                                               u8* __restrict__ out_kind) {
+    typedef UniE<WS> E;
     constexpr int NW = UNI_THREADS / 64;
     constexpr u32 T = UNI_TILE;
     static_assert((T & (T - 1)) == 0, "the staging rings index by g mod T");
-    __shared__ u64 s_in[T * 2 + (T * 2) / 8 + 8];  // A's ring at logical [0, T), B's at [T, 2T); the round's outputs in the slots it consumed
+    constexpr u32 SLOTS = T * 2 + (T * 2) / 8 + 8;
+    __shared__ u64 s_in[SLOTS];  // A's ring at logical [0, T), B's at [T, 2T); the round's outputs in the slots it consumed
+    __shared__ u64 s_inh[WS ? SLOTS : 1];  // (wide suffixes: the high halves, same slots)
     __shared__ u32 s_split[NW + 1];
     __shared__ u32 s_wtot[NW + 1];
     if (blockIdx.x >= *list_n) return;
     const BDesc dsc = list[blockIdx.x];
     const u32 r = dsc.r, c = dsc.c & BDESC_LEN_MASK, cs = m_cs[r], co = c - cs;
-    const u64* __restrict__ A = s_lo + m_sstart[r];
-    const u64* __restrict__ B = o_lo + m_ostart[r];
+    const u64 a_self = m_sstart[r], a_oth = m_ostart[r];
+    const u64* __restrict__ A = s_lo + a_self;
+    const u64* __restrict__ B = o_lo + a_oth;
+    const u64* __restrict__ Ah = WS ? s_hi + a_self : nullptr;
+    const u64* __restrict__ Bh = WS ? o_hi + a_oth : nullptr;
     u64* __restrict__ dst = out_lo + dsc.start;
-    const u64 mask = SB >= 64 ? ~0ull : ((1ull << SB) - 1ull);
+    u64* __restrict__ dsth = WS ? out_hi + dsc.start : nullptr;
+    // narrow: suffix = lo & mask; wide: (hi & mask(SB - 64), lo)
+    const u64 mask = WS ? ((1ull << (SB - 64)) - 1ull) : (SB >= 64 ? ~0ull : ((1ull << SB) - 1ull));
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    auto get = [&](u32 slot) { E e; e.lo = s_in[slot]; if constexpr (WS) e.hi = s_inh[slot]; return e; };
+    auto put = [&](u32 slot, const E& e) { s_in[slot] = e.lo; if constexpr (WS) s_inh[slot] = e.hi; };
     // The two staging areas are RINGS of T slots (round 5): word g of a list lives in slot g mod T of its ring, a round consumes nout
     // words — iend from A, the rest from B — and only those nout slots are refilled in front of the next round; the round's outputs pass
     // through exactly the slots it freed. As first written every round staged the next T words of BOTH lists again and consumed T in
@@ -375,21 +419,27 @@ __global__ __launch_bounds__(UNI_THREADS) void k_bucket_union(const BDesc* __res
     // 4.0 GB of lists by the TCC counters (profiles/r05_merge_hbm_traffic.md).
     u32 ia = 0, ib = 0, written = 0;
     u32 ha = 0, hb = 0;  // words of A from ia / of B from ib already in the rings
-    u64 carry = 0;
+    E carry = uni_inf<WS>();
     bool have_carry = false;
     auto ra = [&](u32 g) { return uni_pad(g & (T - 1)); };
     auto rb = [&](u32 g) { return uni_pad(T + (g & (T - 1))); };
     while (ia < cs || ib < co) {
         const u32 na = cs - ia < T ? cs - ia : T, nb = co - ib < T ? co - ib : T, nout = na + nb < T ? na + nb : T;
-        for (u32 g = ia + ha + tid; g < ia + na; g += UNI_THREADS) s_in[ra(g)] = A[g] & mask;
-        for (u32 g = ib + hb + tid; g < ib + nb; g += UNI_THREADS) s_in[rb(g)] = B[g] & mask;
+        for (u32 g = ia + ha + tid; g < ia + na; g += UNI_THREADS) {
+            if constexpr (WS) { s_in[ra(g)] = A[g]; s_inh[ra(g)] = Ah[g] & mask; }
+            else s_in[ra(g)] = A[g] & mask;
+        }
+        for (u32 g = ib + hb + tid; g < ib + nb; g += UNI_THREADS) {
+            if constexpr (WS) { s_in[rb(g)] = B[g]; s_inh[rb(g)] = Bh[g] & mask; }
+            else s_in[rb(g)] = B[g] & mask;
+        }
         __syncthreads();
         // co-rank of the end of this thread's outputs: how many of the first d1 outputs come from A
         const u32 d0 = tid * UNI_ITEMS < nout ? tid * UNI_ITEMS : nout, d1 = (tid + 1) * UNI_ITEMS < nout ? (tid + 1) * UNI_ITEMS : nout;
         u32 lo = d1 > nb ? d1 - nb : 0u, hi = d1 < na ? d1 : na;
         while (lo < hi) {
             const u32 mid = (lo + hi) >> 1;
-            if (s_in[ra(ia + mid)] <= s_in[rb(ib + d1 - 1 - mid)]) lo = mid + 1; else hi = mid;
+            if (!uni_lt<WS>(get(rb(ib + d1 - 1 - mid)), get(ra(ia + mid)))) lo = mid + 1; else hi = mid;  // A[mid] <= B[d1 - 1 - mid]: ties take self's copy first
         }
         const u32 i1 = lo;
         if (lane == 63) s_split[w + 1] = i1;
@@ -399,46 +449,44 @@ __global__ __launch_bounds__(UNI_THREADS) void k_bucket_union(const BDesc* __res
         if (lane == 0) i0 = s_split[w];
         const u32 iend = s_split[NW];  // co-rank of nout (the last thread's end)
         const u32 j0 = d0 - i0;
-        u64 a[UNI_ITEMS], b[UNI_ITEMS];
+        E a[UNI_ITEMS], b[UNI_ITEMS];
 #pragma unroll
         for (int k = 0; k < UNI_ITEMS; ++k) {
             const u32 x = i0 + k, y = j0 + k;
-            a[k] = s_in[ra(ia + (x < na ? x : 0u))];
-            b[k] = s_in[rb(ib + (y < nb ? y : 0u))];
-            if (x >= na) a[k] = ~0ull;
-            if (y >= nb) b[k] = ~0ull;
+            a[k] = uni_sel<WS>(x < na, get(ra(ia + (x < na ? x : 0u))), uni_inf<WS>());
+            b[k] = uni_sel<WS>(y < nb, get(rb(ib + (y < nb ? y : 0u))), uni_inf<WS>());
         }
-        u64 o[UNI_ITEMS];
+        E o[UNI_ITEMS];
 #pragma unroll
-        for (int k = 0; k < UNI_ITEMS; ++k) o[k] = a[k] < b[UNI_ITEMS - 1 - k] ? a[k] : b[UNI_ITEMS - 1 - k];
+        for (int k = 0; k < UNI_ITEMS; ++k) o[k] = uni_sel<WS>(uni_lt<WS>(a[k], b[UNI_ITEMS - 1 - k]), a[k], b[UNI_ITEMS - 1 - k]);
 #pragma unroll
         for (int st = UNI_ITEMS / 2; st >= 1; st >>= 1)
 #pragma unroll
             for (int k = 0; k < UNI_ITEMS; ++k)
-                if ((k & st) == 0) uni_cmpx(o[k], o[k + st]);
+                if ((k & st) == 0) uni_cmpx<WS>(o[k], o[k + st]);
         __syncthreads();  // every read of the chunks is done: the outputs take the place of what the round consumed
         // output q of the round sits in the q-th freed slot: A's ring first (iend of them), then B's
         auto oslot = [&](u32 q) { return q < iend ? ra(ia + q) : rb(ib + (q - iend)); };
 #pragma unroll
         for (int k = 0; k < UNI_ITEMS; ++k) {
             const u32 q = tid * UNI_ITEMS + k;
-            if (q < nout) s_in[oslot(q)] = o[k];  // (nothing past nout: those slots hold words of the next round)
+            if (q < nout) put(oslot(q), o[k]);  // (nothing past nout: those slots hold words of the next round)
         }
         __syncthreads();
         // ordered compaction of the outputs that differ from their predecessor (wave-contiguous slices keep the order)
-        u64 v[UNI_ITEMS];
+        E v[UNI_ITEMS];
         bool head[UNI_ITEMS];
         u32 wh = 0;
 #pragma unroll
         for (int j = 0; j < UNI_ITEMS; ++j) {
             const u32 p = w * (64 * UNI_ITEMS) + j * 64 + lane;
             const bool live = p < nout;
-            v[j] = s_in[oslot(live ? p : 0u)];
-            const u64 u = s_in[oslot((live && p) ? p - 1 : 0u)];
-            head[j] = live && (p ? v[j] != u : (!have_carry || v[j] != carry));
+            v[j] = get(oslot(live ? p : 0u));
+            const E u = get(oslot((live && p) ? p - 1 : 0u));
+            head[j] = live && (p ? !uni_eq<WS>(v[j], u) : (!have_carry || !uni_eq<WS>(v[j], carry)));
             wh += (u32)__builtin_popcountll(__ballot(head[j]));
         }
-        const u64 last = s_in[oslot(nout - 1)];
+        const E last = get(oslot(nout - 1));
         if (lane == 0) s_wtot[w] = wh;
         __syncthreads();
         u32 run = 0, tot = 0;
@@ -447,7 +495,10 @@ __global__ __launch_bounds__(UNI_THREADS) void k_bucket_union(const BDesc* __res
 #pragma unroll
         for (int j = 0; j < UNI_ITEMS; ++j) {
             const u64 bal = __ballot(head[j]);
-            if (head[j]) dst[written + run + mbcnt(bal)] = v[j];
+            if (head[j]) {
+                dst[written + run + mbcnt(bal)] = v[j].lo;
+                if constexpr (WS) dsth[written + run + mbcnt(bal)] = v[j].hi;
+            }
             run += (u32)__builtin_popcountll(bal);
         }
         carry = last;

@@ -1428,10 +1428,10 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& s, const Re
     const u64 nb = nr.nb;
     nr.a_lo = Buf<u64>(c->pool, N + 2);
     if (WS) nr.a_hi = Buf<u64>(c->pool, N + 2);
-    // Trie |= Trie (both lists ascending): merged by k_bucket_union straight from the two arenas — not gathered, not sorted again.
-    // Narrow suffixes; CBLX_MERGE_UNION=0 keeps the counting-sort route (tests compare the two)
+    // Trie |= Trie (both lists ascending): merged by k_bucket_union straight from the two arenas — not gathered, not sorted again
+    // (wide suffixes too since round 5: two-word elements). CBLX_MERGE_UNION=0 keeps the counting-sort route (tests compare the two)
     const char* union_env = std::getenv("CBLX_MERGE_UNION");  // (read per call: tests switch it)
-    const bool union_path = !WS && !(union_env && union_env[0] == '0');
+    const bool union_path = !(union_env && union_env[0] == '0');
     // both-sided buckets of up to 4096 words (the counting-sort classes) are read where they are stored: their kernel loads self's part from
     // self's arena and other's from other's, and only the result is written — the gather moved 16 bytes per word for nothing.
     // CBLX_MERGE_DIRECT=0 gathers them as before
@@ -1468,8 +1468,9 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& s, const Re
     //  after the other, launched second they share the chip and the pair takes exactly the sum of the two: 10.10 against 10.06 ms. One stream it stays.)
     if (ln[CLS_UNION]) {
         StageTimer t(c, ST_BBIG);
-        hipLaunchKernelGGL(k_bucket_union, dim3(ln[CLS_UNION]), dim3(UNI_THREADS), 0, c->stream, lists.get() + (size_t)CLS_UNION * nb, list_n.get() + CLS_UNION, m_cs.get(), m_sstart.get(),
-                           m_ostart.get(), (const u64*)s.a_lo.get(), (const u64*)o.a_lo.get(), a_lo, P.SB, nr.cnt.get(), nr.kind.get());
+        hipLaunchKernelGGL((k_bucket_union<WS>), dim3(ln[CLS_UNION]), dim3(UNI_THREADS), 0, c->stream, lists.get() + (size_t)CLS_UNION * nb, list_n.get() + CLS_UNION, m_cs.get(), m_sstart.get(),
+                           m_ostart.get(), (const u64*)s.a_lo.get(), (const u64*)s.a_hi.get(), (const u64*)o.a_lo.get(), (const u64*)o.a_hi.get(), a_lo, (u64*)nr.a_hi.get(), P.SB,
+                           nr.cnt.get(), nr.kind.get());
         CBLX_HIP(hipGetLastError());
     }
     {
