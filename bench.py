@@ -148,6 +148,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-full", action="store_true", help="time the CPU oracle on the whole workload (cfg 2: about 10 minutes) and compare the index bytes of both sides (parity_full_size); "
                     "--config merge: the oracle builds both operands, merges them, and both resulting indexes are compared")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-sample", action="store_true", help="skip parity_sample (the CPU leg's sample built once more on the GPU after the timed region, bytes against the oracle's)")
+    ap.add_argument("--no-set-check", action="store_true", help="N > 1: skip set_check (count / checksum / validate / membership of the sharded index against every rank's own word stream)")
     ap.add_argument("--no-serialize", action="store_true", help="skip the serialize leg (index bytes into a host buffer)")
     ap.add_argument("--merge-clone", action="store_true", help="--config merge on one GPU: a step = clone A into the work index, then `|=` (the round-4 step) instead of cblx_merge_from")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive measurement (value_h2d_inclusive)")
@@ -201,7 +203,7 @@ def build_in_child():
             fcntl.flock(lk, fcntl.LOCK_UN)
 
 
-def cpu_baseline_leg(args, genome_reads=None, keep=None):
+def cpu_baseline_leg(args, genome_reads=None, keep=None, keep_sample=None):
     """The CPU oracle (C++ port of the reference algorithm, oracle/) on a bounded sample of the same reads, 1 thread: one
     insert_seq call per read. Needs no GPU and no process group: at N > 1 rank 0 runs it BEFORE the group is formed (the other
     ranks wait in the rendezvous), so every line of a scaling run carries it."""
@@ -228,6 +230,8 @@ def cpu_baseline_leg(args, genome_reads=None, keep=None):
         curve.append(round(m * (L - K + 1) / s1 / 1e6, 2))
     if keep is not None and ns == NR:  # --cpu-full: the finished oracle index is what the GPU's bytes are compared with (parity_full_size)
         keep.append(orc)
+    elif keep_sample is not None and genome_reads is None:  # the default run: the oracle's index of the sample is the checker of `parity_sample`
+        keep_sample.append((orc, ns))
     return {"value": round(ns * (L - K + 1) / secs, 1), "unit": "k-mers/s", "cores": 1, "kind": "port",
             "sample": (f"all {ns} reads" if ns == NR else f"first {ns} of rank 0's reads") + f" (seed 42), one insert_seq call per read, {secs:.1f} s"
                       + ("" if ns == NR else "; throughput falls as the index grows, so the full-size CPU figure is lower (profiles/ holds a full run)"),
@@ -301,6 +305,78 @@ def merge_parity_full_size(args, work, other, kmers_b):
            "sample": f"the oracle's merge of the two full indexes ({NR} reads each, seeds 42 / 43): {tm:.1f} s (their builds, one insert_seq per read: {sa:.0f} + {sb:.0f} s)",
            "mkmers_per_s_by_1M_read_block": None, "host_cores_available": os.cpu_count()}
     return rec, cpu
+
+
+def parity_sample_leg(args, orc, ns, d_bases, d_offsets, device):
+    """The default run's own parity verdict: the reads the CPU leg timed (the first `ns` of rank 0's) built once more on the GPU — after the
+    timed region, in a context of their own — and the serialized bytes compared with the oracle's index of exactly those reads, which the CPU
+    leg built anyway. Length, SHA-256 of both sides, first differing byte. The oracle is the checker, never the thing measured."""
+    import cbl_amd
+
+    K, PB, L = args.k, args.prefix_bits, args.read_len
+    g = cbl_amd.CBL(K, PB, canonical=args.canonical, device=device)
+    try:
+        g.insert_seqs_device(d_bases[: ns * L], d_offsets[: ns + 1], ns)
+        rec = parity_full_size(g, orc, ns * (L - K + 1))
+    finally:
+        g.close()
+    rec["reads"] = int(ns)
+    rec["what"] = (f"cblx_serialize of a GPU build of the first {ns} of rank 0's reads (the CPU leg's sample, built after the timed region in a context of its own) vs the "
+                   "CPU oracle's serialize of the index the cpu_baseline leg built from the same reads: same length, same SHA-256, no differing byte")
+    return rec
+
+
+def set_check_leg(args, cbl, d_bases, d_offsets, rank, world, dev, reduce_sums):
+    """An N > 1 line's own correctness verdict on the SHARDED index the timed steps left (every rank holds its prefix range):
+      - `count` (all-reduced) against the k-mers inserted: the difference is the repeats of the stream (iid 31-mers: n^2 / 2 / 4^K of them);
+      - the set checksum (a sum of word hashes, all-reduced) against the same sum over every rank's OWN word stream (KRN-1 alone): equal when
+        the stream holds no repeat — with repeats the index sum is the smaller by their hashes and `checksums_equal` is null;
+      - `validate()` of every share (prefix in range and in its bucket, Trie runs ascending, no repeat inside a bucket), all-reduced;
+      - membership: every rank's reads (regenerated here, seed 42) queried against THIS rank's share; summed over the shares every inserted
+        k-mer must be found exactly once — a word that went to the wrong rank, or was lost on the way, is missing here.
+    `reduce_sums(list of ints) -> list of ints` sums over the ranks (values < 2^62)."""
+    import torch
+
+    from cbl_amd import synth
+
+    K, L, NR = args.k, args.read_len, args.reads
+    n_kmers = NR * (L - K + 1)
+    M32 = (1 << 32) - 1
+    cnt, cs, bad = cbl.count(), cbl.checksum(), cbl.validate()
+    lo = torch.empty(n_kmers + 1, dtype=torch.int64, device=dev)
+    hb = cbl.consts()["hi_bytes"]
+    hi = None if hb == 0 else torch.zeros(n_kmers + 1, dtype=torch.uint8 if hb == 1 else torch.int64, device=dev)
+    nw = cbl.seq_words_device(d_bases, d_offsets, NR, lo, hi, n_kmers)
+    cs_w = cbl.checksum_words_device(lo, hi, nw)
+    del lo, hi
+    found = queried = 0
+    for r in range(world):
+        if r == rank or args.genome:
+            qb, qo = d_bases, d_offsets
+        else:
+            qb, qo = synth.reads_torch(42, NR, L, first_read=r * NR, device=dev)
+        t, f = cbl.contains_seqs_device(qb, qo, NR)
+        queried += t
+        found += f
+        del qb, qo
+        if args.genome:
+            break
+    tot = reduce_sums([cnt, cs & M32, cs >> 32, bad, nw, cs_w & M32, cs_w >> 32, found, queried])
+    cs_index = (tot[1] + (tot[2] << 32)) & ((1 << 64) - 1)
+    cs_stream = (tot[5] + (tot[6] << 32)) & ((1 << 64) - 1)
+    repeats = tot[4] - tot[0]
+    expected_found = tot[4] if not args.genome else None  # every share was asked about every rank's reads
+    members_ok = None if args.genome else (tot[7] == expected_found and tot[8] == world * tot[4])
+    # iid reads: repeats ~ n^2 / (2 * 4^K) (+ the all-ones / low-complexity words count as any other); anything above a generous multiple is a loss
+    bound = None if args.genome else int(8 * tot[4] * tot[4] / (2 * 4.0 ** K)) + 64
+    ok = (tot[3] == 0 and repeats >= 0 and (bound is None or repeats <= bound) and (members_ok is not False)
+          and (repeats != 0 or cs_index == cs_stream))
+    return {"ok": bool(ok), "count": int(tot[0]), "kmers_inserted": int(tot[4]), "repeats_implied": int(repeats), "repeats_bound": bound,
+            "checksum_index": f"{cs_index:016x}", "checksum_word_streams": f"{cs_stream:016x}",
+            "checksums_equal": (cs_index == cs_stream) if repeats == 0 else None,
+            "validate_violations": int(tot[3]), "members_found": int(tot[7]), "members_expected": expected_found, "members_ok": members_ok,
+            "what": "sharded index after the timed steps: all-reduced cblx_count / cblx_checksum / cblx_validate of the shares; cblx_checksum_words_device over every "
+                    "rank's own KRN-1 word stream; every rank's reads (regenerated) through cblx_contains_seqs_device against every share, positives summed"}
 
 
 # ---- launcher: `python bench.py --gpus N` without torchrun -------------------------------------------------------------
@@ -455,8 +531,9 @@ def main():
     # the CPU leg first: no GPU, no process group (rank 0 only; at N > 1 the other ranks wait for it in the rendezvous)
     cpu_early = None
     oracle_full = []  # --cpu-full: the oracle's finished index of ALL of rank 0's reads, the checker of parity_full_size
+    oracle_sample = []  # the default run: (oracle, reads) of the CPU leg's sample, the checker of parity_sample
     if rank == 0 and not args.no_cpu_baseline and args.kind == "build" and not args.genome:
-        cpu_early = cpu_baseline_leg(args, keep=oracle_full)
+        cpu_early = cpu_baseline_leg(args, keep=oracle_full, keep_sample=None if args.no_parity_sample else oracle_sample)
 
     import torch
 
@@ -665,8 +742,11 @@ def main():
             row.update({"alg_bytes_per_launch": int(bpl), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4)})
         kernels.append(row)
     kernels.sort(key=lambda x: -x["ms_per_step"])
-    for row in kernels:  # an algorithmic rate above the peak is a bookkeeping error, never a result
-        assert row["frac"] is None or row["frac"] <= 1.0, f"stage {row['stage']}: algorithmic rate {row['achieved']} GB/s above the HBM peak"
+    roofline_error = None
+    for row in kernels:  # an algorithmic rate above the peak is a bookkeeping error, never a result: the row loses its fraction, the line says so and the run fails AFTER printing
+        if row["frac"] is not None and row["frac"] > 1.0:
+            roofline_error = (roofline_error or "") + f"stage {row['stage']}: algorithmic rate {row['achieved']} GB/s above the HBM peak (pricing error); "
+            row["frac_error"], row["frac"] = row["frac"], None
     roofline = None
     if kernels:
         dom = kernels[0]
@@ -705,6 +785,22 @@ def main():
     # chunk-by-chunk comparison. The oracle is the checker here, never the thing measured.
     if args.kind == "build" and oracle_full and world == 1 and engine is None:
         extra["parity_full_size"] = parity_full_size(cbl, oracle_full.pop(), kmers_per_rank)
+
+    # the line's own correctness evidence: the sharded index against every rank's word stream (N > 1), and the CPU leg's sample
+    # rebuilt on the GPU and byte-compared with the oracle's index of it (rank 0)
+    if args.kind == "build" and engine is not None and world > 1 and not args.no_set_check:
+        def reduce_sums(vals):
+            t = torch.tensor(vals, dtype=torch.int64, device=dev)
+            dist.all_reduce(t)
+            return [int(x) for x in t.cpu().tolist()]
+        extra["set_check"] = set_check_leg(args, cbl, d_bases, d_offsets, rank, world, dev, reduce_sums)
+    if args.kind == "build" and oracle_sample:
+        orc_s, ns_s = oracle_sample.pop()
+        try:
+            extra["parity_sample"] = parity_sample_leg(args, orc_s, ns_s, d_bases, d_offsets, local_rank)
+        except Exception as e:  # (the line must come out: the verdict is then "not equal")
+            extra["parity_sample"] = {"equal": False, "error": f"{type(e).__name__}: {e}"}
+        del orc_s
 
     # what the N-GPU code path costs a rank over the direct build of the same reads (no exchange, no slices): the direct steps
     # run AFTER the timed region, each rank on its own reads
@@ -888,6 +984,8 @@ def main():
             "value_h2d_inclusive": h2d["value"] if h2d else None, "h2d_inclusive": h2d,
             "roofline": roofline, "cpu_baseline": cpu, "exchange": exchange,
         }
+        if roofline_error:
+            out["roofline_error"] = roofline_error
         out.update(extra)
     if dist is not None:
         dist.barrier()
@@ -896,6 +994,9 @@ def main():
         sys.stdout.flush()
         sys.stdout.write("\n" + json.dumps(out) + "\n")
         sys.stdout.flush()
+    bad = roofline_error is not None or (extra.get("parity_sample") or {}).get("equal") is False or (extra.get("set_check") or {}).get("ok") is False
+    if bad:  # the measurements are on stdout; a pricing slip, a differing byte or a failed set check still fails the run
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -65,6 +65,8 @@ class BatchView(C.Structure):
 
 BUCKET_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 
+ABI_VERSION = 3  # include/cblx.h CBLX_ABI_VERSION
+
 # name -> (restype, argtypes): every symbol include/cblx.h declares
 SIGNATURES = {
     "cblx_abi_version": (C.c_uint32, []),
@@ -167,6 +169,9 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if not os.environ.get("CBLX_LIB_PATH") and L.cblx_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} reports ABI version {L.cblx_abi_version()}, this binding was written against {ABI_VERSION} "
+                              "(include/cblx.h CBLX_ABI_VERSION): rebuild with __graft_entry__.build()")
         _LIB = L
     return _LIB
 

@@ -856,19 +856,25 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     }
     const u64 LIMIT = 0xFFFFFFF0ull - 2 * RDX_TILE;
     // (every term of the decision below is replicated: a rank that alone holds 2^32 k-mers says so through the sum)
-    u64 agree[3] = {mine, c->res.count != 0 ? 1ull : 0ull, mine >= LIMIT ? 1ull : 0ull};
-    T.all_reduce_sum_u64(agree, 3);
-    const u64 job = agree[0];
-    if (!M.ok || agree[1] != 0 || agree[2] != 0 || job / W + job / (2 * W) + (1u << 20) >= LIMIT) return false;
-    if (single && mine < fine_min_words()) return false;  // (a small batch: the groups' fixed costs outweigh the pass saved)
-    const bool trace = std::getenv("CBLX_TRACE_SHARDED") != nullptr;
-    const LsdPlan LP = fine ? lsd_plan_bits(FINE_LEVEL) : lsd_plan(P, false);  // (the receiver runs LSD passes only: pipeline.hpp; FINE bins: the first digit is the same for 16 and 24 sorted bits)
     // The digit side channel of the receiver's first LSD pass (1 byte per word) stays OFF the wire by default (round 5): at 8 GPUs and 55 GB/s per
     // link the step is bound by the wire from the first group on, the byte is a ninth of it, and the receiver's first histogram
     // reads the records instead (8 bytes per word where it read 1: about the millisecond the senders' byte stores cost). CBLX_WIRE_DIGITS=1 sends
     // it as rounds 3 - 4 did; one rank (no wire) always keeps it.
     const char* wd_env = std::getenv("CBLX_WIRE_DIGITS");
     const bool wire_dig = single || (wd_env && wd_env[0] == '1');
+    // What crosses the wire follows from switches every rank reads in its OWN environment (CBLX_FINE_BINS, CBLX_WIRE_DIGITS, CBLX_FINE_TAIL_WEIGHT,
+    // CBLX_RECV_GROUPS): they are job-wide. A rank started with other values would wait for items its peers never send, or bin records by another
+    // table — so the resolved choices ride in the all-reduce below (sum and sum of squares: equal on every rank iff W x sum(v^2) = sum(v)^2).
+    const u64 choice = (fine ? 1ull : 0ull) | (wire_dig ? 2ull : 0ull) | ((u64)G << 2) | (std::min<u64>(fine_tail_weight_pct(), 0xFFFFull) << 8);
+    u64 agree[5] = {mine, c->res.count != 0 ? 1ull : 0ull, mine >= LIMIT ? 1ull : 0ull, choice, choice * choice};
+    T.all_reduce_sum_u64(agree, 5);
+    if (agree[4] * W != agree[3] * agree[3])
+        throw Error(CBLX_EINVAL, "sharded build: the ranks resolved CBLX_FINE_BINS / CBLX_WIRE_DIGITS / CBLX_FINE_TAIL_WEIGHT / CBLX_RECV_GROUPS differently (they are job-wide: set them in every rank's environment)");
+    const u64 job = agree[0];
+    if (!M.ok || agree[1] != 0 || agree[2] != 0 || job / W + job / (2 * W) + (1u << 20) >= LIMIT) return false;
+    if (single && mine < fine_min_words()) return false;  // (a small batch: the groups' fixed costs outweigh the pass saved)
+    const bool trace = std::getenv("CBLX_TRACE_SHARDED") != nullptr;
+    const LsdPlan LP = fine ? lsd_plan_bits(FINE_LEVEL) : lsd_plan(P, false);  // (the receiver runs LSD passes only: pipeline.hpp; FINE bins: the first digit is the same for 16 and 24 sorted bits)
     const DigitBits nextd = wire_dig ? DigitBits{P.SB + LP.sh[0], LP.wid[0]} : DigitBits{0, 0};
     Buf<u32> d_tab(c->pool, DigitCut::LDS_WORDS);  // CutCell[CUT_KEYS], or u32[FINE_CELLS]: staged in LDS by the kernels that look bins up
     if (fine) h2d(c, d_tab.get(), FM.tab32.data(), FM.tab32.size());
@@ -1120,7 +1126,11 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
             for (u32 cl = gc0[g]; cl < gc0[g + 1]; ++cl) {
                 const u32 bin = my_lo + cl, iv = M.iv_of[bin];
                 if (iv == 0xFFFFFFFFu) continue;
-                segp[FM.seg_of[bin]] = bin == 255 ? (u32)((1ull << P.PB) - 1) : (FM.first[iv] >> FM.level[iv]) << FM.level[iv];
+                // (the all-ones bin: the block of 2^sort_bits prefixes that ends at 2^PREFIX_BITS — its records OR their low bits back in and land
+                // on the all-ones prefix; with the all-ones prefix ITSELF as the base every row of k_dir_gather's table for this segment
+                // mapped to that one prefix, one of them with the real start and the others with EMPTY, unordered)
+                const u32 sbg = FM.sort_bits[me][g];
+                segp[FM.seg_of[bin]] = bin == 255 ? (u32)((((1ull << P.PB) - 1) >> sbg) << sbg) : (FM.first[iv] >> FM.level[iv]) << FM.level[iv];
             }
         for (size_t p = 0; p < np; ++p) {
             u64 before = 0;

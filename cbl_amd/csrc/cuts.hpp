@@ -283,11 +283,14 @@ inline FinePlan make_fine_plan(u32 PB, u32 lmax, const u32* bounds, u32 W, const
 // each other at 55 GB/s per link and without a wire (47.6 / 46.5 and 45.4 / 46.2 ms with 8-byte records on the wire; 1.12: 46.4 / 48.3,
 // 1.28: 47.6 / 45.6 — box-to-box noise is a millisecond). (A heuristic: the factor is cfg 3's; any bounds are correct, only the balance
 // depends on it. CBLX_FINE_TAIL_WEIGHT overrides it in percent, 100 = off.)
+inline u64 fine_tail_weight_pct() {  // (job-wide like every switch that shapes the plan: comm.hpp checks that the ranks agree)
+    const char* we = std::getenv("CBLX_FINE_TAIL_WEIGHT");
+    return we ? std::strtoull(we, nullptr, 10) : 120;
+}
 inline void weigh_tail_for_fine_bins(std::vector<u64>& hist, u32 PB, u32 W, u32 G, u32 hb) {
     const char* fe = std::getenv("CBLX_FINE_BINS");
     if (PB <= 24 || PB > 28 || W < 2 || (fe && fe[0] == '0') || hb + FINE_LEVEL < PB) return;  // (cells must not be wider than 2^16 prefixes)
-    const char* we = std::getenv("CBLX_FINE_TAIL_WEIGHT");
-    const u64 pct = we ? std::strtoull(we, nullptr, 10) : 120;
+    const u64 pct = fine_tail_weight_pct();
     if (pct == 100 || pct == 0) return;
     const u64 forced = (u64)W * G - 1, fixed = 8;  // rank bounds + group cuts, the multiples of 2^lmax
     if (forced + fixed + 16 >= FINE_MAX_CUTS) return;

@@ -1045,6 +1045,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
     __shared__ u32 s_wtot[NW + 1];
     __shared__ u32 s_max;
     __shared__ u32 s_sel[MERGE ? NW : 1];  // merge epilogue: per-wave counts of its three selections (10-bit fields)
+    static_assert(!MERGE || 64 * ITEMS < 1024, "the merge epilogue counts a wave's selections in 10-bit fields: a wave owns fewer than 1024 slots");
 
     if (blockIdx.x >= *list_n) return;
     const BDesc dsc = list[blockIdx.x];
@@ -1521,6 +1522,183 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
     if (tid == 0) {
         out_count[r] = d;
         out_kind[r] = trie ? KIND_TRIE : KIND_VEC;
+    }
+}
+
+// ---- KRN-3, runs that end up SORTED (more than 1024 words, or a bucket that is a Trie already), narrow packed elements (round 6) --------
+// k_bucket_msd ranks every element inside its sub-bucket by reading the whole sub-bucket: s reads per element, and under the top
+// suffix bits — the only kind of sub-bucket a sorted result allows — an element shares its sub-bucket with 6.5 others on average and
+// up to 45 (necklace clusters): 60 random 8-byte LDS reads per lane of eight slots, issued slot by slot in loops whose
+// trip count is the LARGEST sub-bucket among the wave's 64 lanes (162 LDS instructions per wave, the LDS array 74 % busy, 42 % of it
+// bank conflicts: profiles/r05_sq_counters.md). Here the ranking is turned around: after the same counting sort into sub-bucket order,
+// a lane OWNS eight consecutive positions of that order — entries of the same one or two sub-buckets — and walks ONCE over the span from
+// the start of its first entry's sub-bucket to the end of its last entry's, comparing every entry it reads with all eight of its own
+// (registers). Everything in front of the span is smaller than the lane's entries and everything behind it greater (the sub-buckets are
+// ascending), so final rank = span start + entries of the span that compare less: one LDS read serves eight comparisons, 16 - 25 reads
+// per lane instead of 60, and a lane's reads step through consecutive slots (the array is padded by one slot per eight, so that the
+// 64 lanes' slots of one step spread over the banks: stride 9 words). Repeats are settled AFTER the sort — an element is the head of its
+// value iff the slot in front of it holds another suffix — so the inner loop is one 64-bit compare and one add per pair.
+// Outcome as k_bucket_msd's: the ascending distinct list, KIND_TRIE. A run that turns out to stay a Vec (a run of more than 1024 words
+// with at most 1024 distinct ones, not a Trie yet — repeats) has written nothing yet and is handed on like a crowded one (claim table).
+#ifndef CBLX_SORTED_WAVES
+#define CBLX_SORTED_WAVES 7
+#endif
+template <int THREADS, int CAP, typename HiT>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 4096 ? 6 : CBLX_SORTED_WAVES, 8))) void k_bucket_sorted(
+    const BDesc* __restrict__ list, const u32* __restrict__ list_n, u64* __restrict__ lo, u32 SB, u32* __restrict__ out_count, u8* __restrict__ out_kind,
+    BDesc* __restrict__ retry, u32* __restrict__ retry_n, u8* __restrict__ bail_flag = nullptr, u32* __restrict__ bail_any = nullptr) {
+    static_assert(CAP <= (1 << PK_BITS), "stream index must fit PK_BITS");
+    constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
+    static_assert(ITEMS == 8, "a lane owns eight slots: the padding below is one slot per eight");
+    __shared__ u64 s_k[CAP + CAP / 8 + 4];  // slot p lives at p + p / 8; + the all-ones slots behind the run
+    __shared__ u32 s_off32[CAP / 2 + 2];    // sub-bucket counts, then exclusive offsets: 16-bit entries, counted with 32-bit atomics on the containing dword
+    u16* s_off = reinterpret_cast<u16*>(s_off32);
+    __shared__ u32 s_scan[NW + 1];
+    __shared__ u32 s_wtot[NW + 1];
+    __shared__ u32 s_max;
+    auto pad = [](u32 p) { return p + (p >> 3); };
+
+    if (blockIdx.x >= *list_n) return;
+    const BDesc dsc = list[blockIdx.x];
+    const u32 r = dsc.r;
+    const u64 s0 = dsc.start;
+    const u32 c = dsc.c & BDESC_LEN_MASK;
+    const u32 skip = (dsc.c & BDESC_SKIP_MASK) >> BDESC_SKIP_SHIFT;
+    const bool res_trie = (dsc.c & BDESC_TRIE) != 0;
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    if (c == 0) {  // an empty sub-range of a big run
+        if (tid == 0) { out_count[r] = 0; out_kind[r] = KIND_TRIE; }
+        return;
+    }
+    u32 nbits = 32 - __builtin_clz(c - 1 > 0 ? c - 1 : 1);
+    if (nbits > SB - skip) nbits = SB - skip;
+    const u32 NB = 1u << nbits, sub_sh = SB - skip - nbits;
+    constexpr u32 crowd = MSD_LIMIT;
+    auto give_up = [&]() {
+        if (tid == 0) {
+            if (bail_flag) { bail_flag[blockIdx.x] = 1; *bail_any = 1u; }
+            else retry[atomicAdd(retry_n, 1u)] = dsc;
+        }
+    };
+    for (u32 i = tid; i < NB / 2 + 1; i += THREADS) s_off32[i] = 0;
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    {
+        u64 key[ITEMS];
+        u32 sub[ITEMS], arr[ITEMS];
+        const u64 mask = SB >= 64 ? ~0ull : ((1ull << SB) - 1ull);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {  // all loads first, unconditionally (slots past the run re-read its first word)
+            const u32 e = j * THREADS + tid;
+            key[j] = lo[s0 + (e < c ? e : 0u)] & mask;
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 e = j * THREADS + tid;
+            sub[j] = (u32)(key[j] >> sub_sh) & (NB - 1u);
+            arr[j] = 0;
+            if (e < c) arr[j] = atomicAdd(&s_off32[sub[j] >> 1], 1u << ((sub[j] & 1u) * 16u));
+        }
+        bool crowded = false;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            arr[j] = (arr[j] >> ((sub[j] & 1u) * 16u)) & 0xFFFFu;
+            crowded |= arr[j] >= crowd;
+        }
+        if (crowded) s_max = crowd + 1u;  // benign race: every writer stores the same value
+        __syncthreads();
+        if (s_max > crowd) { give_up(); return; }
+        {   // exclusive scan of the NB counts; each thread owns `per` consecutive entries
+            const u32 per = (NB + THREADS - 1) / THREADS;  // <= ITEMS
+            const u32 b0 = tid * per;
+            u32 sum = 0, cnt[ITEMS];
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                cnt[k] = ((u32)k < per && b0 + k < NB) ? s_off[b0 + k] : 0u;
+                sum += cnt[k];
+            }
+            u32 ex = block_exclusive_scan<THREADS, u32>(sum, s_scan, nullptr);
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                if ((u32)k < per && b0 + k < NB) { s_off[b0 + k] = (u16)ex; ex += cnt[k]; }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_off[NB] = (u16)c;
+        if (tid < 3) s_k[pad(c + tid)] = ~0ull;  // what a walk may read behind the run compares greater than every element
+        u32 sbase[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) sbase[j] = s_off[sub[j]];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 e = j * THREADS + tid;
+            if (e < c) s_k[pad(sbase[j] + arr[j])] = (key[j] << PK_BITS) | e;
+        }
+    }
+    __syncthreads();
+    // -- the walk: lane t owns slots [t per, t per + per) of the sub-bucket order
+    const u32 per = (c + THREADS - 1) / THREADS;  // <= ITEMS
+    const u32 p0 = tid * per;
+    const u32 n_own = p0 < c ? (c - p0 < per ? c - p0 : per) : 0u;
+    u64 me[ITEMS];
+    u32 fin[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const u32 p = p0 + i;
+        me[i] = s_k[pad(p < c ? p : c)];  // (slots past the lane's share read the all-ones slot or a neighbour's entry: never written back)
+        fin[i] = 0;
+    }
+    u32 A = 0, B = 0;
+    if (n_own) {
+        u64 last = me[0];
+#pragma unroll
+        for (int i = 1; i < ITEMS; ++i) if ((u32)i < n_own) last = me[i];
+        A = s_off[(u32)(me[0] >> (PK_BITS + sub_sh)) & (NB - 1u)];
+        B = s_off[((u32)(last >> (PK_BITS + sub_sh)) & (NB - 1u)) + 1u];
+    }
+    for (u32 q = A; q < B; q += 2) {  // (an entry read behind B belongs to a later sub-bucket, or is all ones: greater than every entry of mine)
+        const u64 o0 = s_k[pad(q)], o1 = s_k[pad(q + 1)];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) fin[i] += (o0 < me[i] ? 1u : 0u) + (o1 < me[i] ? 1u : 0u);
+    }
+    __syncthreads();  // every read of the sub-bucket order is done
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if ((u32)i < n_own) s_k[pad(A + fin[i])] = me[i];
+    __syncthreads();
+    // -- heads (the first slot of every suffix value) in wave-contiguous slices, counted, then compacted slot by slot
+    const u32 EPW = 64 * per;
+    bool head[ITEMS];
+    u32 wh = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 p = w * EPW + j * 64 + lane;
+        const bool live = (u32)j < per && p < c;
+        const u32 pc = live ? p : 0u;
+        const u64 v = s_k[pad(pc)], pv = s_k[pad(pc ? pc - 1u : 0u)];
+        head[j] = live && (pc == 0 || (v >> PK_BITS) != (pv >> PK_BITS));
+        me[j] = v >> PK_BITS;
+        wh += (u32)__builtin_popcountll(__ballot(head[j]));
+    }
+    if (lane == 0) s_wtot[w] = wh;
+    __syncthreads();
+    u32 run = 0, d = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
+        const u32 t = s_wtot[ww];
+        if ((u32)ww < w) run += t;
+        d += t;
+    }
+    if (d <= VEC_THRESHOLD && !res_trie) { give_up(); return; }  // stays a Vec (repeats): stream order needed — nothing was written yet
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u64 bal = __ballot(head[j]);
+        if (head[j]) lo[s0 + run + mbcnt(bal)] = me[j];
+        run += (u32)__builtin_popcountll(bal);
+    }
+    if (tid == 0) {
+        out_count[r] = d;
+        out_kind[r] = KIND_TRIE;
     }
 }
 

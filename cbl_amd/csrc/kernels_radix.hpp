@@ -742,14 +742,17 @@ __global__ __launch_bounds__(256) void k_dir_gather(u32 low_bits, u32 last_bits,
     if (seg_prefix && seg_prefix[s] == 0xFFFFFFFFu) return;  // no such segment (its rows would land on another segment's prefixes)
     const u32 prefix = (seg_prefix ? seg_prefix[s] : s << (low_bits + last_bits)) | (d << low_bits) | low;
     if (prefix < w_lo || prefix >= w_hi) return;
+    // (FINE bins: the caller filled the window with EMPTY, and only rows that hold records are written — the blocks of two segments
+    // never share a prefix that holds records, an empty row of one must not land on the other's)
     if (low_bits && seg_cold(seg_start, s)) {  // its tiles were not cut at the groups: k_boundaries_cold fills these in
-        start_dense[prefix] = 0xFFFFFFFFu;
+        if (!seg_prefix) start_dense[prefix] = 0xFFFFFFFFu;
         return;
     }
     const u32 f0 = grp_first[g], f1 = grp_first[g + 1];
     const u32 p0 = f0 < nt ? colpre[(u64)f0 * 256 + d] : coltot[d];
     const u32 p1 = f1 < nt ? colpre[(u64)f1 * 256 + d] : coltot[d];
-    start_dense[prefix] = p1 > p0 ? adj[s * 256 + d] + p0 : 0xFFFFFFFFu;
+    if (p1 > p0) start_dense[prefix] = adj[s * 256 + d] + p0;
+    else if (!seg_prefix) start_dense[prefix] = 0xFFFFFFFFu;
 }
 
 // bucket boundaries of the cold segments from their (few) sorted records

@@ -25,7 +25,10 @@
 extern "C" {
 #endif
 
-#define CBLX_ABI_VERSION 2
+/* 3: cblx_merge_from, cblx_stage_units, cblx_fine_builds, cblx_comm_groups_fine, cblx_comm_protocol_used, CBLX_PROTO_AUTO (the default of a new
+ * communicator: an unchanged 2 - 4 rank caller no longer runs BINS), CBLX_PROTO_REPLICATE; empty PREFIX_BITS > 24 builds take the FINE route. A binding
+ * built against this header must refuse a library that reports less. */
+#define CBLX_ABI_VERSION 3
 
 enum {
     CBLX_OK = 0,

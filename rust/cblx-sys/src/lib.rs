@@ -8,7 +8,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const CBLX_ABI_VERSION: u32 = 2;
+pub const CBLX_ABI_VERSION: u32 = 3;
 
 pub const CBLX_OK: c_int = 0;
 pub const CBLX_EINVAL: c_int = 1;

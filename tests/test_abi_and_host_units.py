@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/cblx.h but not exported by libcblx.so"
     assert sorted(cbl_amd.SIGNATURES) == names
-    assert L.cblx_abi_version() == 2
+    assert L.cblx_abi_version() == 3
 
 
 def test_rust_sys_crate_declares_every_symbol():

@@ -40,8 +40,25 @@ def test_two_rank_line_through_the_launcher(config):
         assert one["value"] > 0 and one["ms_per_step"] > 0 and abs(out["scaling_vs_one_gpu_same_config"] - out["value"] / one["value"]) < 0.01
         # ... and says what crossed the links: the library's choice at two ranks is "sorted" (one link per pair of GPUs bounds the job)
         assert out["exchange"]["protocol_asked"] == "auto" and out["exchange"]["protocol"] == "sorted"
+        # ... and carries its own correctness verdict: the sharded index against every rank's word stream (count, set checksum, structure, every
+        # inserted k-mer found in exactly one share), and the CPU leg's sample rebuilt on the GPU with the oracle's bytes
+        sc = out["set_check"]
+        assert sc["ok"] is True and sc["validate_violations"] == 0 and sc["members_ok"] is True and sc["members_found"] == sc["kmers_inserted"] == 2 * 20000 * (150 - k + 1)
+        assert sc["count"] == out["distinct_kmers_in_index"] and sc["repeats_implied"] == sc["kmers_inserted"] - sc["count"] >= 0
+        assert sc["repeats_implied"] != 0 or (sc["checksums_equal"] is True and sc["checksum_index"] == sc["checksum_word_streams"])
+        ps = out["parity_sample"]
+        assert ps["equal"] is True and ps["sha256"] == ps["sha256_oracle"] and ps["bytes"] == ps["bytes_oracle"] > 0 and ps["reads"] == 2000 and ps["first_difference_at"] is None
     # an algorithmic rate above the HBM peak is a bookkeeping error (bench.py asserts it too)
     assert all(r["frac"] is None or r["frac"] <= 1.0 for r in out["roofline"]["kernels"])
+
+
+def test_default_line_carries_parity_sample():
+    """The driver's N = 1 line: the CPU leg's sample is built once more on the GPU after the timed region and byte-compared with the oracle's index of it."""
+    out = _run("--config", "cfg2", "--reads", "40000", "--steps", "1", "--warmup", "0", "--cpu-sample-reads", "5000", "--no-h2d")
+    ps = out["parity_sample"]
+    assert ps["equal"] is True and ps["reads"] == 5000 and ps["sha256"] == ps["sha256_oracle"] and ps["bytes"] == ps["bytes_oracle"] > 0
+    assert ps["distinct_kmers"] == ps["distinct_kmers_oracle"] <= 5000 * 120
+    assert "set_check" not in out and "roofline_error" not in out
 
 
 def test_launcher_reports_a_failing_rank():

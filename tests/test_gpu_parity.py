@@ -2250,6 +2250,89 @@ def test_rehearsal_of_rank_0_on_recorded_senders(world, k, pb, canonical, groups
     assert nxt >= int(bounds[0])
 
 
+def _reads_with_all_ones(seed, nr, L, first_read, n_poly, n_rich):
+    """Random reads, `n_poly` of them replaced by poly-G (every k-mer is the all-ones word: A=0 C=1 T=2 G=3, the one necklace in the upper half of
+    the prefix space) and `n_rich` by G-rich reads (a C or a T every dozen bases: necklaces 0111..., prefixes right below 2^(PREFIX_BITS-1))."""
+    hb, ho = synth.reads(seed, nr, L, first_read=first_read)
+    b = np.array(hb, copy=True).reshape(nr, L)
+    rng = random.Random(seed * 7919 + first_read)
+    rows = rng.sample(range(nr), n_poly + n_rich)
+    for i in rows[:n_poly]:
+        b[i, :] = ord("G")
+    for i in rows[n_poly:]:
+        b[i, :] = ord("G")
+        for j in range(rng.randrange(12), L, 12):
+            b[i, j] = ord(rng.choice("CT"))
+    return np.ascontiguousarray(b.reshape(-1)), ho
+
+
+@pytest.mark.parametrize("k,pb,n_poly", [(31, 28, 3), (31, 28, 2300), (27, 25, 2300), (59, 28, 1400)])
+def test_fine_bins_build_with_the_all_ones_word(k, pb, n_poly, monkeypatch):
+    """FINE bins and the all-ones word (bin 255, the only necklace above 2^(PREFIX_BITS-1)): a few copies (a cold segment: its bucket start comes from
+    the records) and more than 64 tiles of them (k_dir_gather's table route where the group sorts 16 bits, the fused directory where it sorts 24);
+    non-canonical and canonical (62 / 118 one bits: the forward strand is the canonical one). Same bytes as the oracle and as the plain build."""
+    _need_gpu()
+    monkeypatch.setenv("CBLX_FINE_MIN", "0")
+    L, nr = (150 if k < 59 else 250), 6000
+    hb, ho = _reads_with_all_ones(5 + k, nr, L, 0, n_poly, 40)
+    for canonical in (False, True):
+        o = Oracle(k, pb, canonical)
+        o.insert_seqs(hb, ho)
+        for fine in ("1", "0"):
+            monkeypatch.setenv("CBLX_FINE_BINS", fine)
+            g = cbl_amd.CBL(k, pb, canonical=canonical)
+            g.insert_seqs(hb, ho)
+            g.flush()
+            assert g.fine_builds() == (1 if fine == "1" else 0)
+            _check_index(g, o)
+            assert g.validate() == 0
+            top = [b for b in g.buckets() if b[0] == (1 << pb) - 1]
+            assert len(top) == 1 and len(top[0][2]) == 1  # the all-ones prefix holds the one all-ones suffix
+            g.close()
+
+
+@pytest.mark.parametrize("k,pb,world,n_poly,groups", [(27, 25, 2, 1300, 2), (27, 25, 2, 2, 3), (31, 26, 3, 900, 2), (31, 28, 2, 1300, 0)])
+def test_rehearsal_of_the_last_rank_with_a_narrow_top_range(k, pb, world, n_poly, groups, monkeypatch):
+    """The LAST rank of a FINE-bins plan whose range is a few blocks of 2^16 prefixes below 2^(PREFIX_BITS-1) (bounds given, not quantiles): every
+    one of its groups sorts 16 bits behind the first pass, and the all-ones word rides in bin 255 of its last group — segment 255 of a group whose
+    directory comes from the last pass's tables (k_dir_gather). Round 5 gave that segment the all-ones prefix ITSELF as its block base: every row of
+    the segment's table then mapped to the one all-ones prefix, one with the bucket start and up to 65 535 with EMPTY, in no order, and a segment of
+    more than 64 tiles (not cold) could lose its bucket. Poly-G reads from every rank, few and many; G-rich reads fill the range below."""
+    _need_gpu()
+    L, nr, store, slices = 150, 4000, 61000 + pb + n_poly, 2
+    tgt = world - 1
+    monkeypatch.setenv("CBLX_SIM_TARGET", str(tgt))
+    half = 1 << (pb - 1)
+    bounds = np.array([half - (3 + 2 * (world - 2 - i)) * 65536 + (0 if i else 4096) for i in range(world - 1)], dtype=np.uint32)
+    cuts = [nr * s // slices for s in range(slices + 1)]
+    reads = [_reads_with_all_ones(300 + k, nr, L, r * nr, n_poly, 600) for r in range(world)]
+    for r in [x for x in range(world) if x != tgt] + [tgt]:
+        d_b, d_o = torch.from_numpy(reads[r][0]).cuda(), torch.from_numpy(reads[r][1].astype(np.int64)).cuda()
+        cm = cbl_amd.Comm.sim(r, world, store, 0.0)
+        cm.set_protocol("bins")
+        cm.set_recv_groups(groups)
+        g = cbl_amd.CBL(k, pb)
+        assert g.sharded_insert_seqs_device(cm, d_b, d_o, nr, cuts, bounds, True)
+        if r == tgt:
+            mine, used, fine = g.buckets(), cm.groups_used(), cm.groups_fine()
+            assert g.validate() == 0
+        g.close()
+        cm.close()
+    cbl_amd.Comm.sim_store_free(store)
+    one = Oracle(k, pb, False)
+    for c in range(slices):
+        for r in range(world):
+            hb, ho = reads[r]
+            one.insert_seqs(hb[cuts[c] * L: cuts[c + 1] * L], ho[: cuts[c + 1] - cuts[c] + 1])
+    full = cbl_amd.CBL(k, pb)
+    full.load(one.serialize())
+    want = [b for b in full.buckets() if b[0] >= int(bounds[-1])]
+    full.close()
+    assert used >= 1 and fine == used, (used, fine)  # every group of the last rank sorts 16 bits
+    assert want and want[-1][0] == (1 << pb) - 1 and len(want) > 1
+    assert len(mine) == len(want) and mine == want
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_rehearsal_of_any_rank_on_random_fine_plans(seed, monkeypatch):
     """FINE bins (PREFIX_BITS > 24) under random plans: world size, groups, slices, K, the REHEARSED RANK (CBLX_SIM_TARGET: any rank, not only the
