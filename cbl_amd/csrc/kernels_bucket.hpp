@@ -1543,14 +1543,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
 #ifndef CBLX_SORTED_WAVES
 #define CBLX_SORTED_WAVES 7
 #endif
+#ifndef CBLX_SORTED_PROBE
+#define CBLX_SORTED_PROBE 0  // > 0: timing probes that leave phases out (wrong results); never in the product build
+#endif
+#if CBLX_SORTED_PROBE && !defined(CBLX_TIMING_PROBES)
+#error "CBLX_SORTED_PROBE leaves phases out and produces wrong results: timing builds only (-DCBLX_TIMING_PROBES)"
+#endif
 template <int THREADS, int CAP, typename HiT>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 4096 ? 6 : CBLX_SORTED_WAVES, 8))) void k_bucket_sorted(
     const BDesc* __restrict__ list, const u32* __restrict__ list_n, u64* __restrict__ lo, u32 SB, u32* __restrict__ out_count, u8* __restrict__ out_kind,
     BDesc* __restrict__ retry, u32* __restrict__ retry_n, u8* __restrict__ bail_flag = nullptr, u32* __restrict__ bail_any = nullptr) {
     static_assert(CAP <= (1 << PK_BITS), "stream index must fit PK_BITS");
     constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
-    static_assert(ITEMS == 8, "a lane owns eight slots: the padding below is one slot per eight");
-    __shared__ u64 s_k[CAP + CAP / 8 + 4];  // slot p lives at p + p / 8; + the all-ones slots behind the run
+    __shared__ u64 s_k[CAP + CAP / 8 + 6];  // slot p lives at p + p / 8; + the all-ones slots behind the run
     __shared__ u32 s_off32[CAP / 2 + 2];    // sub-bucket counts, then exclusive offsets: 16-bit entries, counted with 32-bit atomics on the containing dword
     u16* s_off = reinterpret_cast<u16*>(s_off32);
     __shared__ u32 s_scan[NW + 1];
@@ -1587,10 +1592,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 
         u64 key[ITEMS];
         u32 sub[ITEMS], arr[ITEMS];
         const u64 mask = SB >= 64 ? ~0ull : ((1ull << SB) - 1ull);
+        const u64* __restrict__ run_in = lo + s0;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {  // all loads first, unconditionally (slots past the run re-read its first word)
             const u32 e = j * THREADS + tid;
-            key[j] = lo[s0 + (e < c ? e : 0u)] & mask;
+            key[j] = run_in[e < c ? e : 0u] & mask;
         }
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
@@ -1608,6 +1614,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 
         if (crowded) s_max = crowd + 1u;  // benign race: every writer stores the same value
         __syncthreads();
         if (s_max > crowd) { give_up(); return; }
+#if CBLX_SORTED_PROBE == 1  // timing probe only: loads and counting atomics
+        if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_TRIE; }
+        if (s_off32[tid] != 0x12345678u) return;
+#endif
         {   // exclusive scan of the NB counts; each thread owns `per` consecutive entries
             const u32 per = (NB + THREADS - 1) / THREADS;  // <= ITEMS
             const u32 b0 = tid * per;
@@ -1625,7 +1635,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 
         }
         __syncthreads();
         if (tid == 0) s_off[NB] = (u16)c;
-        if (tid < 3) s_k[pad(c + tid)] = ~0ull;  // what a walk may read behind the run compares greater than every element
+        if (tid < 4) s_k[pad(c + tid)] = ~0ull;  // what a walk may read behind the run compares greater than every element
         u32 sbase[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) sbase[j] = s_off[sub[j]];
@@ -1636,6 +1646,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 
         }
     }
     __syncthreads();
+#if CBLX_SORTED_PROBE == 2  // timing probe only: everything up to the scatter
+    if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_TRIE; }
+    if (s_k[tid] != 0x1234567ull) return;
+#endif
     // -- the walk: lane t owns slots [t per, t per + per) of the sub-bucket order
     const u32 per = (c + THREADS - 1) / THREADS;  // <= ITEMS
     const u32 p0 = tid * per;
@@ -1653,14 +1667,52 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 
         u64 last = me[0];
 #pragma unroll
         for (int i = 1; i < ITEMS; ++i) if ((u32)i < n_own) last = me[i];
-        A = s_off[(u32)(me[0] >> (PK_BITS + sub_sh)) & (NB - 1u)];
+        // (rounded down to an even slot: the entry in front of the sub-bucket is smaller than every entry of mine, it counts like the rest in front)
+        A = s_off[(u32)(me[0] >> (PK_BITS + sub_sh)) & (NB - 1u)] & ~1u;
         B = s_off[((u32)(last >> (PK_BITS + sub_sh)) & (NB - 1u)) + 1u];
     }
-    for (u32 q = A; q < B; q += 2) {  // (an entry read behind B belongs to a later sub-bucket, or is all ones: greater than every entry of mine)
-        const u64 o0 = s_k[pad(q)], o1 = s_k[pad(q + 1)];
+#ifndef CBLX_SORTED_UNROLL
+#define CBLX_SORTED_UNROLL 2
+#endif
+#ifdef CBLX_SORTED_STATS  // dev: span statistics into retry_n[0..7] as u64 (tools/dev_msd_bench.cpp)
+    {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(retry_n);
+        const u32 span = B - A;
+        u32 mx = span;
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) fin[i] += (o0 < me[i] ? 1u : 0u) + (o1 < me[i] ? 1u : 0u);
+        for (int o = 32; o > 0; o >>= 1) { const u32 t = __shfl_xor(mx, o, 64); mx = t > mx ? t : mx; }
+        const u32 sm = wave_reduce_sum(span), na = wave_reduce_sum(n_own ? 1u : 0u);
+        if (lane == 0) { atomicAdd(&st[0], (unsigned long long)sm); atomicAdd(&st[1], (unsigned long long)mx); atomicAdd(&st[2], (unsigned long long)na); atomicAdd(&st[3], 1ull); }
     }
+#endif
+    // (an entry read behind B belongs to a later sub-bucket, or is all ones: greater than every entry of mine.) The comparisons are
+    // what this kernel is made of (two VALU instructions per pair, 28.8 steps of the wave's longest span at cfg 2): the loop is
+    // instantiated per `per` — uniform over the workgroup — so that a run of 1300 words (per = 6) does not pay for eight slots
+    auto walk = [&](auto per_tag) {
+        constexpr int PER = decltype(per_tag)::value;
+        // (A is even: the two slots of a step are neighbours in the padded array too, one address and an immediate offset)
+        for (u32 q = A; q < B; q += 2) {
+            const u64* at = &s_k[pad(q)];
+            const u64 o0 = at[0], o1 = at[1];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) fin[i] += (o0 < me[i] ? 1u : 0u) + (o1 < me[i] ? 1u : 0u);
+        }
+    };
+    if constexpr (ITEMS == 8) {
+        switch (per) {
+            case 8: walk(std::integral_constant<int, 8>()); break;
+            case 7: walk(std::integral_constant<int, 7>()); break;
+            case 6: walk(std::integral_constant<int, 6>()); break;
+            case 5: walk(std::integral_constant<int, 5>()); break;
+            default: walk(std::integral_constant<int, 4>()); break;  // (per <= 4: a short run of a class above its length, e.g. a sub-range of a long run)
+        }
+    } else {
+        walk(std::integral_constant<int, ITEMS>());
+    }
+#if CBLX_SORTED_PROBE == 3  // timing probe only: everything up to the walk
+    if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_TRIE; }
+    if (fin[0] + fin[1] + fin[2] + fin[3] + fin[4] + fin[5] + fin[6] + fin[7] != 0x12345678u) return;
+#endif
     __syncthreads();  // every read of the sub-bucket order is done
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
@@ -1690,11 +1742,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 
         d += t;
     }
     if (d <= VEC_THRESHOLD && !res_trie) { give_up(); return; }  // stays a Vec (repeats): stream order needed — nothing was written yet
+    u64* __restrict__ run_out = lo + s0;
+    if (d == c) {  // no repeat in the run (the usual case): every slot is a head and keeps its place
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const u64 bal = __ballot(head[j]);
-        if (head[j]) lo[s0 + run + mbcnt(bal)] = me[j];
-        run += (u32)__builtin_popcountll(bal);
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 p = w * EPW + j * 64 + lane;
+            if ((u32)j < per && p < c) run_out[p] = me[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u64 bal = __ballot(head[j]);
+            if (head[j]) run_out[run + mbcnt(bal)] = me[j];
+            run += (u32)__builtin_popcountll(bal);
+        }
     }
     if (tid == 0) {
         out_count[r] = d;

@@ -432,6 +432,12 @@ __global__ void k_sum_list_counts(const BDesc* __restrict__ list, u32 n, const u
 // segments, out of the arena into a twin buffer at the same positions; sub-ranges sorted + deduplicated in place there by
 // k_bucket_msd; what cannot be finished that way takes the general kernel on the (untouched) arena run. The finished runs stay
 // in the twin: finish_twin decides which buffer becomes the arena.
+// CBLX_SORTED_KERNEL=0: the runs that end up sorted take k_bucket_msd as they did until round 5 instead of k_bucket_sorted (tests compare both
+// routes); read per call
+inline bool sorted_kernel() {
+    const char* e = std::getenv("CBLX_SORTED_KERNEL");
+    return !(e && e[0] == '0');
+}
 struct Twin {
     Buf<u64> lo, hi;   // same positions as the arena; hi only for suffixes wider than 64 bits
     Buf<u8> in_twin;   // per bucket rank: 1 = its final words are in the twin
@@ -510,6 +516,17 @@ template <typename C> void big_stage(cblx_ctx* c, const BDesc* d_list, const u32
         // arguments: that one keeps the top-bit sub-bucket limit (the build's 1024-word class assumes hashed sub-buckets)
         auto sort = [&](auto pk) {
             constexpr bool PK = decltype(pk)::value;
+            if constexpr (PK && !WS) {  // sub-ranges are always asked for the sorted list: the walk kernel (round 6)
+                if (sorted_kernel()) {
+                    if (cn[0])
+                        hipLaunchKernelGGL((k_bucket_sorted<128, 1024, HiT>), dim3(cn[0]), dim3(128), 0, c->stream, cls_lists.get(), cls_n.get() + 0, tw.lo.get(), P.SB, v_count.get(), v_kind.get(),
+                                           retry.get(), retry_n.get(), (u8*)nullptr, (u32*)nullptr);
+                    if (cn[1])
+                        hipLaunchKernelGGL((k_bucket_sorted<256, BIG_VCAP, HiT>), dim3(cn[1]), dim3(256), 0, c->stream, cls_lists.get() + vtot, cls_n.get() + 1, tw.lo.get(), P.SB, v_count.get(),
+                                           v_kind.get(), retry.get(), retry_n.get(), (u8*)nullptr, (u32*)nullptr);
+                    return;
+                }
+            }
             if (cn[0])
                 hipLaunchKernelGGL((k_bucket_msd<128, 1024, PK, WS, HiT, true>), dim3(cn[0]), dim3(128), 0, c->stream, cls_lists.get(), cls_n.get() + 0, tw.lo.get(), th, P.SB, v_count.get(),
                                    v_kind.get(), retry.get(), retry_n.get(), MergeArgs{});
@@ -644,6 +661,7 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
                                        P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
             CBLX_HIP(hipGetLastError());
         }
+        const bool use_sorted = sorted_kernel();
         auto stage = [&](auto packed_tag) {
             constexpr bool PK = decltype(packed_tag)::value;
             if (radix_only) return;
@@ -657,6 +675,13 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
                     return;
                 }
                 used_msd[k] = true;
+                if constexpr (PK && !C::WS && CAPV > (int)VEC_THRESHOLD) {  // runs of more than 1024 words end up sorted (or give up: repeats): the walk kernel (round 6)
+                    if (use_sorted) {
+                        hipLaunchKernelGGL((k_bucket_sorted<T, CAPV, HiT>), dim3(ln[cls]), dim3(T), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls, a_lo, P.SB, nr.cnt.get(),
+                                           nr.kind.get(), (BDesc*)nullptr, (u32*)nullptr, bail.get() + roff[k], bail_any.get() + k);
+                        return;
+                    }
+                }
                 hipLaunchKernelGGL((k_bucket_msd<T, CAPV, PK, C::WS, HiT>), dim3(ln[cls]), dim3(T), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls, a_lo, a_hi, P.SB,
                                    nr.cnt.get(), nr.kind.get(), (BDesc*)nullptr, (u32*)nullptr, MergeArgs{}, bail.get() + roff[k], bail_any.get() + k);
             };
@@ -692,6 +717,15 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
                     Buf<BDesc> retry3(c->pool, n2);
                     Buf<u32> r3n(c->pool, 1);
                     CBLX_HIP(hipMemsetAsync(r3n.get(), 0, 4, c->stream));
+                    bool done2 = false;
+                    if constexpr (PK && !C::WS) {
+                        if (use_sorted) {
+                            hipLaunchKernelGGL((k_bucket_sorted<512, 4096, HiT>), dim3(n2), dim3(512), 0, c->stream, retry2.get(), r2n, a_lo, P.SB, nr.cnt.get(), nr.kind.get(), retry3.get(), r3n.get(),
+                                               (u8*)nullptr, (u32*)nullptr);
+                            done2 = true;
+                        }
+                    }
+                    if (!done2)
                     hipLaunchKernelGGL((k_bucket_msd<512, 4096, PK, C::WS, HiT>), dim3(n2), dim3(512), 0, c->stream, retry2.get(), r2n, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(),
                                        retry3.get(), r3n.get(), MergeArgs{});
                     const u32 n3 = d2h<u32>(c, r3n.get());
@@ -739,6 +773,13 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
             cn = d2h_vec<u32>(c, cnts.get(), 3);
             if (cn[2]) {
                 auto sort = [&](auto pk) {
+                    if constexpr (decltype(pk)::value) {
+                        if (sorted_kernel()) {
+                            hipLaunchKernelGGL((k_bucket_sorted<256, 2048, HiT>), dim3(cn[2]), dim3(256), 0, c->stream, srt.get(), cnts.get() + 2, a_lo, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(),
+                                               cnts.get() + 3, (u8*)nullptr, (u32*)nullptr);
+                            return;
+                        }
+                    }
                     hipLaunchKernelGGL((k_bucket_msd<256, 2048, decltype(pk)::value, false, HiT>), dim3(cn[2]), dim3(256), 0, c->stream, srt.get(), cnts.get() + 2, a_lo, a_hi, P.SB,
                                        nr.cnt.get(), nr.kind.get(), retry.get(), cnts.get() + 3, MergeArgs{});
                 };

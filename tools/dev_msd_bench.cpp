@@ -31,10 +31,10 @@ __global__ void k_gen_offsets(u64* o, u64 n, u64 L) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i <= n) o[i] = i * L;
 }
-__global__ void k_split_words(const u64* lo, const u8* hi, u64 n, u32 SB, u32* prefix) {
+__global__ void k_split_words(const u64* lo, const u8* hi, u64 n, u32 SB, u32 PB, u32* prefix) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    prefix[i] = get_bits(lo[i], hi ? (u64)hi[i] : 0ull, SB, 32) & 0xFFFFFFFFu;
+    prefix[i] = get_bits(lo[i], hi ? (u64)hi[i] : 0ull, SB, PB);
 }
 // run heads of the sorted prefixes -> one descriptor per run in the list of its length class (k_classify's classes)
 __global__ void k_runs(const u32* prefix, u64 n, u32* run_start, u32* nruns) {
@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
     if (nw != n) { printf("words %llu != %llu\n", (unsigned long long)nw, (unsigned long long)n); return 1; }
     CK(hipFree(bases));
     u32 *pfx = dalloc<u32>(n + 8), *pfx_s = dalloc<u32>(n + 8);
-    hipLaunchKernelGGL(k_split_words, dim3((n + 255) / 256), dim3(256), 0, 0, w_lo, w_hi, n, SB, pfx);
+    hipLaunchKernelGGL(k_split_words, dim3((n + 255) / 256), dim3(256), 0, 0, w_lo, w_hi, n, SB, PB, pfx);
     CK(hipFree(w_hi));
     {   // stable sort by prefix: values = the low words (what the arena holds behind the partition passes)
         size_t tb = 0;
@@ -195,6 +195,53 @@ int main(int argc, char** argv) {
     };
     if (SB + PK_BITS <= 64) all(std::true_type()); else all(std::false_type());
     printf("total best %.3f ms\n", total);
+    // round 6: the sorted classes through k_bucket_sorted (a lane walks the span of its eight slots once)
+    auto run_sorted = [&](int k, auto thr, auto cap) {
+        constexpr int T = decltype(thr)::value, CAPV = decltype(cap)::value;
+        if (!ln[k] || SB + PK_BITS > 64) return;
+        float best = 1e30f, sum = 0;
+        unsigned long long chk = 0;
+        for (int rep = 0; rep < reps + 1; ++rep) {
+            CK(hipMemcpy(arena, s_lo, n * 8, hipMemcpyDeviceToDevice));
+            CK(hipMemset(bail, 0, nruns + 8));
+            CK(hipMemset(bail_any, 0, 32));
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+#ifdef CBLX_SORTED_STATS
+            static unsigned long long* d_st = dalloc<unsigned long long>(8);
+            CK(hipMemset(d_st, 0, 64));
+            hipLaunchKernelGGL((k_bucket_sorted<T, CAPV, u8>), dim3(ln[k]), dim3(T), 0, 0, lists + (size_t)k * nruns, list_n + k, arena, SB, cnt, kind, (BDesc*)nullptr, (u32*)d_st, bail, bail_any);
+            if (rep == reps) { unsigned long long h[4]; CK(hipMemcpy(h, d_st, 32, hipMemcpyDeviceToHost));
+                printf("  span: mean per owning lane %.1f, mean of the wave maxima %.1f (%llu waves)\n", (double)h[0] / h[2], (double)h[1] / h[3], h[3]); }
+#else
+            hipLaunchKernelGGL((k_bucket_sorted<T, CAPV, u8>), dim3(ln[k]), dim3(T), 0, 0, lists + (size_t)k * nruns, list_n + k, arena, SB, cnt, kind, (BDesc*)nullptr, (u32*)nullptr, bail, bail_any);
+#endif
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            CK(hipGetLastError());
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) { best = std::min(best, ms); sum += ms; }
+        }
+        CK(hipMemset(d_sum, 0, 8));
+        hipLaunchKernelGGL(k_sum_res, dim3(ln[k]), dim3(256), 0, 0, lists + (size_t)k * nruns, ln[k], cnt, kind, arena, d_sum);
+        CK(hipMemcpy(&chk, d_sum, 8, hipMemcpyDeviceToHost));
+        u32 nbail = 0;
+        std::vector<u8> hb(ln[k]);
+        CK(hipMemcpy(hb.data(), bail, ln[k], hipMemcpyDeviceToHost));
+        for (u8 x : hb) nbail += x;
+        printf("sorted %d <%3d,%4d>: %8u buckets  best %7.3f ms  avg %7.3f ms  gave up %u  chk %016llx\n", k, T, CAPV, ln[k], best, sum / reps, nbail, chk);
+    };
+    run_sorted(3, std::integral_constant<int, 256>(), std::integral_constant<int, 2048>());
+    run_sorted(4, std::integral_constant<int, 512>(), std::integral_constant<int, 4096>());
+#ifdef MSD_BENCH_SHAPES
+    run_sorted(3, std::integral_constant<int, 512>(), std::integral_constant<int, 2048>());
+    run_sorted(3, std::integral_constant<int, 128>(), std::integral_constant<int, 2048>());
+    run_sorted(4, std::integral_constant<int, 1024>(), std::integral_constant<int, 4096>());
+    run_sorted(4, std::integral_constant<int, 256>(), std::integral_constant<int, 4096>());
+    run_sorted(2, std::integral_constant<int, 128>(), std::integral_constant<int, 1024>());
+    run_sorted(2, std::integral_constant<int, 256>(), std::integral_constant<int, 1024>());
+#endif
     cblx_destroy(ctx);
     return 0;
 }
