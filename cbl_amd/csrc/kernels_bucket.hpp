@@ -1525,7 +1525,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
     }
 }
 
-// ---- KRN-3, runs that end up SORTED (more than 1024 words, or a bucket that is a Trie already), narrow packed elements (round 6) --------
+// ---- KRN-3, runs that end up SORTED (more than 1024 words, a bucket that is a Trie already, `self |= other`), packed elements (round 6) ----
 // k_bucket_msd ranks every element inside its sub-bucket by reading the whole sub-bucket: s reads per element, and under the top
 // suffix bits — the only kind of sub-bucket a sorted result allows — an element shares its sub-bucket with 6.5 others on average and
 // up to 45 (necklace clusters): 60 random 8-byte LDS reads per lane of eight slots, issued slot by slot in loops whose
@@ -1534,12 +1534,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
 // a lane OWNS eight consecutive positions of that order — entries of the same one or two sub-buckets — and walks ONCE over the span from
 // the start of its first entry's sub-bucket to the end of its last entry's, comparing every entry it reads with all eight of its own
 // (registers). Everything in front of the span is smaller than the lane's entries and everything behind it greater (the sub-buckets are
-// ascending), so final rank = span start + entries of the span that compare less: one LDS read serves eight comparisons, 16 - 25 reads
-// per lane instead of 60, and a lane's reads step through consecutive slots (the array is padded by one slot per eight, so that the
-// 64 lanes' slots of one step spread over the banks: stride 9 words). Repeats are settled AFTER the sort — an element is the head of its
-// value iff the slot in front of it holds another suffix — so the inner loop is one 64-bit compare and one add per pair.
+// ascending), so final rank = span start + entries of the span that compare less: one LDS read serves eight comparisons, 13 reads per
+// lane on average (29 for the wave's longest span) instead of 60, and a lane's reads step through consecutive slots. Repeats are settled
+// AFTER the sort — an element is the head of its value iff the slot in front of it holds another suffix — so the inner loop is one
+// compare and one add per pair. The kernel is bound by those comparisons (VALU), no longer by the LDS.
 // Outcome as k_bucket_msd's: the ascending distinct list, KIND_TRIE. A run that turns out to stay a Vec (a run of more than 1024 words
 // with at most 1024 distinct ones, not a Trie yet — repeats) has written nothing yet and is handed on like a crowded one (claim table).
+// MERGE: `self |= other` (mg.cs set): the run is [self's suffixes][other's], read where the two indexes store them (mg.s_lo) or from the
+// gathered run; both parts hold distinct words, so a repeat is other's copy of a word self holds and sits right behind it in the sorted
+// order. The rules of /root/reference/src/trievec/set_ops.rs:43-71 are then ordered selections of the sorted slots, as in k_bucket_msd's
+// merge epilogue: what a slot says about its element is whether it came from self (index < cs) and whether it is the first of its value.
 #ifndef CBLX_SORTED_WAVES
 #define CBLX_SORTED_WAVES 7
 #endif
@@ -1549,36 +1553,76 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
 #if CBLX_SORTED_PROBE && !defined(CBLX_TIMING_PROBES)
 #error "CBLX_SORTED_PROBE leaves phases out and produces wrong results: timing builds only (-DCBLX_TIMING_PROBES)"
 #endif
-template <int THREADS, int CAP, typename HiT>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 4096 ? 6 : CBLX_SORTED_WAVES, 8))) void k_bucket_sorted(
-    const BDesc* __restrict__ list, const u32* __restrict__ list_n, u64* __restrict__ lo, u32 SB, u32* __restrict__ out_count, u8* __restrict__ out_kind,
-    BDesc* __restrict__ retry, u32* __restrict__ retry_n, u8* __restrict__ bail_flag = nullptr, u32* __restrict__ bail_any = nullptr) {
+// The element of the walk: suffix << 12 | stream index. Narrow (SUFFIX_BITS + 12 <= 64): one u64 in an array padded by one slot per
+// eight — the 64 lanes' slots of one step are 8 slots apart, 9 with the padding: every bank pair is hit four times, the best a
+// 64 x 8-byte access can do. Wide (SUFFIX_BITS + 12 <= 128): one 16-byte slot (ds_read_b128), slot index XORed with its block-of-eight
+// number instead (eight lanes cover the 32 banks; no LDS spent on padding: the wide classes are bound by LDS residency).
+template <bool WS> struct WalkEl;
+template <> struct WalkEl<false> {
+    typedef u64 T;
+    static constexpr u32 slots(u32 cap) { return cap + cap / 8 + 6; }
+    static __device__ __forceinline__ u32 phys(u32 p) { return p + (p >> 3); }
+    static __device__ __forceinline__ T pack(const Sfx<false>& k, u32 e) { return (k.lo << PK_BITS) | e; }
+    static __device__ __forceinline__ T ones() { return ~0ull; }
+    static __device__ __forceinline__ bool less(const T& a, const T& b) { return a < b; }
+    static __device__ __forceinline__ bool same_sfx(const T& a, const T& b) { return (a >> PK_BITS) == (b >> PK_BITS); }
+    static __device__ __forceinline__ u32 idx(const T& a) { return (u32)a & ((1u << PK_BITS) - 1u); }
+    static __device__ __forceinline__ Sfx<false> sfx(const T& a) { Sfx<false> s; s.lo = a >> PK_BITS; return s; }
+    static __device__ __forceinline__ u32 sub(const T& a, u32 sh, u32 nbits) { return (u32)(a >> (PK_BITS + sh)) & ((1u << nbits) - 1u); }
+};
+template <> struct WalkEl<true> {
+    typedef W128 T;
+    static constexpr u32 slots(u32 cap) { return cap + 8; }
+    static __device__ __forceinline__ u32 phys(u32 p) { return p ^ ((p >> 3) & 7u); }
+    static __device__ __forceinline__ T pack(const Sfx<true>& k, u32 e) { return w128_pack(k, e); }
+    static __device__ __forceinline__ T ones() { return W128{~0ull, ~0ull}; }
+    static __device__ __forceinline__ bool less(const T& a, const T& b) { return w128_less(a, b); }
+    static __device__ __forceinline__ bool same_sfx(const T& a, const T& b) { return w128_same_sfx(a, b); }
+    static __device__ __forceinline__ u32 idx(const T& a) { return (u32)a.lo & ((1u << PK_BITS) - 1u); }
+    static __device__ __forceinline__ Sfx<true> sfx(const T& a) { return w128_sfx(a); }
+    static __device__ __forceinline__ u32 sub(const T& a, u32 sh, u32 nbits) {
+        const u128 v = ((u128)a.hi << 64) | a.lo;
+        return (u32)(v >> (PK_BITS + sh)) & ((1u << nbits) - 1u);
+    }
+};
+template <int CAP, bool WS> constexpr int sorted_waves() { return WS ? (CAP <= 128 ? CBLX_SORTED_WAVES : 4) : (CAP >= 4096 ? 6 : CBLX_SORTED_WAVES); }
+template <int THREADS, int CAP, bool WS, typename HiT, bool MERGE = false>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_waves<CAP, WS>(), 8))) void k_bucket_sorted(
+    const BDesc* __restrict__ list, const u32* __restrict__ list_n, u64* __restrict__ lo, HiT* __restrict__ hi, u32 SB, u32* __restrict__ out_count, u8* __restrict__ out_kind,
+    BDesc* __restrict__ retry, u32* __restrict__ retry_n, u8* __restrict__ bail_flag = nullptr, u32* __restrict__ bail_any = nullptr, MergeArgs mg = MergeArgs{}) {
     static_assert(CAP <= (1 << PK_BITS), "stream index must fit PK_BITS");
+    static_assert(!WS || sizeof(HiT) == 8, "wide suffixes keep their high part in 64-bit words");
+    typedef WalkEl<WS> EL;
+    typedef typename EL::T E;
     constexpr int ITEMS = CAP / THREADS, NW = THREADS / 64;
-    __shared__ u64 s_k[CAP + CAP / 8 + 6];  // slot p lives at p + p / 8; + the all-ones slots behind the run
+    static_assert(!MERGE || 64 * ITEMS < 1024, "the merge epilogue counts a wave's selections in 10-bit fields");
+    __shared__ E s_k[EL::slots(CAP)];       // slot p lives at EL::phys(p); + the all-ones slots behind the run
     __shared__ u32 s_off32[CAP / 2 + 2];    // sub-bucket counts, then exclusive offsets: 16-bit entries, counted with 32-bit atomics on the containing dword
     u16* s_off = reinterpret_cast<u16*>(s_off32);
     __shared__ u32 s_scan[NW + 1];
     __shared__ u32 s_wtot[NW + 1];
     __shared__ u32 s_max;
-    auto pad = [](u32 p) { return p + (p >> 3); };
+    __shared__ u32 s_sel[MERGE ? NW : 1];
 
     if (blockIdx.x >= *list_n) return;
     const BDesc dsc = list[blockIdx.x];
     const u32 r = dsc.r;
     const u64 s0 = dsc.start;
     const u32 c = dsc.c & BDESC_LEN_MASK;
-    const u32 skip = (dsc.c & BDESC_SKIP_MASK) >> BDESC_SKIP_SHIFT;
+    const u32 skip = (dsc.c & BDESC_SKIP_MASK) >> BDESC_SKIP_SHIFT;  // leading suffix bits shared by the whole run (sub-range of a long run)
     const bool res_trie = (dsc.c & BDESC_TRIE) != 0;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    if (c == 0) {  // an empty sub-range of a big run
+    if (c == 0) {  // an empty sub-range of a long run
         if (tid == 0) { out_count[r] = 0; out_kind[r] = KIND_TRIE; }
         return;
     }
-    u32 nbits = 32 - __builtin_clz(c - 1 > 0 ? c - 1 : 1);
+    u32 nbits = 32 - __builtin_clz(c - 1 > 0 ? c - 1 : 1);  // ceil(log2 c)
     if (nbits > SB - skip) nbits = SB - skip;
     const u32 NB = 1u << nbits, sub_sh = SB - skip - nbits;
-    constexpr u32 crowd = MSD_LIMIT;
+    constexpr u32 crowd = WS ? MSD_LIMIT_WIDE : MSD_LIMIT;
+    const bool merging = MERGE && mg.cs != nullptr;
+    u32 cs_m = 0;  // merge: self's length (index < cs_m = the element came from self)
+    if constexpr (MERGE) if (merging) cs_m = mg.cs[r];
     auto give_up = [&]() {
         if (tid == 0) {
             if (bail_flag) { bail_flag[blockIdx.x] = 1; *bail_any = 1u; }
@@ -1589,23 +1633,49 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 
     if (tid == 0) s_max = 0;
     __syncthreads();
     {
-        u64 key[ITEMS];
+        Sfx<WS> key[ITEMS];
         u32 sub[ITEMS], arr[ITEMS];
-        const u64 mask = SB >= 64 ? ~0ull : ((1ull << SB) - 1ull);
-        const u64* __restrict__ run_in = lo + s0;
+        // all loads first, unconditionally (slots past the run re-read its first word): eight independent global loads in flight per lane
+        if constexpr (MERGE) {
+            // element e is word e of `pa` (e < split) or of `pb` (other's pointer moved back by the split: no subtraction per slot)
+            const u64* pa = lo + s0;
+            const u64* pb = pa;
+            const u64* ha = WS ? reinterpret_cast<const u64*>(hi) + s0 : nullptr;
+            const u64* hb = ha;
+            u32 split = 0;
+            if (merging && mg.s_lo) {
+                split = cs_m;
+                const u64 a_self = mg.sstart[r], a_oth = mg.ostart[r];
+                pa = mg.s_lo + a_self;
+                pb = reinterpret_cast<const u64*>(reinterpret_cast<uintptr_t>(mg.o_lo + a_oth) - 8ull * split);
+                if constexpr (WS) {
+                    ha = mg.s_hi + a_self;
+                    hb = reinterpret_cast<const u64*>(reinterpret_cast<uintptr_t>(mg.o_hi + a_oth) - 8ull * split);
+                }
+            }
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {  // all loads first, unconditionally (slots past the run re-read its first word)
-            const u32 e = j * THREADS + tid;
-            key[j] = run_in[e < c ? e : 0u] & mask;
+            for (int j = 0; j < ITEMS; ++j) {
+                const u32 e = j * THREADS + tid, ee = e < c ? e : 0u;
+                const bool in_a = ee < split;
+                key[j] = load_sfx<WS, u64>(in_a ? pa : pb, in_a ? ha : hb, ee, SB);
+            }
+        } else {
+            const u64* __restrict__ run_lo = lo + s0;
+            const HiT* __restrict__ run_hi = WS ? hi + s0 : nullptr;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const u32 e = j * THREADS + tid;
+                key[j] = load_sfx<WS, HiT>(run_lo, run_hi, e < c ? e : 0u, SB);
+            }
         }
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const u32 e = j * THREADS + tid;
-            sub[j] = (u32)(key[j] >> sub_sh) & (NB - 1u);
+            sub[j] = sfx_bits_below<WS>(key[j], SB, skip, nbits);
             arr[j] = 0;
-            if (e < c) arr[j] = atomicAdd(&s_off32[sub[j] >> 1], 1u << ((sub[j] & 1u) * 16u));
+            if (e < c) arr[j] = atomicAdd(&s_off32[sub[j] >> 1], 1u << ((sub[j] & 1u) * 16u));  // raw dword; the field is cut out below
         }
-        bool crowded = false;
+        bool crowded = false;  // an arrival number of `crowd` = a sub-bucket of more than `crowd` entries
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             arr[j] = (arr[j] >> ((sub[j] & 1u) * 16u)) & 0xFFFFu;
@@ -1613,7 +1683,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 
         }
         if (crowded) s_max = crowd + 1u;  // benign race: every writer stores the same value
         __syncthreads();
-        if (s_max > crowd) { give_up(); return; }
+        if (s_max > crowd) { give_up(); return; }  // repeats (or a cluster beyond the limit): claim table (build) / radix kernel (merge, sub-ranges)
 #if CBLX_SORTED_PROBE == 1  // timing probe only: loads and counting atomics
         if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_TRIE; }
         if (s_off32[tid] != 0x12345678u) return;
@@ -1635,45 +1705,42 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 
         }
         __syncthreads();
         if (tid == 0) s_off[NB] = (u16)c;
-        if (tid < 4) s_k[pad(c + tid)] = ~0ull;  // what a walk may read behind the run compares greater than every element
+        if (tid < 4) s_k[EL::phys(c + tid)] = EL::ones();  // what a walk may read behind the run compares greater than every element
         u32 sbase[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) sbase[j] = s_off[sub[j]];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const u32 e = j * THREADS + tid;
-            if (e < c) s_k[pad(sbase[j] + arr[j])] = (key[j] << PK_BITS) | e;
+            if (e < c) s_k[EL::phys(sbase[j] + arr[j])] = EL::pack(key[j], e);
         }
     }
     __syncthreads();
 #if CBLX_SORTED_PROBE == 2  // timing probe only: everything up to the scatter
     if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_TRIE; }
-    if (s_k[tid] != 0x1234567ull) return;
+    if (s_off32[tid] != 0x1234567u) return;
 #endif
     // -- the walk: lane t owns slots [t per, t per + per) of the sub-bucket order
     const u32 per = (c + THREADS - 1) / THREADS;  // <= ITEMS
     const u32 p0 = tid * per;
     const u32 n_own = p0 < c ? (c - p0 < per ? c - p0 : per) : 0u;
-    u64 me[ITEMS];
+    E me[ITEMS];
     u32 fin[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const u32 p = p0 + i;
-        me[i] = s_k[pad(p < c ? p : c)];  // (slots past the lane's share read the all-ones slot or a neighbour's entry: never written back)
+        me[i] = s_k[EL::phys(p < c ? p : c)];  // (slots past the lane's share read the all-ones slot or a neighbour's entry: never written back)
         fin[i] = 0;
     }
     u32 A = 0, B = 0;
     if (n_own) {
-        u64 last = me[0];
+        E last = me[0];
 #pragma unroll
         for (int i = 1; i < ITEMS; ++i) if ((u32)i < n_own) last = me[i];
         // (rounded down to an even slot: the entry in front of the sub-bucket is smaller than every entry of mine, it counts like the rest in front)
-        A = s_off[(u32)(me[0] >> (PK_BITS + sub_sh)) & (NB - 1u)] & ~1u;
-        B = s_off[((u32)(last >> (PK_BITS + sub_sh)) & (NB - 1u)) + 1u];
+        A = s_off[EL::sub(me[0], sub_sh, nbits)] & ~1u;
+        B = s_off[EL::sub(last, sub_sh, nbits) + 1u];
     }
-#ifndef CBLX_SORTED_UNROLL
-#define CBLX_SORTED_UNROLL 2
-#endif
 #ifdef CBLX_SORTED_STATS  // dev: span statistics into retry_n[0..7] as u64 (tools/dev_msd_bench.cpp)
     {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(retry_n);
@@ -1690,12 +1757,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 
     // instantiated per `per` — uniform over the workgroup — so that a run of 1300 words (per = 6) does not pay for eight slots
     auto walk = [&](auto per_tag) {
         constexpr int PER = decltype(per_tag)::value;
-        // (A is even: the two slots of a step are neighbours in the padded array too, one address and an immediate offset)
         for (u32 q = A; q < B; q += 2) {
-            const u64* at = &s_k[pad(q)];
-            const u64 o0 = at[0], o1 = at[1];
+            E o0, o1;
+            if constexpr (WS) {
+                o0 = s_k[EL::phys(q)];
+                o1 = s_k[EL::phys(q + 1)];
+            } else {  // (A is even: the two slots of a step are neighbours in the padded array too, one address and an immediate offset)
+                const E* at = &s_k[EL::phys(q)];
+                o0 = at[0];
+                o1 = at[1];
+            }
 #pragma unroll
-            for (int i = 0; i < PER; ++i) fin[i] += (o0 < me[i] ? 1u : 0u) + (o1 < me[i] ? 1u : 0u);
+            for (int i = 0; i < PER; ++i) fin[i] += (EL::less(o0, me[i]) ? 1u : 0u) + (EL::less(o1, me[i]) ? 1u : 0u);
         }
     };
     if constexpr (ITEMS == 8) {
@@ -1711,15 +1784,76 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 
     }
 #if CBLX_SORTED_PROBE == 3  // timing probe only: everything up to the walk
     if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_TRIE; }
-    if (fin[0] + fin[1] + fin[2] + fin[3] + fin[4] + fin[5] + fin[6] + fin[7] != 0x12345678u) return;
+    { u32 t = 0;
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i) t += fin[i];
+      if (t != 0x12345678u) return; }
 #endif
     __syncthreads();  // every read of the sub-bucket order is done
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
-        if ((u32)i < n_own) s_k[pad(A + fin[i])] = me[i];
+        if ((u32)i < n_own) s_k[EL::phys(A + fin[i])] = me[i];
     __syncthreads();
-    // -- heads (the first slot of every suffix value) in wave-contiguous slices, counted, then compacted slot by slot
-    const u32 EPW = 64 * per;
+    const u32 EPW = 64 * per;  // wave-contiguous slices of the sorted slots: ballots then compact in order
+    Sfx<WS> val[ITEMS];
+    if constexpr (MERGE) if (merging) {
+        // three ordered selections of the sorted slots, counted and written together (k_bucket_msd's merge epilogue):
+        //   O = other's elements (back to other's arena, sorted)            A = Trie |= x: the heads (sorted union); Vec |= x: self's elements
+        //   B = Vec |= x only: other's heads = other \ self, behind self's   (every self element is a head)
+        const bool o_vec = mg.okind[r] == KIND_VEC;  // the reference's iter_sorted leaves other's Vec sorted
+        u32 fl[ITEMS];
+        u32 nO = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u32 p = w * EPW + j * 64 + lane;
+            const bool live = (u32)j < per && p < c;
+            const u32 pc = live ? p : 0u;
+            const E v = s_k[EL::phys(pc)], pv = s_k[EL::phys(pc ? pc - 1u : 0u)];
+            const bool hd = pc == 0 || !EL::same_sfx(v, pv), self_el = EL::idx(v) < cs_m;
+            val[j] = EL::sfx(v);
+            const bool inO = live && !self_el && o_vec, inA = live && (res_trie ? hd : self_el), inB = live && !res_trie && !self_el && hd;
+            fl[j] = (inO ? 1u : 0u) | (inA ? (1u << 10) : 0u) | (inB ? (1u << 20) : 0u);
+            nO += fl[j];
+        }
+        nO = wave_reduce_sum(nO);  // three 10-bit fields, <= 512 each
+        if (lane == 0) s_sel[w] = nO;
+        __syncthreads();
+        u32 runO = 0, runA = 0, runB = 0, totA = 0, totB = 0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) {
+            const u32 t = s_sel[ww], tO = t & 1023u, tA = (t >> 10) & 1023u, tB = t >> 20;
+            if ((u32)ww < w) { runO += tO; runA += tA; runB += tB; }
+            totA += tA;
+            totB += tB;
+        }
+        u64* __restrict__ self_lo = lo + s0;
+        u64* __restrict__ self_hi = WS ? reinterpret_cast<u64*>(hi) + s0 : nullptr;
+        const u64 obase = mg.ostart[r];
+        runB += cs_m;  // B follows self's cs elements
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u64 balO = __ballot((fl[j] & 1u) != 0), balA = __ballot((fl[j] & (1u << 10)) != 0), balB = __ballot((fl[j] & (1u << 20)) != 0);
+            if (fl[j] & 1u) {
+                const u32 q = runO + mbcnt(balO);
+                mg.o_lo[obase + q] = val[j].lo;
+                if constexpr (WS) mg.o_hi[obase + q] = val[j].hi;
+            }
+            if (fl[j] & ((1u << 10) | (1u << 20))) {  // A and B are disjoint
+                const u32 q = (fl[j] & (1u << 10)) ? runA + mbcnt(balA) : runB + mbcnt(balB);
+                self_lo[q] = val[j].lo;
+                if constexpr (WS) self_hi[q] = val[j].hi;
+            }
+            runO += (u32)__builtin_popcountll(balO);
+            runA += (u32)__builtin_popcountll(balA);
+            runB += (u32)__builtin_popcountll(balB);
+        }
+        if (tid == 0) {
+            out_count[r] = res_trie ? totA : cs_m + totB;
+            out_kind[r] = res_trie ? KIND_TRIE : KIND_VEC;
+        }
+        return;
+    }
+    // -- heads (the first slot of every suffix value), counted, then compacted slot by slot
     bool head[ITEMS];
     u32 wh = 0;
 #pragma unroll
@@ -1727,9 +1861,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 
         const u32 p = w * EPW + j * 64 + lane;
         const bool live = (u32)j < per && p < c;
         const u32 pc = live ? p : 0u;
-        const u64 v = s_k[pad(pc)], pv = s_k[pad(pc ? pc - 1u : 0u)];
-        head[j] = live && (pc == 0 || (v >> PK_BITS) != (pv >> PK_BITS));
-        me[j] = v >> PK_BITS;
+        const E v = s_k[EL::phys(pc)], pv = s_k[EL::phys(pc ? pc - 1u : 0u)];
+        head[j] = live && (pc == 0 || !EL::same_sfx(v, pv));
+        val[j] = EL::sfx(v);
         wh += (u32)__builtin_popcountll(__ballot(head[j]));
     }
     if (lane == 0) s_wtot[w] = wh;
@@ -1742,18 +1876,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP >= 
         d += t;
     }
     if (d <= VEC_THRESHOLD && !res_trie) { give_up(); return; }  // stays a Vec (repeats): stream order needed — nothing was written yet
-    u64* __restrict__ run_out = lo + s0;
+    u64* __restrict__ out_lo = lo + s0;
+    HiT* __restrict__ out_hi = WS ? hi + s0 : nullptr;
     if (d == c) {  // no repeat in the run (the usual case): every slot is a head and keeps its place
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const u32 p = w * EPW + j * 64 + lane;
-            if ((u32)j < per && p < c) run_out[p] = me[j];
+            if ((u32)j < per && p < c) store_sfx<WS, HiT>(out_lo, out_hi, p, val[j]);
         }
     } else {
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const u64 bal = __ballot(head[j]);
-            if (head[j]) run_out[run + mbcnt(bal)] = me[j];
+            if (head[j]) store_sfx<WS, HiT>(out_lo, out_hi, run + mbcnt(bal), val[j]);
             run += (u32)__builtin_popcountll(bal);
         }
     }

@@ -516,14 +516,14 @@ template <typename C> void big_stage(cblx_ctx* c, const BDesc* d_list, const u32
         // arguments: that one keeps the top-bit sub-bucket limit (the build's 1024-word class assumes hashed sub-buckets)
         auto sort = [&](auto pk) {
             constexpr bool PK = decltype(pk)::value;
-            if constexpr (PK && !WS) {  // sub-ranges are always asked for the sorted list: the walk kernel (round 6)
+            if constexpr (PK || WS) {  // sub-ranges are always asked for the sorted list: the walk kernel (round 6)
                 if (sorted_kernel()) {
                     if (cn[0])
-                        hipLaunchKernelGGL((k_bucket_sorted<128, 1024, HiT>), dim3(cn[0]), dim3(128), 0, c->stream, cls_lists.get(), cls_n.get() + 0, tw.lo.get(), P.SB, v_count.get(), v_kind.get(),
-                                           retry.get(), retry_n.get(), (u8*)nullptr, (u32*)nullptr);
-                    if (cn[1])
-                        hipLaunchKernelGGL((k_bucket_sorted<256, BIG_VCAP, HiT>), dim3(cn[1]), dim3(256), 0, c->stream, cls_lists.get() + vtot, cls_n.get() + 1, tw.lo.get(), P.SB, v_count.get(),
+                        hipLaunchKernelGGL((k_bucket_sorted<128, 1024, WS, HiT>), dim3(cn[0]), dim3(128), 0, c->stream, cls_lists.get(), cls_n.get() + 0, tw.lo.get(), th, P.SB, v_count.get(),
                                            v_kind.get(), retry.get(), retry_n.get(), (u8*)nullptr, (u32*)nullptr);
+                    if (cn[1])
+                        hipLaunchKernelGGL((k_bucket_sorted<256, BIG_VCAP, WS, HiT>), dim3(cn[1]), dim3(256), 0, c->stream, cls_lists.get() + vtot, cls_n.get() + 1, tw.lo.get(), th, P.SB,
+                                           v_count.get(), v_kind.get(), retry.get(), retry_n.get(), (u8*)nullptr, (u32*)nullptr);
                     return;
                 }
             }
@@ -675,10 +675,10 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
                     return;
                 }
                 used_msd[k] = true;
-                if constexpr (PK && !C::WS && CAPV > (int)VEC_THRESHOLD) {  // runs of more than 1024 words end up sorted (or give up: repeats): the walk kernel (round 6)
+                if constexpr ((PK || C::WS) && CAPV > (int)VEC_THRESHOLD) {  // runs of more than 1024 words end up sorted (or give up: repeats): the walk kernel (round 6)
                     if (use_sorted) {
-                        hipLaunchKernelGGL((k_bucket_sorted<T, CAPV, HiT>), dim3(ln[cls]), dim3(T), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls, a_lo, P.SB, nr.cnt.get(),
-                                           nr.kind.get(), (BDesc*)nullptr, (u32*)nullptr, bail.get() + roff[k], bail_any.get() + k);
+                        hipLaunchKernelGGL((k_bucket_sorted<T, CAPV, C::WS, HiT>), dim3(ln[cls]), dim3(T), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls, a_lo, a_hi, P.SB,
+                                           nr.cnt.get(), nr.kind.get(), (BDesc*)nullptr, (u32*)nullptr, bail.get() + roff[k], bail_any.get() + k);
                         return;
                     }
                 }
@@ -718,10 +718,10 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
                     Buf<u32> r3n(c->pool, 1);
                     CBLX_HIP(hipMemsetAsync(r3n.get(), 0, 4, c->stream));
                     bool done2 = false;
-                    if constexpr (PK && !C::WS) {
+                    if constexpr (PK || C::WS) {
                         if (use_sorted) {
-                            hipLaunchKernelGGL((k_bucket_sorted<512, 4096, HiT>), dim3(n2), dim3(512), 0, c->stream, retry2.get(), r2n, a_lo, P.SB, nr.cnt.get(), nr.kind.get(), retry3.get(), r3n.get(),
-                                               (u8*)nullptr, (u32*)nullptr);
+                            hipLaunchKernelGGL((k_bucket_sorted<512, 4096, C::WS, HiT>), dim3(n2), dim3(512), 0, c->stream, retry2.get(), r2n, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry3.get(),
+                                               r3n.get(), (u8*)nullptr, (u32*)nullptr);
                             done2 = true;
                         }
                     }
@@ -775,8 +775,8 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
                 auto sort = [&](auto pk) {
                     if constexpr (decltype(pk)::value) {
                         if (sorted_kernel()) {
-                            hipLaunchKernelGGL((k_bucket_sorted<256, 2048, HiT>), dim3(cn[2]), dim3(256), 0, c->stream, srt.get(), cnts.get() + 2, a_lo, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(),
-                                               cnts.get() + 3, (u8*)nullptr, (u32*)nullptr);
+                            hipLaunchKernelGGL((k_bucket_sorted<256, 2048, false, HiT>), dim3(cn[2]), dim3(256), 0, c->stream, srt.get(), cnts.get() + 2, a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(),
+                                               retry.get(), cnts.get() + 3, (u8*)nullptr, (u32*)nullptr);
                             return;
                         }
                     }
@@ -1523,6 +1523,22 @@ template <typename C> void merge_direct(cblx_ctx* c, const Resident& s, const Re
         CBLX_HIP(hipMemsetAsync(retry_n.get(), 0, 4, c->stream));
         auto msd = [&](auto packed_tag) {
             constexpr bool PK = decltype(packed_tag)::value;
+            if constexpr (PK || WS) {  // packed elements: the walk kernel in its merge mode (round 6), class by class as below
+                if (sorted_kernel()) {
+                    auto go = [&](auto thr, auto cap, int cls) {
+                        constexpr int T = decltype(thr)::value, CAPV = decltype(cap)::value;
+                        if (ln[cls])
+                            hipLaunchKernelGGL((k_bucket_sorted<T, CAPV, WS, HiT, true>), dim3(ln[cls]), dim3(T), 0, c->stream, lists.get() + (size_t)cls * nb, list_n.get() + cls, a_lo, a_hi, P.SB,
+                                               nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), (u8*)nullptr, (u32*)nullptr, ma_msd);
+                    };
+                    go(std::integral_constant<int, 64>(), std::integral_constant<int, 128>(), CLS_M16);
+                    go(std::integral_constant<int, 64>(), std::integral_constant<int, 512>(), CLS_M64);
+                    go(std::integral_constant<int, 128>(), std::integral_constant<int, 1024>(), CLS_M128);
+                    go(std::integral_constant<int, 256>(), std::integral_constant<int, 2048>(), CLS_M256);
+                    go(std::integral_constant<int, 512>(), std::integral_constant<int, 4096>(), CLS_M512);
+                    return;
+                }
+            }
             if (ln[CLS_M16])
                 hipLaunchKernelGGL((k_bucket_msd<64, 128, PK, WS, HiT, true>), dim3(ln[CLS_M16]), dim3(64), 0, c->stream, lists.get() + (size_t)CLS_M16 * nb, list_n.get() + CLS_M16,
                                    a_lo, a_hi, P.SB, nr.cnt.get(), nr.kind.get(), retry.get(), retry_n.get(), ma_msd);

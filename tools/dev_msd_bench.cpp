@@ -210,11 +210,11 @@ int main(int argc, char** argv) {
 #ifdef CBLX_SORTED_STATS
             static unsigned long long* d_st = dalloc<unsigned long long>(8);
             CK(hipMemset(d_st, 0, 64));
-            hipLaunchKernelGGL((k_bucket_sorted<T, CAPV, u8>), dim3(ln[k]), dim3(T), 0, 0, lists + (size_t)k * nruns, list_n + k, arena, SB, cnt, kind, (BDesc*)nullptr, (u32*)d_st, bail, bail_any);
+            hipLaunchKernelGGL((k_bucket_sorted<T, CAPV, false, u8>), dim3(ln[k]), dim3(T), 0, 0, lists + (size_t)k * nruns, list_n + k, arena, (u8*)nullptr, SB, cnt, kind, (BDesc*)nullptr, (u32*)d_st, bail, bail_any);
             if (rep == reps) { unsigned long long h[4]; CK(hipMemcpy(h, d_st, 32, hipMemcpyDeviceToHost));
                 printf("  span: mean per owning lane %.1f, mean of the wave maxima %.1f (%llu waves)\n", (double)h[0] / h[2], (double)h[1] / h[3], h[3]); }
 #else
-            hipLaunchKernelGGL((k_bucket_sorted<T, CAPV, u8>), dim3(ln[k]), dim3(T), 0, 0, lists + (size_t)k * nruns, list_n + k, arena, SB, cnt, kind, (BDesc*)nullptr, (u32*)nullptr, bail, bail_any);
+            hipLaunchKernelGGL((k_bucket_sorted<T, CAPV, false, u8>), dim3(ln[k]), dim3(T), 0, 0, lists + (size_t)k * nruns, list_n + k, arena, (u8*)nullptr, SB, cnt, kind, (BDesc*)nullptr, (u32*)nullptr, bail, bail_any);
 #endif
             CK(hipEventRecord(e1));
             CK(hipEventSynchronize(e1));
