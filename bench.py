@@ -132,13 +132,15 @@ def parse_args(argv=None):
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--canonical", action="store_true")
-    ap.add_argument("--protocol", choices=["auto", "bins", "sorted", "words"], default=None,
-                    help="N > 1: what crosses the links. native transport: auto (default: the library's choice — sorted on 2 - 4 ranks, where one link per pair "
-                         "of GPUs bounds the job, bins otherwise), bins or sorted; torch transport: sorted (default) or words")
+    ap.add_argument("--protocol", choices=["auto", "bins", "sorted", "replicate", "words"], default=None,
+                    help="N > 1: what crosses the links. native transport: auto (default: the library's choice — replicate on 2 - 3 ranks, where one link per pair "
+                         "of GPUs bounds every protocol that ships words, sorted on 4, bins otherwise), bins, sorted or replicate (the reads as bit planes, every rank "
+                         "transforms all of them and keeps its prefix range); torch transport: sorted (default) or words")
     ap.add_argument("--slices", type=int, default=None,
                     help="N > 1: slices per rank and step. Default 3 for the native bins protocol, 50 / 30 / 20 % of the reads (its grouped receiver sends "
                          "group-major after the rank's whole first pass; the first group's share of slices 0 and 1 crosses under the next slice's kernels, only "
-                         "the short last slice's share of it is exposed), 4 otherwise (the exchange of a slice overlaps the next slice's kernels)")
+                         "the short last slice's share of it is exposed), 1 for replicate (one all-gather of the planes up front), 4 otherwise (the exchange of a "
+                         "slice overlaps the next slice's kernels)")
     ap.add_argument("--transport", choices=["torch", "native"], default="native",
                     help="N > 1: exchange driven from Python over torch.distributed, or the whole sharded insert inside libcblx on RCCL directly")
     ap.add_argument("--cpu-sample-reads", type=int, default=None,
@@ -164,13 +166,13 @@ def parse_args(argv=None):
     if args.protocol is None:
         args.protocol = "auto" if args.transport == "native" else "sorted"
     # what "auto" resolves to inside the library (cblx.h: CBLX_PROTO_AUTO; restated here because the slice schedule follows it)
-    args.protocol_resolved = ("sorted" if 2 <= args.gpus <= 4 else "bins") if args.protocol == "auto" else args.protocol
+    args.protocol_resolved = ("replicate" if 2 <= args.gpus <= 3 else ("sorted" if args.gpus == 4 else "bins")) if args.protocol == "auto" else args.protocol
     cfg = CONFIGS[args.config]
     for name in ("k", "prefix_bits", "reads", "read_len"):
         if getattr(args, name) is None:
             setattr(args, name, cfg[name])
     if args.slices is None:
-        args.slices = 3 if (args.transport == "native" and args.protocol_resolved == "bins" and not args.force_sharded) else 4
+        args.slices = 3 if (args.transport == "native" and args.protocol_resolved == "bins" and not args.force_sharded) else (1 if args.protocol_resolved == "replicate" else 4)
     args.kind = cfg["kind"]
     args.genome = cfg.get("genome", 0)
     if args.cpu_sample_reads is None:  # the oracle slows down with PREFIX_BITS (2^28-bit Fenwick bitvector) and word width

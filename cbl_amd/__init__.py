@@ -316,19 +316,19 @@ class Comm:
     def sim_store_free(store_id: int):
         lib().cblx_sim_store_free(store_id)
 
-    PROTOCOLS = {"sorted": 0, "bins": 1, "auto": 2}  # CBLX_PROTO_SORTED / CBLX_PROTO_BINS / CBLX_PROTO_AUTO (include/cblx.h)
+    PROTOCOLS = {"sorted": 0, "bins": 1, "auto": 2, "replicate": 3}  # CBLX_PROTO_SORTED / _BINS / _AUTO / _REPLICATE (include/cblx.h)
 
     @staticmethod
     def auto_protocol(world: int) -> str:
-        """What "auto" resolves to (the library's rule, restated for callers that shape their slices by it): "sorted" on 2 - 4 ranks
-        (one link per pair of GPUs bounds the job), "bins" otherwise."""
-        return "sorted" if 2 <= world <= 4 else "bins"
+        """What "auto" resolves to (the library's rule, restated for callers that shape their slices by it): "replicate" on 2 - 3 ranks
+        (one link per pair of GPUs bounds every protocol that ships words: the reads cross instead), "sorted" on 4, "bins" otherwise."""
+        return "replicate" if 2 <= world <= 3 else ("sorted" if world == 4 else "bins")
 
     def protocol_used(self) -> str:
         """What the last sharded insert of this rank ran on ("auto" resolved; "bins" falls back to "sorted" at PREFIX_BITS <= 8)."""
         v = C.c_uint32(0)
         self._L.cblx_comm_protocol_used(self._h, C.byref(v))
-        return {0: "sorted", 1: "bins"}[v.value]
+        return {0: "sorted", 1: "bins", 3: "replicate"}[v.value]
 
     def set_protocol(self, name: str):
         """What crosses the links in sharded_insert_seqs_device: "bins" (exchange between the first and the second partition pass),

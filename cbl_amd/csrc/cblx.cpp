@@ -570,7 +570,7 @@ int cblx_comm_stats(cblx_comm* cm, cblx_exchange_stats* out, int reset) {
     return CBLX_OK;
 }
 int cblx_comm_set_protocol(cblx_comm* cm, uint32_t protocol) {
-    if (!cm || (protocol != CBLX_PROTO_SORTED && protocol != CBLX_PROTO_BINS && protocol != CBLX_PROTO_AUTO)) return CBLX_EINVAL;
+    if (!cm || (protocol != CBLX_PROTO_SORTED && protocol != CBLX_PROTO_BINS && protocol != CBLX_PROTO_AUTO && protocol != CBLX_PROTO_REPLICATE)) return CBLX_EINVAL;
     cm->protocol = protocol;
     return CBLX_OK;
 }

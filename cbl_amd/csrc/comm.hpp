@@ -801,16 +801,38 @@ u64 fine_min_words() {  // read per call: tests switch it
     const char* e = std::getenv("CBLX_FINE_MIN");
     return e ? std::strtoull(e, nullptr, 10) : (u64)(4u << 20);
 }
+// What CBLX_PROTO_AUTO resolves to on `world` ranks (cblx.h): between 2 and 4 GPUs every pair shares ONE link and the words of "bins" / "sorted" are
+// bound by it — on 2 and 3 ranks the reads themselves cross ("replicate": 49.8 / 61.9 ms per step at cfg 3 and 55 GB/s per link against 101.3 / 76.7
+// "sorted" and 127 / 89.8 "bins", profiles/r06_wire_emulated.md); on 4 the W encodes of "replicate" cost more than the packed suffixes of "sorted"
+// (74.7 against 69.1); from 5 ranks on the receiver's kernels are the bound and "bins" adds no pass.
+inline u32 auto_protocol(u32 world) { return world >= 2 && world <= 3 ? CBLX_PROTO_REPLICATE : (world == 4 ? CBLX_PROTO_SORTED : CBLX_PROTO_BINS); }
 inline u32 recv_groups_wanted(const cblx_comm* cm) {
     if (cm->recv_groups) return cm->recv_groups;
     const char* e = std::getenv("CBLX_RECV_GROUPS");
     const u32 v = e ? (u32)std::strtoul(e, nullptr, 10) : 0;
-    return v ? std::min(v, 14u) : 4u;  // measured against a paced wire (profiles/r04_wire_emulated.md): 4 groups are best at 55 GB/s per link for every configuration; more pay on slower links
+    if (v) return std::min(v, 14u);
+    // "replicate" has no wire for its groups to hide: two of them (the FINE bins still want the dense part of the range apart from the tail) — 48.2
+    // against 49.0 ms with four at cfg 3 on two ranks
+    const u32 proto = cm->protocol == CBLX_PROTO_AUTO && cm->t ? auto_protocol(cm->t->world) : cm->protocol;
+    if (proto == CBLX_PROTO_REPLICATE) return 2u;
+    return 4u;  // measured against a paced wire (profiles/r04_wire_emulated.md): 4 groups are best at 55 GB/s per link for every configuration; more pay on slower links
 }
+// The "replicate" protocol (sharded_insert_replicate below): the READS of every rank as this rank holds them after the all-gather — the own ones
+// as the caller's ASCII bytes, the peers' as bit planes indexed by the sender's base positions — with every rank's slice cuts.
+struct ReplicaSource {
+    BaseView view{nullptr, nullptr, nullptr};
+    const u64* d_off = nullptr;  // nseq + 1 offsets (the sender's own positions)
+    u64 nseq = 0;
+    std::vector<u64> cuts;       // nslices + 1 sequence indices relative to d_off
+};
+struct Replica { std::vector<ReplicaSource> src; };
 // `single`: ONE rank whose "groups" are the part of the prefix space the FINE bins cover in blocks of 2^16 prefixes and the rest (insert_device_fine):
 // no wire, the same sender and receiver steps
+// `rep`: no records cross the wire — piece (slice, source) is what THIS rank's first pass keeps of the source's reads (its own prefix range), the
+// receiver steps are the same
 template <typename C>
-bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, const u32* bounds, bool single = false) {
+bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, const u32* bounds, bool single = false,
+                            const Replica* rep = nullptr) {
     typedef typename C::HiT HiT;
     constexpr bool WS = C::WS;
     constexpr bool DROP_HI = std::is_same<HiT, u8>::value;
@@ -861,7 +883,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     // reads the records instead (8 bytes per word where it read 1: about the millisecond the senders' byte stores cost). CBLX_WIRE_DIGITS=1 sends
     // it as rounds 3 - 4 did; one rank (no wire) always keeps it.
     const char* wd_env = std::getenv("CBLX_WIRE_DIGITS");
-    const bool wire_dig = single || (wd_env && wd_env[0] == '1');
+    const bool wire_dig = single || rep != nullptr || (wd_env && wd_env[0] == '1');
     // What crosses the wire follows from switches every rank reads in its OWN environment (CBLX_FINE_BINS, CBLX_WIRE_DIGITS, CBLX_FINE_TAIL_WEIGHT,
     // CBLX_RECV_GROUPS): they are job-wide. A rank started with other values would wait for items its peers never send, or bin records by another
     // table — so the resolved choices ride in the all-reduce below (sum and sum of squares: equal on every rank iff W x sum(v^2) = sum(v)^2).
@@ -981,6 +1003,83 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     ChunkPlan PL;
     BaseView pb = ascii_view(d_bases);
     std::vector<PlanSlice> psl(nslices);
+    if (rep) {
+        // -- "replicate": KRN-1 + the first pass over EVERY rank's reads, piece by piece; the pass keeps the records of this rank's prefix range (they
+        //    go straight into the log) and drops the others. The own pieces first: the peers' planes are still crossing the links meanwhile.
+        if (rep->src.size() != W) throw Error(CBLX_EINVAL, "replicate: one source per rank (internal error)");
+        pcnt.assign((size_t)nslices * W * 256, 0u);
+        pbase.assign((size_t)nslices * W, 0u);
+        alloc_log(cap, a_lo, a_hi, a_dig);
+        u64 over = 0;
+        bool waited = false;
+        for (u32 k = 0; k < W; ++k) {
+            const u32 r = k == 0 ? me : (k <= me ? k - 1 : k);
+            const ReplicaSource& R = rep->src[r];
+            if (R.cuts.size() != (size_t)nslices + 1) throw Error(CBLX_EINVAL, "replicate: slice cuts of a source (internal error)");
+            if (r != me && !waited) { T.wait(); waited = true; }  // (the own pieces' kernels are queued: they run while the host waits here)
+            if (R.nseq == 0 || over) continue;
+            ChunkPlan PLr;
+            std::vector<PlanSlice> pslr(nslices);
+            BaseView vr = R.view;
+            plan_chunks(c, vr, R.d_off, R.nseq, PLr, nullptr, &R.cuts, &pslr);
+            for (u32 s = 0; s < nslices && !over; ++s) {
+                const u64 N = pslr[s].k_hi - pslr[s].k_lo;
+                prev_work = Work();
+                if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "one slice takes fewer than 2^32-16 words (use more slices)");
+                if (!N) continue;
+                const u32 ntiles = (u32)ceil_div(N, RDX_TILE);
+                Work wk;
+                wk.coltot = Buf<u32>(c->pool, 256);
+                wk.adj = Buf<u32>(c->pool, 256);
+                const size_t hs = hi_elem_size(P);
+                wk.t_lo = Buf<u64>(c->pool, N + 2);
+                wk.t_hi = Buf<u8>(c->pool, hs ? (N + 2) * hs : 8);
+                wk.counts = Buf<u32>(c->pool, (size_t)256 * (ntiles + 2));
+                wk.colpre = Buf<u32>(c->pool, (size_t)256 * ntiles);
+                CBLX_HIP(hipMemsetAsync(wk.counts.get(), 0, (size_t)256 * (ntiles + 2) * 4, c->stream));
+                EncHist eh = eh0;
+                eh.counts = wk.counts.get();
+                encode<C>(c, vr, PLr, wk.t_lo.get(), (HiT*)wk.t_hi.get(), 0, eh, &pslr[s]);
+                { StageTimer t(c, ST_SCAN);
+                  colscan(c, wk.counts.get(), nullptr, ntiles, wk.colpre.get(), wk.coltot.get(), wk.scratch);
+                  hipLaunchKernelGGL(k_seg_adjust, dim3(1), dim3(256), 0, c->stream, wk.colpre.get(), wk.coltot.get(), (const u32*)nullptr, (const u32*)nullptr,
+                                     (const u32*)nullptr, ntiles, 1u, wk.adj.get()); }
+                CBLX_HIP(hipGetLastError());
+                const std::vector<u32> tot = d2h_vec<u32>(c, wk.coltot.get(), 256);
+                u64 sum = 0, own_a = 0, own = 0;
+                const size_t piece = (size_t)s * W + r;
+                for (u32 bin = 0; bin < 256; ++bin) {
+                    if (!tot[bin]) continue;
+                    if (M.iv_of[bin] == 0xFFFFFFFFu) throw Error(CBLX_EDEVICE, "sharded build: a word fell into a bin no prefix maps to (internal error)");
+                    const u32 d = M.dest_of[M.iv_of[bin]];
+                    if (d < me) own_a += tot[bin];
+                    if (d == me) { own += tot[bin]; pcnt[piece * 256 + (bin - my_lo)] = tot[bin]; }
+                    sum += tot[bin];
+                }
+                if (sum != N) throw Error(CBLX_EDEVICE, "sharded build: the bin histogram counts " + std::to_string(sum) + " words, the piece has " + std::to_string(N) + " (internal error)");
+                if (filled + own >= LIMIT) { over = 1; break; }  // (settled with the other ranks below: the job leaves together)
+                if (filled + own > cap) grow(filled + own);
+                pbase[piece] = (u32)filled;
+                {
+                    const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
+                    const OwnWindow ow{own_a, own_a + own, a_lo.get() + filled, OHS ? (void*)(a_hi.get() + filled * OHS) : nullptr, a_dig.get() + filled};
+                    StageTimer t(c, ST_SCATTER);
+                    c->stages[ST_SCATTER].units += N;
+                    hipLaunchKernelGGL((k_radix_scatter<HiT, OutH, DigitCut, true>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, (const u64*)wk.t_lo.get(), (const HiT*)wk.t_hi.get(), tv, fn,
+                                       (const u32*)wk.colpre.get(), (const u32*)wk.adj.get(), (u64*)nullptr, (OutH*)nullptr, nextd, (u8*)nullptr, (u32*)nullptr, 0u, 0u, 0u, (u32*)nullptr, 0u, ow);
+                    CBLX_HIP(hipGetLastError());
+                }
+                if (trace) fprintf(stderr, "[cblx replicate] rank %u piece (slice %u, source %u): N=%llu kept=%llu filled=%llu\n", me, s, r, (unsigned long long)N, (unsigned long long)own,
+                                   (unsigned long long)filled);
+                filled += own;
+                prev_work = std::move(wk);
+            }
+            CBLX_HIP(hipStreamSynchronize(c->stream));  // the source's plan dies here
+        }
+        if (!waited) T.wait();
+        T.all_reduce_sum_u64(&over, 1);
+        if (over) throw Error(CBLX_ERANGE, "a rank's share of the job takes more than one round: use more ranks");
+    } else {
     if (n1 > n0) {
         std::vector<u64> marks(nslices + 1);
         for (u32 s = 0; s <= nslices; ++s) marks[s] = cuts[s] - n0;
@@ -1084,6 +1183,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         CBLX_HIP(hipEventCreateWithFlags(&gev[k], hipEventDisableTiming));
         T.record(gev[k], c->stream);
     }
+    }  // (records on the wire)
     prev_work = Work();  // (the stream is past the last slice's pass A once the first group is waited for; the workspace is only returned to the pool)
     // -- the receiver, group by group behind the wire
     const u64 nprefix = 1ull << P.PB, nwords = std::max<u64>(1, nprefix / 64);
@@ -1214,6 +1314,94 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     return true;
 }
 
+// ---- protocol "replicate" (round 6): ship READS, not words -----------------------------------------------------------------------------
+// Between 2 - 4 GPUs every pair shares ONE xGMI link, and the words of the other protocols put 5 - 8 bytes per k-mer on it: at cfg 3 and 55 GB/s
+// per link two ranks take 101 ms per step ("sorted"; 127 "bins") where ONE GPU builds the same reads in 39 (profiles/r05_wire_emulated.md). The
+// k-mer -> word transform is a pure function of the bases, and the bases are 0.3 bytes per k-mer as bit planes (3 bits per base,
+// 150 / 120 bases per k-mer): every rank packs ITS reads into planes on the device (k_pack_planes), the planes and the read offsets are
+// all-gathered, and every rank runs KRN-1 and the first partition pass over ALL ranks' reads, keeping the words of its own prefix range
+// (k_radix_scatter drops the others where it would have sent them) — W encodes per rank instead of one, nothing else added, and the job's stream
+// order (slice-major, rank-minor) holds by construction: the pieces are the same (slice, source) pieces the "bins" receiver sees, made locally.
+// The receiver steps (groups, FINE bins, directory windows, bucket kernels) are sharded_insert_grouped's own.
+template <typename C>
+bool sharded_insert_replicate(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_offsets, u64 n, const u64* cuts, u32 nslices, const u32* bounds) {
+    Transport& T = *cm->t;
+    const u32 W = T.world, me = T.rank;
+    if (W < 2 || nslices == 0) return false;
+    check_aligned16(d_bases, "d_bases");
+    for (u32 s = 0; s < nslices; ++s) if (cuts[s + 1] < cuts[s] || cuts[s + 1] > n) throw Error(CBLX_EINVAL, "slice cuts must be ascending and at most n");
+    const u64 n0 = cuts[0], n1 = cuts[nslices], nseq = n1 - n0;
+    u64 first = 0, last = 0;
+    if (nseq) {
+        first = d2h<u64>(c, d_offsets + n0);
+        last = d2h<u64>(c, d_offsets + n1);
+        if (last < first) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
+    }
+    const u64 g0 = first >> 4, g1 = nseq ? (last + 15) >> 4 : g0, ng = g1 - g0;
+    // -- what every rank holds: sequences, plane groups, slice cuts
+    const size_t per = 3 + (size_t)nslices + 1;
+    std::vector<u64> send(per * W), recv(per * W);
+    for (u32 d = 0; d < W; ++d) {
+        u64* h = send.data() + d * per;
+        h[0] = nseq; h[1] = g0; h[2] = g1;
+        for (u32 s = 0; s <= nslices; ++s) h[3 + s] = cuts[s] - n0;
+    }
+    T.all_to_all_u64(send.data(), recv.data(), per);
+    // -- own planes, then the all-gather of planes and offsets (one grouped exchange; the own pieces are transformed under it)
+    Buf<u32> my_codes(c->pool, ng + 4);
+    Buf<u16> my_valid(c->pool, ng + 4);
+    if (ng) hipLaunchKernelGGL(k_pack_planes, grid1(ng, 256), dim3(256), 0, c->stream, d_bases, g0, g1, last, my_codes.get(), my_valid.get());
+    CBLX_HIP(hipGetLastError());
+    std::vector<u64> gro(W + 1, 0), sqo(W + 1, 0);  // plane groups / offset words in front of every peer's share of the gather buffers
+    for (u32 r = 0; r < W; ++r) {
+        const u64* h = recv.data() + r * per;
+        if (h[2] < h[1]) throw Error(CBLX_EDEVICE, "replicate: a rank announced a negative plane range (transport error)");
+        gro[r + 1] = gro[r] + (r == me ? 0 : h[2] - h[1] + 4);  // (+ slack: the tile loads of KRN-1 read a few words ahead)
+        sqo[r + 1] = sqo[r] + (r == me ? 0 : h[0] + 1);
+    }
+    Buf<u32> all_codes(c->pool, gro[W] + 4);
+    Buf<u16> all_valid(c->pool, gro[W] + 4);
+    Buf<u64> all_off(c->pool, sqo[W] + 2);
+    CBLX_HIP(hipMemsetAsync(all_codes.get(), 0, (gro[W] + 4) * 4, c->stream));
+    CBLX_HIP(hipMemsetAsync(all_valid.get(), 0, (gro[W] + 4) * 2, c->stream));
+    {
+        auto item = [&](const void* src, void* dst, u64 mine_elems, size_t es, const std::vector<u64>& off, auto elems_of) {
+            Transport::Item it{(const u8*)src, (u8*)dst, std::vector<u64>(W, 0), std::vector<u64>(W, 0), std::vector<u64>(W, 0), std::vector<u64>(W, 0)};
+            for (u32 r = 0; r < W; ++r) {
+                if (r == me) continue;
+                it.s_len[r] = mine_elems * es;
+                it.r_off[r] = off[r] * es;
+                it.r_len[r] = elems_of(r) * es;
+            }
+            return it;
+        };
+        std::vector<Transport::Item> items;
+        items.push_back(item(my_codes.get(), all_codes.get(), ng, 4, gro, [&](u32 r) { return recv[r * per + 2] - recv[r * per + 1]; }));
+        items.push_back(item(my_valid.get(), all_valid.get(), ng, 2, gro, [&](u32 r) { return recv[r * per + 2] - recv[r * per + 1]; }));
+        items.push_back(item(d_offsets + n0, all_off.get(), nseq ? nseq + 1 : 0, 8, sqo, [&](u32 r) { return recv[r * per] ? recv[r * per] + 1 : 0; }));
+        T.exchange_items(items, c->stream);
+    }
+    Replica rep;
+    rep.src.resize(W);
+    for (u32 r = 0; r < W; ++r) {
+        ReplicaSource& R = rep.src[r];
+        const u64* h = recv.data() + r * per;
+        R.nseq = h[0];
+        R.cuts.assign(h + 3, h + 3 + nslices + 1);
+        for (u32 s = 0; s < nslices; ++s) if (R.cuts[s + 1] < R.cuts[s] || R.cuts[s + 1] > R.nseq) throw Error(CBLX_EDEVICE, "replicate: a rank announced slice cuts out of order (transport error)");
+        if (r == me) { R.view = ascii_view(d_bases); R.d_off = d_offsets + n0; }
+        else {  // planes indexed by the SENDER's base positions: group g of the sender is word g - g0 of its share
+            R.view = BaseView{nullptr, all_codes.get() + gro[r] - h[1], all_valid.get() + gro[r] - h[1]};
+            R.d_off = all_off.get() + sqo[r];
+        }
+    }
+    struct Drain { Transport& t; ~Drain() { try { t.wait(); } catch (...) {} } } drain{T};
+    const bool done = sharded_insert_grouped<C>(c, cm, d_bases, d_offsets, n, cuts, nslices, bounds, false, &rep);
+    T.wait();
+    CBLX_HIP(hipStreamSynchronize(c->stream));  // the gather buffers die here
+    return done;
+}
+
 // one rank's FINE plan: the one "group cut" below which the bins are blocks of 2^16 prefixes (insert_device_fine; a one-rank communicator)
 inline u32 fine_single_cut(u32 PB) { return std::min<u32>(245u << FINE_LEVEL, (1u << (PB - 1)) - (1u << FINE_LEVEL)); }
 template <typename C>
@@ -1223,7 +1411,8 @@ void sharded_insert(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_
     if (nslices && !*bounds_valid) {
         if (cuts[1] < cuts[0] || cuts[1] > n) throw Error(CBLX_EINVAL, "slice cuts must be ascending and at most n");
         std::vector<u64> hist;
-        const bool want_bins = cm->protocol == CBLX_PROTO_AUTO ? !(T.world >= 2 && T.world <= 4) : cm->protocol == CBLX_PROTO_BINS;
+        const u32 asked = cm->protocol == CBLX_PROTO_AUTO ? auto_protocol(T.world) : cm->protocol;
+        const bool want_bins = asked == CBLX_PROTO_BINS || asked == CBLX_PROTO_REPLICATE;
         const u32 G = recv_groups_wanted(cm);
         choose_bounds_from_slice<C>(c, T, d_bases, d_offsets + cuts[0], cuts[1] - cuts[0], bounds, &hist, (want_bins && G >= 2) ? G : 0u);
         *bounds_valid = 1;
@@ -1234,10 +1423,14 @@ void sharded_insert(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const u64* d_
     }
     cm->groups_used = 0;
     cm->groups_fine = 0;
-    // AUTO: between 2 and 4 ranks every pair of GPUs shares one link and its bytes bound the job — "sorted" moves a third fewer
-    // (rehearsed: profiles/r05_wire_emulated.md); from 5 ranks on the receiver's kernels are the bound and "bins" adds no pass
-    u32 proto = cm->protocol == CBLX_PROTO_AUTO ? ((T.world >= 2 && T.world <= 4) ? CBLX_PROTO_SORTED : CBLX_PROTO_BINS) : cm->protocol;
-    if (proto == CBLX_PROTO_BINS && !bins_protocol_fits(c->P, bounds, T.world)) proto = CBLX_PROTO_SORTED;
+    u32 proto = cm->protocol == CBLX_PROTO_AUTO ? auto_protocol(T.world) : cm->protocol;
+    if ((proto == CBLX_PROTO_BINS || proto == CBLX_PROTO_REPLICATE) && !bins_protocol_fits(c->P, bounds, T.world)) proto = CBLX_PROTO_SORTED;
+    if (proto == CBLX_PROTO_REPLICATE) {
+        // (every term of the decision inside is replicated: the ranks take the fallback together)
+        cm->protocol_used = CBLX_PROTO_REPLICATE;
+        if (T.world >= 2 && sharded_insert_replicate<C>(c, cm, d_bases, d_offsets, n, cuts, nslices, bounds)) return;
+        proto = CBLX_PROTO_BINS;  // a non-empty index, a plan the cuts refuse, one rank: the records cross the wire as before
+    }
     cm->protocol_used = proto;
     if (proto == CBLX_PROTO_BINS) {
         if (T.world == 1 && c->P.PB > 24 && c->res.count == 0) {

@@ -61,6 +61,34 @@ __device__ __forceinline__ u32 planes_to_codes(u32 w) {
     return spread(r0) | (spread(r1) << 1);
 }
 
+// ASCII bases -> the bit planes above, on the device (the "replicate" protocol of the multi-GPU build ships a rank's reads as planes:
+// 3 bits per base on the wire instead of 8). One thread per group of 16 bases [16 g, 16 g + 16) of `ascii` (16-byte aligned), groups
+// [g0, g1); bases at or past `end` leave their bits clear, as the host packer does (xfer.hpp). Plane words are indexed from g0.
+__global__ __launch_bounds__(256) void k_pack_planes(const u8* __restrict__ ascii, u64 g0, u64 g1, u64 end, u32* __restrict__ codes, u16* __restrict__ valid) {
+    const u64 g = g0 + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= g1) return;
+    u32 w[4] = {0, 0, 0, 0};
+    if (16 * g + 16 <= end) {
+        const uint4 v = *reinterpret_cast<const uint4*>(ascii + 16 * g);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {  // the batch's last, partly filled group: byte by byte (nothing is read past the end)
+        for (u64 i = 16 * g; i < end; ++i) w[(i >> 2) & 3] |= (u32)ascii[i] << (8 * (i & 3));
+    }
+    u32 c0 = 0, c1 = 0, ok = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const u32 b = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+        c0 |= ((b >> 1) & 1u) << k;
+        c1 |= ((b >> 2) & 1u) << k;
+        ok |= (nuc_valid((u8)b) ? 1u : 0u) << k;
+    }
+    const u64 base = 16 * g;
+    const u32 live = base + 16 <= end ? 0xFFFFu : (base >= end ? 0u : (1u << (u32)(end - base)) - 1u);
+    ok &= live;
+    codes[g - g0] = (c0 & ok) | ((c1 & ok) << 16);
+    valid[g - g0] = (u16)ok;
+}
+
 #ifndef CBLX_ENC_UNIFORM
 #define CBLX_ENC_UNIFORM 1
 #endif

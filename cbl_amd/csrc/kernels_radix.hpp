@@ -540,9 +540,13 @@ __global__ __launch_bounds__(RDX_THREADS, (HiTraits<HiT>::has && HiTraits<OutHiT
                 u64* pl = own ? ow.lo : out_lo;
                 OutHiT* ph = own ? (OutHiT*)ow.hi : out_hi;
                 u8* pn = own ? ow.next : out_next;
-                pl[dst] = a;
-                st_hi<OutHiT>(ph, dst, b);
-                if (pn) pn[dst] = (u8)next_dfn(a, b);
+                // (no send buffer — the "replicate" protocol, comm.hpp: every rank transforms every rank's reads and keeps the words of its
+                // own prefix range; the others' words are dropped here)
+                if (own || out_lo) {
+                    pl[dst] = a;
+                    st_hi<OutHiT>(ph, dst, b);
+                    if (pn) pn[dst] = (u8)next_dfn(a, b);
+                }
             } else {
             out_lo[dst] = a;
             st_hi<OutHiT>(out_hi, dst, b);

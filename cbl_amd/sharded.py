@@ -258,15 +258,16 @@ class ShardedBuilder(_Wire):
 
     def __init__(self, cbl, dist, engine=None, slices: int = 4, slack: float = 1.3, protocol: str | None = None, comm=None, slice_weights=None):
         """comm: a cbl_amd.Comm — the whole insert then runs inside libcblx (cblx_sharded_insert_seqs_device, exchange on
-        RCCL directly; protocol "bins" (default there: the exchange sits between the first and the second partition pass,
-        nothing is partitioned twice or copied) or "sorted"); `dist` is still used for the few host-side agreements (slice
+        RCCL directly; protocol "bins" (the exchange sits between the first and the second partition pass, nothing is
+        partitioned twice or copied), "sorted", "replicate" (reads cross the links as bit planes, every rank transforms all of
+        them and keeps its prefix range) or "auto"); `dist` is still used for the few host-side agreements (slice
         counts). Without comm the device steps are driven from here over torch.distributed: "sorted" (default) or "words"."""
         self.cbl = cbl
         self.engine = engine or GpuEngine(cbl)
         if protocol is None:
             protocol = "auto" if comm is not None else "sorted"
-        if protocol not in (("sorted", "bins", "auto") if comm is not None else ("sorted", "words")):
-            raise ValueError("protocol must be 'sorted', 'bins' or 'auto' with a native communicator, 'sorted' or 'words' without")
+        if protocol not in (("sorted", "bins", "auto", "replicate") if comm is not None else ("sorted", "words")):
+            raise ValueError("protocol must be 'sorted', 'bins', 'replicate' or 'auto' with a native communicator, 'sorted' or 'words' without")
         self.protocol = protocol if (comm is not None or hasattr(self.engine, "sorted_batch_begin")) else "words"
         self.comm = comm
         if comm is not None:

@@ -239,6 +239,12 @@ int cblx_comm_stats(cblx_comm* comm, cblx_exchange_stats* out, int reset);
 #define CBLX_PROTO_SORTED 0u
 #define CBLX_PROTO_BINS 1u
 #define CBLX_PROTO_AUTO 2u
+/*   CBLX_PROTO_REPLICATE (round 6): READS cross the links, not words — every rank packs its reads into bit planes on the device (3 bits per
+ *     base = 0.3 bytes per k-mer), planes and offsets are all-gathered, and every rank runs KRN-1 and the first partition pass over ALL ranks'
+ *     reads, keeping the words of its own prefix range; the receiver steps are those of BINS (groups, FINE bins). W encodes per rank instead
+ *     of one and next to nothing on the wire: the choice where one link per pair of GPUs bounds the other protocols (2 - 3 GPUs). Falls back to
+ *     BINS together with every other rank on a non-empty index or bounds the bins refuse. */
+#define CBLX_PROTO_REPLICATE 3u
 int cblx_comm_set_protocol(cblx_comm* comm, uint32_t protocol);
 int cblx_comm_protocol_used(const cblx_comm* comm, uint32_t* out);
 /* The receiver of CBLX_PROTO_BINS in GROUPS (no reference counterpart; same result, another schedule): every rank's prefix range is

@@ -23,6 +23,7 @@ pub const CBLX_COMM_ID_BYTES: usize = 128;
 pub const CBLX_PROTO_SORTED: u32 = 0;
 pub const CBLX_PROTO_BINS: u32 = 1;
 pub const CBLX_PROTO_AUTO: u32 = 2;
+pub const CBLX_PROTO_REPLICATE: u32 = 3;
 
 #[repr(C)]
 pub struct cblx_ctx {

@@ -38,8 +38,9 @@ def test_two_rank_line_through_the_launcher(config):
         # the line carries its own denominator: the same configuration on one GPU (rank 0's share, built directly after the timed steps) ...
         one = out["one_gpu_same_config"]
         assert one["value"] > 0 and one["ms_per_step"] > 0 and abs(out["scaling_vs_one_gpu_same_config"] - out["value"] / one["value"]) < 0.01
-        # ... and says what crossed the links: the library's choice at two ranks is "sorted" (one link per pair of GPUs bounds the job)
-        assert out["exchange"]["protocol_asked"] == "auto" and out["exchange"]["protocol"] == "sorted"
+        # ... and says what crossed the links: the library's choice at two ranks is "replicate" (one link per pair of GPUs bounds every protocol
+        # that ships words: the reads cross as bit planes instead)
+        assert out["exchange"]["protocol_asked"] == "auto" and out["exchange"]["protocol"] == "replicate"
         # ... and carries its own correctness verdict: the sharded index against every rank's word stream (count, set checksum, structure, every
         # inserted k-mer found in exactly one share), and the CPU leg's sample rebuilt on the GPU with the oracle's bytes
         sc = out["set_check"]

@@ -47,10 +47,13 @@ def test_no_stage_is_priced_for_work_it_does_not_do():
 def test_multi_gpu_defaults_take_the_native_bins_path():
     a = bench.parse_args(["--gpus", "8"])
     assert (a.transport, a.protocol, a.protocol_resolved, a.slices) == ("native", "auto", "bins", 3)
-    # 2 - 4 ranks: one link per pair of GPUs bounds the job, the library picks "sorted" (rehearsed: profiles/r05_wire_emulated.md)
-    for n in (2, 4):
+    # 2 - 4 ranks: one link per pair of GPUs bounds every protocol that ships words — the library picks "replicate" on 2 - 3 ranks (the reads cross as
+    # bit planes), "sorted" on 4 (rehearsed: profiles/r06_wire_emulated.md)
+    for n in (2, 3):
         b = bench.parse_args(["--gpus", str(n)])
-        assert (b.protocol, b.protocol_resolved, b.slices) == ("auto", "sorted", 4)
+        assert (b.protocol, b.protocol_resolved, b.slices) == ("auto", "replicate", 1)
+    b = bench.parse_args(["--gpus", "4"])
+    assert (b.protocol, b.protocol_resolved, b.slices) == ("auto", "sorted", 4)
     assert bench.parse_args(["--gpus", "4", "--protocol", "bins"]).protocol_resolved == "bins"
     assert bench.parse_args(["--gpus", "8", "--transport", "torch"]).protocol == "sorted"
     # the CPU leg stays bounded (about 20-30 s) whatever the configuration

@@ -2129,7 +2129,11 @@ def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q, protoco
     (2, 31, 24, False, "bins", 3), (4, 31, 28, False, "bins", 14), (3, 45, 20, True, "bins", 5), (2, 27, 9, False, "bins", 4),
     (4, 31, 25, True, "bins", 3), (2, 33, 27, False, "bins", 5),  # FINE bins where a 65..72-bit word's bins must imply 21 prefix bits; 16-byte records
     (2, 31, 24, False, "sorted", 0), (3, 59, 28, True, "sorted", 0), (8, 31, 24, False, "sorted", 0),
-    (2, 31, 28, False, "auto", 0), (5, 31, 24, True, "auto", 0)])  # the library's choice: "sorted" on 2 - 4 ranks, "bins" from 5 on
+    (2, 31, 28, False, "auto", 0), (4, 31, 24, False, "auto", 0), (5, 31, 24, True, "auto", 0),  # the library's choice: "replicate" on 2 - 3 ranks, "sorted" on 4, "bins" from 5 on
+    # "replicate" (round 6): reads cross as bit planes, every rank transforms all of them and keeps its prefix range — ragged and empty shards, canonical,
+    # 16-byte records, FINE bins, the ungrouped fallback of the second batch (a non-empty index)
+    (2, 31, 24, False, "replicate", 0), (3, 59, 28, True, "replicate", 0), (4, 31, 28, False, "replicate", 3), (2, 31, 26, True, "replicate", 5),
+    (3, 25, 12, False, "replicate", 0), (4, 33, 27, False, "replicate", 2)])
 def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canonical, protocol, groups, tmp_path):
     """The C++ orchestration of the multi-GPU build (slices, splitter choice, count exchange, grouped exchange, batch merge)
     with `world` ranks sharing this GPU and the bytes moved by host callbacks over gloo: byte-identical to the one-process
@@ -2168,7 +2172,7 @@ def test_native_sharded_insert_on_one_gpu_through_callbacks(world, k, pb, canoni
     elif pb >= 12:  # (a rank whose range is narrower than a few histogram cells gets fewer groups than asked for, down to one)
         assert 1 <= used[0] <= (groups or 4), used
     # PREFIX_BITS > 24: the first pass ran on FINE bins, and rank 0 — the narrowest prefix range — sorted 16 bits in its groups, not 20
-    assert fine[1] == 0 and (fine[0] >= 1 if (pb > 24 and protocol == "bins" and groups != 1) else fine[0] == 0), fine
+    assert fine[1] == 0 and (fine[0] >= 1 if (pb > 24 and protocol in ("bins", "replicate") and groups != 1) else fine[0] == 0), fine
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -2221,7 +2225,7 @@ def test_rehearsal_of_rank_0_on_recorded_senders(world, k, pb, canonical, groups
     for r in list(range(1, world)) + [0, 0]:  # rank 0 twice: a replay can be repeated
         d_b, d_o = synth.reads_torch(5, nr, L, first_read=r * nr, device="cuda")
         cm = cbl_amd.Comm.sim(r, world, store, gbps if r == 0 else 0.0)
-        cm.set_protocol("bins")  # (the default, "auto", is "sorted" up to four ranks)
+        cm.set_protocol("bins")  # (the default, "auto", is "replicate" / "sorted" up to four ranks)
         cm.set_recv_groups(groups)
         g = cbl_amd.CBL(k, pb, canonical=canonical)
         valid = g.sharded_insert_seqs_device(cm, d_b, d_o, nr, cuts, bounds, valid)
@@ -2248,6 +2252,46 @@ def test_rehearsal_of_rank_0_on_recorded_senders(world, k, pb, canonical, groups
     # ... and the next entry of the job's file belongs to rank 1: its prefix is at or above the bound
     nxt, _ = _read_varint(full, pf + len(blob0) - p0)
     assert nxt >= int(bounds[0])
+
+
+@pytest.mark.parametrize("world,k,pb,canonical,tgt,slices,gbps", [(2, 31, 28, False, 1, 1, 0.0), (3, 31, 24, True, 0, 2, 1.0), (4, 59, 27, False, 2, 3, 0.0), (2, 25, 12, False, 0, 1, 0.0)])
+def test_rehearsal_of_any_rank_on_the_replicate_protocol(world, k, pb, canonical, tgt, slices, gbps, monkeypatch):
+    """"replicate" under the one-GPU rehearsal (what tools/emulate_wire.py --protocol replicate times): the other ranks record the planes and offsets
+    they would send, the rehearsed rank transforms every rank's reads and keeps its prefix range — exactly the buckets of that range of the
+    one-process oracle's index (stream order slice-major, rank-minor), paced wire or not."""
+    _need_gpu()
+    monkeypatch.setenv("CBLX_SIM_TARGET", str(tgt))
+    L, nr, store = (150 if k < 59 else 250), 3000, 88000 + world * 10 + pb
+    bounds = np.zeros(world - 1, dtype=np.uint32)
+    valid = False
+    cuts = [nr * s // slices for s in range(slices + 1)]
+    for r in [x for x in range(world) if x != tgt] + [tgt]:
+        d_b, d_o = synth.reads_torch(91, nr, L, first_read=r * nr, device="cuda")
+        cm = cbl_amd.Comm.sim(r, world, store, gbps if r == tgt else 0.0)
+        cm.set_protocol("replicate")
+        g = cbl_amd.CBL(k, pb, canonical=canonical)
+        valid = g.sharded_insert_seqs_device(cm, d_b, d_o, nr, cuts, bounds, valid)
+        if r == tgt:
+            mine, used, st, proto = g.buckets(), cm.groups_used(), cm.stats(), cm.protocol_used()
+            assert g.validate() == 0
+        g.close()
+        cm.close()
+    cbl_amd.Comm.sim_store_free(store)
+    assert proto == "replicate" and used >= 1
+    # what crossed: (world - 1) ranks' planes (6 bytes per 16 bases) and offsets — a fraction of a byte per k-mer
+    assert 0 < st["recv_bytes"] < (world - 1) * (nr * L * 6 // 16 + nr * 8 + 4096)
+    one = Oracle(k, pb, canonical)
+    for c in range(slices):
+        for r in range(world):
+            if cuts[c + 1] > cuts[c]:
+                hb, ho = synth.reads(91, cuts[c + 1] - cuts[c], L, first_read=r * nr + cuts[c])
+                one.insert_seqs(hb, ho)
+    full = cbl_amd.CBL(k, pb, canonical=canonical)
+    full.load(one.serialize())
+    lo, hi = (int(bounds[tgt - 1]) if tgt else 0), (int(bounds[tgt]) if tgt + 1 < world else 1 << pb)
+    want = [b for b in full.buckets() if lo <= b[0] < hi]
+    full.close()
+    assert len(mine) == len(want) and mine == want
 
 
 def _reads_with_all_ones(seed, nr, L, first_read, n_poly, n_rich):

@@ -76,7 +76,9 @@ def _worker(rank, world, port, k, pb, canonical, protocol, native, per, L, q, gr
     (4, 31, 24, False, "sorted", True, 0), (8, 31, 28, False, "sorted", False, 0),
     (2, 31, 24, False, "bins", True, 0), (4, 59, 28, True, "bins", True, 0), (8, 31, 28, False, "bins", True, 0),
     (2, 31, 24, False, "bins", True, 1), (8, 31, 28, False, "bins", True, 1), (4, 31, 24, True, "bins", True, 3),
-    (2, 31, 28, False, "auto", True, 0), (8, 31, 26, True, "auto", True, 0)])  # the library's choice ("sorted" on 2 - 4 ranks); FINE bins at PREFIX_BITS > 24 on 8
+    (2, 31, 28, False, "auto", True, 0), (8, 31, 26, True, "auto", True, 0),  # the library's choice ("replicate" on 2 - 3 ranks, "sorted" on 4); FINE bins at PREFIX_BITS > 24 on 8
+    # "replicate" (round 6): the reads cross as bit planes (one grouped exchange of planes and offsets), every rank transforms all of them
+    (2, 31, 24, False, "replicate", True, 0), (3, 59, 28, True, "replicate", True, 0), (4, 31, 28, False, "replicate", True, 3), (8, 31, 26, False, "replicate", True, 0)])
 def test_sharded_build_and_merge_on_real_rccl(world, k, pb, canonical, protocol, native, groups):
     if _ngpu() < world:
         pytest.skip(f"needs {world} GPUs in one box, {_ngpu()} visible (RCCL refuses two ranks on one GPU)")

@@ -42,7 +42,8 @@ def main():
     ap.add_argument("--taper", default="0.5,0.8,1", help="cumulative fractions of the grouped runs' slices instead of equal ones, e.g. 0.5,0.8,1 (the number of values selects the runs with that many slices)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-ungrouped", action="store_true", help="skip the ungrouped receiver's runs")
-    ap.add_argument("--protocol", choices=["bins", "sorted"], default="bins", help="what crosses the links (sorted: full partition on the sender, packed suffixes; always ungrouped)")
+    ap.add_argument("--protocol", choices=["bins", "sorted", "replicate"], default="bins", help="what crosses the links (sorted: full partition on the sender, packed suffixes; always ungrouped; "
+                    "replicate: the reads as bit planes, every rank transforms all of them and keeps its prefix range — grouped receiver, --groups / --grouped-slices apply)")
     ap.add_argument("--no-direct", action="store_true", help="skip the one-GPU build of the same reads")
     ap.add_argument("--rank", type=int, default=0, help="the rank that is rehearsed (CBLX_SIM_TARGET): 0 = the densest prefix range, W - 1 = the sparse tail")
     a = ap.parse_args()
@@ -75,6 +76,8 @@ def main():
     modes = [("grouped", int(x), int(y)) for x in a.groups.split(",") for y in a.grouped_slices.split(",")] + ([] if a.no_ungrouped else [("ungrouped", 1, a.slices)])
     if a.protocol == "sorted":
         modes = [("sorted", 1, a.slices)]
+    if a.protocol == "replicate":
+        modes = [("replicate", int(x), int(y)) for x in a.groups.split(",") for y in a.grouped_slices.split(",")]
     out["protocol"] = a.protocol
     for mode, groups, slices in modes:
         store = 1000 + groups * 16 + slices + 100000 * tgt
