@@ -59,7 +59,7 @@ def word_layout(k: int, pb: int):
     return kb, wb, hi, sfx, (wb - pb + 7) // 8
 
 
-# ALGORITHMIC bytes per k-mer and step of each kernel group: what the group's contract must move once.
+# ALGORITHMIC bytes per k-mer and step of each kernel group (DESIGN_HISTORY.md §3/§4): what the group's contract must move once.
 #   R_in = record bytes out of KRN-1 (8 lo + hi part); after the first partition pass a 65..72-bit word keeps only lo.
 def stage_alg_bytes(k: int, pb: int, read_len: int):
     _, _, hi, sfx, _ = word_layout(k, pb)
@@ -500,7 +500,7 @@ def fasta_leg(cbl, h_bases, NR, L, kmers):
         return {"value": round(kmers / best, 1), "unit": "k-mers/s", "ms_per_step": round(best * 1e3, 3), "file_bytes": int(size),
                 "file_gbps": round(size / best / 1e9, 2), "distinct_kmers_in_index": int(cbl.count()),
                 "source": f"single-line FASTA in {d} (page cache) -> cblx_insert_fastx_file + cblx_flush, best of 2 after 1 warm-up: counting pass, "
-                          "parser threads pack the sequence lines into bit planes in place, the sliced insert runs behind them (DESIGN.md §3.10)"}
+                          "parser threads pack the sequence lines into bit planes in place, the sliced insert runs behind them (DESIGN_HISTORY.md §3.10)"}
     except Exception as e:  # no room for the file, or no tmpfs: the line says so
         return {"value": None, "error": f"{type(e).__name__}: {e}"}
     finally:
@@ -882,7 +882,7 @@ def main():
                     "protocol": (comm.protocol_used() if (args.kind == "build" and comm is not None) else args.protocol_resolved), "protocol_asked": args.protocol,
                     "slice_weights": (list(sharded.ShardedBuilder.GROUPED_WEIGHTS) if (args.kind == "build" and grouped) else None),
                     # groups rank 0's receiver worked its range off in while the later ones were still on the wire (0: the ungrouped
-                    # receiver — everything waits for the last record)
+                    # receiver — everything waits for the last record; DESIGN_HISTORY.md §5.6)
                     "recv_groups_used": (comm.groups_used() if (args.kind == "build" and comm is not None) else None),
                     "sent_bytes_per_rank_step": sent, "recv_bytes_per_rank_step": recv,
                     "outstanding_ms_per_step": round(out_s / args.steps * 1e3, 3), "wait_ms_per_step": round(allreduce_max(st["wait_s"]) / args.steps * 1e3, 3),

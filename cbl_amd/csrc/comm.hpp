@@ -879,7 +879,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     const u64 LIMIT = 0xFFFFFFF0ull - 2 * RDX_TILE;
     // (every term of the decision below is replicated: a rank that alone holds 2^32 k-mers says so through the sum)
     // The digit side channel of the receiver's first LSD pass (1 byte per word) stays OFF the wire by default (round 5): at 8 GPUs and 55 GB/s per
-    // link the step is bound by the wire from the first group on, the byte is a ninth of it, and the receiver's first histogram
+    // link the step is bound by the wire from the first group on (DESIGN_HISTORY.md §5.8), the byte is a ninth of it, and the receiver's first histogram
     // reads the records instead (8 bytes per word where it read 1: about the millisecond the senders' byte stores cost). CBLX_WIRE_DIGITS=1 sends
     // it as rounds 3 - 4 did; one rank (no wire) always keeps it.
     const char* wd_env = std::getenv("CBLX_WIRE_DIGITS");

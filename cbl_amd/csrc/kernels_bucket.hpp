@@ -997,6 +997,9 @@ static const int MSD_TRIP = CBLX_MSD_TRIP;  // sub-bucket entries read per trip 
 #ifndef CBLX_MSD_MERGE_WAVES
 #define CBLX_MSD_MERGE_WAVES 7
 #endif
+#ifndef CBLX_MSD_PRECHECK
+#define CBLX_MSD_PRECHECK 0  // measured (round 6, tools/dev_msd_bench.cpp at PREFIX_BITS = 28): 4.203 against 4.209 ms — the class is not bound by what follows the loads
+#endif
 #ifndef CBLX_MSD_WAVES
 #define CBLX_MSD_WAVES 7  // waves per SIMD the register allocation aims at (LDS allows 7 workgroups of the 256-thread class; 76 -> 72 VGPRs: 7.28 -> 7.10 ms)
 #endif
@@ -1046,6 +1049,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
     __shared__ u32 s_max;
     __shared__ u32 s_sel[MERGE ? NW : 1];  // merge epilogue: per-wave counts of its three selections (10-bit fields)
     static_assert(!MERGE || 64 * ITEMS < 1024, "the merge epilogue counts a wave's selections in 10-bit fields: a wave owns fewer than 1024 slots");
+    // distinctness pre-check of the shortest class (below): 2^15 bits
+    constexpr bool PRECHECK = CBLX_MSD_PRECHECK && CAP <= 128 && !MERGE;
+    __shared__ u32 s_bits[PRECHECK ? 1024 : 1];
 
     if (blockIdx.x >= *list_n) return;
     const BDesc dsc = list[blockIdx.x];
@@ -1080,7 +1086,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
     // Largest sub-bucket the ranking loop is worth running on. Hashed sub-buckets of distinct suffixes stay below 10
     // entries, so more than MSD_LIMIT_HASHED means repeats (every copy of a value lands in its sub-bucket): such runs are
     // deduplicated far cheaper by the claim table. Top-bit sub-buckets reach 45 entries without a single repeat (necklace
-    // clusters) and give up later. A compile-time constant per length class: the runs of the classes up to
+    // clusters, DESIGN_HISTORY.md §3.7) and give up later. A compile-time constant per length class: the runs of the classes up to
     // 1024 words are the hashed ones (a Trie that short only comes out of a loaded file; as a run-time value the limit cost
     // the 2048-slot instantiation four spilled registers and cfg 2 0.3 ms).
     constexpr u32 crowd = (CAP <= (int)VEC_THRESHOLD && !MERGE) ? MSD_LIMIT_HASHED : (WS ? MSD_LIMIT_WIDE : MSD_LIMIT);
@@ -1133,6 +1139,28 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
             valid[j] = (u32)j < R && e < c;
             const u32 ee = valid[j] ? e : 0u;
             key[j] = load_sfx<WS, HiT>(lo, hi, s0 + ee, SB);
+        }
+    }
+    if constexpr (PRECHECK) {
+        // (measured switch, off) A run of at most 128 words that can only end up a Vec (cfg 3 on one GPU: 9.8 M of them, 77 words each, a wave
+        // per run) and holds no repeat needs none of the phases below: nothing is written, the count is the run length. A test that can only err
+        // on the safe side: every word sets the bit of a 15-bit hash of its suffix in a 4 KB LDS table (atomicOr returns the old word); if no bit
+        // was already set, no two suffixes are equal (91 % of the runs of 77 distinct words) and the run is done; otherwise the counting sort
+        // decides exactly as before. Bit-identical, and worth nothing: the wave's life (3.2 us at 96 % occupancy) is its launch, its scalar loads
+        // and the HBM round trip of its words, not the 400 instructions this saves (DESIGN_HISTORY.md §3.13).
+        if (vec_only) {
+            for (u32 i = tid * 4; i < 1024; i += THREADS * 4) *reinterpret_cast<uint4*>(&s_bits[i]) = uint4{0, 0, 0, 0};
+            __syncthreads();
+            bool hit = false;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const u32 h = sfx_hash_bits<WS>(key[j], 15);
+                if (valid[j]) hit |= (atomicOr(&s_bits[h >> 5], 1u << (h & 31u)) >> (h & 31u)) & 1u;
+            }
+            if (!__syncthreads_or(hit ? 1 : 0)) {
+                if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_VEC; }
+                return;
+            }
         }
     }
 #pragma unroll
@@ -1528,7 +1556,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
 // ---- KRN-3, runs that end up SORTED (more than 1024 words, a bucket that is a Trie already, `self |= other`), packed elements (round 6) ----
 // k_bucket_msd ranks every element inside its sub-bucket by reading the whole sub-bucket: s reads per element, and under the top
 // suffix bits — the only kind of sub-bucket a sorted result allows — an element shares its sub-bucket with 6.5 others on average and
-// up to 45 (necklace clusters): 60 random 8-byte LDS reads per lane of eight slots, issued slot by slot in loops whose
+// up to 45 (necklace clusters, DESIGN_HISTORY.md §3.7): 60 random 8-byte LDS reads per lane of eight slots, issued slot by slot in loops whose
 // trip count is the LARGEST sub-bucket among the wave's 64 lanes (162 LDS instructions per wave, the LDS array 74 % busy, 42 % of it
 // bank conflicts: profiles/r05_sq_counters.md). Here the ranking is turned around: after the same counting sort into sub-bucket order,
 // a lane OWNS eight consecutive positions of that order — entries of the same one or two sub-buckets — and walks ONCE over the span from

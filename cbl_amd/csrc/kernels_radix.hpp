@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256) void k_boundaries_cold(const u64* __restrict__
 // The partition passes sort 24 prefix bits (A + two LSD passes, bucket starts from the last pass's tables); a run of equal 24-bit
 // prefix — a few hundred to a few thousand records, up to 2^xb real buckets interleaved in stream order — is then split by its last
 // xb prefix bits by ONE workgroup that stages the run (tile by tile of SPLIT_TILE records) in LDS in its final order and writes it
-// out front to back: whole cache lines, where the scatter kernel's 16-record runs leave partial ones (that is what a
+// out front to back: whole cache lines, where the scatter kernel's 16-record runs leave partial ones (DESIGN_HISTORY.md §3.4: that is what a
 // scatter pass costs over a copy). Stable (ballot ranking, as tile_rank): the order inside a bucket stays the stream order. A run of
 // several tiles is counted first (its records are read twice; the second read comes from the L2). The kernel also writes the bucket
 // starts of the run's 2^xb prefixes (EMPTY32 for the absent ones) — the fused directory of the old last pass, without candidates to
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split(const SplitRun* __rest
     __shared__ u32 s_tbase[16];      // tile: first staged slot of the digit
     // the tile in its final order: what leaves is one contiguous piece per digit (the whole tile front to back for a one-tile run).
     // (Straight from the registers every store instruction touched ~16 lines with 32 bytes each — the partial-line pieces that make the
-    // scatter kernel slow, DESIGN.md §3.4 — and the split took as long as the pass it replaced.)
+    // scatter kernel slow, DESIGN_HISTORY.md §3.4 — and the split took as long as the pass it replaced.)
     // 16-byte records (K = 59) go straight from the registers instead: staged they take 64 KB per eight-wave workgroup, two per CU,
     // and the split loses more to occupancy than the pieces cost (cfg 4: 61.7 ms staged, 60.1 not)
     constexpr bool STAGE = !HAS;

@@ -62,7 +62,7 @@ struct LsdPlan {
 inline LsdPlan lsd_plan(const Consts& P, bool split_ok = true) {
     // Up to two passes: 8 bits, then the rest (the group-cut tiles of the last pass are built for that shape). PREFIX_BITS > 24:
     // 8 + 8 bits by two passes with the directory of 2^24 "super-prefixes" from the second one's tables, and the last 1 .. 4 bits
-    // by k_prefix_split (a run of equal 24-bit prefix staged in LDS, written back in order: copy speed). Three passes
+    // by k_prefix_split (a run of equal 24-bit prefix staged in LDS, written back in order: copy speed, DESIGN_HISTORY.md §3.11). Three passes
     // of 7 + 7 + 6 bits before that (CBLX_PREFIX_SPLIT=0): a pass costs nearly the same whatever its width.
     LsdPlan L;
     const u32 RB = P.PB - std::min(8u, P.PB);

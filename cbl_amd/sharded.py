@@ -278,7 +278,7 @@ class ShardedBuilder(_Wire):
         self.bounds = None  # fixed by the first batch so later batches land on the same owners
         self.last_counts = None
 
-    # Slices of the GROUPED receiver's schedule (native "bins" protocol on an empty index): the senders run all their
+    # Slices of the GROUPED receiver's schedule (native "bins" protocol on an empty index, DESIGN_HISTORY.md §5.6): the senders run all their
     # slices before the data crosses group-major, and only the first group's share of the LAST slice is exposed (the earlier slices'
     # shares of it cross under the next slice's kernels) — so the last slice is the short one. Measured against a paced wire
     # (cfg 3, 55 GB/s per link, 4 groups): 2 equal slices 56.6 ms, these three 54.9, four (45 / 30 / 17 / 8 %) 55.3.

@@ -1,5 +1,5 @@
 """bench.py's command line and accounting tables (no GPU): every --config resolves to a complete workload, the defaults are
-the ones the contract names, and the per-stage algorithmic bytes add up to what DESIGN.md §4 states for cfg 2."""
+the ones the contract names, and the per-stage algorithmic bytes add up to what DESIGN_HISTORY.md §4 states for cfg 2."""
 import os
 import sys
 

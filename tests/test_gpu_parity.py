@@ -337,7 +337,7 @@ def test_deep_buckets_take_the_split_path(k, pb, nreads, L, canonical):
     ],
 )
 def test_prefix_split_on_crowded_runs_full_of_repeats(k, pb, canonical, alphabet, glen, cov):
-    """PREFIX_BITS > 24: the runs of equal 24-bit prefix are split by their last bits in LDS (k_prefix_split).
+    """PREFIX_BITS > 24: the runs of equal 24-bit prefix are split by their last bits in LDS (k_prefix_split, DESIGN_HISTORY.md §3.11).
     Low-complexity reads crowd the runs (two-letter genomes: 4096 possible 24-bit prefixes, runs of one to several tiles, buckets on
     both sides of the Vec threshold), coverage repeats every word. Build, an incremental batch on top, everything again."""
     _need_gpu()

@@ -1,7 +1,7 @@
 """The multi-GPU build on a REAL multi-rank RCCL group: one process per GPU, torch.distributed nccl backend (and the native
 cblx_comm on RCCL), byte-identical to the one-process oracle. Needs >= 2 GPUs in one box: on the one-GPU pool this repo was
 built on these tests SKIP (RCCL refuses two ranks on one GPU) — the same workers run there with the exchange staged through
-gloo (tests/test_gpu_parity.py: *_through_a_gloo_shim, *_through_callbacks). DESIGN.md §5 states the multi-GPU path as
+gloo (tests/test_gpu_parity.py: *_through_a_gloo_shim, *_through_callbacks). DESIGN_HISTORY.md §5 states the multi-GPU path as
 unverified on hardware until these have run."""
 import os
 import socket

@@ -15,6 +15,9 @@
 
 #include "cblx.h"
 #include "kernels_bucket.hpp"
+#ifdef MSD_BENCH_HASHED
+#include "bucket_hashed_experiment.hpp"
+#endif
 using namespace cblx;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 #define CB(x) do { int r_ = (x); if (r_) { printf("cblx error %d at %s:%d\n", r_, __FILE__, __LINE__); exit(1); } } while (0)
@@ -234,6 +237,41 @@ int main(int argc, char** argv) {
     };
     run_sorted(3, std::integral_constant<int, 256>(), std::integral_constant<int, 2048>());
     run_sorted(4, std::integral_constant<int, 512>(), std::integral_constant<int, 4096>());
+#ifdef MSD_BENCH_HASHED
+    // round 6: the short classes through k_bucket_hashed (a persistent grid, the next bucket's words in flight): tools/bucket_hashed_experiment.hpp
+    auto run_hashed = [&](int k, auto thr, auto cap, u32 wgs_per_cu) {
+        constexpr int T = decltype(thr)::value, CAPV = decltype(cap)::value;
+        if (!ln[k] || SB + PK_BITS > 64) return;
+        const u32 grid = std::min<u32>(ln[k], 256u * wgs_per_cu);
+        float best = 1e30f, sum = 0;
+        unsigned long long chk = 0;
+        for (int rep = 0; rep < reps + 1; ++rep) {
+            CK(hipMemcpy(arena, s_lo, n * 8, hipMemcpyDeviceToDevice));
+            CK(hipMemset(bail, 0, nruns + 8));
+            CK(hipMemset(bail_any, 0, 32));
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL((k_bucket_hashed<T, CAPV, u8>), dim3(grid), dim3(T), 0, 0, lists + (size_t)k * nruns, list_n + k, arena, SB, cnt, kind, bail, bail_any);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            CK(hipGetLastError());
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep) { best = std::min(best, ms); sum += ms; }
+        }
+        CK(hipMemset(d_sum, 0, 8));
+        hipLaunchKernelGGL(k_sum_res, dim3(ln[k]), dim3(256), 0, 0, lists + (size_t)k * nruns, ln[k], cnt, kind, arena, d_sum);
+        CK(hipMemcpy(&chk, d_sum, 8, hipMemcpyDeviceToHost));
+        u32 nbail = 0;
+        std::vector<u8> hb(ln[k]);
+        CK(hipMemcpy(hb.data(), bail, ln[k], hipMemcpyDeviceToHost));
+        for (u8 x : hb) nbail += x;
+        printf("hashed %d <%3d,%4d> %3u wg/cu: %8u buckets  best %7.3f ms  avg %7.3f ms  gave up %u  chk %016llx\n", k, T, CAPV, wgs_per_cu, ln[k], best, sum / reps, nbail, chk);
+    };
+    for (u32 f : {16u, 32u, 64u}) run_hashed(0, std::integral_constant<int, 64>(), std::integral_constant<int, 128>(), f);
+    for (u32 f : {16u, 32u, 64u}) run_hashed(1, std::integral_constant<int, 64>(), std::integral_constant<int, 512>(), f);
+    for (u32 f : {8u, 16u, 32u}) run_hashed(2, std::integral_constant<int, 128>(), std::integral_constant<int, 1024>(), f);
+#endif
 #ifdef MSD_BENCH_SHAPES
     run_sorted(3, std::integral_constant<int, 512>(), std::integral_constant<int, 2048>());
     run_sorted(3, std::integral_constant<int, 128>(), std::integral_constant<int, 2048>());

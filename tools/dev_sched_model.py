@@ -1,6 +1,6 @@
 """Dev model (round 5) of the grouped receiver's schedule at cfg 3, 8 ranks, 55 GB/s per link: a send phase (KRN-1 + first pass per slice), a FIFO wire (group 0's share of
 every slice right behind that slice, then the groups one after the other) and the chain of the groups' receiver kernels. Reproduces the rehearsed 48.0 ms; every
-variant of slices / group sizes stays within 0.9 ms of it."""
+variant of slices / group sizes stays within 0.9 ms of it (DESIGN_HISTORY.md §5.8)."""
 import itertools
 def sim(slices, groups, W=30.8, send=15.9, comp=28.0, fixed=0.6, early=None):
     # slices: fractions (sum 1) of reads; groups: fractions of the rank's words; early: list of (slice, group) sent right after that slice besides g0

@@ -22,7 +22,7 @@ for w in "--reads 10000000" "" "--reads 12500000 --prefix-bits 28" "--k 59 --pre
   m=""; case "$n" in reads10000000|cfg5) m="--merge";; esac
   timeout 900 python tools/emulate_rank.py --protocol words $m $w > $OUT/emul_$n.json 2> $OUT/emul_$n.err; echo "emul [$w] rc=$?"
 done
-# round 4: rank 0 of 8 against a paced wire, grouped receiver on / off
+# round 4: rank 0 of 8 against a paced wire, grouped receiver on / off (DESIGN_HISTORY.md §5.7)
 for c in cfg3 cfg2 cfg4; do
   timeout 1200 python tools/emulate_wire.py --config $c --groups 4,8 --wire-gbps 40,55,75,0 > $OUT/wire_$c.json 2> $OUT/wire_$c.err; echo "wire $c rc=$?"
 done

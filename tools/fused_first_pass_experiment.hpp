@@ -1,6 +1,6 @@
-// REJECTED EXPERIMENT (round 2), kept as the record DESIGN.md §3.4 cites — not part of the library. It was
+// REJECTED EXPERIMENT (round 2), kept as the record DESIGN_HISTORY.md §3.4 cites — not part of the library. It was
 // cbl_amd/csrc/kernels_fused.hpp; tools/fused_first_pass_experiment.patch holds the plumbing (pipeline.hpp, kernels_encode.hpp).
-// Bit-identical (full GPU suite + 300 fuzz cases green with it on by default), but slower: see the numbers in DESIGN.md.
+// Bit-identical (full GPU suite + 300 fuzz cases green with it on by default), but slower: see the numbers in DESIGN_HISTORY.md §3.4.
 //
 // kernels_fused.hpp — KRN-1b: the word transform fused into the FIRST partition pass.
 //

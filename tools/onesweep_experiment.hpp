@@ -1,6 +1,6 @@
 // onesweep_experiment.hpp — NOT part of libcblx. The single-read ("onesweep") form of a partition pass, kept for the
 // dev harness (tools/dev_radix_bench.cpp): one up-front histogram of all digits + a decoupled look-back across tiles.
-// Bit-identical to the two-kernel pass, but not faster on MI355X: an agent-scope look-back hop across
+// Bit-identical to the two-kernel pass, but not faster on MI355X (DESIGN_HISTORY.md §3.4): an agent-scope look-back hop across
 // the non-coherent per-XCD L2s costs 1-3 us and tiles arrive at ~35/us, so the walk is latency-unstable.
 #pragma once
 #include "kernels_radix.hpp"

@@ -3,7 +3,7 @@
 #
 # The image this repository was built in has no Rust toolchain, so the serialized bytes of the golden vectors come from the
 # C++ oracle (oracle/cbl_oracle.hpp) cross-checked by an independent Python restatement (oracle/pyref.py): "parity unpinned"
-# for the bincode / serde layer. This script closes that gap: for every golden case it writes the case's FASTA
+# for the bincode / serde layer (DESIGN_HISTORY.md §7). This script closes that gap: for every golden case it writes the case's FASTA
 # with the generator the vectors were made with (cbl_amd.synth, numpy only), builds the reference's CLI for the case's K /
 # PREFIX_BITS as its README prescribes (README.md:112-129: K=.. PREFIX_BITS=.. cargo +nightly build --release --examples),
 # runs `cbl build [-c] <fasta> -o <index>` (examples/cbl.rs:147-167) and compares SHA-256 with the golden file.

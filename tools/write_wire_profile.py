@@ -13,7 +13,7 @@ def main():
          "directory and bucket kernels at the bucket depth of the W-GPU job — on a replaying communicator whose exchanges are D2D copies on a side stream, held back by",
          "a host function until a wire of `link` GB/s per source rank (W - 1 links in parallel) would have delivered them. ms per step, best of 3; `no wire` = the",
          "copies at their own speed (what the kernels alone take). Not emulated: the CUs RCCL's kernels occupy, link contention, the peers' own pace. Grouped runs",
-         "with three slices use 50 / 30 / 20 % of the reads (`ShardedBuilder.GROUPED_WEIGHTS`). Round 5: PREFIX_BITS > 24 runs on FINE bins (DESIGN.md §3.12, §5.8:",
+         "with three slices use 50 / 30 / 20 % of the reads (`ShardedBuilder.GROUPED_WEIGHTS`). Round 5: PREFIX_BITS > 24 runs on FINE bins (DESIGN_HISTORY.md §3.12, §5.8:",
          "`fine groups` = groups of the rehearsed rank that sort 16 prefix bits behind the first pass, in two LSD passes), any rank can be rehearsed (rank 0 = the",
          "densest prefix range, rank W - 1 = the sparse tail), and the rank bounds are cost-weighted quantiles (the tail's histogram cells count 1.20 x); 8 bytes per word on the wire (the digit byte stays home).", ""]
     for f in files:
