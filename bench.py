@@ -98,7 +98,8 @@ def merge_alg_bytes(k: int, pb: int):
 
 
 KERNEL_OF = {"radix_scatter": "k_radix_scatter", "radix_hist": "k_radix_hist_bytes", "radix_scan": "k_colscan_*+k_seg_*", "encode": "k_encode",
-             "bucket_medium": "k_bucket_msd (+ k_bucket_claim for runs full of repeats)", "bucket_small": "k_bucket_small", "bucket_huge": "k_bucket_huge", "bucket_big": "long runs: k_radix_scatter on the runs + k_bucket_msd (build); k_bucket_union (Trie |= Trie)",
+             "bucket_medium": "k_bucket_sorted (runs that end up sorted; self |= other) + k_bucket_msd (short runs; + k_bucket_claim for runs full of repeats)", "bucket_small": "k_bucket_small", "bucket_huge": "k_bucket_huge",
+             "bucket_big": "long runs: k_radix_scatter on the runs + k_bucket_sorted on the sub-ranges (build); k_bucket_union (Trie |= Trie)",
              "directory": "k_dir_gather/k_dir_resolve+k_bitvector+k_bucket_table", "chunks": "k_scan_invalid+chunk table",
              "merge_gather": "k_merge_gather"}
 

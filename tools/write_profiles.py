@@ -44,7 +44,7 @@ import bench as _b  # noqa: E402  (the price list the line uses)
 
 alg = _b.stage_alg_bytes(K_, PB_, L_)
 per_kernel = {}
-for stage, pred in (("encode", lambda k: "k_encode<" in k), ("bucket_medium", lambda k: "k_bucket_msd<" in k or "k_bucket_claim<" in k),
+for stage, pred in (("encode", lambda k: "k_encode<" in k), ("bucket_medium", lambda k: "k_bucket_msd<" in k or "k_bucket_sorted<" in k or "k_bucket_claim<" in k),
                     ("radix_scatter", lambda k: "k_radix_scatter<" in k), ("radix_hist", lambda k: "k_radix_hist" in k)):
     n, fk, wk = group(pred)
     if n:

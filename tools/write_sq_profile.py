@@ -27,7 +27,7 @@ out = [f"# {rnd} — SQ counters of the compute-bound kernels (rocprofv3 --pmc, 
        "--warmup 0 --no-cpu-baseline --no-h2d`, program directly after `--`, four passes (sq1 / sq2 / sq3 / grbm). Values are per dispatch, summed over the "
        "whole chip (8 XCDs, 256 CUs). `*_CYCLES` / `WAIT_*` / `ACTIVE_INST_*` count quad-cycles of waves (MI355X_MICROARCH.md); LDS_IDX_ACTIVE / LDS_BANK_CONFLICT are "
        "LDS-array cycles summed over the CUs. Workload: cfg 2, 1.2 G k-mers per step.\n"]
-keys = [k for k in vals if any(t in k for t in ("k_encode<", "k_bucket_msd<", "k_radix_scatter<"))]
+keys = [k for k in vals if any(t in k for t in ("k_encode<", "k_bucket_msd<", "k_bucket_sorted<", "k_radix_scatter<"))]
 for k in sorted(keys):
     v, r = vals[k], res.get(k, {})
     out.append(f"\n## `{k.replace('void ', '')}`\n")
