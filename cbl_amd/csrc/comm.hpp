@@ -22,6 +22,7 @@
 #include <condition_variable>
 #include <atomic>
 #include <map>
+#include <functional>
 
 #include "shard.hpp"
 
@@ -825,7 +826,13 @@ struct ReplicaSource {
     u64 nseq = 0;
     std::vector<u64> cuts;       // nslices + 1 sequence indices relative to d_off
 };
-struct Replica { std::vector<ReplicaSource> src; };
+struct Replica {
+    std::vector<ReplicaSource> src;
+    // a batch that is still ARRIVING (one rank, insert_device_sliced: slices land over PCIe): every slice is planned on its own once `ready(s)` has
+    // made the stream wait for it (s = ~0u: the offsets' first and last entry)
+    bool per_slice = false;
+    std::function<void(u32)> ready;
+};
 // `single`: ONE rank whose "groups" are the part of the prefix space the FINE bins cover in blocks of 2^16 prefixes and the rest (insert_device_fine):
 // no wire, the same sender and receiver steps
 // `rep`: no records cross the wire — piece (slice, source) is what THIS rank's first pass keeps of the source's reads (its own prefix range), the
@@ -870,6 +877,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     // -- the job: k-mers per rank (upper bound), whether any rank holds an index already
     const u64 n0 = cuts[0], n1 = cuts[nslices];
     u64 mine = 0;
+    if (rep && rep->ready) rep->ready(~0u);
     if (n1 > n0) {
         const u64 first = d2h<u64>(c, d_offsets + n0), last = d2h<u64>(c, d_offsets + n1);
         if (last < first) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
@@ -997,7 +1005,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         if (OHS) item(S.hi.get(), a_hi.get(), OHS);
         if (wire_dig) item(S.dig.get(), a_dig.get(), 1);
     };
-    struct Work { Buf<u64> t_lo; Buf<u8> t_hi; Buf<u32> counts, colpre, scratch, adj, coltot; };
+    struct Work { ChunkPlan pl; Buf<u64> t_lo; Buf<u8> t_hi; Buf<u32> counts, colpre, scratch, adj, coltot; };
     Work prev_work;
     // ONE chunk plan for the call, the slices are ranges of it (a plan per slice cost the send phase 0.4 ms of host round trips each)
     ChunkPlan PL;
@@ -1012,6 +1020,8 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         alloc_log(cap, a_lo, a_hi, a_dig);
         u64 over = 0;
         bool waited = false;
+        struct Late { size_t piece; u64 n; Buf<u32> coltot; };
+        std::vector<Late> late;
         for (u32 k = 0; k < W; ++k) {
             const u32 r = k == 0 ? me : (k <= me ? k - 1 : k);
             const ReplicaSource& R = rep->src[r];
@@ -1021,14 +1031,25 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
             ChunkPlan PLr;
             std::vector<PlanSlice> pslr(nslices);
             BaseView vr = R.view;
-            plan_chunks(c, vr, R.d_off, R.nseq, PLr, nullptr, &R.cuts, &pslr);
+            if (!rep->per_slice) plan_chunks(c, vr, R.d_off, R.nseq, PLr, nullptr, &R.cuts, &pslr);
             for (u32 s = 0; s < nslices && !over; ++s) {
-                const u64 N = pslr[s].k_hi - pslr[s].k_lo;
                 prev_work = Work();
+                Work wk;
+                const ChunkPlan* plan = &PLr;
+                const PlanSlice* part = &pslr[s];
+                BaseView vs = vr;
+                if (rep->per_slice) {  // the slice is planned once it has landed
+                    if (rep->ready) rep->ready(s);
+                    if (R.cuts[s + 1] == R.cuts[s]) continue;
+                    vs = R.view;
+                    plan_chunks(c, vs, R.d_off + R.cuts[s], R.cuts[s + 1] - R.cuts[s], wk.pl);
+                    plan = &wk.pl;
+                    part = nullptr;
+                }
+                const u64 N = part ? part->k_hi - part->k_lo : plan->n_kmers;
                 if (N >= 0xFFFFFFF0ull) throw Error(CBLX_ERANGE, "one slice takes fewer than 2^32-16 words (use more slices)");
                 if (!N) continue;
                 const u32 ntiles = (u32)ceil_div(N, RDX_TILE);
-                Work wk;
                 wk.coltot = Buf<u32>(c->pool, 256);
                 wk.adj = Buf<u32>(c->pool, 256);
                 const size_t hs = hi_elem_size(P);
@@ -1039,15 +1060,32 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
                 CBLX_HIP(hipMemsetAsync(wk.counts.get(), 0, (size_t)256 * (ntiles + 2) * 4, c->stream));
                 EncHist eh = eh0;
                 eh.counts = wk.counts.get();
-                encode<C>(c, vr, PLr, wk.t_lo.get(), (HiT*)wk.t_hi.get(), 0, eh, &pslr[s]);
+                encode<C>(c, vs, *plan, wk.t_lo.get(), (HiT*)wk.t_hi.get(), 0, eh, part);
                 { StageTimer t(c, ST_SCAN);
                   colscan(c, wk.counts.get(), nullptr, ntiles, wk.colpre.get(), wk.coltot.get(), wk.scratch);
                   hipLaunchKernelGGL(k_seg_adjust, dim3(1), dim3(256), 0, c->stream, wk.colpre.get(), wk.coltot.get(), (const u32*)nullptr, (const u32*)nullptr,
                                      (const u32*)nullptr, ntiles, 1u, wk.adj.get()); }
                 CBLX_HIP(hipGetLastError());
+                const size_t piece = (size_t)s * W + r;
+                if (single) {
+                    // one rank: every record is its own and the pass writes the log directly; the bin counts of the piece stay on the device until
+                    // the last slice is through (no host round trip between KRN-1 and the first pass: the next slice may be landing)
+                    if (filled + N >= LIMIT) { over = 1; break; }
+                    if (filled + N > cap) grow(filled + N);
+                    pbase[piece] = (u32)filled;
+                    const TileView tv{nullptr, nullptr, nullptr, nullptr, ntiles, N};
+                    { StageTimer t(c, ST_SCATTER);
+                      c->stages[ST_SCATTER].units += N;
+                      hipLaunchKernelGGL((k_radix_scatter<HiT, OutH, DigitCut, false>), dim3(xcd_grid(ntiles)), dim3(RDX_THREADS), 0, c->stream, (const u64*)wk.t_lo.get(), (const HiT*)wk.t_hi.get(), tv, fn,
+                                         (const u32*)wk.colpre.get(), (const u32*)wk.adj.get(), a_lo.get() + filled, OHS ? (OutH*)(a_hi.get() + filled * OHS) : (OutH*)nullptr, nextd, a_dig.get() + filled); }
+                    CBLX_HIP(hipGetLastError());
+                    late.push_back(Late{piece, N, std::move(wk.coltot)});
+                    filled += N;
+                    prev_work = std::move(wk);
+                    continue;
+                }
                 const std::vector<u32> tot = d2h_vec<u32>(c, wk.coltot.get(), 256);
                 u64 sum = 0, own_a = 0, own = 0;
-                const size_t piece = (size_t)s * W + r;
                 for (u32 bin = 0; bin < 256; ++bin) {
                     if (!tot[bin]) continue;
                     if (M.iv_of[bin] == 0xFFFFFFFFu) throw Error(CBLX_EDEVICE, "sharded build: a word fell into a bin no prefix maps to (internal error)");
@@ -1079,6 +1117,17 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         if (!waited) T.wait();
         T.all_reduce_sum_u64(&over, 1);
         if (over) throw Error(CBLX_ERANGE, "a rank's share of the job takes more than one round: use more ranks");
+        for (Late& l : late) {  // one rank: the bin counts of every piece, read once the passes are queued
+            const std::vector<u32> t = d2h_vec<u32>(c, l.coltot.get(), 256);
+            u64 sum = 0;
+            for (u32 bin = 0; bin < 256; ++bin) {
+                if (!t[bin]) continue;
+                if (M.iv_of[bin] == 0xFFFFFFFFu || bin < my_lo || bin - my_lo >= my_cells) throw Error(CBLX_EDEVICE, "sharded build: a word fell into a bin no prefix maps to (internal error)");
+                pcnt[l.piece * 256 + (bin - my_lo)] = t[bin];
+                sum += t[bin];
+            }
+            if (sum != l.n) throw Error(CBLX_EDEVICE, "sharded build: the bin histogram counts " + std::to_string(sum) + " words, the piece has " + std::to_string(l.n) + " (internal error)");
+        }
     } else {
     if (n1 > n0) {
         std::vector<u64> marks(nslices + 1);
@@ -1491,6 +1540,27 @@ namespace {
 template <typename Ready>
 void insert_device_sliced(cblx_ctx* c, const BaseView& bases, const u64* d_offsets, u64 nseq, const std::vector<u64>& seq_cuts, Ready&& ready) {
     const u32 ns = (u32)seq_cuts.size() - 1;
+    {   // PREFIX_BITS > 24 on an empty index: the FINE-bins build (insert_device_fine's plan: one rank, two groups, a fixed cut) slice by slice as
+        // the batch lands — two LSD passes behind the first one for the dense part of the prefix space instead of three for everything (round 6)
+        const char* fe = std::getenv("CBLX_FINE_BINS");
+        if (c->P.PB > 24 && c->res.count == 0 && nseq && ns && !(fe && fe[0] == '0')) {
+            cblx_comm cm;
+            cm.t.reset(new LocalTransport());
+            cm.recv_groups = 2;
+            cm.g_cuts.assign(1, fine_single_cut(c->P.PB));
+            Replica rep;
+            rep.src.resize(1);
+            rep.src[0].view = bases;
+            rep.src[0].d_off = d_offsets + seq_cuts[0];
+            rep.src[0].nseq = seq_cuts[ns] - seq_cuts[0];
+            for (u64 x : seq_cuts) rep.src[0].cuts.push_back(x - seq_cuts[0]);
+            rep.per_slice = true;
+            rep.ready = [&](u32 s) { ready(s); };
+            bool done = false;
+            dispatch(c->P, [&](auto cfg) { done = sharded_insert_grouped<decltype(cfg)>(c, &cm, nullptr, d_offsets, nseq, seq_cuts.data(), ns, nullptr, true, &rep); });
+            if (done) { ++c->fine_builds; collect_events(c); return; }
+        }
+    }
     LocalTransport T;
     u32 none = 0;
     dispatch(c->P, [&](auto cfg) { sharded_insert_bins<decltype(cfg)>(c, T, bases, d_offsets, nseq, seq_cuts.data(), ns, &none, ready); });

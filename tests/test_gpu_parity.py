@@ -512,7 +512,7 @@ def test_streamed_insert_rejects_bad_offsets_and_leaves_the_index_alone(pack, mo
     assert g.serialize() == o.serialize()
 
 @pytest.mark.parametrize("k,pb,canonical,nreads,L,dirty", [(31, 24, False, 600_000, 150, False), (59, 28, True, 300_000, 250, True), (25, 12, False, 700_000, 120, True),
-                                                          (31, 8, False, 500_000, 150, False), (27, 20, True, 600_000, 130, "mixed")])
+                                                          (31, 8, False, 500_000, 150, False), (27, 20, True, 600_000, 130, "mixed"), (31, 28, False, 400_000, 150, "mixed")])
 def test_streamed_insert_from_pinned_host_memory_equals_one_shot(k, pb, canonical, nreads, L, dirty, monkeypatch):
     """A big batch handed over in PINNED host memory crosses PCIe in slices that land front to back; flush() runs KRN-1 and the
     first partition pass of slice c while the later slices are on the wire (cblx_insert_seqs + cblx_flush). Same index bytes as
@@ -548,6 +548,8 @@ def test_streamed_insert_from_pinned_host_memory_equals_one_shot(k, pb, canonica
         g.flush()
         assert g.count() == ref.count()
         assert g.serialize() == want, slices
+        # PREFIX_BITS > 24: the slices take the FINE-bins route as they land (round 6), like the resident build
+        assert g.fine_builds() == (1 if pb > 24 else 0)
         g.close()
     # the batch as bit planes (host threads pack 3 bits per base, the insert runs right behind the transfer): from the pinned
     # buffer, from a pageable copy, and with offsets that do not start at 0
@@ -559,6 +561,7 @@ def test_streamed_insert_from_pinned_host_memory_equals_one_shot(k, pb, canonica
         g.insert_seqs(bases, offs)
         assert g.count() == ref.count()
         assert g.serialize() == want
+        assert g.fine_builds() == (1 if pb > 24 else 0)
         g.close()
     # on top of a resident index (the incremental path behind the pieces), then the same batch again: nothing new
     for pack in ("0", "1"):
