@@ -173,7 +173,8 @@ static const int CLASSIFY_THREADS = 1024;
 
 __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify(u64 nb, u32 lds_max /* longest run one workgroup sorts in LDS */, const u32* __restrict__ bucket_prefix, const u64* __restrict__ raw_start,
                                                                 DirView old, u32* __restrict__ res_count, u8* __restrict__ res_kind, u32* __restrict__ out_count,
-                                                                u8* __restrict__ out_kind, BDesc* __restrict__ lists /* [CLS_N][nb] */, u32* __restrict__ list_n) {
+                                                                u8* __restrict__ out_kind, BDesc* __restrict__ lists /* [CLS_N][nb] */, u32* __restrict__ list_n,
+                                                                const u8* __restrict__ span_done = nullptr /* buckets a clean span settled already (k_bucket_span) */) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     int cls = -1;
     u64 c = 0;
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify(u64 nb, u32 lds_m
         if (dir_lookup(old, bucket_prefix[r], orank)) { rc = old.count[orank]; rk = old.kind[orank]; }
         res_count[r] = rc;
         res_kind[r] = rk;
-        if (rc != 0 && c == rc) {  // untouched by this batch: keep as is (src/wordset/mod.rs:213-214 only re-checks touched buckets)
+        if (span_done && span_done[r]) {  // no repeat in the whole span it belongs to: count and kind are written, the words stay where they are
+        } else if (rc != 0 && c == rc) {  // untouched by this batch: keep as is (src/wordset/mod.rs:213-214 only re-checks touched buckets)
             out_count[r] = rc;
             out_kind[r] = rk;
         } else if (c == 1 && rc == 0) {  // a single new word: nothing to deduplicate, it already sits in its slot
@@ -915,6 +917,131 @@ __global__ __launch_bounds__(THREADS) void k_bucket_medium(const BDesc* __restri
     if (tid == 0) {
         out_count[r] = d;
         out_kind[r] = trie ? KIND_TRIE : KIND_VEC;
+    }
+}
+
+// ---- clean spans (round 6; a measured switch, OFF by default: CBLX_SPANS=1): many SHORT runs settled by one workgroup, when none holds a repeat ----
+// At PREFIX_BITS = 28 a bucket holds 90 words: 14 M one-wave workgroups at cfg 3 on one GPU, each a chain of launch -> scalar loads -> the
+// HBM round trip of 600 bytes -> a dozen LDS phases (3.2 us of wave life at 96 % occupancy, DESIGN_HISTORY.md §3.13) — for runs that, in a
+// batch of distinct k-mers, need NOTHING: no repeat means count = run length, kind = Vec, the words stay where they are. A SPAN is a maximal
+// stretch of consecutive buckets that are all short new runs (2 .. SPAN_MAX_RUN words, empty index) and start inside one aligned block of
+// SPAN_BLOCK arena positions: at most SPAN_CAP words. One workgroup loads the span's words coalesced and inserts a 64-bit fingerprint of
+// (bucket number inside the span, suffix) of every word into an LDS table (compare-and-swap, linear probing, two slots per word): if no
+// fingerprint was there already, no two words of any bucket of the span are equal — exact — and all its buckets are final. Any hit (a
+// repeat, or two words sharing a fingerprint: 2^-43 per span) leaves the span to the kernels below, bucket by bucket, untouched: this kernel
+// writes counts and kinds only, never a word. Spans of fewer than SPAN_MIN_RUNS buckets are left alone too (one bucket per workgroup is what
+// the other kernels do). k_classify then skips the settled buckets.
+static const u32 SPAN_BLOCK = 1024, SPAN_MAX_RUN = 512, SPAN_CAP = SPAN_BLOCK + SPAN_MAX_RUN, SPAN_MIN_RUNS = 3, SPAN_THREADS = 256, SPAN_SLOTS = 4096;
+__device__ __forceinline__ bool span_eligible(const u64* __restrict__ raw_start, u64 nb, u64 r) {
+    if (r >= nb) return false;
+    const u64 c = raw_start[r + 1] - raw_start[r];
+    return c >= 2 && c <= SPAN_MAX_RUN;
+}
+// span heads: an eligible bucket whose predecessor is not eligible or starts in another block; cont[r] = bucket r continues its predecessor's span
+__global__ __launch_bounds__(CLASSIFY_THREADS) void k_span_heads(u64 nb, const u64* __restrict__ raw_start, u32* __restrict__ heads, u32* __restrict__ nheads, u8* __restrict__ cont) {
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    int cls = -1;
+    if (r < nb) {
+        const bool el = span_eligible(raw_start, nb, r);
+        const bool head = el && (r == 0 || !span_eligible(raw_start, nb, r - 1) || raw_start[r - 1] / SPAN_BLOCK != raw_start[r] / SPAN_BLOCK);
+        cont[r] = el && !head ? 1 : 0;
+        if (head) cls = 0;
+    }
+    const u32 slot = block_append<CLASSIFY_THREADS, 1>(cls, nheads);
+    if (cls == 0) heads[slot] = (u32)r;
+}
+// (32-bit fingerprints: two words of a span share one with probability n^2 / 2^33 — 3 spans in 10 000 go the long way for nothing — and the table
+// is 16 KB: eight workgroups per CU. The chain of dependent HBM round trips is what a span costs, so everything a workgroup needs is requested at
+// once: the continuation flags and starts of the buckets behind the head, and SPAN_CAP words from the head's first word on, before it knows where
+// the span ends.)
+template <bool WS, typename HiT>
+__global__ __launch_bounds__(SPAN_THREADS) void k_bucket_span(const u32* __restrict__ heads, const u32* __restrict__ nheads, u64 nb, const u64* __restrict__ raw_start,
+                                                            const u8* __restrict__ cont, const u64* __restrict__ lo, const HiT* __restrict__ hi, u32 SB, u32* __restrict__ out_count,
+                                                            u8* __restrict__ out_kind, u8* __restrict__ span_done) {
+    constexpr int ITEMS = (SPAN_CAP + SPAN_THREADS - 1) / SPAN_THREADS;  // 6
+    constexpr int LOOK = (SPAN_BLOCK / 2 + 2 + SPAN_THREADS - 1) / SPAN_THREADS;  // buckets behind the head, per thread (runs of two words: 513 of them) = 3
+    constexpr u32 HW = SPAN_CAP / 64 + 1;
+    __shared__ u32 s_tab[SPAN_SLOTS];
+    __shared__ u64 s_heads[HW + 1];  // bit q: a bucket starts at word q of the span
+    __shared__ u32 s_hpre[HW + 1];
+    __shared__ u32 s_r1, s_end, s_hit;
+    if (blockIdx.x >= *nheads) return;
+    const u32 tid = threadIdx.x;
+    const u64 r0 = heads[blockIdx.x];
+    const u64 total = raw_start[nb];
+    const u64 a0 = raw_start[r0];
+    if (tid == 0) { s_r1 = 0xFFFFFFFFu; s_end = 0; s_hit = 0; }
+    for (u32 i = tid; i < HW + 1; i += SPAN_THREADS) s_heads[i] = 0;
+    for (u32 i = tid * 4; i < SPAN_SLOTS; i += SPAN_THREADS * 4) *reinterpret_cast<uint4*>(&s_tab[i]) = uint4{~0u, ~0u, ~0u, ~0u};
+    // -- one batch of requests: flags + starts of the buckets behind the head, the words
+    u32 ct[LOOK];
+    u64 st[LOOK];
+#pragma unroll
+    for (int k = 0; k < LOOK; ++k) {
+        const u64 r = r0 + 1 + tid + (u32)k * SPAN_THREADS;
+        ct[k] = r < nb ? cont[r] : 0u;
+        st[k] = raw_start[r <= nb ? r : nb];
+    }
+    const u64* __restrict__ wl = lo + a0;
+    const HiT* __restrict__ wh = WS ? hi + a0 : nullptr;
+    Sfx<WS> key[ITEMS];
+    const u32 nmax = total - a0 < SPAN_CAP ? (u32)(total - a0) : SPAN_CAP;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 e = j * SPAN_THREADS + tid;
+        key[j] = load_sfx<WS, HiT>(wl, wh, e < nmax ? e : 0u, SB);
+    }
+    __syncthreads();
+    // -- the span's members: buckets r0 .. r0 + s_r1 (s_r1 = the first bucket behind the head that does not continue it)
+#pragma unroll
+    for (int k = 0; k < LOOK; ++k)
+        if (!ct[k]) { atomicMin(&s_r1, tid + (u32)k * SPAN_THREADS); break; }
+    __syncthreads();
+    const u32 nruns = s_r1 + 1u;
+    if (nruns < SPAN_MIN_RUNS) return;
+#pragma unroll
+    for (int k = 0; k < LOOK; ++k) {
+        const u32 i = tid + (u32)k * SPAN_THREADS;
+        if (i < s_r1) atomicOr(reinterpret_cast<unsigned long long*>(&s_heads[(st[k] - a0) >> 6]), 1ull << ((st[k] - a0) & 63));
+        else if (i == s_r1) s_end = (u32)(st[k] - a0);  // where the bucket behind the span starts
+    }
+    __syncthreads();
+    const u32 n = s_end;  // <= SPAN_CAP
+    if (tid < 64) {  // exclusive prefix of the bucket-start bits per 64-bit word
+        const u32 v = tid < HW ? (u32)__builtin_popcountll(s_heads[tid]) : 0u;
+        const u32 inc = wave_inclusive_scan(v);
+        if (tid < HW) s_hpre[tid] = inc - v;
+    }
+    __syncthreads();
+    bool hit = false;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const u32 e = j * SPAN_THREADS + tid;
+        if (e < n && !*reinterpret_cast<volatile u32*>(&s_hit)) {
+            // bucket number of word e inside the span = bucket starts at or before e (the head's own start carries no bit)
+            const u32 b = s_hpre[e >> 6] + (u32)__builtin_popcountll(s_heads[e >> 6] & ((e & 63) == 63 ? ~0ull : ((2ull << (e & 63)) - 1ull)));
+            u64 f64 = key[j].lo * 0x9E3779B97F4A7C15ull + (u64)b * 0xD6E8FEB86659FD93ull;
+            if constexpr (WS) f64 ^= (key[j].hi + 0x2545F4914F6CDD1Dull) * 0xBF58476D1CE4E5B9ull;
+            f64 ^= f64 >> 29; f64 *= 0x94D049BB133111EBull; f64 ^= f64 >> 32;
+            u32 f = (u32)f64;
+            if (f == ~0u) f = 0;  // (the empty mark)
+            u32 h = (u32)(f64 >> 40) & (SPAN_SLOTS - 1);
+            for (;;) {
+                const u32 old = atomicCAS(&s_tab[h], ~0u, f);
+                if (old == ~0u) break;
+                if (old == f) { hit = true; break; }
+                h = (h + 1u) & (SPAN_SLOTS - 1);
+            }
+            if (hit) s_hit = 1u;  // (the others stop early: a batch full of repeats pays for a fraction of its spans)
+        }
+    }
+    if (__syncthreads_or((hit || s_hit) ? 1 : 0)) return;  // a repeat (or a shared fingerprint): the span's buckets take the kernels below
+    // (the members' lengths from the starts this thread holds: bucket r0 + 1 + i runs from st[k] to its successor's start — re-read, L2-warm)
+    for (u32 i = tid; i < nruns; i += SPAN_THREADS) {
+        const u64 r = r0 + i;
+        out_count[r] = (u32)(raw_start[r + 1] - raw_start[r]);
+        out_kind[r] = KIND_VEC;
+        span_done[r] = 1;
     }
 }
 

@@ -585,6 +585,14 @@ template <typename C> void finish_twin(cblx_ctx* c, Resident& nr, Twin& tw, int 
 // KRN-3 over the runs of `nr` (run of a prefix = [its resident suffixes as stored][the new words in stream order]) in the
 // arena a_lo / a_hi: per-bucket dedup / sort by size class; fills nr.cnt, nr.kind, nr.count. `old` = the resident index
 // the runs were built against (tells which buckets are untouched and which are Tries already).
+// CBLX_SPANS=1: the clean-span pre-filter in front of the classification (kernels_bucket.hpp: k_bucket_span). OFF by default — measured (round 6, one
+// MI355X): cfg 3 38.71 against 38.80 ms, cfg 4 50.9 against 51.6, cfg 2 +0.4 ms, 30 x coverage +2.4 ms: a span's life is its chain of dependent HBM
+// round trips (head -> first start -> flags, starts and words) just as a bucket's is, and eight 1 500-word spans per CU keep no more bytes in flight
+// per microsecond than thirty-two 77-word waves (DESIGN_HISTORY.md §3.13). Tests run both routes; read per call
+inline bool spans_enabled() {
+    const char* e = std::getenv("CBLX_SPANS");
+    return e && e[0] == '1';
+}
 // CBLX_REPEAT_PREPASS=0 switches the pre-pass of the long runs off (tests compare both routes); read per call
 bool repeat_prepass() {
     const char* e = std::getenv("CBLX_REPEAT_PREPASS");
@@ -615,8 +623,26 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
     // long-run path instead was measured — CBLX_LDS_MAX_WS — and is slower: 134 -> 143 / 165 ms per 1.2 G words at K = 59, the
     // cost is the ranking inside clusters of up to K mates, whatever the workgroup)
     static const u32 lds_max_ws = [] { const char* e = std::getenv("CBLX_LDS_MAX_WS"); const u32 v = e ? (u32)std::strtoul(e, nullptr, 10) : 0; return v ? v : 4096u; }();
+    // clean spans (kernels_bucket.hpp: k_bucket_span; a measured switch, off by default): on an empty index, stretches of consecutive short runs
+    // without a single repeat are settled by one workgroup each before anything is classified
+    Buf<u8> span_done;
+    if ((old.bv == nullptr || old.nb == 0) && nb >= SPAN_MIN_RUNS && spans_enabled()) {
+        StageTimer t(c, ST_BSMALL);
+        span_done = Buf<u8>(c->pool, nb + 1);
+        Buf<u32> heads(c->pool, nb + 1), nheads(c->pool, 1);
+        Buf<u8> cont(c->pool, nb + 1);
+        CBLX_HIP(hipMemsetAsync(span_done.get(), 0, nb + 1, c->stream));
+        CBLX_HIP(hipMemsetAsync(nheads.get(), 0, 4, c->stream));
+        hipLaunchKernelGGL(k_span_heads, grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, (const u64*)nr.start.get(), heads.get(), nheads.get(), cont.get());
+        const u32 nh = d2h<u32>(c, nheads.get());
+        if (nh)
+            hipLaunchKernelGGL((k_bucket_span<C::WS, HiT>), dim3(nh), dim3(SPAN_THREADS), 0, c->stream, (const u32*)heads.get(), (const u32*)nheads.get(), nb, (const u64*)nr.start.get(),
+                               (const u8*)cont.get(), (const u64*)a_lo, (const HiT*)a_hi, P.SB, nr.cnt.get(), nr.kind.get(), span_done.get());
+        CBLX_HIP(hipGetLastError());
+        CBLX_HIP(hipStreamSynchronize(c->stream));  // heads die here
+    }
     hipLaunchKernelGGL(k_classify, grid1(nb, CLASSIFY_THREADS), dim3(CLASSIFY_THREADS), 0, c->stream, nb, C::WS ? lds_max_ws : 4096u, nr.prefix.get(), nr.start.get(), old,
-                       res_count.get(), res_kind.get(), nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get());
+                       res_count.get(), res_kind.get(), nr.cnt.get(), nr.kind.get(), lists.get(), list_n.get(), (const u8*)span_done.get());
     std::vector<u32> ln = d2h_vec<u32>(c, list_n.get(), CLS_N);
     if (ln[CLS_S32] | ln[CLS_S16]) {
         StageTimer t(c, ST_BSMALL);

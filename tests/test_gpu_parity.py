@@ -257,6 +257,36 @@ def test_fine_bins_build_on_one_gpu(k, pb, nreads, L, canonical, monkeypatch):
         g.close()
 
 
+@pytest.mark.parametrize("k,pb,nreads,L,canonical,repeated", [(31, 16, 40000, 150, False, 60), (31, 18, 30000, 150, True, 0), (59, 20, 12000, 250, False, 25), (25, 14, 30000, 150, False, 400),
+                                                             (31, 28, 400000, 150, False, 300), (33, 17, 20000, 150, True, 10)])
+def test_clean_spans_equal_the_per_bucket_route(k, pb, nreads, L, canonical, repeated, monkeypatch):
+    """Clean spans (k_bucket_span): on an empty index, stretches of consecutive short runs (2 .. 512 words) are checked for repeats by ONE workgroup — a
+    fingerprint table of (bucket, suffix) — and settled without another kernel when there is none; a span with a repeat is left to the per-bucket
+    kernels untouched. Buckets of a few dozen to a few hundred words, `repeated` of the reads inserted twice (their spans must NOT be settled: the
+    first occurrence stays, in stream order), 16-byte suffixes, canonical; same bytes as the oracle and as the build without (the default: the
+    pre-filter is a measured switch that did not pay, DESIGN_HISTORY.md §3.13)."""
+    _need_gpu()
+    hb, ho = synth.reads(7 + k, nreads, L)
+    if repeated:  # the first `repeated` reads once more at the end
+        hb = np.concatenate([hb, hb[: repeated * L]])
+        ho = np.concatenate([ho, ho[1: repeated + 1] + ho[-1]])
+    o = Oracle(k, pb, canonical)
+    o.insert_seqs(hb, ho)
+    blobs = []
+    for spans in ("1", "0"):
+        monkeypatch.setenv("CBLX_SPANS", spans)
+        g = cbl_amd.CBL(k, pb, canonical=canonical)
+        g.insert_seqs(hb, ho)
+        g.flush()
+        _check_index(g, o)
+        assert g.validate() == 0
+        blobs.append(g.serialize())
+        g.insert_seqs(hb[: 500 * L], ho[:501])  # on a non-empty index (no spans there): nothing new
+        assert g.count() == o.count()
+        g.close()
+    assert blobs[0] == blobs[1]
+
+
 @pytest.mark.parametrize(
     "k,pb,n,canonical",
     [(9, 4, 40000, False), (9, 4, 40000, True), (11, 8, 60000, False), (11, 10, 200000, False), (13, 12, 300000, False),

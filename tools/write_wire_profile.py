@@ -15,7 +15,9 @@ def main():
          "copies at their own speed (what the kernels alone take). Not emulated: the CUs RCCL's kernels occupy, link contention, the peers' own pace. Grouped runs",
          "with three slices use 50 / 30 / 20 % of the reads (`ShardedBuilder.GROUPED_WEIGHTS`). Round 5: PREFIX_BITS > 24 runs on FINE bins (DESIGN_HISTORY.md §3.12, §5.8:",
          "`fine groups` = groups of the rehearsed rank that sort 16 prefix bits behind the first pass, in two LSD passes), any rank can be rehearsed (rank 0 = the",
-         "densest prefix range, rank W - 1 = the sparse tail), and the rank bounds are cost-weighted quantiles (the tail's histogram cells count 1.20 x); 8 bytes per word on the wire (the digit byte stays home).", ""]
+         "densest prefix range, rank W - 1 = the sparse tail), and the rank bounds are cost-weighted quantiles (the tail's histogram cells count 1.20 x); 8 bytes per word on the wire (the digit byte stays home).",
+         "Round 6: runs that end up sorted take `k_bucket_sorted` (DESIGN.md §3.1); protocol \"replicate\" (DESIGN.md §5.1): the READS cross as bit planes (0.3 bytes per k-mer, one",
+         "grouped all-gather up front), the rehearsed rank transforms every rank's reads and keeps its prefix range — `bytes received` are planes and offsets.", ""]
     for f in files:
         o = json.loads(open(f).read().strip().splitlines()[-1])
         W, rk, proto = o["world"], o.get("rank", 0), o.get("protocol", "bins")
@@ -38,6 +40,8 @@ def main():
                 name = f"grouped, {any_r['groups_used']} groups ({any_r.get('groups_fine', 0)} fine), {m[2]} slice{'s' if m[2] > 1 else ''}"
             elif m[0] == "sorted":
                 name = f"\"sorted\" protocol, {m[2]} slices"
+            elif m[0] == "replicate":
+                name = f"\"replicate\" protocol (reads as bit planes), {any_r['groups_used']} groups ({any_r.get('groups_fine', 0)} fine), {m[2]} slice{'s' if m[2] > 1 else ''}"
             else:
                 name = f"ungrouped (round 3), {m[2]} slices"
             L.append(f"| {name} | " + " | ".join(f"**{row[x]['ms_best']:.1f}**" if x in row else "—" for x in rates) +
@@ -51,7 +55,7 @@ def main():
                 one = f" = {W * km / ms / (km / o['direct_one_gpu_ms']):.2f} x the one-GPU rate of the same configuration" if "direct_one_gpu_ms" in o else ""
                 L.append(f"* {m[0]}{' ' + str(m[1]) + ' groups, ' + str(m[2]) + ' slice(s)' if m[0] == 'grouped' else ''} at 55 GB/s: {W} x {km / 1e9:.2f} G / {ms:.1f} ms = "
                          f"{W * km / ms / 1e6:.0f} G k-mers/s if every rank kept this rank's pace{one}.")
-        g = [r for r in o["runs"] if r["mode"] in ("grouped", "sorted") and r["link_gbps"] == 0]
+        g = [r for r in o["runs"] if r["mode"] in ("grouped", "sorted", "replicate") and r["link_gbps"] == 0]
         u = [r for r in o["runs"] if r["mode"] == "ungrouped" and r["link_gbps"] == 0]
         if g:
             L += ["", "Stage times of the last step without a wire (HIP events on the rank's stream; ms):", "", "| stage | " + g[0]["mode"] + (" | ungrouped |" if u else " |"), "|---|---|" + ("---|" if u else "")]
