@@ -51,6 +51,7 @@ PY
       done ;;
     cpu23) timeout 1800 python bench.py --cpu-full --steps 5 --warmup 1 --no-h2d --no-fasta --no-per-record > $OUT/bench_cpufull.json 2> $OUT/bench_cpufull.err; echo "cpu-full cfg2 rc=$?"
       timeout 2400 python bench.py --config cfg3 --cpu-full --steps 5 --warmup 1 --no-h2d --no-fasta --no-per-record > $OUT/bench_cpufull_cfg3.json 2> $OUT/bench_cpufull_cfg3.err; echo "cpu-full cfg3 rc=$?" ;;
+    cpu4) timeout 2400 python bench.py --config cfg4 --cpu-full --steps 5 --warmup 1 --no-h2d --no-fasta --no-per-record > $OUT/bench_cpufull_cfg4.json 2> $OUT/bench_cpufull_cfg4.err; echo "cpu-full cfg4 rc=$?" ;;
     cpumerge) timeout 2400 python bench.py --config merge --cpu-full --steps 5 --warmup 1 --no-h2d --no-fasta --no-per-record > $OUT/bench_cpufull_merge.json 2> $OUT/bench_cpufull_merge.err; echo "cpu-full merge rc=$?" ;;
     fuzz) bash tools/fuzz_campaign.sh ${TAG}_fuzz ${FUZZ_FROM:-1211} ${FUZZ_TO:-1220} ;;
   esac
