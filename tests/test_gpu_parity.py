@@ -258,7 +258,7 @@ def test_fine_bins_build_on_one_gpu(k, pb, nreads, L, canonical, monkeypatch):
 
 
 @pytest.mark.parametrize("k,pb,nreads,L,canonical,repeated", [(31, 16, 40000, 150, False, 60), (31, 18, 30000, 150, True, 0), (59, 20, 12000, 250, False, 25), (25, 14, 30000, 150, False, 400),
-                                                             (31, 28, 400000, 150, False, 300), (33, 17, 20000, 150, True, 10)])
+                                                             (31, 22, 60000, 150, False, 300), (33, 17, 20000, 150, True, 10)])
 def test_clean_spans_equal_the_per_bucket_route(k, pb, nreads, L, canonical, repeated, monkeypatch):
     """Clean spans (k_bucket_span): on an empty index, stretches of consecutive short runs (2 .. 512 words) are checked for repeats by ONE workgroup — a
     fingerprint table of (bucket, suffix) — and settled without another kernel when there is none; a span with a repeat is left to the per-bucket
