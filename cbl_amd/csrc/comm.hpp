@@ -828,6 +828,11 @@ struct ReplicaSource {
 };
 struct Replica {
     std::vector<ReplicaSource> src;
+    // every slice in `parts` parts (the cuts of a source then hold nslices * parts + 1 entries): the peers' planes cross the links part by part and
+    // a peer's part is transformed as soon as part_ready[t] has fired (null / empty: nothing to wait for). Stream order stays slice-major, rank-minor,
+    // part-minor: parts only cut the pieces, they do not reorder them.
+    u32 parts = 1;
+    std::vector<hipEvent_t> part_ready;
     // a batch that is still ARRIVING (one rank, insert_device_sliced: slices land over PCIe): every slice is planned on its own once `ready(s)` has
     // made the stream wait for it (s = ~0u: the offsets' first and last entry)
     bool per_slice = false;
@@ -1015,34 +1020,44 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
         // -- "replicate": KRN-1 + the first pass over EVERY rank's reads, piece by piece; the pass keeps the records of this rank's prefix range (they
         //    go straight into the log) and drops the others. The own pieces first: the peers' planes are still crossing the links meanwhile.
         if (rep->src.size() != W) throw Error(CBLX_EINVAL, "replicate: one source per rank (internal error)");
-        pcnt.assign((size_t)nslices * W * 256, 0u);
-        pbase.assign((size_t)nslices * W, 0u);
+        const u32 Q = std::max(1u, rep->parts), NT = nslices * Q;  // parts per slice, parts per source
+        pcnt.assign((size_t)NT * W * 256, 0u);
+        pbase.assign((size_t)NT * W, 0u);
         alloc_log(cap, a_lo, a_hi, a_dig);
         u64 over = 0;
-        bool waited = false;
         struct Late { size_t piece; u64 n; Buf<u32> coltot; };
         std::vector<Late> late;
-        for (u32 k = 0; k < W; ++k) {
-            const u32 r = k == 0 ? me : (k <= me ? k - 1 : k);
-            const ReplicaSource& R = rep->src[r];
-            if (R.cuts.size() != (size_t)nslices + 1) throw Error(CBLX_EINVAL, "replicate: slice cuts of a source (internal error)");
-            if (r != me && !waited) { T.wait(); waited = true; }  // (the own pieces' kernels are queued: they run while the host waits here)
-            if (R.nseq == 0 || over) continue;
-            ChunkPlan PLr;
-            std::vector<PlanSlice> pslr(nslices);
-            BaseView vr = R.view;
-            if (!rep->per_slice) plan_chunks(c, vr, R.d_off, R.nseq, PLr, nullptr, &R.cuts, &pslr);
-            for (u32 s = 0; s < nslices && !over; ++s) {
+        for (u32 r = 0; r < W; ++r) if (rep->src[r].cuts.size() != (size_t)NT + 1) throw Error(CBLX_EINVAL, "replicate: slice cuts of a source (internal error)");
+        // the own source is planned once (its parts are ranges of the plan) and goes first: the peers' planes are crossing the links meanwhile;
+        // then the peers part-major — exchange t carries part t of every peer — each part planned on its own once it has landed
+        ChunkPlan PLme;
+        std::vector<PlanSlice> pslme(NT);
+        BaseView vme = rep->src[me].view;
+        const bool own_whole = !rep->per_slice && rep->src[me].nseq != 0;
+        if (own_whole) plan_chunks(c, vme, rep->src[me].d_off, rep->src[me].nseq, PLme, nullptr, &rep->src[me].cuts, &pslme);
+        std::vector<std::pair<u32, u32>> order;  // (source, part)
+        for (u32 t = 0; t < NT; ++t) order.push_back({me, t});
+        for (u32 t = 0; t < NT; ++t) for (u32 r = 0; r < W; ++r) if (r != me) order.push_back({r, t});
+        {
+            for (const auto& rt : order) {
+                if (over) break;
+                const u32 r = rt.first, t = rt.second, s = t / Q;
+                const ReplicaSource& R = rep->src[r];
+                if (R.nseq == 0) continue;
                 prev_work = Work();
                 Work wk;
-                const ChunkPlan* plan = &PLr;
-                const PlanSlice* part = &pslr[s];
-                BaseView vs = vr;
-                if (rep->per_slice) {  // the slice is planned once it has landed
-                    if (rep->ready) rep->ready(s);
-                    if (R.cuts[s + 1] == R.cuts[s]) continue;
+                const ChunkPlan* plan = &PLme;
+                const PlanSlice* part = &pslme[t];
+                BaseView vs = vme;
+                if (!(r == me && own_whole)) {  // the part is planned once it has landed
+                    if (rep->ready) rep->ready(t);
+                    if (r != me) {
+                        if (t < rep->part_ready.size() && rep->part_ready[t]) CBLX_HIP(hipStreamWaitEvent(c->stream, rep->part_ready[t], 0));
+                        else T.wait();
+                    }
+                    if (R.cuts[t + 1] == R.cuts[t]) continue;
                     vs = R.view;
-                    plan_chunks(c, vs, R.d_off + R.cuts[s], R.cuts[s + 1] - R.cuts[s], wk.pl);
+                    plan_chunks(c, vs, R.d_off + R.cuts[t], R.cuts[t + 1] - R.cuts[t], wk.pl);
                     plan = &wk.pl;
                     part = nullptr;
                 }
@@ -1066,7 +1081,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
                   hipLaunchKernelGGL(k_seg_adjust, dim3(1), dim3(256), 0, c->stream, wk.colpre.get(), wk.coltot.get(), (const u32*)nullptr, (const u32*)nullptr,
                                      (const u32*)nullptr, ntiles, 1u, wk.adj.get()); }
                 CBLX_HIP(hipGetLastError());
-                const size_t piece = (size_t)s * W + r;
+                const size_t piece = ((size_t)s * W + r) * Q + (t % Q);
                 if (single) {
                     // one rank: every record is its own and the pass writes the log directly; the bin counts of the piece stay on the device until
                     // the last slice is through (no host round trip between KRN-1 and the first pass: the next slice may be landing)
@@ -1107,14 +1122,14 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
                                        (const u32*)wk.colpre.get(), (const u32*)wk.adj.get(), (u64*)nullptr, (OutH*)nullptr, nextd, (u8*)nullptr, (u32*)nullptr, 0u, 0u, 0u, (u32*)nullptr, 0u, ow);
                     CBLX_HIP(hipGetLastError());
                 }
-                if (trace) fprintf(stderr, "[cblx replicate] rank %u piece (slice %u, source %u): N=%llu kept=%llu filled=%llu\n", me, s, r, (unsigned long long)N, (unsigned long long)own,
-                                   (unsigned long long)filled);
+                if (trace) fprintf(stderr, "[cblx replicate] rank %u piece (slice %u, source %u, part %u): N=%llu kept=%llu filled=%llu\n", me, s, r, t % Q, (unsigned long long)N,
+                                   (unsigned long long)own, (unsigned long long)filled);
                 filled += own;
                 prev_work = std::move(wk);
             }
-            CBLX_HIP(hipStreamSynchronize(c->stream));  // the source's plan dies here
+            CBLX_HIP(hipStreamSynchronize(c->stream));  // the own source's plan dies here
         }
-        if (!waited) T.wait();
+        T.wait();
         T.all_reduce_sum_u64(&over, 1);
         if (over) throw Error(CBLX_ERANGE, "a rank's share of the job takes more than one round: use more ranks");
         for (Late& l : late) {  // one rank: the bin counts of every piece, read once the passes are queued
@@ -1246,7 +1261,7 @@ bool sharded_insert_grouped(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, const
     u64* fin_hi = WS ? fin.a_hi.get() : fin_hi_keep.get();
     // words of every group of mine
     std::vector<u64> gN(NG, 0);
-    const size_t np = (size_t)nslices * W;
+    const size_t np = pbase.size();  // nslices * W pieces (times the parts of a slice under "replicate")
     for (size_t p = 0; p < np; ++p)
         for (u32 g = 0; g < NG; ++g)
             for (u32 cl = gc0[g]; cl < gc0[g + 1]; ++cl) gN[g] += pcnt[p * 256 + cl];
@@ -1380,71 +1395,97 @@ bool sharded_insert_replicate(cblx_ctx* c, cblx_comm* cm, const u8* d_bases, con
     check_aligned16(d_bases, "d_bases");
     for (u32 s = 0; s < nslices; ++s) if (cuts[s + 1] < cuts[s] || cuts[s + 1] > n) throw Error(CBLX_EINVAL, "slice cuts must be ascending and at most n");
     const u64 n0 = cuts[0], n1 = cuts[nslices], nseq = n1 - n0;
-    u64 first = 0, last = 0;
+    // The planes cross the links in PARTS (two per call at least: a one-slice call is cut in halves of its reads) so that a peer's first part can be
+    // transformed while its later ones are still on the wire; parts cut the (slice, source) pieces, they do not reorder them. (Every part of every
+    // peer is planned on its own — 0.4 ms of host round trips each: four parts were measured too and cost what they hid at 55 GB/s per link.)
+    const u32 Q = std::max(1u, 2u / nslices), NT = nslices * Q;
+    std::vector<u64> xcuts(NT + 1), ox(NT + 1, 0);  // sequence index (relative to n0) and base offset at every part boundary
+    for (u32 s = 0; s < nslices; ++s)
+        for (u32 q = 0; q < Q; ++q) xcuts[s * Q + q] = cuts[s] - n0 + (cuts[s + 1] - cuts[s]) * q / Q;
+    xcuts[NT] = nseq;
     if (nseq) {
-        first = d2h<u64>(c, d_offsets + n0);
-        last = d2h<u64>(c, d_offsets + n1);
-        if (last < first) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
+        for (u32 t = 0; t <= NT; ++t) ox[t] = (t && xcuts[t] == xcuts[t - 1]) ? ox[t - 1] : d2h<u64>(c, d_offsets + n0 + xcuts[t]);
+        for (u32 t = 0; t < NT; ++t) if (ox[t + 1] < ox[t]) throw Error(CBLX_EINVAL, "offsets must be non-decreasing");
     }
+    const u64 first = ox[0], last = ox[NT];
     const u64 g0 = first >> 4, g1 = nseq ? (last + 15) >> 4 : g0, ng = g1 - g0;
-    // -- what every rank holds: sequences, plane groups, slice cuts
-    const size_t per = 3 + (size_t)nslices + 1;
+    // -- what every rank holds: sequences, part boundaries (sequence index and base offset)
+    const size_t per = 1 + 2 * ((size_t)NT + 1);
     std::vector<u64> send(per * W), recv(per * W);
     for (u32 d = 0; d < W; ++d) {
         u64* h = send.data() + d * per;
-        h[0] = nseq; h[1] = g0; h[2] = g1;
-        for (u32 s = 0; s <= nslices; ++s) h[3 + s] = cuts[s] - n0;
+        h[0] = nseq;
+        for (u32 t = 0; t <= NT; ++t) { h[1 + t] = xcuts[t]; h[2 + NT + t] = ox[t]; }
     }
     T.all_to_all_u64(send.data(), recv.data(), per);
-    // -- own planes, then the all-gather of planes and offsets (one grouped exchange; the own pieces are transformed under it)
+    auto hdr_cut = [&](u32 r, u32 t) { return recv[r * per + 1 + t]; };
+    auto hdr_off = [&](u32 r, u32 t) { return recv[r * per + 2 + NT + t]; };
+    auto ga_of = [&](u32 r, u32 t) { return hdr_off(r, t) >> 4; };                                           // first plane group of part t of rank r
+    auto gb_of = [&](u32 r, u32 t) { return recv[r * per] ? (hdr_off(r, t + 1) + 15) >> 4 : ga_of(r, t); };  // one past its last
+    // -- own planes, then the all-gather of planes and offsets, part by part (the own pieces are transformed under it)
     Buf<u32> my_codes(c->pool, ng + 4);
     Buf<u16> my_valid(c->pool, ng + 4);
     if (ng) hipLaunchKernelGGL(k_pack_planes, grid1(ng, 256), dim3(256), 0, c->stream, d_bases, g0, g1, last, my_codes.get(), my_valid.get());
     CBLX_HIP(hipGetLastError());
     std::vector<u64> gro(W + 1, 0), sqo(W + 1, 0);  // plane groups / offset words in front of every peer's share of the gather buffers
     for (u32 r = 0; r < W; ++r) {
-        const u64* h = recv.data() + r * per;
-        if (h[2] < h[1]) throw Error(CBLX_EDEVICE, "replicate: a rank announced a negative plane range (transport error)");
-        gro[r + 1] = gro[r] + (r == me ? 0 : h[2] - h[1] + 4);  // (+ slack: the tile loads of KRN-1 read a few words ahead)
-        sqo[r + 1] = sqo[r] + (r == me ? 0 : h[0] + 1);
+        for (u32 t = 0; t < NT; ++t) if (hdr_cut(r, t + 1) < hdr_cut(r, t) || hdr_off(r, t + 1) < hdr_off(r, t)) throw Error(CBLX_EDEVICE, "replicate: a rank announced part boundaries out of order (transport error)");
+        if (hdr_cut(r, NT) != recv[r * per]) throw Error(CBLX_EDEVICE, "replicate: a rank's parts do not add up to its reads (transport error)");
+        const u64 ngr = recv[r * per] ? gb_of(r, NT - 1) - ga_of(r, 0) : 0;
+        gro[r + 1] = gro[r] + (r == me ? 0 : ngr + 4);  // (+ slack: the tile loads of KRN-1 read a few words ahead)
+        sqo[r + 1] = sqo[r] + (r == me ? 0 : recv[r * per] + 1);
     }
     Buf<u32> all_codes(c->pool, gro[W] + 4);
     Buf<u16> all_valid(c->pool, gro[W] + 4);
     Buf<u64> all_off(c->pool, sqo[W] + 2);
     CBLX_HIP(hipMemsetAsync(all_codes.get(), 0, (gro[W] + 4) * 4, c->stream));
     CBLX_HIP(hipMemsetAsync(all_valid.get(), 0, (gro[W] + 4) * 2, c->stream));
-    {
-        auto item = [&](const void* src, void* dst, u64 mine_elems, size_t es, const std::vector<u64>& off, auto elems_of) {
+    std::vector<hipEvent_t> ev(NT, nullptr);
+    struct Events { std::vector<hipEvent_t>& v; ~Events() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } events{ev};
+    struct Drain { Transport& t; ~Drain() { try { t.wait(); } catch (...) {} } } drain{T};
+    for (u32 t = 0; t < NT; ++t) {
+        auto planes = [&](const void* src, void* dst, size_t es) {
             Transport::Item it{(const u8*)src, (u8*)dst, std::vector<u64>(W, 0), std::vector<u64>(W, 0), std::vector<u64>(W, 0), std::vector<u64>(W, 0)};
             for (u32 r = 0; r < W; ++r) {
                 if (r == me) continue;
-                it.s_len[r] = mine_elems * es;
-                it.r_off[r] = off[r] * es;
-                it.r_len[r] = elems_of(r) * es;
+                it.s_off[r] = (ga_of(me, t) - ga_of(me, 0)) * es;
+                it.s_len[r] = (gb_of(me, t) - ga_of(me, t)) * es;
+                it.r_off[r] = (gro[r] + ga_of(r, t) - ga_of(r, 0)) * es;
+                it.r_len[r] = (gb_of(r, t) - ga_of(r, t)) * es;
             }
             return it;
         };
         std::vector<Transport::Item> items;
-        items.push_back(item(my_codes.get(), all_codes.get(), ng, 4, gro, [&](u32 r) { return recv[r * per + 2] - recv[r * per + 1]; }));
-        items.push_back(item(my_valid.get(), all_valid.get(), ng, 2, gro, [&](u32 r) { return recv[r * per + 2] - recv[r * per + 1]; }));
-        items.push_back(item(d_offsets + n0, all_off.get(), nseq ? nseq + 1 : 0, 8, sqo, [&](u32 r) { return recv[r * per] ? recv[r * per] + 1 : 0; }));
+        items.push_back(planes(my_codes.get(), all_codes.get(), 4));
+        items.push_back(planes(my_valid.get(), all_valid.get(), 2));
+        if (t == 0) {  // every read offset rides with the first part
+            Transport::Item it{(const u8*)(d_offsets + n0), (u8*)all_off.get(), std::vector<u64>(W, 0), std::vector<u64>(W, 0), std::vector<u64>(W, 0), std::vector<u64>(W, 0)};
+            for (u32 r = 0; r < W; ++r) {
+                if (r == me) continue;
+                it.s_len[r] = nseq ? (nseq + 1) * 8 : 0;
+                it.r_off[r] = sqo[r] * 8;
+                it.r_len[r] = recv[r * per] ? (recv[r * per] + 1) * 8 : 0;
+            }
+            items.push_back(std::move(it));
+        }
         T.exchange_items(items, c->stream);
+        CBLX_HIP(hipEventCreateWithFlags(&ev[t], hipEventDisableTiming));
+        T.record(ev[t], c->stream);
     }
     Replica rep;
     rep.src.resize(W);
+    rep.parts = Q;
+    rep.part_ready = ev;
     for (u32 r = 0; r < W; ++r) {
         ReplicaSource& R = rep.src[r];
-        const u64* h = recv.data() + r * per;
-        R.nseq = h[0];
-        R.cuts.assign(h + 3, h + 3 + nslices + 1);
-        for (u32 s = 0; s < nslices; ++s) if (R.cuts[s + 1] < R.cuts[s] || R.cuts[s + 1] > R.nseq) throw Error(CBLX_EDEVICE, "replicate: a rank announced slice cuts out of order (transport error)");
+        R.nseq = recv[r * per];
+        for (u32 t = 0; t <= NT; ++t) R.cuts.push_back(hdr_cut(r, t));
         if (r == me) { R.view = ascii_view(d_bases); R.d_off = d_offsets + n0; }
-        else {  // planes indexed by the SENDER's base positions: group g of the sender is word g - g0 of its share
-            R.view = BaseView{nullptr, all_codes.get() + gro[r] - h[1], all_valid.get() + gro[r] - h[1]};
+        else {  // planes indexed by the SENDER's base positions: group g of the sender is word g - (its first group) of its share
+            R.view = BaseView{nullptr, all_codes.get() + gro[r] - ga_of(r, 0), all_valid.get() + gro[r] - ga_of(r, 0)};
             R.d_off = all_off.get() + sqo[r];
         }
     }
-    struct Drain { Transport& t; ~Drain() { try { t.wait(); } catch (...) {} } } drain{T};
     const bool done = sharded_insert_grouped<C>(c, cm, d_bases, d_offsets, n, cuts, nslices, bounds, false, &rep);
     T.wait();
     CBLX_HIP(hipStreamSynchronize(c->stream));  // the gather buffers die here
