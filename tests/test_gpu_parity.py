@@ -2157,7 +2157,7 @@ def _native_worker(rank, world, port, k, pb, canonical, per, L, path, q, protoco
 
 @pytest.mark.parametrize("world,k,pb,canonical,protocol,groups", [
     (2, 31, 24, False, "bins", 0), (3, 59, 28, True, "bins", 0), (4, 25, 12, False, "bins", 0), (8, 31, 24, False, "bins", 0),
-    (3, 31, 28, True, "bins", 0), (2, 21, 16, False, "bins", 0), (5, 33, 25, False, "bins", 0),  # (five ranks, 16-byte records, FINE bins; K = 59 at PREFIX_BITS = 26 on five ranks spent 91 s in gigabyte-sized first allocations)
+    (3, 31, 28, True, "bins", 0), (2, 21, 16, False, "bins", 0), (3, 33, 25, False, "bins", 0),  # (16-byte records, FINE bins; five ranks sharing the GPU spend 30 - 90 s in their first allocations: one such case is kept, under "auto")
     (2, 31, 24, False, "bins", 1), (3, 59, 28, True, "bins", 1), (8, 31, 24, False, "bins", 1), (3, 31, 28, True, "bins", 1),  # the ungrouped receiver
     (2, 31, 24, False, "bins", 3), (4, 31, 28, False, "bins", 14), (3, 45, 20, True, "bins", 5), (2, 27, 9, False, "bins", 4),
     (4, 31, 25, True, "bins", 3), (2, 33, 27, False, "bins", 5),  # FINE bins where a 65..72-bit word's bins must imply 21 prefix bits; 16-byte records
