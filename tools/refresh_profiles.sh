@@ -22,7 +22,7 @@ d = json.loads(open(f'profiles/{R}_bench_cfg2.json').read())
 print('cfg2', d['ms_per_step'], d['value'], 'h2d', d['h2d_inclusive']['ms_per_step'], 'fasta', d['fasta_inclusive']['ms_per_step'], 'per record', d['per_record']['ms_total'],
       'serialize', d['serialize']['to_host_ms'], 'frac', d['roofline']['frac'])
 PY
-W=""; for f in wire_cfg3 wire_cfg3_rank3 wire_cfg3_rank6 wire_cfg3_rank7 wire_cfg2 wire_cfg4 wire_cfg4_rank7 wire_w2_replicate wire_w2_sorted wire_w2_bins wire_w3_replicate wire_w3_sorted wire_w3_bins wire_w4_replicate wire_w4_sorted wire_w4_bins wire_w2_replicate_cfg4; do [ -s gpurun_out/$T/$f.json ] && W="$W gpurun_out/$T/$f.json"; done
+W=""; for f in wire_cfg3 wire_cfg3_rank3 wire_cfg3_rank6 wire_cfg3_rank7 wire_cfg2 wire_cfg4 wire_cfg4_rank7 wire_w2_replicate wire_w2_sorted wire_w2_bins wire_w3_replicate wire_w3_sorted wire_w3_bins wire_w4_replicate wire_w4_sorted wire_w4_bins wire_w5_replicate wire_w5_sorted wire_w5_bins wire_w2_replicate_cfg4; do [ -s gpurun_out/$T/$f.json ] && W="$W gpurun_out/$T/$f.json"; done
 python tools/write_wire_profile.py profiles/${R}_wire_emulated.md $R $W
 [ -s gpurun_out/$T/bench_cpufull.json ] && tail -1 gpurun_out/$T/bench_cpufull.json | python -c "import json,sys; json.dump(json.loads(sys.stdin.read()), open('profiles/${R}_bench_cpufull.json','w'), indent=1)"
 for c in cfg3 cfg4 merge; do
