@@ -1702,6 +1702,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
 #ifndef CBLX_SORTED_WAVES
 #define CBLX_SORTED_WAVES 7
 #endif
+#ifndef CBLX_SORTED_BALANCE
+#define CBLX_SORTED_BALANCE 0  // the chunks of a workgroup dealt to its lanes in order of their span (measured: see DESIGN_HISTORY.md §3.13)
+#endif
 #ifndef CBLX_SORTED_PROBE
 #define CBLX_SORTED_PROBE 0  // > 0: timing probes that leave phases out (wrong results); never in the product build
 #endif
@@ -1877,7 +1880,39 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
 #endif
     // -- the walk: lane t owns slots [t per, t per + per) of the sub-bucket order
     const u32 per = (c + THREADS - 1) / THREADS;  // <= ITEMS
-    const u32 p0 = tid * per;
+    u32 chunk = tid;
+#if CBLX_SORTED_BALANCE
+    if constexpr (NW > 1 && THREADS <= 256) {
+        // The wave's longest span is what its walk costs (2.2 x the mean): the chunks are dealt to the lanes in order of their span, so that a wave's
+        // lanes walk spans of about one length (a counting sort of the THREADS chunks on min(span, 127))
+        __shared__ u32 s_bins32[64];
+        __shared__ u8 s_perm[THREADS];
+        u16* s_bins = reinterpret_cast<u16*>(s_bins32);
+        if (tid < 64) s_bins32[tid] = 0;
+        const u32 q0 = tid * per;
+        u32 span = 0;
+        if (q0 < c) {
+            const u32 q1 = (q0 + per < c ? q0 + per : c) - 1u;
+            const E f = s_k[EL::phys(q0)], l = s_k[EL::phys(q1)];
+            span = s_off[EL::sub(l, sub_sh, nbits) + 1u] - (s_off[EL::sub(f, sub_sh, nbits)] & ~1u);
+        }
+        const u32 bin = span < 127u ? span : 127u;
+        __syncthreads();
+        const u32 arr = (atomicAdd(&s_bins32[bin >> 1], 1u << ((bin & 1u) * 16u)) >> ((bin & 1u) * 16u)) & 0xFFFFu;
+        __syncthreads();
+        if (tid < 64) {  // exclusive scan of the 128 counts, two per lane
+            const u32 a = s_bins[2 * tid], b = s_bins[2 * tid + 1];
+            const u32 inc = wave_inclusive_scan(a + b);
+            s_bins[2 * tid] = (u16)(inc - a - b);
+            s_bins[2 * tid + 1] = (u16)(inc - b);
+        }
+        __syncthreads();
+        s_perm[s_bins[bin] + arr] = (u8)tid;
+        __syncthreads();
+        chunk = s_perm[tid];
+    }
+#endif
+    const u32 p0 = chunk * per;
     const u32 n_own = p0 < c ? (c - p0 < per ? c - p0 : per) : 0u;
     E me[ITEMS];
     u32 fin[ITEMS];
