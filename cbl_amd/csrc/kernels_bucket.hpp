@@ -120,7 +120,13 @@ __device__ __forceinline__ bool dir_lookup(const DirView& d, u32 p, u64& rank) {
 }
 
 // ---- classification of buckets by run length -----------------------------------------------------------
-enum { CLS_M16 = 0, CLS_M64 = 1, CLS_M128 = 2, CLS_M256 = 3, CLS_M512 = 4, CLS_M1024 = 5, CLS_HUGE = 6, CLS_S16 = 7, CLS_S32 = 8, CLS_BIG = 9, CLS_N = 10 };
+enum { CLS_M16 = 0, CLS_M64 = 1, CLS_M128 = 2, CLS_M256 = 3, CLS_M512 = 4, CLS_M1024 = 5, CLS_HUGE = 6, CLS_S16 = 7, CLS_S32 = 8, CLS_BIG = 9, CLS_M32 = 10, CLS_N = 11 };
+// CLS_M32 (round 6, the build only): runs of 129 - 256 words as 64 threads x FOUR slots. In the 512-slot class they paid for eight slots per lane
+// — the phases are unrolled over the slots — and at PREFIX_BITS = 28 nearly all of that class is this short (cfg 3: 3.97 M of its 4.02 M runs):
+// 3.51 -> 2.53 ms on the same runs (tools/dev_msd_bench.cpp -DMSD_BENCH_SPLIT). 0 = the classes of rounds 1 - 5.
+#ifndef CBLX_CLASS_256
+#define CBLX_CLASS_256 1
+#endif
 // Runs longer than one workgroup's LDS sort takes (> 4096) and up to BIG_MAX: split by the top suffix bits into sub-ranges of
 // about a thousand words in scratch, each sorted + deduplicated by k_bucket_msd, then collected in order (k_big_*). Such
 // buckets are the rule, not the exception, once an index holds tens of millions of reads at PREFIX_BITS = 24 (one rank of an
@@ -195,6 +201,7 @@ __global__ __launch_bounds__(CLASSIFY_THREADS) void k_classify(u64 nb, u32 lds_m
             out_kind[r] = KIND_VEC;
         } else if (c <= SMALL_MAX && rk != KIND_TRIE) cls = c <= 16 ? CLS_S16 : CLS_S32;  // lanes per bucket: 16 / 32
         else if (c <= 16 * MED_ITEMS) cls = CLS_M16;
+        else if (CBLX_CLASS_256 && c <= 32 * MED_ITEMS) cls = CLS_M32;  // one wave, four slots per lane
         else if (c <= 64 * MED_ITEMS) cls = CLS_M64;    // workgroup size follows the run length: THREADS = CAP / 8
         else if (c <= 128 * MED_ITEMS) cls = CLS_M128;
         else if (c <= 256 * MED_ITEMS && c <= lds_max) cls = CLS_M256;

@@ -662,26 +662,28 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
         // fast path (counting sort on the top suffix bits + in-sub-bucket ranking); a run with a crowded sub-bucket marks its
         // list entry and takes the claim-table kernel of its length class (runs full of repeats); what needs the sorted layout
         // after that goes to the LDS radix sort
-        static const int MCLS[5] = {CLS_M16, CLS_M64, CLS_M128, CLS_M256, CLS_M512};
-        u64 roff[6] = {0, 0, 0, 0, 0, 0};
-        for (int k = 0; k < 5; ++k) roff[k + 1] = roff[k] + ln[MCLS[k]];
-        Buf<u8> bail(c->pool, roff[5] + 8);
-        Buf<u32> bail_any(c->pool, 6);  // one word per class, then the radix kernel's list counter
-        Buf<BDesc> retry2(c->pool, std::max<u64>(roff[5], 1));
-        CBLX_HIP(hipMemsetAsync(bail.get(), 0, roff[5] + 8, c->stream));
-        CBLX_HIP(hipMemsetAsync(bail_any.get(), 0, 6 * 4, c->stream));
-        u32* r2n = bail_any.get() + 5;
+        constexpr int NM = 6;
+        static const int MCLS[NM] = {CLS_M16, CLS_M32, CLS_M64, CLS_M128, CLS_M256, CLS_M512};
+        u64 roff[NM + 1] = {0};
+        for (int k = 0; k < NM; ++k) roff[k + 1] = roff[k] + ln[MCLS[k]];
+        Buf<u8> bail(c->pool, roff[NM] + 8);
+        Buf<u32> bail_any(c->pool, NM + 1);  // one word per class, then the radix kernel's list counter
+        Buf<BDesc> retry2(c->pool, std::max<u64>(roff[NM], 1));
+        CBLX_HIP(hipMemsetAsync(bail.get(), 0, roff[NM] + 8, c->stream));
+        CBLX_HIP(hipMemsetAsync(bail_any.get(), 0, (NM + 1) * 4, c->stream));
+        u32* r2n = bail_any.get() + NM;
         // The classes up to 1024 words (hashed sub-buckets) never give up without repeats in the batch: once one of them did
         // — the shortest is asked first — the classes after it start with the claim table (`repeat_mode`) instead of a
         // counting sort that is going to give up.
         bool repeat_mode = false;
-        std::vector<u32> any(5, 0u);
-        bool used_msd[5] = {false, false, false, false, false};
+        std::vector<u32> any(NM, 0u);
+        bool used_msd[NM] = {false};
+        auto any_of = [&](const std::vector<u32>& v) { u32 a = 0; for (u32 x : v) a |= x; return a != 0; };
         // suffixes too wide for the counting-sort kernel's 16-byte elements (SUFFIX_BITS > 116: K >= 57 with a handful of prefix
         // bits): every class takes the LDS radix kernel
         const bool radix_only = !msd_takes<C::WS>(P.SB);
         if (radix_only) {
-            for (int k = 0; k < 5; ++k)
+            for (int k = 0; k < NM; ++k)
                 if (ln[MCLS[k]])
                     hipLaunchKernelGGL((k_bucket_medium<512, C::WS, HiT>), dim3(ln[MCLS[k]]), dim3(512), 0, c->stream, lists.get() + (size_t)MCLS[k] * nb, list_n.get() + MCLS[k], a_lo, a_hi,
                                        P.SB, nr.cnt.get(), nr.kind.get(), MergeArgs{});
@@ -712,18 +714,17 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
                                    nr.cnt.get(), nr.kind.get(), (BDesc*)nullptr, (u32*)nullptr, MergeArgs{}, bail.get() + roff[k], bail_any.get() + k);
             };
             go(std::integral_constant<int, 64>(), std::integral_constant<int, 128>(), 0);
-            if (used_msd[0] && (ln[CLS_M64] | ln[CLS_M128] | ln[CLS_M256] | ln[CLS_M512]))  // the shortest class is the cheapest witness
+            if (used_msd[0] && (ln[CLS_M32] | ln[CLS_M64] | ln[CLS_M128] | ln[CLS_M256] | ln[CLS_M512]))  // the shortest class is the cheapest witness
                 repeat_mode = d2h<u32>(c, bail_any.get() + 0) != 0;
-            go(std::integral_constant<int, 64>(), std::integral_constant<int, 512>(), 1);
-            go(std::integral_constant<int, 128>(), std::integral_constant<int, 1024>(), 2);
-            if (!repeat_mode && (ln[CLS_M256] | ln[CLS_M512]) && (used_msd[1] | used_msd[2])) {
-                const std::vector<u32> a3 = d2h_vec<u32>(c, bail_any.get(), 3);
-                repeat_mode = (a3[0] | a3[1] | a3[2]) != 0;
-            }
-            go(std::integral_constant<int, 256>(), std::integral_constant<int, 2048>(), 3);
-            go(std::integral_constant<int, 512>(), std::integral_constant<int, 4096>(), 4);
-            if (!roff[5]) return;
-            any = d2h_vec<u32>(c, bail_any.get(), 5);
+            go(std::integral_constant<int, 64>(), std::integral_constant<int, 256>(), 1);
+            go(std::integral_constant<int, 64>(), std::integral_constant<int, 512>(), 2);
+            go(std::integral_constant<int, 128>(), std::integral_constant<int, 1024>(), 3);
+            if (!repeat_mode && (ln[CLS_M256] | ln[CLS_M512]) && (used_msd[1] | used_msd[2] | used_msd[3]))
+                repeat_mode = any_of(d2h_vec<u32>(c, bail_any.get(), 4));
+            go(std::integral_constant<int, 256>(), std::integral_constant<int, 2048>(), 4);
+            go(std::integral_constant<int, 512>(), std::integral_constant<int, 4096>(), 5);
+            if (!roff[NM]) return;
+            any = d2h_vec<u32>(c, bail_any.get(), NM);
             auto claim = [&](auto thr, auto cap, int k) {
                 constexpr int T = decltype(thr)::value, CAPV = decltype(cap)::value;
                 const int cls = MCLS[k];
@@ -732,11 +733,12 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
                                    P.SB, nr.cnt.get(), nr.kind.get(), retry2.get(), r2n, (const u8*)(bail.get() + roff[k]));
             };
             claim(std::integral_constant<int, 64>(), std::integral_constant<int, 128>(), 0);
-            claim(std::integral_constant<int, 64>(), std::integral_constant<int, 512>(), 1);
-            claim(std::integral_constant<int, 128>(), std::integral_constant<int, 1024>(), 2);
-            claim(std::integral_constant<int, 256>(), std::integral_constant<int, 2048>(), 3);
-            claim(std::integral_constant<int, 512>(), std::integral_constant<int, 4096>(), 4);
-            if (CBLX_CLAIM_FIRST || repeat_mode || (any[0] | any[1] | any[2] | any[3] | any[4])) {
+            claim(std::integral_constant<int, 64>(), std::integral_constant<int, 256>(), 1);
+            claim(std::integral_constant<int, 64>(), std::integral_constant<int, 512>(), 2);
+            claim(std::integral_constant<int, 128>(), std::integral_constant<int, 1024>(), 3);
+            claim(std::integral_constant<int, 256>(), std::integral_constant<int, 2048>(), 4);
+            claim(std::integral_constant<int, 512>(), std::integral_constant<int, 4096>(), 5);
+            if (CBLX_CLAIM_FIRST || repeat_mode || any_of(any)) {
                 // what the claim tables left for the sorted layout: distinct words now, at most 4096 per run
                 const u32 n2 = d2h<u32>(c, r2n);
                 if (n2) {
@@ -766,14 +768,14 @@ template <typename C> void bucket_stage(cblx_ctx* c, Resident& nr, const DirView
         } else {
             stage(std::false_type());
         }
-        saw_repeats = roff[5] ? repeat_mode : true;  // no shorter runs at all: unknown = yes
-        if (roff[5] && !repeat_mode && (ln[CLS_BIG] | ln[CLS_HUGE]) && (any[0] | any[1] | any[2] | any[3] | any[4])) {
+        saw_repeats = roff[NM] ? repeat_mode : true;  // no shorter runs at all: unknown = yes
+        if (roff[NM] && !repeat_mode && (ln[CLS_BIG] | ln[CLS_HUGE]) && any_of(any)) {
             // no shorter hashed runs to tell: a sizeable share of the runs that went through the counting sort must have given up
             // (a few do without a single repeat — necklace clusters)
             Buf<u64> nbail(c->pool, 1);
             CBLX_HIP(hipMemsetAsync(nbail.get(), 0, 8, c->stream));
-            hipLaunchKernelGGL(k_sum_u8, dim3((unsigned)std::min<u64>(1024, ceil_div(roff[5], 256))), dim3(256), 0, c->stream, bail.get(), roff[5], nbail.get());
-            saw_repeats = d2h<u64>(c, nbail.get()) * 8 >= roff[5];
+            hipLaunchKernelGGL(k_sum_u8, dim3((unsigned)std::min<u64>(1024, ceil_div(roff[NM], 256))), dim3(256), 0, c->stream, bail.get(), roff[NM], nbail.get());
+            saw_repeats = d2h<u64>(c, nbail.get()) * 8 >= roff[NM];
         }
         CBLX_HIP(hipStreamSynchronize(c->stream));  // retry buffers die here
     }

@@ -58,6 +58,10 @@ __global__ void k_lists(const u32* run_start, u32 nruns, u64 n, BDesc* lists, u3
     else if (c <= 512 * MED_ITEMS) cls = 4;
     if (cls < 0) return;
     lists[(u64)cls * cap + atomicAdd(&list_n[cls], 1u)] = BDesc{s, c, r};
+#ifdef MSD_BENCH_SPLIT  // half classes: 5 = (32, 64], 6 = (64, 128], 7 = (128, 256], 8 = (256, 512]
+    const int h = c <= 64 ? 5 : c <= 128 ? 6 : c <= 256 ? 7 : c <= 512 ? 8 : -1;
+    if (h >= 0) lists[(u64)h * cap + atomicAdd(&list_n[h], 1u)] = BDesc{s, c, r};
+#endif
 }
 __global__ void k_sum64(const u64* v, u64 n, unsigned long long* out) {
     u64 s = 0;
@@ -130,16 +134,17 @@ int main(int argc, char** argv) {
         CK(hipFree(tmp)); CK(hipFree(rs2));
     }
     CK(hipFree(pfx_s));
-    BDesc* lists = dalloc<BDesc>((size_t)5 * nruns);
-    u32* list_n = dalloc<u32>(8);
-    CK(hipMemset(list_n, 0, 32));
+    constexpr int NL = 9;
+    BDesc* lists = dalloc<BDesc>((size_t)NL * nruns);
+    u32* list_n = dalloc<u32>(16);
+    CK(hipMemset(list_n, 0, 64));
     hipLaunchKernelGGL(k_lists, dim3((nruns + 255) / 256), dim3(256), 0, 0, run_start, nruns, n, lists, list_n, nruns);
-    u32 ln[5];
-    CK(hipMemcpy(ln, list_n, 20, hipMemcpyDeviceToHost));
+    u32 ln[NL];
+    CK(hipMemcpy(ln, list_n, 4 * NL, hipMemcpyDeviceToHost));
     {   // bucket order inside every class list (k_classify appends workgroup by workgroup: nearly ascending)
-        std::vector<BDesc> h((size_t)5 * nruns);
+        std::vector<BDesc> h((size_t)NL * nruns);
         CK(hipMemcpy(h.data(), lists, h.size() * sizeof(BDesc), hipMemcpyDeviceToHost));
-        for (int k = 0; k < 5; ++k) std::sort(h.begin() + (size_t)k * nruns, h.begin() + (size_t)k * nruns + ln[k], [](const BDesc& a, const BDesc& b) { return a.start < b.start; });
+        for (int k = 0; k < NL; ++k) std::sort(h.begin() + (size_t)k * nruns, h.begin() + (size_t)k * nruns + ln[k], [](const BDesc& a, const BDesc& b) { return a.start < b.start; });
         CK(hipMemcpy(lists, h.data(), h.size() * sizeof(BDesc), hipMemcpyHostToDevice));
     }
     u64* arena = dalloc<u64>(n + 8);
@@ -198,6 +203,17 @@ int main(int argc, char** argv) {
     };
     if (SB + PK_BITS <= 64) all(std::true_type()); else all(std::false_type());
     printf("total best %.3f ms\n", total);
+#ifdef MSD_BENCH_SPLIT
+    if (SB + PK_BITS <= 64) {
+        run_class(5, std::integral_constant<int, 64>(), std::integral_constant<int, 64>(), std::true_type());
+        run_class(6, std::integral_constant<int, 64>(), std::integral_constant<int, 128>(), std::true_type());
+        run_class(7, std::integral_constant<int, 64>(), std::integral_constant<int, 256>(), std::true_type());
+        run_class(8, std::integral_constant<int, 64>(), std::integral_constant<int, 512>(), std::true_type());
+        run_class(5, std::integral_constant<int, 64>(), std::integral_constant<int, 128>(), std::true_type());
+        run_class(7, std::integral_constant<int, 64>(), std::integral_constant<int, 512>(), std::true_type());
+        run_class(7, std::integral_constant<int, 128>(), std::integral_constant<int, 256>(), std::true_type());
+    }
+#endif
     // round 6: the sorted classes through k_bucket_sorted (a lane walks the span of its eight slots once)
     auto run_sorted = [&](int k, auto thr, auto cap) {
         constexpr int T = decltype(thr)::value, CAPV = decltype(cap)::value;
