@@ -1712,6 +1712,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(msd_wav
 #ifndef CBLX_SORTED_BALANCE
 #define CBLX_SORTED_BALANCE 0  // the chunks of a workgroup dealt to its lanes in order of their span (measured: see DESIGN_HISTORY.md §3.13)
 #endif
+#ifndef CBLX_SORTED_PERBODY
+#define CBLX_SORTED_PERBODY 0  // every phase instantiated per slots-per-lane, not the walk alone (measured: 3.471 against 3.449 ms, DESIGN_HISTORY.md §3.13)
+#endif
 #ifndef CBLX_SORTED_PROBE
 #define CBLX_SORTED_PROBE 0  // > 0: timing probes that leave phases out (wrong results); never in the product build
 #endif
@@ -1797,9 +1800,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
     for (u32 i = tid; i < NB / 2 + 1; i += THREADS) s_off32[i] = 0;
     if (tid == 0) s_max = 0;
     __syncthreads();
+    // (CBLX_SORTED_PERBODY=1 instantiates everything below per `per` = slots a lane owns, uniform over the workgroup — a run of 1 300 words on 256
+    // threads then issues six slots per lane in every phase, not eight; the masked slots turned out to cost nothing outside the walk)
+    const u32 per = (c + THREADS - 1) / THREADS;  // <= ITEMS
+    auto body = [&](auto per_tag) {
+    constexpr int PI = decltype(per_tag)::value;
     {
-        Sfx<WS> key[ITEMS];
-        u32 sub[ITEMS], arr[ITEMS];
+        Sfx<WS> key[PI];
+        u32 sub[PI], arr[PI];
         // all loads first, unconditionally (slots past the run re-read its first word): eight independent global loads in flight per lane
         if constexpr (MERGE) {
             // element e is word e of `pa` (e < split) or of `pb` (other's pointer moved back by the split: no subtraction per slot)
@@ -1819,7 +1827,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
                 }
             }
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
+            for (int j = 0; j < PI; ++j) {
                 const u32 e = j * THREADS + tid, ee = e < c ? e : 0u;
                 const bool in_a = ee < split;
                 key[j] = load_sfx<WS, u64>(in_a ? pa : pb, in_a ? ha : hb, ee, SB);
@@ -1828,13 +1836,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
             const u64* __restrict__ run_lo = lo + s0;
             const HiT* __restrict__ run_hi = WS ? hi + s0 : nullptr;
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
+            for (int j = 0; j < PI; ++j) {
                 const u32 e = j * THREADS + tid;
                 key[j] = load_sfx<WS, HiT>(run_lo, run_hi, e < c ? e : 0u, SB);
             }
         }
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
+        for (int j = 0; j < PI; ++j) {
             const u32 e = j * THREADS + tid;
             sub[j] = sfx_bits_below<WS>(key[j], SB, skip, nbits);
             arr[j] = 0;
@@ -1842,7 +1850,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
         }
         bool crowded = false;  // an arrival number of `crowd` = a sub-bucket of more than `crowd` entries
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
+        for (int j = 0; j < PI; ++j) {
             arr[j] = (arr[j] >> ((sub[j] & 1u) * 16u)) & 0xFFFFu;
             crowded |= arr[j] >= crowd;
         }
@@ -1854,28 +1862,28 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
         if (s_off32[tid] != 0x12345678u) return;
 #endif
         {   // exclusive scan of the NB counts; each thread owns `per` consecutive entries
-            const u32 per = (NB + THREADS - 1) / THREADS;  // <= ITEMS
-            const u32 b0 = tid * per;
+            const u32 per_nb = (NB + THREADS - 1) / THREADS;  // <= ITEMS
+            const u32 b0 = tid * per_nb;
             u32 sum = 0, cnt[ITEMS];
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) {
-                cnt[k] = ((u32)k < per && b0 + k < NB) ? s_off[b0 + k] : 0u;
+                cnt[k] = ((u32)k < per_nb && b0 + k < NB) ? s_off[b0 + k] : 0u;
                 sum += cnt[k];
             }
             u32 ex = block_exclusive_scan<THREADS, u32>(sum, s_scan, nullptr);
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) {
-                if ((u32)k < per && b0 + k < NB) { s_off[b0 + k] = (u16)ex; ex += cnt[k]; }
+                if ((u32)k < per_nb && b0 + k < NB) { s_off[b0 + k] = (u16)ex; ex += cnt[k]; }
             }
         }
         __syncthreads();
         if (tid == 0) s_off[NB] = (u16)c;
         if (tid < 4) s_k[EL::phys(c + tid)] = EL::ones();  // what a walk may read behind the run compares greater than every element
-        u32 sbase[ITEMS];
+        u32 sbase[PI];
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) sbase[j] = s_off[sub[j]];
+        for (int j = 0; j < PI; ++j) sbase[j] = s_off[sub[j]];
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
+        for (int j = 0; j < PI; ++j) {
             const u32 e = j * THREADS + tid;
             if (e < c) s_k[EL::phys(sbase[j] + arr[j])] = EL::pack(key[j], e);
         }
@@ -1886,7 +1894,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
     if (s_off32[tid] != 0x1234567u) return;
 #endif
     // -- the walk: lane t owns slots [t per, t per + per) of the sub-bucket order
-    const u32 per = (c + THREADS - 1) / THREADS;  // <= ITEMS
     u32 chunk = tid;
 #if CBLX_SORTED_BALANCE
     if constexpr (NW > 1 && THREADS <= 256) {
@@ -1921,10 +1928,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
 #endif
     const u32 p0 = chunk * per;
     const u32 n_own = p0 < c ? (c - p0 < per ? c - p0 : per) : 0u;
-    E me[ITEMS];
-    u32 fin[ITEMS];
+    E me[PI];
+    u32 fin[PI];
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
+    for (int i = 0; i < PI; ++i) {
         const u32 p = p0 + i;
         me[i] = s_k[EL::phys(p < c ? p : c)];  // (slots past the lane's share read the all-ones slot or a neighbour's entry: never written back)
         fin[i] = 0;
@@ -1933,7 +1940,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
     if (n_own) {
         E last = me[0];
 #pragma unroll
-        for (int i = 1; i < ITEMS; ++i) if ((u32)i < n_own) last = me[i];
+        for (int i = 1; i < PI; ++i) if ((u32)i < n_own) last = me[i];
         // (rounded down to an even slot: the entry in front of the sub-bucket is smaller than every entry of mine, it counts like the rest in front)
         A = s_off[EL::sub(me[0], sub_sh, nbits)] & ~1u;
         B = s_off[EL::sub(last, sub_sh, nbits) + 1u];
@@ -1952,8 +1959,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
     // (an entry read behind B belongs to a later sub-bucket, or is all ones: greater than every entry of mine.) The comparisons are
     // what this kernel is made of (two VALU instructions per pair, 28.8 steps of the wave's longest span at cfg 2): the loop is
     // instantiated per `per` — uniform over the workgroup — so that a run of 1300 words (per = 6) does not pay for eight slots
-    auto walk = [&](auto per_tag) {
-        constexpr int PER = decltype(per_tag)::value;
+    auto walk = [&](auto walk_tag) {
+        constexpr int PER = decltype(walk_tag)::value;
         for (u32 q = A; q < B; q += 2) {
             E o0, o1;
             if constexpr (WS) {
@@ -1968,40 +1975,44 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
             for (int i = 0; i < PER; ++i) fin[i] += (EL::less(o0, me[i]) ? 1u : 0u) + (EL::less(o1, me[i]) ? 1u : 0u);
         }
     };
-    if constexpr (ITEMS == 8) {
+#if CBLX_SORTED_PERBODY
+    walk(std::integral_constant<int, PI>());
+#else
+    if constexpr (PI == 8) {
         switch (per) {
             case 8: walk(std::integral_constant<int, 8>()); break;
             case 7: walk(std::integral_constant<int, 7>()); break;
             case 6: walk(std::integral_constant<int, 6>()); break;
             case 5: walk(std::integral_constant<int, 5>()); break;
-            default: walk(std::integral_constant<int, 4>()); break;  // (per <= 4: a short run of a class above its length, e.g. a sub-range of a long run)
+            default: walk(std::integral_constant<int, 4>()); break;
         }
     } else {
-        walk(std::integral_constant<int, ITEMS>());
+        walk(std::integral_constant<int, PI>());
     }
+#endif
 #if CBLX_SORTED_PROBE == 3  // timing probe only: everything up to the walk
     if (tid == 0) { out_count[r] = c; out_kind[r] = KIND_TRIE; }
     { u32 t = 0;
 #pragma unroll
-      for (int i = 0; i < ITEMS; ++i) t += fin[i];
+      for (int i = 0; i < PI; ++i) t += fin[i];
       if (t != 0x12345678u) return; }
 #endif
     __syncthreads();  // every read of the sub-bucket order is done
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i)
+    for (int i = 0; i < PI; ++i)
         if ((u32)i < n_own) s_k[EL::phys(A + fin[i])] = me[i];
     __syncthreads();
     const u32 EPW = 64 * per;  // wave-contiguous slices of the sorted slots: ballots then compact in order
-    Sfx<WS> val[ITEMS];
+    Sfx<WS> val[PI];
     if constexpr (MERGE) if (merging) {
         // three ordered selections of the sorted slots, counted and written together (k_bucket_msd's merge epilogue):
         //   O = other's elements (back to other's arena, sorted)            A = Trie |= x: the heads (sorted union); Vec |= x: self's elements
         //   B = Vec |= x only: other's heads = other \ self, behind self's   (every self element is a head)
         const bool o_vec = mg.okind[r] == KIND_VEC;  // the reference's iter_sorted leaves other's Vec sorted
-        u32 fl[ITEMS];
+        u32 fl[PI];
         u32 nO = 0;
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
+        for (int j = 0; j < PI; ++j) {
             const u32 p = w * EPW + j * 64 + lane;
             const bool live = (u32)j < per && p < c;
             const u32 pc = live ? p : 0u;
@@ -2028,7 +2039,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
         const u64 obase = mg.ostart[r];
         runB += cs_m;  // B follows self's cs elements
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
+        for (int j = 0; j < PI; ++j) {
             const u64 balO = __ballot((fl[j] & 1u) != 0), balA = __ballot((fl[j] & (1u << 10)) != 0), balB = __ballot((fl[j] & (1u << 20)) != 0);
             if (fl[j] & 1u) {
                 const u32 q = runO + mbcnt(balO);
@@ -2051,10 +2062,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
         return;
     }
     // -- heads (the first slot of every suffix value), counted, then compacted slot by slot
-    bool head[ITEMS];
+    bool head[PI];
     u32 wh = 0;
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
+    for (int j = 0; j < PI; ++j) {
         const u32 p = w * EPW + j * 64 + lane;
         const bool live = (u32)j < per && p < c;
         const u32 pc = live ? p : 0u;
@@ -2077,13 +2088,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
     HiT* __restrict__ out_hi = WS ? hi + s0 : nullptr;
     if (d == c) {  // no repeat in the run (the usual case): every slot is a head and keeps its place
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
+        for (int j = 0; j < PI; ++j) {
             const u32 p = w * EPW + j * 64 + lane;
             if ((u32)j < per && p < c) store_sfx<WS, HiT>(out_lo, out_hi, p, val[j]);
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
+        for (int j = 0; j < PI; ++j) {
             const u64 bal = __ballot(head[j]);
             if (head[j]) store_sfx<WS, HiT>(out_lo, out_hi, run + mbcnt(bal), val[j]);
             run += (u32)__builtin_popcountll(bal);
@@ -2093,6 +2104,22 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(sorted_
         out_count[r] = d;
         out_kind[r] = KIND_TRIE;
     }
+    };
+#if CBLX_SORTED_PERBODY
+    if constexpr (ITEMS == 8) {
+        switch (per) {
+            case 8: body(std::integral_constant<int, 8>()); break;
+            case 7: body(std::integral_constant<int, 7>()); break;
+            case 6: body(std::integral_constant<int, 6>()); break;
+            case 5: body(std::integral_constant<int, 5>()); break;
+            default: body(std::integral_constant<int, 4>()); break;  // (per <= 4: a short run of a class above its length, e.g. a sub-range of a long run)
+        }
+    } else {
+        body(std::integral_constant<int, ITEMS>());
+    }
+#else
+    body(std::integral_constant<int, ITEMS>());
+#endif
 }
 
 // ---- KRN-3 for runs full of repeats (one batch at high coverage: every k-mer arrives dozens of times). The counting sort
