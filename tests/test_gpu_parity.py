@@ -1616,6 +1616,25 @@ def test_heavily_duplicated_runs_of_33_to_128_words(preload):
         assert g2.serialize() == o2.serialize() and g2.validate() == 0
 
 
+@pytest.mark.parametrize("k,pb,n,preload", [(11, 8, 45000, 0), (11, 8, 30000, 18000), (7, 8, 45000, 0), (7, 8, 30000, 20000), (13, 10, 170000, 0)])
+def test_runs_of_129_to_256_words_take_the_four_slot_class(k, pb, n, preload):
+    """Round 6: runs of 129..256 words have a class of their own (k_classify CLS_M32: one wave, four slots per lane; their claim-table and
+    counting-sort kernels are instantiations no other length reaches). Random k-mers spread evenly over the 2^pb prefixes put every run
+    of the batch into that class — all distinct (k = 11, 13), full of repeats (k = 7: 512 suffixes per prefix, the claim table), and on top
+    of the Vec buckets of an earlier batch. Per-k-mer return values, count, bytes: the reference's TrieVec::insert
+    (/root/reference/src/trievec/mod.rs:72-99) word by word."""
+    _need_gpu()
+    rng = np.random.default_rng(1000 * k + pb + preload)
+    g, o = cbl_amd.CBL(k, pb), Oracle(k, pb)
+    for m in (preload, n):
+        if not m:
+            continue
+        batch = rng.integers(0, 4 ** k, size=m, dtype=np.uint64).tolist()
+        assert g.insert_kmers(batch).tolist() == [o.insert_kmer(x) for x in batch]
+        assert g.count() == o.count() and g.validate() == 0
+    assert g.serialize() == o.serialize()
+
+
 def test_serializer_patches_huge_buckets_into_the_device_body(monkeypatch):
     """Low-complexity reads put > 8192 distinct words under one prefix (a 12-base poly-A run zeroes the whole 24-bit prefix):
     the entries of such buckets are emitted on the host and patched into the body the kernels emit for everything else."""
