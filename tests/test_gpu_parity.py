@@ -1635,6 +1635,40 @@ def test_runs_of_129_to_256_words_take_the_four_slot_class(k, pb, n, preload):
     assert g.serialize() == o.serialize()
 
 
+@pytest.mark.parametrize("k,pb,n1,n2", [(11, 8, 40000, 30000), (13, 10, 100000, 60000), (11, 8, 12000, 9000)])
+def test_insert_into_short_tries_of_a_loaded_file(k, pb, n1, n2):
+    """A Trie bucket of a few hundred words only comes out of a file (the reference can `remove`; this path cannot): an insert that touches
+    it must leave the ascending list — every length class has its sorted route for `res_trie` runs, the 256-slot class of round 6 included.
+    The short Tries are made here: words inserted in ascending order leave every Vec bucket ascending, the exported buckets are installed
+    elsewhere with kind = Trie, the oracle loads those bytes; then random k-mers go into both (TrieVec::insert on a Trie,
+    /root/reference/src/trievec/mod.rs:100-115)."""
+    _need_gpu()
+    rng = np.random.default_rng(77 * k + pb + n1)
+    g, o = cbl_amd.CBL(k, pb), Oracle(k, pb)
+    words = sorted({o.word_of_kmer(int(x)) for x in rng.integers(0, 4 ** k, size=n1, dtype=np.uint64)})
+    first = [o.kmer_of_word(w) for w in words]
+    assert g.insert_kmers(first).all()
+    nb, nw, B = g.num_buckets(), g.count(), g.consts()["bytes"]
+    prefix = torch.empty(nb, dtype=torch.int32, device="cuda")
+    count = torch.empty(nb, dtype=torch.int32, device="cuda")
+    kind = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    suffix = torch.empty(nw * B, dtype=torch.uint8, device="cuda")
+    g.resident_export(prefix, count, kind, suffix)
+    vec = kind == 0  # (the lowest prefixes hold more than 1024 words — necklace skew — and are Tries already)
+    assert int((vec & (count > 128) & (count <= 256)).sum()) >= 4 and int((vec & (count > 32) & (count <= 128)).sum()) >= 4
+    kind.fill_(1)
+    g2, o2 = cbl_amd.CBL(k, pb), Oracle(k, pb)
+    g2.install_buckets_device([(nb, nw, prefix, count, kind, suffix)])
+    blob = g2.serialize()
+    assert g2.validate(strict=False) == 0 and g2.bucket_table_np()[2].min() == 1
+    o2.load(blob)
+    assert o2.serialize() == blob and o2.count() == nw
+    batch = rng.integers(0, 4 ** k, size=n2, dtype=np.uint64).tolist() + first[:: 7]
+    assert g2.insert_kmers(batch).tolist() == [o2.insert_kmer(x) for x in batch]
+    assert g2.count() == o2.count() and g2.serialize() == o2.serialize() and g2.validate(strict=False) == 0
+    assert int((g2.bucket_table_np()[2] == 1).sum()) >= nb  # a Trie stays a Trie (the batch's new prefixes are Vecs)
+
+
 def test_serializer_patches_huge_buckets_into_the_device_body(monkeypatch):
     """Low-complexity reads put > 8192 distinct words under one prefix (a 12-base poly-A run zeroes the whole 24-bit prefix):
     the entries of such buckets are emitted on the host and patched into the body the kernels emit for everything else."""
