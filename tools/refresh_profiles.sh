@@ -33,7 +33,7 @@ python tools/write_emulated_rank_md.py $R r04
 # round 6: the bucket kernels alone (tools/dev_msd_bench.cpp) and their SQ counters
 if [ -s gpurun_out/$T/msd_bench_cfg2.txt ]; then
   { echo "# ${R} — the bucket kernels alone on the real buckets of a cfg-2 build (tools/dev_msd_bench.cpp: K = 31, PREFIX_BITS = 24, 10 M x 150 bp; best / average of 5 launches over pristine copies of the arena;"
-    echo "\`class\` rows = k_bucket_msd, \`sorted\` rows = k_bucket_sorted on the same class list; \`chk\` = checksum of counts, kinds and words of the class: equal = same result)"; echo; echo '```'; cat gpurun_out/$T/msd_bench_cfg2.txt; echo '```'; } > profiles/${R}_msd_bench.md
+    echo "\`class\` rows = k_bucket_msd, \`sorted\` rows = k_bucket_sorted on the same class list; \`chk\` = checksum of counts, kinds and words of the class: equal = same result)"; echo "(the harness keeps the five classes of rounds 1 - 5; in the library the 129 - 256-word runs of class 1 now take \`<64, 256>\`: profiles/${R}_msd_bench_split.md)"; echo; echo '```'; cat gpurun_out/$T/msd_bench_cfg2.txt; echo '```'; } > profiles/${R}_msd_bench.md
 fi
 if [ -d gpurun_out/${T}_msdsq ]; then
   { echo "# ${R} — SQ counters of the bucket kernels alone (tools/r6_msd_counters.sh: rocprofv3 --kernel-trace --pmc, one pass per counter group, tools/dev_msd_bench.bin directly behind \`--\`; per dispatch, summed over the chip)"; echo
